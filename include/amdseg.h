@@ -1,0 +1,155 @@
+/* libamdseg -- C ABI of the MI355X-native (gfx950) BERT token-classification encoder path.
+ *
+ * Drop-in boundary for the topic-segmentation hot path of alibaba-damo-academy/SpokenNLP.  The reference has no
+ * native layer at all: every entry point below replaces a torch/ATen call made (through HuggingFace
+ * `transformers`) from the reference's wrapper model
+ *     emnlp2023-topic_segmentation/src/models/bert_for_ts.py:55-82   self.bert(...)      -> encoder layers
+ *     emnlp2023-topic_segmentation/src/models/modules/loss_calculator.py:42              -> classifier
+ *     transformers.Trainer (ts_sentence_seq_labeling.py:1077-1094)                       -> clip + AdamW
+ * and is bound from Python with ctypes (spokennlp_amd/lib.py).
+ *
+ * Conventions
+ *  - plain C: raw device pointers, ints, floats; no torch / C++ types cross this boundary;
+ *  - every call takes a stream (hipStream_t passed as void*), is asynchronous, and returns 0 on success,
+ *    AMDSEG_ERR_* (>= 1000) for argument/shape errors, or the hipError_t of a failed launch;
+ *  - the caller owns every buffer (activations, saved-for-backward tensors, workspaces); the library keeps no
+ *    global state;  one process per GPU, calls serialised per stream;
+ *  - activations are row-major [tokens, features]; `dtype` selects bf16 (AMDSEG_BF16, the fast path) or fp32
+ *    (AMDSEG_F32) for the HBM-bound kernels; MFMA GEMMs take bf16 operands and accumulate in fp32;
+ *  - weights follow torch.nn.Linear: W[out, in] row-major.
+ */
+#ifndef AMDSEG_H
+#define AMDSEG_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMDSEG_ABI_VERSION 1
+#define AMDSEG_BF16 0
+#define AMDSEG_F32 1
+#define AMDSEG_OK 0
+#define AMDSEG_ERR_SHAPE 1001
+#define AMDSEG_ERR_ARG 1002
+#define AMDSEG_ERR_LAUNCH 1003
+#define AMDSEG_MAX_GROUP 8
+
+/* epilogues of amdseg_gemm_nt */
+#define AMDSEG_EPI_NONE 0       /* C = A B^T                                                     */
+#define AMDSEG_EPI_BIAS 1       /* C = A B^T + bias[n]                                           */
+#define AMDSEG_EPI_BIAS_GELU 2  /* C2 = A B^T + bias (pre-activation), C = gelu_erf(C2)          */
+#define AMDSEG_EPI_ADD_RES 3    /* C = A B^T + R                                                  */
+#define AMDSEG_EPI_GELU_BWD 4   /* C = (A B^T) * gelu_erf'(R)                                     */
+
+typedef void* amdseg_stream_t;  /* hipStream_t */
+
+int amdseg_abi_version(void);
+const char* amdseg_error_string(int code);
+
+/* ---- MFMA GEMMs (csrc/gemm.hip) -------------------------------------------------------------------------------
+ * gemm_nt: C[M,N] = A[M,K] . B[N,K]^T, bf16 in / fp32 accumulate, M,N multiples of 128, K multiple of 64.
+ *   replaces torch.nn.functional.linear in BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput
+ *   ([hf] models/bert/modeling_bert.py:175-177,282-293,325-351) and, with transposed weight shadows, its dgrad. */
+int amdseg_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
+                   const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32, amdseg_stream_t stream);
+/* gemm_tn_grouped: for each problem i: C_i[N_i,K_i] (+)= sum_m A_i[m,N_i] . B_i[m,K_i]  (fp32 out), shared M.
+ *   the weight gradients dW = dY^T X of one encoder layer in ONE launch (autograd of the Linear layers above). */
+int amdseg_gemm_tn_grouped(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                           float* const* C, const int* ldc, const int* N, const int* K, int M, int accumulate,
+                           amdseg_stream_t stream);
+
+/* ---- fused attention (csrc/attention.hip), head_dim 64, L multiple of 64 -----------------------------------------
+ * qkv [B*L, 3*heads*64] bf16 (q|k|v), mask_bias [B, L] fp32 additive key mask (0 or a large negative),
+ * ctx [B*L, heads*64] bf16, lse [B, heads, L] fp32 (saved for backward; may be NULL for inference).
+ *   replaces eager_attention_forward ([hf] models/bert/modeling_bert.py:111-136) and its backward. */
+int amdseg_attn_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
+                    float dropout_p, uint64_t seed, amdseg_stream_t stream);
+int amdseg_attn_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                    float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, uint64_t seed,
+                    amdseg_stream_t stream);
+
+/* ---- HBM-bound row kernels (csrc/elementwise.hip) ---------------------------------------------------------------
+ * embeddings + LayerNorm + dropout ([hf] models/bert/modeling_bert.py:53-108); tables are the fp32 masters.
+ * pos_ids may be NULL (position = token index % L); z (pre-LN sum), mean, rstd are saved for backward (may be NULL) */
+int amdseg_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
+                        const float* pos, const float* type, const float* gamma, const float* beta, void* z, void* out,
+                        float* mean, float* rstd, int M, int L, int H, int vocab, int type_vocab, int npos, float eps,
+                        float dropout_p, uint64_t seed, int dtype, amdseg_stream_t stream);
+int amdseg_embed_bwd(const void* dz, const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, float* dword,
+                     float* dpos, float* dtype_emb, int M, int L, int H, int vocab, int type_vocab, int npos, int pad_id,
+                     int dtype, amdseg_stream_t stream);
+/* z = resid + dropout(y) (written over y), out = LayerNorm(z)   ([hf] modeling_bert.py:282-293, 340-351) */
+int amdseg_add_ln_fwd(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out, float* mean,
+                      float* rstd, int M, int H, float eps, float dropout_p, uint64_t seed, int dtype,
+                      amdseg_stream_t stream);
+/* LayerNorm backward: dz (residual-stream grad), dbranch = dropout-masked dz (NULL when p == 0), and the column
+ * reductions dgamma, dbeta, dbias (= colsum(dbranch)); partials = workspace of 3*ceil(M/32)*H floats */
+int amdseg_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz,
+                  void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M, int H,
+                  float dropout_p, uint64_t seed, int accumulate, int dtype, amdseg_stream_t stream);
+/* out[N] (+)= column sums of x[M, ld];  partials = workspace of ceil(M/128)*N floats  (bias gradients) */
+int amdseg_colsum(const void* x, int ld, float* partials, float* out, int M, int N, int accumulate, int dtype,
+                  amdseg_stream_t stream);
+int amdseg_dropout(const void* x, void* y, size_t n, float p, uint64_t seed, int dtype_in, int dtype_out,
+                   amdseg_stream_t stream);
+int amdseg_cast(const void* x, void* y, size_t n, int dtype_in, int dtype_out, amdseg_stream_t stream);
+/* fp32 master W[N,K] -> bf16 Wb[N,K] and bf16 transpose Wt[K,N] (either may be NULL); N,K multiples of 64 */
+int amdseg_cast_transpose(const float* W, void* Wb, void* Wt, int N, int K, amdseg_stream_t stream);
+/* small-C linear heads: logits[M,C] = x[M,H] W[C,H]^T + b, C <= 4
+ * (modules/loss_calculator.py:17,42 classifier; modules/tssp.py:14,31) and their backward */
+int amdseg_rowdot_fwd(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
+                      amdseg_stream_t stream);
+int amdseg_rowdot_bwd(const void* x, const float* W, const float* dlogits, void* dx, float* partials, float* dW, float* db,
+                      int M, int H, int C, int accumulate, int dtype, amdseg_stream_t stream);
+
+/* ---- optimiser (csrc/optim.hip): torch.optim.AdamW + clip_grad_norm_ semantics over flat fp32 buffers ---------- */
+int amdseg_adamw(float* p, const float* g, float* m, float* v, void* bf16_shadow, size_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int step, const float* grad_scale, int zero_grad,
+                 amdseg_stream_t stream);
+int amdseg_sumsq(const float* x, size_t n, float* partials, float* out, int accumulate, amdseg_stream_t stream);
+int amdseg_clip_coef(const float* sumsq, float max_norm, float extra_scale, float* coef, float* norm,
+                     amdseg_stream_t stream);
+int amdseg_scale(float* x, size_t n, const float* coef, amdseg_stream_t stream);
+
+/* ---- composite: one BertLayer forward / backward ([hf] models/bert/modeling_bert.py:374-416) -------------------- */
+typedef struct amdseg_bert_cfg {
+    int32_t B, L, H, heads, I;      /* batch, sequence, hidden, heads (H = heads*64), intermediate */
+    float ln_eps, p_hidden, p_attn; /* dropout probabilities (0 in eval) */
+    uint64_t seed;                  /* dropout seed of this step; per-layer/site streams are derived from it */
+    int32_t accumulate_grads;       /* weight grads: 0 overwrite, 1 add into existing */
+    int32_t dtype;                  /* AMDSEG_BF16 */
+} amdseg_bert_cfg;
+
+typedef struct amdseg_bert_layer_params {   /* bf16 compute shadows (+ transposes for dgrad), fp32 vectors */
+    const void *wqkv, *wo, *w1, *w2;        /* [3H,H] [H,H] [I,H] [H,I] */
+    const void *wqkv_t, *wo_t, *w1_t, *w2_t;/* [H,3H] [H,H] [H,I] [I,H] (backward only) */
+    const float *bqkv, *bo, *b1, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+} amdseg_bert_layer_params;
+
+typedef struct amdseg_bert_layer_grads {    /* fp32, views into the flat gradient buffer */
+    float *wqkv, *wo, *w1, *w2, *bqkv, *bo, *b1, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+} amdseg_bert_layer_grads;
+
+typedef struct amdseg_bert_layer_acts {     /* caller-owned activations; all but x_in are written by forward */
+    const void* x_in;                       /* [M,H] layer input */
+    void *qkv, *ctx, *z1, *x1, *u, *h, *z2, *x_out;   /* [M,3H] [M,H] [M,H] [M,H] [M,I] [M,I] [M,H] [M,H] */
+    float *lse, *mean1, *rstd1, *mean2, *rstd2;       /* [B*heads*L] [M] [M] [M] [M] */
+} amdseg_bert_layer_acts;
+
+typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across layers */
+    void *dz2, *dbr2, *du, *dx1, *dz1, *dbr1, *dctx, *dqkv;  /* [M,H] [M,H] [M,I] [M,H] [M,H] [M,H] [M,H] [M,3H] */
+    float *delta, *partials;                /* [B*heads*L], max(3*ceil(M/32)*H, ceil(M/128)*max(I,3H)) floats */
+} amdseg_bert_layer_ws;
+
+int amdseg_bert_layer_fwd(const amdseg_bert_cfg* cfg, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,
+                          const float* mask_bias, int layer_idx, amdseg_stream_t stream);
+/* dy: gradient w.r.t. x_out [M,H]; dx_in: gradient w.r.t. x_in [M,H] (output) */
+int amdseg_bert_layer_bwd(const amdseg_bert_cfg* cfg, const amdseg_bert_layer_params* p, const amdseg_bert_layer_grads* g,
+                          const amdseg_bert_layer_acts* a, const amdseg_bert_layer_ws* ws, const float* mask_bias,
+                          const void* dy, void* dx_in, int layer_idx, amdseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMDSEG_H */

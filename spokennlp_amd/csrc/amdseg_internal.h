@@ -1,0 +1,58 @@
+// Internal (C++-side) launcher prototypes shared by the kernel translation units and api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AMDSEG_MAX_GROUP 8
+
+// dtype codes used across the C-ABI
+#define AMDSEG_BF16 0
+#define AMDSEG_F32 1
+
+int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                        int epi, const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32,
+                        hipStream_t stream);
+int amdseg_gemm_tn_grouped_impl(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                                float* const* C, const int* ldc, const int* N, const int* Kp, int M, int accumulate,
+                                hipStream_t stream);
+int amdseg_gemm_f32_nt_impl(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                            int epi, const float* bias, hipStream_t stream);
+
+int amdseg_embed_ln_fwd_impl(const int64_t* ids, const int64_t* type_ids, const float* word, const float* pos,
+                             const float* type, const float* gamma, const float* beta, void* z, void* out, float* mean,
+                             float* rstd, int M, int L, int H, int vocab, int type_vocab, int npos,
+                             const int64_t* pos_ids, float eps, float p, uint64_t seed, int dtype, hipStream_t s);
+int amdseg_embed_bwd_impl(const void* dz, const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
+                          float* dword, float* dpos, float* dtype_emb, int M, int L, int H, int vocab, int type_vocab,
+                          int npos, int pad_id, int dtype, hipStream_t s);
+int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out,
+                           float* mean, float* rstd, int M, int H, float eps, float p, uint64_t seed, int dtype,
+                           hipStream_t s);
+int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                       void* dz, void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M,
+                       int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s);
+int amdseg_colsum_impl(const void* x, int ld, float* partials, float* out, int M, int N, int accumulate, int dtype,
+                       hipStream_t s);
+int amdseg_dropout_impl(const void* x, void* y, size_t n, float p, uint64_t seed, int dtype_in, int dtype_out,
+                        hipStream_t s);
+int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K, hipStream_t s);
+int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_out, hipStream_t s);
+
+int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,
+                         float scale, float p, uint64_t seed, hipStream_t s);
+int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                         float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
+                         hipStream_t s);
+int amdseg_attn_f32_impl(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, int d,
+                         float scale, hipStream_t s);
+
+int amdseg_rowdot_fwd_impl(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
+                           hipStream_t s);
+int amdseg_rowdot_bwd_impl(const void* x, const float* W, const float* dlogits, void* dx, float* partials, float* dW,
+                           float* db, int M, int H, int C, int accumulate, int dtype, hipStream_t s);
+
+int amdseg_adamw_impl(float* p, const float* g, float* m, float* v, void* shadow, size_t n, float lr, float beta1,
+                      float beta2, float eps, float wd, int step, const float* gscale, int zero_grad, hipStream_t s);
+int amdseg_sumsq_impl(const float* x, size_t n, float* partials, float* out, int accumulate, hipStream_t s);
+int amdseg_clip_coef_impl(const float* sumsq, float max_norm, float extra_scale, float* coef, float* norm, hipStream_t s);
+int amdseg_scale_impl(float* x, size_t n, const float* coef, hipStream_t s);

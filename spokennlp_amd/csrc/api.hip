@@ -1,0 +1,176 @@
+// extern "C" surface of libamdseg (declared in include/amdseg.h) + the composite BertLayer forward/backward drivers.
+#include "../../include/amdseg.h"
+#include "amdseg_internal.h"
+#include "common.h"
+
+#define S(x) ((hipStream_t)(x))
+
+extern "C" {
+
+int amdseg_abi_version(void) { return AMDSEG_ABI_VERSION; }
+
+const char* amdseg_error_string(int code) {
+    switch (code) {
+        case AMDSEG_OK: return "ok";
+        case AMDSEG_ERR_SHAPE: return "amdseg: unsupported or misaligned shape";
+        case AMDSEG_ERR_ARG: return "amdseg: bad argument (null pointer / enum / missing workspace)";
+        case AMDSEG_ERR_LAUNCH: return "amdseg: kernel launch failed";
+        default: return hipGetErrorString((hipError_t)code);
+    }
+}
+
+int amdseg_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
+                   const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32, amdseg_stream_t stream) {
+    return amdseg_gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, R, ldr, C2, ldc2, out_fp32, S(stream));
+}
+int amdseg_gemm_tn_grouped(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                           float* const* C, const int* ldc, const int* N, const int* K, int M, int accumulate,
+                           amdseg_stream_t stream) {
+    return amdseg_gemm_tn_grouped_impl(nprob, A, lda, B, ldb, C, ldc, N, K, M, accumulate, S(stream));
+}
+int amdseg_attn_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
+                    float dropout_p, uint64_t seed, amdseg_stream_t stream) {
+    return amdseg_attn_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, dropout_p, seed, S(stream));
+}
+int amdseg_attn_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                    float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, uint64_t seed,
+                    amdseg_stream_t stream) {
+    return amdseg_attn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, seed, S(stream));
+}
+int amdseg_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
+                        const float* pos, const float* type, const float* gamma, const float* beta, void* z, void* out,
+                        float* mean, float* rstd, int M, int L, int H, int vocab, int type_vocab, int npos, float eps,
+                        float dropout_p, uint64_t seed, int dtype, amdseg_stream_t stream) {
+    return amdseg_embed_ln_fwd_impl(ids, type_ids, word, pos, type, gamma, beta, z, out, mean, rstd, M, L, H, vocab, type_vocab,
+                                    npos, pos_ids, eps, dropout_p, seed, dtype, S(stream));
+}
+int amdseg_embed_bwd(const void* dz, const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, float* dword,
+                     float* dpos, float* dtype_emb, int M, int L, int H, int vocab, int type_vocab, int npos, int pad_id,
+                     int dtype, amdseg_stream_t stream) {
+    return amdseg_embed_bwd_impl(dz, ids, type_ids, pos_ids, dword, dpos, dtype_emb, M, L, H, vocab, type_vocab, npos, pad_id,
+                                 dtype, S(stream));
+}
+int amdseg_add_ln_fwd(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out, float* mean,
+                      float* rstd, int M, int H, float eps, float dropout_p, uint64_t seed, int dtype,
+                      amdseg_stream_t stream) {
+    return amdseg_add_ln_fwd_impl(y_inout_z, resid, gamma, beta, out, mean, rstd, M, H, eps, dropout_p, seed, dtype, S(stream));
+}
+int amdseg_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz,
+                  void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M, int H,
+                  float dropout_p, uint64_t seed, int accumulate, int dtype, amdseg_stream_t stream) {
+    return amdseg_ln_bwd_impl(dy, z, mean, rstd, gamma, dz, dbranch, partials, dgamma, dbeta, dbias, M, H, dropout_p, seed,
+                              accumulate, dtype, S(stream));
+}
+int amdseg_colsum(const void* x, int ld, float* partials, float* out, int M, int N, int accumulate, int dtype,
+                  amdseg_stream_t stream) {
+    return amdseg_colsum_impl(x, ld, partials, out, M, N, accumulate, dtype, S(stream));
+}
+int amdseg_dropout(const void* x, void* y, size_t n, float p, uint64_t seed, int dtype_in, int dtype_out,
+                   amdseg_stream_t stream) {
+    return amdseg_dropout_impl(x, y, n, p, seed, dtype_in, dtype_out, S(stream));
+}
+int amdseg_cast(const void* x, void* y, size_t n, int dtype_in, int dtype_out, amdseg_stream_t stream) {
+    return amdseg_cast_impl(x, y, n, dtype_in, dtype_out, S(stream));
+}
+int amdseg_cast_transpose(const float* W, void* Wb, void* Wt, int N, int K, amdseg_stream_t stream) {
+    return amdseg_cast_transpose_impl(W, Wb, Wt, N, K, S(stream));
+}
+int amdseg_rowdot_fwd(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
+                      amdseg_stream_t stream) {
+    return amdseg_rowdot_fwd_impl(x, W, b, out, M, H, C, dtype, S(stream));
+}
+int amdseg_rowdot_bwd(const void* x, const float* W, const float* dlogits, void* dx, float* partials, float* dW, float* db,
+                      int M, int H, int C, int accumulate, int dtype, amdseg_stream_t stream) {
+    return amdseg_rowdot_bwd_impl(x, W, dlogits, dx, partials, dW, db, M, H, C, accumulate, dtype, S(stream));
+}
+int amdseg_adamw(float* p, const float* g, float* m, float* v, void* bf16_shadow, size_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int step, const float* grad_scale, int zero_grad,
+                 amdseg_stream_t stream) {
+    return amdseg_adamw_impl(p, g, m, v, bf16_shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, S(stream));
+}
+int amdseg_sumsq(const float* x, size_t n, float* partials, float* out, int accumulate, amdseg_stream_t stream) {
+    return amdseg_sumsq_impl(x, n, partials, out, accumulate, S(stream));
+}
+int amdseg_clip_coef(const float* sumsq, float max_norm, float extra_scale, float* coef, float* norm,
+                     amdseg_stream_t stream) {
+    return amdseg_clip_coef_impl(sumsq, max_norm, extra_scale, coef, norm, S(stream));
+}
+int amdseg_scale(float* x, size_t n, const float* coef, amdseg_stream_t stream) {
+    return amdseg_scale_impl(x, n, coef, S(stream));
+}
+
+// ---------------------------------------------------------------------------------------------------- composite layer
+static inline uint64_t site_seed(uint64_t seed, int layer, int site) {
+    return seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer * 8 + site + 1) * 0xD1B54A32D192ED03ull;
+}
+#define RET_IF(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+static int check_cfg(const amdseg_bert_cfg* c) {
+    if (!c) return AMDSEG_ERR_ARG;
+    if (c->dtype != AMDSEG_BF16) return AMDSEG_ERR_ARG;
+    if (c->H != c->heads * 64 || c->B <= 0 || c->L <= 0 || c->I <= 0) return AMDSEG_ERR_SHAPE;
+    const long M = (long)c->B * c->L;
+    if ((M % 128) || (c->H % 128) || (c->I % 128) || (c->L % 64)) return AMDSEG_ERR_SHAPE;
+    return AMDSEG_OK;
+}
+
+int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,
+                          const float* mask_bias, int li, amdseg_stream_t stream) {
+    RET_IF(check_cfg(c));
+    if (!p || !a || !mask_bias) return AMDSEG_ERR_ARG;
+    hipStream_t s = S(stream);
+    const int M = c->B * c->L, H = c->H, I = c->I;
+    // q|k|v projection with bias
+    RET_IF(amdseg_gemm_nt_impl(a->x_in, H, p->wqkv, H, a->qkv, 3 * H, M, 3 * H, H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 0, s));
+    RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0), s));
+    // attention output dense -> dropout -> +residual -> LN
+    RET_IF(amdseg_gemm_nt_impl(a->ctx, H, p->wo, H, a->z1, H, M, H, H, AMDSEG_EPI_BIAS, p->bo, nullptr, 0, nullptr, 0, 0, s));
+    RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
+                                  site_seed(c->seed, li, 1), c->dtype, s));
+    // FFN
+    RET_IF(amdseg_gemm_nt_impl(a->x1, H, p->w1, H, a->h, I, M, I, H, AMDSEG_EPI_BIAS_GELU, p->b1, nullptr, 0, a->u, I, 0, s));
+    RET_IF(amdseg_gemm_nt_impl(a->h, I, p->w2, I, a->z2, H, M, H, I, AMDSEG_EPI_BIAS, p->b2, nullptr, 0, nullptr, 0, 0, s));
+    RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, c->p_hidden,
+                                  site_seed(c->seed, li, 2), c->dtype, s));
+    return AMDSEG_OK;
+}
+
+int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_params* p, const amdseg_bert_layer_grads* g,
+                          const amdseg_bert_layer_acts* a, const amdseg_bert_layer_ws* w, const float* mask_bias,
+                          const void* dy, void* dx_in, int li, amdseg_stream_t stream) {
+    RET_IF(check_cfg(c));
+    if (!p || !g || !a || !w || !mask_bias || !dy || !dx_in) return AMDSEG_ERR_ARG;
+    hipStream_t s = S(stream);
+    const int M = c->B * c->L, H = c->H, I = c->I, acc = c->accumulate_grads;
+    const bool drop = c->p_hidden > 0.f;
+    // LN2 backward: dz2 (residual grad), d_out = masked dz2 (grad of the FFN output dense), dln2, db2
+    RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, w->partials, g->ln2_g, g->ln2_b,
+                              g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, c->dtype, s));
+    const void* d_out = drop ? w->dbr2 : w->dz2;
+    // du = (d_out . W2) * gelu'(u)
+    RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD, nullptr, a->u, I, nullptr, 0, 0, s));
+    // dx1 = du . W1 + dz2
+    RET_IF(amdseg_gemm_nt_impl(w->du, I, p->w1_t, I, w->dx1, H, M, H, I, AMDSEG_EPI_ADD_RES, nullptr, w->dz2, H, nullptr, 0, 0, s));
+    RET_IF(amdseg_colsum_impl(w->du, I, w->partials, g->b1, M, I, acc, c->dtype, s));
+    // LN1 backward
+    RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, w->partials, g->ln1_g,
+                              g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, c->dtype, s));
+    const void* d_ao = drop ? w->dbr1 : w->dz1;
+    // dctx = d_ao . Wo
+    RET_IF(amdseg_gemm_nt_impl(d_ao, H, p->wo_t, H, w->dctx, H, M, H, H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, s));
+    RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
+                                site_seed(c->seed, li, 0), s));
+    // dx_in = dqkv . Wqkv + dz1
+    RET_IF(amdseg_gemm_nt_impl(w->dqkv, 3 * H, p->wqkv_t, 3 * H, dx_in, H, M, H, 3 * H, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s));
+    RET_IF(amdseg_colsum_impl(w->dqkv, 3 * H, w->partials, g->bqkv, M, 3 * H, acc, c->dtype, s));
+    // all four weight gradients of the layer in one grouped launch: dW = dY^T X
+    const void* A[4] = {d_out, w->du, d_ao, w->dqkv};
+    const void* Bm[4] = {a->h, a->x1, a->ctx, a->x_in};
+    float* C[4] = {g->w2, g->w1, g->wo, g->wqkv};
+    const int lda[4] = {H, I, H, 3 * H}, ldb[4] = {I, H, H, H}, ldc[4] = {I, H, H, H};
+    const int N[4] = {H, I, H, 3 * H}, K[4] = {I, H, H, H};
+    RET_IF(amdseg_gemm_tn_grouped_impl(4, A, lda, Bm, ldb, C, ldc, N, K, M, acc, s));
+    return AMDSEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,447 @@
+// Fused multi-head self-attention (head_dim 64) forward + backward for gfx950, bf16 MFMA / fp32 softmax.
+//
+// Replaces eager_attention_forward of [hf] models/bert/modeling_bert.py:111-136 (scores = QK^T*d^-1/2 + additive
+// key mask -> softmax -> dropout -> .V) and its autograd backward; in-tree 4.x copy of the same arithmetic:
+// mmvts/src/models/cross_encoder/bert_model.py:308-352.
+//
+// Layout: qkv is the fused projection output [B*L, 3H] bf16 (q | k | v, head h at columns h*64); ctx is [B*L, H].
+// One 256-thread workgroup = 4 waves x 16 rows (64 query rows, or 64 key rows in the dK/dV kernel) of one (b, h);
+// the other operand streams through LDS in 64-row chunks by global_load_lds DMA, double buffered.
+// All matmuls are v_mfma_f32_16x16x32_bf16 computed in the *transposed* orientation that keeps the softmax row
+// index in the lane id (S^T = K Q^T, O^T = V^T P^T ...), so row max / sum / LSE / delta are lane-local scalars and
+// P never leaves registers; k-strided operands are gathered with ds_read_b64_tr_b16, so no transposed copy of
+// K, V, Q or dO is ever written to HBM.  The score matrix is never materialised; backward recomputes it from the
+// saved log-sum-exp.  Dropout uses the stateless (seed, element) hash of common.h, re-evaluated in backward.
+#include "common.h"
+#include "amdseg_internal.h"
+
+#define HD 64          // head dim
+#define CH 64          // rows per streamed chunk
+
+// universal XOR swizzle for [rows][64] bf16 tiles (128 B rows, 8 chunks of 16 B): conflict-free for both the
+// ds_read_b128 fragment reads (16 rows, one chunk) and the tr_b16 gathers (8 rows x 32 B per half-wave)
+__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
+
+__device__ __forceinline__ void at_glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(void, lds_wave_base), 16, 0, 0);
+}
+// stage a [64][64] bf16 tile; `base` points at element (row 0, col 0), rows are row_stride elements apart
+__device__ __forceinline__ void at_stage(const bf16_t* base, int row_stride, char* tile, int w, int l) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int R0 = (w * 2 + q) * 8;
+        const int r = R0 + (l >> 3), s = l & 7;
+        const int c = s ^ swz(r);
+        at_glds16(base + (size_t)r * row_stride + c * 8, tile + R0 * 128);
+    }
+}
+// 8 consecutive k-elements (chunk c) of row r
+__device__ __forceinline__ bf16x8 at_frag(const char* tile, int r, int c) {
+    return *reinterpret_cast<const bf16x8*>(tile + r * 128 + ((c ^ swz(r)) << 4));
+}
+// transposed gather: lane (i16 = l&15, g = l>>4) receives tile[r0a + j][col0 + i16] (j<4) and tile[r0b + j-4][..] (j>=4)
+__device__ __forceinline__ bf16x8 at_frag_tr(const char* tile, int r0a, int r0b, int col0, int l) {
+    const int i16 = l & 15;
+    const int c = (col0 >> 3) + ((i16 & 3) >> 1);
+    bf16x8 f;
+    {
+        const int row = r0a + (i16 >> 2);
+        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4, tile + row * 128 + ((c ^ swz(row)) << 4) + (i16 & 1) * 8));
+        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+    }
+    {
+        const int row = r0b + (i16 >> 2);
+        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4, tile + row * 128 + ((c ^ swz(row)) << 4) + (i16 & 1) * 8));
+        f[4] = v[0]; f[5] = v[1]; f[6] = v[2]; f[7] = v[3];
+    }
+    return f;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+    bf16x8 f;
+    f[0] = (short)f2bf(a[0]); f[1] = (short)f2bf(a[1]); f[2] = (short)f2bf(a[2]); f[3] = (short)f2bf(a[3]);
+    f[4] = (short)f2bf(b[0]); f[5] = (short)f2bf(b[1]); f[6] = (short)f2bf(b[2]); f[7] = (short)f2bf(b[3]);
+    return f;
+}
+// dropout on attention probabilities: one 32-bit hash per aligned key pair, 16 bits per element.
+// element (row = bh*L + q, key); keep iff 16-bit field >= thresh16
+__device__ __forceinline__ uint32_t pdrop_bits(uint64_t seed, uint64_t row, int L, int key_even) {
+    return rng_u32(seed, (row * (uint64_t)L + (uint64_t)key_even) >> 1);
+}
+__device__ __forceinline__ float xor_reduce_max_g(float v) {   // across the 4 lane groups sharing l&15
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ float xor_reduce_sum_g(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+struct AttnArgs {
+    const bf16_t* qkv; const float* mask_bias; bf16_t* ctx; float* lse;
+    const bf16_t* dctx; const float* delta; bf16_t* dqkv;
+    int B, L, heads, H3;    // H3 = 3*H row stride of qkv
+    float scale, inv_keep; uint32_t thresh16; uint64_t seed;
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[32768];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int H = a.heads * HD;
+    const size_t tok0 = (size_t)b * a.L;
+    const int q = qb * 64 + w * 16 + i16;                       // this lane's query row (shared by the 4 g-groups)
+    const uint64_t prow = ((uint64_t)(b * a.heads + h)) * a.L + q;
+#define bufK(i) (smem + (i) * 16384)
+#define bufV(i) (smem + 8192 + (i) * 16384)
+
+    // Q as the B operand of S^T = K Q^T : lane holds Q[q][kk*32 + g*8 .. +8]
+    bf16x8 fq[2];
+    {
+        const bf16_t* qp = a.qkv + (tok0 + q) * a.H3 + h * HD;
+        fq[0] = *reinterpret_cast<const bf16x8*>(qp + g * 8);
+        fq[1] = *reinterpret_cast<const bf16x8*>(qp + 32 + g * 8);
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_part = 0.f;
+
+    const bf16_t* kbase = a.qkv + tok0 * a.H3 + H + h * HD;
+    const bf16_t* vbase = a.qkv + tok0 * a.H3 + 2 * H + h * HD;
+    const int nch = a.L / CH;
+    at_stage(kbase, a.H3, bufK(0), w, l);
+    at_stage(vbase, a.H3, bufV(0), w, l);
+    for (int ch = 0; ch < nch; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = ch & 1;
+        if (ch + 1 < nch) {
+            at_stage(kbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
+            at_stage(vbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
+        }
+        const char* tK = bufK(cur);
+        const char* tV = bufV(cur);
+        const int key0 = ch * CH;
+        // S^T[key][q]: 4 key frags of 16
+        f32x4 s[4];
+#pragma unroll
+        for (int fc = 0; fc < 4; ++fc) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fk = at_frag(tK, fc * 16 + i16, kk * 4 + g);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[kk], acc, 0, 0, 0);
+            }
+            const float4 mb = *reinterpret_cast<const float4*>(a.mask_bias + tok0 + key0 + fc * 16 + g * 4);
+            s[fc][0] = acc[0] * a.scale + mb.x; s[fc][1] = acc[1] * a.scale + mb.y;
+            s[fc][2] = acc[2] * a.scale + mb.z; s[fc][3] = acc[3] * a.scale + mb.w;
+        }
+        float cmax = s[0][0];
+#pragma unroll
+        for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[fc][r]);
+        cmax = xor_reduce_max_g(cmax);
+        const float m_new = fmaxf(m_run, cmax);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[fc][r] = __expf(s[fc][r] - m_new); psum += s[fc][r]; }
+        l_part = l_part * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+        if (a.thresh16) {
+#pragma unroll
+            for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp) {
+                    const uint32_t u = pdrop_bits(a.seed, prow, a.L, key0 + fc * 16 + g * 4 + rp * 2);
+                    s[fc][rp * 2] = (u & 0xffffu) >= a.thresh16 ? s[fc][rp * 2] * a.inv_keep : 0.f;
+                    s[fc][rp * 2 + 1] = (u >> 16) >= a.thresh16 ? s[fc][rp * 2 + 1] * a.inv_keep : 0.f;
+                }
+        }
+        // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            const bf16x8 fp = pack8(s[2 * kp], s[2 * kp + 1]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x8 fv = at_frag_tr(tV, (2 * kp) * 16 + g * 4, (2 * kp + 1) * 16 + g * 4, d * 16, l);
+                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fp, o[d], 0, 0, 0);
+            }
+        }
+    }
+    const float lsum = xor_reduce_sum_g(l_part);
+    const float inv = 1.0f / lsum;
+    bf16_t* op = a.ctx + (tok0 + q) * H + h * HD;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint2 pk;
+        pk.x = pack2bf(o[d][0] * inv, o[d][1] * inv);
+        pk.y = pack2bf(o[d][2] * inv, o[d][3] * inv);
+        *reinterpret_cast<uint2*>(op + d * 16 + g * 4) = pk;
+    }
+    if (a.lse && g == 0) a.lse[prow] = m_run + __logf(lsum);
+}
+
+// ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
+__global__ void attn_delta_kernel(const bf16_t* ctx, const bf16_t* dctx, float* delta, int B, int L, int heads) {
+    // one thread per (token, head, 8-col chunk) -> 8 lanes per (token, head)
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * L * heads * 8;
+    if (gid >= total) return;
+    const int c = gid & 7;
+    const size_t th = gid >> 3;
+    const int h = th % heads;
+    const size_t tok = th / heads;
+    const int H = heads * HD;
+    float x[8], y[8];
+    ld8<bf16_t>(ctx + tok * H + h * HD + c * 8, x);
+    ld8<bf16_t>(dctx + tok * H + h * HD + c * 8, y);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += x[e] * y[e];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (c == 0) {
+        const int b = tok / L, qq = tok % L;
+        delta[((size_t)(b * heads + h)) * L + qq] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[32768];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int H = a.heads * HD;
+    const size_t tok0 = (size_t)b * a.L;
+    const int q = qb * 64 + w * 16 + i16;
+    const uint64_t prow = ((uint64_t)(b * a.heads + h)) * a.L + q;
+#define bufK(i) (smem + (i) * 16384)
+#define bufV(i) (smem + 8192 + (i) * 16384)
+
+    bf16x8 fq[2], fdo[2];
+    {
+        const bf16_t* qp = a.qkv + (tok0 + q) * a.H3 + h * HD;
+        fq[0] = *reinterpret_cast<const bf16x8*>(qp + g * 8);
+        fq[1] = *reinterpret_cast<const bf16x8*>(qp + 32 + g * 8);
+        const bf16_t* dp = a.dctx + (tok0 + q) * H + h * HD;
+        fdo[0] = *reinterpret_cast<const bf16x8*>(dp + g * 8);
+        fdo[1] = *reinterpret_cast<const bf16x8*>(dp + 32 + g * 8);
+    }
+    const float lse_q = a.lse[prow], delta_q = a.delta[prow];
+    f32x4 dq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bf16_t* kbase = a.qkv + tok0 * a.H3 + H + h * HD;
+    const bf16_t* vbase = a.qkv + tok0 * a.H3 + 2 * H + h * HD;
+    const int nch = a.L / CH;
+    at_stage(kbase, a.H3, bufK(0), w, l);
+    at_stage(vbase, a.H3, bufV(0), w, l);
+    for (int ch = 0; ch < nch; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = ch & 1;
+        if (ch + 1 < nch) {
+            at_stage(kbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
+            at_stage(vbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
+        }
+        const char* tK = bufK(cur);
+        const char* tV = bufV(cur);
+        const int key0 = ch * CH;
+        f32x4 ds[4];
+#pragma unroll
+        for (int fc = 0; fc < 4; ++fc) {
+            f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fk = at_frag(tK, fc * 16 + i16, kk * 4 + g);
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[kk], sacc, 0, 0, 0);
+                bf16x8 fv = at_frag(tV, fc * 16 + i16, kk * 4 + g);
+                pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fdo[kk], pacc, 0, 0, 0);
+            }
+            const float4 mb4 = *reinterpret_cast<const float4*>(a.mask_bias + tok0 + key0 + fc * 16 + g * 4);
+            const float mb[4] = {mb4.x, mb4.y, mb4.z, mb4.w};
+            float keepf[4] = {1.f, 1.f, 1.f, 1.f};
+            if (a.thresh16) {
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp) {
+                    const uint32_t u = pdrop_bits(a.seed, prow, a.L, key0 + fc * 16 + g * 4 + rp * 2);
+                    keepf[rp * 2] = (u & 0xffffu) >= a.thresh16 ? a.inv_keep : 0.f;
+                    keepf[rp * 2 + 1] = (u >> 16) >= a.thresh16 ? a.inv_keep : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sacc[r] * a.scale + mb[r] - lse_q);
+                ds[fc][r] = p * (pacc[r] * keepf[r] - delta_q);
+            }
+        }
+        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            const bf16x8 fds = pack8(ds[2 * kp], ds[2 * kp + 1]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x8 fk = at_frag_tr(tK, (2 * kp) * 16 + g * 4, (2 * kp + 1) * 16 + g * 4, d * 16, l);
+                dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fds, dq[d], 0, 0, 0);
+            }
+        }
+    }
+    bf16_t* op = a.dqkv + (tok0 + q) * a.H3 + h * HD;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint2 pk;
+        pk.x = pack2bf(dq[d][0] * a.scale, dq[d][1] * a.scale);
+        pk.y = pack2bf(dq[d][2] * a.scale, dq[d][3] * a.scale);
+        *reinterpret_cast<uint2*>(op + d * 16 + g * 4) = pk;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[32768];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
+    const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int H = a.heads * HD;
+    const size_t tok0 = (size_t)b * a.L;
+    const int key = kb * 64 + w * 16 + i16;                    // this lane's key row
+    const uint64_t bh = (uint64_t)(b * a.heads + h);
+#define bufQ(i) (smem + (i) * 16384)
+#define bufO(i) (smem + 8192 + (i) * 16384)
+
+    // K, V rows of this lane's key as B operands (B[k=d][j=key])
+    bf16x8 fk[2], fv[2];
+    {
+        const bf16_t* kp = a.qkv + (tok0 + key) * a.H3 + H + h * HD;
+        fk[0] = *reinterpret_cast<const bf16x8*>(kp + g * 8);
+        fk[1] = *reinterpret_cast<const bf16x8*>(kp + 32 + g * 8);
+        const bf16_t* vp = a.qkv + (tok0 + key) * a.H3 + 2 * H + h * HD;
+        fv[0] = *reinterpret_cast<const bf16x8*>(vp + g * 8);
+        fv[1] = *reinterpret_cast<const bf16x8*>(vp + 32 + g * 8);
+    }
+    const float mb = a.mask_bias[tok0 + key];
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const bf16_t* qbase = a.qkv + tok0 * a.H3 + h * HD;
+    const bf16_t* obase = a.dctx + tok0 * H + h * HD;
+    const int nch = a.L / CH;
+    at_stage(qbase, a.H3, bufQ(0), w, l);
+    at_stage(obase, H, bufO(0), w, l);
+    for (int ch = 0; ch < nch; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = ch & 1;
+        if (ch + 1 < nch) {
+            at_stage(qbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufQ(cur ^ 1), w, l);
+            at_stage(obase + (size_t)(ch + 1) * CH * H, H, bufO(cur ^ 1), w, l);
+        }
+        const char* tQ = bufQ(cur);
+        const char* tO = bufO(cur);
+        const int q0 = ch * CH;
+        f32x4 pd[4], ds[4];     // P_drop[q][key], dS[q][key] : lane key = i16, q = qf*16 + g*4 + r
+#pragma unroll
+        for (int qf = 0; qf < 4; ++qf) {
+            f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fqa = at_frag(tQ, qf * 16 + i16, kk * 4 + g);
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqa, fk[kk], sacc, 0, 0, 0);
+                bf16x8 foa = at_frag(tO, qf * 16 + i16, kk * 4 + g);
+                pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(foa, fv[kk], pacc, 0, 0, 0);
+            }
+            const size_t rbase = bh * a.L + q0 + qf * 16 + g * 4;
+            const float4 ls4 = *reinterpret_cast<const float4*>(a.lse + rbase);
+            const float4 dl4 = *reinterpret_cast<const float4*>(a.delta + rbase);
+            const float ls[4] = {ls4.x, ls4.y, ls4.z, ls4.w}, dl[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sacc[r] * a.scale + mb - ls[r]);
+                float keepf = 1.f;
+                if (a.thresh16) {
+                    const uint32_t u = pdrop_bits(a.seed, rbase + r, a.L, key & ~1);
+                    const uint32_t f = (key & 1) ? (u >> 16) : (u & 0xffffu);
+                    keepf = f >= a.thresh16 ? a.inv_keep : 0.f;
+                }
+                pd[qf][r] = p * keepf;
+                ds[qf][r] = p * (pacc[r] * keepf - dl[r]);
+            }
+        }
+        // dV^T[d][key] += dO^T[d][q] P_drop[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            const bf16x8 fp = pack8(pd[2 * qp], pd[2 * qp + 1]);
+            const bf16x8 fds = pack8(ds[2 * qp], ds[2 * qp + 1]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x8 fo = at_frag_tr(tO, (2 * qp) * 16 + g * 4, (2 * qp + 1) * 16 + g * 4, d * 16, l);
+                dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo, fp, dv[d], 0, 0, 0);
+                bf16x8 fqt = at_frag_tr(tQ, (2 * qp) * 16 + g * 4, (2 * qp + 1) * 16 + g * 4, d * 16, l);
+                dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, fds, dk[d], 0, 0, 0);
+            }
+        }
+    }
+    bf16_t* okp = a.dqkv + (tok0 + key) * a.H3 + H + h * HD;
+    bf16_t* ovp = a.dqkv + (tok0 + key) * a.H3 + 2 * H + h * HD;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint2 pk;
+        pk.x = pack2bf(dk[d][0] * a.scale, dk[d][1] * a.scale);
+        pk.y = pack2bf(dk[d][2] * a.scale, dk[d][3] * a.scale);
+        *reinterpret_cast<uint2*>(okp + d * 16 + g * 4) = pk;
+        uint2 pv;
+        pv.x = pack2bf(dv[d][0], dv[d][1]);
+        pv.y = pack2bf(dv[d][2], dv[d][3]);
+        *reinterpret_cast<uint2*>(ovp + d * 16 + g * 4) = pv;
+    }
+}
+
+static int attn_fill(AttnArgs& a, int B, int L, int heads, float scale, float p, uint64_t seed) {
+    if (B <= 0 || L <= 0 || heads <= 0 || (L % CH)) return AMDSEG_ERR_SHAPE;
+    if (p < 0.f || p >= 1.f) return AMDSEG_ERR_ARG;
+    a.B = B; a.L = L; a.heads = heads; a.H3 = 3 * heads * HD; a.scale = scale; a.seed = seed;
+    uint32_t th = (uint32_t)(p * 65536.0f + 0.5f);
+    if (p > 0.f && th == 0) th = 1;
+    a.thresh16 = th;
+    a.inv_keep = th ? 65536.0f / (float)(65536u - th) : 1.0f;    // unbiased for the realised drop rate th/65536
+    return AMDSEG_OK;
+}
+
+int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,
+                         float scale, float p, uint64_t seed, hipStream_t s) {
+    if (!qkv || !mask_bias || !ctx) return AMDSEG_ERR_ARG;
+    AttnArgs a = {};
+    int rc = attn_fill(a, B, L, heads, scale, p, seed);
+    if (rc) return rc;
+    a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    return amdseg_launch_status();
+}
+
+int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                         float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
+                         hipStream_t s) {
+    if (!qkv || !mask_bias || !ctx || !dctx || !lse || !delta || !dqkv) return AMDSEG_ERR_ARG;
+    AttnArgs a = {};
+    int rc = attn_fill(a, B, L, heads, scale, p, seed);
+    if (rc) return rc;
+    a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = (float*)lse;
+    a.dctx = (const bf16_t*)dctx; a.delta = delta; a.dqkv = (bf16_t*)dqkv;
+    const size_t total = (size_t)B * L * heads * 8;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)ctx,
+                       (const bf16_t*)dctx, delta, B, L, heads);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    return amdseg_launch_status();
+}

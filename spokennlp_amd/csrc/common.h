@@ -1,0 +1,98 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libamdseg.
+// wave = 64 lanes; MFMA operand/accumulator layouts verified by tools/probe_gfx950.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define AMDSEG_OK 0
+#define AMDSEG_ERR_SHAPE 1001      // unsupported / misaligned shape
+#define AMDSEG_ERR_ARG 1002        // null pointer / bad enum
+#define AMDSEG_ERR_LAUNCH 1003     // hip launch error (hipGetLastError non-zero)
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// generic load/store of an activation element type T in {float, bf16_t}
+template <typename T> struct Act;
+template <> struct Act<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Act<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+// 8 consecutive elements <-> 8 floats
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    uint4 q = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    uint4 q;
+    q.x = pack2bf(v[0], v[1]); q.y = pack2bf(v[2], v[3]); q.z = pack2bf(v[4], v[5]); q.w = pack2bf(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = q;
+}
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// exact-erf GELU ([hf] activations "gelu"; reference mmvts/src/models/cross_encoder/bert_model.py:427-439)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+// Stateless counter-based dropout RNG: keep(element idx) iff hash(seed, idx) >= threshold.
+// The same (seed, idx) is re-evaluated in backward, so no mask is stored.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+    return mix32(mix32(lo ^ s0) + hi * 0x9e3779b9u + s1);
+}
+// thresh = floor(p * 2^32); keep when rng >= thresh
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) { return rng_u32(seed, idx) >= thresh; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int amdseg_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? AMDSEG_OK : (int)e;
+}

@@ -1,0 +1,607 @@
+// HBM-bound row kernels of the BERT encoder for gfx950: embedding+LayerNorm, bias/dropout/residual+LayerNorm,
+// their backward passes, column sums (bias gradients), dropout, casts and the weight cast+transpose.
+//
+// Reference arithmetic: [hf] models/bert/modeling_bert.py:53-108 (BertEmbeddings), :282-293 (BertSelfOutput),
+// :340-351 (BertOutput) -- LayerNorm eps 1e-12, dropout after the dense, residual add before the norm; in-tree copy
+// mmvts/src/models/cross_encoder/bert_model.py:166-211,364-375,442-453.
+//
+// One wave (64 lanes) owns one token row; every global access is a 16 B/lane vector (8 bf16 or 2x float4), the row
+// lives in registers between the statistics passes (two-pass mean / variance like torch.nn.LayerNorm), row
+// reductions are wave shuffles, column reductions go register -> LDS -> per-block partials -> a deterministic
+// second-stage reduce (no atomics on the hot path).
+#include "common.h"
+#include "amdseg_internal.h"
+
+#define MAXCH 4                 // up to 4 chunks of 8 elements per lane -> H <= 2048
+#define ROWS_PER_BLOCK 4        // one wave per row, 4 waves per block
+
+template <typename T>
+__device__ __forceinline__ void row_load(const T* row, int nch, int l, float (&v)[MAXCH][8]) {
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = l + c * 64;
+        if (ch < nch) ld8<T>(row + ch * 8, v[c]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void row_store(T* row, int nch, int l, const float (&v)[MAXCH][8]) {
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = l + c * 64;
+        if (ch < nch) st8<T>(row + ch * 8, v[c]);
+    }
+}
+__device__ __forceinline__ void row_stats(const float (&v)[MAXCH][8], int nch, int l, int H, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c)
+        if (l + c * 64 < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[c][e];
+        }
+    mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c)
+        if (l + c * 64 < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
+        }
+    rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+}
+
+// ------------------------------------------------------------------------------------------------ embeddings + LN
+template <typename T>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
+                                                           const float* word, const float* pos, const float* type,
+                                                           const float* gamma, const float* beta, T* z, T* out, float* mean,
+                                                           float* rstd, int M, int L, int H, int vocab, int type_vocab,
+                                                           int npos, float eps, uint32_t thresh, float inv_keep, uint64_t seed) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int m = blockIdx.x * ROWS_PER_BLOCK + w;
+    if (m >= M) return;
+    const int nch = H >> 3;
+    int64_t id = ids[m]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int64_t tt = type_ids ? type_ids[m] : 0; tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
+    int64_t pp = pos_ids ? pos_ids[m] : (int64_t)(m % L); pp = pp < 0 ? 0 : (pp >= npos ? npos - 1 : pp);
+    float v[MAXCH][8];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = l + c * 64;
+        if (ch < nch) {
+            float a[8], b[8], d[8];
+            ld8<float>(word + (size_t)id * H + ch * 8, a);
+            ld8<float>(pos + (size_t)pp * H + ch * 8, b);
+            ld8<float>(type + (size_t)tt * H + ch * 8, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] = (a[e] + d[e]) + b[e];     // (word + type) + position, as the reference
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+        }
+    }
+    if (z) row_store<T>(z + (size_t)m * H, nch, l, v);
+    float mu, rs;
+    row_stats(v, nch, l, H, eps, mu, rs);
+    if (l == 0) { if (mean) mean[m] = mu; if (rstd) rstd[m] = rs; }
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = l + c * 64;
+        if (ch < nch) {
+            float gg[8], bb[8];
+            ld8<float>(gamma + ch * 8, gg); ld8<float>(beta + ch * 8, bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y = (v[c][e] - mu) * rs * gg[e] + bb[e];
+                if (thresh) y = drop_keep(seed, (uint64_t)m * H + ch * 8 + e, thresh) ? y * inv_keep : 0.f;
+                v[c][e] = y;
+            }
+        }
+    }
+    row_store<T>(out + (size_t)m * H, nch, l, v);
+}
+
+// scatter the embedding-sum gradient dz[M,H] into the three tables
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const T* dz, const int64_t* ids, const int64_t* type_ids,
+                                                        const int64_t* pos_ids, float* dword, float* dpos, float* dtype,
+                                                        int M, int L, int H, int vocab, int type_vocab, int npos, int pad_id) {
+    // block = 64 consecutive rows x one 256-column slab; type-embedding grads are reduced in LDS first (2-16 hot rows)
+    __shared__ float tacc[4][256];
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int r0 = blockIdx.x * 64;
+    for (int t = 0; t < 4; ++t) tacc[t][threadIdx.x] = 0.f;
+    if (c >= H) return;
+    for (int r = r0; r < r0 + 64 && r < M; ++r) {
+        const float g = Act<T>::ld(dz + (size_t)r * H + c);
+        int64_t id = ids[r];
+        if (id >= 0 && id < vocab && id != pad_id) unsafeAtomicAdd(dword + (size_t)id * H + c, g);
+        int64_t pp = pos_ids ? pos_ids[r] : (int64_t)(r % L);
+        if (pp >= 0 && pp < npos) unsafeAtomicAdd(dpos + (size_t)pp * H + c, g);
+        int64_t tt = type_ids ? type_ids[r] : 0;
+        if (tt >= 0 && tt < 4 && tt < type_vocab) tacc[tt][threadIdx.x] += g;
+        else if (tt >= 4 && tt < type_vocab) unsafeAtomicAdd(dtype + (size_t)tt * H + c, g);
+    }
+    for (int t = 0; t < 4 && t < type_vocab; ++t)
+        if (tacc[t][threadIdx.x] != 0.f) unsafeAtomicAdd(dtype + (size_t)t * H + c, tacc[t][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------ dropout + residual + LN
+// y (dense output incl. bias) is overwritten by z = resid + dropout(y) (kept for backward); out = LN(z)
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid, const float* gamma, const float* beta, T* out,
+                                                         float* mean, float* rstd, int M, int H, float eps, uint32_t thresh,
+                                                         float inv_keep, uint64_t seed) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int m = blockIdx.x * ROWS_PER_BLOCK + w;
+    if (m >= M) return;
+    const int nch = H >> 3;
+    float v[MAXCH][8], x[MAXCH][8];
+    row_load<T>(y_z + (size_t)m * H, nch, l, v);
+    row_load<T>(resid + (size_t)m * H, nch, l, x);
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = l + c * 64;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y = v[c][e];
+                if (thresh) y = drop_keep(seed, (uint64_t)m * H + ch * 8 + e, thresh) ? y * inv_keep : 0.f;
+                v[c][e] = x[c][e] + y;
+            }
+        }
+    }
+    row_store<T>(y_z + (size_t)m * H, nch, l, v);
+    float mu, rs;
+    row_stats(v, nch, l, H, eps, mu, rs);
+    if (l == 0) { if (mean) mean[m] = mu; if (rstd) rstd[m] = rs; }
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = l + c * 64;
+        if (ch < nch) {
+            float gg[8], bb[8];
+            ld8<float>(gamma + ch * 8, gg); ld8<float>(beta + ch * 8, bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] = (v[c][e] - mu) * rs * gg[e] + bb[e];
+        }
+    }
+    row_store<T>(out + (size_t)m * H, nch, l, v);
+}
+
+// LN backward.  dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  Also emits
+//   dbranch = dz * keepmask / (1-p)   (gradient of the dense output; == dz when p == 0 -> pass dbranch = nullptr)
+//   per-block column partials of dgamma (sum dy*xhat), dbeta (sum dy) and dbias (sum dbranch)
+#define LNB_ROWS 32     // rows per block (8 per wave)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, const float* mean, const float* rstd,
+                                                     const float* gamma, T* dz, T* dbranch, float* partials, int M, int H,
+                                                     uint32_t thresh, float inv_keep, uint64_t seed) {
+    extern __shared__ float red[];         // [3][4 waves][H]
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nch = H >> 3;
+    float gg[MAXCH][8];
+    float ag[MAXCH][8], ab[MAXCH][8], abias[MAXCH][8];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = l + c * 64;
+        if (ch < nch) ld8<float>(gamma + ch * 8, gg[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; abias[c][e] = 0.f; if (ch >= nch) gg[c][e] = 0.f; }
+    }
+    for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+        const int m = blockIdx.x * LNB_ROWS + rr * 4 + w;
+        if (m >= M) break;
+        float g[MAXCH][8], x[MAXCH][8];
+        row_load<T>(dy + (size_t)m * H, nch, l, g);
+        row_load<T>(z + (size_t)m * H, nch, l, x);
+        const float mu = mean[m], rs = rstd[m];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c)
+            if (l + c * 64 < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (x[c][e] - mu) * rs;
+                    x[c][e] = xh;
+                    ab[c][e] += g[c][e];
+                    ag[c][e] += g[c][e] * xh;
+                    g[c][e] *= gg[c][e];
+                    s1 += g[c][e];
+                    s2 += g[c][e] * xh;
+                }
+            }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c)
+            if (l + c * 64 < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[c][e] = rs * (g[c][e] - s1 - x[c][e] * s2);
+            }
+        row_store<T>(dz + (size_t)m * H, nch, l, g);
+        if (dbranch || partials) {
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c) {
+                const int ch = l + c * 64;
+                if (ch < nch) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float d = g[c][e];
+                        if (thresh) d = drop_keep(seed, (uint64_t)m * H + ch * 8 + e, thresh) ? d * inv_keep : 0.f;
+                        g[c][e] = d;
+                        abias[c][e] += d;
+                    }
+                }
+            }
+            if (dbranch) row_store<T>(dbranch + (size_t)m * H, nch, l, g);
+        }
+    }
+    if (!partials) return;
+    // cross-wave reduce through LDS, then one partial row per block
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = l + c * 64;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(0 * 4 + w) * H + ch * 8 + e] = ag[c][e];
+                red[(1 * 4 + w) * H + ch * 8 + e] = ab[c][e];
+                red[(2 * 4 + w) * H + ch * 8 + e] = abias[c][e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * H; i += 256) {
+        const int k = i / H, c = i - k * H;
+        const float s = red[(k * 4 + 0) * H + c] + red[(k * 4 + 1) * H + c] + red[(k * 4 + 2) * H + c] + red[(k * 4 + 3) * H + c];
+        partials[((size_t)k * gridDim.x + blockIdx.x) * H + c] = s;
+    }
+}
+
+// out[c] (+)= sum_b partials[b][c]   (deterministic second stage; one thread per column, coalesced across columns)
+__global__ void reduce_partials_kernel(const float* partials, int nblocks, int N, float* out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * N + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// strided variant: partial rows have `stride` floats, reduce columns [offset, offset+n)
+__global__ void reduce_partials_strided_kernel(const float* partials, int nblocks, int stride, int offset, int n, float* out,
+                                               int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * stride + offset + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// x[M, ld] (first N columns) -> partials[nblk][N]; block = 256 threads = 32 column-chunks(8) x 8 row lanes
+#define CS_ROWS 128
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, int ld, float* partials, int M, int N) {
+    __shared__ float red[8][256];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int col = (blockIdx.y * 32 + cx) * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < N) {
+        const int r1 = min(M, (int)(blockIdx.x + 1) * CS_ROWS);
+        for (int r = blockIdx.x * CS_ROWS + ry; r < r1; r += 8) {
+            float v[8]; ld8<T>(x + (size_t)r * ld + col, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ry][cx * 8 + e] = acc[e];
+    __syncthreads();
+    const int c = threadIdx.x;
+    const int gc = blockIdx.y * 256 + c;
+    if (gc < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += red[r][c];
+        partials[(size_t)blockIdx.x * N + gc] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dropout / cast
+template <typename TI, typename TO>
+__global__ void dropout_kernel(const TI* x, TO* y, size_t n8, uint32_t thresh, float inv_keep, uint64_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        float v[8]; ld8<TI>(x + i * 8, v);
+        if (thresh) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = drop_keep(seed, i * 8 + e, thresh) ? v[e] * inv_keep : 0.f;
+        }
+        st8<TO>(y + i * 8, v);
+    }
+}
+
+// W[N,K] fp32 master -> bf16 copy Wb[N,K] and bf16 transpose Wt[K,N]; 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* W, bf16_t* Wb, bf16_t* Wt, int N, int K) {
+    __shared__ bf16_t tile[64][66];
+    const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 16 threads, each 4 columns x 4 rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty * 4 + i;
+        const float4 v = *reinterpret_cast<const float4*>(W + (size_t)(n0 + r) * K + k0 + tx * 4);
+        const bf16_t b0 = f2bf(v.x), b1 = f2bf(v.y), b2 = f2bf(v.z), b3 = f2bf(v.w);
+        tile[r][tx * 4 + 0] = b0; tile[r][tx * 4 + 1] = b1; tile[r][tx * 4 + 2] = b2; tile[r][tx * 4 + 3] = b3;
+        if (Wb) {
+            uint2 pk; pk.x = (uint32_t)b0 | ((uint32_t)b1 << 16); pk.y = (uint32_t)b2 | ((uint32_t)b3 << 16);
+            *reinterpret_cast<uint2*>(Wb + (size_t)(n0 + r) * K + k0 + tx * 4) = pk;
+        }
+    }
+    __syncthreads();
+    if (Wt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = ty * 4 + i;        // row of Wt within the tile
+            uint2 pk;
+            pk.x = (uint32_t)tile[tx * 4 + 0][kr] | ((uint32_t)tile[tx * 4 + 1][kr] << 16);
+            pk.y = (uint32_t)tile[tx * 4 + 2][kr] | ((uint32_t)tile[tx * 4 + 3][kr] << 16);
+            *reinterpret_cast<uint2*>(Wt + (size_t)(k0 + kr) * N + n0 + tx * 4) = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ small-C row dot (heads)
+// logits[m][c] = x[m,:] . W[c,:] + b[c]   (classifier H->2, TSSP H->3;  modules/loss_calculator.py:17,42, modules/tssp.py:14,31)
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* x, const float* W, const float* b, float* out, int M, int H, int C) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int m = blockIdx.x * ROWS_PER_BLOCK + w;
+    if (m >= M) return;
+    const int nch = H >> 3;
+    float v[MAXCH][8];
+    row_load<T>(x + (size_t)m * H, nch, l, v);
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            const int ch = l + k * 64;
+            if (ch < nch) {
+                float ww[8]; ld8<float>(W + (size_t)c * H + ch * 8, ww);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[k][e] * ww[e];
+            }
+        }
+        s = wave_sum(s);
+        if (l == 0) out[(size_t)m * C + c] = s + (b ? b[c] : 0.f);
+    }
+}
+// dx[m,:] = sum_c dl[m][c] W[c,:] ; partial dW[c,:] = sum_m dl[m][c] x[m,:] ; partial db[c] = sum_m dl[m][c]   (C <= 4)
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* x, const float* W, const float* dl, T* dx, float* partials,
+                                                         int M, int H, int C) {
+    extern __shared__ float red[];      // [4 waves][C][H]
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nch = H >> 3;
+    float aw[4][MAXCH][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) aw[c][k][e] = 0.f;
+    float adb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+        const int m = blockIdx.x * LNB_ROWS + rr * 4 + w;
+        if (m >= M) break;
+        float v[MAXCH][8], o[MAXCH][8];
+        row_load<T>(x + (size_t)m * H, nch, l, v);
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[k][e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < C) {
+                const float d = dl[(size_t)m * C + c];
+                adb[c] += d;
+#pragma unroll
+                for (int k = 0; k < MAXCH; ++k) {
+                    const int ch = l + k * 64;
+                    if (ch < nch) {
+                        float ww[8]; ld8<float>(W + (size_t)c * H + ch * 8, ww);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { o[k][e] += d * ww[e]; aw[c][k][e] += d * v[k][e]; }
+                    }
+                }
+            }
+        }
+        if (dx) row_store<T>(dx + (size_t)m * H, nch, l, o);
+    }
+    if (!partials) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < C) {
+#pragma unroll
+            for (int k = 0; k < MAXCH; ++k) {
+                const int ch = l + k * 64;
+                if (ch < nch) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) red[((size_t)w * C + c) * H + ch * 8 + e] = aw[c][k][e];
+                }
+            }
+        }
+    __syncthreads();
+    // partial layout: [C*H weights | C biases] per block
+    const int PW = C * H + C;
+    for (int i = threadIdx.x; i < C * H; i += 256) {
+        const float s = red[(size_t)0 * C * H + i] + red[(size_t)1 * C * H + i] + red[(size_t)2 * C * H + i] + red[(size_t)3 * C * H + i];
+        partials[(size_t)blockIdx.x * PW + i] = s;
+    }
+    // bias partials: every lane of a wave holds the same adb; combine the 4 waves via LDS tail
+    __syncthreads();
+    if (l == 0)
+        for (int c = 0; c < C; ++c) red[w * 4 + c] = adb[c];
+    __syncthreads();
+    if (threadIdx.x < C)
+        partials[(size_t)blockIdx.x * PW + C * H + threadIdx.x] = red[0 * 4 + threadIdx.x] + red[1 * 4 + threadIdx.x] + red[2 * 4 + threadIdx.x] + red[3 * 4 + threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static inline void drop_params(float p, uint32_t& thresh, float& inv_keep) {
+    if (p <= 0.f) { thresh = 0; inv_keep = 1.f; return; }
+    double t = (double)p * 4294967296.0;
+    thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    if (thresh == 0) thresh = 1;
+    inv_keep = (float)(4294967296.0 / (4294967296.0 - (double)thresh));
+}
+
+int amdseg_embed_ln_fwd_impl(const int64_t* ids, const int64_t* type_ids, const float* word, const float* pos,
+                             const float* type, const float* gamma, const float* beta, void* z, void* out, float* mean,
+                             float* rstd, int M, int L, int H, int vocab, int type_vocab, int npos,
+                             const int64_t* pos_ids, float eps, float p, uint64_t seed, int dtype, hipStream_t s) {
+    if (!ids || !word || !pos || !type || !gamma || !beta || !out) return AMDSEG_ERR_ARG;
+    if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH || L <= 0) return AMDSEG_ERR_SHAPE;
+    uint32_t th; float ik; drop_params(p, th, ik);
+    dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    if (dtype == AMDSEG_BF16)
+        hipLaunchKernelGGL(embed_ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, ids, type_ids, pos_ids, word, pos, type, gamma, beta,
+                           (bf16_t*)z, (bf16_t*)out, mean, rstd, M, L, H, vocab, type_vocab, npos, eps, th, ik, seed);
+    else
+        hipLaunchKernelGGL(embed_ln_fwd_kernel<float>, grid, dim3(256), 0, s, ids, type_ids, pos_ids, word, pos, type, gamma, beta,
+                           (float*)z, (float*)out, mean, rstd, M, L, H, vocab, type_vocab, npos, eps, th, ik, seed);
+    return amdseg_launch_status();
+}
+
+int amdseg_embed_bwd_impl(const void* dz, const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
+                           float* dword, float* dpos, float* dtype_emb, int M, int L, int H, int vocab, int type_vocab,
+                           int npos, int pad_id, int dtype, hipStream_t s) {
+    if (!dz || !ids || !dword || !dpos || !dtype_emb) return AMDSEG_ERR_ARG;
+    if (M <= 0 || H <= 0) return AMDSEG_ERR_SHAPE;
+    dim3 grid((M + 63) / 64, (H + 255) / 256);
+    if (dtype == AMDSEG_BF16)
+        hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dz, ids, type_ids, pos_ids, dword, dpos,
+                           dtype_emb, M, L, H, vocab, type_vocab, npos, pad_id);
+    else
+        hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dz, ids, type_ids, pos_ids, dword, dpos,
+                           dtype_emb, M, L, H, vocab, type_vocab, npos, pad_id);
+    return amdseg_launch_status();
+}
+
+int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out,
+                           float* mean, float* rstd, int M, int H, float eps, float p, uint64_t seed, int dtype,
+                           hipStream_t s) {
+    if (!y_inout_z || !resid || !gamma || !beta || !out) return AMDSEG_ERR_ARG;
+    if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
+    uint32_t th; float ik; drop_params(p, th, ik);
+    dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    if (dtype == AMDSEG_BF16)
+        hipLaunchKernelGGL(add_ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta,
+                           (bf16_t*)out, mean, rstd, M, H, eps, th, ik, seed);
+    else
+        hipLaunchKernelGGL(add_ln_fwd_kernel<float>, grid, dim3(256), 0, s, (float*)y_inout_z, (const float*)resid, gamma, beta,
+                           (float*)out, mean, rstd, M, H, eps, th, ik, seed);
+    return amdseg_launch_status();
+}
+
+int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                       void* dz, void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M,
+                       int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s) {
+    if (!dy || !z || !mean || !rstd || !gamma || !dz) return AMDSEG_ERR_ARG;
+    if ((dgamma || dbeta || dbias) && !partials) return AMDSEG_ERR_ARG;
+    if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
+    uint32_t th; float ik; drop_params(p, th, ik);
+    const int nblk = (M + LNB_ROWS - 1) / LNB_ROWS;
+    const size_t shm = (size_t)3 * 4 * H * sizeof(float);
+    if (dtype == AMDSEG_BF16)
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), shm, s, (const bf16_t*)dy, (const bf16_t*)z, mean, rstd,
+                           gamma, (bf16_t*)dz, (bf16_t*)dbranch, partials, M, H, th, ik, seed);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nblk), dim3(256), shm, s, (const float*)dy, (const float*)z, mean, rstd, gamma,
+                           (float*)dz, (float*)dbranch, partials, M, H, th, ik, seed);
+    if (partials) {
+        dim3 g((H + 255) / 256);
+        if (dgamma) hipLaunchKernelGGL(reduce_partials_kernel, g, dim3(256), 0, s, partials, nblk, H, dgamma, accumulate);
+        if (dbeta) hipLaunchKernelGGL(reduce_partials_kernel, g, dim3(256), 0, s, partials + (size_t)nblk * H, nblk, H, dbeta, accumulate);
+        if (dbias) hipLaunchKernelGGL(reduce_partials_kernel, g, dim3(256), 0, s, partials + (size_t)2 * nblk * H, nblk, H, dbias, accumulate);
+    }
+    return amdseg_launch_status();
+}
+
+int amdseg_colsum_impl(const void* x, int ld, float* partials, float* out, int M, int N, int accumulate, int dtype,
+                       hipStream_t s) {
+    if (!x || !partials || !out) return AMDSEG_ERR_ARG;
+    if (M <= 0 || N <= 0 || (N % 8) || (ld % 8)) return AMDSEG_ERR_SHAPE;
+    const int nblk = (M + CS_ROWS - 1) / CS_ROWS;
+    dim3 grid(nblk, (N + 255) / 256);
+    if (dtype == AMDSEG_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, partials, M, N);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, partials, M, N);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partials, nblk, N, out, accumulate);
+    return amdseg_launch_status();
+}
+
+int amdseg_dropout_impl(const void* x, void* y, size_t n, float p, uint64_t seed, int dtype_in, int dtype_out,
+                        hipStream_t s) {
+    if (!x || !y) return AMDSEG_ERR_ARG;
+    if (n == 0 || (n % 8)) return AMDSEG_ERR_SHAPE;
+    uint32_t th; float ik; drop_params(p, th, ik);
+    const size_t n8 = n / 8;
+    const unsigned grid = (unsigned)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+    if (dtype_in == AMDSEG_BF16 && dtype_out == AMDSEG_BF16)
+        hipLaunchKernelGGL((dropout_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n8, th, ik, seed);
+    else if (dtype_in == AMDSEG_BF16 && dtype_out == AMDSEG_F32)
+        hipLaunchKernelGGL((dropout_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (float*)y, n8, th, ik, seed);
+    else if (dtype_in == AMDSEG_F32 && dtype_out == AMDSEG_BF16)
+        hipLaunchKernelGGL((dropout_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const float*)x, (bf16_t*)y, n8, th, ik, seed);
+    else
+        hipLaunchKernelGGL((dropout_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, n8, th, ik, seed);
+    return amdseg_launch_status();
+}
+
+int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_out, hipStream_t s) {
+    return amdseg_dropout_impl(x, y, n, 0.f, 0, dtype_in, dtype_out, s);
+}
+
+int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K, hipStream_t s) {
+    if (!W || (!Wb && !Wt)) return AMDSEG_ERR_ARG;
+    if (N <= 0 || K <= 0 || (N % 64) || (K % 64)) return AMDSEG_ERR_SHAPE;
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(K / 64, N / 64), dim3(256), 0, s, W, (bf16_t*)Wb, (bf16_t*)Wt, N, K);
+    return amdseg_launch_status();
+}
+
+int amdseg_rowdot_fwd_impl(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
+                           hipStream_t s) {
+    if (!x || !W || !out) return AMDSEG_ERR_ARG;
+    if (M <= 0 || C <= 0 || C > 4 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
+    dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    if (dtype == AMDSEG_BF16)
+        hipLaunchKernelGGL(rowdot_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, W, b, out, M, H, C);
+    else
+        hipLaunchKernelGGL(rowdot_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)x, W, b, out, M, H, C);
+    return amdseg_launch_status();
+}
+
+int amdseg_rowdot_bwd_impl(const void* x, const float* W, const float* dlogits, void* dx, float* partials, float* dW,
+                           float* db, int M, int H, int C, int accumulate, int dtype, hipStream_t s) {
+    if (!x || !W || !dlogits) return AMDSEG_ERR_ARG;
+    if ((dW || db) && !partials) return AMDSEG_ERR_ARG;
+    if (M <= 0 || C <= 0 || C > 4 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
+    const int nblk = (M + LNB_ROWS - 1) / LNB_ROWS;
+    const size_t shm = (size_t)4 * C * H * sizeof(float);
+    if (dtype == AMDSEG_BF16)
+        hipLaunchKernelGGL(rowdot_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), shm, s, (const bf16_t*)x, W, dlogits, (bf16_t*)dx, partials, M, H, C);
+    else
+        hipLaunchKernelGGL(rowdot_bwd_kernel<float>, dim3(nblk), dim3(256), shm, s, (const float*)x, W, dlogits, (float*)dx, partials, M, H, C);
+    if (partials) {
+        const int PW = C * H + C;
+        // partial rows are [C*H | C]; reduce weights and biases with a strided view: treat as N = PW columns
+        // (dW and db are contiguous in the flat parameter layout only by convention, so reduce separately)
+        if (dW) hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((C * H + 255) / 256), dim3(256), 0, s, partials, nblk, PW, 0, C * H, dW, accumulate);
+        if (db) hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3(1), dim3(256), 0, s, partials, nblk, PW, C * H, C, db, accumulate);
+    }
+    return amdseg_launch_status();
+}

@@ -1,0 +1,119 @@
+// Fused optimiser-side kernels over the flat fp32 parameter / gradient buffers (HBM-bound, 16 B/lane streams).
+//
+// Replaces torch.optim.AdamW.step + torch.nn.utils.clip_grad_norm_ as driven by transformers.Trainer
+// ([hf] trainer.py:2539 clip, training_args.py:777-856 defaults; reference launch values run_finetune.sh:29,73:
+// lr 5e-5, betas (0.9, 0.999), eps 1e-8, weight_decay 0, max_grad_norm 1.0).  Update rule = torch.optim.AdamW
+// (decoupled decay, bias-corrected, eps added to sqrt(v_hat)) -- the oracle for it is torch.optim.AdamW on CPU.
+// One pass reads p,g,m,v and writes p,m,v (+ the bf16 compute shadow, + optionally zeroes g): 28-34 B/param.
+#include "common.h"
+#include "amdseg_internal.h"
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n4, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1, float rsqrt_bc2,
+                                                    const float* __restrict__ gscale, int zero_grad) {
+    const float gs = gscale ? *gscale : 1.0f;
+    const float step_size = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        float4 gg = reinterpret_cast<float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x, gg.y, gg.z, gg.w}, Mm[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = G[e] * gs;
+            P[e] *= (1.0f - lr * wd);
+            Mm[e] = beta1 * Mm[e] + (1.0f - beta1) * gr;
+            V[e] = beta2 * V[e] + (1.0f - beta2) * gr * gr;
+            const float denom = sqrtf(V[e]) * rsqrt_bc2 + eps;
+            P[e] -= step_size * (Mm[e] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = make_float4(P[0], P[1], P[2], P[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(Mm[0], Mm[1], Mm[2], Mm[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(V[0], V[1], V[2], V[3]);
+        if (shadow) {
+            uint2 pk; pk.x = pack2bf(P[0], P[1]); pk.y = pack2bf(P[2], P[3]);
+            reinterpret_cast<uint2*>(shadow)[i] = pk;
+        }
+        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n4, float* partials) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4*>(x)[i];
+        s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_final_kernel(const float* partials, int n, float* out, int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { const float t = red[0] + red[1] + red[2] + red[3]; out[0] = accumulate ? out[0] + t : t; }
+}
+// coef = min(1, max_norm / (norm + 1e-6)) * extra_scale  (torch.nn.utils.clip_grad_norm_), norm = sqrt(sumsq) * |extra_scale| ... see api
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float extra_scale, float* coef, float* norm) {
+    const float nrm = sqrtf(sumsq[0]) * extra_scale;       // extra_scale: 1/world_size or 1/grad_accum pre-scaling
+    if (norm) norm[0] = nrm;
+    float c = max_norm > 0.f ? max_norm / (nrm + 1e-6f) : 1.0f;
+    c = c > 1.0f ? 1.0f : c;
+    coef[0] = c * extra_scale;
+}
+__global__ void scale_kernel(float* x, size_t n4, const float* coef) {
+    const float c = *coef;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<float4*>(x)[i];
+        a.x *= c; a.y *= c; a.z *= c; a.w *= c;
+        reinterpret_cast<float4*>(x)[i] = a;
+    }
+}
+
+static inline unsigned stream_grid(size_t n4) {
+    size_t b = (n4 + 255) / 256;
+    return (unsigned)(b > 2048 ? 2048 : (b == 0 ? 1 : b));
+}
+
+int amdseg_adamw_impl(float* p, const float* g, float* m, float* v, void* shadow, size_t n, float lr, float beta1,
+                      float beta2, float eps, float wd, int step, const float* gscale, int zero_grad, hipStream_t s) {
+    if (!p || !g || !m || !v) return AMDSEG_ERR_ARG;
+    if (n == 0 || (n % 4) || step < 1) return AMDSEG_ERR_SHAPE;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, s, p, (float*)g, m, v, (bf16_t*)shadow, n / 4, lr, beta1,
+                       beta2, eps, wd, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, zero_grad);
+    return amdseg_launch_status();
+}
+
+#define SUMSQ_BLOCKS 1024
+int amdseg_sumsq_impl(const float* x, size_t n, float* partials, float* out, int accumulate, hipStream_t s) {
+    if (!x || !partials || !out) return AMDSEG_ERR_ARG;
+    if (n == 0 || (n % 4)) return AMDSEG_ERR_SHAPE;
+    unsigned grid = stream_grid(n / 4);
+    if (grid > SUMSQ_BLOCKS) grid = SUMSQ_BLOCKS;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, x, n / 4, partials);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, partials, (int)grid, out, accumulate);
+    return amdseg_launch_status();
+}
+
+int amdseg_clip_coef_impl(const float* sumsq, float max_norm, float extra_scale, float* coef, float* norm, hipStream_t s) {
+    if (!sumsq || !coef) return AMDSEG_ERR_ARG;
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, sumsq, max_norm, extra_scale, coef, norm);
+    return amdseg_launch_status();
+}
+
+int amdseg_scale_impl(float* x, size_t n, const float* coef, hipStream_t s) {
+    if (!x || !coef) return AMDSEG_ERR_ARG;
+    if (n == 0 || (n % 4)) return AMDSEG_ERR_SHAPE;
+    hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, s, x, n / 4, coef);
+    return amdseg_launch_status();
+}

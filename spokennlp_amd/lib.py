@@ -1,0 +1,107 @@
+"""ctypes binding of libamdseg.so (C ABI declared in include/amdseg.h).
+
+The product path has no CPU / PyTorch fallback: if the HIP library is missing or an entry point is absent this
+module raises immediately (build it with ``python -m spokennlp_amd.build`` or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libamdseg.so")
+
+BF16, F32 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
+ABI_VERSION = 1
+
+vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
+
+
+class BertCfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("heads", C.c_int32), ("I", C.c_int32),
+                ("ln_eps", f32), ("p_hidden", f32), ("p_attn", f32), ("seed", u64),
+                ("accumulate_grads", C.c_int32), ("dtype", C.c_int32)]
+
+
+class LayerParams(C.Structure):
+    _fields_ = [(n, vp) for n in ("wqkv", "wo", "w1", "w2", "wqkv_t", "wo_t", "w1_t", "w2_t",
+                                  "bqkv", "bo", "b1", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+
+
+class LayerGrads(C.Structure):
+    _fields_ = [(n, vp) for n in ("wqkv", "wo", "w1", "w2", "bqkv", "bo", "b1", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+
+
+class LayerActs(C.Structure):
+    _fields_ = [(n, vp) for n in ("x_in", "qkv", "ctx", "z1", "x1", "u", "h", "z2", "x_out",
+                                  "lse", "mean1", "rstd1", "mean2", "rstd2")]
+
+
+class LayerWs(C.Structure):
+    _fields_ = [(n, vp) for n in ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx", "dqkv", "delta", "partials")]
+
+
+# name -> argtypes (restype is always int unless listed in _RESTYPE); mirrors include/amdseg.h one for one
+_PROTOS = {
+    "amdseg_abi_version": [],
+    "amdseg_error_string": [i32],
+    "amdseg_gemm_nt": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp],
+    "amdseg_gemm_tn_grouped": [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp),
+                               C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, i32, vp],
+    "amdseg_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
+    "amdseg_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
+    "amdseg_embed_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, u64, i32, vp],
+    "amdseg_embed_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "amdseg_add_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, i32, vp],
+    "amdseg_ln_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u64, i32, i32, vp],
+    "amdseg_colsum": [vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "amdseg_dropout": [vp, vp, sz, f32, u64, i32, i32, vp],
+    "amdseg_cast": [vp, vp, sz, i32, i32, vp],
+    "amdseg_cast_transpose": [vp, vp, vp, i32, i32, vp],
+    "amdseg_rowdot_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "amdseg_rowdot_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "amdseg_adamw": [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, vp, i32, vp],
+    "amdseg_sumsq": [vp, sz, vp, vp, i32, vp],
+    "amdseg_clip_coef": [vp, f32, f32, vp, vp, vp],
+    "amdseg_scale": [vp, sz, vp, vp],
+    "amdseg_bert_layer_fwd": [C.POINTER(BertCfg), C.POINTER(LayerParams), C.POINTER(LayerActs), vp, i32, vp],
+    "amdseg_bert_layer_bwd": [C.POINTER(BertCfg), C.POINTER(LayerParams), C.POINTER(LayerGrads), C.POINTER(LayerActs),
+                              C.POINTER(LayerWs), vp, vp, vp, i32, vp],
+}
+_RESTYPE = {"amdseg_error_string": C.c_char_p}
+
+EXPORTS = tuple(_PROTOS)
+_lib = None
+
+
+class AmdsegError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """Load libamdseg.so and bind every declared symbol; raises AmdsegError if anything is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise AmdsegError(f"libamdseg.so not found at {p}: the HIP extension is required (no CPU fallback); "
+                          f"run `python -m spokennlp_amd.build`")
+    lib = C.CDLL(p)
+    for name, args in _PROTOS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise AmdsegError(f"libamdseg.so does not export {name}") from e
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    if lib.amdseg_abi_version() != ABI_VERSION:
+        raise AmdsegError("libamdseg.so ABI version mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().amdseg_error_string(rc)
+        raise AmdsegError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,207 @@
+"""Thin torch-tensor wrappers over the libamdseg C ABI (tensors are storage only: data_ptr + stream go to HIP).
+
+Every function launches on torch's current HIP stream and raises ``AmdsegError`` on a non-zero return code.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import BF16, F32, EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD  # noqa: F401
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _chk(t, name):
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous device tensor")
+
+
+def gemm_nt(A, B, epilogue=EPI_NONE, bias=None, R=None, out=None, out2=None, out_dtype=torch.bfloat16):
+    """C[M,N] = A[M,K] @ B[N,K]^T with fused epilogue; A, B bf16. Returns C (and C2 for EPI_BIAS_GELU)."""
+    _chk(A, "A"); _chk(B, "B")
+    M, K = A.shape
+    N = B.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    if epilogue == EPI_BIAS_GELU and out2 is None:
+        out2 = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    rc = L.load().amdseg_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, epilogue,
+                                 _p(bias), _p(R), 0 if R is None else R.stride(0), _p(out2),
+                                 0 if out2 is None else out2.stride(0), 1 if out.dtype == torch.float32 else 0, _s())
+    L.check(rc, "amdseg_gemm_nt")
+    return (out, out2) if epilogue == EPI_BIAS_GELU else out
+
+
+def gemm_tn_grouped(As, Bs, Cs, accumulate=False):
+    """For each i: Cs[i][N_i,K_i] (+)= As[i]^T @ Bs[i]  (As[i]: [M,N_i] bf16, Bs[i]: [M,K_i] bf16, Cs[i] fp32)."""
+    n = len(As)
+    M = As[0].shape[0]
+    vpa = (C.c_void_p * n)(*[a.data_ptr() for a in As])
+    vpb = (C.c_void_p * n)(*[b.data_ptr() for b in Bs])
+    vpc = (C.c_void_p * n)(*[c.data_ptr() for c in Cs])
+    ia = (C.c_int * n)(*[a.stride(0) for a in As])
+    ib = (C.c_int * n)(*[b.stride(0) for b in Bs])
+    ic = (C.c_int * n)(*[c.stride(0) for c in Cs])
+    nn = (C.c_int * n)(*[a.shape[1] for a in As])
+    kk = (C.c_int * n)(*[b.shape[1] for b in Bs])
+    rc = L.load().amdseg_gemm_tn_grouped(n, vpa, ia, vpb, ib, vpc, ic, nn, kk, M, 1 if accumulate else 0, _s())
+    L.check(rc, "amdseg_gemm_tn_grouped")
+    return Cs
+
+
+def attn_fwd(qkv, mask_bias, B, Lseq, heads, p=0.0, seed=0, need_lse=True, scale=0.125):
+    H = heads * 64
+    ctx = torch.empty((B * Lseq, H), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device) if need_lse else None
+    rc = L.load().amdseg_attn_fwd(_p(qkv), _p(mask_bias), _p(ctx), _p(lse), B, Lseq, heads, scale, p, seed, _s())
+    L.check(rc, "amdseg_attn_fwd")
+    return ctx, lse
+
+
+def attn_bwd(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, p=0.0, seed=0, scale=0.125):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device)
+    rc = L.load().amdseg_attn_bwd(_p(qkv), _p(mask_bias), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, Lseq, heads,
+                                  scale, p, seed, _s())
+    L.check(rc, "amdseg_attn_bwd")
+    return dqkv
+
+
+def embed_ln_fwd(ids, type_ids, pos_ids, word, pos, typ, gamma, beta, Lseq, eps, p=0.0, seed=0, dtype=torch.bfloat16,
+                 save=True):
+    M = ids.numel()
+    H = word.shape[1]
+    dev = word.device
+    out = torch.empty((M, H), dtype=dtype, device=dev)
+    z = torch.empty((M, H), dtype=dtype, device=dev) if save else None
+    mean = torch.empty((M,), dtype=torch.float32, device=dev) if save else None
+    rstd = torch.empty((M,), dtype=torch.float32, device=dev) if save else None
+    rc = L.load().amdseg_embed_ln_fwd(_p(ids), _p(type_ids), _p(pos_ids), _p(word), _p(pos), _p(typ), _p(gamma), _p(beta),
+                                      _p(z), _p(out), _p(mean), _p(rstd), M, Lseq, H, word.shape[0], typ.shape[0],
+                                      pos.shape[0], eps, p, seed, _dt(out), _s())
+    L.check(rc, "amdseg_embed_ln_fwd")
+    return out, z, mean, rstd
+
+
+def embed_bwd(dz, ids, type_ids, pos_ids, dword, dpos, dtyp, Lseq, pad_id=-1):
+    M, H = dz.shape
+    rc = L.load().amdseg_embed_bwd(_p(dz), _p(ids), _p(type_ids), _p(pos_ids), _p(dword), _p(dpos), _p(dtyp), M, Lseq, H,
+                                   dword.shape[0], dtyp.shape[0], dpos.shape[0], pad_id, _dt(dz), _s())
+    L.check(rc, "amdseg_embed_bwd")
+
+
+def add_ln_fwd(y, resid, gamma, beta, eps, p=0.0, seed=0):
+    """y is overwritten with z = resid + dropout(y); returns (out, mean, rstd)."""
+    M, H = y.shape
+    out = torch.empty_like(y)
+    mean = torch.empty((M,), dtype=torch.float32, device=y.device)
+    rstd = torch.empty((M,), dtype=torch.float32, device=y.device)
+    rc = L.load().amdseg_add_ln_fwd(_p(y), _p(resid), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), M, H, eps, p, seed,
+                                    _dt(y), _s())
+    L.check(rc, "amdseg_add_ln_fwd")
+    return out, mean, rstd
+
+
+def ln_partials_numel(M, H):
+    return 3 * ((M + 31) // 32) * H
+
+
+def ln_bwd(dy, z, mean, rstd, gamma, p=0.0, seed=0, dgamma=None, dbeta=None, dbias=None, accumulate=False, partials=None):
+    M, H = dy.shape
+    dz = torch.empty_like(dy)
+    dbr = torch.empty_like(dy) if p > 0 else None
+    if partials is None and (dgamma is not None or dbeta is not None or dbias is not None):
+        partials = torch.empty((ln_partials_numel(M, H),), dtype=torch.float32, device=dy.device)
+    rc = L.load().amdseg_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dbr), _p(partials), _p(dgamma),
+                                _p(dbeta), _p(dbias), M, H, p, seed, 1 if accumulate else 0, _dt(dy), _s())
+    L.check(rc, "amdseg_ln_bwd")
+    return dz, (dbr if dbr is not None else dz)
+
+
+def colsum(x, out=None, accumulate=False, ncols=None):
+    M = x.shape[0]
+    N = ncols or x.shape[1]
+    if out is None:
+        out = torch.zeros((N,), dtype=torch.float32, device=x.device)
+    partials = torch.empty((((M + 127) // 128) * N,), dtype=torch.float32, device=x.device)
+    rc = L.load().amdseg_colsum(_p(x), x.stride(0), _p(partials), _p(out), M, N, 1 if accumulate else 0, _dt(x), _s())
+    L.check(rc, "amdseg_colsum")
+    return out
+
+
+def dropout(x, p, seed, out_dtype=None):
+    y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    rc = L.load().amdseg_dropout(_p(x), _p(y), x.numel(), p, seed, _dt(x), _dt(y), _s())
+    L.check(rc, "amdseg_dropout")
+    return y
+
+
+def cast(x, dtype):
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    rc = L.load().amdseg_cast(_p(x), _p(y), x.numel(), _dt(x), _dt(y), _s())
+    L.check(rc, "amdseg_cast")
+    return y
+
+
+def cast_transpose(W, Wb=None, Wt=None):
+    N, K = W.shape
+    rc = L.load().amdseg_cast_transpose(_p(W), _p(Wb), _p(Wt), N, K, _s())
+    L.check(rc, "amdseg_cast_transpose")
+
+
+def rowdot_fwd(x, W, b):
+    M, H = x.shape
+    Cc = W.shape[0]
+    out = torch.empty((M, Cc), dtype=torch.float32, device=x.device)
+    rc = L.load().amdseg_rowdot_fwd(_p(x), _p(W), _p(b), _p(out), M, H, Cc, _dt(x), _s())
+    L.check(rc, "amdseg_rowdot_fwd")
+    return out
+
+
+def rowdot_bwd(x, W, dlogits, dW=None, db=None, need_dx=True, accumulate=False):
+    M, H = x.shape
+    Cc = W.shape[0]
+    dx = torch.empty_like(x) if need_dx else None
+    partials = None
+    if dW is not None or db is not None:
+        partials = torch.empty((((M + 31) // 32) * (Cc * H + Cc),), dtype=torch.float32, device=x.device)
+    rc = L.load().amdseg_rowdot_bwd(_p(x), _p(W), _p(dlogits), _p(dx), _p(partials), _p(dW), _p(db), M, H, Cc,
+                                    1 if accumulate else 0, _dt(x), _s())
+    L.check(rc, "amdseg_rowdot_bwd")
+    return dx
+
+
+def adamw(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, gscale=None, zero_grad=False):
+    rc = L.load().amdseg_adamw(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, beta1, beta2, eps, wd, step,
+                               _p(gscale), 1 if zero_grad else 0, _s())
+    L.check(rc, "amdseg_adamw")
+
+
+def sumsq(x, out, partials, accumulate=False):
+    rc = L.load().amdseg_sumsq(_p(x), x.numel(), _p(partials), _p(out), 1 if accumulate else 0, _s())
+    L.check(rc, "amdseg_sumsq")
+
+
+def clip_coef(sumsq_t, max_norm, extra_scale, coef, norm=None):
+    rc = L.load().amdseg_clip_coef(_p(sumsq_t), max_norm, extra_scale, _p(coef), _p(norm), _s())
+    L.check(rc, "amdseg_clip_coef")
+
+
+def scale_(x, coef):
+    rc = L.load().amdseg_scale(_p(x), x.numel(), _p(coef), _s())
+    L.check(rc, "amdseg_scale")

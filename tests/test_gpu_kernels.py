@@ -1,0 +1,379 @@
+"""Per-kernel numerics tests of libamdseg on a real MI355X: each HIP kernel (called through the C ABI) against a plain
+fp32 torch reference of the same op on the same seeded inputs.  Tolerances are stated per test: bf16 outputs carry a
+2^-9 relative rounding, MFMA accumulates in fp32."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from spokennlp_amd import ops
+    return ops
+
+
+def rel_err(a, b):
+    a = a.float(); b = b.float()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+def gelu_grad(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+# ----------------------------------------------------------------------------------------------------------- GEMM NT
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (512, 768, 768), (1024, 2304, 768), (256, 768, 3072)])
+def test_gemm_nt_plain(dev, M, N, K):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    B = torch.randn(N, K, generator=g).to(dev).bfloat16()
+    ref = A.float() @ B.float().t()
+    C32 = ops.gemm_nt(A, B, ops.EPI_NONE, out_dtype=torch.float32)
+    # fp32 accumulation of exact bf16 products: only summation-order differences
+    assert rel_err(C32, ref) < 2e-6
+    assert (C32 - ref).abs().max().item() < 1e-3 * math.sqrt(K / 64)
+    Cb = ops.gemm_nt(A, B, ops.EPI_NONE)
+    assert torch.equal(Cb, C32.bfloat16()) or rel_err(Cb, ref) < 4e-3   # one bf16 rounding
+
+
+def test_gemm_nt_transpose_detect(dev):
+    """asymmetric operands: catches row/col swaps of the accumulator layout."""
+    ops = _ops()
+    M, N, K = 128, 256, 64
+    A = torch.zeros(M, K, device=dev); B = torch.zeros(N, K, device=dev)
+    A[:, 0] = torch.arange(M, device=dev) % 32          # small ints, exact in bf16
+    B[:, 0] = 1.0
+    B[:, 1] = torch.arange(N, device=dev) % 16
+    A[:, 1] = 1.0
+    C = ops.gemm_nt(A.bfloat16(), B.bfloat16(), ops.EPI_NONE, out_dtype=torch.float32)
+    ref = A @ B.t()
+    assert torch.equal(C, ref)
+
+
+def test_gemm_nt_epilogues(dev):
+    ops = _ops()
+    M, N, K = 256, 512, 256
+    g = torch.Generator(device="cpu").manual_seed(7)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16()
+    B = (torch.randn(N, K, generator=g) * 0.1).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    R = torch.randn(M, N, generator=g).to(dev).bfloat16()
+    base = A.float() @ B.float().t()
+    C = ops.gemm_nt(A, B, ops.EPI_BIAS, bias=bias, out_dtype=torch.float32)
+    assert rel_err(C, base + bias) < 2e-6
+    H, U = ops.gemm_nt(A, B, ops.EPI_BIAS_GELU, bias=bias)
+    assert rel_err(U, base + bias) < 4e-3
+    assert rel_err(H, gelu(base + bias)) < 4e-3
+    C = ops.gemm_nt(A, B, ops.EPI_ADD_RES, R=R, out_dtype=torch.float32)
+    assert rel_err(C, base + R.float()) < 2e-6
+    C = ops.gemm_nt(A, B, ops.EPI_GELU_BWD, R=R)
+    assert rel_err(C, base * gelu_grad(R.float())) < 4e-3
+
+
+def test_gemm_nt_strided_views(dev):
+    """operands / outputs that are column slices of wider buffers (ld != width)."""
+    ops = _ops()
+    M, N, K = 128, 128, 128
+    g = torch.Generator(device="cpu").manual_seed(3)
+    Abig = torch.randn(M, 3 * K, generator=g).to(dev).bfloat16()
+    B = torch.randn(N, K, generator=g).to(dev).bfloat16()
+    A = Abig[:, K:2 * K]
+    from spokennlp_amd import lib as L
+    out = torch.zeros(M, 2 * N, dtype=torch.float32, device=dev)
+    rc = L.load().amdseg_gemm_nt(A.data_ptr(), 3 * K, B.data_ptr(), K, out[:, N:].data_ptr(), 2 * N, M, N, K, 0, None, None, 0,
+                                 None, 0, 1, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    ref = A.float() @ B.float().t()
+    assert rel_err(out[:, N:], ref) < 2e-6
+    assert out[:, :N].abs().max().item() == 0
+
+
+def test_gemm_nt_rejects_bad_shapes(dev):
+    from spokennlp_amd import lib as L
+    a = torch.zeros(128, 64, dtype=torch.bfloat16, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.load().amdseg_gemm_nt(a.data_ptr(), 64, a.data_ptr(), 64, a.data_ptr(), 64, 100, 128, 64, 0, None, None, 0, None, 0, 0, s) == 1001
+    assert L.load().amdseg_gemm_nt(None, 64, a.data_ptr(), 64, a.data_ptr(), 64, 128, 128, 64, 0, None, None, 0, None, 0, 0, s) == 1002
+
+
+# ----------------------------------------------------------------------------------------------------------- GEMM TN
+def test_gemm_tn_grouped(dev):
+    ops = _ops()
+    M = 512
+    shapes = [(128, 256), (256, 128), (384, 128), (128, 128)]
+    g = torch.Generator(device="cpu").manual_seed(11)
+    As = [torch.randn(M, n, generator=g).to(dev).bfloat16() for n, _ in shapes]
+    Bs = [torch.randn(M, k, generator=g).to(dev).bfloat16() for _, k in shapes]
+    Cs = [torch.full((n, k), 7.0, dtype=torch.float32, device=dev) for n, k in shapes]
+    ops.gemm_tn_grouped(As, Bs, Cs, accumulate=False)
+    for a, b, c in zip(As, Bs, Cs):
+        ref = a.float().t() @ b.float()
+        assert rel_err(c, ref) < 2e-6
+    ops.gemm_tn_grouped(As, Bs, Cs, accumulate=True)
+    for a, b, c in zip(As, Bs, Cs):
+        ref = 2 * (a.float().t() @ b.float())
+        assert rel_err(c, ref) < 2e-6
+
+
+def test_gemm_tn_transpose_detect(dev):
+    ops = _ops()
+    M, N, K = 64, 128, 256
+    A = torch.zeros(M, N, device=dev); B = torch.zeros(M, K, device=dev)
+    A[0] = torch.arange(N, device=dev) % 32
+    B[0] = 1.0
+    A[1] = 1.0
+    B[1] = torch.arange(K, device=dev) % 16
+    C = torch.empty(N, K, dtype=torch.float32, device=dev)
+    ops.gemm_tn_grouped([A.bfloat16()], [B.bfloat16()], [C])
+    assert torch.equal(C, A.t() @ B)
+
+
+# ----------------------------------------------------------------------------------------------------------- attention
+def attn_ref(qkv, mask_bias, B, L, heads, keep=None, inv_keep=1.0):
+    """fp32 reference on the bf16 inputs. keep: optional [B,heads,L,L] 0/1 mask of kept probabilities."""
+    H = heads * 64
+    x = qkv.float().view(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)   # [3,B,h,L,64]
+    q, k, v = x[0], x[1], x[2]
+    s = q @ k.transpose(-1, -2) * 0.125 + mask_bias.view(B, 1, 1, L)
+    p = torch.softmax(s, dim=-1)
+    pd = p if keep is None else p * keep * inv_keep
+    o = pd @ v
+    return o.permute(0, 2, 1, 3).reshape(B * L, H), p
+
+
+def make_qkv(dev, B, L, heads, seed, pad=True):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    qkv = (torch.randn(B * L, 3 * heads * 64, generator=g) * 1.0).to(dev).bfloat16()
+    mask = torch.ones(B, L)
+    if pad:
+        for b in range(B):
+            n = L - (b * 37) % (L // 2)
+            mask[b, n:] = 0
+    mask_bias = ((1.0 - mask) * -1e30).to(dev)
+    return qkv, mask_bias
+
+
+@pytest.mark.parametrize("B,L,heads", [(1, 64, 1), (2, 128, 2), (2, 512, 3)])
+def test_attn_fwd(dev, B, L, heads):
+    ops = _ops()
+    qkv, mb = make_qkv(dev, B, L, heads, 5)
+    ctx, lse = ops.attn_fwd(qkv, mb, B, L, heads)
+    ref, p = attn_ref(qkv, mb, B, L, heads)
+    # P is rounded to bf16 before P.V (relative 2^-9), output rounded to bf16
+    assert (ctx.float() - ref).abs().max().item() < 2e-2
+    assert rel_err(ctx, ref) < 6e-3
+    x = qkv.float().view(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = x[0] @ x[1].transpose(-1, -2) * 0.125 + mb.view(B, 1, 1, L)
+    lse_ref = torch.logsumexp(s, dim=-1).reshape(-1)
+    assert (lse - lse_ref).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("B,L,heads", [(1, 64, 1), (2, 128, 2), (1, 512, 2)])
+def test_attn_bwd(dev, B, L, heads):
+    ops = _ops()
+    qkv, mb = make_qkv(dev, B, L, heads, 9)
+    g = torch.Generator(device="cpu").manual_seed(10)
+    dctx = torch.randn(B * L, heads * 64, generator=g).to(dev).bfloat16()
+    ctx, lse = ops.attn_fwd(qkv, mb, B, L, heads)
+    dqkv = ops.attn_bwd(qkv, mb, ctx, dctx, lse, B, L, heads)
+    q32 = qkv.float().requires_grad_(True)
+    ref, _ = attn_ref(q32, mb, B, L, heads)
+    ref.backward(dctx.float())
+    assert rel_err(dqkv, q32.grad) < 1.5e-2
+    # per-section (dq, dk, dv) so a wrong section cannot hide
+    H = heads * 64
+    for i, name in enumerate(["dq", "dk", "dv"]):
+        assert rel_err(dqkv[:, i * H:(i + 1) * H], q32.grad[:, i * H:(i + 1) * H]) < 1.5e-2, name
+
+
+def extract_keep_mask(ops, dev, B, L, heads, p, seed):
+    """recover the kernel's dropout mask on attention probabilities: with q=k=0 the probabilities are uniform 1/L and
+    with V = one-hot rows of a 64-key block the output row q is P_drop[q, block]."""
+    keep = torch.zeros(B, heads, L, L, device=dev)
+    mb = torch.zeros(B, L, device=dev)
+    for blk in range(L // 64):
+        qkv = torch.zeros(B, L, 3, heads, 64, device=dev)
+        for j in range(64):
+            qkv[:, blk * 64 + j, 2, :, j] = 1.0
+        ctx, _ = ops.attn_fwd(qkv.view(B * L, -1).bfloat16(), mb, B, L, heads, p=p, seed=seed)
+        o = ctx.float().view(B, L, heads, 64).permute(0, 2, 1, 3)      # [B,h,L(q),64(key in block)]
+        keep[:, :, :, blk * 64:(blk + 1) * 64] = (o > 0).float()
+    return keep
+
+
+def test_attn_dropout_fwd_bwd(dev):
+    ops = _ops()
+    B, L, heads, p, seed = 2, 128, 2, 0.1, 1234
+    keep = extract_keep_mask(ops, dev, B, L, heads, p, seed)
+    frac = 1.0 - keep.mean().item()
+    assert abs(frac - p) < 0.01, frac
+    th = round(p * 65536)
+    inv_keep = 65536.0 / (65536 - th)
+    qkv, mb = make_qkv(dev, B, L, heads, 21, pad=False)
+    g = torch.Generator(device="cpu").manual_seed(22)
+    dctx = torch.randn(B * L, heads * 64, generator=g).to(dev).bfloat16()
+    ctx, lse = ops.attn_fwd(qkv, mb, B, L, heads, p=p, seed=seed)
+    q32 = qkv.float().requires_grad_(True)
+    ref, _ = attn_ref(q32, mb, B, L, heads, keep=keep, inv_keep=inv_keep)
+    assert rel_err(ctx, ref) < 8e-3
+    dqkv = ops.attn_bwd(qkv, mb, ctx, dctx, lse, B, L, heads, p=p, seed=seed)
+    ref.backward(dctx.float())
+    assert rel_err(dqkv, q32.grad) < 2e-2
+
+
+# ----------------------------------------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_embed_ln_fwd_bwd(dev, dtype):
+    ops = _ops()
+    B, L, H, V = 2, 64, 128, 100
+    g = torch.Generator(device="cpu").manual_seed(1)
+    word = torch.randn(V, H, generator=g).to(dev); pos = torch.randn(L, H, generator=g).to(dev); typ = torch.randn(2, H, generator=g).to(dev)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev); beta = (0.1 * torch.randn(H, generator=g)).to(dev)
+    ids = torch.randint(0, V, (B * L,), generator=g).to(dev); tt = torch.randint(0, 2, (B * L,), generator=g).to(dev)
+    out, z, mean, rstd = ops.embed_ln_fwd(ids, tt, None, word, pos, typ, gamma, beta, L, 1e-12, dtype=dtype)
+    zr = word[ids] + typ[tt] + pos[torch.arange(B * L, device=dev) % L]
+    ref = torch.nn.functional.layer_norm(zr, (H,), gamma, beta, 1e-12)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert (out.float() - ref).abs().max().item() < tol * 4
+    assert (mean - zr.mean(-1)).abs().max().item() < 1e-5
+    dz = torch.randn(B * L, H, generator=g).to(dev).to(dtype)
+    dword = torch.zeros_like(word); dpos = torch.zeros_like(pos); dtyp = torch.zeros_like(typ)
+    ops.embed_bwd(dz, ids, tt, None, dword, dpos, dtyp, L, pad_id=0)
+    rw = torch.zeros_like(word).index_add_(0, ids, dz.float()); rw[0] = 0
+    rp = torch.zeros_like(pos).index_add_(0, torch.arange(B * L, device=dev) % L, dz.float())
+    rt = torch.zeros_like(typ).index_add_(0, tt, dz.float())
+    assert (dword - rw).abs().max().item() < 1e-4
+    assert (dpos - rp).abs().max().item() < 1e-4
+    assert (dtyp - rt).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("dtype,H", [(torch.bfloat16, 768), (torch.float32, 768), (torch.bfloat16, 128), (torch.float32, 1024)])
+def test_add_ln_fwd_bwd(dev, dtype, H):
+    ops = _ops()
+    M = 256
+    g = torch.Generator(device="cpu").manual_seed(2)
+    y = torch.randn(M, H, generator=g).to(dev).to(dtype); x = torch.randn(M, H, generator=g).to(dev).to(dtype)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev); beta = (0.1 * torch.randn(H, generator=g)).to(dev)
+    dy = torch.randn(M, H, generator=g).to(dev).to(dtype)
+    zr = (x.float() + y.float()).requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(zr, (H,), gamma.clone().requires_grad_(True), beta, 1e-12)
+    ybuf = y.clone()
+    out, mean, rstd = ops.add_ln_fwd(ybuf, x, gamma, beta, 1e-12)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert (out.float() - ref).abs().max().item() < tol
+    assert (ybuf.float() - zr).abs().max().item() < (1e-6 if dtype == torch.float32 else 2e-2)
+    # backward against autograd on the *stored* z (what the kernel sees)
+    z32 = ybuf.float().requires_grad_(True)
+    g32 = gamma.clone().requires_grad_(True); b32 = beta.clone().requires_grad_(True)
+    r2 = torch.nn.functional.layer_norm(z32, (H,), g32, b32, 1e-12)
+    r2.backward(dy.float())
+    dgamma = torch.zeros(H, device=dev); dbeta = torch.zeros(H, device=dev); dbias = torch.zeros(H, device=dev)
+    dz, dbr = ops.ln_bwd(dy, ybuf, mean, rstd, gamma, dgamma=dgamma, dbeta=dbeta, dbias=dbias)
+    rt = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(dz, z32.grad) < rt
+    assert rel_err(dgamma, g32.grad) < rt
+    assert rel_err(dbeta, b32.grad) < rt
+    # dbias is summed from the unrounded fp32 dz inside the kernel; the stored dz carries one bf16 rounding
+    assert rel_err(dbias, dz.float().sum(0)) < (1e-5 if dtype == torch.float32 else 5e-3)
+
+
+def test_hidden_dropout_consistency(dev):
+    """the dropout mask of add_ln_fwd (seed, element) is the one ln_bwd re-creates; drop rate ~ p; scaling unbiased."""
+    ops = _ops()
+    M, H, p, seed = 512, 768, 0.1, 99
+    y = torch.ones(M, H, device=dev, dtype=torch.float32); x = torch.zeros(M, H, device=dev, dtype=torch.float32)
+    gamma = torch.ones(H, device=dev); beta = torch.zeros(H, device=dev)
+    ybuf = y.clone()
+    out, mean, rstd = ops.add_ln_fwd(ybuf, x, gamma, beta, 1e-12, p=p, seed=seed)
+    keep = (ybuf > 0).float()
+    assert abs(1 - keep.mean().item() - p) < 5e-3
+    assert abs(ybuf.mean().item() - 1.0) < 5e-3
+    dy = torch.randn(M, H, device=dev)
+    dz, dbr = ops.ln_bwd(dy, ybuf, mean, rstd, gamma, p=p, seed=seed)
+    assert torch.allclose(dbr, dz * keep / (1 - p), rtol=1e-5, atol=1e-6)
+    # a different seed gives a different mask
+    yb2 = y.clone(); ops.add_ln_fwd(yb2, x, gamma, beta, 1e-12, p=p, seed=seed + 1)
+    assert ((yb2 > 0).float() != keep).float().mean().item() > 0.05
+
+
+def test_colsum_dropout_cast_transpose(dev):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x = torch.randn(1000, 384, generator=g).to(dev)
+    assert rel_err(ops.colsum(x), x.sum(0)) < 1e-5
+    xb = x.bfloat16()
+    assert rel_err(ops.colsum(xb), xb.float().sum(0)) < 1e-5
+    wide = torch.randn(256, 512, generator=g).to(dev).bfloat16()
+    assert rel_err(ops.colsum(wide[:, 128:256]), wide[:, 128:256].float().sum(0)) < 1e-5
+    assert torch.equal(ops.cast(x, torch.bfloat16), xb)
+    assert torch.equal(ops.cast(xb, torch.float32), xb.float())
+    d = ops.dropout(x, 0.25, 5)
+    kept = d != 0
+    assert abs(1 - kept.float().mean().item() - 0.25) < 1e-2
+    assert torch.allclose(d[kept], x[kept] / 0.75, rtol=1e-5)
+    assert torch.equal(ops.dropout(x, 0.25, 5), d)
+    W = torch.randn(192, 320, generator=g).to(dev)
+    Wb = torch.empty(192, 320, dtype=torch.bfloat16, device=dev); Wt = torch.empty(320, 192, dtype=torch.bfloat16, device=dev)
+    ops.cast_transpose(W, Wb, Wt)
+    assert torch.equal(Wb, W.bfloat16()) and torch.equal(Wt, W.bfloat16().t().contiguous())
+
+
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 2), (torch.bfloat16, 3)])
+def test_rowdot(dev, dtype, C):
+    ops = _ops()
+    M, H = 300, 768
+    g = torch.Generator(device="cpu").manual_seed(6)
+    x = torch.randn(M, H, generator=g).to(dev).to(dtype)
+    W = (0.3 * torch.randn(C, H, generator=g)).to(dev); b = torch.randn(C, generator=g).to(dev)
+    out = ops.rowdot_fwd(x, W, b)
+    ref = x.float() @ W.t() + b
+    assert (out - ref).abs().max().item() < 1e-3
+    dl = torch.randn(M, C, generator=g).to(dev)
+    dW = torch.zeros_like(W); db = torch.zeros_like(b)
+    dx = ops.rowdot_bwd(x, W, dl, dW=dW, db=db)
+    assert rel_err(dx, dl @ W) < (1e-5 if dtype == torch.float32 else 5e-3)
+    assert rel_err(dW, dl.t() @ x.float()) < 1e-5
+    assert rel_err(db, dl.sum(0)) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------------- optimiser
+def test_adamw_matches_torch(dev):
+    ops = _ops()
+    n = 4096 * 3
+    g = torch.Generator(device="cpu").manual_seed(8)
+    p0 = torch.randn(n, generator=g)
+    p = p0.clone().to(dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g)
+        pr.grad = gr.clone(); opt.step()
+        gd = gr.to(dev)
+        ops.adamw(p, gd, m, v, shadow, 5e-3, 0.9, 0.999, 1e-8, 0.01, step, zero_grad=True)
+        assert gd.abs().max().item() == 0
+    assert (p.cpu() - pr.data).abs().max().item() < 2e-6
+    assert torch.equal(shadow, p.bfloat16())
+
+
+def test_gradnorm_clip(dev):
+    ops = _ops()
+    n = 1 << 20
+    x = torch.randn(n, device=dev)
+    out = torch.zeros(1, device=dev); partials = torch.empty(1024, device=dev)
+    ops.sumsq(x, out, partials)
+    assert abs(out.item() - (x.double() ** 2).sum().item()) / n < 1e-5
+    coef = torch.zeros(1, device=dev); norm = torch.zeros(1, device=dev)
+    ops.clip_coef(out, 1.0, 1.0, coef, norm)
+    nr = x.norm().item()
+    assert abs(norm.item() - nr) / nr < 1e-5
+    assert abs(coef.item() - 1.0 / (nr + 1e-6)) / coef.item() < 1e-5
+    y = x.clone(); ops.scale_(y, coef)
+    assert abs(y.norm().item() - 1.0) < 1e-4
