@@ -1,0 +1,316 @@
+"""MI355X-native drop-in for the reference wrapper model
+    emnlp2023-topic_segmentation/src/models/bert_for_ts.py:19-113  BertWithDAForSentenceLabelingTopicSegmentation
+and its heads (modules/loss_calculator.py, modules/cssl.py, modules/tssp.py, modules/utils.py).
+
+Same HuggingFace plug-in surface: a `BertPreTrainedModel` subclass with the reference's class name, parameter names
+(`bert.*`, `loss_calculator.classifier.*`, `loss_calculator.tssp.classifier.*`), `forward(**batch)` argument names and
+`(loss, logits (B,2,L,2), cos_sim (B,k))` return tuple, so `from_pretrained` / `save_pretrained` / `transformers.Trainer`
+work unchanged (ts_sentence_seq_labeling.py:247-257,1077-1094).  Differences, all deliberate:
+  * the encoder never runs torch ops: `self.bert` is only the parameter container; forward/backward go through
+    libamdseg (engine.py).  The anchor and augmented passes are batched into ONE encoder pass of 2B sequences.
+  * the reference's CPU-only in-place-on-leaf bug (`loss += ...`, loss_calculator.py:35,51) is not reproduced.
+  * the host loops of EopPairCosineSimilarity / CSSL run on a host copy of `labels` fetched once, before the encoder
+    kernels are queued, instead of B boolean-mask syncs per step.
+There is no CPU fallback: a missing libamdseg.so or a CPU tensor raises.
+"""
+import random
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from transformers.models.bert.modeling_bert import BertModel, BertPreTrainedModel
+
+from . import lib as L
+from .engine import BertEncoderEngine, EncoderFn, RowDotFn
+
+HEAD_DEFAULTS = dict(do_da_ts=False, do_cssl=False, do_tssp=False, ts_loss_weight=1.0, ts_score_predictor="lt",
+                     ts_score_predictor_cos_temp=1, focal_loss_gamma=0.0, weight_label_zero=0.5, cl_loss_weight=0.0,
+                     cl_temp=1, cl_anchor_level="eop_matrix", cl_positive_k=1, cl_negative_k=1, tssp_loss_weight=0.0,
+                     tssp_ablation="none", num_tssp_labels=3)
+
+
+class _TSSP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.classifier = nn.Linear(config.hidden_size, config.num_tssp_labels)
+
+
+class _LossCalculator(nn.Module):
+    """parameter container with the reference's names (loss_calculator.py:16-19)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.classifier = nn.Linear(config.hidden_size, config.num_labels)
+        self.tssp = _TSSP(config)
+
+
+def _topic_segment_ids(label_rows):
+    ids, seg = [], 0
+    for ex in label_rows:
+        if len(ex) == 0:
+            continue
+        for l in ex:
+            ids.append(seg)
+            if l == 0:
+                seg += 1
+        if ex[-1] == 1:
+            seg += 1
+    return ids
+
+
+def _cos(x, y, temp):
+    if temp == 0:
+        return x.squeeze(1) @ y.squeeze(0).t()
+    return F.cosine_similarity(x, y, dim=-1) / temp
+
+
+class BertWithDAForSentenceLabelingTopicSegmentation(BertPreTrainedModel):
+    _keys_to_ignore_on_load_unexpected = [r"pooler"]
+
+    def __init__(self, config):
+        for k, v in HEAD_DEFAULTS.items():
+            if not hasattr(config, k):
+                setattr(config, k, v)
+        super().__init__(config)
+        self.config = config
+        self.bert = BertModel(config)          # parameter container only (HF names); its torch forward is never called
+        classifier_dropout = config.classifier_dropout if config.classifier_dropout is not None else config.hidden_dropout_prob
+        self.classifier_dropout_p = float(classifier_dropout)
+        self.loss_calculator = _LossCalculator(config)
+        self.post_init()
+        self._engine = None
+        self._step_seed = 0
+        self.amdseg_seed = 0
+
+    # ------------------------------------------------------------------------------------------------ engine plumbing
+    def engine(self):
+        p = next(self.parameters())
+        if not p.is_cuda:
+            raise L.AmdsegError("spokennlp_amd runs on MI355X only: move the model to a cuda device (no CPU fallback)")
+        if self._engine is None or not self._engine.fp.intact() or self._engine.device != p.device:
+            self._engine = BertEncoderEngine(self, self.config, p.device, bert_attr="bert")
+        return self._engine
+
+    def _next_seed(self):
+        self._step_seed += 1
+        return (int(self.amdseg_seed) * 1000003 + self._step_seed) & 0x7FFFFFFF
+
+    def encode(self, input_ids, attention_mask, token_type_ids):
+        """[N, L] int64 -> fp32 [N, L, H] sequence output (after the wrapper's dropout in training)."""
+        eng = self.engine()
+        train = self.training and torch.is_grad_enabled()
+        if train:
+            p0 = next(iter(eng.fp.params.values()))
+            if p0.grad is None or p0.grad.data_ptr() != eng.fp.view(eng.fp.flat_g, next(iter(eng.fp.params))).data_ptr():
+                eng.fp.flat_g.zero_()
+                eng.fp.attach_grads()
+        return EncoderFn.apply(eng._trigger, eng, input_ids, attention_mask, token_type_ids, train, self._next_seed(),
+                               self.classifier_dropout_p)
+
+    # ------------------------------------------------------------------------------------------------ heads
+    def _ts_loss(self, logits, labels):
+        cfg = self.config
+        weight = None
+        if cfg.weight_label_zero != 0.5:
+            weight = torch.tensor([cfg.weight_label_zero, 1 - cfg.weight_label_zero], dtype=torch.float32, device=logits.device)
+        if cfg.focal_loss_gamma != 0:
+            # the reference's FocalLoss ends up with reduction='mean' inside super().forward (modules/utils.py:145-168):
+            # scalar mean CE times the per-row focal factor, averaged over ALL rows (ignored rows use target 0)
+            ce = F.cross_entropy(logits, labels, weight=weight, ignore_index=-100, reduction="mean")
+            tgt = labels * (labels != -100).long()
+            pt = torch.gather(F.softmax(logits, 1), 1, tgt.unsqueeze(1))
+            return torch.mean(torch.pow(1 - pt, cfg.focal_loss_gamma) * ce)
+        return F.cross_entropy(logits, labels, weight=weight, ignore_index=-100)
+
+    @staticmethod
+    def _labelled_rows(labels_cpu):
+        """host-side index lists: per example the positions with label != -100 and their labels."""
+        pos, lab = [], []
+        for row in labels_cpu:
+            idx = (row != -100).nonzero(as_tuple=False).flatten()
+            pos.append(idx); lab.append(row[idx].tolist())
+        return pos, lab
+
+    def _cos_sim(self, seq, pos, temp):
+        """utils.py:111-138: cos(row_i, row_{(i+1)%n}) / temp, padded with -100 to the batch max."""
+        B, Lq, H = seq.shape
+        mx = max((len(p) for p in pos), default=0)
+        out = torch.full((B, mx), -100.0, dtype=seq.dtype, device=seq.device)
+        rows_a, rows_b, dst_b, dst_j = [], [], [], []
+        for b, p in enumerate(pos):
+            n = len(p)
+            if n == 0:
+                continue
+            base = b * Lq
+            a = (p + base).tolist()
+            rows_a += a
+            rows_b += a[1:] + a[:1]
+            dst_b += [b] * n
+            dst_j += list(range(n))
+        if rows_a:
+            flat = seq.reshape(B * Lq, H)
+            ia = torch.tensor(rows_a, device=seq.device); ib = torch.tensor(rows_b, device=seq.device)
+            xa, xb = flat[ia], flat[ib]
+            cs = (xa * xb).sum(-1) if temp == 0 else F.cosine_similarity(xa, xb, dim=-1) / temp
+            out[torch.tensor(dst_b, device=seq.device), torch.tensor(dst_j, device=seq.device)] = cs
+        return out
+
+    def _cssl(self, seq, pos, lab):
+        """cssl.py:230-274 with the degenerate amax pooling replaced by the equivalent row gather."""
+        cfg = self.config
+        B, Lq, H = seq.shape
+        rows = [int(p_) + b * Lq for b, p in enumerate(pos) for p_ in p.tolist()]
+        seg = _topic_segment_ids(lab)
+        zero = seq.new_zeros(())
+        if not (len(seg) > 2 and seg[-1] > 0):
+            return zero
+        feats = seq.reshape(B * Lq, H)[torch.tensor(rows, device=seq.device)]
+        n = len(seg)
+        total_topic = seg[-1] + 1
+        bot = [seg.index(i) for i in range(total_topic)]
+        eot = [v - 1 for v in bot[1:]] + [n - 1]
+        if cfg.cl_anchor_level == "eop_matrix":
+            seg_t = torch.tensor(seg, device=seq.device)
+            same = seg_t[:, None] == seg_t[None, :]
+            num_mask = same & ~torch.eye(n, dtype=torch.bool, device=seq.device)
+            e = torch.exp(_cos(feats.unsqueeze(1), feats.unsqueeze(0), cfg.cl_temp))
+            num = (num_mask * e).sum(0)
+            den = num + ((~same) * e).sum(0)
+            prob = num / den
+            sel = prob != 0
+            if bool(torch.isnan(prob).any()) or int(sel.sum()) == 0:
+                return zero
+            return (-torch.log(prob[sel])).mean()
+        pk, nk = cfg.cl_positive_k, cfg.cl_negative_k
+        pos_i = [[] for _ in range(pk)]
+        neg_i = [[] for _ in range(nk)]
+        if cfg.cl_anchor_level == "eop_list":
+            for idx, t in enumerate(seg):
+                s, e_ = bot[t], eot[t]
+                choice = list(range(s, e_)) or [e_]
+                pid = idx
+                for i in range(pk):
+                    pid -= 1
+                    if pid < s:
+                        pid = random.choice(choice)
+                    pos_i[i].append(pid)
+                choice = list(range(e_ + 1, eot[-1] + 1)) or list(range(bot[0], bot[1]))
+                pid = e_
+                for i in range(nk):
+                    pid += 1
+                    if pid >= n:
+                        pid = random.choice(choice)
+                    neg_i[i].append(pid)
+            anchors = feats
+        elif cfg.cl_anchor_level == "eot_list":
+            for s, e_ in zip(bot, eot):
+                choice = list(range(s, e_)) or [e_]
+                pid = e_
+                for i in range(pk):
+                    pid -= 1
+                    if pid < s:
+                        pid = random.choice(choice)
+                    pos_i[i].append(pid)
+            for e_ in eot:
+                choice = list(range(e_ + 1, eot[-1] + 1)) or list(range(bot[0], bot[1]))
+                pid = e_
+                for i in range(nk):
+                    pid += 1
+                    if pid >= n:
+                        pid = random.choice(choice)
+                    neg_i[i].append(pid)
+            anchors = feats[torch.tensor(eot, device=seq.device)]
+        else:
+            raise ValueError("not supported cl_anchor_level %s " % cfg.cl_anchor_level)
+        sims = [_cos(anchors, feats[torch.tensor(ix, device=seq.device)], cfg.cl_temp).unsqueeze(0) for ix in pos_i + neg_i]
+        e = torch.exp(torch.cat(sims))
+        return (-torch.log(e[:pk].sum(0) / e.sum(0))).mean()
+
+    def _tssp(self, da_seq, sent_token_mask, sent_pair_orders):
+        """tssp.py:16-36 (returns w * CE; the caller multiplies by w again, loss_calculator.py:71)."""
+        cfg = self.config
+        feats = da_seq[sent_token_mask != -100]
+        tl = sent_pair_orders[sent_pair_orders != -100]
+        logits = F.linear(feats, self.loss_calculator.tssp.classifier.weight, self.loss_calculator.tssp.classifier.bias)
+        return cfg.tssp_loss_weight * F.cross_entropy(logits.reshape(-1, cfg.num_tssp_labels), tl.reshape(-1))
+
+    def _loss_calculator(self, seq, labels, labels_cpu, sent_token_mask=None, sent_pair_orders=None, da_example_flag=False,
+                         need_cos=True):
+        cfg = self.config
+        pos, lab = self._labelled_rows(labels_cpu)
+        cos = self._cos_sim(seq, pos, cfg.ts_score_predictor_cos_temp) if need_cos else None
+        if cfg.ts_score_predictor == "lt":
+            clf = self.loss_calculator.classifier
+            logits = RowDotFn.apply(seq, clf.weight, clf.bias)
+            ts = self._ts_loss(logits.reshape(-1, cfg.num_labels), labels.reshape(-1))
+        elif cfg.ts_score_predictor == "cos":
+            cos_labels = torch.full(cos.shape, -100, dtype=torch.long)
+            for b, l_ in enumerate(lab):
+                cos_labels[b, :len(l_)] = torch.tensor(l_, dtype=torch.long)
+            ts = F.binary_cross_entropy_with_logits(cos.reshape(-1), cos_labels.to(cos.device).reshape(-1).float())
+            logits = torch.sigmoid(cos)
+        else:
+            raise ValueError("not supported ts_score_predictor %s" % cfg.ts_score_predictor)
+        loss = cfg.ts_loss_weight * ts
+        if not da_example_flag and cfg.cl_loss_weight != 0:
+            loss = loss + cfg.cl_loss_weight * self._cssl(seq, pos, lab)
+        if da_example_flag and cfg.tssp_loss_weight != 0:
+            loss = loss + cfg.tssp_loss_weight * self._tssp(seq, sent_token_mask, sent_pair_orders)
+        return loss, logits, cos
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(
+        self,
+        input_ids,
+        attention_mask=None,
+        head_mask=None,
+        token_type_ids=None,
+        position_ids=None,
+        inputs_embeds=None,
+        labels=None,
+        output_attentions=None,
+        output_hidden_states=None,
+        return_dict=False,
+        sent_level_labels=None,
+        extract_eop_segment_ids=None,
+        eop_index_for_aggregate_batch_eop_features=None,
+        sent_pair_orders=None,
+        sent_token_mask=None,
+    ):
+        if head_mask is not None or position_ids is not None or inputs_embeds is not None:
+            raise L.AmdsegError("head_mask / position_ids / inputs_embeds are not supported by the HIP encoder path")
+        if output_attentions or output_hidden_states:
+            raise L.AmdsegError("attention maps / hidden states are never materialised by the fused HIP path")
+        cfg = self.config
+        B, two, Lq = input_ids.shape
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        labels_cpu = labels.cpu() if labels is not None else None        # the one host fetch, before any kernel is queued
+        two_pass = bool(cfg.do_da_ts or cfg.do_tssp)
+        if two_pass:   # anchor + augmented sequences in one encoder pass of 2B sequences
+            ids = torch.cat((input_ids[:, 0], input_ids[:, 1])); am = torch.cat((attention_mask[:, 0], attention_mask[:, 1]))
+            tt = torch.cat((token_type_ids[:, 0], token_type_ids[:, 1]))
+        else:
+            ids, am, tt = input_ids[:, 0].contiguous(), attention_mask[:, 0].contiguous(), token_type_ids[:, 0].contiguous()
+        seq = self.encode(ids, am, tt)
+        a_seq = seq[:B]
+        logits, cos = None, None
+        loss = None
+        if labels is not None:
+            need_cos = (not (self.training and torch.is_grad_enabled())) or cfg.ts_score_predictor == "cos"
+            a_loss, a_logits, cos = self._loss_calculator(a_seq, labels[:, 0], labels_cpu[:, 0], need_cos=need_cos)
+            loss = a_loss
+            logits = torch.cat((a_logits.unsqueeze(1), a_logits.unsqueeze(1)), dim=1)
+            if two_pass:
+                d_loss, d_logits, _ = self._loss_calculator(seq[B:], labels[:, 1], labels_cpu[:, 1],
+                                                            sent_token_mask=sent_token_mask[:, 1],
+                                                            sent_pair_orders=sent_pair_orders[:, 1], da_example_flag=True,
+                                                            need_cos=cfg.ts_score_predictor == "cos")
+                loss = loss + d_loss
+                logits = torch.cat((a_logits.unsqueeze(1), d_logits.unsqueeze(1)), dim=1)
+            if cos is None:
+                cos = torch.full((B, 1), -100.0, device=seq.device)
+        output = (logits, cos)
+        return ((loss,) + output) if loss is not None else output

@@ -1,0 +1,334 @@
+"""Host-side engine of the MI355X BERT encoder: flat parameter storage, bf16 compute shadows, activation arenas, and
+the forward / backward drivers that call libamdseg through the C ABI.  PyTorch tensors are storage + autograd glue.
+
+Memory layout in HBM (one process per GPU):
+  flat_p / flat_g / adam m, v : fp32 [n_params]      every nn.Parameter of the HF module tree is a VIEW into flat_p (and
+                                                     its .grad a view into flat_g); q,k,v weights (and biases) of a layer
+                                                     are adjacent, so the fused QKV projection reads one [3H,H] block
+  shadow                      : bf16 [n_params]      compute copy of the encoder matrices (same layout), written by AdamW
+  shadow_t (per layer)        : bf16 W^T blocks      for the dgrad GEMMs (refreshed after each optimiser step)
+  activations                 : bf16 [layers][...]   saved-for-backward tensors (~25 KB/token/layer), one arena per M
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import lib as L
+from . import ops
+
+LAYER_ORDER = ["attention.self.query.weight", "attention.self.key.weight", "attention.self.value.weight",
+               "attention.self.query.bias", "attention.self.key.bias", "attention.self.value.bias",
+               "attention.output.dense.weight", "attention.output.dense.bias",
+               "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
+               "intermediate.dense.weight", "intermediate.dense.bias",
+               "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias"]
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class FlatParams:
+    """Re-homes the parameters of a module tree into one flat fp32 buffer (+ a flat gradient buffer)."""
+
+    def __init__(self, module, device, encoder_prefix="bert.encoder.layer."):
+        named = OrderedDict(module.named_parameters())
+        order = []
+        nlayers = 0
+        while f"{encoder_prefix}{nlayers}.{LAYER_ORDER[0]}" in named:
+            nlayers += 1
+        enc_names = set()
+        for i in range(nlayers):
+            for suffix in LAYER_ORDER:
+                n = f"{encoder_prefix}{i}.{suffix}"
+                order.append(n); enc_names.add(n)
+        rest = [n for n in named if n not in enc_names]
+        order = rest + order
+        self.offsets, off = OrderedDict(), 0
+        for n in order:
+            self.offsets[n] = off
+            off = _align(off + named[n].numel())
+        self.numel = off
+        self.nlayers = nlayers
+        self.encoder_prefix = encoder_prefix
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
+        self.params = named
+        with torch.no_grad():
+            for n, p in named.items():
+                v = self.view(self.flat_p, n, p.shape)
+                v.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = v
+        self.attach_grads()
+
+    def view(self, flat, name, shape=None):
+        shape = self.params[name].shape if shape is None else shape
+        n = 1
+        for s in shape:
+            n *= s
+        o = self.offsets[name]
+        return flat[o:o + n].view(shape)
+
+    def attach_grads(self):
+        for n, p in self.params.items():
+            p.grad = self.view(self.flat_g, n)
+
+    def intact(self):
+        """parameters still alias the flat buffer (False after model.to(...) / external re-materialisation)."""
+        n = next(iter(self.params))
+        p = self.params[n]
+        return p.data_ptr() == self.flat_p.data_ptr() + 4 * self.offsets[n] and p.device == self.flat_p.device
+
+    def lp(self, i, suffix):
+        return f"{self.encoder_prefix}{i}.{suffix}"
+
+
+class BertEncoderEngine:
+    """Runs embeddings + N BertLayers (+ final dropout) forward and backward on libamdseg kernels."""
+
+    def __init__(self, module, config, device, bert_attr="bert"):
+        L.load()      # fail loudly right away if the HIP library is absent
+        self.cfg = config
+        self.device = device
+        self.H, self.I, self.heads = config.hidden_size, config.intermediate_size, config.num_attention_heads
+        if self.H != self.heads * 64:
+            raise L.AmdsegError("libamdseg attention kernels need head_dim == 64")
+        self.prefix = bert_attr + "."
+        self.fp = FlatParams(module, device, encoder_prefix=self.prefix + "encoder.layer.")
+        self.nlayers = self.fp.nlayers
+        self.shadow = torch.zeros(self.fp.numel, dtype=torch.bfloat16, device=device)
+        H, I = self.H, self.I
+        self.shadow_t = [dict(wqkv_t=torch.empty(H, 3 * H, dtype=torch.bfloat16, device=device),
+                              wo_t=torch.empty(H, H, dtype=torch.bfloat16, device=device),
+                              w1_t=torch.empty(H, I, dtype=torch.bfloat16, device=device),
+                              w2_t=torch.empty(I, H, dtype=torch.bfloat16, device=device)) for _ in range(self.nlayers)]
+        self._shadow_version = -1
+        self._arenas = {}
+        self._trigger = torch.zeros(1, device=device, requires_grad=True)
+        self.adam_m = None
+        self.adam_v = None
+        self.opt_step = 0
+        self._scratch = dict(sumsq=torch.zeros(1, device=device), coef=torch.ones(1, device=device),
+                             norm=torch.zeros(1, device=device), partials=torch.empty(2048, device=device))
+        self._build_param_structs()
+
+    # ------------------------------------------------------------------------------------------------ parameters
+    def _p(self, flat, i, suffix):
+        return self.fp.view(flat, self.fp.lp(i, suffix))
+
+    def _build_param_structs(self):
+        self.lparams, self.lgrads = [], []
+        fp = self.fp
+        for i in range(self.nlayers):
+            sh = lambda s: self._p(self.shadow, i, s).data_ptr()          # noqa: E731
+            ps = lambda s: self._p(fp.flat_p, i, s).data_ptr()            # noqa: E731
+            gs = lambda s: self._p(fp.flat_g, i, s).data_ptr()            # noqa: E731
+            t = self.shadow_t[i]
+            P = L.LayerParams(wqkv=sh("attention.self.query.weight"), wo=sh("attention.output.dense.weight"),
+                              w1=sh("intermediate.dense.weight"), w2=sh("output.dense.weight"),
+                              wqkv_t=t["wqkv_t"].data_ptr(), wo_t=t["wo_t"].data_ptr(), w1_t=t["w1_t"].data_ptr(),
+                              w2_t=t["w2_t"].data_ptr(),
+                              bqkv=ps("attention.self.query.bias"), bo=ps("attention.output.dense.bias"),
+                              b1=ps("intermediate.dense.bias"), b2=ps("output.dense.bias"),
+                              ln1_g=ps("attention.output.LayerNorm.weight"), ln1_b=ps("attention.output.LayerNorm.bias"),
+                              ln2_g=ps("output.LayerNorm.weight"), ln2_b=ps("output.LayerNorm.bias"))
+            G = L.LayerGrads(wqkv=gs("attention.self.query.weight"), wo=gs("attention.output.dense.weight"),
+                             w1=gs("intermediate.dense.weight"), w2=gs("output.dense.weight"),
+                             bqkv=gs("attention.self.query.bias"), bo=gs("attention.output.dense.bias"),
+                             b1=gs("intermediate.dense.bias"), b2=gs("output.dense.bias"),
+                             ln1_g=gs("attention.output.LayerNorm.weight"), ln1_b=gs("attention.output.LayerNorm.bias"),
+                             ln2_g=gs("output.LayerNorm.weight"), ln2_b=gs("output.LayerNorm.bias"))
+            self.lparams.append(P); self.lgrads.append(G)
+
+    def refresh_shadows(self, force=False):
+        """bf16 compute copies of the encoder matrices (+ transposes); re-done whenever flat_p was written."""
+        ver = self.fp.flat_p._version
+        if not force and ver == self._shadow_version:
+            return
+        H, I = self.H, self.I
+        for i in range(self.nlayers):
+            t = self.shadow_t[i]
+            wq = self.fp.view(self.fp.flat_p, self.fp.lp(i, "attention.self.query.weight"), (3 * H, H))
+            ops.cast_transpose(wq, self.fp.view(self.shadow, self.fp.lp(i, "attention.self.query.weight"), (3 * H, H)), t["wqkv_t"])
+            for s, key in (("attention.output.dense.weight", "wo_t"), ("intermediate.dense.weight", "w1_t"),
+                           ("output.dense.weight", "w2_t")):
+                ops.cast_transpose(self._p(self.fp.flat_p, i, s), self._p(self.shadow, i, s), t[key])
+        self._shadow_version = self.fp.flat_p._version
+
+    # ------------------------------------------------------------------------------------------------ arenas
+    def _arena(self, B, Lseq, train):
+        key = (B, Lseq, train)
+        if key in self._arenas:
+            return self._arenas[key]
+        dev, H, I, M = self.device, self.H, self.I, B * Lseq
+        bf = torch.bfloat16
+        nsave = self.nlayers if train else 1
+
+        def e(*s, dt=bf):
+            return torch.empty(*s, dtype=dt, device=dev)
+
+        A = dict(x=[e(M, H) for _ in range(nsave + 1)] if train else [e(M, H), e(M, H)],
+                 layers=[dict(qkv=e(M, 3 * H), ctx=e(M, H), z1=e(M, H), x1=e(M, H), u=e(M, I), h=e(M, I), z2=e(M, H),
+                              lse=e(B * self.heads * Lseq, dt=torch.float32), mean1=e(M, dt=torch.float32),
+                              rstd1=e(M, dt=torch.float32), mean2=e(M, dt=torch.float32), rstd2=e(M, dt=torch.float32))
+                         for _ in range(nsave)],
+                 emb_z=e(M, H), emb_mean=e(M, dt=torch.float32), emb_rstd=e(M, dt=torch.float32),
+                 mask_bias=e(B, Lseq, dt=torch.float32), out=e(M, H, dt=torch.float32))
+        if train:
+            npart = max(3 * ((M + 31) // 32) * H, ((M + 127) // 128) * max(I, 3 * H))
+            A["ws"] = dict(dz2=e(M, H), dbr2=e(M, H), du=e(M, I), dx1=e(M, H), dz1=e(M, H), dbr1=e(M, H), dctx=e(M, H),
+                           dqkv=e(M, 3 * H), delta=e(B * self.heads * Lseq, dt=torch.float32),
+                           partials=e(npart, dt=torch.float32), dy=[e(M, H), e(M, H)])
+            w = A["ws"]
+            A["ws_struct"] = L.LayerWs(**{k: w[k].data_ptr() for k in ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx",
+                                                                       "dqkv", "delta", "partials")})
+        A["acts_struct"] = []
+        for i in range(self.nlayers):
+            la = A["layers"][i if train else 0]
+            xin = A["x"][i] if train else A["x"][i % 2]
+            xout = A["x"][i + 1] if train else A["x"][(i + 1) % 2]
+            A["acts_struct"].append(L.LayerActs(x_in=xin.data_ptr(), x_out=xout.data_ptr(),
+                                                **{k: la[k].data_ptr() for k in ("qkv", "ctx", "z1", "x1", "u", "h", "z2", "lse",
+                                                                                 "mean1", "rstd1", "mean2", "rstd2")}))
+        A["x_final"] = A["x"][self.nlayers] if train else A["x"][self.nlayers % 2]
+        self._arenas[key] = A
+        return A
+
+    def _cfg_struct(self, B, Lseq, p_hidden, p_attn, seed, accumulate):
+        return L.BertCfg(B=B, L=Lseq, H=self.H, heads=self.heads, I=self.I, ln_eps=float(self.cfg.layer_norm_eps),
+                         p_hidden=p_hidden, p_attn=p_attn, seed=seed, accumulate_grads=1 if accumulate else 0, dtype=L.BF16)
+
+    # ------------------------------------------------------------------------------------------------ forward / backward
+    def _emb(self, name):
+        return self.fp.params[self.prefix + "embeddings." + name]
+
+    def forward(self, input_ids, attention_mask, token_type_ids, train, seed=0, p_out=0.0):
+        """input_ids/attention_mask/token_type_ids: int64 [B, L] on device.  Returns fp32 [B, L, H] (after the wrapper's
+        classifier dropout p_out when training) and a context for backward."""
+        B, Lseq = input_ids.shape
+        M = B * Lseq
+        if (M % 128) or (Lseq % 64):
+            raise L.AmdsegError(f"batch*seq must be a multiple of 128 and seq a multiple of 64 (got B={B}, L={Lseq})")
+        self.refresh_shadows()
+        A = self._arena(B, Lseq, train)
+        p_h = float(self.cfg.hidden_dropout_prob) if train else 0.0
+        p_a = float(self.cfg.attention_probs_dropout_prob) if train else 0.0
+        cfg = self._cfg_struct(B, Lseq, p_h, p_a, seed, True)
+        ids = input_ids.reshape(-1).contiguous()
+        tts = token_type_ids.reshape(-1).contiguous()
+        torch.mul(1.0 - attention_mask.to(torch.float32), -1e30, out=A["mask_bias"])
+        lib = L.load()
+        s = torch.cuda.current_stream().cuda_stream
+        eps = float(self.cfg.layer_norm_eps)
+        we, pe, te = self._emb("word_embeddings.weight"), self._emb("position_embeddings.weight"), self._emb("token_type_embeddings.weight")
+        rc = lib.amdseg_embed_ln_fwd(ids.data_ptr(), tts.data_ptr(), None, we.data_ptr(), pe.data_ptr(), te.data_ptr(),
+                                     self._emb("LayerNorm.weight").data_ptr(), self._emb("LayerNorm.bias").data_ptr(),
+                                     A["emb_z"].data_ptr(), A["x"][0].data_ptr(), A["emb_mean"].data_ptr(), A["emb_rstd"].data_ptr(),
+                                     M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], eps, p_h, seed * 1000003 + 17, L.BF16, s)
+        L.check(rc, "amdseg_embed_ln_fwd")
+        mb = A["mask_bias"].data_ptr()
+        for i in range(self.nlayers):
+            rc = lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(self.lparams[i]), C.byref(A["acts_struct"][i]), mb, i, s)
+            L.check(rc, f"amdseg_bert_layer_fwd[{i}]")
+        rc = lib.amdseg_dropout(A["x_final"].data_ptr(), A["out"].data_ptr(), M * self.H, p_out if train else 0.0,
+                                seed * 1000003 + 29, L.BF16, L.F32, s)
+        L.check(rc, "amdseg_dropout")
+        ctx = dict(B=B, L=Lseq, ids=ids, tts=tts, seed=seed, p_h=p_h, p_a=p_a, p_out=p_out if train else 0.0)
+        return A["out"].view(B, Lseq, self.H), ctx
+
+    def backward(self, ctx, dseq, accumulate=True):
+        """dseq: fp32 [B, L, H] gradient of the encoder output.  Writes every parameter gradient into flat_g."""
+        B, Lseq = ctx["B"], ctx["L"]
+        M = B * Lseq
+        A = self._arena(B, Lseq, True)
+        ws = A["ws"]
+        lib = L.load()
+        s = torch.cuda.current_stream().cuda_stream
+        cfg = self._cfg_struct(B, Lseq, ctx["p_h"], ctx["p_a"], ctx["seed"], accumulate)
+        dseq = dseq.contiguous()
+        dy, other = ws["dy"]
+        rc = lib.amdseg_dropout(dseq.data_ptr(), dy.data_ptr(), M * self.H, ctx["p_out"], ctx["seed"] * 1000003 + 29, L.F32, L.BF16, s)
+        L.check(rc, "amdseg_dropout(bwd)")
+        mb = A["mask_bias"].data_ptr()
+        for i in reversed(range(self.nlayers)):
+            rc = lib.amdseg_bert_layer_bwd(C.byref(cfg), C.byref(self.lparams[i]), C.byref(self.lgrads[i]),
+                                           C.byref(A["acts_struct"][i]), C.byref(A["ws_struct"]), mb, dy.data_ptr(), other.data_ptr(), i, s)
+            L.check(rc, f"amdseg_bert_layer_bwd[{i}]")
+            dy, other = other, dy
+        # embeddings: out = dropout(LN(z)); grads of LN affine + the three tables
+        if ctx["p_h"] > 0:
+            rc = lib.amdseg_dropout(dy.data_ptr(), other.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, L.BF16, L.BF16, s)
+            L.check(rc, "amdseg_dropout(emb bwd)")
+            dy, other = other, dy
+        g = lambda n: self.fp.view(self.fp.flat_g, self.prefix + "embeddings." + n)        # noqa: E731
+        rc = lib.amdseg_ln_bwd(dy.data_ptr(), A["emb_z"].data_ptr(), A["emb_mean"].data_ptr(), A["emb_rstd"].data_ptr(),
+                               self._emb("LayerNorm.weight").data_ptr(), other.data_ptr(), None, ws["partials"].data_ptr(),
+                               g("LayerNorm.weight").data_ptr(), g("LayerNorm.bias").data_ptr(), None, M, self.H, 0.0, 0,
+                               1 if accumulate else 0, L.BF16, s)
+        L.check(rc, "amdseg_ln_bwd(emb)")
+        we, pe, te = g("word_embeddings.weight"), g("position_embeddings.weight"), g("token_type_embeddings.weight")
+        if not accumulate:
+            we.zero_(); pe.zero_(); te.zero_()
+        pad = self.cfg.pad_token_id if getattr(self.cfg, "pad_token_id", None) is not None else -1
+        rc = lib.amdseg_embed_bwd(other.data_ptr(), ctx["ids"].data_ptr(), ctx["tts"].data_ptr(), None, we.data_ptr(), pe.data_ptr(),
+                                  te.data_ptr(), M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], pad, L.BF16, s)
+        L.check(rc, "amdseg_embed_bwd")
+
+    # ------------------------------------------------------------------------------------------------ optimiser
+    def zero_grad(self):
+        self.fp.flat_g.zero_()
+
+    def grad_norm_and_clip_coef(self, max_norm, extra_scale=1.0):
+        sc = self._scratch
+        ops.sumsq(self.fp.flat_g, sc["sumsq"], sc["partials"])
+        ops.clip_coef(sc["sumsq"], max_norm, extra_scale, sc["coef"], sc["norm"])
+        return sc["norm"], sc["coef"]
+
+    def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, grad_scale=1.0,
+                   zero_grad=True):
+        """clip_grad_norm_(max_grad_norm) + torch.optim.AdamW step over the flat buffers, fused; refreshes the bf16 shadows."""
+        if self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.fp.flat_p)
+            self.adam_v = torch.zeros_like(self.fp.flat_p)
+        self.opt_step += 1
+        _, coef = self.grad_norm_and_clip_coef(max_grad_norm, grad_scale)
+        ops.adamw(self.fp.flat_p, self.fp.flat_g, self.adam_m, self.adam_v, None, lr, betas[0], betas[1], eps, weight_decay,
+                  self.opt_step, gscale=coef, zero_grad=zero_grad)
+        self.refresh_shadows(force=True)
+
+
+class EncoderFn(torch.autograd.Function):
+    """autograd glue: forward/backward of the whole encoder run in HIP; parameter grads are written straight into
+    the flat gradient buffer (param.grad views), so autograd only carries the activation gradient."""
+
+    @staticmethod
+    def forward(ctx, trigger, engine, input_ids, attention_mask, token_type_ids, train, seed, p_out):
+        out, ectx = engine.forward(input_ids, attention_mask, token_type_ids, train, seed, p_out)
+        ctx.engine, ctx.ectx = engine, ectx
+        return out
+
+    @staticmethod
+    def backward(ctx, dseq):
+        ctx.engine.backward(ctx.ectx, dseq, accumulate=True)
+        return (torch.zeros(1, device=dseq.device),) + (None,) * 7
+
+
+class RowDotFn(torch.autograd.Function):
+    """small-C linear head (classifier H->2 over every token) on the HIP rowdot kernels."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        M = x.numel() // x.shape[-1]
+        x2 = x.reshape(M, x.shape[-1])
+        ctx.save_for_backward(x2, W)
+        ctx.shape = x.shape
+        return ops.rowdot_fwd(x2, W, b).view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dl):
+        x2, W = ctx.saved_tensors
+        dl2 = dl.reshape(-1, W.shape[0]).contiguous().float()
+        dW = torch.empty_like(W); db = torch.empty(W.shape[0], dtype=torch.float32, device=W.device)
+        dx = ops.rowdot_bwd(x2, W, dl2, dW=dW, db=db, need_dx=True)
+        return dx.view(ctx.shape), dW, db

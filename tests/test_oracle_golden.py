@@ -1,0 +1,111 @@
+"""Pins the CPU oracle (oracle/bert_ts_oracle.py) against golden vectors produced by the reference itself
+(tools/gen_golden.py imported /root/reference in the build container; only data travelled).  CPU-only."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import bert_ts_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    batch = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in.")}
+    arch = dict(zip(z["arch_keys"].tolist(), [int(v) for v in z["arch_vals"].tolist()]))
+    return z, sd, batch, arch
+
+
+def flags_of(z, v):
+    out = {}
+    for k, s in zip(z[f"{v}.flags_keys"].tolist(), z[f"{v}.flags_vals"].tolist()):
+        if s in ("True", "False"):
+            out[k] = s == "True"
+        else:
+            try:
+                out[k] = int(s)
+            except ValueError:
+                try:
+                    out[k] = float(s)
+                except ValueError:
+                    out[k] = s
+    return out
+
+
+def cfg_for(arch, flags):
+    return O.make_cfg(num_labels=2, **arch, **flags)
+
+
+@pytest.mark.parametrize("case", ["tiny_L64", "tiny_L128"])
+@pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
+def test_eval_forward_matches_reference(case, variant):
+    z, sd, batch, arch = load_case(case)
+    cfg = cfg_for(arch, flags_of(z, variant))
+    random.seed(int(z[f"{variant}.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos, hs = O.model_forward(sd, cfg, batch, return_hidden=True)
+    assert abs(loss.item() - float(z[f"{variant}.loss"])) < 2e-5
+    assert np.abs(logits.numpy() - z[f"{variant}.logits"]).max() < 2e-5
+    assert np.abs(cos.numpy() - z[f"{variant}.cos"]).max() < 2e-6
+    if variant == "plain_eval":
+        for i, h in enumerate(hs):
+            assert np.abs(h.numpy() - z[f"plain_eval.hidden{i}"]).max() < 2e-5, i
+    # decoded boundaries identical (argmax at labelled positions)
+    ref_pred = O.decode_predictions(torch.from_numpy(z[f"{variant}.logits"])[:, 0], batch["labels"][:, 0])
+    assert O.decode_predictions(logits[:, 0], batch["labels"][:, 0]) == ref_pred
+
+
+TRAIN = ["train_full", "train_eop_matrix", "train_eot_list", "train_focal", "train_wce"]
+
+
+@pytest.mark.parametrize("variant", TRAIN)
+def test_train_loss_and_grads_match_reference(variant):
+    z, sd, batch, arch = load_case("tiny_L64")
+    cfg = cfg_for(arch, flags_of(z, variant))
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    random.seed(int(z[f"{variant}.random_seed"]))
+    loss, logits, cos = O.model_forward(sd, cfg, batch)
+    loss.backward()
+    assert abs(loss.item() - float(z[f"{variant}.loss"])) < 3e-5
+    names = z[f"{variant}.gradnorm_names"].tolist()
+    vals = z[f"{variant}.gradnorm_vals"].tolist()
+    for n, gv in zip(names, vals):
+        g = sd[n].grad
+        if gv < 0:       # the reference gives no grad at all (bert.pooler.*, unused heads)
+            assert g is None or float(g.norm()) == 0.0, n
+            continue
+        mine = 0.0 if g is None else float(g.norm())
+        assert abs(mine - gv) <= 2e-4 * max(1.0, gv), (n, mine, gv)
+    if variant == "train_full":
+        for k in z.files:
+            if k.startswith("train_full.grad."):
+                n = k[len("train_full.grad."):]
+                assert np.abs(sd[n].grad.numpy() - z[k]).max() < 5e-5, n
+
+
+def test_train_full_L128():
+    z, sd, batch, arch = load_case("tiny_L128")
+    cfg = cfg_for(arch, flags_of(z, "train_full"))
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    random.seed(int(z["train_full.random_seed"]))
+    loss, _, _ = O.model_forward(sd, cfg, batch)
+    assert abs(loss.item() - float(z["train_full.loss"])) < 3e-5
+
+
+def test_amax_pooling_is_a_row_gather():
+    """extract_eop_segment_ids marks exactly one token per id, so scatter_reduce(amax) == gather."""
+    z, sd, batch, arch = load_case("tiny_L64")
+    seq = torch.randn(2, 64, 16)
+    ids = batch["extract_eop_segment_ids"][:, 0]
+    pooled = torch.zeros_like(seq).scatter_reduce(1, ids[:, :, None].expand_as(seq), seq, reduce="amax", include_self=False)
+    lab = batch["labels"][:, 0]
+    for b in range(2):
+        rows = seq[b][lab[b] != -100]
+        assert torch.equal(pooled[b, 1:1 + rows.shape[0]], rows)

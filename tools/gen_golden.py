@@ -1,0 +1,139 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference (never copying it).
+
+Runs only in the build container, where /root/reference exists; the fixtures (inputs + expected outputs, data only)
+travel with the repo, the reference does not.  Recipe = SURVEY.md Appendix A-1 / A-4:
+  * sys.path -> /root/reference/emnlp2023-topic_segmentation/src, import models.bert_for_ts
+  * custom config flags set by hand (the driver does it at ts_sentence_seq_labeling.py:196-197)
+  * train mode needs the harness-side `torch` proxy (the reference's `loss += ...` on a CPU leaf raises otherwise)
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/emnlp2023-topic_segmentation/src"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+from transformers import BertConfig  # noqa: E402
+import models.bert_for_ts as ref_bt  # noqa: E402
+import models.modules.loss_calculator as ref_lc  # noqa: E402
+from spokennlp_amd import data  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+class TorchProxy:
+    """what `.to('cuda')` yields in the reference environment: a non-leaf copy of the zero loss."""
+
+    def __getattr__(self, k):
+        return getattr(torch, k)
+
+    def tensor(self, *a, **kw):
+        t = torch.tensor(*a, **kw)
+        return t.clone() if t.requires_grad else t
+
+
+ref_bt.torch = TorchProxy()
+ref_lc.torch = TorchProxy()
+
+FULL = dict(do_da_ts=True, do_cssl=True, do_tssp=True, ts_loss_weight=1.0, ts_score_predictor="lt", ts_score_predictor_cos_temp=1,
+            focal_loss_gamma=0.0, weight_label_zero=0.5, cl_loss_weight=0.5, cl_temp=0.1, cl_anchor_level="eop_list",
+            cl_positive_k=1, cl_negative_k=3, tssp_loss_weight=1.0, tssp_ablation="none", num_tssp_labels=3)
+PLAIN = dict(do_da_ts=False, do_cssl=False, do_tssp=False, ts_loss_weight=1.0, ts_score_predictor="lt", ts_score_predictor_cos_temp=1,
+             focal_loss_gamma=0.0, weight_label_zero=0.5, cl_loss_weight=0.0, cl_temp=1, cl_anchor_level="eop_matrix",
+             cl_positive_k=1, cl_negative_k=1, tssp_loss_weight=0.0, tssp_ablation="none", num_tssp_labels=3)
+
+
+def make_model(arch, flags, seed):
+    cfg = BertConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **arch)
+    for k, v in flags.items():
+        setattr(cfg, k, v)
+    torch.manual_seed(seed)
+    m = ref_bt.BertWithDAForSentenceLabelingTopicSegmentation(cfg)
+    with torch.no_grad():       # O(1) logits so that parity is meaningful
+        m.loss_calculator.classifier.weight.normal_(0, 0.3)
+        m.loss_calculator.tssp.classifier.weight.normal_(0, 0.3)
+        for n, p in m.named_parameters():
+            if "LayerNorm.weight" in n:
+                p.add_(0.1 * torch.randn_like(p))
+            if n.endswith("bias"):
+                p.add_(0.05 * torch.randn_like(p))
+    return m, cfg
+
+
+def run_case(name, arch, L, B, seed, variants):
+    docs = data.synth_docs(8, seed=seed + 11, vocab=arch["vocab_size"], mean_sents=14, sd_sents=5, mean_boundaries=3,
+                           mu_tok=1.4 + 0.2 * (L > 64), sigma_tok=0.4)
+    batch = data.batches_from_docs(docs, L, B, seed=seed)[0]
+    out = {"arch_keys": np.array(list(arch.keys())), "arch_vals": np.array(list(arch.values())), "L": L, "B": B}
+    for k, v in batch.items():
+        out["in." + k] = v.numpy()
+    saved_sd = False
+    for vname, flags, mode, rseed, ts_over in variants:
+        fl = dict(flags); fl.update(ts_over)
+        m, cfg = make_model(arch, fl, seed)
+        if not saved_sd:
+            for k, v in m.state_dict().items():
+                if "position_ids" in k or "token_type_ids" in k.split(".")[-1]:
+                    continue
+                out["sd." + k] = v.numpy().copy()
+            saved_sd = True
+        random.seed(rseed)
+        if mode == "eval":
+            m.eval()
+            with torch.no_grad():
+                res = m(**batch, output_hidden_states=True)
+            loss, logits, cos = res[0], res[1], res[2]
+            out[f"{vname}.loss"] = loss.numpy(); out[f"{vname}.logits"] = logits.numpy(); out[f"{vname}.cos"] = cos.numpy()
+            if len(res) > 3 and vname == "plain_eval":
+                for i, h in enumerate(res[3]):
+                    out[f"{vname}.hidden{i}"] = h.numpy()
+        else:
+            m.train()
+            loss, logits, cos = m(**batch)[:3]
+            loss.backward()
+            out[f"{vname}.loss"] = loss.detach().numpy(); out[f"{vname}.logits"] = logits.detach().numpy()
+            gn = {}
+            for n, p in m.named_parameters():
+                if p.grad is None:
+                    gn[n] = -1.0
+                    continue
+                gn[n] = float(p.grad.norm())
+                if vname.endswith("full"):
+                    out[f"{vname}.grad.{n}"] = p.grad.numpy().copy()
+            out[f"{vname}.gradnorm_names"] = np.array(list(gn.keys()))
+            out[f"{vname}.gradnorm_vals"] = np.array(list(gn.values()), dtype=np.float64)
+        out[f"{vname}.flags_keys"] = np.array(list(fl.keys())); out[f"{vname}.flags_vals"] = np.array([str(v) for v in fl.values()])
+        out[f"{vname}.random_seed"] = rseed
+        print(name, vname, "loss", float(loss))
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def main():
+    arch = dict(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                max_position_embeddings=128, type_vocab_size=2)
+    variants = [
+        ("plain_eval", PLAIN, "eval", 0, {}),
+        ("full_eval", FULL, "eval", 5, {}),
+        ("train_full", FULL, "train", 7, {}),
+        ("train_eop_matrix", FULL, "train", 7, dict(cl_anchor_level="eop_matrix", cl_temp=0.5)),
+        ("train_eot_list", FULL, "train", 9, dict(cl_anchor_level="eot_list")),
+        ("train_focal", PLAIN, "train", 3, dict(focal_loss_gamma=2.0, weight_label_zero=0.7)),
+        ("train_wce", PLAIN, "train", 3, dict(weight_label_zero=0.3)),
+    ]
+    run_case("tiny_L64", arch, 64, 2, 0, variants)
+    run_case("tiny_L128", arch, 128, 2, 1, variants[:3])
+
+
+if __name__ == "__main__":
+    main()
