@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py -- train throughput of the MI355X-native BERT topic-segmentation fine-tune step.
+
+Metric (BASELINE.json): train sequences/s (512-token) for bert-base topic segmentation; a "step" = one optimiser step
+over one batch of synthetic Wiki-727K-shaped windows: 2 encoder passes worth of sequences (anchor + augmented, the
+reference's run_finetune.sh flags) forward + backward + grad-norm clip + AdamW, all inside the timed region, inputs
+already resident in HBM.  N GPUs = pure data parallel (weak scaling: per-GPU batch fixed), RCCL all-reduce of the flat
+gradient buffer overlapped with backward.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` (dominant kernel = gemm_nt MFMA projections,
+timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed on the host cores).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0       # gfx950 dense bf16 (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
+
+
+def flops_per_seq(L, H, I, layers, train=True):
+    """algorithmic FLOPs: projections 2*(3H^2 + H^2 + 2HI) + attention 2*(2*L*H) per token per layer."""
+    per_tok_layer = 2 * (4 * H * H + 2 * H * I) + 4 * L * H
+    return per_tok_layer * layers * L * (3 if train else 1)
+
+
+def build(args, device):
+    from transformers import BertConfig
+    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+    cfg = BertConfig(vocab_size=30523, num_labels=2)          # bert-base-uncased + [BOS]
+    flags = dict(do_da_ts=True, do_cssl=True, do_tssp=True, ts_loss_weight=1.0, cl_loss_weight=0.5, cl_temp=0.1,
+                 cl_anchor_level="eop_list", cl_positive_k=1, cl_negative_k=3, tssp_loss_weight=1.0) if args.workload == "full_da" else {}
+    for k, v in flags.items():
+        setattr(cfg, k, v)
+    torch.manual_seed(0)
+    m = M(cfg).to(device).train()
+    return m, cfg
+
+
+def make_batches(args, n, seed, device):
+    from spokennlp_amd import data
+    pairs = args.seqs_per_gpu // 2 if args.workload == "full_da" else args.seqs_per_gpu
+    docs = data.synth_docs(max(64, pairs * n // 2), seed=1234 + seed)
+    bs = data.batches_from_docs(docs, args.seq_len, pairs, seed=seed)
+    while len(bs) < n:
+        bs = bs + bs
+    return [{k: v.to(device) for k, v in b.items()} for b in bs[:n]], pairs
+
+
+def gemm_roofline(model, args, device):
+    """time every gemm_nt launch shape of one step standalone (HIP events on the launch stream, same buffers), weight by
+    its call count: achieved = algorithmic projection FLOPs per launch / average launch duration."""
+    from spokennlp_amd import ops
+    cfg = model.config
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    M = args.seqs_per_gpu * args.seq_len
+    shapes = [  # (N, K, epilogue, calls per layer per step)  forward 4 + dgrad 4
+        (3 * H, H, ops.EPI_BIAS, 1), (H, H, ops.EPI_BIAS, 1), (I, H, ops.EPI_BIAS_GELU, 1), (H, I, ops.EPI_BIAS, 1),
+        (I, H, ops.EPI_GELU_BWD, 1), (H, I, ops.EPI_ADD_RES, 1), (H, H, ops.EPI_NONE, 1), (H, 3 * H, ops.EPI_ADD_RES, 1)]
+    tot_t, tot_f, launches = 0.0, 0.0, 0
+    detail = []
+    for N, K, epi, calls in shapes:
+        A = torch.randn(M, K, device=device).bfloat16(); B = (torch.randn(N, K, device=device) * 0.05).bfloat16()
+        bias = torch.randn(N, device=device); R = torch.randn(M, N, device=device).bfloat16()
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=device); out2 = torch.empty_like(out)
+        kw = dict(bias=bias if epi in (ops.EPI_BIAS, ops.EPI_BIAS_GELU) else None, R=R if epi in (ops.EPI_ADD_RES, ops.EPI_GELU_BWD) else None,
+                  out=out, out2=out2 if epi == ops.EPI_BIAS_GELU else None)
+        for _ in range(3):
+            ops.gemm_nt(A, B, epi, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            ops.gemm_nt(A, B, epi, **kw)
+        e1.record(); e1.synchronize()
+        t = e0.elapsed_time(e1) / reps * 1e-3
+        f = 2.0 * M * N * K
+        detail.append(dict(N=N, K=K, epi=epi, us=round(t * 1e6, 1), tflops=round(f / t / 1e12, 1)))
+        tot_t += t * calls; tot_f += f * calls; launches += calls
+    return dict(bound="mfma", achieved=round(tot_f / tot_t / 1e12, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(tot_f / tot_t / 1e12 / MFMA_PEAK_TFLOPS, 4), traffic=None, kernel="gemm_nt_kernel",
+                avg_launch_us=round(tot_t / launches * 1e6, 1), per_shape=detail)
+
+
+def cpu_baseline(args):
+    """the CPU oracle (validated against the reference's golden vectors) timed on the host cores: bert-base shape,
+    forward + backward + AdamW on a bounded sample (a few sequences) -- a reported baseline, not the target."""
+    from oracle import bert_ts_oracle as O
+    from tests.util import tiny_state_dict
+    from spokennlp_amd import data
+    ncores = os.cpu_count() or 1
+    threads = max(1, min(ncores // 2, 128))
+    torch.set_num_threads(threads)
+    arch = dict(vocab_size=30523, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                max_position_embeddings=512, type_vocab_size=2)
+    flags = dict(do_da_ts=True, do_cssl=True, do_tssp=True, cl_loss_weight=0.5, cl_temp=0.1, cl_anchor_level="eop_list",
+                 cl_positive_k=1, cl_negative_k=3, tssp_loss_weight=1.0) if args.workload == "full_da" else {}
+    sd = tiny_state_dict(arch, seed=0, std=0.02)
+    params = {k: torch.nn.Parameter(v) for k, v in sd.items()}
+    cfg = O.make_cfg(num_labels=2, **arch, **flags)
+    pairs = 4
+    docs = data.synth_docs(32, seed=99)
+    batch = data.batches_from_docs(docs, args.seq_len, pairs, seed=1)[0]
+    opt = torch.optim.AdamW(list(params.values()), lr=5e-5)
+    nseq = pairs * (2 if args.workload == "full_da" else 1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        random.seed(0)
+        loss, _, _ = O.model_forward(params, cfg, batch)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+        opt.step()
+
+    step()
+    t0 = time.time(); n = 0
+    while n < 3 or (time.time() - t0 < 10 and n < 20):
+        step(); n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=round(nseq / dt, 3), unit="seq/s", cores=threads, kind="port",
+                sample=f"{n} train steps (fwd+bwd+clip+AdamW, fp32 torch CPU oracle) of {nseq} x {args.seq_len}-token sequences, bert-base shape; "
+                       f"host has {ncores} logical CPUs")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--seq-len", type=int, default=512)
+    ap.add_argument("--seqs-per-gpu", type=int, default=32)
+    ap.add_argument("--workload", default="full_da", choices=["full_da", "plain"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from spokennlp_amd import dp
+    rank, world, local = dp.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    model, cfg = build(args, device)
+    eng = model.engine()
+    eng.enable_data_parallel()
+    batches, pairs = make_batches(args, 8, seed=rank, device=device)
+    total_steps = args.steps + args.warmup
+    lr0 = 5e-5
+
+    def step(i):
+        random.seed(i)
+        loss = model(**batches[i % len(batches)])[0]
+        loss.backward()
+        eng.finish_grad_sync()
+        lr = lr0 * max(0.0, (total_steps - i) / total_steps)        # linear decay, no warm-up (run_finetune.sh:73)
+        eng.adamw_step(lr, max_grad_norm=1.0, grad_scale=1.0 / world)
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    seqs = args.seqs_per_gpu * world * args.steps
+    value = seqs / dt
+    fl = flops_per_seq(args.seq_len, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers)
+    out = dict(metric="train seq/s (512-tok) bert-base topic-seg", value=round(value, 2), unit="seq/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
+               config=dict(workload=f"bert-base-uncased(+[BOS]) topic-seg fine-tune, {args.workload}, seq_len={args.seq_len}, "
+                                    f"{args.seqs_per_gpu} seqs/GPU/step ({pairs} samples), fwd+bwd+clip+AdamW, dropout 0.1",
+                           global_batch=args.seqs_per_gpu * world, seq_len=args.seq_len, parallelism=f"dp{world}"),
+               mfma_frac_whole_step=round(value / world * fl / (MFMA_PEAK_TFLOPS * 1e12), 4),
+               final_loss=round(float(loss), 4))
+    if rank == 0:
+        if not args.no_roofline:
+            out["roofline"] = gemm_roofline(model, args, device)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

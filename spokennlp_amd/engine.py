@@ -112,6 +112,21 @@ class BertEncoderEngine:
         self._scratch = dict(sumsq=torch.zeros(1, device=device), coef=torch.ones(1, device=device),
                              norm=torch.zeros(1, device=device), partials=torch.empty(2048, device=device))
         self._build_param_structs()
+        self.buckets = None
+
+    def enable_data_parallel(self):
+        """overlap per-layer RCCL all-reduce of the flat gradient slices with backward (dp.GradBuckets)."""
+        import torch.distributed as dist
+        from .dp import GradBuckets
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            self.buckets = GradBuckets(self.fp)
+        return self.buckets is not None
+
+    def finish_grad_sync(self):
+        """reduce the non-encoder slice (embeddings, heads) and wait for every outstanding bucket."""
+        if self.buckets is not None:
+            self.buckets.reduce_rest()
+            self.buckets.wait()
 
     # ------------------------------------------------------------------------------------------------ parameters
     def _p(self, flat, i, suffix):
@@ -256,6 +271,8 @@ class BertEncoderEngine:
                                            C.byref(A["acts_struct"][i]), C.byref(A["ws_struct"]), mb, dy.data_ptr(), other.data_ptr(), i, s)
             L.check(rc, f"amdseg_bert_layer_bwd[{i}]")
             dy, other = other, dy
+            if self.buckets is not None:          # data parallel: this layer's gradient slice is final -> start its all-reduce
+                self.buckets.reduce_layer(i)
         # embeddings: out = dropout(LN(z)); grads of LN affine + the three tables
         if ctx["p_h"] > 0:
             rc = lib.amdseg_dropout(dy.data_ptr(), other.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, L.BF16, L.BF16, s)
