@@ -59,6 +59,14 @@ int amdseg_gemm_tn_grouped(int nprob, const void* const* A, const int* lda, cons
                            float* const* C, const int* ldc, const int* N, const int* K, int M, int accumulate,
                            amdseg_stream_t stream);
 
+/* fp32 parity-mode GEMM (csrc/gemm_f32.hip): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), epilogue 0 none / 1 bias /
+ * 2 bias+gelu_erf; M,N multiples of 128, K multiple of 32.  Same reference lines as amdseg_gemm_nt. */
+int amdseg_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, int epilogue,
+                       const float* bias, amdseg_stream_t stream);
+/* fp32 attention (inference, no dropout), qkv [B*L, 3*heads*64] fp32 -> ctx [B*L, heads*64] fp32 */
+int amdseg_attn_f32(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, float scale,
+                    amdseg_stream_t stream);
+
 /* ---- fused attention (csrc/attention.hip), head_dim 64, L multiple of 64 -----------------------------------------
  * qkv [B*L, 3*heads*64] bf16 (q|k|v), mask_bias [B, L] fp32 additive key mask (0 or a large negative),
  * ctx [B*L, heads*64] bf16, lse [B, heads, L] fp32 (saved for backward; may be NULL for inference).
@@ -118,7 +126,8 @@ typedef struct amdseg_bert_cfg {
     float ln_eps, p_hidden, p_attn; /* dropout probabilities (0 in eval) */
     uint64_t seed;                  /* dropout seed of this step; per-layer/site streams are derived from it */
     int32_t accumulate_grads;       /* weight grads: 0 overwrite, 1 add into existing */
-    int32_t dtype;                  /* AMDSEG_BF16 */
+    int32_t dtype;                  /* AMDSEG_BF16 (train + inference) or AMDSEG_F32 (inference parity mode: the
+                                       layer params then point at the fp32 master weights, activations are fp32) */
 } amdseg_bert_cfg;
 
 typedef struct amdseg_bert_layer_params {   /* bf16 compute shadows (+ transposes for dgrad), fp32 vectors */

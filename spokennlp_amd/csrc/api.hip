@@ -28,6 +28,14 @@ int amdseg_gemm_tn_grouped(int nprob, const void* const* A, const int* lda, cons
                            amdseg_stream_t stream) {
     return amdseg_gemm_tn_grouped_impl(nprob, A, lda, B, ldb, C, ldc, N, K, M, accumulate, S(stream));
 }
+int amdseg_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, int epilogue,
+                       const float* bias, amdseg_stream_t stream) {
+    return amdseg_gemm_f32_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, S(stream));
+}
+int amdseg_attn_f32(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, float scale,
+                    amdseg_stream_t stream) {
+    return amdseg_attn_f32_impl(qkv, mask_bias, ctx, B, L, heads, 64, scale, S(stream));
+}
 int amdseg_attn_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                     float dropout_p, uint64_t seed, amdseg_stream_t stream) {
     return amdseg_attn_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, dropout_p, seed, S(stream));
@@ -107,7 +115,7 @@ static inline uint64_t site_seed(uint64_t seed, int layer, int site) {
 
 static int check_cfg(const amdseg_bert_cfg* c) {
     if (!c) return AMDSEG_ERR_ARG;
-    if (c->dtype != AMDSEG_BF16) return AMDSEG_ERR_ARG;
+    if (c->dtype != AMDSEG_BF16 && c->dtype != AMDSEG_F32) return AMDSEG_ERR_ARG;
     if (c->H != c->heads * 64 || c->B <= 0 || c->L <= 0 || c->I <= 0) return AMDSEG_ERR_SHAPE;
     const long M = (long)c->B * c->L;
     if ((M % 128) || (c->H % 128) || (c->I % 128) || (c->L % 64)) return AMDSEG_ERR_SHAPE;
@@ -120,6 +128,18 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     if (!p || !a || !mask_bias) return AMDSEG_ERR_ARG;
     hipStream_t s = S(stream);
     const int M = c->B * c->L, H = c->H, I = c->I;
+    if (c->dtype == AMDSEG_F32) {
+        // fp32 parity mode (inference): exact-fp32 MFMA GEMMs on the fp32 master weights, fp32 activations, no dropout
+        if (c->p_hidden != 0.f || c->p_attn != 0.f) return AMDSEG_ERR_ARG;
+        RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->x_in, H, (const float*)p->wqkv, H, (float*)a->qkv, 3 * H, M, 3 * H, H, 1, p->bqkv, s));
+        RET_IF(amdseg_attn_f32_impl((const float*)a->qkv, mask_bias, (float*)a->ctx, c->B, c->L, c->heads, 64, 0.125f, s));
+        RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->ctx, H, (const float*)p->wo, H, (float*)a->z1, H, M, H, H, 1, p->bo, s));
+        RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, 0.f, 0, AMDSEG_F32, s));
+        RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->x1, H, (const float*)p->w1, H, (float*)a->h, I, M, I, H, 2, p->b1, s));
+        RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->h, I, (const float*)p->w2, I, (float*)a->z2, H, M, H, I, 1, p->b2, s));
+        RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, 0.f, 0, AMDSEG_F32, s));
+        return AMDSEG_OK;
+    }
     // q|k|v projection with bias
     RET_IF(amdseg_gemm_nt_impl(a->x_in, H, p->wqkv, H, a->qkv, 3 * H, M, 3 * H, H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 0, s));
     RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0), s));
@@ -139,6 +159,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
                           const amdseg_bert_layer_acts* a, const amdseg_bert_layer_ws* w, const float* mask_bias,
                           const void* dy, void* dx_in, int li, amdseg_stream_t stream) {
     RET_IF(check_cfg(c));
+    if (c->dtype != AMDSEG_BF16) return AMDSEG_ERR_ARG;      // training runs on the bf16 MFMA path only
     if (!p || !g || !a || !w || !mask_bias || !dy || !dx_in) return AMDSEG_ERR_ARG;
     hipStream_t s = S(stream);
     const int M = c->B * c->L, H = c->H, I = c->I, acc = c->accumulate_grads;

@@ -133,7 +133,7 @@ class BertEncoderEngine:
         return self.fp.view(flat, self.fp.lp(i, suffix))
 
     def _build_param_structs(self):
-        self.lparams, self.lgrads = [], []
+        self.lparams, self.lgrads, self.lparams32 = [], [], []
         fp = self.fp
         for i in range(self.nlayers):
             sh = lambda s: self._p(self.shadow, i, s).data_ptr()          # noqa: E731
@@ -155,6 +155,14 @@ class BertEncoderEngine:
                              ln1_g=gs("attention.output.LayerNorm.weight"), ln1_b=gs("attention.output.LayerNorm.bias"),
                              ln2_g=gs("output.LayerNorm.weight"), ln2_b=gs("output.LayerNorm.bias"))
             self.lparams.append(P); self.lgrads.append(G)
+            # fp32 parity mode reads the fp32 masters directly (no shadows, no transposes)
+            self.lparams32.append(L.LayerParams(
+                wqkv=ps("attention.self.query.weight"), wo=ps("attention.output.dense.weight"),
+                w1=ps("intermediate.dense.weight"), w2=ps("output.dense.weight"), wqkv_t=None, wo_t=None, w1_t=None, w2_t=None,
+                bqkv=ps("attention.self.query.bias"), bo=ps("attention.output.dense.bias"),
+                b1=ps("intermediate.dense.bias"), b2=ps("output.dense.bias"),
+                ln1_g=ps("attention.output.LayerNorm.weight"), ln1_b=ps("attention.output.LayerNorm.bias"),
+                ln2_g=ps("output.LayerNorm.weight"), ln2_b=ps("output.LayerNorm.bias")))
 
     def refresh_shadows(self, force=False):
         """bf16 compute copies of the encoder matrices (+ transposes); re-done whenever flat_p was written."""
@@ -172,12 +180,12 @@ class BertEncoderEngine:
         self._shadow_version = self.fp.flat_p._version
 
     # ------------------------------------------------------------------------------------------------ arenas
-    def _arena(self, B, Lseq, train):
-        key = (B, Lseq, train)
+    def _arena(self, B, Lseq, train, fp32=False):
+        key = (B, Lseq, train, fp32)
         if key in self._arenas:
             return self._arenas[key]
         dev, H, I, M = self.device, self.H, self.I, B * Lseq
-        bf = torch.bfloat16
+        bf = torch.float32 if fp32 else torch.bfloat16
         nsave = self.nlayers if train else 1
 
         def e(*s, dt=bf):
@@ -225,11 +233,16 @@ class BertEncoderEngine:
         M = B * Lseq
         if (M % 128) or (Lseq % 64):
             raise L.AmdsegError(f"batch*seq must be a multiple of 128 and seq a multiple of 64 (got B={B}, L={Lseq})")
-        self.refresh_shadows()
-        A = self._arena(B, Lseq, train)
+        fp32 = (not train) and getattr(self.cfg, "amdseg_precision", "bf16") == "fp32"
+        if not fp32:
+            self.refresh_shadows()
+        A = self._arena(B, Lseq, train, fp32)
+        dt = L.F32 if fp32 else L.BF16
         p_h = float(self.cfg.hidden_dropout_prob) if train else 0.0
         p_a = float(self.cfg.attention_probs_dropout_prob) if train else 0.0
         cfg = self._cfg_struct(B, Lseq, p_h, p_a, seed, True)
+        cfg.dtype = dt
+        lparams = self.lparams32 if fp32 else self.lparams
         ids = input_ids.reshape(-1).contiguous()
         tts = token_type_ids.reshape(-1).contiguous()
         torch.mul(1.0 - attention_mask.to(torch.float32), -1e30, out=A["mask_bias"])
@@ -240,14 +253,14 @@ class BertEncoderEngine:
         rc = lib.amdseg_embed_ln_fwd(ids.data_ptr(), tts.data_ptr(), None, we.data_ptr(), pe.data_ptr(), te.data_ptr(),
                                      self._emb("LayerNorm.weight").data_ptr(), self._emb("LayerNorm.bias").data_ptr(),
                                      A["emb_z"].data_ptr(), A["x"][0].data_ptr(), A["emb_mean"].data_ptr(), A["emb_rstd"].data_ptr(),
-                                     M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], eps, p_h, seed * 1000003 + 17, L.BF16, s)
+                                     M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], eps, p_h, seed * 1000003 + 17, dt, s)
         L.check(rc, "amdseg_embed_ln_fwd")
         mb = A["mask_bias"].data_ptr()
         for i in range(self.nlayers):
-            rc = lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(self.lparams[i]), C.byref(A["acts_struct"][i]), mb, i, s)
+            rc = lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lparams[i]), C.byref(A["acts_struct"][i]), mb, i, s)
             L.check(rc, f"amdseg_bert_layer_fwd[{i}]")
         rc = lib.amdseg_dropout(A["x_final"].data_ptr(), A["out"].data_ptr(), M * self.H, p_out if train else 0.0,
-                                seed * 1000003 + 29, L.BF16, L.F32, s)
+                                seed * 1000003 + 29, dt, L.F32, s)
         L.check(rc, "amdseg_dropout")
         ctx = dict(B=B, L=Lseq, ids=ids, tts=tts, seed=seed, p_h=p_h, p_a=p_a, p_out=p_out if train else 0.0)
         return A["out"].view(B, Lseq, self.H), ctx

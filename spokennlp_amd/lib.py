@@ -47,6 +47,8 @@ _PROTOS = {
     "amdseg_gemm_nt": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp],
     "amdseg_gemm_tn_grouped": [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp),
                                C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, i32, vp],
+    "amdseg_gemm_f32_nt": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp],
+    "amdseg_attn_f32": [vp, vp, vp, i32, i32, i32, f32, vp],
     "amdseg_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_embed_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, u64, i32, vp],
@@ -82,6 +84,9 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # torch ships its own libamdhip64.so.7; it must be in the process BEFORE libamdseg.so is dlopen'ed so that both share
+    # ONE HIP runtime (and one device context / stream namespace).  Loading ours first would pull /opt/rocm's copy.
+    import torch  # noqa: F401
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise AmdsegError(f"libamdseg.so not found at {p}: the HIP extension is required (no CPU fallback); "

@@ -377,3 +377,35 @@ def test_gradnorm_clip(dev):
     assert abs(coef.item() - 1.0 / (nr + 1e-6)) / coef.item() < 1e-5
     y = x.clone(); ops.scale_(y, coef)
     assert abs(y.norm().item() - 1.0) < 1e-4
+
+
+# ----------------------------------------------------------------------------------------------------------- fp32 parity mode
+@pytest.mark.parametrize("M,N,K,epi", [(128, 128, 32, 0), (256, 384, 160, 1), (512, 768, 768, 2), (256, 768, 3072, 1)])
+def test_gemm_f32(dev, M, N, K, epi):
+    from spokennlp_amd import lib as L
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(dev); B = (torch.randn(N, K, generator=g) * 0.1).to(dev); bias = torch.randn(N, generator=g).to(dev)
+    C = torch.empty(M, N, device=dev)
+    rc = L.load().amdseg_gemm_f32_nt(A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, M, N, K, epi, bias.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    ref = A.double() @ B.double().t()
+    if epi >= 1:
+        ref = ref + bias.double()
+    if epi == 2:
+        ref = gelu(ref)
+    # exact fp32 fma chain: error is fp32 round-off of a K-long sum
+    assert (C.double() - ref).abs().max().item() < 2e-5 * math.sqrt(K / 32)
+    assert rel_err(C, ref.float()) < 1e-6
+
+
+@pytest.mark.parametrize("B,L,heads", [(1, 64, 1), (2, 256, 2)])
+def test_attn_f32(dev, B, L, heads):
+    from spokennlp_amd import lib as Lb
+    qkv, mb = make_qkv(dev, B, L, heads, 31)
+    q32 = qkv.float()
+    ctx = torch.empty(B * L, heads * 64, device=dev)
+    rc = Lb.load().amdseg_attn_f32(q32.data_ptr(), mb.data_ptr(), ctx.data_ptr(), B, L, heads, 0.125, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    ref, _ = attn_ref(q32, mb, B, L, heads)
+    assert (ctx - ref).abs().max().item() < 2e-5

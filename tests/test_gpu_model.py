@@ -87,6 +87,9 @@ def test_train_grads_vs_reference_golden(dev, variant):
             if k.startswith("train_full.grad."):
                 n = k[len("train_full.grad."):]
                 ref = torch.from_numpy(z[k])
+                if float(ref.norm()) < 1e-5:          # e.g. key.bias: softmax is shift-invariant, its true gradient is 0
+                    assert float(params[n].grad.float().norm()) < 1e-2, n
+                    continue
                 g = params[n].grad.float().cpu()
                 cosine = torch.nn.functional.cosine_similarity(g.flatten(), ref.flatten(), dim=0).item()
                 assert cosine > 0.995, (n, cosine)
@@ -97,7 +100,7 @@ def test_fresh_inputs_vs_oracle(dev):
     from oracle import bert_ts_oracle as O
     from spokennlp_amd import data
     from tests.util import tiny_state_dict
-    arch = dict(vocab_size=300, hidden_size=192, num_hidden_layers=3, num_attention_heads=3, intermediate_size=384,
+    arch = dict(vocab_size=300, hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=512,
                 max_position_embeddings=128, type_vocab_size=2)
     flags = dict(do_da_ts=True, do_cssl=True, do_tssp=True, cl_loss_weight=0.5, cl_temp=0.1, cl_anchor_level="eop_list",
                  cl_positive_k=1, cl_negative_k=3, tssp_loss_weight=1.0)
@@ -117,7 +120,7 @@ def test_fresh_inputs_vs_oracle(dev):
     assert (logits_m.detach().cpu() - logits_o.detach()).abs().max().item() < 0.08
     for n, p in m.named_parameters():
         go = sdo[n].grad
-        if go is None or float(go.norm()) == 0:
+        if go is None or float(go.norm()) < 1e-5:
             continue
         c = torch.nn.functional.cosine_similarity(p.grad.float().cpu().flatten(), go.flatten(), dim=0).item()
         assert c > 0.99, (n, c)
@@ -155,3 +158,27 @@ def test_fused_adamw_step_matches_torch(dev):
     for n, p in m.named_parameters():
         assert (p.detach() - ref_params[n].detach()).abs().max().item() < 1e-6, n
     assert m.engine().fp.flat_g.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("case", ["tiny_L64", "tiny_L128"])
+@pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
+def test_fp32_parity_mode_logits_within_1e3(dev, case, variant):
+    """north star: logits within 1e-3 of the fp32 CPU reference, predicted boundary indices bit-exact.
+    config.amdseg_precision = 'fp32' runs inference on the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32)."""
+    from oracle import bert_ts_oracle as O
+    z, sd, batch, arch = load_case(case)
+    fl = flags_of(z, variant)
+    fl["amdseg_precision"] = "fp32"
+    m = build_model(arch, fl, sd, dev).eval()
+    random.seed(int(z[f"{variant}.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos = m(**to_dev(batch, dev))
+    ref_logits = torch.from_numpy(z[f"{variant}.logits"])
+    d = (logits.cpu() - ref_logits).abs().max().item()
+    print(f"{case}/{variant} fp32 mode: max|dlogit| = {d:.2e}")
+    assert d < 1e-3                                     # tolerance stated by BASELINE.json north_star
+    assert d < 1e-4                                     # what exact-fp32 MFMA actually delivers
+    assert abs(loss.item() - float(z[f"{variant}.loss"])) < 1e-4
+    assert (cos.cpu() - torch.from_numpy(z[f"{variant}.cos"])).abs().max().item() < 1e-4
+    assert O.decode_predictions(logits.cpu()[:, 0], batch["labels"][:, 0]) == \
+        O.decode_predictions(ref_logits[:, 0], batch["labels"][:, 0])
