@@ -92,7 +92,7 @@ int amdseg_add_ln_fwd(void* y_inout_z, const void* resid, const float* gamma, co
                       float* rstd, int M, int H, float eps, float dropout_p, uint64_t seed, int dtype,
                       amdseg_stream_t stream);
 /* LayerNorm backward: dz (residual-stream grad), dbranch = dropout-masked dz (NULL when p == 0), and the column
- * reductions dgamma, dbeta, dbias (= colsum(dbranch)); partials = workspace of 3*ceil(M/32)*H floats */
+ * reductions dgamma, dbeta, dbias (= colsum(dbranch)); partials = workspace of 3*ceil(M/16)*H floats */
 int amdseg_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz,
                   void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M, int H,
                   float dropout_p, uint64_t seed, int accumulate, int dtype, amdseg_stream_t stream);
@@ -148,7 +148,7 @@ typedef struct amdseg_bert_layer_acts {     /* caller-owned activations; all but
 
 typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across layers */
     void *dz2, *dbr2, *du, *dx1, *dz1, *dbr1, *dctx, *dqkv;  /* [M,H] [M,H] [M,I] [M,H] [M,H] [M,H] [M,H] [M,3H] */
-    float *delta, *partials;                /* [B*heads*L], max(3*ceil(M/32)*H, ceil(M/128)*max(I,3H)) floats */
+    float *delta, *partials;                /* [B*heads*L], max(3*ceil(M/16)*H, ceil(M/128)*max(I,3H)) floats */
 } amdseg_bert_layer_ws;
 
 int amdseg_bert_layer_fwd(const amdseg_bert_cfg* cfg, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,

@@ -66,6 +66,23 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
 }
+// bf16 fast path: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output rounding 2^-9) sharing
+// ONE exponential e = exp(-x^2/2) between erf(x/sqrt2) and the Gaussian term of the derivative.
+__device__ __forceinline__ float erf_as_from_e(float ax_over_sqrt2, float e) {     // erf(z), z >= 0, e = exp(-z^2)
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax_over_sqrt2);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    return 1.0f - poly * e;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float e = __expf(-0.5f * x * x);
+    const float er = erf_as_from_e(fabsf(x) * 0.70710678118654752f, e);
+    return 0.5f * x * (1.0f + copysignf(er, x));
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const float e = __expf(-0.5f * x * x);
+    const float er = erf_as_from_e(fabsf(x) * 0.70710678118654752f, e);
+    return 0.5f * (1.0f + copysignf(er, x)) + x * 0.39894228040143268f * e;
+}
 
 // Stateless counter-based dropout RNG: keep(element idx) iff hash(seed, idx) >= threshold.
 // The same (seed, idx) is re-evaluated in backward, so no mask is stored.

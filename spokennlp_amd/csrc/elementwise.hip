@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
 // LN backward.  dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  Also emits
 //   dbranch = dz * keepmask / (1-p)   (gradient of the dense output; == dz when p == 0 -> pass dbranch = nullptr)
 //   per-block column partials of dgamma (sum dy*xhat), dbeta (sum dy) and dbias (sum dbranch)
-#define LNB_ROWS 32     // rows per block (8 per wave)
+#define LNB_ROWS 16     // rows per block (4 per wave)
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, const float* mean, const float* rstd,
                                                      const float* gamma, T* dz, T* dbranch, float* partials, int M, int H,
@@ -262,23 +262,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
     }
 }
 
-// out[c] (+)= sum_b partials[b][c]   (deterministic second stage; one thread per column, coalesced across columns)
-__global__ void reduce_partials_kernel(const float* partials, int nblocks, int N, float* out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * N + c];
-    out[c] = accumulate ? out[c] + s : s;
+// out[c] (+)= sum_b partials[b*stride + offset + c]   (deterministic second stage)
+// block = 16 float4 column groups (64 columns) x 16 row lanes; each lane strides over the partial rows, LDS tree at the end
+__global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float* partials, int nblocks, int stride, int offset,
+                                                                      int n, float* out, int accumulate) {
+    __shared__ float red[16][64];
+    const int cg = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cg * 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const bool vec = (c + 3 < n) && ((stride & 3) == 0) && ((offset & 3) == 0);
+    if (vec) {
+#pragma unroll 4
+        for (int b = ry; b < nblocks; b += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(partials + (size_t)b * stride + offset + c);
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        }
+    } else {
+        for (int b = ry; b < nblocks; b += 16) {
+            const float* p = partials + (size_t)b * stride + offset;
+            if (c < n) a0 += p[c];
+            if (c + 1 < n) a1 += p[c + 1];
+            if (c + 2 < n) a2 += p[c + 2];
+            if (c + 3 < n) a3 += p[c + 3];
+        }
+    }
+    red[ry][cg * 4 + 0] = a0; red[ry][cg * 4 + 1] = a1; red[ry][cg * 4 + 2] = a2; red[ry][cg * 4 + 3] = a3;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cc = blockIdx.x * 64 + threadIdx.x;
+        if (cc < n) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += red[r][threadIdx.x];
+            out[cc] = accumulate ? out[cc] + sum : sum;
+        }
+    }
 }
-
-// strided variant: partial rows have `stride` floats, reduce columns [offset, offset+n)
-__global__ void reduce_partials_strided_kernel(const float* partials, int nblocks, int stride, int offset, int n, float* out,
-                                               int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * stride + offset + c];
-    out[c] = accumulate ? out[c] + s : s;
+static inline void launch_reduce(const float* partials, int nblocks, int stride, int offset, int n, float* out, int accumulate,
+                                 hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblocks, stride, offset, n, out, accumulate);
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
@@ -522,10 +544,9 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nblk), dim3(256), shm, s, (const float*)dy, (const float*)z, mean, rstd, gamma,
                            (float*)dz, (float*)dbranch, partials, M, H, th, ik, seed);
     if (partials) {
-        dim3 g((H + 255) / 256);
-        if (dgamma) hipLaunchKernelGGL(reduce_partials_kernel, g, dim3(256), 0, s, partials, nblk, H, dgamma, accumulate);
-        if (dbeta) hipLaunchKernelGGL(reduce_partials_kernel, g, dim3(256), 0, s, partials + (size_t)nblk * H, nblk, H, dbeta, accumulate);
-        if (dbias) hipLaunchKernelGGL(reduce_partials_kernel, g, dim3(256), 0, s, partials + (size_t)2 * nblk * H, nblk, H, dbias, accumulate);
+        if (dgamma) launch_reduce(partials, nblk, H, 0, H, dgamma, accumulate, s);
+        if (dbeta) launch_reduce(partials + (size_t)nblk * H, nblk, H, 0, H, dbeta, accumulate, s);
+        if (dbias) launch_reduce(partials + (size_t)2 * nblk * H, nblk, H, 0, H, dbias, accumulate, s);
     }
     return amdseg_launch_status();
 }
@@ -540,7 +561,7 @@ int amdseg_colsum_impl(const void* x, int ld, float* partials, float* out, int M
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, partials, M, N);
     else
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, partials, M, N);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partials, nblk, N, out, accumulate);
+    launch_reduce(partials, nblk, N, 0, N, out, accumulate, s);
     return amdseg_launch_status();
 }
 
@@ -600,8 +621,8 @@ int amdseg_rowdot_bwd_impl(const void* x, const float* W, const float* dlogits, 
         const int PW = C * H + C;
         // partial rows are [C*H | C]; reduce weights and biases with a strided view: treat as N = PW columns
         // (dW and db are contiguous in the flat parameter layout only by convention, so reduce separately)
-        if (dW) hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((C * H + 255) / 256), dim3(256), 0, s, partials, nblk, PW, 0, C * H, dW, accumulate);
-        if (db) hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3(1), dim3(256), 0, s, partials, nblk, PW, C * H, C, db, accumulate);
+        if (dW) launch_reduce(partials, nblk, PW, 0, C * H, dW, accumulate, s);
+        if (db) launch_reduce(partials, nblk, PW, C * H, C, db, accumulate, s);
     }
     return amdseg_launch_status();
 }

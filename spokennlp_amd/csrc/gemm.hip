@@ -18,6 +18,7 @@
 #define BM 128
 #define BN 128
 #define BK 64
+#define GROUP_M 8
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_BWD = 4 };
 
@@ -63,7 +64,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
     const int wr = w >> 1, wc = w & 1;
     const int nwg = a.tiles_m * a.tiles_n;
     const int t = xcd_remap(blockIdx.x, nwg);
-    const int tm = t / a.tiles_n, tn = t - tm * a.tiles_n;
+    // grouped tile order inside each XCD's contiguous range: the ~64 tiles resident on one XCD (32 CUs x 2) form a
+    // GROUP_M x 8 patch, so each A/B panel fetched into the XCD's 4 MiB L2 is shared by 8 tiles and the resident
+    // working set (8 + 8 panels) stays below the L2 size
+    const int gsz_full = GROUP_M * a.tiles_n;
+    const int grp = t / gsz_full, first_m = grp * GROUP_M;
+    const int gm = min(a.tiles_m - first_m, GROUP_M);
+    const int rem = t - grp * gsz_full;
+    const int tm = first_m + rem % gm, tn = rem / gm;
     const int m0 = tm * BM, n0 = tn * BN;
 #define bufA(i) (smem + (i) * 32768)
 #define bufB(i) (smem + 16384 + (i) * 32768)
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
         if (EPI == EPI_BIAS_GELU) {
             st8<bf16_t>(a.C2 + gm * a.ldc2 + gn, v);     // pre-activation u, kept for backward
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
         } else if (EPI == EPI_ADD_RES) {
             float rr[8]; ld8<bf16_t>(a.R + gm * a.ldr + gn, rr);
 #pragma unroll
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
         } else if (EPI == EPI_GELU_BWD) {
             float u[8]; ld8<bf16_t>(a.R + gm * a.ldr + gn, u);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(u[e]);
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast(u[e]);
         }
         st8<OutT>(reinterpret_cast<OutT*>(a.C) + gm * a.ldc + gn, v);
     }

@@ -199,7 +199,7 @@ class BertEncoderEngine:
                  emb_z=e(M, H), emb_mean=e(M, dt=torch.float32), emb_rstd=e(M, dt=torch.float32),
                  mask_bias=e(B, Lseq, dt=torch.float32), out=e(M, H, dt=torch.float32))
         if train:
-            npart = max(3 * ((M + 31) // 32) * H, ((M + 127) // 128) * max(I, 3 * H))
+            npart = max(ops.ln_partials_numel(M, H), ((M + 127) // 128) * max(I, 3 * H))
             A["ws"] = dict(dz2=e(M, H), dbr2=e(M, H), du=e(M, I), dx1=e(M, H), dz1=e(M, H), dbr1=e(M, H), dctx=e(M, H),
                            dqkv=e(M, 3 * H), delta=e(B * self.heads * Lseq, dt=torch.float32),
                            partials=e(npart, dt=torch.float32), dy=[e(M, H), e(M, H)])

@@ -117,8 +117,11 @@ def add_ln_fwd(y, resid, gamma, beta, eps, p=0.0, seed=0):
     return out, mean, rstd
 
 
+LNB_ROWS = 16      # rows per workgroup of ln_bwd / rowdot_bwd (csrc/elementwise.hip)
+
+
 def ln_partials_numel(M, H):
-    return 3 * ((M + 31) // 32) * H
+    return 3 * ((M + LNB_ROWS - 1) // LNB_ROWS) * H
 
 
 def ln_bwd(dy, z, mean, rstd, gamma, p=0.0, seed=0, dgamma=None, dbeta=None, dbias=None, accumulate=False, partials=None):
@@ -179,7 +182,7 @@ def rowdot_bwd(x, W, dlogits, dW=None, db=None, need_dx=True, accumulate=False):
     dx = torch.empty_like(x) if need_dx else None
     partials = None
     if dW is not None or db is not None:
-        partials = torch.empty((((M + 31) // 32) * (Cc * H + Cc),), dtype=torch.float32, device=x.device)
+        partials = torch.empty((((M + LNB_ROWS - 1) // LNB_ROWS) * (Cc * H + Cc),), dtype=torch.float32, device=x.device)
     rc = L.load().amdseg_rowdot_bwd(_p(x), _p(W), _p(dlogits), _p(dx), _p(partials), _p(dW), _p(db), M, H, Cc,
                                     1 if accumulate else 0, _dt(x), _s())
     L.check(rc, "amdseg_rowdot_bwd")
