@@ -41,40 +41,53 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 }
 
 // ------------------------------------------------------------------------------------------------ gemm_nt
-// LDS image of an operand tile: [128 rows][64 k] bf16, 128 B per row, 16-B chunk c of row r stored at slot
-// c ^ ((r >> 1) & 7): a ds_read_b128 lane group (16 distinct rows mod 16, one k-chunk) covers all 16 slots of the
+// Pipeline (measured motivation, profiles/r01_v0): with a 2-deep LDS double buffer the kernel moved 21 B/clk/CU = 64 KiB in
+// flight per CU / ~3000 clk loaded memory latency, i.e. it was bound by the latency x bandwidth product, not by MFMA or
+// L2.  So: BK = 32, a 5-slot LDS ring per workgroup (80 KiB, 2 workgroups per CU -> 128 KiB of DMA in flight per CU), loads
+// issued 4 K-steps ahead, COUNTED s_waitcnt vmcnt(N) (never 0 in the steady state) + a raw s_barrier so the DMA queue is
+// never drained inside the K loop.
+// LDS image of an operand stage: [128 rows][32 k] bf16, 64 B per row, 16-B chunk c of row r stored at slot
+// c ^ ((r >> 2) & 3): a ds_read_b128 lane group (16 distinct rows mod 16, one k-chunk) covers all 16 slots of the
 // 256-B bank row -> conflict free.
+#define NT_NS 5
+#define NT_STAGE_BYTES 16384          // A 8 KiB + B 8 KiB
 __device__ __forceinline__ void nt_stage(const bf16_t* __restrict__ G, int ld, int row0, int k0, char* lds_tile, int w, int l) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int R0 = w * 32 + q * 8;
-        int r = R0 + (l >> 3), s = l & 7;
-        int c = s ^ ((r >> 1) & 7);
-        glds16(G + (size_t)(row0 + r) * ld + k0 + c * 8, lds_tile + R0 * 128);
+    for (int q = 0; q < 2; ++q) {
+        int R0 = w * 32 + q * 16;
+        int r = R0 + (l >> 2), s = l & 3;
+        int c = s ^ ((r >> 2) & 3);
+        glds16(G + (size_t)(row0 + r) * ld + k0 + c * 8, lds_tile + R0 * 64);
     }
 }
 __device__ __forceinline__ bf16x8 nt_frag(const char* lds_tile, int r, int c) {
-    return *reinterpret_cast<const bf16x8*>(lds_tile + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+    return *reinterpret_cast<const bf16x8*>(lds_tile + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
+}
+// wait until this wave's loads of the oldest in-flight stage have landed; `younger` = stages issued after it (0..3)
+__device__ __forceinline__ void wait_stage(int younger) {
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int EPI, typename OutT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[65536];
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // NT_NS * 16 KiB ring; reused as fp32 [128][128] in the epilogue
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int wr = w >> 1, wc = w & 1;
     const int nwg = a.tiles_m * a.tiles_n;
     const int t = xcd_remap(blockIdx.x, nwg);
     // grouped tile order inside each XCD's contiguous range: the ~64 tiles resident on one XCD (32 CUs x 2) form a
-    // GROUP_M x 8 patch, so each A/B panel fetched into the XCD's 4 MiB L2 is shared by 8 tiles and the resident
-    // working set (8 + 8 panels) stays below the L2 size
+    // GROUP_M x 8 patch, so each A/B panel fetched into the XCD's 4 MiB L2 is shared by 8 tiles
     const int gsz_full = GROUP_M * a.tiles_n;
     const int grp = t / gsz_full, first_m = grp * GROUP_M;
     const int gm = min(a.tiles_m - first_m, GROUP_M);
     const int rem = t - grp * gsz_full;
     const int tm = first_m + rem % gm, tn = rem / gm;
     const int m0 = tm * BM, n0 = tn * BN;
-#define bufA(i) (smem + (i) * 32768)
-#define bufB(i) (smem + 16384 + (i) * 32768)
+#define slotA(i) (smem + (i) * NT_STAGE_BYTES)
+#define slotB(i) (smem + (i) * NT_STAGE_BYTES + 8192)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -84,21 +97,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.K / BK;
-    nt_stage(a.A, a.lda, m0, 0, bufA(0), w, l);
-    nt_stage(a.B, a.ldb, n0, 0, bufB(0), w, l);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            nt_stage(a.A, a.lda, m0, (kt + 1) * BK, bufA(cur ^ 1), w, l);
-            nt_stage(a.B, a.ldb, n0, (kt + 1) * BK, bufB(cur ^ 1), w, l);
-        }
-        const char* tA = bufA(cur);
-        const char* tB = bufB(cur);
+    const int nk = a.K / 32;
+    // prologue: fill NT_NS-1 slots
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+    for (int p = 0; p < NT_NS - 1; ++p)
+        if (p < nk) {
+            nt_stage(a.A, a.lda, m0, p * 32, slotA(p), w, l);
+            nt_stage(a.B, a.ldb, n0, p * 32, slotB(p), w, l);
+        }
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int issued_after = min(nk - 1 - kt, NT_NS - 2);   // stages younger than kt currently in flight
+        wait_stage(issued_after);
+        __builtin_amdgcn_s_barrier();                           // stage kt visible to all waves; slot (kt-1)%NS free
+        if (kt + NT_NS - 1 < nk) {
+            const int ps = slot == 0 ? NT_NS - 1 : slot - 1;    // == (kt + NS - 1) % NS
+            nt_stage(a.A, a.lda, m0, (kt + NT_NS - 1) * 32, slotA(ps), w, l);
+            nt_stage(a.B, a.ldb, n0, (kt + NT_NS - 1) * 32, slotB(ps), w, l);
+        }
+        const char* tA = slotA(slot);
+        const char* tB = slotB(slot);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
             const int c = kk * 2 + (l >> 5);
             bf16x8 fa[2], fb[2];
 #pragma unroll
@@ -111,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+        slot = slot == NT_NS - 1 ? 0 : slot + 1;
     }
     // ---- epilogue: accumulators -> LDS (fp32 [128][128]) -> coalesced 16 B/lane stores
     __syncthreads();
@@ -139,28 +160,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
             float4 y = *reinterpret_cast<const float4*>(sm + r * BN + cc + 4);
             v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
         }
-        const size_t gm = (size_t)(m0 + r);
+        const size_t gm_ = (size_t)(m0 + r);
         const int gn = n0 + cc;
         if (EPI == EPI_BIAS_GELU) {
-            st8<bf16_t>(a.C2 + gm * a.ldc2 + gn, v);     // pre-activation u, kept for backward
+            st8<bf16_t>(a.C2 + gm_ * a.ldc2 + gn, v);     // pre-activation u, kept for backward
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
         } else if (EPI == EPI_ADD_RES) {
-            float rr[8]; ld8<bf16_t>(a.R + gm * a.ldr + gn, rr);
+            float rr[8]; ld8<bf16_t>(a.R + gm_ * a.ldr + gn, rr);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rr[e];
         } else if (EPI == EPI_GELU_BWD) {
-            float u[8]; ld8<bf16_t>(a.R + gm * a.ldr + gn, u);
+            float u[8]; ld8<bf16_t>(a.R + gm_ * a.ldr + gn, u);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast(u[e]);
         }
-        st8<OutT>(reinterpret_cast<OutT*>(a.C) + gm * a.ldc + gn, v);
+        st8<OutT>(reinterpret_cast<OutT*>(a.C) + gm_ * a.ldc + gn, v);
     }
 }
 
+#define NT_LDS_BYTES (NT_NS * NT_STAGE_BYTES)
 template <int EPI, typename OutT>
 static int launch_nt(const GemmNTArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+    static bool attr_set = false;          // > 64 KiB of dynamic LDS must be opted into once per kernel
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<EPI, OutT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(256), NT_LDS_BYTES, s, a);
     return amdseg_launch_status();
 }
 
@@ -168,7 +197,7 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
                         int epi, const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32,
                         hipStream_t stream) {
     if (!A || !B || !C) return AMDSEG_ERR_ARG;
-    if (M <= 0 || N <= 0 || K <= 0 || (M % BM) || (N % BN) || (K % BK)) return AMDSEG_ERR_SHAPE;
+    if (M <= 0 || N <= 0 || K <= 0 || (M % BM) || (N % BN) || (K % 32)) return AMDSEG_ERR_SHAPE;
     if ((lda % 8) || (ldb % 8) || (ldc % 8)) return AMDSEG_ERR_SHAPE;
     GemmNTArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = bias; a.R = (const bf16_t*)R; a.C2 = (bf16_t*)C2;
@@ -200,8 +229,8 @@ struct GemmTNArgs { TNProblem p[AMDSEG_MAX_GROUP]; int nprob, M, accumulate, tot
 
 __device__ __forceinline__ void tn_stage(const bf16_t* __restrict__ G, int ld, int m0, int col0, char* lds_tile, int w, int l) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int R0 = w * 16 + q * 4;
+    for (int q = 0; q < 2; ++q) {
+        int R0 = w * 8 + q * 4;
         int r = R0 + (l >> 4), s = l & 15;
         int c = s ^ ((r & 3) << 2);
         glds16(G + (size_t)(m0 + r) * ld + col0 + c * 8, lds_tile + R0 * 256);
@@ -222,8 +251,9 @@ __device__ __forceinline__ bf16x8 tn_frag(const char* lds_tile, int col, int kk,
     return f;
 }
 
+// same 5-slot LDS ring / counted-vmcnt pipeline as gemm_nt (stage = [32 m][128] of A + [32 m][128] of B = 16 KiB)
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[65536];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int wr = w >> 1, wc = w & 1;
     const int t = xcd_remap(blockIdx.x, a.total_tiles);
@@ -235,8 +265,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNArgs a) {
     const int lt = t - P.tile_begin;
     const int tn_ = lt / P.tiles_k, tk = lt - tn_ * P.tiles_k;
     const int n0 = tn_ * 128, k0 = tk * 128;
-#define bufA(i) (smem + (i) * 32768)
-#define bufB(i) (smem + 16384 + (i) * 32768)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -246,21 +274,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nm = a.M / 64;
-    tn_stage(P.A, P.lda, 0, n0, bufA(0), w, l);
-    tn_stage(P.B, P.ldb, 0, k0, bufB(0), w, l);
-    for (int mt = 0; mt < nm; ++mt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int cur = mt & 1;
-        if (mt + 1 < nm) {
-            tn_stage(P.A, P.lda, (mt + 1) * 64, n0, bufA(cur ^ 1), w, l);
-            tn_stage(P.B, P.ldb, (mt + 1) * 64, k0, bufB(cur ^ 1), w, l);
-        }
-        const char* tA = bufA(cur);
-        const char* tB = bufB(cur);
+    const int nm = a.M / 32;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+    for (int p = 0; p < NT_NS - 1; ++p)
+        if (p < nm) {
+            tn_stage(P.A, P.lda, p * 32, n0, slotA(p), w, l);
+            tn_stage(P.B, P.ldb, p * 32, k0, slotB(p), w, l);
+        }
+    int slot = 0;
+    for (int mt = 0; mt < nm; ++mt) {
+        wait_stage(min(nm - 1 - mt, NT_NS - 2));
+        __builtin_amdgcn_s_barrier();
+        if (mt + NT_NS - 1 < nm) {
+            const int ps = slot == 0 ? NT_NS - 1 : slot - 1;
+            tn_stage(P.A, P.lda, (mt + NT_NS - 1) * 32, n0, slotA(ps), w, l);
+            tn_stage(P.B, P.ldb, (mt + NT_NS - 1) * 32, k0, slotB(ps), w, l);
+        }
+        const char* tA = slotA(slot);
+        const char* tB = slotB(slot);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) fa[i] = tn_frag(tA, wr * 64 + i * 32, kk, l);
@@ -272,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNArgs a) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+        slot = slot == NT_NS - 1 ? 0 : slot + 1;
     }
     __syncthreads();
     float* sm = reinterpret_cast<float*>(smem);
@@ -305,7 +339,7 @@ int amdseg_gemm_tn_grouped_impl(int nprob, const void* const* A, const int* lda,
                                 float* const* C, const int* ldc, const int* N, const int* Kp, int M, int accumulate,
                                 hipStream_t stream) {
     if (nprob <= 0 || nprob > AMDSEG_MAX_GROUP || !A || !B || !C) return AMDSEG_ERR_ARG;
-    if (M <= 0 || (M % 64)) return AMDSEG_ERR_SHAPE;
+    if (M <= 0 || (M % 32)) return AMDSEG_ERR_SHAPE;
     GemmTNArgs a;
     int tiles = 0;
     for (int i = 0; i < nprob; ++i) {
@@ -319,6 +353,12 @@ int amdseg_gemm_tn_grouped_impl(int nprob, const void* const* A, const int* lda,
     }
     for (int i = nprob; i < AMDSEG_MAX_GROUP; ++i) a.p[i] = a.p[0];
     a.nprob = nprob; a.M = M; a.accumulate = accumulate; a.total_tiles = tiles;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles), dim3(256), 0, stream, a);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles), dim3(256), NT_LDS_BYTES, stream, a);
     return amdseg_launch_status();
 }

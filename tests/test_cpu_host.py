@@ -1,0 +1,131 @@
+"""CPU-only tests (run in the build container, no GPU): C-ABI surface, host logic, synthetic data invariants."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from spokennlp_amd import lib
+    hdr = open(os.path.join(ROOT, "include", "amdseg.h")).read()
+    declared = set(re.findall(r"\b(amdseg_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"amdseg_stream_t"}
+    assert declared, "no declarations parsed"
+    l = lib.load()
+    for name in sorted(declared):
+        assert hasattr(l, name), f"{name} declared in include/amdseg.h but not exported"
+    assert set(lib.EXPORTS) == declared, (set(lib.EXPORTS) ^ declared)
+    assert l.amdseg_abi_version() == lib.ABI_VERSION
+    assert b"shape" in l.amdseg_error_string(1001)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from spokennlp_amd import lib
+    with pytest.raises(lib.AmdsegError):
+        lib.load(str(tmp_path / "nope.so"))
+
+
+def test_model_refuses_cpu_tensors():
+    from transformers import BertConfig
+    from spokennlp_amd import lib
+    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+    cfg = BertConfig(vocab_size=50, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=128, num_labels=2)
+    m = M(cfg)
+    ids = torch.zeros(1, 2, 64, dtype=torch.long)
+    with pytest.raises(lib.AmdsegError):
+        m(input_ids=ids, labels=torch.full((1, 2, 64), -100))
+
+
+def test_hf_parameter_names_match_reference_checkpoint_layout():
+    from transformers import BertConfig
+    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+    cfg = BertConfig(vocab_size=50, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, num_labels=2)
+    names = set(dict(M(cfg).named_parameters()))
+    for n in ["bert.embeddings.word_embeddings.weight", "bert.encoder.layer.1.attention.self.query.weight",
+              "bert.encoder.layer.0.attention.output.LayerNorm.bias", "bert.encoder.layer.1.intermediate.dense.weight",
+              "bert.pooler.dense.weight", "loss_calculator.classifier.weight", "loss_calculator.classifier.bias",
+              "loss_calculator.tssp.classifier.weight", "loss_calculator.tssp.classifier.bias"]:
+        assert n in names, n
+
+
+def test_flat_params_alias_and_qkv_adjacent():
+    from transformers import BertConfig
+    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+    from spokennlp_amd.engine import FlatParams
+    cfg = BertConfig(vocab_size=50, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, num_labels=2)
+    m = M(cfg)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    fp = FlatParams(m, torch.device("cpu"))
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), before[n])
+        assert p.data_ptr() == fp.flat_p.data_ptr() + 4 * fp.offsets[n]
+        assert p.grad is not None and p.grad.data_ptr() == fp.flat_g.data_ptr() + 4 * fp.offsets[n]
+    H = 128
+    for i in range(2):
+        q = fp.offsets[f"bert.encoder.layer.{i}.attention.self.query.weight"]
+        assert fp.offsets[f"bert.encoder.layer.{i}.attention.self.key.weight"] == q + H * H
+        assert fp.offsets[f"bert.encoder.layer.{i}.attention.self.value.weight"] == q + 2 * H * H
+        qb = fp.offsets[f"bert.encoder.layer.{i}.attention.self.query.bias"]
+        assert fp.offsets[f"bert.encoder.layer.{i}.attention.self.value.bias"] == qb + 2 * H
+    assert fp.intact()
+    # writes through a parameter land in the flat buffer
+    with torch.no_grad():
+        m.loss_calculator.classifier.bias.fill_(3.0)
+    o = fp.offsets["loss_calculator.classifier.bias"]
+    assert fp.flat_p[o].item() == 3.0
+
+
+@pytest.mark.parametrize("L,vocab", [(64, 200), (512, 30523)])
+def test_synthetic_batches_satisfy_reference_invariants(L, vocab):
+    """the invariants without which the reference heads crash or silently skip."""
+    from spokennlp_amd import data
+    kw = dict(mean_sents=14, sd_sents=5, mean_boundaries=3, mu_tok=1.6, sigma_tok=0.4) if L == 64 else {}
+    docs = data.synth_docs(12, seed=3, vocab=vocab, **kw)
+    bs = data.batches_from_docs(docs, L, 4, seed=1, as_torch=False)
+    assert len(bs) >= 2
+    bos = vocab - 1
+    for b in bs:
+        for c in data.COLUMNS:
+            assert b[c].shape == (4, 2, L) and b[c].dtype == np.int64
+        for i in range(4):
+            for s in range(2):
+                ids, lab = b["input_ids"][i, s], b["labels"][i, s]
+                am, seg = b["attention_mask"][i, s], b["extract_eop_segment_ids"][i, s]
+                assert ids[0] == data.CLS_ID and lab[0] == -100
+                labelled = np.nonzero(lab != -100)[0]
+                assert (ids[labelled] == bos).all()
+                assert set(lab[labelled].tolist()) <= {0, 1}
+                k = len(labelled)
+                assert seg[labelled].tolist() == list(range(1, k + 1)) and (np.delete(seg, labelled) == 0).all()
+                eidx = b["eop_index_for_aggregate_batch_eop_features"][i, s]
+                assert eidx[:k + 1].tolist() == list(range(k + 1)) and (eidx[k + 1:] == 0).all()
+                n = int(am.sum())
+                assert (am[:n] == 1).all() and (am[n:] == 0).all() and (ids[n:] == data.PAD_ID).all() and (lab[n:] == -100).all()
+                is_bos = (ids == bos) & (am == 1)
+                stm = b["sent_token_mask"][i, s]
+                assert ((stm != -100) == is_bos).all()
+                assert (stm[labelled] == (lab[labelled] != 0)).all()
+                sll = b["sent_level_labels"][i, s]
+                assert sll[0] == -100 and sll[1:1 + int(is_bos.sum())].tolist() == lab[is_bos].tolist()
+            if L == 64 or True:
+                # TSSP labels sit on every BOS of the augmented half; anchors carry a copy of them
+                spo = b["sent_pair_orders"][i, 1]
+                da_bos = (b["input_ids"][i, 1] == bos) & (b["attention_mask"][i, 1] == 1)
+                assert ((spo != -100) == da_bos).all() and set(spo[da_bos].tolist()) <= {0, 1, 2}
+                assert (b["sent_pair_orders"][i, 0] == spo).all()
+            assert (b["labels"][i, 0] != -100).sum() >= 1
+            # the augmented half is a permutation of the anchor's tokens
+            assert sorted(b["input_ids"][i, 0].tolist()) == sorted(b["input_ids"][i, 1].tolist())
+
+
+def test_dense_batch_shape():
+    from spokennlp_amd import data
+    b = data.dense_batch(3, L=512, as_torch=False)
+    assert b["input_ids"].shape == (3, 2, 512) and (b["attention_mask"] == 1).all()
+    assert ((b["labels"][:, 0] != -100).sum(-1) == 20).all()       # 21 sentences, the last one unlabelled

@@ -1,0 +1,62 @@
+"""Data-parallel gradient exchange, world_size 2 on CPU with the gloo backend (the N>1 path of bench.py uses the same
+GradBuckets over RCCL).  Checks: bucket slices tile the flat buffer exactly, per-layer async all-reduce + rest + wait
+gives the elementwise SUM on every rank, and sample sharding is a partition."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from transformers import BertConfig
+    from spokennlp_amd import dp
+    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+    from spokennlp_amd.engine import FlatParams
+    r, w, _ = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    cfg = BertConfig(vocab_size=50, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256, num_labels=2)
+    fp = FlatParams(M(cfg), torch.device("cpu"))
+    b = dp.GradBuckets(fp)
+    # slices tile [0, numel) without gaps or overlap
+    sl = sorted([b.rest_slice] + b.layer_slices)
+    assert sl[0][0] == 0 and sl[-1][1] == fp.numel and all(sl[i][1] == sl[i + 1][0] for i in range(len(sl) - 1))
+    g = torch.Generator().manual_seed(100 + rank)
+    fp.flat_g.copy_(torch.randn(fp.numel, generator=g))
+    mine = fp.flat_g.clone()
+    for li in reversed(range(fp.nlayers)):
+        b.reduce_layer(li)
+    b.reduce_rest()
+    b.wait()
+    expect = sum(torch.randn(fp.numel, generator=torch.Generator().manual_seed(100 + k)) for k in range(world))
+    ok = torch.allclose(fp.flat_g, expect, atol=1e-6) and not torch.equal(fp.flat_g, mine)
+    # parameter .grad views see the reduced values
+    n = "bert.encoder.layer.2.output.dense.weight"
+    ok = ok and torch.equal(fp.params[n].grad.flatten(), fp.flat_g[fp.offsets[n]:fp.offsets[n] + fp.params[n].numel()])
+    idx = dp.shard_indices(11, rank, world)
+    q.put((rank, bool(ok), idx))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_allreduce_gloo_world2():
+    world = 2
+    port = 29500 + (os.getpid() % 500)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    idx = sorted(i for _, _, ix in res for i in ix)
+    assert set(idx) == set(range(11)) and len(idx) == 12       # DistributedSampler-style partition with one wrapped pad
