@@ -57,10 +57,10 @@ __device__ __forceinline__ bf16x8 at_frag_tr(const char* tile, int r0a, int r0b,
     return f;
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
-    bf16x8 f;
-    f[0] = (short)f2bf(a[0]); f[1] = (short)f2bf(a[1]); f[2] = (short)f2bf(a[2]); f[3] = (short)f2bf(a[3]);
-    f[4] = (short)f2bf(b[0]); f[5] = (short)f2bf(b[1]); f[6] = (short)f2bf(b[2]); f[7] = (short)f2bf(b[3]);
-    return f;
+    union { uint32_t u[4]; bf16x8 v; } r;
+    r.u[0] = pack2bf(a[0], a[1]); r.u[1] = pack2bf(a[2], a[3]);
+    r.u[2] = pack2bf(b[0], b[1]); r.u[3] = pack2bf(b[2], b[3]);
+    return r.v;
 }
 // dropout on attention probabilities: one 32-bit hash per aligned key pair, 16 bits per element.
 // element (row = bh*L + q, key); keep iff 16-bit field >= thresh16

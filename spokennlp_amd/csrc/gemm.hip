@@ -22,8 +22,19 @@
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_BWD = 4 };
 
+#ifdef AMDSEG_PHASE_TIMERS
+#define PT_DECL unsigned long long pt_wait = 0, pt_comp = 0, pt_t0, pt_t1, pt_t2; const unsigned long long pt_start = __builtin_readcyclecounter();
+#define PT_A pt_t0 = __builtin_readcyclecounter();
+#define PT_B pt_t1 = __builtin_readcyclecounter(); pt_wait += pt_t1 - pt_t0;
+#define PT_C pt_t2 = __builtin_readcyclecounter(); pt_comp += pt_t2 - pt_t1;
+#else
+#define PT_DECL
+#define PT_A
+#define PT_B
+#define PT_C
+#endif
 struct GemmNTArgs {
-    const bf16_t* A; const bf16_t* B; void* C; const float* bias; const bf16_t* R; bf16_t* C2;
+    const bf16_t* A; const bf16_t* B; void* C; const float* bias; const bf16_t* R; bf16_t* C2; unsigned long long* dbg;
     int lda, ldb, ldc, ldr, ldc2;
     int M, N, K;
     int tiles_m, tiles_n;
@@ -41,53 +52,48 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 }
 
 // ------------------------------------------------------------------------------------------------ gemm_nt
-// Pipeline (measured motivation, profiles/r01_v0): with a 2-deep LDS double buffer the kernel moved 21 B/clk/CU = 64 KiB in
-// flight per CU / ~3000 clk loaded memory latency, i.e. it was bound by the latency x bandwidth product, not by MFMA or
-// L2.  So: BK = 32, a 5-slot LDS ring per workgroup (80 KiB, 2 workgroups per CU -> 128 KiB of DMA in flight per CU), loads
-// issued 4 K-steps ahead, COUNTED s_waitcnt vmcnt(N) (never 0 in the steady state) + a raw s_barrier so the DMA queue is
-// never drained inside the K loop.
-// LDS image of an operand stage: [128 rows][32 k] bf16, 64 B per row, 16-B chunk c of row r stored at slot
-// c ^ ((r >> 2) & 3): a ds_read_b128 lane group (16 distinct rows mod 16, one k-chunk) covers all 16 slots of the
+// LDS image of an operand tile: [128 rows][64 k] bf16, 128 B per row, 16-B chunk c of row r stored at slot
+// c ^ ((r >> 1) & 7): a ds_read_b128 lane group (16 distinct rows mod 16, one k-chunk) covers all 16 slots of the
 // 256-B bank row -> conflict free.
-#define NT_NS 5
-#define NT_STAGE_BYTES 16384          // A 8 KiB + B 8 KiB
-__device__ __forceinline__ void nt_stage(const bf16_t* __restrict__ G, int ld, int row0, int k0, char* lds_tile, int w, int l) {
+// per-lane element offsets of the 4 DMA pieces a wave contributes to one operand tile (constant over the K loop);
+// the K-step only moves the wave-uniform base pointer, so the loads use the saddr + 32-bit voffset form
+struct NtLane { int off[4]; };
+__device__ __forceinline__ NtLane nt_lane_offsets(int ld, int w, int l) {
+    NtLane o;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        int R0 = w * 32 + q * 16;
-        int r = R0 + (l >> 2), s = l & 3;
-        int c = s ^ ((r >> 2) & 3);
-        glds16(G + (size_t)(row0 + r) * ld + k0 + c * 8, lds_tile + R0 * 64);
+    for (int q = 0; q < 4; ++q) {
+        const int r = w * 32 + q * 8 + (l >> 3), s = l & 7;
+        o.off[q] = r * ld + ((s ^ ((r >> 1) & 7)) << 3);
     }
+    return o;
+}
+__device__ __forceinline__ void nt_stage(const bf16_t* __restrict__ base, const NtLane& o, char* lds_tile, int w) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16(base + o.off[q], lds_tile + (w * 32 + q * 8) * 128);
 }
 __device__ __forceinline__ bf16x8 nt_frag(const char* lds_tile, int r, int c) {
-    return *reinterpret_cast<const bf16x8*>(lds_tile + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
-}
-// wait until this wave's loads of the oldest in-flight stage have landed; `younger` = stages issued after it (0..3)
-__device__ __forceinline__ void wait_stage(int younger) {
-    if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return *reinterpret_cast<const bf16x8*>(lds_tile + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
 }
 
 template <int EPI, typename OutT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // NT_NS * 16 KiB ring; reused as fp32 [128][128] in the epilogue
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    __shared__ __attribute__((aligned(16))) char smem[65536];
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id as a scalar: LDS bases / M0 stay in SGPRs
     const int wr = w >> 1, wc = w & 1;
     const int nwg = a.tiles_m * a.tiles_n;
     const int t = xcd_remap(blockIdx.x, nwg);
     // grouped tile order inside each XCD's contiguous range: the ~64 tiles resident on one XCD (32 CUs x 2) form a
-    // GROUP_M x 8 patch, so each A/B panel fetched into the XCD's 4 MiB L2 is shared by 8 tiles
+    // GROUP_M x 8 patch, so each A/B panel fetched into the XCD's 4 MiB L2 is shared by 8 tiles and the resident
+    // working set (8 + 8 panels) stays below the L2 size
     const int gsz_full = GROUP_M * a.tiles_n;
     const int grp = t / gsz_full, first_m = grp * GROUP_M;
     const int gm = min(a.tiles_m - first_m, GROUP_M);
     const int rem = t - grp * gsz_full;
     const int tm = first_m + rem % gm, tn = rem / gm;
     const int m0 = tm * BM, n0 = tn * BN;
-#define slotA(i) (smem + (i) * NT_STAGE_BYTES)
-#define slotB(i) (smem + (i) * NT_STAGE_BYTES + 8192)
+#define bufA(i) (smem + (i) * 32768)
+#define bufB(i) (smem + 16384 + (i) * 32768)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -97,99 +103,124 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.K / 32;
-    // prologue: fill NT_NS-1 slots
-#pragma unroll
-    for (int p = 0; p < NT_NS - 1; ++p)
-        if (p < nk) {
-            nt_stage(a.A, a.lda, m0, p * 32, slotA(p), w, l);
-            nt_stage(a.B, a.ldb, n0, p * 32, slotB(p), w, l);
-        }
-    int slot = 0;
+    const int nk = a.K / BK;
+    PT_DECL
+    const NtLane offA = nt_lane_offsets(a.lda, w, l), offB = nt_lane_offsets(a.ldb, w, l);
+    const bf16_t* pA = a.A + (size_t)m0 * a.lda;
+    const bf16_t* pB = a.B + (size_t)n0 * a.ldb;
+    nt_stage(pA, offA, bufA(0), w);
+    nt_stage(pB, offB, bufB(0), w);
     for (int kt = 0; kt < nk; ++kt) {
-        const int issued_after = min(nk - 1 - kt, NT_NS - 2);   // stages younger than kt currently in flight
-        wait_stage(issued_after);
-        __builtin_amdgcn_s_barrier();                           // stage kt visible to all waves; slot (kt-1)%NS free
-        if (kt + NT_NS - 1 < nk) {
-            const int ps = slot == 0 ? NT_NS - 1 : slot - 1;    // == (kt + NS - 1) % NS
-            nt_stage(a.A, a.lda, m0, (kt + NT_NS - 1) * 32, slotA(ps), w, l);
-            nt_stage(a.B, a.ldb, n0, (kt + NT_NS - 1) * 32, slotB(ps), w, l);
+        PT_A
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        PT_B
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            pA += BK; pB += BK;
+            nt_stage(pA, offA, bufA(cur ^ 1), w);
+            nt_stage(pB, offB, bufB(cur ^ 1), w);
         }
-        const char* tA = slotA(slot);
-        const char* tB = slotB(slot);
+        const char* tA = bufA(cur);
+        const char* tB = bufB(cur);
+        // all 16 fragment reads of the K-step are issued back to back, the 16 MFMAs then retire behind counted
+        // lgkmcnt waits: one exposed LDS latency per K-step instead of four (phase timers: 1510 -> see profiles/)
+        bf16x8 fa[4][2], fb[4][2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < 4; ++kk) {
             const int c = kk * 2 + (l >> 5);
-            bf16x8 fa[2], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = nt_frag(tA, wr * 64 + i * 32 + (l & 31), c);
+            for (int i = 0; i < 2; ++i) fa[kk][i] = nt_frag(tA, wr * 64 + i * 32 + (l & 31), c);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = nt_frag(tB, wc * 64 + j * 32 + (l & 31), c);
+            for (int j = 0; j < 2; ++j) fb[kk][j] = nt_frag(tB, wc * 64 + j * 32 + (l & 31), c);
+        }
+        // operands swapped (B fragment first): D[row = n][col = m], so a lane owns ONE output row m = lane&31 and
+        // 4 consecutive n per register quad -> the epilogue stores straight from registers, no LDS round trip
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+        // schedule: 8 reads up front, then one read behind each of the first 8 MFMAs, then the last 8 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        slot = slot == NT_NS - 1 ? 0 : slot + 1;
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#ifdef AMDSEG_PHASE_TIMERS
+        asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][1][15]));
+        asm volatile("s_nop 0" ::: "memory");
+#endif
+        PT_C
     }
-    // ---- epilogue: accumulators -> LDS (fp32 [128][128]) -> coalesced 16 B/lane stores
-    __syncthreads();
-    float* sm = reinterpret_cast<float*>(smem);
+#ifdef AMDSEG_PHASE_TIMERS
+    const unsigned long long pt_loop_end = __builtin_readcyclecounter();
+#endif
+    // ---- epilogue straight from the accumulators: lane (row m, 4 consecutive n) -> 8-B (bf16) / 16-B (fp32) accesses
+    const int hi = l >> 5;
+    float4 bv[2][4];
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = wc * 64 + j * 32 + (l & 31);
-            float bv = 0.f;
-            if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) bv = a.bias[n0 + n];
+            for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const float4*>(a.bias + n0 + wc * 64 + j * 32 + q * 8 + hi * 4);
+    }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-                sm[m * BN + n] = acc[i][j][r] + bv;
+    for (int i = 0; i < 2; ++i) {
+        const size_t gm = (size_t)(m0 + wr * 64 + i * 32 + (l & 31));
+        uint2 rr[2][4];
+        if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {        // all operand loads of this row block first, then the math
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    rr[j][q] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + n0 + wc * 64 + j * 32 + q * 8 + hi * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gn = n0 + wc * 64 + j * 32 + q * 8 + hi * 4;
+                float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+                    v[0] += bv[j][q].x; v[1] += bv[j][q].y; v[2] += bv[j][q].z; v[3] += bv[j][q].w;
+                }
+                if (EPI == EPI_BIAS_GELU) {
+                    uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(a.C2 + gm * a.ldc2 + gn) = pk;      // pre-activation u, kept for backward
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+                    const float r0 = __uint_as_float(rr[j][q].x << 16), r1 = __uint_as_float(rr[j][q].x & 0xffff0000u);
+                    const float r2 = __uint_as_float(rr[j][q].y << 16), r3 = __uint_as_float(rr[j][q].y & 0xffff0000u);
+                    if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
+                    else { v[0] *= gelu_grad_fast(r0); v[1] *= gelu_grad_fast(r1); v[2] *= gelu_grad_fast(r2); v[3] *= gelu_grad_fast(r3); }
+                }
+                OutT* dst = reinterpret_cast<OutT*>(a.C) + gm * a.ldc + gn;
+                if (sizeof(OutT) == 2) {
+                    uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                }
             }
-        }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int chunk = it * 256 + tid;
-        const int r = chunk >> 4, cc = (chunk & 15) * 8;
-        float v[8];
-        {
-            float4 x = *reinterpret_cast<const float4*>(sm + r * BN + cc);
-            float4 y = *reinterpret_cast<const float4*>(sm + r * BN + cc + 4);
-            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
-        }
-        const size_t gm_ = (size_t)(m0 + r);
-        const int gn = n0 + cc;
-        if (EPI == EPI_BIAS_GELU) {
-            st8<bf16_t>(a.C2 + gm_ * a.ldc2 + gn, v);     // pre-activation u, kept for backward
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
-        } else if (EPI == EPI_ADD_RES) {
-            float rr[8]; ld8<bf16_t>(a.R + gm_ * a.ldr + gn, rr);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rr[e];
-        } else if (EPI == EPI_GELU_BWD) {
-            float u[8]; ld8<bf16_t>(a.R + gm_ * a.ldr + gn, u);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast(u[e]);
-        }
-        st8<OutT>(reinterpret_cast<OutT*>(a.C) + gm_ * a.ldc + gn, v);
     }
+#ifdef AMDSEG_PHASE_TIMERS
+    if (a.dbg && l == 0) {
+        const unsigned long long pt_end = __builtin_readcyclecounter();
+        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + w) * 4;
+        d[0] = pt_wait; d[1] = pt_comp; d[2] = pt_loop_end - pt_start; d[3] = pt_end - pt_loop_end;
+    }
+#endif
 }
 
-#define NT_LDS_BYTES (NT_NS * NT_STAGE_BYTES)
 template <int EPI, typename OutT>
 static int launch_nt(const GemmNTArgs& a, hipStream_t s) {
-    static bool attr_set = false;          // > 64 KiB of dynamic LDS must be opted into once per kernel
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<EPI, OutT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(256), NT_LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }
 
@@ -197,10 +228,15 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
                         int epi, const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32,
                         hipStream_t stream) {
     if (!A || !B || !C) return AMDSEG_ERR_ARG;
-    if (M <= 0 || N <= 0 || K <= 0 || (M % BM) || (N % BN) || (K % 32)) return AMDSEG_ERR_SHAPE;
+    if (M <= 0 || N <= 0 || K <= 0 || (M % BM) || (N % BN) || (K % BK)) return AMDSEG_ERR_SHAPE;
     if ((lda % 8) || (ldb % 8) || (ldc % 8)) return AMDSEG_ERR_SHAPE;
     GemmNTArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = bias; a.R = (const bf16_t*)R; a.C2 = (bf16_t*)C2;
+    a.dbg = nullptr;
+#ifdef AMDSEG_PHASE_TIMERS
+    extern unsigned long long* g_amdseg_dbg;
+    a.dbg = g_amdseg_dbg;
+#endif
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldc2 = ldc2; a.M = M; a.N = N; a.K = K;
     a.tiles_m = M / BM; a.tiles_n = N / BN;
     switch (epi) {
@@ -229,8 +265,8 @@ struct GemmTNArgs { TNProblem p[AMDSEG_MAX_GROUP]; int nprob, M, accumulate, tot
 
 __device__ __forceinline__ void tn_stage(const bf16_t* __restrict__ G, int ld, int m0, int col0, char* lds_tile, int w, int l) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        int R0 = w * 8 + q * 4;
+    for (int q = 0; q < 4; ++q) {
+        int R0 = w * 16 + q * 4;
         int r = R0 + (l >> 4), s = l & 15;
         int c = s ^ ((r & 3) << 2);
         glds16(G + (size_t)(m0 + r) * ld + col0 + c * 8, lds_tile + R0 * 256);
@@ -251,9 +287,8 @@ __device__ __forceinline__ bf16x8 tn_frag(const char* lds_tile, int col, int kk,
     return f;
 }
 
-// same 5-slot LDS ring / counted-vmcnt pipeline as gemm_nt (stage = [32 m][128] of A + [32 m][128] of B = 16 KiB)
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) char smem[65536];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int wr = w >> 1, wc = w & 1;
     const int t = xcd_remap(blockIdx.x, a.total_tiles);
@@ -265,6 +300,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNArgs a) {
     const int lt = t - P.tile_begin;
     const int tn_ = lt / P.tiles_k, tk = lt - tn_ * P.tiles_k;
     const int n0 = tn_ * 128, k0 = tk * 128;
+#define bufA(i) (smem + (i) * 32768)
+#define bufB(i) (smem + 16384 + (i) * 32768)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -274,26 +311,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nm = a.M / 32;
-#pragma unroll
-    for (int p = 0; p < NT_NS - 1; ++p)
-        if (p < nm) {
-            tn_stage(P.A, P.lda, p * 32, n0, slotA(p), w, l);
-            tn_stage(P.B, P.ldb, p * 32, k0, slotB(p), w, l);
-        }
-    int slot = 0;
+    const int nm = a.M / 64;
+    tn_stage(P.A, P.lda, 0, n0, bufA(0), w, l);
+    tn_stage(P.B, P.ldb, 0, k0, bufB(0), w, l);
     for (int mt = 0; mt < nm; ++mt) {
-        wait_stage(min(nm - 1 - mt, NT_NS - 2));
-        __builtin_amdgcn_s_barrier();
-        if (mt + NT_NS - 1 < nm) {
-            const int ps = slot == 0 ? NT_NS - 1 : slot - 1;
-            tn_stage(P.A, P.lda, (mt + NT_NS - 1) * 32, n0, slotA(ps), w, l);
-            tn_stage(P.B, P.ldb, (mt + NT_NS - 1) * 32, k0, slotB(ps), w, l);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = mt & 1;
+        if (mt + 1 < nm) {
+            tn_stage(P.A, P.lda, (mt + 1) * 64, n0, bufA(cur ^ 1), w, l);
+            tn_stage(P.B, P.ldb, (mt + 1) * 64, k0, bufB(cur ^ 1), w, l);
         }
-        const char* tA = slotA(slot);
-        const char* tB = slotB(slot);
+        const char* tA = bufA(cur);
+        const char* tB = bufB(cur);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < 4; ++kk) {
             bf16x8 fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) fa[i] = tn_frag(tA, wr * 64 + i * 32, kk, l);
@@ -305,7 +337,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNArgs a) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        slot = slot == NT_NS - 1 ? 0 : slot + 1;
     }
     __syncthreads();
     float* sm = reinterpret_cast<float*>(smem);
@@ -339,7 +370,7 @@ int amdseg_gemm_tn_grouped_impl(int nprob, const void* const* A, const int* lda,
                                 float* const* C, const int* ldc, const int* N, const int* Kp, int M, int accumulate,
                                 hipStream_t stream) {
     if (nprob <= 0 || nprob > AMDSEG_MAX_GROUP || !A || !B || !C) return AMDSEG_ERR_ARG;
-    if (M <= 0 || (M % 32)) return AMDSEG_ERR_SHAPE;
+    if (M <= 0 || (M % 64)) return AMDSEG_ERR_SHAPE;
     GemmTNArgs a;
     int tiles = 0;
     for (int i = 0; i < nprob; ++i) {
@@ -353,12 +384,6 @@ int amdseg_gemm_tn_grouped_impl(int nprob, const void* const* A, const int* lda,
     }
     for (int i = nprob; i < AMDSEG_MAX_GROUP; ++i) a.p[i] = a.p[0];
     a.nprob = nprob; a.M = M; a.accumulate = accumulate; a.total_tiles = tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles), dim3(256), NT_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles), dim3(256), 0, stream, a);
     return amdseg_launch_status();
 }
