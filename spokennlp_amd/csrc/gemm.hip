@@ -218,9 +218,225 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
 #endif
 }
 
+static int g_force_small_tile = 0;      // test hook (amdseg_debug_force_small_tile): exercise the 128x128 kernel on big shapes
+int amdseg_set_force_small_tile(int v) { int o = g_force_small_tile; g_force_small_tile = v; return o; }
+
+// ------------------------------------------------------------------------------------------------ gemm_nt, ping-pong 256x192
+// Large-shape kernel (M % 256 == 0, N % 192 == 0): one 512-thread workgroup per CU computes a 256 x 192 tile.
+// Why this shape: every projection of the encoder has N in {768, 2304, 3072} = {4, 12, 16} x 192 and M = 64 x 256 at the
+// bench size, so the tile count is an exact multiple of 256 CUs (no tail), and it moves 0.0091 B/FLOP from L2 instead of
+// the 0.0156 of a 128 x 128 tile.
+// Why ping-pong: the 8 waves form two groups of 4 (hardware puts wave w and w+4 on the same SIMD).  Group g owns output
+// columns [96 g, 96 g + 96); wave q of a group owns rows [64 q, 64 q + 64): 2 x 3 fragments of v_mfma_f32_32x32x16_bf16.
+// Every half K-step is a phase ended by s_barrier; in each phase one group only moves data (10 ds_read_b128 fragment
+// loads, and once per K-step its share of the global->LDS staging) while the other group only issues MFMAs (12 per wave)
+// from registers, then they swap, so each SIMD's matrix pipe is fed by one wave while the other hides memory latency:
+//   phase 4t   : G0 stage + mem(t,0)      | G1 mfma(t-1,1)
+//   phase 4t+1 : G0 mfma(t,0)             | G1 stage + mem(t,0)
+//   phase 4t+2 : G0 mem(t,1)              | G1 mfma(t,0)
+//   phase 4t+3 : G0 mfma(t,1)             | G1 mem(t,1)
+// Staging: global_load_lds DMA (16 B/lane) into a 2-stage LDS ring (2 x 56 KiB), the stage for K-step t+1 is issued in
+// the first data phase of K-step t and awaited (vmcnt(0)) before the last barrier of K-step t.  Measured alternatives
+// (profiles/r01_gemm_experiments.md): register staging two K-steps deeper and an L2 "touch" prefetch were both slower.
+// LDS image = 128-B rows, XOR-swizzled via the per-lane SOURCE address: SQ_LDS_BANK_CONFLICT = 0.
+#define PP_BM 256
+#define PP_BN 192
+#define PP_STAGE 57344
+#define PP_LDS (2 * PP_STAGE)
+#ifndef PP_ABL_NO_DMA
+#define PP_ABL_NO_DMA 0
+#endif
+#ifndef PP_ABL_NO_MFMA
+#define PP_ABL_NO_MFMA 0
+#endif
+#ifndef PP_ABL_NO_READ
+#define PP_ABL_NO_READ 0
+#endif
+
+struct PpLane { int a[4]; int b[3]; };
+
 template <int EPI, typename OutT>
-static int launch_nt(const GemmNTArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = w >> 2, wq = w & 3;
+    const int nwg = a.tiles_m * a.tiles_n;
+    const int t_ = xcd_remap(blockIdx.x, nwg);
+    const int gsz_full = GROUP_M * a.tiles_n;
+    const int gidx = t_ / gsz_full, first_m = gidx * GROUP_M;
+    const int gm_ = min(a.tiles_m - first_m, GROUP_M);
+    const int rem = t_ - gidx * gsz_full;
+    const int tm = first_m + rem % gm_, tn = rem / gm_;
+    const int m0 = tm * PP_BM, n0 = tn * PP_BN;
+
+    // DMA pieces of this wave: A rows [32 w, 32 w + 32) (4 pieces of 8 rows), B rows [24 w, 24 w + 24) (3 pieces)
+    PpLane off;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int r = w * 32 + q * 8 + (l >> 3), sl = l & 7; off.a[q] = r * a.lda + ((sl ^ ((r >> 1) & 7)) << 3); }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const int r = w * 24 + q * 8 + (l >> 3), sl = l & 7; off.b[q] = r * a.ldb + ((sl ^ ((r >> 1) & 7)) << 3); }
+    const bf16_t* pA = a.A + (size_t)m0 * a.lda;
+    const bf16_t* pB = a.B + (size_t)n0 * a.ldb;
+#define PP_DMA(stage_base)                                                                                   \
+    do {                                                                                                     \
+        if (PP_ABL_NO_DMA) break;                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(pA + off.a[q], (stage_base) + (w * 32 + q * 8) * 128); \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) glds16(pB + off.b[q], (stage_base) + 32768 + (w * 24 + q * 8) * 128); \
+    } while (0)
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 fa[2][2] = {}, fb[2][3] = {};          // fragments of one half K-step: [kk][frag]
+
+    const int rowA = wq * 64 + (l & 31);            // + i*32
+    const int rowB = grp * 96 + (l & 31);           // + j*32
+    const int hi = l >> 5;
+#define PP_MEM(stage_base, h)                                                                                \
+    do {                                                                                                     \
+        if (PP_ABL_NO_READ) break;                                                                           \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                   \
+            const int c = ((h) * 2 + kk) * 2 + hi;                                                           \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) fa[kk][i] = nt_frag((stage_base), rowA + i * 32, c); \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j) fb[kk][j] = nt_frag((stage_base) + 32768, rowB + j * 32, c); \
+        }                                                                                                    \
+    } while (0)
+#define PP_MFMA()                                                                                            \
+    do {                                                                                                     \
+        if (PP_ABL_NO_MFMA) { asm volatile("" :: "v"(fa[0][0]), "v"(fa[1][1]), "v"(fb[0][0]), "v"(fb[1][2]), "v"(fb[0][1]), "v"(fb[1][0]), "v"(fa[0][1]), "v"(fa[1][0]), "v"(fb[0][2]), "v"(fb[1][1])); break; } \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                     \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                    \
+                _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+    } while (0)
+#define PP_SYNC_MEM() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#define PP_SYNC() __builtin_amdgcn_s_barrier()
+
+    const int nk = a.K / BK;
+    // prologue: stage 0
+    PP_DMA(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (grp == 0) {
+        for (int t = 0; t < nk; ++t) {
+            char* cur = smem + (t & 1) * PP_STAGE;
+            char* nxt = smem + ((t + 1) & 1) * PP_STAGE;
+            // phase 4t: DMA(t+1) + mem(t,0)
+            if (t + 1 < nk) { pA += BK; pB += BK; PP_DMA(nxt); }
+            PP_MEM(cur, 0);
+            PP_SYNC_MEM();
+            // phase 4t+1: mfma(t,0)
+            PP_MFMA();
+            PP_SYNC();
+            // phase 4t+2: mem(t,1)
+            PP_MEM(cur, 1);
+            PP_SYNC_MEM();
+            // phase 4t+3: mfma(t,1); then make stage t+1 visible
+            PP_MFMA();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_SYNC();
+        }
+    } else {
+        for (int t = 0; t < nk; ++t) {
+            char* cur = smem + (t & 1) * PP_STAGE;
+            char* nxt = smem + ((t + 1) & 1) * PP_STAGE;
+            // phase 4t: mfma(t-1,1)
+            if (t > 0) PP_MFMA();
+            PP_SYNC();
+            // phase 4t+1: DMA(t+1) + mem(t,0)
+            if (t + 1 < nk) { pA += BK; pB += BK; PP_DMA(nxt); }
+            PP_MEM(cur, 0);
+            PP_SYNC_MEM();
+            // phase 4t+2: mfma(t,0)
+            PP_MFMA();
+            PP_SYNC();
+            // phase 4t+3: mem(t,1); then make stage t+1 visible
+            PP_MEM(cur, 1);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            PP_SYNC();
+        }
+        PP_MFMA();                       // phase 4 nk: mfma(nk-1,1) (no LDS use after the loop: no trailing barrier)
+    }
+
+    // ---- epilogue straight from the accumulators (lane: row m, 4 consecutive n per register quad)
+    float4 bv[3][4];
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const float4*>(a.bias + n0 + grp * 96 + j * 32 + q * 8 + hi * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const size_t gm = (size_t)(m0 + wq * 64 + i * 32 + (l & 31));
+        uint2 rr[3][4];
+        if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    rr[j][q] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + n0 + grp * 96 + j * 32 + q * 8 + hi * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gn = n0 + grp * 96 + j * 32 + q * 8 + hi * 4;
+                float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+                    v[0] += bv[j][q].x; v[1] += bv[j][q].y; v[2] += bv[j][q].z; v[3] += bv[j][q].w;
+                }
+                if (EPI == EPI_BIAS_GELU) {
+                    uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(a.C2 + gm * a.ldc2 + gn) = pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+                    const float r0 = __uint_as_float(rr[j][q].x << 16), r1 = __uint_as_float(rr[j][q].x & 0xffff0000u);
+                    const float r2 = __uint_as_float(rr[j][q].y << 16), r3 = __uint_as_float(rr[j][q].y & 0xffff0000u);
+                    if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
+                    else { v[0] *= gelu_grad_fast(r0); v[1] *= gelu_grad_fast(r1); v[2] *= gelu_grad_fast(r2); v[3] *= gelu_grad_fast(r3); }
+                }
+                OutT* dst = reinterpret_cast<OutT*>(a.C) + gm * a.ldc + gn;
+                if (sizeof(OutT) == 2) {
+                    uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+    }
+}
+
+template <int EPI, typename OutT>
+static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
+    // tile choice (measured at M = 16384, tools/bench_kernels.py): the 256x192 ping-pong kernel wins for long K (its one
+    // workgroup per CU pays an exposed prologue + epilogue per tile), the 128x128 kernel (2 workgroups per CU overlap each
+    // other's prologue/epilogue) for K <= 768; shapes the small kernel cannot tile always take the ping-pong kernel
+    const bool pp_ok = (a_in.M % PP_BM) == 0 && (a_in.N % PP_BN) == 0;
+    const bool small_ok = (a_in.M % BM) == 0 && (a_in.N % BN) == 0;
+    if (pp_ok && !(g_force_small_tile && small_ok) && (a_in.K >= 1536 || !small_ok || g_force_small_tile < 0)) {
+        static bool attr_set = false;          // > 64 KiB of dynamic LDS is opted into once per kernel instantiation
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<EPI, OutT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        GemmNTArgs a = a_in;
+        a.tiles_m = a.M / PP_BM; a.tiles_n = a.N / PP_BN;
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(512), PP_LDS, s, a);
+        return amdseg_launch_status();
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a_in.tiles_m * a_in.tiles_n), dim3(256), 0, s, a_in);
     return amdseg_launch_status();
 }
 
@@ -228,7 +444,8 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
                         int epi, const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32,
                         hipStream_t stream) {
     if (!A || !B || !C) return AMDSEG_ERR_ARG;
-    if (M <= 0 || N <= 0 || K <= 0 || (M % BM) || (N % BN) || (K % BK)) return AMDSEG_ERR_SHAPE;
+    const bool big = (M % PP_BM) == 0 && (N % PP_BN) == 0, small = (M % BM) == 0 && (N % BN) == 0;
+    if (M <= 0 || N <= 0 || K <= 0 || !(big || small) || (K % BK)) return AMDSEG_ERR_SHAPE;
     if ((lda % 8) || (ldb % 8) || (ldc % 8)) return AMDSEG_ERR_SHAPE;
     GemmNTArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = bias; a.R = (const bf16_t*)R; a.C2 = (bf16_t*)C2;
@@ -289,7 +506,8 @@ __device__ __forceinline__ bf16x8 tn_frag(const char* lds_tile, int col, int kk,
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[65536];
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 1, wc = w & 1;
     const int t = xcd_remap(blockIdx.x, a.total_tiles);
     int pi = 0;
@@ -324,19 +542,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNArgs a) {
         }
         const char* tA = bufA(cur);
         const char* tB = bufB(cur);
+        bf16x8 fa[4][2], fb[4][2];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 fa[2], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = tn_frag(tA, wr * 64 + i * 32, kk, l);
+            for (int i = 0; i < 2; ++i) fa[kk][i] = tn_frag(tA, wr * 64 + i * 32, kk, l);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = tn_frag(tB, wc * 64 + j * 32, kk, l);
+            for (int j = 0; j < 2; ++j) fb[kk][j] = tn_frag(tB, wc * 64 + j * 32, kk, l);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+        // 16 transpose reads up front, then two more behind each of the first 8 MFMAs, then the last 8 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     }
     __syncthreads();
     float* sm = reinterpret_cast<float*>(smem);

@@ -77,6 +77,39 @@ def test_gemm_nt_epilogues(dev):
     assert rel_err(C, base * gelu_grad(R.float())) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 192, 64), (512, 384, 320), (768, 960, 128)])
+def test_gemm_nt_pingpong_kernel_epilogues(dev, M, N, K):
+    """shapes with M % 256 == 0 and N % 192 == 0 take the 256x192 ping-pong kernel; all epilogues + fp32 output."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(M * 3 + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16()
+    B = (torch.randn(N, K, generator=g) * 0.1).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    R = torch.randn(M, N, generator=g).to(dev).bfloat16()
+    base = A.float() @ B.float().t()
+    assert rel_err(ops.gemm_nt(A, B, ops.EPI_NONE, out_dtype=torch.float32), base) < 2e-6
+    assert rel_err(ops.gemm_nt(A, B, ops.EPI_BIAS, bias=bias, out_dtype=torch.float32), base + bias) < 2e-6
+    Cb = ops.gemm_nt(A, B, ops.EPI_BIAS, bias=bias)
+    assert torch.equal(Cb, ops.gemm_nt(A, B, ops.EPI_BIAS, bias=bias, out_dtype=torch.float32).bfloat16())
+    H, U = ops.gemm_nt(A, B, ops.EPI_BIAS_GELU, bias=bias)
+    assert rel_err(U, base + bias) < 4e-3 and rel_err(H, gelu(base + bias)) < 4e-3
+    assert rel_err(ops.gemm_nt(A, B, ops.EPI_ADD_RES, R=R, out_dtype=torch.float32), base + R.float()) < 2e-6
+    assert rel_err(ops.gemm_nt(A, B, ops.EPI_GELU_BWD, R=R), base * gelu_grad(R.float())) < 4e-3
+    # asymmetric small-integer operands: exact, catches any row/col or fragment swap
+    A2 = torch.zeros(M, K, device=dev); B2 = torch.zeros(N, K, device=dev)
+    A2[:, 0] = torch.arange(M, device=dev) % 61; B2[:, 0] = 1.0
+    B2[:, 1] = torch.arange(N, device=dev) % 53; A2[:, 1] = 1.0
+    assert torch.equal(ops.gemm_nt(A2.bfloat16(), B2.bfloat16(), ops.EPI_NONE, out_dtype=torch.float32), A2 @ B2.t())
+    # strided operands / output inside wider buffers
+    Abig = torch.randn(M, 2 * K, generator=g).to(dev).bfloat16()
+    out = torch.zeros(M, 2 * N, dtype=torch.float32, device=dev)
+    from spokennlp_amd import lib as L
+    rc = L.load().amdseg_gemm_nt(Abig[:, K:].data_ptr(), 2 * K, B.data_ptr(), K, out[:, N:].data_ptr(), 2 * N, M, N, K, 0, None, None, 0,
+                                 None, 0, 1, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert rel_err(out[:, N:], Abig[:, K:].float() @ B.float().t()) < 2e-6 and out[:, :N].abs().max().item() == 0
+
+
 def test_gemm_nt_strided_views(dev):
     """operands / outputs that are column slices of wider buffers (ld != width)."""
     ops = _ops()
