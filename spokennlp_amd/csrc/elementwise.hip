@@ -15,10 +15,10 @@
 #define MAXCH 4                 // up to 4 chunks of 8 elements per lane -> H <= 2048
 #define ROWS_PER_BLOCK 4        // one wave per row, 4 waves per block
 
-template <typename T>
-__device__ __forceinline__ void row_load(const T* row, int nch, int l, float (&v)[MAXCH][8]) {
+template <typename T, int NCH>
+__device__ __forceinline__ void row_load(const T* row, int nch, int l, float (&v)[NCH][8]) {
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
         if (ch < nch) ld8<T>(row + ch * 8, v[c]);
         else {
@@ -27,18 +27,19 @@ __device__ __forceinline__ void row_load(const T* row, int nch, int l, float (&v
         }
     }
 }
-template <typename T>
-__device__ __forceinline__ void row_store(T* row, int nch, int l, const float (&v)[MAXCH][8]) {
+template <typename T, int NCH>
+__device__ __forceinline__ void row_store(T* row, int nch, int l, const float (&v)[NCH][8]) {
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
         if (ch < nch) st8<T>(row + ch * 8, v[c]);
     }
 }
-__device__ __forceinline__ void row_stats(const float (&v)[MAXCH][8], int nch, int l, int H, float eps, float& mean, float& rstd) {
+template <int NCH>
+__device__ __forceinline__ void row_stats(const float (&v)[NCH][8], int nch, int l, int H, float eps, float& mean, float& rstd) {
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c)
+    for (int c = 0; c < NCH; ++c)
         if (l + c * 64 < nch) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += v[c][e];
@@ -46,7 +47,7 @@ __device__ __forceinline__ void row_stats(const float (&v)[MAXCH][8], int nch, i
     mean = wave_sum(s) / (float)H;
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c)
+    for (int c = 0; c < NCH; ++c)
         if (l + c * 64 < nch) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
@@ -55,7 +56,7 @@ __device__ __forceinline__ void row_stats(const float (&v)[MAXCH][8], int nch, i
 }
 
 // ------------------------------------------------------------------------------------------------ embeddings + LN
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
                                                            const float* word, const float* pos, const float* type,
                                                            const float* gamma, const float* beta, T* z, T* out, float* mean,
@@ -68,9 +69,9 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
     int64_t id = ids[m]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     int64_t tt = type_ids ? type_ids[m] : 0; tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
     int64_t pp = pos_ids ? pos_ids[m] : (int64_t)(m % L); pp = pp < 0 ? 0 : (pp >= npos ? npos - 1 : pp);
-    float v[MAXCH][8];
+    float v[NCH][8];
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
         if (ch < nch) {
             float a[8], b[8], d[8];
@@ -84,12 +85,12 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
             for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
         }
     }
-    if (z) row_store<T>(z + (size_t)m * H, nch, l, v);
+    if (z) row_store<T, NCH>(z + (size_t)m * H, nch, l, v);
     float mu, rs;
     row_stats(v, nch, l, H, eps, mu, rs);
     if (l == 0) { if (mean) mean[m] = mu; if (rstd) rstd[m] = rs; }
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
         if (ch < nch) {
             float gg[8], bb[8];
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
             }
         }
     }
-    row_store<T>(out + (size_t)m * H, nch, l, v);
+    row_store<T, NCH>(out + (size_t)m * H, nch, l, v);
 }
 
 // scatter the embedding-sum gradient dz[M,H] into the three tables
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* dz, const int64
 
 // ------------------------------------------------------------------------------------------------ dropout + residual + LN
 // y (dense output incl. bias) is overwritten by z = resid + dropout(y) (kept for backward); out = LN(z)
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid, const float* gamma, const float* beta, T* out,
                                                          float* mean, float* rstd, int M, int H, float eps, uint32_t thresh,
                                                          float inv_keep, uint64_t seed) {
@@ -140,11 +141,11 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
     const int m = blockIdx.x * ROWS_PER_BLOCK + w;
     if (m >= M) return;
     const int nch = H >> 3;
-    float v[MAXCH][8], x[MAXCH][8];
-    row_load<T>(y_z + (size_t)m * H, nch, l, v);
-    row_load<T>(resid + (size_t)m * H, nch, l, x);
+    float v[NCH][8], x[NCH][8];
+    row_load<T, NCH>(y_z + (size_t)m * H, nch, l, v);
+    row_load<T, NCH>(resid + (size_t)m * H, nch, l, x);
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
         if (ch < nch) {
 #pragma unroll
@@ -155,12 +156,12 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
             }
         }
     }
-    row_store<T>(y_z + (size_t)m * H, nch, l, v);
+    row_store<T, NCH>(y_z + (size_t)m * H, nch, l, v);
     float mu, rs;
     row_stats(v, nch, l, H, eps, mu, rs);
     if (l == 0) { if (mean) mean[m] = mu; if (rstd) rstd[m] = rs; }
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
         if (ch < nch) {
             float gg[8], bb[8];
@@ -169,24 +170,24 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
             for (int e = 0; e < 8; ++e) v[c][e] = (v[c][e] - mu) * rs * gg[e] + bb[e];
         }
     }
-    row_store<T>(out + (size_t)m * H, nch, l, v);
+    row_store<T, NCH>(out + (size_t)m * H, nch, l, v);
 }
 
 // LN backward.  dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  Also emits
 //   dbranch = dz * keepmask / (1-p)   (gradient of the dense output; == dz when p == 0 -> pass dbranch = nullptr)
 //   per-block column partials of dgamma (sum dy*xhat), dbeta (sum dy) and dbias (sum dbranch)
 #define LNB_ROWS 16     // rows per block (4 per wave)
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, const float* mean, const float* rstd,
                                                      const float* gamma, T* dz, T* dbranch, float* partials, int M, int H,
                                                      uint32_t thresh, float inv_keep, uint64_t seed) {
     extern __shared__ float red[];         // [3][4 waves][H]
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nch = H >> 3;
-    float gg[MAXCH][8];
-    float ag[MAXCH][8], ab[MAXCH][8], abias[MAXCH][8];
+    float gg[NCH][8];
+    float ag[NCH][8], ab[NCH][8], abias[NCH][8];
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
         if (ch < nch) ld8<float>(gamma + ch * 8, gg[c]);
 #pragma unroll
@@ -195,13 +196,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
     for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
         const int m = blockIdx.x * LNB_ROWS + rr * 4 + w;
         if (m >= M) break;
-        float g[MAXCH][8], x[MAXCH][8];
-        row_load<T>(dy + (size_t)m * H, nch, l, g);
-        row_load<T>(z + (size_t)m * H, nch, l, x);
+        float g[NCH][8], x[NCH][8];
+        row_load<T, NCH>(dy + (size_t)m * H, nch, l, g);
+        row_load<T, NCH>(z + (size_t)m * H, nch, l, x);
         const float mu = mean[m], rs = rstd[m];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c)
+        for (int c = 0; c < NCH; ++c)
             if (l + c * 64 < nch) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -217,15 +218,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
         s1 = wave_sum(s1) / (float)H;
         s2 = wave_sum(s2) / (float)H;
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c)
+        for (int c = 0; c < NCH; ++c)
             if (l + c * 64 < nch) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[c][e] = rs * (g[c][e] - s1 - x[c][e] * s2);
             }
-        row_store<T>(dz + (size_t)m * H, nch, l, g);
+        row_store<T, NCH>(dz + (size_t)m * H, nch, l, g);
         if (dbranch || partials) {
 #pragma unroll
-            for (int c = 0; c < MAXCH; ++c) {
+            for (int c = 0; c < NCH; ++c) {
                 const int ch = l + c * 64;
                 if (ch < nch) {
 #pragma unroll
@@ -237,13 +238,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
                     }
                 }
             }
-            if (dbranch) row_store<T>(dbranch + (size_t)m * H, nch, l, g);
+            if (dbranch) row_store<T, NCH>(dbranch + (size_t)m * H, nch, l, g);
         }
     }
     if (!partials) return;
     // cross-wave reduce through LDS, then one partial row per block
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
         if (ch < nch) {
 #pragma unroll
@@ -294,6 +295,35 @@ __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const floa
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sum += red[r][threadIdx.x];
+            out[cc] = accumulate ? out[cc] + sum : sum;
+        }
+    }
+}
+// three reductions in one launch (LayerNorm backward: dgamma, dbeta, dbias); blockIdx.y selects the output
+struct Reduce3 { const float* part[3]; float* out[3]; };
+__global__ __launch_bounds__(256) void reduce3_kernel(Reduce3 r, int nblocks, int n, int accumulate) {
+    __shared__ float red[16][64];
+    float* out = r.out[blockIdx.y];
+    if (!out) return;
+    const float* partials = r.part[blockIdx.y];
+    const int cg = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cg * 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c + 3 < n) {
+#pragma unroll 4
+        for (int b = ry; b < nblocks; b += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(partials + (size_t)b * n + c);
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        }
+    }
+    red[ry][cg * 4 + 0] = a0; red[ry][cg * 4 + 1] = a1; red[ry][cg * 4 + 2] = a2; red[ry][cg * 4 + 3] = a3;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cc = blockIdx.x * 64 + threadIdx.x;
+        if (cc < n) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += red[q][threadIdx.x];
             out[cc] = accumulate ? out[cc] + sum : sum;
         }
     }
@@ -377,18 +407,18 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* W, bf1
 
 // ------------------------------------------------------------------------------------------------ small-C row dot (heads)
 // logits[m][c] = x[m,:] . W[c,:] + b[c]   (classifier H->2, TSSP H->3;  modules/loss_calculator.py:17,42, modules/tssp.py:14,31)
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* x, const float* W, const float* b, float* out, int M, int H, int C) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int m = blockIdx.x * ROWS_PER_BLOCK + w;
     if (m >= M) return;
     const int nch = H >> 3;
-    float v[MAXCH][8];
-    row_load<T>(x + (size_t)m * H, nch, l, v);
+    float v[NCH][8];
+    row_load<T, NCH>(x + (size_t)m * H, nch, l, v);
     for (int c = 0; c < C; ++c) {
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < MAXCH; ++k) {
+        for (int k = 0; k < NCH; ++k) {
             const int ch = l + k * 64;
             if (ch < nch) {
                 float ww[8]; ld8<float>(W + (size_t)c * H + ch * 8, ww);
@@ -401,27 +431,27 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* x, const float
     }
 }
 // dx[m,:] = sum_c dl[m][c] W[c,:] ; partial dW[c,:] = sum_m dl[m][c] x[m,:] ; partial db[c] = sum_m dl[m][c]   (C <= 4)
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* x, const float* W, const float* dl, T* dx, float* partials,
                                                          int M, int H, int C) {
     extern __shared__ float red[];      // [4 waves][C][H]
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nch = H >> 3;
-    float aw[4][MAXCH][8];
+    float aw[4][NCH][8];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int k = 0; k < MAXCH; ++k)
+        for (int k = 0; k < NCH; ++k)
 #pragma unroll
             for (int e = 0; e < 8; ++e) aw[c][k][e] = 0.f;
     float adb[4] = {0.f, 0.f, 0.f, 0.f};
     for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
         const int m = blockIdx.x * LNB_ROWS + rr * 4 + w;
         if (m >= M) break;
-        float v[MAXCH][8], o[MAXCH][8];
-        row_load<T>(x + (size_t)m * H, nch, l, v);
+        float v[NCH][8], o[NCH][8];
+        row_load<T, NCH>(x + (size_t)m * H, nch, l, v);
 #pragma unroll
-        for (int k = 0; k < MAXCH; ++k)
+        for (int k = 0; k < NCH; ++k)
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[k][e] = 0.f;
 #pragma unroll
@@ -430,7 +460,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* x, const float
                 const float d = dl[(size_t)m * C + c];
                 adb[c] += d;
 #pragma unroll
-                for (int k = 0; k < MAXCH; ++k) {
+                for (int k = 0; k < NCH; ++k) {
                     const int ch = l + k * 64;
                     if (ch < nch) {
                         float ww[8]; ld8<float>(W + (size_t)c * H + ch * 8, ww);
@@ -440,14 +470,14 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* x, const float
                 }
             }
         }
-        if (dx) row_store<T>(dx + (size_t)m * H, nch, l, o);
+        if (dx) row_store<T, NCH>(dx + (size_t)m * H, nch, l, o);
     }
     if (!partials) return;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (c < C) {
 #pragma unroll
-            for (int k = 0; k < MAXCH; ++k) {
+            for (int k = 0; k < NCH; ++k) {
                 const int ch = l + k * 64;
                 if (ch < nch) {
 #pragma unroll
@@ -471,6 +501,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* x, const float
         partials[(size_t)blockIdx.x * PW + C * H + threadIdx.x] = red[0 * 4 + threadIdx.x] + red[1 * 4 + threadIdx.x] + red[2 * 4 + threadIdx.x] + red[3 * 4 + threadIdx.x];
 }
 
+#define ROWK(K, T, H, ...) do { if ((H) <= 1024) hipLaunchKernelGGL((K<T, 2>), __VA_ARGS__); else hipLaunchKernelGGL((K<T, 4>), __VA_ARGS__); } while (0)
 // ------------------------------------------------------------------------------------------------ launchers
 static inline void drop_params(float p, uint32_t& thresh, float& inv_keep) {
     if (p <= 0.f) { thresh = 0; inv_keep = 1.f; return; }
@@ -489,10 +520,10 @@ int amdseg_embed_ln_fwd_impl(const int64_t* ids, const int64_t* type_ids, const 
     uint32_t th; float ik; drop_params(p, th, ik);
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     if (dtype == AMDSEG_BF16)
-        hipLaunchKernelGGL(embed_ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, ids, type_ids, pos_ids, word, pos, type, gamma, beta,
+        ROWK(embed_ln_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, ids, type_ids, pos_ids, word, pos, type, gamma, beta,
                            (bf16_t*)z, (bf16_t*)out, mean, rstd, M, L, H, vocab, type_vocab, npos, eps, th, ik, seed);
     else
-        hipLaunchKernelGGL(embed_ln_fwd_kernel<float>, grid, dim3(256), 0, s, ids, type_ids, pos_ids, word, pos, type, gamma, beta,
+        ROWK(embed_ln_fwd_kernel, float, H, grid, dim3(256), 0, s, ids, type_ids, pos_ids, word, pos, type, gamma, beta,
                            (float*)z, (float*)out, mean, rstd, M, L, H, vocab, type_vocab, npos, eps, th, ik, seed);
     return amdseg_launch_status();
 }
@@ -520,10 +551,10 @@ int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamm
     uint32_t th; float ik; drop_params(p, th, ik);
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     if (dtype == AMDSEG_BF16)
-        hipLaunchKernelGGL(add_ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta,
+        ROWK(add_ln_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta,
                            (bf16_t*)out, mean, rstd, M, H, eps, th, ik, seed);
     else
-        hipLaunchKernelGGL(add_ln_fwd_kernel<float>, grid, dim3(256), 0, s, (float*)y_inout_z, (const float*)resid, gamma, beta,
+        ROWK(add_ln_fwd_kernel, float, H, grid, dim3(256), 0, s, (float*)y_inout_z, (const float*)resid, gamma, beta,
                            (float*)out, mean, rstd, M, H, eps, th, ik, seed);
     return amdseg_launch_status();
 }
@@ -538,15 +569,17 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
     const int nblk = (M + LNB_ROWS - 1) / LNB_ROWS;
     const size_t shm = (size_t)3 * 4 * H * sizeof(float);
     if (dtype == AMDSEG_BF16)
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), shm, s, (const bf16_t*)dy, (const bf16_t*)z, mean, rstd,
+        ROWK(ln_bwd_kernel, bf16_t, H, dim3(nblk), dim3(256), shm, s, (const bf16_t*)dy, (const bf16_t*)z, mean, rstd,
                            gamma, (bf16_t*)dz, (bf16_t*)dbranch, partials, M, H, th, ik, seed);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nblk), dim3(256), shm, s, (const float*)dy, (const float*)z, mean, rstd, gamma,
+        ROWK(ln_bwd_kernel, float, H, dim3(nblk), dim3(256), shm, s, (const float*)dy, (const float*)z, mean, rstd, gamma,
                            (float*)dz, (float*)dbranch, partials, M, H, th, ik, seed);
     if (partials) {
-        if (dgamma) launch_reduce(partials, nblk, H, 0, H, dgamma, accumulate, s);
-        if (dbeta) launch_reduce(partials + (size_t)nblk * H, nblk, H, 0, H, dbeta, accumulate, s);
-        if (dbias) launch_reduce(partials + (size_t)2 * nblk * H, nblk, H, 0, H, dbias, accumulate, s);
+        Reduce3 r;
+        r.part[0] = partials; r.part[1] = partials + (size_t)nblk * H; r.part[2] = partials + (size_t)2 * nblk * H;
+        r.out[0] = dgamma; r.out[1] = dbeta; r.out[2] = dbias;
+        if ((H % 4) == 0 && (dgamma || dbeta || dbias))
+            hipLaunchKernelGGL(reduce3_kernel, dim3((H + 63) / 64, 3), dim3(256), 0, s, r, nblk, H, accumulate);
     }
     return amdseg_launch_status();
 }
@@ -600,9 +633,9 @@ int amdseg_rowdot_fwd_impl(const void* x, const float* W, const float* b, float*
     if (M <= 0 || C <= 0 || C > 4 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     if (dtype == AMDSEG_BF16)
-        hipLaunchKernelGGL(rowdot_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, W, b, out, M, H, C);
+        ROWK(rowdot_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, (const bf16_t*)x, W, b, out, M, H, C);
     else
-        hipLaunchKernelGGL(rowdot_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)x, W, b, out, M, H, C);
+        ROWK(rowdot_fwd_kernel, float, H, grid, dim3(256), 0, s, (const float*)x, W, b, out, M, H, C);
     return amdseg_launch_status();
 }
 
@@ -614,9 +647,9 @@ int amdseg_rowdot_bwd_impl(const void* x, const float* W, const float* dlogits, 
     const int nblk = (M + LNB_ROWS - 1) / LNB_ROWS;
     const size_t shm = (size_t)4 * C * H * sizeof(float);
     if (dtype == AMDSEG_BF16)
-        hipLaunchKernelGGL(rowdot_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), shm, s, (const bf16_t*)x, W, dlogits, (bf16_t*)dx, partials, M, H, C);
+        ROWK(rowdot_bwd_kernel, bf16_t, H, dim3(nblk), dim3(256), shm, s, (const bf16_t*)x, W, dlogits, (bf16_t*)dx, partials, M, H, C);
     else
-        hipLaunchKernelGGL(rowdot_bwd_kernel<float>, dim3(nblk), dim3(256), shm, s, (const float*)x, W, dlogits, (float*)dx, partials, M, H, C);
+        ROWK(rowdot_bwd_kernel, float, H, dim3(nblk), dim3(256), shm, s, (const float*)x, W, dlogits, (float*)dx, partials, M, H, C);
     if (partials) {
         const int PW = C * H + C;
         // partial rows are [C*H | C]; reduce weights and biases with a strided view: treat as N = PW columns
