@@ -44,6 +44,31 @@ class _LossCalculator(nn.Module):
         self.tssp = _TSSP(config)
 
 
+class _IndexUploader:
+    """collects the step's host-built index lists and uploads them with one pinned, asynchronous H2D copy."""
+
+    def __init__(self, device):
+        self.device, self.flat, self.dev = device, [], None
+
+    def add(self, lst):
+        off = len(self.flat)
+        self.flat.extend(lst)
+        return (off, len(lst))
+
+    def flush(self):
+        n = max(len(self.flat), 1)
+        if self.device.type == "cuda":
+            buf = torch.empty(n, dtype=torch.long, pin_memory=True)
+            if self.flat:
+                buf.copy_(torch.tensor(self.flat, dtype=torch.long))
+            self.dev = buf.to(self.device, non_blocking=True)
+        else:
+            self.dev = torch.tensor(self.flat or [0], dtype=torch.long)
+
+    def get(self, h):
+        return self.dev[h[0]:h[0] + h[1]]
+
+
 def _topic_segment_ids(label_rows):
     ids, seg = [], 0
     for ex in label_rows:
@@ -127,71 +152,51 @@ class BertWithDAForSentenceLabelingTopicSegmentation(BertPreTrainedModel):
         """host-side index lists: per example the positions with label != -100 and their labels."""
         pos, lab = [], []
         for row in labels_cpu:
-            idx = (row != -100).nonzero(as_tuple=False).flatten()
+            idx = (row != -100).nonzero(as_tuple=False).flatten().tolist()
             pos.append(idx); lab.append(row[idx].tolist())
         return pos, lab
 
-    def _cos_sim(self, seq, pos, temp):
-        """utils.py:111-138: cos(row_i, row_{(i+1)%n}) / temp, padded with -100 to the batch max."""
-        B, Lq, H = seq.shape
+    # ---- host planning: every index list of the step is built on the host from the (already fetched) label tensors,
+    #      packed into ONE pinned buffer and uploaded with ONE async copy; the device math below never synchronises.
+    def _plan_cos(self, up, pos, Lq):
         mx = max((len(p) for p in pos), default=0)
-        out = torch.full((B, mx), -100.0, dtype=seq.dtype, device=seq.device)
-        rows_a, rows_b, dst_b, dst_j = [], [], [], []
+        rows_a, rows_b, dst = [], [], []
         for b, p in enumerate(pos):
             n = len(p)
             if n == 0:
                 continue
-            base = b * Lq
-            a = (p + base).tolist()
+            a = [q + b * Lq for q in p]
             rows_a += a
             rows_b += a[1:] + a[:1]
-            dst_b += [b] * n
-            dst_j += list(range(n))
-        if rows_a:
-            flat = seq.reshape(B * Lq, H)
-            ia = torch.tensor(rows_a, device=seq.device); ib = torch.tensor(rows_b, device=seq.device)
-            xa, xb = flat[ia], flat[ib]
-            cs = (xa * xb).sum(-1) if temp == 0 else F.cosine_similarity(xa, xb, dim=-1) / temp
-            out[torch.tensor(dst_b, device=seq.device), torch.tensor(dst_j, device=seq.device)] = cs
-        return out
+            dst += [b * mx + j for j in range(n)]
+        return dict(mx=mx, n=len(rows_a), a=up.add(rows_a), b=up.add(rows_b), dst=up.add(dst))
 
-    def _cssl(self, seq, pos, lab):
-        """cssl.py:230-274 with the degenerate amax pooling replaced by the equivalent row gather (SURVEY 8a-7)."""
+    def _plan_cssl(self, up, pos, lab, Lq):
+        """index lists of cssl.py:118-228 (same Python `random` call sequence as the reference)."""
         cfg = self.config
-        B, Lq, H = seq.shape
-        rows = [int(p_) + b * Lq for b, p in enumerate(pos) for p_ in p.tolist()]
+        rows = [q + b * Lq for b, p in enumerate(pos) for q in p]
         seg = _topic_segment_ids(lab)
-        zero = seq.new_zeros(())
         if not (len(seg) > 2 and seg[-1] > 0):
-            return zero
-        feats = seq.reshape(B * Lq, H)[torch.tensor(rows, device=seq.device)]
+            return None
         n = len(seg)
         total_topic = seg[-1] + 1
         bot = [seg.index(i) for i in range(total_topic)]
         eot = [v - 1 for v in bot[1:]] + [n - 1]
+        plan = dict(level=cfg.cl_anchor_level, n=n, rows=up.add(rows))
         if cfg.cl_anchor_level == "eop_matrix":
-            seg_t = torch.tensor(seg, device=seq.device)
-            same = seg_t[:, None] == seg_t[None, :]
-            num_mask = same & ~torch.eye(n, dtype=torch.bool, device=seq.device)
-            e = torch.exp(_cos(feats.unsqueeze(1), feats.unsqueeze(0), cfg.cl_temp))
-            num = (num_mask * e).sum(0)
-            den = num + ((~same) * e).sum(0)
-            prob = num / den
-            sel = prob != 0
-            if bool(torch.isnan(prob).any()) or int(sel.sum()) == 0:
-                return zero
-            return (-torch.log(prob[sel])).mean()
+            plan["seg"] = up.add(seg)
+            return plan
         pk, nk = cfg.cl_positive_k, cfg.cl_negative_k
         pos_i = [[] for _ in range(pk)]
         neg_i = [[] for _ in range(nk)]
         if cfg.cl_anchor_level == "eop_list":
             for idx, t in enumerate(seg):
-                s, e_ = bot[t], eot[t]
-                choice = list(range(s, e_)) or [e_]
+                s_, e_ = bot[t], eot[t]
+                choice = list(range(s_, e_)) or [e_]
                 pid = idx
                 for i in range(pk):
                     pid -= 1
-                    if pid < s:
+                    if pid < s_:
                         pid = random.choice(choice)
                     pos_i[i].append(pid)
                 choice = list(range(e_ + 1, eot[-1] + 1)) or list(range(bot[0], bot[1]))
@@ -201,14 +206,14 @@ class BertWithDAForSentenceLabelingTopicSegmentation(BertPreTrainedModel):
                     if pid >= n:
                         pid = random.choice(choice)
                     neg_i[i].append(pid)
-            anchors = feats
+            plan["anchors"] = None
         elif cfg.cl_anchor_level == "eot_list":
-            for s, e_ in zip(bot, eot):
-                choice = list(range(s, e_)) or [e_]
+            for s_, e_ in zip(bot, eot):
+                choice = list(range(s_, e_)) or [e_]
                 pid = e_
                 for i in range(pk):
                     pid -= 1
-                    if pid < s:
+                    if pid < s_:
                         pid = random.choice(choice)
                     pos_i[i].append(pid)
             for e_ in eot:
@@ -219,43 +224,102 @@ class BertWithDAForSentenceLabelingTopicSegmentation(BertPreTrainedModel):
                     if pid >= n:
                         pid = random.choice(choice)
                     neg_i[i].append(pid)
-            anchors = feats[torch.tensor(eot, device=seq.device)]
+            plan["anchors"] = up.add(eot)
         else:
             raise ValueError("not supported cl_anchor_level %s " % cfg.cl_anchor_level)
-        sims = [_cos(anchors, feats[torch.tensor(ix, device=seq.device)], cfg.cl_temp).unsqueeze(0) for ix in pos_i + neg_i]
+        plan["lists"] = [up.add(ix) for ix in pos_i + neg_i]
+        return plan
+
+    def _plan_tssp(self, up, stm_cpu, spo_cpu, Lq):
+        rows, labs = [], []
+        for b in range(stm_cpu.shape[0]):
+            idx = (stm_cpu[b] != -100).nonzero(as_tuple=False).flatten().tolist()
+            rows += [q + b * Lq for q in idx]
+            row = spo_cpu[b]
+            labs += row[row != -100].tolist()
+        return dict(rows=up.add(rows), labs=up.add(labs), n=len(rows))
+
+    # ---- device math (no host synchronisation)
+    def _cos_sim(self, seq, up, plan, temp):
+        """utils.py:111-138: cos(row_i, row_{(i+1)%n}) / temp, padded with -100 to the batch max."""
+        B, Lq, H = seq.shape
+        out = torch.full((B * max(plan["mx"], 1),), -100.0, dtype=seq.dtype, device=seq.device)
+        if plan["n"]:
+            flat = seq.reshape(B * Lq, H)
+            xa, xb = flat[up.get(plan["a"])], flat[up.get(plan["b"])]
+            cs = (xa * xb).sum(-1) if temp == 0 else F.cosine_similarity(xa, xb, dim=-1) / temp
+            out = out.index_put((up.get(plan["dst"]),), cs)
+        return out.view(B, max(plan["mx"], 1))[:, :plan["mx"]] if plan["mx"] else out.view(B, 1)[:, :0]
+
+    def _cssl(self, seq, up, plan):
+        """cssl.py:230-274 with the degenerate amax pooling replaced by the equivalent row gather (SURVEY 8a-7)."""
+        cfg = self.config
+        if plan is None:
+            return seq.new_zeros(())
+        B, Lq, H = seq.shape
+        feats = seq.reshape(B * Lq, H)[up.get(plan["rows"])]
+        n = plan["n"]
+        if plan["level"] == "eop_matrix":
+            seg_t = up.get(plan["seg"])
+            same = seg_t[:, None] == seg_t[None, :]
+            num_mask = same & ~torch.eye(n, dtype=torch.bool, device=seq.device)
+            e = torch.exp(_cos(feats.unsqueeze(1), feats.unsqueeze(0), cfg.cl_temp))
+            num = (num_mask * e).sum(0)
+            den = num + ((~same) * e).sum(0)
+            prob = num / den
+            sel = prob != 0          # reference: mean of -log(prob) over prob != 0 (cssl.py:64-71), done without a host sync
+            cnt = sel.sum().clamp(min=1)
+            return (torch.where(sel, -torch.log(torch.where(sel, prob, torch.ones_like(prob))), torch.zeros_like(prob)).sum() / cnt)
+        pk = cfg.cl_positive_k
+        anchors = feats if plan["anchors"] is None else feats[up.get(plan["anchors"])]
+        sims = [_cos(anchors, feats[up.get(h)], cfg.cl_temp).unsqueeze(0) for h in plan["lists"]]
         e = torch.exp(torch.cat(sims))
         return (-torch.log(e[:pk].sum(0) / e.sum(0))).mean()
 
-    def _tssp(self, da_seq, sent_token_mask, sent_pair_orders):
+    def _tssp(self, da_seq, up, plan):
         """tssp.py:16-36 (returns w * CE; the caller multiplies by w again, loss_calculator.py:71)."""
         cfg = self.config
-        feats = da_seq[sent_token_mask != -100]
-        tl = sent_pair_orders[sent_pair_orders != -100]
+        B, Lq, H = da_seq.shape
+        feats = da_seq.reshape(B * Lq, H)[up.get(plan["rows"])]
         logits = F.linear(feats, self.loss_calculator.tssp.classifier.weight, self.loss_calculator.tssp.classifier.bias)
-        return cfg.tssp_loss_weight * F.cross_entropy(logits.reshape(-1, cfg.num_tssp_labels), tl.reshape(-1))
+        return cfg.tssp_loss_weight * F.cross_entropy(logits.reshape(-1, cfg.num_tssp_labels), up.get(plan["labs"]))
 
-    def _loss_calculator(self, seq, labels, labels_cpu, sent_token_mask=None, sent_pair_orders=None, da_example_flag=False,
-                         need_cos=True):
+    def _plan_half(self, up, labels_cpu, Lq, da_example_flag, need_cos, stm_cpu=None, spo_cpu=None):
         cfg = self.config
         pos, lab = self._labelled_rows(labels_cpu)
-        cos = self._cos_sim(seq, pos, cfg.ts_score_predictor_cos_temp) if need_cos else None
+        plan = dict(pos=pos, lab=lab, cos=None, cssl=None, tssp=None)
+        if need_cos:
+            plan["cos"] = self._plan_cos(up, pos, Lq)
+        if not da_example_flag and cfg.cl_loss_weight != 0:
+            plan["cssl"] = self._plan_cssl(up, pos, lab, Lq)
+            plan["has_cssl"] = True
+        if da_example_flag and cfg.tssp_loss_weight != 0:
+            plan["tssp"] = self._plan_tssp(up, stm_cpu, spo_cpu, Lq)
+        if cfg.ts_score_predictor == "cos":
+            mx = plan["cos"]["mx"]
+            flat = []
+            for l_ in lab:
+                flat += l_ + [-100] * (mx - len(l_))
+            plan["cos_labels"] = up.add(flat)
+        return plan
+
+    def _loss_calculator(self, seq, labels, up, plan, da_example_flag=False):
+        cfg = self.config
+        cos = self._cos_sim(seq, up, plan["cos"], cfg.ts_score_predictor_cos_temp) if plan["cos"] is not None else None
         if cfg.ts_score_predictor == "lt":
             clf = self.loss_calculator.classifier
             logits = RowDotFn.apply(seq, clf.weight, clf.bias)
             ts = self._ts_loss(logits.reshape(-1, cfg.num_labels), labels.reshape(-1))
         elif cfg.ts_score_predictor == "cos":
-            cos_labels = torch.full(cos.shape, -100, dtype=torch.long)
-            for b, l_ in enumerate(lab):
-                cos_labels[b, :len(l_)] = torch.tensor(l_, dtype=torch.long)
-            ts = F.binary_cross_entropy_with_logits(cos.reshape(-1), cos_labels.to(cos.device).reshape(-1).float())
+            ts = F.binary_cross_entropy_with_logits(cos.reshape(-1), up.get(plan["cos_labels"]).float())
             logits = torch.sigmoid(cos)
         else:
             raise ValueError("not supported ts_score_predictor %s" % cfg.ts_score_predictor)
         loss = cfg.ts_loss_weight * ts
         if not da_example_flag and cfg.cl_loss_weight != 0:
-            loss = loss + cfg.cl_loss_weight * self._cssl(seq, pos, lab)
+            loss = loss + cfg.cl_loss_weight * self._cssl(seq, up, plan["cssl"])
         if da_example_flag and cfg.tssp_loss_weight != 0:
-            loss = loss + cfg.tssp_loss_weight * self._tssp(seq, sent_token_mask, sent_pair_orders)
+            loss = loss + cfg.tssp_loss_weight * self._tssp(seq, up, plan["tssp"])
         return loss, logits, cos
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -287,27 +351,53 @@ class BertWithDAForSentenceLabelingTopicSegmentation(BertPreTrainedModel):
             attention_mask = torch.ones_like(input_ids)
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
-        labels_cpu = labels.cpu() if labels is not None else None        # the one host fetch, before any kernel is queued
+        # the host fetch of the step: label-like tensors are copied to pinned memory BEFORE the encoder kernels are queued
+        # and awaited AFTER, so the copy only waits for the previous step's tail and all host-side index building below
+        # overlaps the encoder running on the GPU
         two_pass = bool(cfg.do_da_ts or cfg.do_tssp)
+        need_tssp = two_pass and labels is not None and cfg.tssp_loss_weight != 0
+        host, ev = {}, None
+        if labels is not None:
+            fetch = {"labels": labels}
+            if need_tssp:
+                fetch["stm"] = sent_token_mask[:, 1]
+                fetch["spo"] = sent_pair_orders[:, 1]
+            for k, t in fetch.items():
+                if t.is_cuda:
+                    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    h.copy_(t, non_blocking=True)
+                    host[k] = h
+                else:
+                    host[k] = t
+            if labels.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
         if two_pass:   # anchor + augmented sequences in one encoder pass of 2B sequences
             ids = torch.cat((input_ids[:, 0], input_ids[:, 1])); am = torch.cat((attention_mask[:, 0], attention_mask[:, 1]))
             tt = torch.cat((token_type_ids[:, 0], token_type_ids[:, 1]))
         else:
             ids, am, tt = input_ids[:, 0].contiguous(), attention_mask[:, 0].contiguous(), token_type_ids[:, 0].contiguous()
         seq = self.encode(ids, am, tt)
+        if ev is not None:
+            ev.synchronize()
         a_seq = seq[:B]
         logits, cos = None, None
         loss = None
         if labels is not None:
-            need_cos = (not (self.training and torch.is_grad_enabled())) or cfg.ts_score_predictor == "cos"
-            a_loss, a_logits, cos = self._loss_calculator(a_seq, labels[:, 0], labels_cpu[:, 0], need_cos=need_cos)
+            train = self.training and torch.is_grad_enabled()
+            need_cos = (not train) or cfg.ts_score_predictor == "cos"
+            up = _IndexUploader(seq.device)
+            a_plan = self._plan_half(up, host["labels"][:, 0], Lq, False, need_cos)
+            d_plan = None
+            if two_pass:
+                d_plan = self._plan_half(up, host["labels"][:, 1], Lq, True, cfg.ts_score_predictor == "cos",
+                                         stm_cpu=host.get("stm"), spo_cpu=host.get("spo"))
+            up.flush()
+            a_loss, a_logits, cos = self._loss_calculator(a_seq, labels[:, 0], up, a_plan)
             loss = a_loss
             logits = torch.cat((a_logits.unsqueeze(1), a_logits.unsqueeze(1)), dim=1)
             if two_pass:
-                d_loss, d_logits, _ = self._loss_calculator(seq[B:], labels[:, 1], labels_cpu[:, 1],
-                                                            sent_token_mask=sent_token_mask[:, 1],
-                                                            sent_pair_orders=sent_pair_orders[:, 1], da_example_flag=True,
-                                                            need_cos=cfg.ts_score_predictor == "cos")
+                d_loss, d_logits, _ = self._loss_calculator(seq[B:], labels[:, 1], up, d_plan, da_example_flag=True)
                 loss = loss + d_loss
                 logits = torch.cat((a_logits.unsqueeze(1), d_logits.unsqueeze(1)), dim=1)
             if cos is None:

@@ -17,6 +17,8 @@
 
 #define HD 64          // head dim
 #define CH 64          // rows per streamed chunk
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
 
 // universal XOR swizzle for [rows][64] bf16 tiles (128 B rows, 8 chunks of 16 B): conflict-free for both the
 // ds_read_b128 fragment reads (16 rows, one chunk) and the tr_b16 gathers (8 rows x 32 B per half-wave)
@@ -64,8 +66,12 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 }
 // dropout on attention probabilities: one 32-bit hash per aligned key pair, 16 bits per element.
 // element (row = bh*L + q, key); keep iff 16-bit field >= thresh16
-__device__ __forceinline__ uint32_t pdrop_bits(uint64_t seed, uint64_t row, int L, int key_even) {
-    return rng_u32(seed, (row * (uint64_t)L + (uint64_t)key_even) >> 1);
+// (one mix32 round over (pair index ^ per-row salt): enough decorrelation for dropout, 1/3 of the integer ops)
+__device__ __forceinline__ uint32_t pdrop_salt(uint64_t seed, uint64_t row) {
+    return mix32((uint32_t)seed ^ (uint32_t)(seed >> 32) * 0x9e3779b9u ^ mix32((uint32_t)row * 0x85ebca6bu + (uint32_t)(row >> 32)));
+}
+__device__ __forceinline__ uint32_t pdrop_bits(uint32_t salt, int key_even) {
+    return mix32(salt + (uint32_t)(key_even >> 1) * 0x9e3779b9u);
 }
 __device__ __forceinline__ float xor_reduce_max_g(float v) {   // across the 4 lane groups sharing l&15
     v = fmaxf(v, __shfl_xor(v, 16, 64));
@@ -108,6 +114,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_part = 0.f;
+    const float sc2 = a.scale * LOG2E;
+    const uint32_t salt = pdrop_salt(a.seed, prow);
 
     const bf16_t* kbase = a.qkv + tok0 * a.H3 + H + h * HD;
     const bf16_t* vbase = a.qkv + tok0 * a.H3 + 2 * H + h * HD;
@@ -135,9 +143,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 bf16x8 fk = at_frag(tK, fc * 16 + i16, kk * 4 + g);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[kk], acc, 0, 0, 0);
             }
+            // scores in the log2 domain: s2 = (q.k * scale + mask) * log2(e), so exp() is the native v_exp_f32 (2^x)
             const float4 mb = *reinterpret_cast<const float4*>(a.mask_bias + tok0 + key0 + fc * 16 + g * 4);
-            s[fc][0] = acc[0] * a.scale + mb.x; s[fc][1] = acc[1] * a.scale + mb.y;
-            s[fc][2] = acc[2] * a.scale + mb.z; s[fc][3] = acc[3] * a.scale + mb.w;
+            s[fc][0] = acc[0] * sc2 + mb.x * LOG2E; s[fc][1] = acc[1] * sc2 + mb.y * LOG2E;
+            s[fc][2] = acc[2] * sc2 + mb.z * LOG2E; s[fc][3] = acc[3] * sc2 + mb.w * LOG2E;
         }
         float cmax = s[0][0];
 #pragma unroll
@@ -145,25 +154,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[fc][r]);
         cmax = xor_reduce_max_g(cmax);
-        const float m_new = fmaxf(m_run, cmax);
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
+        if (__any(cmax > m_run)) {                 // wave-uniform: rescale only when some row's running max grew
+            const float m_new = fmaxf(m_run, cmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_part *= alpha;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int fc = 0; fc < 4; ++fc)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[fc][r] = __expf(s[fc][r] - m_new); psum += s[fc][r]; }
-        l_part = l_part * alpha + psum;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+            for (int r = 0; r < 4; ++r) { s[fc][r] = __builtin_amdgcn_exp2f(s[fc][r] - m_run); psum += s[fc][r]; }
+        l_part += psum;
         if (a.thresh16) {
 #pragma unroll
             for (int fc = 0; fc < 4; ++fc)
 #pragma unroll
                 for (int rp = 0; rp < 2; ++rp) {
-                    const uint32_t u = pdrop_bits(a.seed, prow, a.L, key0 + fc * 16 + g * 4 + rp * 2);
+                    const uint32_t u = pdrop_bits(salt, key0 + fc * 16 + g * 4 + rp * 2);
                     s[fc][rp * 2] = (u & 0xffffu) >= a.thresh16 ? s[fc][rp * 2] * a.inv_keep : 0.f;
                     s[fc][rp * 2 + 1] = (u >> 16) >= a.thresh16 ? s[fc][rp * 2 + 1] * a.inv_keep : 0.f;
                 }
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         pk.y = pack2bf(o[d][2] * inv, o[d][3] * inv);
         *reinterpret_cast<uint2*>(op + d * 16 + g * 4) = pk;
     }
-    if (a.lse && g == 0) a.lse[prow] = m_run + __logf(lsum);
+    if (a.lse && g == 0) a.lse[prow] = (m_run + __builtin_amdgcn_logf(lsum)) * LN2;      // natural-log LSE, as backward expects
 }
 
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
@@ -237,7 +249,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         fdo[0] = *reinterpret_cast<const bf16x8*>(dp + g * 8);
         fdo[1] = *reinterpret_cast<const bf16x8*>(dp + 32 + g * 8);
     }
-    const float lse_q = a.lse[prow], delta_q = a.delta[prow];
+    const float lse2_q = a.lse[prow] * LOG2E, delta_q = a.delta[prow];
+    const float sc2 = a.scale * LOG2E;
+    const uint32_t salt = pdrop_salt(a.seed, prow);
     f32x4 dq[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -275,14 +289,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             if (a.thresh16) {
 #pragma unroll
                 for (int rp = 0; rp < 2; ++rp) {
-                    const uint32_t u = pdrop_bits(a.seed, prow, a.L, key0 + fc * 16 + g * 4 + rp * 2);
+                    const uint32_t u = pdrop_bits(salt, key0 + fc * 16 + g * 4 + rp * 2);
                     keepf[rp * 2] = (u & 0xffffu) >= a.thresh16 ? a.inv_keep : 0.f;
                     keepf[rp * 2 + 1] = (u >> 16) >= a.thresh16 ? a.inv_keep : 0.f;
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(sacc[r] * a.scale + mb[r] - lse_q);
+                const float p = __builtin_amdgcn_exp2f(sacc[r] * sc2 + mb[r] * LOG2E - lse2_q);
                 ds[fc][r] = p * (pacc[r] * keepf[r] - delta_q);
             }
         }
@@ -329,7 +343,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         fv[0] = *reinterpret_cast<const bf16x8*>(vp + g * 8);
         fv[1] = *reinterpret_cast<const bf16x8*>(vp + 32 + g * 8);
     }
-    const float mb = a.mask_bias[tok0 + key];
+    const float mb2 = a.mask_bias[tok0 + key] * LOG2E;
+    const float sc2 = a.scale * LOG2E;
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) { dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -367,10 +382,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             const float ls[4] = {ls4.x, ls4.y, ls4.z, ls4.w}, dl[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(sacc[r] * a.scale + mb - ls[r]);
+                const float p = __builtin_amdgcn_exp2f(sacc[r] * sc2 + mb2 - ls[r] * LOG2E);
                 float keepf = 1.f;
                 if (a.thresh16) {
-                    const uint32_t u = pdrop_bits(a.seed, rbase + r, a.L, key & ~1);
+                    const uint32_t u = pdrop_bits(pdrop_salt(a.seed, rbase + r), key & ~1);
                     const uint32_t f = (key & 1) ? (u >> 16) : (u & 0xffffu);
                     keepf = f >= a.thresh16 ? a.inv_keep : 0.f;
                 }
