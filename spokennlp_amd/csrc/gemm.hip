@@ -14,6 +14,7 @@
 // are remapped so that each XCD (private 4 MiB L2) walks a contiguous run of tiles sharing operand panels.
 #include "common.h"
 #include "amdseg_internal.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -255,34 +256,137 @@ int amdseg_set_force_small_tile(int v) { int o = g_force_small_tile; g_force_sma
 
 struct PpLane { int a[4]; int b[3]; };
 
+// tile t (in XCD-contiguous, GROUP_M-grouped order) -> (m0, n0)
+__device__ __forceinline__ void pp_tile_coords(const GemmNTArgs& a, int t_, int& m0, int& n0) {
+    const int gsz_full = GROUP_M * a.tiles_n;
+    const int gidx = t_ / gsz_full, first_m = gidx * GROUP_M;
+    const int gm_ = min(a.tiles_m - first_m, GROUP_M);
+    const int rem = t_ - gidx * gsz_full;
+    m0 = (first_m + rem % gm_) * PP_BM;
+    n0 = (rem / gm_) * PP_BN;
+}
+// persistent schedule: 256 workgroups (one per CU); workgroup b lives on XCD b & 7 and walks that XCD's contiguous tile
+// range 32 tiles per round, so the 32 CUs of an XCD always work on neighbouring tiles (shared A/B panels in its L2)
+__device__ __forceinline__ int pp_tile_of(int b, int r, int T) {
+    const int x = b & 7, i = b >> 3;
+    const int q = T >> 3, rm = T & 7;
+    const int start = x < rm ? x * (q + 1) : rm * (q + 1) + (x - rm) * q;
+    const int len = q + (x < rm ? 1 : 0);
+    const int idx = r * 32 + i;
+    return idx < len ? start + idx : -1;
+}
+
+// epilogue operands (bias quad or residual / pre-activation tile) are loaded BEFORE the next stage's DMA is queued and the
+// stores are issued AFTER it, so (in-order vmcnt) the K-step can wait for its DMA with vmcnt(#stores) and leave the stores
+// in flight -- waiting for ~100 KB of stores per tile with vmcnt(0) cost 5.7 us per tile (profiles/r01_gemm_experiments.md)
+struct PpEpiRegs { float4 bv[3][4]; uint2 rr[2][3][4]; };
+template <int EPI>
+__device__ __forceinline__ void pp_epi_load(const GemmNTArgs& a, PpEpiRegs& e, int m0, int n0, int grp, int wq, int l) {
+    const int hi = l >> 5;
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e.bv[j][q] = *reinterpret_cast<const float4*>(a.bias + n0 + grp * 96 + j * 32 + q * 8 + hi * 4);
+    }
+    if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t gm = (size_t)(m0 + wq * 64 + i * 32 + (l & 31));
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    e.rr[i][j][q] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + n0 + grp * 96 + j * 32 + q * 8 + hi * 4);
+        }
+    }
+}
+template <int EPI, typename OutT>
+__device__ __forceinline__ void pp_epi_store(const GemmNTArgs& a, const PpEpiRegs& e, f32x16 (&acc)[2][3], int m0, int n0, int grp,
+                                             int wq, int l) {
+    const int hi = l >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const size_t gm = (size_t)(m0 + wq * 64 + i * 32 + (l & 31));
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gn = n0 + grp * 96 + j * 32 + q * 8 + hi * 4;
+                float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+                    v[0] += e.bv[j][q].x; v[1] += e.bv[j][q].y; v[2] += e.bv[j][q].z; v[3] += e.bv[j][q].w;
+                }
+                if (EPI == EPI_BIAS_GELU) {
+                    uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(a.C2 + gm * a.ldc2 + gn) = pk;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = gelu_fast(v[k]);
+                } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+                    const uint2 r = e.rr[i][j][q];
+                    const float r0 = __uint_as_float(r.x << 16), r1 = __uint_as_float(r.x & 0xffff0000u);
+                    const float r2 = __uint_as_float(r.y << 16), r3 = __uint_as_float(r.y & 0xffff0000u);
+                    if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
+                    else { v[0] *= gelu_grad_fast(r0); v[1] *= gelu_grad_fast(r1); v[2] *= gelu_grad_fast(r2); v[3] *= gelu_grad_fast(r3); }
+                }
+                OutT* dst = reinterpret_cast<OutT*>(a.C) + gm * a.ldc + gn;
+                if (sizeof(OutT) == 2) {
+                    uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+// number of store instructions pp_epi_store issues per wave
+template <int EPI> struct PpStores { static constexpr int n = (EPI == EPI_BIAS_GELU) ? 48 : 24; };
+
 template <int EPI, typename OutT>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = w >> 2, wq = w & 3;
-    const int nwg = a.tiles_m * a.tiles_n;
-    const int t_ = xcd_remap(blockIdx.x, nwg);
-    const int gsz_full = GROUP_M * a.tiles_n;
-    const int gidx = t_ / gsz_full, first_m = gidx * GROUP_M;
-    const int gm_ = min(a.tiles_m - first_m, GROUP_M);
-    const int rem = t_ - gidx * gsz_full;
-    const int tm = first_m + rem % gm_, tn = rem / gm_;
-    const int m0 = tm * PP_BM, n0 = tn * PP_BN;
+    const int T = a.tiles_m * a.tiles_n;
+    const int nk = a.K / BK;
+    // tiles of this workgroup (persistent: the K-loops of consecutive tiles form ONE software pipeline, so the DMA of the
+    // next tile's first stage flies during the last K-step of the current tile and the epilogue stores overlap the
+    // next tile's first phases -- no per-tile prologue / re-dispatch bubble)
+    int ntl = 0;
+    while (pp_tile_of(blockIdx.x, ntl, T) >= 0) ++ntl;
+    if (ntl == 0) return;
+    const int total = ntl * nk;
 
-    // DMA pieces of this wave: A rows [32 w, 32 w + 32) (4 pieces of 8 rows), B rows [24 w, 24 w + 24) (3 pieces)
     PpLane off;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int r = w * 32 + q * 8 + (l >> 3), sl = l & 7; off.a[q] = r * a.lda + ((sl ^ ((r >> 1) & 7)) << 3); }
 #pragma unroll
     for (int q = 0; q < 3; ++q) { const int r = w * 24 + q * 8 + (l >> 3), sl = l & 7; off.b[q] = r * a.ldb + ((sl ^ ((r >> 1) & 7)) << 3); }
-    const bf16_t* pA = a.A + (size_t)m0 * a.lda;
-    const bf16_t* pB = a.B + (size_t)n0 * a.ldb;
+    // DMA cursor: (tile round, k) of the NEXT stage to fetch
+    int dr = 0, dk = 0, dm0, dn0;
+    pp_tile_coords(a, pp_tile_of(blockIdx.x, 0, T), dm0, dn0);
+    const bf16_t* pA = a.A + (size_t)dm0 * a.lda;
+    const bf16_t* pB = a.B + (size_t)dn0 * a.ldb;
 #define PP_DMA(stage_base)                                                                                   \
     do {                                                                                                     \
-        if (PP_ABL_NO_DMA) break;                                                                            \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(pA + off.a[q], (stage_base) + (w * 32 + q * 8) * 128); \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q) glds16(pB + off.b[q], (stage_base) + 32768 + (w * 24 + q * 8) * 128); \
+        if (!PP_ABL_NO_DMA) {                                                                                \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(pA + off.a[q], (stage_base) + (w * 32 + q * 8) * 128); \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) glds16(pB + off.b[q], (stage_base) + 32768 + (w * 24 + q * 8) * 128); \
+        }                                                                                                    \
+        if (++dk == nk) {                                                                                    \
+            dk = 0; ++dr;                                                                                    \
+            if (dr < ntl) {                                                                                  \
+                pp_tile_coords(a, pp_tile_of(blockIdx.x, dr, T), dm0, dn0);                                  \
+                pA = a.A + (size_t)dm0 * a.lda; pB = a.B + (size_t)dn0 * a.ldb;                              \
+            }                                                                                                \
+        } else { pA += BK; pB += BK; }                                                                       \
     } while (0)
 
     f32x16 acc[2][3];
@@ -318,101 +422,82 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
     } while (0)
 #define PP_SYNC_MEM() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #define PP_SYNC() __builtin_amdgcn_s_barrier()
+#define PP_WAIT_DMA_KEEP_STORES()                                                                            \
+    do {                                                                                                     \
+        if (PpStores<EPI>::n == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");                        \
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                               \
+    } while (0)
+    PpEpiRegs er;
 
-    const int nk = a.K / BK;
-    // prologue: stage 0
+    // prologue: stage 0 of the first tile
     PP_DMA(smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    if (grp == 0) {
-        for (int t = 0; t < nk; ++t) {
-            char* cur = smem + (t & 1) * PP_STAGE;
-            char* nxt = smem + ((t + 1) & 1) * PP_STAGE;
-            // phase 4t: DMA(t+1) + mem(t,0)
-            if (t + 1 < nk) { pA += BK; pB += BK; PP_DMA(nxt); }
-            PP_MEM(cur, 0);
-            PP_SYNC_MEM();
-            // phase 4t+1: mfma(t,0)
-            PP_MFMA();
-            PP_SYNC();
-            // phase 4t+2: mem(t,1)
-            PP_MEM(cur, 1);
-            PP_SYNC_MEM();
-            // phase 4t+3: mfma(t,1); then make stage t+1 visible
-            PP_MFMA();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PP_SYNC();
-        }
-    } else {
-        for (int t = 0; t < nk; ++t) {
-            char* cur = smem + (t & 1) * PP_STAGE;
-            char* nxt = smem + ((t + 1) & 1) * PP_STAGE;
-            // phase 4t: mfma(t-1,1)
-            if (t > 0) PP_MFMA();
-            PP_SYNC();
-            // phase 4t+1: DMA(t+1) + mem(t,0)
-            if (t + 1 < nk) { pA += BK; pB += BK; PP_DMA(nxt); }
-            PP_MEM(cur, 0);
-            PP_SYNC_MEM();
-            // phase 4t+2: mfma(t,0)
-            PP_MFMA();
-            PP_SYNC();
-            // phase 4t+3: mem(t,1); then make stage t+1 visible
-            PP_MEM(cur, 1);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            PP_SYNC();
-        }
-        PP_MFMA();                       // phase 4 nk: mfma(nk-1,1) (no LDS use after the loop: no trailing barrier)
-    }
+    // compute cursor: tile round cr, k-step ck
+    int cr = 0, ck = 0, cm0, cn0;
+    pp_tile_coords(a, pp_tile_of(blockIdx.x, 0, T), cm0, cn0);
+    int pm0 = cm0, pn0 = cn0;          // tile whose accumulators are complete and await their epilogue
+    bool pending = false;
 
-    // ---- epilogue straight from the accumulators (lane: row m, 4 consecutive n per register quad)
-    float4 bv[3][4];
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const float4*>(a.bias + n0 + grp * 96 + j * 32 + q * 8 + hi * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const size_t gm = (size_t)(m0 + wq * 64 + i * 32 + (l & 31));
-        uint2 rr[3][4];
-        if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    rr[j][q] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + n0 + grp * 96 + j * 32 + q * 8 + hi * 4);
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int gn = n0 + grp * 96 + j * 32 + q * 8 + hi * 4;
-                float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-                if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-                    v[0] += bv[j][q].x; v[1] += bv[j][q].y; v[2] += bv[j][q].z; v[3] += bv[j][q].w;
-                }
-                if (EPI == EPI_BIAS_GELU) {
-                    uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(a.C2 + gm * a.ldc2 + gn) = pk;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
-                } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
-                    const float r0 = __uint_as_float(rr[j][q].x << 16), r1 = __uint_as_float(rr[j][q].x & 0xffff0000u);
-                    const float r2 = __uint_as_float(rr[j][q].y << 16), r3 = __uint_as_float(rr[j][q].y & 0xffff0000u);
-                    if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
-                    else { v[0] *= gelu_grad_fast(r0); v[1] *= gelu_grad_fast(r1); v[2] *= gelu_grad_fast(r2); v[3] *= gelu_grad_fast(r3); }
-                }
-                OutT* dst = reinterpret_cast<OutT*>(a.C) + gm * a.ldc + gn;
-                if (sizeof(OutT) == 2) {
-                    uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(dst) = pk;
-                } else {
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                }
+    if (grp == 0) {
+        for (int s = 0; s < total; ++s) {
+            char* cur = smem + (s & 1) * PP_STAGE;
+            char* nxt = smem + ((s + 1) & 1) * PP_STAGE;
+            // phase 4s: [epilogue of the previous tile] + DMA(s+1) + mem(s,0)       (G1: mfma(s-1,1))
+            const bool epi = pending;
+            if (epi) pp_epi_load<EPI>(a, er, pm0, pn0, grp, wq, l);
+            if (s + 1 < total) PP_DMA(nxt);
+            if (epi) { pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l); pending = false; }
+            PP_MEM(cur, 0);
+            PP_SYNC_MEM();
+            // phase 4s+1: mfma(s,0)
+            PP_MFMA();
+            PP_SYNC();
+            // phase 4s+2: mem(s,1)
+            PP_MEM(cur, 1);
+            PP_SYNC_MEM();
+            // phase 4s+3: mfma(s,1); then make stage s+1 visible (epilogue stores of this K-step may stay in flight)
+            PP_MFMA();
+            if (epi) PP_WAIT_DMA_KEEP_STORES(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_SYNC();
+            if (++ck == nk) {
+                ck = 0; pm0 = cm0; pn0 = cn0; pending = true;
+                if (++cr < ntl) pp_tile_coords(a, pp_tile_of(blockIdx.x, cr, T), cm0, cn0);
             }
+        }
+        pp_epi_load<EPI>(a, er, pm0, pn0, grp, wq, l);
+        pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l);
+    } else {
+        for (int s = 0; s < total; ++s) {
+            char* cur = smem + (s & 1) * PP_STAGE;
+            char* nxt = smem + ((s + 1) & 1) * PP_STAGE;
+            // phase 4s: mfma(s-1,1)
+            if (s > 0) PP_MFMA();
+            PP_SYNC();
+            // phase 4s+1: [epilogue of the previous tile] + DMA(s+1) + mem(s,0)     (G0: mfma(s,0))
+            const bool epi = pending;
+            if (epi) pp_epi_load<EPI>(a, er, pm0, pn0, grp, wq, l);
+            if (s + 1 < total) PP_DMA(nxt);
+            if (epi) { pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l); pending = false; }
+            PP_MEM(cur, 0);
+            PP_SYNC_MEM();
+            // phase 4s+2: mfma(s,0)
+            PP_MFMA();
+            PP_SYNC();
+            // phase 4s+3: mem(s,1); then make stage s+1 visible (epilogue stores of this K-step may stay in flight)
+            PP_MEM(cur, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (epi) PP_WAIT_DMA_KEEP_STORES(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_SYNC();
+            if (++ck == nk) {
+                ck = 0; pm0 = cm0; pn0 = cn0; pending = true;
+                if (++cr < ntl) pp_tile_coords(a, pp_tile_of(blockIdx.x, cr, T), cm0, cn0);
+            }
+        }
+        PP_MFMA();                       // trailing mfma(total-1,1)
+        pp_epi_load<EPI>(a, er, pm0, pn0, grp, wq, l);
+        pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l);
     }
 }
 
@@ -423,7 +508,9 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     // other's prologue/epilogue) for K <= 768; shapes the small kernel cannot tile always take the ping-pong kernel
     const bool pp_ok = (a_in.M % PP_BM) == 0 && (a_in.N % PP_BN) == 0;
     const bool small_ok = (a_in.M % BM) == 0 && (a_in.N % BN) == 0;
-    if (pp_ok && !(g_force_small_tile && small_ok) && (a_in.K >= 1536 || !small_ok || g_force_small_tile < 0)) {
+    static int pp_min_k = -1;
+    if (pp_min_k < 0) { const char* e = getenv("AMDSEG_PP_MIN_K"); pp_min_k = e ? atoi(e) : 1536; }
+    if (pp_ok && !(g_force_small_tile && small_ok) && (a_in.K >= pp_min_k || !small_ok || g_force_small_tile < 0)) {
         static bool attr_set = false;          // > 64 KiB of dynamic LDS is opted into once per kernel instantiation
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<EPI, OutT>),
@@ -433,7 +520,8 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
         }
         GemmNTArgs a = a_in;
         a.tiles_m = a.M / PP_BM; a.tiles_n = a.N / PP_BN;
-        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(512), PP_LDS, s, a);
+        const int T = a.tiles_m * a.tiles_n;
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, OutT>), dim3(T < 256 ? ((T + 7) / 8) * 8 : 256), dim3(512), PP_LDS, s, a);
         return amdseg_launch_status();
     }
     hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a_in.tiles_m * a_in.tiles_n), dim3(256), 0, s, a_in);
