@@ -28,10 +28,11 @@ __device__ __forceinline__ void at_glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(void, lds_wave_base), 16, 0, 0);
 }
 // stage a [64][64] bf16 tile; `base` points at element (row 0, col 0), rows are row_stride elements apart
+template <int NW>
 __device__ __forceinline__ void at_stage(const bf16_t* base, int row_stride, char* tile, int w, int l) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int R0 = (w * 2 + q) * 8;
+    for (int q = 0; q < 8 / NW; ++q) {
+        const int R0 = (w * (8 / NW) + q) * 8;
         const int r = R0 + (l >> 3), s = l & 7;
         const int c = s ^ swz(r);
         at_glds16(base + (size_t)r * row_stride + c * 8, tile + R0 * 128);
@@ -92,13 +93,14 @@ struct AttnArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
-    const int q = qb * 64 + w * 16 + i16;                       // this lane's query row (shared by the 4 g-groups)
+    const int q = qb * (NW * 16) + w * 16 + i16;                       // this lane's query row (shared by the 4 g-groups)
     const uint64_t prow = ((uint64_t)(b * a.heads + h)) * a.L + q;
 #define bufK(i) (smem + (i) * 16384)
 #define bufV(i) (smem + 8192 + (i) * 16384)
@@ -120,15 +122,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const bf16_t* kbase = a.qkv + tok0 * a.H3 + H + h * HD;
     const bf16_t* vbase = a.qkv + tok0 * a.H3 + 2 * H + h * HD;
     const int nch = a.L / CH;
-    at_stage(kbase, a.H3, bufK(0), w, l);
-    at_stage(vbase, a.H3, bufV(0), w, l);
+    at_stage<NW>(kbase, a.H3, bufK(0), w, l);
+    at_stage<NW>(vbase, a.H3, bufV(0), w, l);
     for (int ch = 0; ch < nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = ch & 1;
         if (ch + 1 < nch) {
-            at_stage(kbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
-            at_stage(vbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
+            at_stage<NW>(kbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
+            at_stage<NW>(vbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
         }
         const char* tK = bufK(cur);
         const char* tV = bufV(cur);
@@ -229,13 +231,14 @@ __global__ void attn_delta_kernel(const bf16_t* ctx, const bf16_t* dctx, float* 
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
-    const int q = qb * 64 + w * 16 + i16;
+    const int q = qb * (NW * 16) + w * 16 + i16;
     const uint64_t prow = ((uint64_t)(b * a.heads + h)) * a.L + q;
 #define bufK(i) (smem + (i) * 16384)
 #define bufV(i) (smem + 8192 + (i) * 16384)
@@ -259,15 +262,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const bf16_t* kbase = a.qkv + tok0 * a.H3 + H + h * HD;
     const bf16_t* vbase = a.qkv + tok0 * a.H3 + 2 * H + h * HD;
     const int nch = a.L / CH;
-    at_stage(kbase, a.H3, bufK(0), w, l);
-    at_stage(vbase, a.H3, bufV(0), w, l);
+    at_stage<NW>(kbase, a.H3, bufK(0), w, l);
+    at_stage<NW>(vbase, a.H3, bufV(0), w, l);
     for (int ch = 0; ch < nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = ch & 1;
         if (ch + 1 < nch) {
-            at_stage(kbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
-            at_stage(vbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
+            at_stage<NW>(kbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
+            at_stage<NW>(vbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
         }
         const char* tK = bufK(cur);
         const char* tV = bufV(cur);
@@ -322,13 +325,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
-    const int key = kb * 64 + w * 16 + i16;                    // this lane's key row
+    const int key = kb * (NW * 16) + w * 16 + i16;                    // this lane's key row
     const uint64_t bh = (uint64_t)(b * a.heads + h);
 #define bufQ(i) (smem + (i) * 16384)
 #define bufO(i) (smem + 8192 + (i) * 16384)
@@ -352,15 +356,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     const bf16_t* qbase = a.qkv + tok0 * a.H3 + h * HD;
     const bf16_t* obase = a.dctx + tok0 * H + h * HD;
     const int nch = a.L / CH;
-    at_stage(qbase, a.H3, bufQ(0), w, l);
-    at_stage(obase, H, bufO(0), w, l);
+    at_stage<NW>(qbase, a.H3, bufQ(0), w, l);
+    at_stage<NW>(obase, H, bufO(0), w, l);
     for (int ch = 0; ch < nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = ch & 1;
         if (ch + 1 < nch) {
-            at_stage(qbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufQ(cur ^ 1), w, l);
-            at_stage(obase + (size_t)(ch + 1) * CH * H, H, bufO(cur ^ 1), w, l);
+            at_stage<NW>(qbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufQ(cur ^ 1), w, l);
+            at_stage<NW>(obase + (size_t)(ch + 1) * CH * H, H, bufO(cur ^ 1), w, l);
         }
         const char* tQ = bufQ(cur);
         const char* tO = bufO(cur);
@@ -440,7 +444,8 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
     int rc = attn_fill(a, B, L, heads, scale, p, seed);
     if (rc) return rc;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    if (L % 128 == 0) hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3(L / 128, heads, B), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(L / 64, heads, B), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }
 
@@ -456,7 +461,8 @@ int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ct
     const size_t total = (size_t)B * L * heads * 8;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)ctx,
                        (const bf16_t*)dctx, delta, B, L, heads);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    // backward kernels need 144-168 VGPRs: 4-wave workgroups keep 3 waves per SIMD resident (8-wave ones would spill or halve occupancy)
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3(L / 64, heads, B), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }

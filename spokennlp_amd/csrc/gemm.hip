@@ -242,8 +242,10 @@ int amdseg_set_force_small_tile(int v) { int o = g_force_small_tile; g_force_sma
 // LDS image = 128-B rows, XOR-swizzled via the per-lane SOURCE address: SQ_LDS_BANK_CONFLICT = 0.
 #define PP_BM 256
 #define PP_BN 192
-#define PP_STAGE 57344
-#define PP_LDS (2 * PP_STAGE)
+#define PP_A_SLOT 32768                 // A stage: 256 rows x 128 B
+#define PP_B_SLOT 24576                 // B stage: 192 rows x 128 B
+#define PP_B_BASE (3 * PP_A_SLOT)        // LDS: 3-slot A ring (96 KiB) | 2-slot B ring (48 KiB) = 144 KiB
+#define PP_LDS (3 * PP_A_SLOT + 2 * PP_B_SLOT)
 #ifndef PP_ABL_NO_DMA
 #define PP_ABL_NO_DMA 0
 #endif
@@ -362,6 +364,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
     int ntl = 0;
     while (pp_tile_of(blockIdx.x, ntl, T) >= 0) ++ntl;
     if (ntl == 0) return;
+#ifdef AMDSEG_CLOCK_PROBE
+    const unsigned long long cp_c0 = __builtin_readcyclecounter();
+    unsigned long long cp_r0; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp_r0));
+#endif
     const int total = ntl * nk;
 
     PpLane off;
@@ -369,24 +375,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
     for (int q = 0; q < 4; ++q) { const int r = w * 32 + q * 8 + (l >> 3), sl = l & 7; off.a[q] = r * a.lda + ((sl ^ ((r >> 1) & 7)) << 3); }
 #pragma unroll
     for (int q = 0; q < 3; ++q) { const int r = w * 24 + q * 8 + (l >> 3), sl = l & 7; off.b[q] = r * a.ldb + ((sl ^ ((r >> 1) & 7)) << 3); }
-    // DMA cursor: (tile round, k) of the NEXT stage to fetch
-    int dr = 0, dk = 0, dm0, dn0;
-    pp_tile_coords(a, pp_tile_of(blockIdx.x, 0, T), dm0, dn0);
-    const bf16_t* pA = a.A + (size_t)dm0 * a.lda;
-    const bf16_t* pB = a.B + (size_t)dn0 * a.ldb;
-#define PP_DMA(stage_base)                                                                                   \
+    // DMA cursors: (tile round, k) of the NEXT A stage / B stage to fetch.  A (the activation panel, 57 % of the bytes, shared
+    // by only tiles_n tiles of an XCD -> 1/4 of its lines miss L2 and pay HBM latency) runs TWO K-steps ahead in a 3-slot
+    // ring; B (weights, shared by 8 tiles, L2-resident) one K-step ahead in a 2-slot ring.  144 KiB of the 160 KiB LDS.
+    int arA = 0, akA = 0, arB = 0, akB = 0, tm0, tn0;
+    pp_tile_coords(a, pp_tile_of(blockIdx.x, 0, T), tm0, tn0);
+    const bf16_t* pA = a.A + (size_t)tm0 * a.lda;
+    const bf16_t* pB = a.B + (size_t)tn0 * a.ldb;
+#define PP_DMA_A(slot)                                                                                       \
     do {                                                                                                     \
         if (!PP_ABL_NO_DMA) {                                                                                \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(pA + off.a[q], (stage_base) + (w * 32 + q * 8) * 128); \
-            _Pragma("unroll") for (int q = 0; q < 3; ++q) glds16(pB + off.b[q], (stage_base) + 32768 + (w * 24 + q * 8) * 128); \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) glds16(pA + off.a[q], smem + (slot) * PP_A_SLOT + (w * 32 + q * 8) * 128); \
         }                                                                                                    \
-        if (++dk == nk) {                                                                                    \
-            dk = 0; ++dr;                                                                                    \
-            if (dr < ntl) {                                                                                  \
-                pp_tile_coords(a, pp_tile_of(blockIdx.x, dr, T), dm0, dn0);                                  \
-                pA = a.A + (size_t)dm0 * a.lda; pB = a.B + (size_t)dn0 * a.ldb;                              \
-            }                                                                                                \
-        } else { pA += BK; pB += BK; }                                                                       \
+        if (++akA == nk) {                                                                                   \
+            akA = 0; ++arA;                                                                                  \
+            if (arA < ntl) { pp_tile_coords(a, pp_tile_of(blockIdx.x, arA, T), tm0, tn0); pA = a.A + (size_t)tm0 * a.lda; } \
+        } else pA += BK;                                                                                     \
+    } while (0)
+#define PP_DMA_B(slot)                                                                                       \
+    do {                                                                                                     \
+        if (!PP_ABL_NO_DMA) {                                                                                \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) glds16(pB + off.b[q], smem + PP_B_BASE + (slot) * PP_B_SLOT + (w * 24 + q * 8) * 128); \
+        }                                                                                                    \
+        if (++akB == nk) {                                                                                   \
+            akB = 0; ++arB;                                                                                  \
+            if (arB < ntl) { pp_tile_coords(a, pp_tile_of(blockIdx.x, arB, T), tm0, tn0); pB = a.B + (size_t)tn0 * a.ldb; } \
+        } else pB += BK;                                                                                     \
     } while (0)
 
     f32x16 acc[2][3];
@@ -401,13 +415,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
     const int rowA = wq * 64 + (l & 31);            // + i*32
     const int rowB = grp * 96 + (l & 31);           // + j*32
     const int hi = l >> 5;
-#define PP_MEM(stage_base, h)                                                                                \
+#define PP_MEM(baseA, baseB, h)                                                                              \
     do {                                                                                                     \
         if (PP_ABL_NO_READ) break;                                                                           \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                   \
             const int c = ((h) * 2 + kk) * 2 + hi;                                                           \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) fa[kk][i] = nt_frag((stage_base), rowA + i * 32, c); \
-            _Pragma("unroll") for (int j = 0; j < 3; ++j) fb[kk][j] = nt_frag((stage_base) + 32768, rowB + j * 32, c); \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) fa[kk][i] = nt_frag((baseA), rowA + i * 32, c);    \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j) fb[kk][j] = nt_frag((baseB), rowB + j * 32, c);    \
         }                                                                                                    \
     } while (0)
 #define PP_MFMA()                                                                                            \
@@ -422,17 +436,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
     } while (0)
 #define PP_SYNC_MEM() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #define PP_SYNC() __builtin_amdgcn_s_barrier()
-#define PP_WAIT_DMA_KEEP_STORES()                                                                            \
+// end of K-step s: A(s+1) and B(s+1) must have landed; the younger A(s+2) pieces (4) and this K-step's epilogue stores may fly
+#define PP_WAIT_STAGE(a2, epi)                                                                               \
     do {                                                                                                     \
-        if (PpStores<EPI>::n == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");                        \
-        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                               \
+        const int S_ = PpStores<EPI>::n;                                                                     \
+        if (epi) {                                                                                           \
+            if (a2) { if (S_ == 48) asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); } \
+            else { if (S_ == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); } \
+        } else {                                                                                             \
+            if (a2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        }                                                                                                    \
     } while (0)
     PpEpiRegs er;
 
-    // prologue: stage 0 of the first tile
-    PP_DMA(smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // prologue: A(0), B(0) must land, A(1) stays in flight
+    PP_DMA_A(0);
+    PP_DMA_B(0);
+    if (total > 1) { PP_DMA_A(1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    int sa = 0;                          // s % 3
 
     // compute cursor: tile round cr, k-step ck
     int cr = 0, ck = 0, cm0, cn0;
@@ -442,25 +465,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
 
     if (grp == 0) {
         for (int s = 0; s < total; ++s) {
-            char* cur = smem + (s & 1) * PP_STAGE;
-            char* nxt = smem + ((s + 1) & 1) * PP_STAGE;
-            // phase 4s: [epilogue of the previous tile] + DMA(s+1) + mem(s,0)       (G1: mfma(s-1,1))
-            const bool epi = pending;
+            const char* curA = smem + sa * PP_A_SLOT;
+            const char* curB = smem + PP_B_BASE + (s & 1) * PP_B_SLOT;
+            // phase 4s: [epilogue of the previous tile] + DMA B(s+1), A(s+2) + mem(s,0)       (G1: mfma(s-1,1))
+            const bool epi = pending, a2 = s + 2 < total;
             if (epi) pp_epi_load<EPI>(a, er, pm0, pn0, grp, wq, l);
-            if (s + 1 < total) PP_DMA(nxt);
+            if (s + 1 < total) PP_DMA_B((s + 1) & 1);
+            if (a2) PP_DMA_A(sa == 0 ? 2 : sa - 1);            // (s + 2) % 3
             if (epi) { pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l); pending = false; }
-            PP_MEM(cur, 0);
+            PP_MEM(curA, curB, 0);
             PP_SYNC_MEM();
             // phase 4s+1: mfma(s,0)
             PP_MFMA();
             PP_SYNC();
             // phase 4s+2: mem(s,1)
-            PP_MEM(cur, 1);
+            PP_MEM(curA, curB, 1);
             PP_SYNC_MEM();
-            // phase 4s+3: mfma(s,1); then make stage s+1 visible (epilogue stores of this K-step may stay in flight)
+            // phase 4s+3: mfma(s,1); then make stage s+1 visible
             PP_MFMA();
-            if (epi) PP_WAIT_DMA_KEEP_STORES(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_WAIT_STAGE(a2, epi);
             PP_SYNC();
+            sa = sa == 2 ? 0 : sa + 1;
             if (++ck == nk) {
                 ck = 0; pm0 = cm0; pn0 = cn0; pending = true;
                 if (++cr < ntl) pp_tile_coords(a, pp_tile_of(blockIdx.x, cr, T), cm0, cn0);
@@ -470,26 +495,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
         pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l);
     } else {
         for (int s = 0; s < total; ++s) {
-            char* cur = smem + (s & 1) * PP_STAGE;
-            char* nxt = smem + ((s + 1) & 1) * PP_STAGE;
+            const char* curA = smem + sa * PP_A_SLOT;
+            const char* curB = smem + PP_B_BASE + (s & 1) * PP_B_SLOT;
             // phase 4s: mfma(s-1,1)
             if (s > 0) PP_MFMA();
             PP_SYNC();
-            // phase 4s+1: [epilogue of the previous tile] + DMA(s+1) + mem(s,0)     (G0: mfma(s,0))
-            const bool epi = pending;
+            // phase 4s+1: [epilogue of the previous tile] + DMA B(s+1), A(s+2) + mem(s,0)     (G0: mfma(s,0))
+            const bool epi = pending, a2 = s + 2 < total;
             if (epi) pp_epi_load<EPI>(a, er, pm0, pn0, grp, wq, l);
-            if (s + 1 < total) PP_DMA(nxt);
+            if (s + 1 < total) PP_DMA_B((s + 1) & 1);
+            if (a2) PP_DMA_A(sa == 0 ? 2 : sa - 1);
             if (epi) { pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l); pending = false; }
-            PP_MEM(cur, 0);
+            PP_MEM(curA, curB, 0);
             PP_SYNC_MEM();
             // phase 4s+2: mfma(s,0)
             PP_MFMA();
             PP_SYNC();
-            // phase 4s+3: mem(s,1); then make stage s+1 visible (epilogue stores of this K-step may stay in flight)
-            PP_MEM(cur, 1);
+            // phase 4s+3: mem(s,1); then make stage s+1 visible
+            PP_MEM(curA, curB, 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (epi) PP_WAIT_DMA_KEEP_STORES(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_WAIT_STAGE(a2, epi);
             PP_SYNC();
+            sa = sa == 2 ? 0 : sa + 1;
             if (++ck == nk) {
                 ck = 0; pm0 = cm0; pn0 = cn0; pending = true;
                 if (++cr < ntl) pp_tile_coords(a, pp_tile_of(blockIdx.x, cr, T), cm0, cn0);
@@ -499,6 +526,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
         pp_epi_load<EPI>(a, er, pm0, pn0, grp, wq, l);
         pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l);
     }
+#ifdef AMDSEG_CLOCK_PROBE
+    if (a.dbg && tid == 0) {
+        const unsigned long long cp_c1 = __builtin_readcyclecounter();
+        unsigned long long cp_r1; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp_r1));
+        a.dbg[blockIdx.x * 2] = cp_c1 - cp_c0; a.dbg[blockIdx.x * 2 + 1] = cp_r1 - cp_r0;
+    }
+#endif
 }
 
 template <int EPI, typename OutT>
@@ -538,7 +572,7 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     GemmNTArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = bias; a.R = (const bf16_t*)R; a.C2 = (bf16_t*)C2;
     a.dbg = nullptr;
-#ifdef AMDSEG_PHASE_TIMERS
+#if defined(AMDSEG_PHASE_TIMERS) || defined(AMDSEG_CLOCK_PROBE)
     extern unsigned long long* g_amdseg_dbg;
     a.dbg = g_amdseg_dbg;
 #endif
