@@ -108,7 +108,7 @@ def cpu_baseline(args):
     sd = tiny_state_dict(arch, seed=0, std=0.02)
     params = {k: torch.nn.Parameter(v) for k, v in sd.items()}
     cfg = O.make_cfg(num_labels=2, **arch, **flags)
-    pairs = 4
+    pairs = 2
     docs = data.synth_docs(32, seed=99)
     batch = data.batches_from_docs(docs, args.seq_len, pairs, seed=1)[0]
     opt = torch.optim.AdamW(list(params.values()), lr=5e-5)
@@ -124,7 +124,7 @@ def cpu_baseline(args):
 
     step()
     t0 = time.time(); n = 0
-    while n < 3 or (time.time() - t0 < 10 and n < 20):
+    while n < 2 or (time.time() - t0 < 12 and n < 20):
         step(); n += 1
     dt = (time.time() - t0) / n
     return dict(value=round(nseq / dt, 3), unit="seq/s", cores=threads, kind="port",
@@ -192,7 +192,7 @@ def main():
                                     f"{args.seqs_per_gpu} seqs/GPU/step ({pairs} samples), fwd+bwd+clip+AdamW, dropout 0.1",
                            global_batch=args.seqs_per_gpu * world, seq_len=args.seq_len, parallelism=f"dp{world}"),
                mfma_frac_whole_step=round(value / world * fl / (MFMA_PEAK_TFLOPS * 1e12), 4),
-               final_loss=round(float(loss), 4))
+               final_loss=round(float(loss.detach()), 4))
     if rank == 0:
         if not args.no_roofline:
             out["roofline"] = gemm_roofline(model, args, device)
