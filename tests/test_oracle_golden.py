@@ -109,3 +109,50 @@ def test_amax_pooling_is_a_row_gather():
     for b in range(2):
         rows = seq[b][lab[b] != -100]
         assert torch.equal(pooled[b, 1:1 + rows.shape[0]], rows)
+
+
+# ------------------------------------------------------------------------------------------------ Longformer (a4)
+from oracle import longformer_ts_oracle as LO  # noqa: E402
+
+
+def lf_case(name):
+    z, sd, batch, arch = load_case(name)
+    arch["attention_window"] = [int(v) for v in z["attention_window"]]
+    arch.pop("layer_norm_eps", None)
+    return z, sd, batch, arch
+
+
+@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16"])
+@pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
+def test_longformer_eval_matches_reference(case, variant):
+    z, sd, batch, arch = lf_case(case)
+    cfg = O.make_cfg(num_labels=2, **arch, **flags_of(z, variant)); cfg["layer_norm_eps"] = 1e-5
+    random.seed(int(z[f"{variant}.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos, hs = O.model_forward(sd, cfg, batch, return_hidden=True, encode=LO.longformer_encode)
+    assert abs(loss.item() - float(z[f"{variant}.loss"])) < 2e-5
+    assert np.abs(logits.numpy() - z[f"{variant}.logits"]).max() < 3e-5
+    assert np.abs(cos.numpy() - z[f"{variant}.cos"]).max() < 3e-6
+    if variant == "plain_eval":
+        for i, h in enumerate(hs):
+            assert np.abs(h.numpy() - z[f"plain_eval.hidden{i}"]).max() < 3e-5, i
+
+
+@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16"])
+def test_longformer_train_grads_match_reference(case):
+    z, sd, batch, arch = lf_case(case)
+    cfg = O.make_cfg(num_labels=2, **arch, **flags_of(z, "train_full")); cfg["layer_norm_eps"] = 1e-5
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    random.seed(int(z["train_full.random_seed"]))
+    loss, _, _ = O.model_forward(sd, cfg, batch, encode=LO.longformer_encode)
+    loss.backward()
+    assert abs(loss.item() - float(z["train_full.loss"])) < 3e-5
+    n_checked = 0
+    for k in z.files:
+        if k.startswith("train_full.grad."):
+            n = k[len("train_full.grad."):]
+            g = sd[n].grad
+            g = torch.zeros_like(sd[n]) if g is None else g
+            assert np.abs(g.numpy() - z[k]).max() < 5e-5, n
+            n_checked += 1
+    assert n_checked > 40

@@ -23,7 +23,9 @@ sys.path.insert(0, REF)
 
 from transformers import BertConfig  # noqa: E402
 import models.bert_for_ts as ref_bt  # noqa: E402
+import models.longformer_for_ts as ref_lf  # noqa: E402
 import models.modules.loss_calculator as ref_lc  # noqa: E402
+from transformers import LongformerConfig  # noqa: E402
 from spokennlp_amd import data  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -42,6 +44,7 @@ class TorchProxy:
 
 ref_bt.torch = TorchProxy()
 ref_lc.torch = TorchProxy()
+ref_lf.torch = TorchProxy()
 
 FULL = dict(do_da_ts=True, do_cssl=True, do_tssp=True, ts_loss_weight=1.0, ts_score_predictor="lt", ts_score_predictor_cos_temp=1,
             focal_loss_gamma=0.0, weight_label_zero=0.5, cl_loss_weight=0.5, cl_temp=0.1, cl_anchor_level="eop_list",
@@ -51,12 +54,16 @@ PLAIN = dict(do_da_ts=False, do_cssl=False, do_tssp=False, ts_loss_weight=1.0, t
              cl_positive_k=1, cl_negative_k=1, tssp_loss_weight=0.0, tssp_ablation="none", num_tssp_labels=3)
 
 
-def make_model(arch, flags, seed):
-    cfg = BertConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **arch)
+def make_model(arch, flags, seed, kind="bert"):
+    C = BertConfig if kind == "bert" else LongformerConfig
+    cfg = C(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **arch)
     for k, v in flags.items():
         setattr(cfg, k, v)
     torch.manual_seed(seed)
-    m = ref_bt.BertWithDAForSentenceLabelingTopicSegmentation(cfg)
+    if kind == "bert":
+        m = ref_bt.BertWithDAForSentenceLabelingTopicSegmentation(cfg)
+    else:
+        m = ref_lf.LongformerWithDAForSentenceLabelingTopicSegmentation(cfg)
     with torch.no_grad():       # O(1) logits so that parity is meaningful
         m.loss_calculator.classifier.weight.normal_(0, 0.3)
         m.loss_calculator.tssp.classifier.weight.normal_(0, 0.3)
@@ -68,17 +75,23 @@ def make_model(arch, flags, seed):
     return m, cfg
 
 
-def run_case(name, arch, L, B, seed, variants):
+def run_case(name, arch, L, B, seed, variants, kind="bert"):
     docs = data.synth_docs(8, seed=seed + 11, vocab=arch["vocab_size"], mean_sents=14, sd_sents=5, mean_boundaries=3,
                            mu_tok=1.4 + 0.2 * (L > 64), sigma_tok=0.4)
     batch = data.batches_from_docs(docs, L, B, seed=seed)[0]
-    out = {"arch_keys": np.array(list(arch.keys())), "arch_vals": np.array(list(arch.values())), "L": L, "B": B}
+    if kind == "longformer":        # RoBERTa convention: pad id 1 (position ids depend on it); no real token has id 1
+        batch["input_ids"] = torch.where(batch["attention_mask"] == 0, torch.full_like(batch["input_ids"], arch["pad_token_id"]),
+                                         batch["input_ids"])
+    akeys = [k for k in arch if k != "attention_window"]
+    out = {"arch_keys": np.array(akeys), "arch_vals": np.array([arch[k] for k in akeys]), "L": L, "B": B}
+    if "attention_window" in arch:
+        out["attention_window"] = np.array(arch["attention_window"])
     for k, v in batch.items():
         out["in." + k] = v.numpy()
     saved_sd = False
     for vname, flags, mode, rseed, ts_over in variants:
         fl = dict(flags); fl.update(ts_over)
-        m, cfg = make_model(arch, fl, seed)
+        m, cfg = make_model(arch, fl, seed, kind)
         if not saved_sd:
             for k, v in m.state_dict().items():
                 if "position_ids" in k or "token_type_ids" in k.split(".")[-1]:
@@ -133,6 +146,10 @@ def main():
     ]
     run_case("tiny_L64", arch, 64, 2, 0, variants)
     run_case("tiny_L128", arch, 128, 2, 1, variants[:3])
+    lf = dict(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+              max_position_embeddings=130, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2, layer_norm_eps=1e-5)
+    run_case("lf_tiny_L64_w8", dict(lf, attention_window=[16, 16]), 64, 2, 2, variants[:3], kind="longformer")
+    run_case("lf_tiny_L128_w16", dict(lf, attention_window=[32, 32]), 128, 2, 3, variants[:3], kind="longformer")
 
 
 if __name__ == "__main__":
