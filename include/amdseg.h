@@ -77,6 +77,39 @@ int amdseg_attn_bwd(const void* qkv, const float* mask_bias, const void* ctx, co
                     float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, uint64_t seed,
                     amdseg_stream_t stream);
 
+/* ---- Longformer attention (csrc/attention.hip band variants + csrc/longformer.hip global row) -------------------
+ * Replaces LongformerSelfAttention.forward ([hf] models/longformer/modeling_longformer.py:482-640: sliding chunks
+ * :759-868, global key columns :559-604, global rows :964-1058) as driven by the reference wrapper
+ * emnlp2023-topic_segmentation/src/models/longformer_for_ts.py:55-89 (tokens 0..nglobal-1 global; the wrapper uses
+ * nglobal = 1, [CLS]).  Band variants: key j visible from query i iff j < nglobal or |i-j| <= window
+ * (window = attention_window/2), padded keys carry a large negative mask_bias, rows of padded queries
+ * (mask_bias[q] < 0) are zeroed; only the 64-key chunks intersecting the band are streamed. */
+int amdseg_attn_band_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
+                         float dropout_p, uint64_t seed, int window, int nglobal, amdseg_stream_t stream);
+int amdseg_attn_band_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                         float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, uint64_t seed,
+                         int window, int nglobal, amdseg_stream_t stream);
+int amdseg_attn_band_f32(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, float scale, int window,
+                         int nglobal, amdseg_stream_t stream);
+/* Global row ([hf]:964-1058) with the key_global / value_global projections folded onto the query side (see
+ * csrc/longformer.hip): x [B*L, H] (dtype bf16/fp32), per-(b, head) vectors [B, heads, H] fp32, per-(b, head, token)
+ * coefficient planes [B, heads, L] fp32.  heads <= 16, H <= 1024, L multiple of 64.
+ *   rowvec_dot : out[b,h,j] = vec[b,h,:] . x[b,j,:] + add_tok[b,j] (may be NULL) + add_bh[b,h] (may be NULL)
+ *   softmax_fwd: rows = B*heads rows of L scores; p over the scores in place, pd = dropout(p), sp[row] = sum(pd)
+ *   softmax_bwd: in p (saved) and d(pd) -> ds written over d(pd); pd recomputed
+ *   wsum       : y[b,h,:] = sum_j coef[b,h,j] x[b,j,:]   (partials: B * L/64 * heads * H floats)
+ *   dx_update  : dx[b,j,:] += sum_h coefA[b,h,j] vecA[b,h,:] + coefB[b,h,j] vecB[b,h,:] */
+int amdseg_lf_rowvec_dot(const void* x, const float* vec, const float* add_tok, const float* add_bh, float* out, int B, int L, int H,
+                         int heads, int dtype, amdseg_stream_t stream);
+int amdseg_lf_softmax_fwd(float* s_inout_p, float* pd, float* sp, int rows, int L, float dropout_p, uint64_t seed,
+                          amdseg_stream_t stream);
+int amdseg_lf_softmax_bwd(const float* p_saved, float* dpd_inout_ds, float* pd, int rows, int L, float dropout_p, uint64_t seed,
+                          amdseg_stream_t stream);
+int amdseg_lf_wsum(const void* x, const float* coef, float* partials, float* y, int B, int L, int H, int heads, int dtype,
+                   amdseg_stream_t stream);
+int amdseg_lf_dx_update(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, int B, int L, int H,
+                        int heads, int dtype, amdseg_stream_t stream);
+
 /* ---- HBM-bound row kernels (csrc/elementwise.hip) ---------------------------------------------------------------
  * embeddings + LayerNorm + dropout ([hf] models/bert/modeling_bert.py:53-108); tables are the fp32 masters.
  * pos_ids may be NULL (position = token index % L); z (pre-LN sum), mean, rstd are saved for backward (may be NULL) */
@@ -128,6 +161,12 @@ typedef struct amdseg_bert_cfg {
     int32_t accumulate_grads;       /* weight grads: 0 overwrite, 1 add into existing */
     int32_t dtype;                  /* AMDSEG_BF16 (train + inference) or AMDSEG_F32 (inference parity mode: the
                                        layer params then point at the fp32 master weights, activations are fp32) */
+    int32_t window, nglobal;        /* Longformer layers: band attention (see amdseg_attn_band_fwd); 0, 0 = BERT */
+    int32_t phase;                  /* 0 or 3 = whole layer.  1 / 2 = the part before / after the attention context:
+                                       forward 1 = QKV projection + attention (writes acts.ctx), 2 = the rest;
+                                       backward 1 = from dy down to ws.dctx, 2 = attention backward, dx_in, all weight
+                                       gradients.  A Longformer caller overwrites the global token's ctx row between
+                                       forward phases and consumes + zeroes its dctx row between backward phases. */
 } amdseg_bert_cfg;
 
 typedef struct amdseg_bert_layer_params {   /* bf16 compute shadows (+ transposes for dgrad), fp32 vectors */

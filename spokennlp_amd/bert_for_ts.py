@@ -89,32 +89,23 @@ def _cos(x, y, temp):
     return F.cosine_similarity(x, y, dim=-1) / temp
 
 
-class BertWithDAForSentenceLabelingTopicSegmentation(BertPreTrainedModel):
-    _keys_to_ignore_on_load_unexpected = [r"pooler"]
+class TopicSegHeadsMixin:
+    """everything of the reference wrappers that is encoder-agnostic (bert_for_ts.py:35-113 == longformer_for_ts.py:34-129
+    == electra_for_ts.py / bigbird_for_ts.py): the anchor/augmented split, LossCalculator, CSSL, TSSP, cos-sim output.
+    The concrete class provides `engine()` (the HIP encoder engine over its HF parameter container)."""
 
-    def __init__(self, config):
-        for k, v in HEAD_DEFAULTS.items():
-            if not hasattr(config, k):
-                setattr(config, k, v)
-        super().__init__(config)
-        self.config = config
-        self.bert = BertModel(config)          # parameter container only (HF names); its torch forward is never called
-        classifier_dropout = config.classifier_dropout if config.classifier_dropout is not None else config.hidden_dropout_prob
+    def _init_heads(self, config, classifier_dropout):
         self.classifier_dropout_p = float(classifier_dropout)
         self.loss_calculator = _LossCalculator(config)
-        self.post_init()
         self._engine = None
         self._step_seed = 0
         self.amdseg_seed = 0
 
-    # ------------------------------------------------------------------------------------------------ engine plumbing
-    def engine(self):
-        p = next(self.parameters())
-        if not p.is_cuda:
-            raise L.AmdsegError("spokennlp_amd runs on MI355X only: move the model to a cuda device (no CPU fallback)")
-        if self._engine is None or not self._engine.fp.intact() or self._engine.device != p.device:
-            self._engine = BertEncoderEngine(self, self.config, p.device, bert_attr="bert")
-        return self._engine
+    @staticmethod
+    def _fill_head_defaults(config):
+        for k, v in HEAD_DEFAULTS.items():
+            if not hasattr(config, k):
+                setattr(config, k, v)
 
     def _next_seed(self):
         self._step_seed += 1
@@ -404,3 +395,26 @@ class BertWithDAForSentenceLabelingTopicSegmentation(BertPreTrainedModel):
                 cos = torch.full((B, 1), -100.0, device=seq.device)
         output = (logits, cos)
         return ((loss,) + output) if loss is not None else output
+
+
+class BertWithDAForSentenceLabelingTopicSegmentation(TopicSegHeadsMixin, BertPreTrainedModel):
+    _keys_to_ignore_on_load_unexpected = [r"pooler"]
+
+    def __init__(self, config):
+        self._fill_head_defaults(config)
+        super().__init__(config)
+        self.config = config
+        self.bert = BertModel(config)          # parameter container only (HF names); its torch forward is never called
+        classifier_dropout = config.classifier_dropout if config.classifier_dropout is not None else config.hidden_dropout_prob
+        self._init_heads(config, classifier_dropout)
+        self.post_init()
+
+    # ------------------------------------------------------------------------------------------------ engine plumbing
+    def engine(self):
+        p = next(self.parameters())
+        if not p.is_cuda:
+            raise L.AmdsegError("spokennlp_amd runs on MI355X only: move the model to a cuda device (no CPU fallback)")
+        if self._engine is None or not self._engine.fp.intact() or self._engine.device != p.device:
+            self._engine = BertEncoderEngine(self, self.config, p.device, bert_attr="bert")
+        return self._engine
+

@@ -39,12 +39,22 @@ int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K,
 int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_out, hipStream_t s);
 
 int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,
-                         float scale, float p, uint64_t seed, hipStream_t s);
+                         float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s);
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
-                         hipStream_t s);
+                         int window, int nglobal, hipStream_t s);
 int amdseg_attn_f32_impl(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, int d,
-                         float scale, hipStream_t s);
+                         float scale, int window, int nglobal, hipStream_t s);
+
+int amdseg_lf_rowvec_dot_impl(const void* x, const float* vec, const float* add_tok, const float* add_bh, float* out, int B, int L,
+                              int H, int heads, int dtype, hipStream_t s);
+int amdseg_lf_softmax_fwd_impl(float* s_inout_p, float* pd, float* sp, int rows, int L, float p, uint64_t seed, hipStream_t s);
+int amdseg_lf_softmax_bwd_impl(const float* p_saved, float* dpd_inout_ds, float* pd, int rows, int L, float p, uint64_t seed,
+                               hipStream_t s);
+int amdseg_lf_wsum_impl(const void* x, const float* coef, float* partials, float* y, int B, int L, int H, int heads, int dtype,
+                        hipStream_t s);
+int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, int B, int L,
+                             int H, int heads, int dtype, hipStream_t s);
 
 int amdseg_rowdot_fwd_impl(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
                            hipStream_t s);

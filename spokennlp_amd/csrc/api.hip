@@ -34,16 +34,52 @@ int amdseg_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, float* 
 }
 int amdseg_attn_f32(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, float scale,
                     amdseg_stream_t stream) {
-    return amdseg_attn_f32_impl(qkv, mask_bias, ctx, B, L, heads, 64, scale, S(stream));
+    return amdseg_attn_f32_impl(qkv, mask_bias, ctx, B, L, heads, 64, scale, 0, 0, S(stream));
 }
 int amdseg_attn_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                     float dropout_p, uint64_t seed, amdseg_stream_t stream) {
-    return amdseg_attn_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, dropout_p, seed, S(stream));
+    return amdseg_attn_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, dropout_p, seed, 0, 0, S(stream));
 }
 int amdseg_attn_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                     float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, uint64_t seed,
                     amdseg_stream_t stream) {
-    return amdseg_attn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, seed, S(stream));
+    return amdseg_attn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, seed, 0, 0, S(stream));
+}
+int amdseg_attn_band_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
+                         float dropout_p, uint64_t seed, int window, int nglobal, amdseg_stream_t stream) {
+    if (window <= 0) return AMDSEG_ERR_ARG;
+    return amdseg_attn_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, dropout_p, seed, window, nglobal, S(stream));
+}
+int amdseg_attn_band_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                         float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, uint64_t seed,
+                         int window, int nglobal, amdseg_stream_t stream) {
+    if (window <= 0) return AMDSEG_ERR_ARG;
+    return amdseg_attn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, seed, window, nglobal, S(stream));
+}
+int amdseg_attn_band_f32(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, float scale, int window,
+                         int nglobal, amdseg_stream_t stream) {
+    if (window <= 0) return AMDSEG_ERR_ARG;
+    return amdseg_attn_f32_impl(qkv, mask_bias, ctx, B, L, heads, 64, scale, window, nglobal, S(stream));
+}
+int amdseg_lf_rowvec_dot(const void* x, const float* vec, const float* add_tok, const float* add_bh, float* out, int B, int L, int H,
+                         int heads, int dtype, amdseg_stream_t stream) {
+    return amdseg_lf_rowvec_dot_impl(x, vec, add_tok, add_bh, out, B, L, H, heads, dtype, S(stream));
+}
+int amdseg_lf_softmax_fwd(float* s_inout_p, float* pd, float* sp, int rows, int L, float dropout_p, uint64_t seed,
+                          amdseg_stream_t stream) {
+    return amdseg_lf_softmax_fwd_impl(s_inout_p, pd, sp, rows, L, dropout_p, seed, S(stream));
+}
+int amdseg_lf_softmax_bwd(const float* p_saved, float* dpd_inout_ds, float* pd, int rows, int L, float dropout_p, uint64_t seed,
+                          amdseg_stream_t stream) {
+    return amdseg_lf_softmax_bwd_impl(p_saved, dpd_inout_ds, pd, rows, L, dropout_p, seed, S(stream));
+}
+int amdseg_lf_wsum(const void* x, const float* coef, float* partials, float* y, int B, int L, int H, int heads, int dtype,
+                   amdseg_stream_t stream) {
+    return amdseg_lf_wsum_impl(x, coef, partials, y, B, L, H, heads, dtype, S(stream));
+}
+int amdseg_lf_dx_update(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, int B, int L, int H,
+                        int heads, int dtype, amdseg_stream_t stream) {
+    return amdseg_lf_dx_update_impl(dx, coefA, vecA, coefB, vecB, B, L, H, heads, dtype, S(stream));
 }
 int amdseg_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                         const float* pos, const float* type, const float* gamma, const float* beta, void* z, void* out,
@@ -119,8 +155,14 @@ static int check_cfg(const amdseg_bert_cfg* c) {
     if (c->H != c->heads * 64 || c->B <= 0 || c->L <= 0 || c->I <= 0) return AMDSEG_ERR_SHAPE;
     const long M = (long)c->B * c->L;
     if ((M % 128) || (c->H % 128) || (c->I % 128) || (c->L % 64)) return AMDSEG_ERR_SHAPE;
+    if (c->window < 0 || c->nglobal < 0 || c->phase < 0 || c->phase > 3) return AMDSEG_ERR_ARG;
     return AMDSEG_OK;
 }
+// phase: 0 or 3 = whole layer; 1 = first part only; 2 = second part only.  The split point is the attention context:
+// a Longformer caller overwrites the global token's ctx row between forward phases 1 and 2, and consumes / zeroes its
+// dctx row between backward phases 1 and 2 (see include/amdseg.h).
+#define PHASE1(c) ((c)->phase != 2)
+#define PHASE2(c) ((c)->phase != 1)
 
 int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,
                           const float* mask_bias, int li, amdseg_stream_t stream) {
@@ -131,8 +173,11 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     if (c->dtype == AMDSEG_F32) {
         // fp32 parity mode (inference): exact-fp32 MFMA GEMMs on the fp32 master weights, fp32 activations, no dropout
         if (c->p_hidden != 0.f || c->p_attn != 0.f) return AMDSEG_ERR_ARG;
-        RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->x_in, H, (const float*)p->wqkv, H, (float*)a->qkv, 3 * H, M, 3 * H, H, 1, p->bqkv, s));
-        RET_IF(amdseg_attn_f32_impl((const float*)a->qkv, mask_bias, (float*)a->ctx, c->B, c->L, c->heads, 64, 0.125f, s));
+        if (PHASE1(c)) {
+            RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->x_in, H, (const float*)p->wqkv, H, (float*)a->qkv, 3 * H, M, 3 * H, H, 1, p->bqkv, s));
+            RET_IF(amdseg_attn_f32_impl((const float*)a->qkv, mask_bias, (float*)a->ctx, c->B, c->L, c->heads, 64, 0.125f, c->window, c->nglobal, s));
+        }
+        if (!PHASE2(c)) return AMDSEG_OK;
         RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->ctx, H, (const float*)p->wo, H, (float*)a->z1, H, M, H, H, 1, p->bo, s));
         RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, 0.f, 0, AMDSEG_F32, s));
         RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->x1, H, (const float*)p->w1, H, (float*)a->h, I, M, I, H, 2, p->b1, s));
@@ -140,9 +185,13 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, 0.f, 0, AMDSEG_F32, s));
         return AMDSEG_OK;
     }
-    // q|k|v projection with bias
-    RET_IF(amdseg_gemm_nt_impl(a->x_in, H, p->wqkv, H, a->qkv, 3 * H, M, 3 * H, H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 0, s));
-    RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0), s));
+    if (PHASE1(c)) {
+        // q|k|v projection with bias
+        RET_IF(amdseg_gemm_nt_impl(a->x_in, H, p->wqkv, H, a->qkv, 3 * H, M, 3 * H, H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 0, s));
+        RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0),
+                                    c->window, c->nglobal, s));
+    }
+    if (!PHASE2(c)) return AMDSEG_OK;
     // attention output dense -> dropout -> +residual -> LN
     RET_IF(amdseg_gemm_nt_impl(a->ctx, H, p->wo, H, a->z1, H, M, H, H, AMDSEG_EPI_BIAS, p->bo, nullptr, 0, nullptr, 0, 0, s));
     RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
@@ -164,10 +213,12 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     hipStream_t s = S(stream);
     const int M = c->B * c->L, H = c->H, I = c->I, acc = c->accumulate_grads;
     const bool drop = c->p_hidden > 0.f;
+    const void* d_out = drop ? w->dbr2 : w->dz2;
+    const void* d_ao = drop ? w->dbr1 : w->dz1;
+    if (PHASE1(c)) {
     // LN2 backward: dz2 (residual grad), d_out = masked dz2 (grad of the FFN output dense), dln2, db2
     RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, w->partials, g->ln2_g, g->ln2_b,
                               g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, c->dtype, s));
-    const void* d_out = drop ? w->dbr2 : w->dz2;
     // du = (d_out . W2) * gelu'(u)
     RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD, nullptr, a->u, I, nullptr, 0, 0, s));
     // dx1 = du . W1 + dz2
@@ -176,11 +227,12 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     // LN1 backward
     RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, w->partials, g->ln1_g,
                               g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, c->dtype, s));
-    const void* d_ao = drop ? w->dbr1 : w->dz1;
     // dctx = d_ao . Wo
     RET_IF(amdseg_gemm_nt_impl(d_ao, H, p->wo_t, H, w->dctx, H, M, H, H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, s));
+    }
+    if (!PHASE2(c)) return AMDSEG_OK;
     RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
-                                site_seed(c->seed, li, 0), s));
+                                site_seed(c->seed, li, 0), c->window, c->nglobal, s));
     // dx_in = dqkv . Wqkv + dz1
     RET_IF(amdseg_gemm_nt_impl(w->dqkv, 3 * H, p->wqkv_t, 3 * H, dx_in, H, M, H, 3 * H, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s));
     RET_IF(amdseg_colsum_impl(w->dqkv, 3 * H, w->partials, g->bqkv, M, 3 * H, acc, c->dtype, s));

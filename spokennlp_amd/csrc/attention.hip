@@ -90,10 +90,20 @@ struct AttnArgs {
     const bf16_t* dctx; const float* delta; bf16_t* dqkv;
     int B, L, heads, H3;    // H3 = 3*H row stride of qkv
     float scale, inv_keep; uint32_t thresh16; uint64_t seed;
+    int window, nglobal;    // band attention (Longformer): one-sided window W (0 = full attention), leading global tokens G
 };
 
+// Band ("sliding window + global") visibility, [hf] models/longformer/modeling_longformer.py:524-604 restated as a mask:
+// key j is visible from query i  <=>  j < G (global key, re-added as extra column :559-568)  or  |i - j| <= W (:744-822);
+// padded keys carry -inf in mask_bias as in the full-attention path.  Rows of padded queries are zeroed (:579).
+// A workgroup only streams the 64-key chunks that intersect its band (+ chunk 0 for the global keys).
+__device__ __forceinline__ bool band_masked(int q, int key, int W, int G) {
+    const int d = key - q;
+    return key >= G && (d > W || d < -W);
+}
+
 // ------------------------------------------------------------------------------------------------ forward
-template <int NW>
+template <int NW, bool BAND>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
@@ -121,20 +131,28 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
 
     const bf16_t* kbase = a.qkv + tok0 * a.H3 + H + h * HD;
     const bf16_t* vbase = a.qkv + tok0 * a.H3 + 2 * H + h * HD;
-    const int nch = a.L / CH;
-    at_stage<NW>(kbase, a.H3, bufK(0), w, l);
-    at_stage<NW>(vbase, a.H3, bufV(0), w, l);
+    int c0 = 0, c1 = a.L / CH - 1, extra = 0;
+    if (BAND) {
+        const int q_lo = qb * (NW * 16), q_hi = q_lo + NW * 16 - 1;
+        c0 = q_lo > a.window ? (q_lo - a.window) / CH : 0;
+        c1 = min(c1, (q_hi + a.window) / CH);
+        extra = (a.nglobal > 0 && c0 > 0) ? 1 : 0;
+    }
+    const int nch = c1 - c0 + 1 + extra;
+#define CHUNK_OF(t) ((BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
+    at_stage<NW>(kbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufK(0), w, l);
+    at_stage<NW>(vbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufV(0), w, l);
     for (int ch = 0; ch < nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = ch & 1;
         if (ch + 1 < nch) {
-            at_stage<NW>(kbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
-            at_stage<NW>(vbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
+            at_stage<NW>(kbase + (size_t)CHUNK_OF(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
+            at_stage<NW>(vbase + (size_t)CHUNK_OF(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
         }
         const char* tK = bufK(cur);
         const char* tV = bufV(cur);
-        const int key0 = ch * CH;
+        const int key0 = CHUNK_OF(ch) * CH;
         // S^T[key][q]: 4 key frags of 16
         f32x4 s[4];
 #pragma unroll
@@ -150,6 +168,16 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
             s[fc][0] = acc[0] * sc2 + mb.x * LOG2E; s[fc][1] = acc[1] * sc2 + mb.y * LOG2E;
             s[fc][2] = acc[2] * sc2 + mb.z * LOG2E; s[fc][3] = acc[3] * sc2 + mb.w * LOG2E;
         }
+        if (BAND) {
+            const int wq_lo = qb * (NW * 16) + w * 16;                  // wave-uniform: chunk wholly inside every row's band?
+            if (!(key0 >= wq_lo + 15 - a.window && key0 + CH - 1 <= wq_lo + a.window)) {
+#pragma unroll
+                for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (band_masked(q, key0 + fc * 16 + g * 4 + r, a.window, a.nglobal)) s[fc][r] = -INFINITY;
+            }
+        }
         float cmax = s[0][0];
 #pragma unroll
         for (int fc = 0; fc < 4; ++fc)
@@ -158,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
         cmax = xor_reduce_max_g(cmax);
         if (__any(cmax > m_run)) {                 // wave-uniform: rescale only when some row's running max grew
             const float m_new = fmaxf(m_run, cmax);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            const float alpha = (BAND && m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
             l_part *= alpha;
 #pragma unroll
@@ -167,10 +195,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
         }
         float psum = 0.f;
+        const float m_use = (BAND && m_run == -INFINITY) ? 0.f : m_run;   // a row whose visited keys were all masked so far
 #pragma unroll
         for (int fc = 0; fc < 4; ++fc)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[fc][r] = __builtin_amdgcn_exp2f(s[fc][r] - m_run); psum += s[fc][r]; }
+            for (int r = 0; r < 4; ++r) { s[fc][r] = __builtin_amdgcn_exp2f(s[fc][r] - m_use); psum += s[fc][r]; }
         l_part += psum;
         if (a.thresh16) {
 #pragma unroll
@@ -194,7 +223,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
         }
     }
     const float lsum = xor_reduce_sum_g(l_part);
-    const float inv = 1.0f / lsum;
+    float inv = 1.0f / lsum;
+    float lse_q = (m_run + __builtin_amdgcn_logf(lsum)) * LN2;          // natural-log LSE, as backward expects
+    if (BAND && a.mask_bias[tok0 + q] < 0.f) { inv = 0.f; lse_q = INFINITY; }   // padded query: zero row, p == 0 in backward
     bf16_t* op = a.ctx + (tok0 + q) * H + h * HD;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -203,7 +234,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
         pk.y = pack2bf(o[d][2] * inv, o[d][3] * inv);
         *reinterpret_cast<uint2*>(op + d * 16 + g * 4) = pk;
     }
-    if (a.lse && g == 0) a.lse[prow] = (m_run + __builtin_amdgcn_logf(lsum)) * LN2;      // natural-log LSE, as backward expects
+    if (a.lse && g == 0) a.lse[prow] = lse_q;
+#undef CHUNK_OF
 }
 
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
@@ -231,7 +263,7 @@ __global__ void attn_delta_kernel(const bf16_t* ctx, const bf16_t* dctx, float* 
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-template <int NW>
+template <int NW, bool BAND>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
@@ -261,20 +293,33 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dq_kernel(AttnArgs a
 
     const bf16_t* kbase = a.qkv + tok0 * a.H3 + H + h * HD;
     const bf16_t* vbase = a.qkv + tok0 * a.H3 + 2 * H + h * HD;
-    const int nch = a.L / CH;
-    at_stage<NW>(kbase, a.H3, bufK(0), w, l);
-    at_stage<NW>(vbase, a.H3, bufV(0), w, l);
+    int c0 = 0, c1 = a.L / CH - 1, extra = 0;
+    if (BAND) {
+        const int q_lo = qb * (NW * 16), q_hi = q_lo + NW * 16 - 1;
+        c0 = q_lo > a.window ? (q_lo - a.window) / CH : 0;
+        c1 = min(c1, (q_hi + a.window) / CH);
+        extra = (a.nglobal > 0 && c0 > 0) ? 1 : 0;
+    }
+    const int nch = c1 - c0 + 1 + extra;
+#define CHUNK_OF(t) ((BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
+    at_stage<NW>(kbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufK(0), w, l);
+    at_stage<NW>(vbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufV(0), w, l);
     for (int ch = 0; ch < nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = ch & 1;
         if (ch + 1 < nch) {
-            at_stage<NW>(kbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
-            at_stage<NW>(vbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
+            at_stage<NW>(kbase + (size_t)CHUNK_OF(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
+            at_stage<NW>(vbase + (size_t)CHUNK_OF(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
         }
         const char* tK = bufK(cur);
         const char* tV = bufV(cur);
-        const int key0 = ch * CH;
+        const int key0 = CHUNK_OF(ch) * CH;
+        bool edge = false;
+        if (BAND) {
+            const int wq_lo = qb * (NW * 16) + w * 16;
+            edge = !(key0 >= wq_lo + 15 - a.window && key0 + CH - 1 <= wq_lo + a.window);
+        }
         f32x4 ds[4];
 #pragma unroll
         for (int fc = 0; fc < 4; ++fc) {
@@ -299,7 +344,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dq_kernel(AttnArgs a
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sacc[r] * sc2 + mb[r] * LOG2E - lse2_q);
+                float p = __builtin_amdgcn_exp2f(sacc[r] * sc2 + mb[r] * LOG2E - lse2_q);
+                if (BAND && edge && band_masked(q, key0 + fc * 16 + g * 4 + r, a.window, a.nglobal)) p = 0.f;
                 ds[fc][r] = p * (pacc[r] * keepf[r] - delta_q);
             }
         }
@@ -322,10 +368,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dq_kernel(AttnArgs a
         pk.y = pack2bf(dq[d][2] * a.scale, dq[d][3] * a.scale);
         *reinterpret_cast<uint2*>(op + d * 16 + g * 4) = pk;
     }
+#undef CHUNK_OF
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <int NW>
+template <int NW, bool BAND>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
@@ -355,20 +402,32 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dkv_kernel(AttnArgs 
 
     const bf16_t* qbase = a.qkv + tok0 * a.H3 + h * HD;
     const bf16_t* obase = a.dctx + tok0 * H + h * HD;
-    const int nch = a.L / CH;
-    at_stage<NW>(qbase, a.H3, bufQ(0), w, l);
-    at_stage<NW>(obase, H, bufO(0), w, l);
+    // query chunks that can see this key block: the band around it -- or every chunk if the block holds a global key
+    int c0 = 0, c1 = a.L / CH - 1;
+    if (BAND && !(a.nglobal > 0 && kb * (NW * 16) < a.nglobal)) {
+        const int k_lo = kb * (NW * 16), k_hi = k_lo + NW * 16 - 1;
+        c0 = k_lo > a.window ? (k_lo - a.window) / CH : 0;
+        c1 = min(c1, (k_hi + a.window) / CH);
+    }
+    const int nch = c1 - c0 + 1;
+    at_stage<NW>(qbase + (size_t)c0 * CH * a.H3, a.H3, bufQ(0), w, l);
+    at_stage<NW>(obase + (size_t)c0 * CH * H, H, bufO(0), w, l);
     for (int ch = 0; ch < nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = ch & 1;
         if (ch + 1 < nch) {
-            at_stage<NW>(qbase + (size_t)(ch + 1) * CH * a.H3, a.H3, bufQ(cur ^ 1), w, l);
-            at_stage<NW>(obase + (size_t)(ch + 1) * CH * H, H, bufO(cur ^ 1), w, l);
+            at_stage<NW>(qbase + (size_t)(c0 + ch + 1) * CH * a.H3, a.H3, bufQ(cur ^ 1), w, l);
+            at_stage<NW>(obase + (size_t)(c0 + ch + 1) * CH * H, H, bufO(cur ^ 1), w, l);
         }
         const char* tQ = bufQ(cur);
         const char* tO = bufO(cur);
-        const int q0 = ch * CH;
+        const int q0 = (c0 + ch) * CH;
+        bool edge = false;
+        if (BAND) {
+            const int wk_lo = kb * (NW * 16) + w * 16;
+            edge = !(q0 >= wk_lo + 15 - a.window && q0 + CH - 1 <= wk_lo + a.window);
+        }
         f32x4 pd[4], ds[4];     // P_drop[q][key], dS[q][key] : lane key = i16, q = qf*16 + g*4 + r
 #pragma unroll
         for (int qf = 0; qf < 4; ++qf) {
@@ -386,7 +445,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dkv_kernel(AttnArgs 
             const float ls[4] = {ls4.x, ls4.y, ls4.z, ls4.w}, dl[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sacc[r] * sc2 + mb2 - ls[r] * LOG2E);
+                float p = __builtin_amdgcn_exp2f(sacc[r] * sc2 + mb2 - ls[r] * LOG2E);
+                if (BAND && edge && band_masked(q0 + qf * 16 + g * 4 + r, key, a.window, a.nglobal)) p = 0.f;
                 float keepf = 1.f;
                 if (a.thresh16) {
                     const uint32_t u = pdrop_bits(pdrop_salt(a.seed, rbase + r), key & ~1);
@@ -426,9 +486,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dkv_kernel(AttnArgs 
     }
 }
 
-static int attn_fill(AttnArgs& a, int B, int L, int heads, float scale, float p, uint64_t seed) {
+static int attn_fill(AttnArgs& a, int B, int L, int heads, float scale, float p, uint64_t seed, int window, int nglobal) {
     if (B <= 0 || L <= 0 || heads <= 0 || (L % CH)) return AMDSEG_ERR_SHAPE;
-    if (p < 0.f || p >= 1.f) return AMDSEG_ERR_ARG;
+    if (p < 0.f || p >= 1.f || window < 0 || nglobal < 0 || nglobal > CH) return AMDSEG_ERR_ARG;
+    a.window = window; a.nglobal = window > 0 ? nglobal : 0;
     a.B = B; a.L = L; a.heads = heads; a.H3 = 3 * heads * HD; a.scale = scale; a.seed = seed;
     uint32_t th = (uint32_t)(p * 65536.0f + 0.5f);
     if (p > 0.f && th == 0) th = 1;
@@ -438,23 +499,28 @@ static int attn_fill(AttnArgs& a, int B, int L, int heads, float scale, float p,
 }
 
 int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,
-                         float scale, float p, uint64_t seed, hipStream_t s) {
+                         float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s) {
     if (!qkv || !mask_bias || !ctx) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
-    int rc = attn_fill(a, B, L, heads, scale, p, seed);
+    int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
-    if (L % 128 == 0) hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3(L / 128, heads, B), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    if (window > 0) {
+        if (L % 128 == 0) hipLaunchKernelGGL((attn_fwd_kernel<8, true>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    } else {
+        if (L % 128 == 0) hipLaunchKernelGGL((attn_fwd_kernel<8, false>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    }
     return amdseg_launch_status();
 }
 
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
-                         hipStream_t s) {
+                         int window, int nglobal, hipStream_t s) {
     if (!qkv || !mask_bias || !ctx || !dctx || !lse || !delta || !dqkv) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
-    int rc = attn_fill(a, B, L, heads, scale, p, seed);
+    int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = (float*)lse;
     a.dctx = (const bf16_t*)dctx; a.delta = delta; a.dqkv = (bf16_t*)dqkv;
@@ -462,7 +528,12 @@ int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ct
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)ctx,
                        (const bf16_t*)dctx, delta, B, L, heads);
     // backward kernels need 144-168 VGPRs: 4-wave workgroups keep 3 waves per SIMD resident (8-wave ones would spill or halve occupancy)
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3(L / 64, heads, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    if (window > 0) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    }
     return amdseg_launch_status();
 }

@@ -123,8 +123,9 @@ int amdseg_gemm_f32_nt_impl(const float* A, int lda, const float* B, int ldb, fl
 // ------------------------------------------------------------------------------------------------ fp32 attention
 // one wave per (b, h, q): lanes own keys j = lane + 64*s for the scores, then own the output column d = lane (d == 64)
 #define F32_MAXS 64      // L <= 4096
+// window > 0: Longformer band (|q - j| <= window or j < nglobal; see attention.hip), rows of padded queries zeroed
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads,
-                                                       float scale) {
+                                                       float scale, int window, int nglobal) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const size_t row = (size_t)blockIdx.x * 4 + w;            // (b*heads + h)*L + q
     const size_t total = (size_t)B * heads * L;
@@ -138,13 +139,16 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* qkv, const f
     const int ns = L / 64;
     float s[F32_MAXS];
     float mx = -INFINITY;
+#define SLAB_VISIBLE(si) (window <= 0 || (si) * 64 < nglobal || ((si) * 64 + 63 >= q - window && (si) * 64 <= q + window))
     for (int si = 0; si < ns; ++si) {
+        if (!SLAB_VISIBLE(si)) { s[si] = -INFINITY; continue; }
         const int j = si * 64 + l;
         const float* kp = qkv + ((size_t)b * L + j) * H3 + H + h * 64;
         float acc = 0.f;
 #pragma unroll 8
         for (int d = 0; d < 64; ++d) acc = fmaf(__shfl(qd, d, 64), kp[d], acc);
         acc = acc * scale + mask_bias[(size_t)b * L + j];
+        if (window > 0 && j >= nglobal && (j - q > window || q - j > window)) acc = -INFINITY;
         s[si] = acc;
         mx = fmaxf(mx, acc);
     }
@@ -152,9 +156,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* qkv, const f
     float sum = 0.f;
     for (int si = 0; si < ns; ++si) { s[si] = expf(s[si] - mx); sum += s[si]; }
     sum = wave_sum(sum);
-    const float inv = 1.0f / sum;
+    const float inv = (window > 0 && mask_bias[(size_t)b * L + q] < 0.f) ? 0.f : 1.0f / sum;
     float o = 0.f;
     for (int si = 0; si < ns; ++si) {
+        if (!SLAB_VISIBLE(si)) continue;
         const float ps = s[si] * inv;
         for (int jj = 0; jj < 64; ++jj) {
             const float pj = __shfl(ps, jj, 64);
@@ -166,10 +171,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* qkv, const f
 }
 
 int amdseg_attn_f32_impl(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, int d, float scale,
-                         hipStream_t s) {
-    if (!qkv || !mask_bias || !ctx) return AMDSEG_ERR_ARG;
+                         int window, int nglobal, hipStream_t s) {
+    if (!qkv || !mask_bias || !ctx || window < 0 || nglobal < 0) return AMDSEG_ERR_ARG;
     if (d != 64 || B <= 0 || heads <= 0 || L <= 0 || (L % 64) || L > 64 * F32_MAXS) return AMDSEG_ERR_SHAPE;
     const size_t total = (size_t)B * heads * L;
-    hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, qkv, mask_bias, ctx, B, L, heads, scale);
+    hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, qkv, mask_bias, ctx, B, L, heads, scale, window, window > 0 ? nglobal : 0);
     return amdseg_launch_status();
 }

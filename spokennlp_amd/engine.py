@@ -220,7 +220,8 @@ class BertEncoderEngine:
 
     def _cfg_struct(self, B, Lseq, p_hidden, p_attn, seed, accumulate):
         return L.BertCfg(B=B, L=Lseq, H=self.H, heads=self.heads, I=self.I, ln_eps=float(self.cfg.layer_norm_eps),
-                         p_hidden=p_hidden, p_attn=p_attn, seed=seed, accumulate_grads=1 if accumulate else 0, dtype=L.BF16)
+                         p_hidden=p_hidden, p_attn=p_attn, seed=seed, accumulate_grads=1 if accumulate else 0, dtype=L.BF16,
+                         window=0, nglobal=0, phase=0)
 
     # ------------------------------------------------------------------------------------------------ forward / backward
     def _emb(self, name):
@@ -250,20 +251,36 @@ class BertEncoderEngine:
         s = torch.cuda.current_stream().cuda_stream
         eps = float(self.cfg.layer_norm_eps)
         we, pe, te = self._emb("word_embeddings.weight"), self._emb("position_embeddings.weight"), self._emb("token_type_embeddings.weight")
-        rc = lib.amdseg_embed_ln_fwd(ids.data_ptr(), tts.data_ptr(), None, we.data_ptr(), pe.data_ptr(), te.data_ptr(),
+        pos = self._position_ids(input_ids)
+        rc = lib.amdseg_embed_ln_fwd(ids.data_ptr(), tts.data_ptr(), None if pos is None else pos.data_ptr(), we.data_ptr(), pe.data_ptr(), te.data_ptr(),
                                      self._emb("LayerNorm.weight").data_ptr(), self._emb("LayerNorm.bias").data_ptr(),
                                      A["emb_z"].data_ptr(), A["x"][0].data_ptr(), A["emb_mean"].data_ptr(), A["emb_rstd"].data_ptr(),
                                      M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], eps, p_h, seed * 1000003 + 17, dt, s)
         L.check(rc, "amdseg_embed_ln_fwd")
         mb = A["mask_bias"].data_ptr()
+        saved = []
         for i in range(self.nlayers):
-            rc = lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lparams[i]), C.byref(A["acts_struct"][i]), mb, i, s)
-            L.check(rc, f"amdseg_bert_layer_fwd[{i}]")
+            saved.append(self._layer_forward(lib, cfg, lparams[i], A, i, mb, s, train))
         rc = lib.amdseg_dropout(A["x_final"].data_ptr(), A["out"].data_ptr(), M * self.H, p_out if train else 0.0,
                                 seed * 1000003 + 29, dt, L.F32, s)
         L.check(rc, "amdseg_dropout")
-        ctx = dict(B=B, L=Lseq, ids=ids, tts=tts, seed=seed, p_h=p_h, p_a=p_a, p_out=p_out if train else 0.0)
+        ctx = dict(B=B, L=Lseq, ids=ids, tts=tts, pos=pos, seed=seed, p_h=p_h, p_a=p_a, p_out=p_out if train else 0.0,
+                   layer_saved=saved)
         return A["out"].view(B, Lseq, self.H), ctx
+
+    # hooks overridden by the Longformer engine
+    def _position_ids(self, input_ids):
+        return None
+
+    def _layer_forward(self, lib, cfg, lp, A, i, mb, s, train):
+        rc = lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(A["acts_struct"][i]), mb, i, s)
+        L.check(rc, f"amdseg_bert_layer_fwd[{i}]")
+        return None
+
+    def _layer_backward(self, lib, cfg, A, i, mb, dy, other, s, saved):
+        rc = lib.amdseg_bert_layer_bwd(C.byref(cfg), C.byref(self.lparams[i]), C.byref(self.lgrads[i]),
+                                       C.byref(A["acts_struct"][i]), C.byref(A["ws_struct"]), mb, dy.data_ptr(), other.data_ptr(), i, s)
+        L.check(rc, f"amdseg_bert_layer_bwd[{i}]")
 
     def backward(self, ctx, dseq, accumulate=True):
         """dseq: fp32 [B, L, H] gradient of the encoder output.  Writes every parameter gradient into flat_g."""
@@ -280,9 +297,7 @@ class BertEncoderEngine:
         L.check(rc, "amdseg_dropout(bwd)")
         mb = A["mask_bias"].data_ptr()
         for i in reversed(range(self.nlayers)):
-            rc = lib.amdseg_bert_layer_bwd(C.byref(cfg), C.byref(self.lparams[i]), C.byref(self.lgrads[i]),
-                                           C.byref(A["acts_struct"][i]), C.byref(A["ws_struct"]), mb, dy.data_ptr(), other.data_ptr(), i, s)
-            L.check(rc, f"amdseg_bert_layer_bwd[{i}]")
+            self._layer_backward(lib, cfg, A, i, mb, dy, other, s, ctx["layer_saved"][i])
             dy, other = other, dy
             if self.buckets is not None:          # data parallel: this layer's gradient slice is final -> start its all-reduce
                 self.buckets.reduce_layer(i)
@@ -301,9 +316,15 @@ class BertEncoderEngine:
         if not accumulate:
             we.zero_(); pe.zero_(); te.zero_()
         pad = self.cfg.pad_token_id if getattr(self.cfg, "pad_token_id", None) is not None else -1
-        rc = lib.amdseg_embed_bwd(other.data_ptr(), ctx["ids"].data_ptr(), ctx["tts"].data_ptr(), None, we.data_ptr(), pe.data_ptr(),
-                                  te.data_ptr(), M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], pad, L.BF16, s)
+        pos = ctx.get("pos")
+        rc = lib.amdseg_embed_bwd(other.data_ptr(), ctx["ids"].data_ptr(), ctx["tts"].data_ptr(), None if pos is None else pos.data_ptr(),
+                                  we.data_ptr(), pe.data_ptr(), te.data_ptr(), M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], pad,
+                                  L.BF16, s)
         L.check(rc, "amdseg_embed_bwd")
+        self._embed_backward_fixup(pe, pad)
+
+    def _embed_backward_fixup(self, dpos, pad):
+        pass
 
     # ------------------------------------------------------------------------------------------------ optimiser
     def zero_grad(self):

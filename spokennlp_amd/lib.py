@@ -19,7 +19,8 @@ vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 class BertCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("heads", C.c_int32), ("I", C.c_int32),
                 ("ln_eps", f32), ("p_hidden", f32), ("p_attn", f32), ("seed", u64),
-                ("accumulate_grads", C.c_int32), ("dtype", C.c_int32)]
+                ("accumulate_grads", C.c_int32), ("dtype", C.c_int32), ("window", C.c_int32), ("nglobal", C.c_int32),
+                ("phase", C.c_int32)]
 
 
 class LayerParams(C.Structure):
@@ -51,6 +52,14 @@ _PROTOS = {
     "amdseg_attn_f32": [vp, vp, vp, i32, i32, i32, f32, vp],
     "amdseg_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
+    "amdseg_attn_band_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, i32, vp],
+    "amdseg_attn_band_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, i32, vp],
+    "amdseg_attn_band_f32": [vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
+    "amdseg_lf_rowvec_dot": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "amdseg_lf_softmax_fwd": [vp, vp, vp, i32, i32, f32, u64, vp],
+    "amdseg_lf_softmax_bwd": [vp, vp, vp, i32, i32, f32, u64, vp],
+    "amdseg_lf_wsum": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "amdseg_lf_dx_update": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "amdseg_embed_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, u64, i32, vp],
     "amdseg_embed_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "amdseg_add_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, i32, vp],

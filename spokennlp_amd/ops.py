@@ -82,6 +82,76 @@ def attn_bwd(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, p=0.0, seed=0, scal
     return dqkv
 
 
+def attn_band_fwd(qkv, mask_bias, B, Lseq, heads, window, nglobal=1, p=0.0, seed=0, need_lse=True, scale=0.125):
+    H = heads * 64
+    ctx = torch.empty((B * Lseq, H), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device) if need_lse else None
+    rc = L.load().amdseg_attn_band_fwd(_p(qkv), _p(mask_bias), _p(ctx), _p(lse), B, Lseq, heads, scale, p, seed, window, nglobal, _s())
+    L.check(rc, "amdseg_attn_band_fwd")
+    return ctx, lse
+
+
+def attn_band_bwd(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, window, nglobal=1, p=0.0, seed=0, scale=0.125):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device)
+    rc = L.load().amdseg_attn_band_bwd(_p(qkv), _p(mask_bias), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, Lseq, heads,
+                                       scale, p, seed, window, nglobal, _s())
+    L.check(rc, "amdseg_attn_band_bwd")
+    return dqkv
+
+
+def attn_band_f32(qkv, mask_bias, B, Lseq, heads, window, nglobal=1, scale=0.125):
+    ctx = torch.empty((B * Lseq, heads * 64), dtype=torch.float32, device=qkv.device)
+    rc = L.load().amdseg_attn_band_f32(_p(qkv), _p(mask_bias), _p(ctx), B, Lseq, heads, scale, window, nglobal, _s())
+    L.check(rc, "amdseg_attn_band_f32")
+    return ctx
+
+
+# ---- Longformer global row (csrc/longformer.hip): x [B*L, H] bf16/fp32; vec [B, heads, H] fp32; planes [B, heads, L] fp32
+def lf_rowvec_dot(x, vec, B, Lseq, add_tok=None, add_bh=None):
+    heads, H = vec.shape[1], vec.shape[2]
+    out = torch.empty((B, heads, Lseq), dtype=torch.float32, device=x.device)
+    rc = L.load().amdseg_lf_rowvec_dot(_p(x), _p(vec), _p(add_tok), _p(add_bh), _p(out), B, Lseq, H, heads, _dt(x), _s())
+    L.check(rc, "amdseg_lf_rowvec_dot")
+    return out
+
+
+def lf_softmax_fwd(scores, p=0.0, seed=0):
+    """scores [B, heads, L] fp32 is overwritten with the probabilities; returns (p, dropped p, sum of dropped p [B, heads])."""
+    B, heads, Lseq = scores.shape
+    pd = torch.empty_like(scores)
+    sp = torch.empty((B, heads), dtype=torch.float32, device=scores.device)
+    rc = L.load().amdseg_lf_softmax_fwd(_p(scores), _p(pd), _p(sp), B * heads, Lseq, p, seed, _s())
+    L.check(rc, "amdseg_lf_softmax_fwd")
+    return scores, pd, sp
+
+
+def lf_softmax_bwd(p_saved, dpd, p=0.0, seed=0):
+    """dpd is overwritten with ds; returns (ds, recomputed dropped p)."""
+    B, heads, Lseq = p_saved.shape
+    pd = torch.empty_like(p_saved)
+    rc = L.load().amdseg_lf_softmax_bwd(_p(p_saved), _p(dpd), _p(pd), B * heads, Lseq, p, seed, _s())
+    L.check(rc, "amdseg_lf_softmax_bwd")
+    return dpd, pd
+
+
+def lf_wsum(x, coef, H, partials=None):
+    B, heads, Lseq = coef.shape
+    if partials is None:
+        partials = torch.empty((B * (Lseq // 64) * heads * H,), dtype=torch.float32, device=x.device)
+    y = torch.empty((B, heads, H), dtype=torch.float32, device=x.device)
+    rc = L.load().amdseg_lf_wsum(_p(x), _p(coef), _p(partials), _p(y), B, Lseq, H, heads, _dt(x), _s())
+    L.check(rc, "amdseg_lf_wsum")
+    return y
+
+
+def lf_dx_update(dx, coefA, vecA, coefB, vecB):
+    B, heads, Lseq = coefA.shape
+    H = vecA.shape[2]
+    rc = L.load().amdseg_lf_dx_update(_p(dx), _p(coefA), _p(vecA), _p(coefB), _p(vecB), B, Lseq, H, heads, _dt(dx), _s())
+    L.check(rc, "amdseg_lf_dx_update")
+
+
 def embed_ln_fwd(ids, type_ids, pos_ids, word, pos, typ, gamma, beta, Lseq, eps, p=0.0, seed=0, dtype=torch.bfloat16,
                  save=True):
     M = ids.numel()

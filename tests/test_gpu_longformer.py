@@ -1,0 +1,187 @@
+"""Longformer path on the GPU: band attention kernels, the folded global-row kernels, and the
+HF-surface wrapper end to end against golden vectors produced by the reference (tests/golden/lf_*.npz)."""
+import math
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+from tests.test_oracle_golden import lf_case, flags_of  # noqa: E402
+
+
+# ---------------------------------------------------------------------------------------------------- kernel level
+def band_reference(qkv, mask_bias, B, L, heads, w, G, dctx=None):
+    """plain torch fp32: softmax over allowed keys (j < G or |i-j| <= w, not pad); padded query rows zeroed"""
+    H = heads * 64
+    qkv = qkv.float().clone().requires_grad_(dctx is not None)
+    q, k, v = [t.view(B, L, heads, 64).transpose(1, 2) for t in qkv.view(B, L, 3 * H).split(H, dim=-1)]
+    i = torch.arange(L, device=qkv.device)
+    ok = ((i[:, None] - i[None, :]).abs() <= w) | (i[None, :] < G)
+    s = q @ k.transpose(-1, -2) * 0.125 + mask_bias.view(B, 1, 1, L)
+    s = s.masked_fill(~ok, float("-inf"))
+    p = torch.softmax(s, -1) * (mask_bias.view(B, 1, L, 1) >= 0)
+    ctx = (p @ v).transpose(1, 2).reshape(B * L, H)
+    if dctx is None:
+        return ctx
+    ctx.backward(dctx.float())
+    return ctx.detach(), qkv.grad
+
+
+@pytest.mark.parametrize("B,L,heads,w,G", [(2, 128, 2, 16, 1), (2, 512, 4, 64, 1), (1, 1024, 2, 256, 1), (2, 256, 2, 40, 0),
+                                           (1, 192, 2, 8, 3)])
+def test_band_attention_fwd_bwd(dev, B, L, heads, w, G):
+    from spokennlp_amd import ops
+    torch.manual_seed(L + w)
+    H = heads * 64
+    qkv = torch.randn(B * L, 3 * H, device=dev).bfloat16()
+    mask = torch.zeros(B, L, device=dev)
+    mask[0, L - 37:] = -1e30                                   # padded tail in the first sequence
+    dctx = (torch.randn(B * L, H, device=dev) * 0.5).bfloat16()
+    ctx, lse = ops.attn_band_fwd(qkv, mask, B, L, heads, w, G)
+    dqkv = ops.attn_band_bwd(qkv, mask, ctx, dctx, lse, B, L, heads, w, G)
+    ref_ctx, ref_dqkv = band_reference(qkv, mask, B, L, heads, w, G, dctx)
+    assert (ctx.float() - ref_ctx).abs().max().item() < 0.03
+    assert torch.isfinite(dqkv.float()).all()
+    err = (dqkv.float() - ref_dqkv).abs().max().item()
+    assert err < 0.03 * max(1.0, ref_dqkv.abs().max().item()), err
+    assert (ctx.float().view(B, L, H)[0, L - 37:] == 0).all()          # padded queries: zero rows
+    # fp32 parity kernel
+    ctx32 = ops.attn_band_f32(qkv.float(), mask, B, L, heads, w, G)
+    assert (ctx32 - ref_ctx).abs().max().item() < 2e-5
+
+
+def test_band_equals_full_when_window_covers_sequence(dev):
+    from spokennlp_amd import ops
+    B, L, heads = 2, 256, 2
+    qkv = torch.randn(B * L, 3 * heads * 64, device=dev).bfloat16()
+    mask = torch.zeros(B, L, device=dev)
+    full, _ = ops.attn_fwd(qkv, mask, B, L, heads)
+    band, _ = ops.attn_band_fwd(qkv, mask, B, L, heads, L, 0)
+    assert torch.equal(full, band)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_global_row_kernels(dev, dt):
+    from spokennlp_amd import ops
+    torch.manual_seed(3)
+    B, L, H, heads = 2, 192, 256, 4
+    x = torch.randn(B * L, H, device=dev).to(dt)
+    vec = torch.randn(B, heads, H, device=dev) * 0.1
+    addt = torch.zeros(B, L, device=dev); addt[1, 150:] = -1e30
+    addb = torch.randn(B, heads, device=dev)
+    xf = x.float().view(B, L, H)
+    out = ops.lf_rowvec_dot(x, vec, B, L, add_tok=addt, add_bh=addb)
+    ref = torch.einsum("bhk,bjk->bhj", vec, xf) + addt[:, None, :] + addb[:, :, None]
+    live = ref > -1e29
+    assert (out - ref)[live].abs().max().item() < 1e-3
+    # softmax fwd (no dropout) + wsum
+    s = ops.lf_rowvec_dot(x, vec, B, L, add_tok=addt)
+    pref = torch.softmax(s, -1)
+    p, pd, sp = ops.lf_softmax_fwd(s.clone(), 0.0, 0)
+    assert (p - pref).abs().max().item() < 1e-6 and torch.equal(p, pd) and (sp - 1).abs().max().item() < 1e-5
+    y = ops.lf_wsum(x, pd, H)
+    assert (y - torch.einsum("bhj,bjk->bhk", pref, xf)).abs().max().item() < 1e-4
+    # softmax bwd
+    dpd = torch.randn(B, heads, L, device=dev)
+    ds_ref = pref * (dpd - (pref * dpd).sum(-1, keepdim=True))
+    ds, pd2 = ops.lf_softmax_bwd(p, dpd.clone(), 0.0, 0)
+    assert (ds - ds_ref).abs().max().item() < 1e-5 and torch.equal(pd2, p)
+    # dropout: consistent masks fwd/bwd, unbiased scale
+    p2, pdd, spd = ops.lf_softmax_fwd(s.clone(), 0.25, 99)
+    keep = pdd != 0
+    assert 0.6 < keep[p2 > 1e-12].float().mean().item() < 0.9
+    assert (pdd[keep] - p2[keep] / 0.75).abs().max().item() < 1e-6
+    _, pdd2 = ops.lf_softmax_bwd(p2, dpd.clone(), 0.25, 99)
+    assert torch.equal(pdd2, pdd)
+    # dx update
+    dx = torch.randn(B * L, H, device=dev).to(dt)
+    cA, cB = torch.randn(B, heads, L, device=dev), torch.randn(B, heads, L, device=dev)
+    vB = torch.randn(B, heads, H, device=dev)
+    ref_dx = dx.float().view(B, L, H) + torch.einsum("bhj,bhk->bjk", cA, vec) + torch.einsum("bhj,bhk->bjk", cB, vB)
+    ops.lf_dx_update(dx, cA, vec, cB, vB)
+    tol = 0.05 if dt == torch.bfloat16 else 1e-4
+    assert (dx.float().view(B, L, H) - ref_dx).abs().max().item() < tol
+
+
+# ---------------------------------------------------------------------------------------------------- model level
+def build_lf(arch, flags, sd, dev, dropout=0.0, precision=None):
+    from transformers import LongformerConfig
+    from spokennlp_amd.longformer_for_ts import LongformerWithDAForSentenceLabelingTopicSegmentation as M
+    cfg = LongformerConfig(num_labels=2, hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout, layer_norm_eps=1e-5, **arch)
+    for k, v in flags.items():
+        setattr(cfg, k, v)
+    if precision:
+        cfg.amdseg_precision = precision
+    m = M(cfg)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("position_ids" in k or "token_type_ids" in k for k in missing), (missing, unexpected)
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16"])
+@pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_longformer_eval_vs_reference_golden(dev, case, variant, precision):
+    from oracle import bert_ts_oracle as O
+    z, sd, batch, arch = lf_case(case)
+    m = build_lf(arch, flags_of(z, variant), sd, dev, precision=precision).eval()
+    random.seed(int(z[f"{variant}.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos = m(**{k: v.to(dev) for k, v in batch.items()})
+    ref = torch.from_numpy(z[f"{variant}.logits"])
+    d = (logits.cpu() - ref).abs().max().item()
+    print(f"{case}/{variant}/{precision}: max|dlogit| {d:.2e}")
+    if precision == "fp32":
+        assert d < 1e-3                                     # north-star tolerance (measured ~1e-5)
+        assert abs(loss.item() - float(z[f"{variant}.loss"])) < 1e-3
+    else:
+        assert d < 0.08 and abs(loss.item() - float(z[f"{variant}.loss"])) < 0.05
+    assert O.decode_predictions(logits.cpu()[:, 0], batch["labels"][:, 0]) == O.decode_predictions(ref[:, 0], batch["labels"][:, 0])
+
+
+@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16"])
+def test_longformer_train_grads_vs_reference_golden(dev, case):
+    z, sd, batch, arch = lf_case(case)
+    m = build_lf(arch, flags_of(z, "train_full"), sd, dev).train()
+    random.seed(int(z["train_full.random_seed"]))
+    loss, logits, cos = m(**{k: v.to(dev) for k, v in batch.items()})
+    loss.backward()
+    assert abs(loss.item() - float(z["train_full.loss"])) < 0.05
+    params = dict(m.named_parameters())
+    checked = 0
+    for k in z.files:
+        if not k.startswith("train_full.grad."):
+            continue
+        n = k[len("train_full.grad."):]
+        ref = torch.from_numpy(z[k])
+        g = params[n].grad.float().cpu()
+        if float(ref.norm()) < 1e-5:
+            assert float(g.norm()) < 1e-2, n
+            continue
+        c = torch.nn.functional.cosine_similarity(g.flatten(), ref.flatten(), dim=0).item()
+        rel = abs(float(g.norm()) - float(ref.norm())) / float(ref.norm())
+        assert c > 0.99 and rel < 0.06, (n, c, rel)
+        checked += 1
+    assert checked > 40
+
+
+def test_longformer_dropout_step_deterministic(dev):
+    z, sd, batch, arch = lf_case("lf_tiny_L64_w8")
+    vals = []
+    for _ in range(2):
+        m = build_lf(arch, flags_of(z, "train_full"), sd, dev, dropout=0.1).train()
+        m.amdseg_seed = 5
+        random.seed(1)
+        loss, _, _ = m(**{k: v.to(dev) for k, v in batch.items()})
+        loss.backward()
+        gn = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in m.parameters())).item()
+        assert math.isfinite(loss.item()) and math.isfinite(gn)
+        vals.append((loss.item(), gn))
+    assert vals[0] == vals[1]
