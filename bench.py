@@ -28,16 +28,23 @@ import torch  # noqa: E402
 MFMA_PEAK_TFLOPS = 2500.0       # gfx950 dense bf16 (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
 
 
-def flops_per_seq(L, H, I, layers, train=True):
-    """algorithmic FLOPs: projections 2*(3H^2 + H^2 + 2HI) + attention 2*(2*L*H) per token per layer."""
-    per_tok_layer = 2 * (4 * H * H + 2 * H * I) + 4 * L * H
+def flops_per_seq(L, H, I, layers, train=True, span=None):
+    """algorithmic FLOPs: projections 2*(3H^2 + H^2 + 2HI) + attention 2*(2*span*H) per token per layer
+    (span = L keys for BERT, the 2w+1 band + 1 global key for Longformer)."""
+    per_tok_layer = 2 * (4 * H * H + 2 * H * I) + 4 * (span or L) * H
     return per_tok_layer * layers * L * (3 if train else 1)
 
 
 def build(args, device):
     from transformers import BertConfig
-    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
-    cfg = BertConfig(vocab_size=30523, num_labels=2)          # bert-base-uncased + [BOS]
+    if args.model == "longformer":      # BASELINE config 5: longformer-base-4096 (+[BOS]), window 512, CLS global
+        from transformers import LongformerConfig
+        from spokennlp_amd.longformer_for_ts import LongformerWithDAForSentenceLabelingTopicSegmentation as M
+        cfg = LongformerConfig(vocab_size=50266, num_labels=2, max_position_embeddings=4098, type_vocab_size=1, pad_token_id=1,
+                               attention_window=[512] * 12, layer_norm_eps=1e-5)
+    else:
+        from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+        cfg = BertConfig(vocab_size=30523, num_labels=2)          # bert-base-uncased + [BOS]
     flags = dict(do_da_ts=True, do_cssl=True, do_tssp=True, ts_loss_weight=1.0, cl_loss_weight=0.5, cl_temp=0.1,
                  cl_anchor_level="eop_list", cl_positive_k=1, cl_negative_k=3, tssp_loss_weight=1.0) if args.workload == "full_da" else {}
     for k, v in flags.items():
@@ -50,10 +57,16 @@ def build(args, device):
 def make_batches(args, n, seed, device):
     from spokennlp_amd import data
     pairs = args.seqs_per_gpu // 2 if args.workload == "full_da" else args.seqs_per_gpu
-    docs = data.synth_docs(max(64, pairs * n // 2), seed=1234 + seed)
+    if args.model == "longformer":
+        docs = data.synth_docs(max(64, pairs * n * 3), seed=1234 + seed, vocab=50266, mean_sents=160, sd_sents=40)
+    else:
+        docs = data.synth_docs(max(64, pairs * n // 2), seed=1234 + seed)
     bs = data.batches_from_docs(docs, args.seq_len, pairs, seed=seed)
     while len(bs) < n:
         bs = bs + bs
+    if args.model == "longformer":      # RoBERTa convention: pad id 1
+        for b in bs:
+            b["input_ids"] = torch.where(b["attention_mask"] == 0, torch.ones_like(b["input_ids"]), b["input_ids"])
     return [{k: v.to(device) for k, v in b.items()} for b in bs[:n]], pairs
 
 
@@ -137,12 +150,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--seq-len", type=int, default=512)
-    ap.add_argument("--seqs-per-gpu", type=int, default=32)
+    ap.add_argument("--model", default="bert", choices=["bert", "longformer"])
+    ap.add_argument("--seq-len", type=int, default=None)
+    ap.add_argument("--seqs-per-gpu", type=int, default=None)
     ap.add_argument("--workload", default="full_da", choices=["full_da", "plain"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.seq_len is None:
+        args.seq_len = 4096 if args.model == "longformer" else 512
+    if args.seqs_per_gpu is None:
+        args.seqs_per_gpu = 8 if args.model == "longformer" else 32
+    if args.model == "longformer":
+        args.no_cpu_baseline = True       # the cpu_baseline leg times the BERT oracle (headline metric) only
 
     from spokennlp_amd import dp
     rank, world, local = dp.init_from_env()
@@ -184,11 +204,14 @@ def main():
         dt = t.item()
     seqs = args.seqs_per_gpu * world * args.steps
     value = seqs / dt
-    fl = flops_per_seq(args.seq_len, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers)
-    out = dict(metric="train seq/s (512-tok) bert-base topic-seg", value=round(value, 2), unit="seq/s", n_gpus=world,
+    fl = flops_per_seq(args.seq_len, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers,
+                       span=514 if args.model == "longformer" else None)
+    name = "bert-base-uncased(+[BOS])" if args.model == "bert" else "longformer-base-4096(+[BOS], window 512, CLS global)"
+    out = dict(metric="train seq/s (512-tok) bert-base topic-seg" if args.model == "bert" else "train seq/s (4096-tok) longformer-base topic-seg",
+               value=round(value, 2), unit="seq/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
-               config=dict(workload=f"bert-base-uncased(+[BOS]) topic-seg fine-tune, {args.workload}, seq_len={args.seq_len}, "
+               config=dict(workload=f"{name} topic-seg fine-tune, {args.workload}, seq_len={args.seq_len}, "
                                     f"{args.seqs_per_gpu} seqs/GPU/step ({pairs} samples), fwd+bwd+clip+AdamW, dropout 0.1",
                            global_batch=args.seqs_per_gpu * world, seq_len=args.seq_len, parallelism=f"dp{world}"),
                mfma_frac_whole_step=round(value / world * fl / (MFMA_PEAK_TFLOPS * 1e12), 4),

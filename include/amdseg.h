@@ -98,7 +98,8 @@ int amdseg_attn_band_f32(const float* qkv, const float* mask_bias, float* ctx, i
  *   softmax_fwd: rows = B*heads rows of L scores; p over the scores in place, pd = dropout(p), sp[row] = sum(pd)
  *   softmax_bwd: in p (saved) and d(pd) -> ds written over d(pd); pd recomputed
  *   wsum       : y[b,h,:] = sum_j coef[b,h,j] x[b,j,:]   (partials: B * L/64 * heads * H floats)
- *   dx_update  : dx[b,j,:] += sum_h coefA[b,h,j] vecA[b,h,:] + coefB[b,h,j] vecB[b,h,:] */
+ *   dx_update  : dx[b,j,:] += sum_h coefA[b,h,j] vecA[b,h,:] + coefB[b,h,j] vecB[b,h,:]
+ *                (vt_ws: B*H*32 bf16 scratch for the MFMA path; NULL selects the scalar kernel) */
 int amdseg_lf_rowvec_dot(const void* x, const float* vec, const float* add_tok, const float* add_bh, float* out, int B, int L, int H,
                          int heads, int dtype, amdseg_stream_t stream);
 int amdseg_lf_softmax_fwd(float* s_inout_p, float* pd, float* sp, int rows, int L, float dropout_p, uint64_t seed,
@@ -107,8 +108,8 @@ int amdseg_lf_softmax_bwd(const float* p_saved, float* dpd_inout_ds, float* pd, 
                           amdseg_stream_t stream);
 int amdseg_lf_wsum(const void* x, const float* coef, float* partials, float* y, int B, int L, int H, int heads, int dtype,
                    amdseg_stream_t stream);
-int amdseg_lf_dx_update(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, int B, int L, int H,
-                        int heads, int dtype, amdseg_stream_t stream);
+int amdseg_lf_dx_update(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, void* vt_ws, int B,
+                        int L, int H, int heads, int dtype, amdseg_stream_t stream);
 
 /* ---- HBM-bound row kernels (csrc/elementwise.hip) ---------------------------------------------------------------
  * embeddings + LayerNorm + dropout ([hf] models/bert/modeling_bert.py:53-108); tables are the fp32 masters.

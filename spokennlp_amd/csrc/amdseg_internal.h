@@ -53,8 +53,8 @@ int amdseg_lf_softmax_bwd_impl(const float* p_saved, float* dpd_inout_ds, float*
                                hipStream_t s);
 int amdseg_lf_wsum_impl(const void* x, const float* coef, float* partials, float* y, int B, int L, int H, int heads, int dtype,
                         hipStream_t s);
-int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, int B, int L,
-                             int H, int heads, int dtype, hipStream_t s);
+int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, void* vt_ws,
+                             int B, int L, int H, int heads, int dtype, hipStream_t s);
 
 int amdseg_rowdot_fwd_impl(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
                            hipStream_t s);

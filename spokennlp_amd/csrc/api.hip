@@ -77,9 +77,9 @@ int amdseg_lf_wsum(const void* x, const float* coef, float* partials, float* y, 
                    amdseg_stream_t stream) {
     return amdseg_lf_wsum_impl(x, coef, partials, y, B, L, H, heads, dtype, S(stream));
 }
-int amdseg_lf_dx_update(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, int B, int L, int H,
-                        int heads, int dtype, amdseg_stream_t stream) {
-    return amdseg_lf_dx_update_impl(dx, coefA, vecA, coefB, vecB, B, L, H, heads, dtype, S(stream));
+int amdseg_lf_dx_update(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, void* vt_ws, int B,
+                        int L, int H, int heads, int dtype, amdseg_stream_t stream) {
+    return amdseg_lf_dx_update_impl(dx, coefA, vecA, coefB, vecB, vt_ws, B, L, H, heads, dtype, S(stream));
 }
 int amdseg_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                         const float* pos, const float* type, const float* gamma, const float* beta, void* z, void* out,

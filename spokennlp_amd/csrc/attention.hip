@@ -15,56 +15,10 @@
 #include "common.h"
 #include "amdseg_internal.h"
 
-#define HD 64          // head dim
-#define CH 64          // rows per streamed chunk
+#include "tile64.h"
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
-// universal XOR swizzle for [rows][64] bf16 tiles (128 B rows, 8 chunks of 16 B): conflict-free for both the
-// ds_read_b128 fragment reads (16 rows, one chunk) and the tr_b16 gathers (8 rows x 32 B per half-wave)
-__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
-
-__device__ __forceinline__ void at_glds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(void, lds_wave_base), 16, 0, 0);
-}
-// stage a [64][64] bf16 tile; `base` points at element (row 0, col 0), rows are row_stride elements apart
-template <int NW>
-__device__ __forceinline__ void at_stage(const bf16_t* base, int row_stride, char* tile, int w, int l) {
-#pragma unroll
-    for (int q = 0; q < 8 / NW; ++q) {
-        const int R0 = (w * (8 / NW) + q) * 8;
-        const int r = R0 + (l >> 3), s = l & 7;
-        const int c = s ^ swz(r);
-        at_glds16(base + (size_t)r * row_stride + c * 8, tile + R0 * 128);
-    }
-}
-// 8 consecutive k-elements (chunk c) of row r
-__device__ __forceinline__ bf16x8 at_frag(const char* tile, int r, int c) {
-    return *reinterpret_cast<const bf16x8*>(tile + r * 128 + ((c ^ swz(r)) << 4));
-}
-// transposed gather: lane (i16 = l&15, g = l>>4) receives tile[r0a + j][col0 + i16] (j<4) and tile[r0b + j-4][..] (j>=4)
-__device__ __forceinline__ bf16x8 at_frag_tr(const char* tile, int r0a, int r0b, int col0, int l) {
-    const int i16 = l & 15;
-    const int c = (col0 >> 3) + ((i16 & 3) >> 1);
-    bf16x8 f;
-    {
-        const int row = r0a + (i16 >> 2);
-        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4, tile + row * 128 + ((c ^ swz(row)) << 4) + (i16 & 1) * 8));
-        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
-    }
-    {
-        const int row = r0b + (i16 >> 2);
-        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4, tile + row * 128 + ((c ^ swz(row)) << 4) + (i16 & 1) * 8));
-        f[4] = v[0]; f[5] = v[1]; f[6] = v[2]; f[7] = v[3];
-    }
-    return f;
-}
-__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
-    union { uint32_t u[4]; bf16x8 v; } r;
-    r.u[0] = pack2bf(a[0], a[1]); r.u[1] = pack2bf(a[2], a[3]);
-    r.u[2] = pack2bf(b[0], b[1]); r.u[3] = pack2bf(b[2], b[3]);
-    return r.v;
-}
 // dropout on attention probabilities: one 32-bit hash per aligned key pair, 16 bits per element.
 // element (row = bh*L + q, key); keep iff 16-bit field >= thresh16
 // (one mix32 round over (pair index ^ per-row salt): enough decorrelation for dropout, 1/3 of the integer ops)
@@ -376,7 +330,17 @@ template <int NW, bool BAND>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
-    const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    if (BAND) {
+        // 1-D launch.  The key block holding the global keys sees EVERY query chunk (L/64 instead of ~2W/64 + 1): those
+        // B*heads long workgroups come first in dispatch order and land round-robin on all XCDs, so they overlap the
+        // short ones instead of forming a tail on one XCD (block ids = 0 mod 64 all map to XCD 0 in a 3-D launch).
+        const int nkb = a.L / (NW * 16), nbh = a.heads * a.B, id = blockIdx.x;
+        int bh;
+        if (id < nbh) { kb = 0; bh = id; }
+        else { const int r = id - nbh; kb = 1 + r % (nkb - 1); bh = r / (nkb - 1); }
+        h = bh % a.heads; b = bh / a.heads;
+    }
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
     const int key = kb * (NW * 16) + w * 16 + i16;                    // this lane's key row
@@ -530,7 +494,7 @@ int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ct
     // backward kernels need 144-168 VGPRs: 4-wave workgroups keep 3 waves per SIMD resident (8-wave ones would spill or halve occupancy)
     if (window > 0) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, true>), dim3((L / 64) * heads * B), dim3(256), 0, s, a);
     } else {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);

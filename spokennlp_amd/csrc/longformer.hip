@@ -17,6 +17,7 @@
 //   lf_dx_update  : dx[b, j, :] += sum_h coefA[b, h, j] vecA[b, h, :] + coefB[b, h, j] vecB[b, h, :]  rank-2*heads update
 #include "common.h"
 #include "amdseg_internal.h"
+#include "tile64.h"
 
 #define LF_MAXCH 2          // 8-element column chunks per lane: H <= 1024
 #define LF_MAXHEADS 16
@@ -237,6 +238,152 @@ __global__ __launch_bounds__(256) void lf_dx_update_kernel(T* __restrict__ dx, c
     }
 }
 
+
+// ==================================================================================================== MFMA variants
+// bf16 activations: the three O(L) passes as skinny v_mfma_f32_16x16x32_bf16 products with the head index padded to
+// 16.  They are HBM-bound (one read of x; one read-modify-write of dx): the matrix cores only remove the VALU / LDS
+// cost of the per-token dot products.  The fp32 parity mode keeps the scalar kernels above.
+__device__ __forceinline__ void split_bf16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    union { uint32_t u[4]; bf16x8 b; } h, l_;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h.u[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+        const float r0 = v[2 * i] - __uint_as_float(h.u[i] << 16), r1 = v[2 * i + 1] - __uint_as_float(h.u[i] & 0xffff0000u);
+        l_.u[i] = pack2bf(r0, r1);
+    }
+    hi = h.b; lo = l_.b;
+}
+
+// scores: out[b, h, j] = vec[b, h, :] . x[b, j, :].  One wave = 16 tokens; A = x rows straight from global (16 B per lane
+// per k-step), B = vec as bf16 hi + lo (two MFMAs per k-step keep the fp32 vector exact to 2^-17).  grid (L/64, B)
+__global__ __launch_bounds__(256) void lf_rowvec_dot_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ vec,
+                                                                 const float* __restrict__ add_tok, const float* __restrict__ add_bh,
+                                                                 float* __restrict__ out, int L, int H, int heads) {
+    const int b = blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
+    const int j0 = blockIdx.x * 64 + w * 16;
+    const bf16_t* xp = x + ((size_t)b * L + j0 + i16) * H + g * 8;
+    const float* vp = vec + ((size_t)b * heads + (i16 < heads ? i16 : 0)) * H + g * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nk = H / 32;
+    for (int kk = 0; kk < nk; ++kk) {
+        const bf16x8 fx = *reinterpret_cast<const bf16x8*>(xp + kk * 32);
+        float v[8];
+        ld8<float>(vp + kk * 32, v);
+        if (i16 >= heads) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        bf16x8 hi, lo;
+        split_bf16(v, hi, lo);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, lo, acc, 0, 0, 0);
+    }
+    if (i16 < heads) {                         // lane: head i16, tokens j0 + g*4 .. +4
+        const int j = j0 + g * 4;
+        float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (add_tok) {
+            const float4 t = *reinterpret_cast<const float4*>(add_tok + (size_t)b * L + j);
+            o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+        }
+        if (add_bh) { const float c = add_bh[b * heads + i16]; o.x += c; o.y += c; o.z += c; o.w += c; }
+        *reinterpret_cast<float4*>(out + ((size_t)b * heads + i16) * L + j) = o;
+    }
+}
+
+// weighted row sum: part[b][chunk][h][slab*64 + c] = sum_{j in chunk} coef[b,h,j] x[b,j,slab*64+c].  One wave = one
+// [64 tokens][64 cols] tile of x staged in a wave-private LDS region by DMA; the product is the attention P.V step with
+// the 16 (padded) heads in place of the queries.  grid (ceil(L/256), H/64, B), 4 waves = 4 consecutive token chunks
+__global__ __launch_bounds__(256) void lf_wsum_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ coef,
+                                                           float* __restrict__ part, int L, int H, int heads) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 8192];
+    const int b = blockIdx.z, slab = blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
+    const int chunk = blockIdx.x * 4 + w, j0 = chunk * 64;
+    if (j0 >= L) return;                                   // no block-level barrier below: a wave may leave early
+    char* tile = smem + w * 8192;
+    at_stage<1>(x + ((size_t)b * L + j0) * H + slab * 64, H, tile, 0, l);
+    f32x4 s[4];
+    const float* cp = coef + ((size_t)b * heads + (i16 < heads ? i16 : 0)) * L + j0 + g * 4;
+#pragma unroll
+    for (int fc = 0; fc < 4; ++fc) {
+        const float4 c = *reinterpret_cast<const float4*>(cp + fc * 16);
+        s[fc] = i16 < heads ? (f32x4){c.x, c.y, c.z, c.w} : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+        const float v8[8] = {s[2 * kp][0], s[2 * kp][1], s[2 * kp][2], s[2 * kp][3], s[2 * kp + 1][0], s[2 * kp + 1][1], s[2 * kp + 1][2], s[2 * kp + 1][3]};
+        bf16x8 fp, fp_lo;                                   // coefficients as bf16 hi + lo: exact to 2^-17
+        split_bf16(v8, fp, fp_lo);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const bf16x8 fv = at_frag_tr(tile, (2 * kp) * 16 + g * 4, (2 * kp + 1) * 16 + g * 4, d * 16, l);
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fp, o[d], 0, 0, 0);
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fp_lo, o[d], 0, 0, 0);
+        }
+    }
+    if (i16 < heads) {
+        const int nchunk = L / 64;
+        float* pp = part + (((size_t)b * nchunk + chunk) * heads + i16) * H + slab * 64 + g * 4;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) *reinterpret_cast<float4*>(pp + d * 16) = make_float4(o[d][0], o[d][1], o[d][2], o[d][3]);
+    }
+}
+
+// vt[b][c][slot] bf16, slot = which*16 + head (which 0 = vecA, 1 = vecB; heads padded to 16 with zeros)
+__global__ void lf_vt_prep_kernel(const float* __restrict__ vecA, const float* __restrict__ vecB, bf16_t* __restrict__ vt,
+                                  int H, int heads, int total) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;          // over B * H * 32, slot fastest
+    if (gid >= total) return;
+    const int slot = gid & 31, c = (gid >> 5) % H, b = (gid >> 5) / H;
+    const int which = slot >> 4, h = slot & 15;
+    float v = 0.f;
+    if (h < heads) v = (which ? vecB : vecA)[((size_t)b * heads + h) * H + c];
+    vt[gid] = f2bf(v);
+}
+// dx[b, j, :] += [coefA | coefB][:, j]^T . [vecA ; vecB]   -- one k-step of 32 slots per 16x16 output tile.
+// Operands swapped (A = vt rows = columns of dx, B = coefficients of 16 tokens) so that a lane owns one token and 4
+// consecutive columns: 8-byte read-modify-write.  One wave = 32 tokens; grid (L/128, B)
+__global__ __launch_bounds__(256) void lf_dx_update_mfma_kernel(bf16_t* __restrict__ dx, const float* __restrict__ coefA,
+                                                                const float* __restrict__ coefB, const bf16_t* __restrict__ vt,
+                                                                int L, int H, int heads) {
+    const int b = blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
+    const int j0 = blockIdx.x * 128 + w * 32;
+    if (j0 >= L) return;
+    bf16x8 fc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float* cp = ((g >> 1) ? coefB : coefA) + (size_t)b * heads * L + j0 + t * 16 + i16;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int h = (g & 1) * 8 + e;
+            v[e] = h < heads ? cp[(size_t)h * L] : 0.f;
+        }
+        union { uint32_t u[4]; bf16x8 q; } pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk.u[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+        fc[t] = pk.q;
+    }
+    const bf16_t* vp = vt + ((size_t)b * H + i16) * 32 + g * 8;
+    for (int ct = 0; ct < H / 16; ++ct) {
+        const bf16x8 fv = *reinterpret_cast<const bf16x8*>(vp + (size_t)ct * 16 * 32);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fc[t], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            bf16_t* xp = dx + ((size_t)b * L + j0 + t * 16 + i16) * H + ct * 16 + g * 4;
+            const uint2 old = *reinterpret_cast<const uint2*>(xp);
+            uint2 nw;
+            nw.x = pack2bf(__uint_as_float(old.x << 16) + d[0], __uint_as_float(old.x & 0xffff0000u) + d[1]);
+            nw.y = pack2bf(__uint_as_float(old.y << 16) + d[2], __uint_as_float(old.y & 0xffff0000u) + d[3]);
+            *reinterpret_cast<uint2*>(xp) = nw;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- launchers
 static int lf_check(int B, int L, int H, int heads) {
     if (B <= 0 || L <= 0 || (L % 64) || (H % 8) || H > 8 * 64 * LF_MAXCH || heads <= 0 || heads > LF_MAXHEADS) return AMDSEG_ERR_SHAPE;
@@ -258,7 +405,9 @@ int amdseg_lf_rowvec_dot_impl(const void* x, const float* vec, const float* add_
     if (rc) return rc;
     if (L % 64) return AMDSEG_ERR_SHAPE;
     const size_t lds = (size_t)heads * H * 4;
-    if (dtype == AMDSEG_BF16) {
+    if (dtype == AMDSEG_BF16 && (H % 32) == 0) {
+        hipLaunchKernelGGL(lf_rowvec_dot_mfma_kernel, dim3(L / 64, B), dim3(256), 0, s, (const bf16_t*)x, vec, add_tok, add_bh, out, L, H, heads);
+    } else if (dtype == AMDSEG_BF16) {
         (void)hipFuncSetAttribute((const void*)lf_rowvec_dot_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(lf_rowvec_dot_kernel<bf16_t>, dim3(L / 64, B), dim3(256), lds, s, (const bf16_t*)x, vec, add_tok, add_bh, out, L, H, heads);
     } else {
@@ -290,9 +439,12 @@ int amdseg_lf_wsum_impl(const void* x, const float* coef, float* partials, float
     if (!x || !coef || !partials || !y) return AMDSEG_ERR_ARG;
     int rc = lf_check(B, L, H, heads);
     if (rc) return rc;
-    const int seglen = (L % LF_SEG) ? 64 : LF_SEG;
-    const int nseg = L / seglen;
-    if (dtype == AMDSEG_BF16)
+    int seglen = (L % LF_SEG) ? 64 : LF_SEG;
+    int nseg = L / seglen;
+    if (dtype == AMDSEG_BF16 && (H % 64) == 0) {
+        seglen = 64; nseg = L / 64;
+        hipLaunchKernelGGL(lf_wsum_mfma_kernel, dim3((nseg + 3) / 4, H / 64, B), dim3(256), 0, s, (const bf16_t*)x, coef, partials, L, H, heads);
+    } else if (dtype == AMDSEG_BF16)
         hipLaunchKernelGGL(lf_wsum_kernel<bf16_t>, dim3(nseg, B), dim3(256), 0, s, (const bf16_t*)x, coef, partials, L, H, heads, seglen);
     else
         hipLaunchKernelGGL(lf_wsum_kernel<float>, dim3(nseg, B), dim3(256), 0, s, (const float*)x, coef, partials, L, H, heads, seglen);
@@ -301,12 +453,18 @@ int amdseg_lf_wsum_impl(const void* x, const float* coef, float* partials, float
     return amdseg_launch_status();
 }
 
-int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, int B, int L,
-                             int H, int heads, int dtype, hipStream_t s) {
+int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, void* vt_ws,
+                             int B, int L, int H, int heads, int dtype, hipStream_t s) {
     if (!dx || !coefA || !vecA || !coefB || !vecB) return AMDSEG_ERR_ARG;
     int rc = lf_check(B, L, H, heads);
     if (rc) return rc;
     if (L % 64) return AMDSEG_ERR_SHAPE;
+    if (dtype == AMDSEG_BF16 && vt_ws && (H % 16) == 0) {
+        const int total = B * H * 32;
+        hipLaunchKernelGGL(lf_vt_prep_kernel, dim3((total + 255) / 256), dim3(256), 0, s, vecA, vecB, (bf16_t*)vt_ws, H, heads, total);
+        hipLaunchKernelGGL(lf_dx_update_mfma_kernel, dim3((L + 127) / 128, B), dim3(256), 0, s, (bf16_t*)dx, coefA, coefB, (const bf16_t*)vt_ws, L, H, heads);
+        return amdseg_launch_status();
+    }
     const size_t lds = (size_t)heads * H * 4 * 2;
     if (dtype == AMDSEG_BF16) {
         (void)hipFuncSetAttribute((const void*)lf_dx_update_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

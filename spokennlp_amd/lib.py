@@ -59,7 +59,7 @@ _PROTOS = {
     "amdseg_lf_softmax_fwd": [vp, vp, vp, i32, i32, f32, u64, vp],
     "amdseg_lf_softmax_bwd": [vp, vp, vp, i32, i32, f32, u64, vp],
     "amdseg_lf_wsum": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "amdseg_lf_dx_update": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "amdseg_lf_dx_update": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "amdseg_embed_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, u64, i32, vp],
     "amdseg_embed_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "amdseg_add_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, i32, vp],

@@ -104,7 +104,7 @@ class LongformerEncoderEngine(BertEncoderEngine):
         L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].2")
         cfg.phase = 0
         with torch.no_grad():
-            ops.lf_dx_update(other, pd, dyv, ds, r)
+            ops.lf_dx_update(other, pd, dyv, ds, r, A["lf_vt"])
             row0 = other.view(B, Lseq, H)[:, 0, :]
             row0.copy_((row0.float() + dx0).to(other.dtype))
 
@@ -112,4 +112,5 @@ class LongformerEncoderEngine(BertEncoderEngine):
         A = super()._arena(B, Lseq, train, fp32)
         if "lf_partials" not in A:
             A["lf_partials"] = torch.empty(B * (Lseq // 64) * self.heads * self.H, dtype=torch.float32, device=self.device)
+            A["lf_vt"] = torch.empty(B * self.H * 32, dtype=torch.bfloat16, device=self.device)
         return A

@@ -145,10 +145,12 @@ def lf_wsum(x, coef, H, partials=None):
     return y
 
 
-def lf_dx_update(dx, coefA, vecA, coefB, vecB):
+def lf_dx_update(dx, coefA, vecA, coefB, vecB, vt_ws=None):
     B, heads, Lseq = coefA.shape
     H = vecA.shape[2]
-    rc = L.load().amdseg_lf_dx_update(_p(dx), _p(coefA), _p(vecA), _p(coefB), _p(vecB), B, Lseq, H, heads, _dt(dx), _s())
+    if vt_ws is None and dx.dtype == torch.bfloat16:
+        vt_ws = torch.empty(B * H * 32, dtype=torch.bfloat16, device=dx.device)
+    rc = L.load().amdseg_lf_dx_update(_p(dx), _p(coefA), _p(vecA), _p(coefB), _p(vecB), _p(vt_ws), B, Lseq, H, heads, _dt(dx), _s())
     L.check(rc, "amdseg_lf_dx_update")
 
 

@@ -106,8 +106,11 @@ def test_global_row_kernels(dev, dt):
     vB = torch.randn(B, heads, H, device=dev)
     ref_dx = dx.float().view(B, L, H) + torch.einsum("bhj,bhk->bjk", cA, vec) + torch.einsum("bhj,bhk->bjk", cB, vB)
     ops.lf_dx_update(dx, cA, vec, cB, vB)
-    tol = 0.05 if dt == torch.bfloat16 else 1e-4
-    assert (dx.float().view(B, L, H) - ref_dx).abs().max().item() < tol
+    err = (dx.float().view(B, L, H) - ref_dx).abs()
+    if dt == torch.bfloat16:        # result stored in bf16 (2^-9 relative) + bf16 MFMA operands
+        assert (err <= 0.01 * ref_dx.abs() + 0.03).all(), err.max().item()
+    else:
+        assert err.max().item() < 1e-4
 
 
 # ---------------------------------------------------------------------------------------------------- model level
