@@ -311,3 +311,62 @@ def write_prediction_file(path, documents):
     import json
     with open(path, "w") as f:
         f.writelines([json.dumps(d, ensure_ascii=False) + "\n" for d in documents])
+
+
+# ---------------------------------------------------------------------------------------------------- PoNet (a12)
+def ponet_prepare_features(docs_sentence_ids, docs_labels, example_ids, max_seq_length, eos_id, cls_id, pad_id,
+                           use_paragraph_segment=False):
+    """alimeeting4mug/src/topic_segment/ponet_topic_segmentation.py:527-691 `prepare_input_features` on token ids.
+    docs_sentence_ids: per document, list of sentences, each a list of token ids ENDING with eos_id (the driver appends
+    "[EOS]" to every sentence, :537-545).  docs_labels: per document the label id of every sentence (-100 = unlabelled).
+    `segment_ids` (:564-596): 1-based sentence index per token, or -- with use_paragraph_segment -- a paragraph index that
+    advances after every LABELLED [EOS]; [CLS] gets 0 (:638), padding gets num_sentences + 1 (:668)."""
+    out = {k: [] for k in ("input_ids", "token_type_ids", "attention_mask", "segment_ids", "example_id", "labels", "sentence_range")}
+    L = max_seq_length
+    for e in range(len(docs_sentence_ids)):
+        ids = [t for s in docs_sentence_ids[e] for t in s]
+        labs = docs_labels[e]
+        tok_lab, seg, para = [], [], []
+        cur, cur_para = 1, 1
+        for ti, t in enumerate(ids):
+            if t == eos_id:
+                tok_lab.append(labs[cur - 1]); seg.append(cur); cur += 1
+            else:
+                tok_lab.append(-100); seg.append(cur)
+            para.append(cur_para)
+            if tok_lab[ti] != -100:
+                cur_para += 1
+        seg_ids = para if use_paragraph_segment else seg
+        total, nsent = len(ids), len(labs)
+        acc = [i for i, x in enumerate(ids) if x == eos_id]
+        left, sent_left, si = 0, 0, 0
+        while si < len(acc):
+            right, sent_right = acc[si] + 1, si + 1
+            if right - left >= L - 1 or right == total:
+                s_ids = ([cls_id] + ids[left:right])[:L]
+                s_seg = ([0] + seg_ids[left:right])[:L]
+                s_lab = ([-100] + tok_lab[left:right])[:L]
+                s_tt = [0] * len(s_ids); s_am = [1] * len(s_ids)
+                if sent_right - 1 == sent_left:
+                    left = right
+                    s_ids[-1] = eos_id
+                    s_lab[-1] = -100
+                else:
+                    left = acc[si - 1] + 1
+                    if s_lab[-1] != -100:
+                        s_lab[-1] = -100
+                if sent_right - 1 == sent_left or right == total:
+                    rng = [sent_left, sent_right]
+                    sent_left = sent_right
+                    si += 1
+                else:
+                    rng = [sent_left, sent_right - 1]
+                    sent_left = sent_right - 1
+                while len(s_ids) < L:
+                    s_ids.append(pad_id); s_tt.append(0); s_am.append(0); s_seg.append(nsent + 1); s_lab.append(-100)
+                out["input_ids"].append(s_ids); out["token_type_ids"].append(s_tt); out["attention_mask"].append(s_am)
+                out["segment_ids"].append(s_seg); out["labels"].append(s_lab); out["example_id"].append(example_ids[e])
+                out["sentence_range"].append(rng)
+            else:
+                si += 1
+    return out

@@ -85,3 +85,23 @@ def test_decode_and_writer(tmp_path):
     P.write_prediction_file(str(path), docs)
     lines = open(path).read().splitlines()
     assert len(lines) == 2 and json.loads(lines[1])["int_labels"] == docs[1]["int_labels"]
+
+
+# ---------------------------------------------------------------------------------------------------- PoNet (a12)
+PONET_CASES = [str(c) for c in G["ponet_cases"]]
+
+
+@pytest.mark.parametrize("name", PONET_CASES)
+def test_ponet_features_bit_exact(name):
+    nd, L, seed, eos, cls, pad, para = [int(v) for v in G[name + ".meta"]]
+    tok, off = G[name + ".sent_tokens"], G[name + ".sent_off"]
+    nsent = G[name + ".doc_nsent"]; labs = G[name + ".sent_labels"].tolist()
+    docs, dl, s = [], [], 0
+    for n in nsent:
+        docs.append([tok[off[i]:off[i + 1]].tolist() + [eos] for i in range(s, s + n)])
+        dl.append(labs[s:s + n]); s += n
+    cols = P.ponet_prepare_features(docs, dl, list(range(nd)), L, eos, cls, pad, use_paragraph_segment=bool(para))
+    for c in ("input_ids", "token_type_ids", "attention_mask", "segment_ids", "example_id", "labels"):
+        got, exp = np.array(cols[c], dtype=np.int32), G[name + "." + c]
+        assert got.shape == exp.shape and np.array_equal(got, exp), c
+    assert [b - a for a, b in cols["sentence_range"]] == G[name + ".num_sentences"].tolist()

@@ -95,6 +95,60 @@ CASES = [  # name, n_docs, mean_sents, max_tok, max_seq_length, seed, tssp_ablat
 ]
 
 
+PONET_SRC = "/root/reference/alimeeting4mug/src/topic_segment/ponet_topic_segmentation.py"
+EOS = 7
+PONET_CASES = [  # name, n_docs, mean_sents, max_tok, max_seq_length, seed, use_paragraph_segment, unknown-label fraction
+    ("ponet_L32_sent", 3, 12, 8, 32, 0, False, 0.0),
+    ("ponet_L32_para", 3, 12, 8, 32, 1, True, 0.0),
+    ("ponet_L64_para_unk", 4, 25, 10, 64, 2, True, 0.4),
+    ("ponet_L16_long", 2, 8, 30, 16, 3, False, 0.0),
+]
+
+
+class PonetStubTokenizer:
+    eos_token_id, cls_token_id, pad_token_id = EOS, CLS, PAD
+
+    def __call__(self, sentences, is_split_into_words=True, add_special_tokens=False, return_token_type_ids=True,
+                 return_attention_mask=True):
+        ids = []
+        for doc in sentences:
+            row = []
+            for s in doc:
+                assert s.endswith("[EOS]")
+                row.extend(int(w) for w in s[:-5].split())
+                row.append(EOS)
+            ids.append(row)
+        return {"input_ids": ids, "token_type_ids": [[0] * len(r) for r in ids], "attention_mask": [[1] * len(r) for r in ids]}
+
+
+def ponet_cases(out, names):
+    tree = ast.parse(open(PONET_SRC).read())
+    main_fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main"][0]
+    fn = [n for n in ast.walk(main_fn) if isinstance(n, ast.FunctionDef) and n.name == "prepare_input_features"]
+    assert len(fn) == 1
+    code = compile(ast.Module(body=fn, type_ignores=[]), "<reference closure>", "exec")
+    for name, nd, ms, mt, L, seed, para, unk in PONET_CASES:
+        ns = dict(tokenizer=PonetStubTokenizer(), target_specical_ids={EOS}, label_to_id={"B-EOP": 0, "O": 1},
+                  use_paragraph_segment=para, max_seq_length=L, question_column_name="labels", context_column_name="sentences",
+                  example_id_column_name="example_id")
+        exec(code, ns)
+        docs = toy_docs(nd, 2000 + seed, ms, mt, unk)
+        examples = {"labels": [d[1] for d in docs], "sentences": [[" ".join(map(str, x)) for x in d[0]] for d in docs],
+                    "example_id": list(range(nd))}
+        res = ns["prepare_input_features"](examples)
+        names.append(name)
+        out[name + ".meta"] = np.array([nd, L, seed, EOS, CLS, PAD, int(para)], dtype=np.int32)
+        sent_flat, sent_off = pack([s for d in docs for s in d[0]])
+        out[name + ".sent_tokens"] = sent_flat; out[name + ".sent_off"] = sent_off
+        out[name + ".doc_nsent"] = np.array([len(d[0]) for d in docs], dtype=np.int32)
+        lab = {"B-EOP": 0, "O": 1}
+        out[name + ".sent_labels"] = np.array([lab.get(l, -100) for d in docs for l in d[1]], dtype=np.int32)
+        for c in ("input_ids", "token_type_ids", "attention_mask", "segment_ids", "example_id", "labels"):
+            out[name + "." + c] = np.array(res[c], dtype=np.int32)
+        out[name + ".num_sentences"] = np.array([len(w) for w in res["sentences"]], dtype=np.int32)
+        print(name, "windows", len(res["input_ids"]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     out = {}
@@ -130,6 +184,9 @@ def main():
         else:
             print(name, "reference raised", err)
     out["cases"] = np.array(names)
+    pn = []
+    ponet_cases(out, pn)
+    out["ponet_cases"] = np.array(pn)
     np.savez_compressed(os.path.join(OUT, "preprocess.npz"), **out)
     print("wrote", os.path.join(OUT, "preprocess.npz"), os.path.getsize(os.path.join(OUT, "preprocess.npz")), "bytes")
 
