@@ -184,3 +184,41 @@ def test_fp32_parity_mode_logits_within_1e3(dev, case, variant):
     assert (cos.cpu() - torch.from_numpy(z[f"{variant}.cos"])).abs().max().item() < 1e-4
     assert O.decode_predictions(logits.cpu()[:, 0], batch["labels"][:, 0]) == \
         O.decode_predictions(ref_logits[:, 0], batch["labels"][:, 0])
+
+
+# ------------------------------------------------------------------------------------------------ ELECTRA wrapper (f-3)
+def test_electra_wrapper_vs_reference_golden(dev):
+    from transformers import ElectraConfig
+    from spokennlp_amd.electra_for_ts import ElectraWithDAForSentenceLabelingTopicSegmentation as M
+    from oracle import bert_ts_oracle as O
+    z, sd, batch, arch = load_case("electra_tiny_L64")
+    for variant, mode in (("full_eval", "eval"), ("train_full", "train")):
+        cfg = ElectraConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **arch)
+        for k, v in flags_of(z, variant).items():
+            setattr(cfg, k, v)
+        m = M(cfg)
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all("position_ids" in k or "token_type_ids" in k for k in missing)
+        m = m.to(dev)
+        random.seed(int(z[f"{variant}.random_seed"]))
+        if mode == "eval":
+            m.eval()
+            with torch.no_grad():
+                loss, logits, cos = m(**to_dev(batch, dev))
+            ref = torch.from_numpy(z[f"{variant}.logits"])
+            assert (logits.cpu() - ref).abs().max().item() < 0.08
+            assert O.decode_predictions(logits.cpu()[:, 0], batch["labels"][:, 0]) == O.decode_predictions(ref[:, 0], batch["labels"][:, 0])
+        else:
+            m.train()
+            loss, _, _ = m(**to_dev(batch, dev))
+            loss.backward()
+            params = dict(m.named_parameters())
+            for k in z.files:
+                if k.startswith("train_full.grad."):
+                    n = k[len("train_full.grad."):]
+                    ref = torch.from_numpy(z[k])
+                    if float(ref.norm()) < 1e-5:
+                        continue
+                    c = torch.nn.functional.cosine_similarity(params[n].grad.float().cpu().flatten(), ref.flatten(), dim=0).item()
+                    assert c > 0.99, (n, c)
+        assert abs(loss.item() - float(z[f"{variant}.loss"])) < 0.05

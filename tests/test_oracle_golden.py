@@ -156,3 +156,41 @@ def test_longformer_train_grads_match_reference(case):
             assert np.abs(g.numpy() - z[k]).max() < 5e-5, n
             n_checked += 1
     assert n_checked > 40
+
+
+# ------------------------------------------------------------------------------------------------ ELECTRA (f-3)
+def electra_encode(sd, cfg, ids, am, tt, return_all=False):
+    return O.bert_encode(sd, cfg, ids, am, tt, return_all=return_all, prefix="electra.")
+
+
+def electra_case():
+    z, sd, batch, arch = load_case("electra_tiny_L64")
+    arch.pop("embedding_size", None)
+    return z, sd, batch, arch
+
+
+@pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
+def test_electra_eval_matches_reference(variant):
+    """ELECTRA-base's encoder is the BERT block under the `electra.` prefix (electra_for_ts.py; the reference's forward
+    only runs with the harness alias documented in tools/gen_golden.py)."""
+    z, sd, batch, arch = electra_case()
+    cfg = cfg_for(arch, flags_of(z, variant))
+    random.seed(int(z[f"{variant}.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos, hs = O.model_forward(sd, cfg, batch, return_hidden=True, encode=electra_encode)
+    assert abs(loss.item() - float(z[f"{variant}.loss"])) < 2e-5
+    assert np.abs(logits.numpy() - z[f"{variant}.logits"]).max() < 2e-5
+
+
+def test_electra_train_grads_match_reference():
+    z, sd, batch, arch = electra_case()
+    cfg = cfg_for(arch, flags_of(z, "train_full"))
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    random.seed(int(z["train_full.random_seed"]))
+    loss, _, _ = O.model_forward(sd, cfg, batch, encode=electra_encode)
+    loss.backward()
+    assert abs(loss.item() - float(z["train_full.loss"])) < 3e-5
+    for k in z.files:
+        if k.startswith("train_full.grad."):
+            n = k[len("train_full.grad."):]
+            assert np.abs(sd[n].grad.numpy() - z[k]).max() < 5e-5, n

@@ -24,8 +24,9 @@ sys.path.insert(0, REF)
 from transformers import BertConfig  # noqa: E402
 import models.bert_for_ts as ref_bt  # noqa: E402
 import models.longformer_for_ts as ref_lf  # noqa: E402
+import models.electra_for_ts as ref_el  # noqa: E402
 import models.modules.loss_calculator as ref_lc  # noqa: E402
-from transformers import LongformerConfig  # noqa: E402
+from transformers import LongformerConfig, ElectraConfig  # noqa: E402
 from spokennlp_amd import data  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -45,6 +46,7 @@ class TorchProxy:
 ref_bt.torch = TorchProxy()
 ref_lc.torch = TorchProxy()
 ref_lf.torch = TorchProxy()
+ref_el.torch = TorchProxy()
 
 FULL = dict(do_da_ts=True, do_cssl=True, do_tssp=True, ts_loss_weight=1.0, ts_score_predictor="lt", ts_score_predictor_cos_temp=1,
             focal_loss_gamma=0.0, weight_label_zero=0.5, cl_loss_weight=0.5, cl_temp=0.1, cl_anchor_level="eop_list",
@@ -55,13 +57,19 @@ PLAIN = dict(do_da_ts=False, do_cssl=False, do_tssp=False, ts_loss_weight=1.0, t
 
 
 def make_model(arch, flags, seed, kind="bert"):
-    C = BertConfig if kind == "bert" else LongformerConfig
+    C = {"bert": BertConfig, "longformer": LongformerConfig, "electra": ElectraConfig}[kind]
     cfg = C(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **arch)
     for k, v in flags.items():
         setattr(cfg, k, v)
     torch.manual_seed(seed)
     if kind == "bert":
         m = ref_bt.BertWithDAForSentenceLabelingTopicSegmentation(cfg)
+    elif kind == "electra":
+        m = ref_el.ElectraWithDAForSentenceLabelingTopicSegmentation(cfg)
+        # reference quirk: electra_for_ts.py builds `self.electra` (:25) but its forward calls `self.bert(...)` (:52) and
+        # raises AttributeError as shipped; the harness aliases the attribute (not registered as a sub-module, so the
+        # state-dict names stay `electra.*`) to obtain the values the code evidently intends
+        object.__setattr__(m, "bert", m.electra)
     else:
         m = ref_lf.LongformerWithDAForSentenceLabelingTopicSegmentation(cfg)
     with torch.no_grad():       # O(1) logits so that parity is meaningful
@@ -146,6 +154,7 @@ def main():
     ]
     run_case("tiny_L64", arch, 64, 2, 0, variants)
     run_case("tiny_L128", arch, 128, 2, 1, variants[:3])
+    run_case("electra_tiny_L64", dict(arch, embedding_size=128), 64, 2, 4, variants[:3], kind="electra")
     lf = dict(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
               max_position_embeddings=130, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2, layer_norm_eps=1e-5)
     run_case("lf_tiny_L64_w8", dict(lf, attention_window=[16, 16]), 64, 2, 2, variants[:3], kind="longformer")
