@@ -138,6 +138,10 @@ int amdseg_dropout(const void* x, void* y, size_t n, float p, uint64_t seed, int
 int amdseg_cast(const void* x, void* y, size_t n, int dtype_in, int dtype_out, amdseg_stream_t stream);
 /* fp32 master W[N,K] -> bf16 Wb[N,K] and bf16 transpose Wt[K,N] (either may be NULL); N,K multiples of 64 */
 int amdseg_cast_transpose(const float* W, void* Wb, void* Wt, int N, int K, amdseg_stream_t stream);
+/* the same for n matrices in one launch (host pointer tables; Wb or Wt may be NULL as a whole): the per-step refresh of
+ * the bf16 compute shadows after the optimiser step ([hf] trainer.py optimizer.step -> next forward) */
+int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
+                                  amdseg_stream_t stream);
 /* small-C linear heads: logits[M,C] = x[M,H] W[C,H]^T + b, C <= 4
  * (modules/loss_calculator.py:17,42 classifier; modules/tssp.py:14,31) and their backward */
 int amdseg_rowdot_fwd(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,

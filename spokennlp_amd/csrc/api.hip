@@ -119,6 +119,10 @@ int amdseg_cast(const void* x, void* y, size_t n, int dtype_in, int dtype_out, a
 int amdseg_cast_transpose(const float* W, void* Wb, void* Wt, int N, int K, amdseg_stream_t stream) {
     return amdseg_cast_transpose_impl(W, Wb, Wt, N, K, S(stream));
 }
+int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
+                                  amdseg_stream_t stream) {
+    return amdseg_cast_transpose_batched_impl(n, W, Wb, Wt, N, K, S(stream));
+}
 int amdseg_rowdot_fwd(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
                       amdseg_stream_t stream) {
     return amdseg_rowdot_fwd_impl(x, W, b, out, M, H, C, dtype, S(stream));

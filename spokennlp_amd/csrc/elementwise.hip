@@ -405,6 +405,45 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* W, bf1
     }
 }
 
+// batched form: every matrix of the model in ONE launch (the per-step shadow refresh after AdamW was 60 launches of ~6 us)
+#define CT_MAXB 64
+struct CastTransposeBatch {
+    const float* W[CT_MAXB]; bf16_t* Wb[CT_MAXB]; bf16_t* Wt[CT_MAXB];
+    int N[CT_MAXB], K[CT_MAXB], tile0[CT_MAXB + 1];      // tile0: prefix sum of (N/64)*(K/64)
+    int n;
+};
+__global__ __launch_bounds__(256) void cast_transpose_batched_kernel(CastTransposeBatch b) {
+    __shared__ bf16_t tile[64][66];
+    int m = 0;
+    while (m + 1 < b.n && (int)blockIdx.x >= b.tile0[m + 1]) ++m;
+    const float* W = b.W[m]; bf16_t* Wb = b.Wb[m]; bf16_t* Wt = b.Wt[m];
+    const int N = b.N[m], K = b.K[m], t = blockIdx.x - b.tile0[m], kt = K / 64;
+    const int n0 = (t / kt) * 64, k0 = (t % kt) * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty * 4 + i;
+        const float4 v = *reinterpret_cast<const float4*>(W + (size_t)(n0 + r) * K + k0 + tx * 4);
+        const bf16_t b0 = f2bf(v.x), b1 = f2bf(v.y), b2 = f2bf(v.z), b3 = f2bf(v.w);
+        tile[r][tx * 4 + 0] = b0; tile[r][tx * 4 + 1] = b1; tile[r][tx * 4 + 2] = b2; tile[r][tx * 4 + 3] = b3;
+        if (Wb) {
+            uint2 pk; pk.x = (uint32_t)b0 | ((uint32_t)b1 << 16); pk.y = (uint32_t)b2 | ((uint32_t)b3 << 16);
+            *reinterpret_cast<uint2*>(Wb + (size_t)(n0 + r) * K + k0 + tx * 4) = pk;
+        }
+    }
+    __syncthreads();
+    if (Wt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = ty * 4 + i;
+            uint2 pk;
+            pk.x = (uint32_t)tile[tx * 4 + 0][kr] | ((uint32_t)tile[tx * 4 + 1][kr] << 16);
+            pk.y = (uint32_t)tile[tx * 4 + 2][kr] | ((uint32_t)tile[tx * 4 + 3][kr] << 16);
+            *reinterpret_cast<uint2*>(Wt + (size_t)(k0 + kr) * N + n0 + tx * 4) = pk;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ small-C row dot (heads)
 // logits[m][c] = x[m,:] . W[c,:] + b[c]   (classifier H->2, TSSP H->3;  modules/loss_calculator.py:17,42, modules/tssp.py:14,31)
 template <typename T, int NCH>
@@ -624,6 +663,26 @@ int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K,
     if (!W || (!Wb && !Wt)) return AMDSEG_ERR_ARG;
     if (N <= 0 || K <= 0 || (N % 64) || (K % 64)) return AMDSEG_ERR_SHAPE;
     hipLaunchKernelGGL(cast_transpose_kernel, dim3(K / 64, N / 64), dim3(256), 0, s, W, (bf16_t*)Wb, (bf16_t*)Wt, N, K);
+    return amdseg_launch_status();
+}
+
+int amdseg_cast_transpose_batched_impl(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
+                                       hipStream_t s) {
+    if (n <= 0 || !W || !N || !K || (!Wb && !Wt)) return AMDSEG_ERR_ARG;
+    for (int base = 0; base < n; base += CT_MAXB) {
+        CastTransposeBatch b = {};
+        b.n = n - base < CT_MAXB ? n - base : CT_MAXB;
+        int tiles = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const int j = base + i;
+            if (!W[j] || N[j] <= 0 || K[j] <= 0 || (N[j] % 64) || (K[j] % 64)) return AMDSEG_ERR_SHAPE;
+            b.W[i] = W[j]; b.Wb[i] = Wb ? (bf16_t*)Wb[j] : nullptr; b.Wt[i] = Wt ? (bf16_t*)Wt[j] : nullptr;
+            b.N[i] = N[j]; b.K[i] = K[j]; b.tile0[i] = tiles;
+            tiles += (N[j] / 64) * (K[j] / 64);
+        }
+        b.tile0[b.n] = tiles;
+        hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3(tiles), dim3(256), 0, s, b);
+    }
     return amdseg_launch_status();
 }
 

@@ -39,6 +39,7 @@ struct GemmNTArgs {
     int lda, ldb, ldc, ldr, ldc2;
     int M, N, K;
     int tiles_m, tiles_n;
+    int stagger;        // gemm_nt_kernel: units of 6400 clk the second resident workgroup of every CU waits at start
 };
 
 // bijective XCD-aware remap: hardware places workgroup b on XCD b % 8; give each XCD a contiguous tile range
@@ -84,6 +85,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
     const int wr = w >> 1, wc = w & 1;
     const int nwg = a.tiles_m * a.tiles_n;
     const int t = xcd_remap(blockIdx.x, nwg);
+    // De-phase the two workgroups resident on a CU.  Tiles of one launch all take the same time, so the 512 slots would run
+    // in lock step: every CU stores its tile at the same moment (an HBM-write-bound burst with the matrix pipes idle), then
+    // every CU computes (no HBM writes).  Delaying the second slot of each CU by about half a tile makes one workgroup's
+    // output burst overlap the other's K loop for the whole launch (profiles/r01_gemm_experiments.md, store ablation).
+    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(100);
     // grouped tile order inside each XCD's contiguous range: the ~64 tiles resident on one XCD (32 CUs x 2) form a
     // GROUP_M x 8 patch, so each A/B panel fetched into the XCD's 4 MiB L2 is shared by 8 tiles and the resident
     // working set (8 + 8 panels) stays below the L2 size
@@ -161,7 +168,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
 #ifdef AMDSEG_PHASE_TIMERS
     const unsigned long long pt_loop_end = __builtin_readcyclecounter();
 #endif
-    // ---- epilogue straight from the accumulators: lane (row m, 4 consecutive n) -> 8-B (bf16) / 16-B (fp32) accesses
+    // ---- epilogue.  The accumulator layout gives a lane one row and 4 consecutive columns (8 B of bf16): stored directly,
+    // one instruction touches 32 rows x 16 B -- 32 partial cache lines -- and the CU's address path (shared with the
+    // other resident workgroup's global->LDS staging) becomes the bottleneck (store ablation: +23 us on the QKV shape,
+    // +59 us on the dual-output FFN shape).  bf16 outputs therefore go through a wave-private LDS transpose: 8-B
+    // ds_writes in the accumulator layout, 16-B ds_reads in a row-contiguous layout (8 lanes = one 128-B row segment),
+    // so every global store instruction writes 8 complete 128-B lines.  16-B chunk c of row r lives at chunk
+    // c ^ ((r ^ (r >> 3)) & 7): conflict-free for both access shapes (two 64 x 128-B images per wave = all 64 KiB).
     const int hi = l >> 5;
     float4 bv[2][4];
     if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
@@ -169,6 +182,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const float4*>(a.bias + n0 + wc * 64 + j * 32 + q * 8 + hi * 4);
+    }
+    constexpr bool STAGED = sizeof(OutT) == 2;
+    constexpr int SROW = 128;
+    char* stg = smem + w * (64 * SROW);                           // 8 KiB per wave; a second image for C2 follows
+    char* stg2 = smem + 4 * (64 * SROW) + w * (64 * SROW);
+#define STG_OFF(r, c16) ((r) * SROW + ((((c16) ^ ((r) ^ ((r) >> 3))) & 7) << 4))
+    // (staging the R operand through LDS the same way was measured slower: +13 us on the GELU-backward shape)
+    constexpr bool RSTAGED = false;
+    uint4 rload[8];
+    if (RSTAGED) {                                                // the R tile of this wave, row-contiguous 16-B loads
+        const bf16_t* rbase = a.R + (size_t)(m0 + wr * 64) * a.ldr + n0 + wc * 64 + (l & 7) * 8;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) rload[p] = *reinterpret_cast<const uint4*>(rbase + (size_t)(p * 8 + (l >> 3)) * a.ldr);
+    }
+    if (STAGED) __syncthreads();                                  // every wave is done reading the K-loop tiles
+    if (RSTAGED) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<uint4*>(stg2 + STG_OFF(p * 8 + (l >> 3), l & 7)) = rload[p];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -178,21 +211,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    rr[j][q] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + n0 + wc * 64 + j * 32 + q * 8 + hi * 4);
+                for (int q = 0; q < 4; ++q) {
+                    if (RSTAGED) rr[j][q] = *reinterpret_cast<const uint2*>(stg2 + STG_OFF(i * 32 + (l & 31), j * 4 + q) + hi * 8);
+                    else rr[j][q] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + n0 + wc * 64 + j * 32 + q * 8 + hi * 4);
+                }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int gn = n0 + wc * 64 + j * 32 + q * 8 + hi * 4;
+                const int soff = STG_OFF(i * 32 + (l & 31), j * 4 + q) + hi * 8;
                 float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
                 if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
                     v[0] += bv[j][q].x; v[1] += bv[j][q].y; v[2] += bv[j][q].z; v[3] += bv[j][q].w;
                 }
                 if (EPI == EPI_BIAS_GELU) {
                     uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(a.C2 + gm * a.ldc2 + gn) = pk;      // pre-activation u, kept for backward
+                    *reinterpret_cast<uint2*>(stg2 + soff) = pk;                    // pre-activation u, kept for backward
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                 } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
@@ -201,14 +237,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
                     if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
                     else { v[0] *= gelu_grad_fast(r0); v[1] *= gelu_grad_fast(r1); v[2] *= gelu_grad_fast(r2); v[3] *= gelu_grad_fast(r3); }
                 }
-                OutT* dst = reinterpret_cast<OutT*>(a.C) + gm * a.ldc + gn;
-                if (sizeof(OutT) == 2) {
+                if (STAGED) {
                     uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(dst) = pk;
+                    *reinterpret_cast<uint2*>(stg + soff) = pk;
                 } else {
+                    OutT* dst = reinterpret_cast<OutT*>(a.C) + gm * a.ldc + gn;
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
+    }
+    if (STAGED) {
+        __builtin_amdgcn_wave_barrier();                              // wave-private image: only this wave's ds ops matter
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int rr0 = l >> 3, cc = l & 7;                           // lane -> (row within an 8-row group, 16-B chunk)
+        bf16_t* cbase = reinterpret_cast<bf16_t*>(a.C) + (size_t)(m0 + wr * 64) * a.ldc + n0 + wc * 64 + cc * 8;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int r = p * 8 + rr0;
+            const uint4 val = *reinterpret_cast<const uint4*>(stg + STG_OFF(r, cc));
+            *reinterpret_cast<uint4*>(cbase + (size_t)r * a.ldc) = val;
+        }
+        if (EPI == EPI_BIAS_GELU) {
+            bf16_t* c2base = a.C2 + (size_t)(m0 + wr * 64) * a.ldc2 + n0 + wc * 64 + cc * 8;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int r = p * 8 + rr0;
+                const uint4 val = *reinterpret_cast<const uint4*>(stg2 + STG_OFF(r, cc));
+                *reinterpret_cast<uint4*>(c2base + (size_t)r * a.ldc2) = val;
+            }
+        }
     }
 #ifdef AMDSEG_PHASE_TIMERS
     if (a.dbg && l == 0) {
@@ -558,7 +615,11 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
         hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, OutT>), dim3(T < 256 ? ((T + 7) / 8) * 8 : 256), dim3(512), PP_LDS, s, a);
         return amdseg_launch_status();
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a_in.tiles_m * a_in.tiles_n), dim3(256), 0, s, a_in);
+    GemmNTArgs a = a_in;
+    static int stagger = -1;
+    if (stagger < 0) { const char* e = getenv("AMDSEG_STAGGER"); stagger = e ? atoi(e) : 0; }
+    a.stagger = stagger;
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }
 
@@ -577,7 +638,7 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     a.dbg = g_amdseg_dbg;
 #endif
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldc2 = ldc2; a.M = M; a.N = N; a.K = K;
-    a.tiles_m = M / BM; a.tiles_n = N / BN;
+    a.tiles_m = M / BM; a.tiles_n = N / BN; a.stagger = 0;
     switch (epi) {
         case EPI_NONE: return out_fp32 ? launch_nt<EPI_NONE, float>(a, stream) : launch_nt<EPI_NONE, bf16_t>(a, stream);
         case EPI_BIAS:

@@ -104,6 +104,7 @@ class BertEncoderEngine:
                               w1_t=torch.empty(H, I, dtype=torch.bfloat16, device=device),
                               w2_t=torch.empty(I, H, dtype=torch.bfloat16, device=device)) for _ in range(self.nlayers)]
         self._shadow_version = -1
+        self._ct_table = None
         self._arenas = {}
         self._trigger = torch.zeros(1, device=device, requires_grad=True)
         self.adam_m = None
@@ -169,14 +170,23 @@ class BertEncoderEngine:
         ver = self.fp.flat_p._version
         if not force and ver == self._shadow_version:
             return
-        H, I = self.H, self.I
-        for i in range(self.nlayers):
-            t = self.shadow_t[i]
-            wq = self.fp.view(self.fp.flat_p, self.fp.lp(i, "attention.self.query.weight"), (3 * H, H))
-            ops.cast_transpose(wq, self.fp.view(self.shadow, self.fp.lp(i, "attention.self.query.weight"), (3 * H, H)), t["wqkv_t"])
-            for s, key in (("attention.output.dense.weight", "wo_t"), ("intermediate.dense.weight", "w1_t"),
-                           ("output.dense.weight", "w2_t")):
-                ops.cast_transpose(self._p(self.fp.flat_p, i, s), self._p(self.shadow, i, s), t[key])
+        if self._ct_table is None:
+            Ws, Wbs, Wts, Ns, Ks = [], [], [], [], []
+            H = self.H
+            for i in range(self.nlayers):
+                t = self.shadow_t[i]
+                qn = self.fp.lp(i, "attention.self.query.weight")
+                Ws.append(self.fp.view(self.fp.flat_p, qn, (3 * H, H))); Wbs.append(self.fp.view(self.shadow, qn, (3 * H, H))); Wts.append(t["wqkv_t"])
+                for s_, key in (("attention.output.dense.weight", "wo_t"), ("intermediate.dense.weight", "w1_t"),
+                                ("output.dense.weight", "w2_t")):
+                    Ws.append(self._p(self.fp.flat_p, i, s_)); Wbs.append(self._p(self.shadow, i, s_)); Wts.append(t[key])
+            n = len(Ws)
+            self._ct_table = (n, (C.c_void_p * n)(*[w.data_ptr() for w in Ws]), (C.c_void_p * n)(*[w.data_ptr() for w in Wbs]),
+                              (C.c_void_p * n)(*[w.data_ptr() for w in Wts]), (C.c_int * n)(*[w.shape[0] for w in Ws]),
+                              (C.c_int * n)(*[w.shape[1] for w in Ws]))
+        n, pw, pb, pt, pn, pk = self._ct_table
+        rc = L.load().amdseg_cast_transpose_batched(n, pw, pb, pt, pn, pk, torch.cuda.current_stream().cuda_stream)
+        L.check(rc, "amdseg_cast_transpose_batched")
         self._shadow_version = self.fp.flat_p._version
 
     # ------------------------------------------------------------------------------------------------ arenas
