@@ -22,11 +22,20 @@
 // dropout on attention probabilities: one 32-bit hash per aligned key pair, 16 bits per element.
 // element (row = bh*L + q, key); keep iff 16-bit field >= thresh16
 // (one mix32 round over (pair index ^ per-row salt): enough decorrelation for dropout, 1/3 of the integer ops)
-__device__ __forceinline__ uint32_t pdrop_salt(uint64_t seed, uint64_t row) {
-    return mix32((uint32_t)seed ^ (uint32_t)(seed >> 32) * 0x9e3779b9u ^ mix32((uint32_t)row * 0x85ebca6bu + (uint32_t)(row >> 32)));
+__device__ __forceinline__ uint32_t pdrop_seedmix(uint64_t seed) {           // wave-uniform, once per kernel
+    return mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9e3779b9u));
+}
+// per-row salt: ONE multiply -- the dK/dV kernel needs it for 16 different rows per lane and chunk, the avalanche is done
+// by the mix32 round of pdrop_bits over (salt + pair index * golden ratio)
+__device__ __forceinline__ uint32_t pdrop_salt(uint32_t seedmix, uint64_t row) {
+    return seedmix + (uint32_t)row * 0x85ebca6bu;
 }
 __device__ __forceinline__ uint32_t pdrop_bits(uint32_t salt, int key_even) {
-    return mix32(salt + (uint32_t)(key_even >> 1) * 0x9e3779b9u);
+    // one multiply round: the argument is already a sum of odd-constant multiples of (row, pair), and v_mul_lo_u32 runs at
+    // quarter rate -- the two-round mix32 made dropout a third of the forward kernel's time
+    uint32_t x = salt + (uint32_t)(key_even >> 1) * 0x9e3779b9u;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+    return x;
 }
 __device__ __forceinline__ float xor_reduce_max_g(float v) {   // across the 4 lane groups sharing l&15
     v = fmaxf(v, __shfl_xor(v, 16, 64));
@@ -37,6 +46,12 @@ __device__ __forceinline__ float xor_reduce_sum_g(float v) {
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;
+}
+
+// 64 consecutive floats (a chunk's key mask / LSE / delta) global -> LDS by DMA, 4 B per lane; issued by ONE wave and
+// covered by the same vmcnt(0) + barrier hand-off as the tiles
+__device__ __forceinline__ void at_stage_f32x64(const float* g, char* lds, int l) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(g + l), LDS_PTR(void, lds), 4, 0, 0);
 }
 
 struct AttnArgs {
@@ -58,13 +73,14 @@ __device__ __forceinline__ bool band_masked(int q, int key, int W, int G) {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int NW, bool BAND>
-__global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[32768];
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
     const int q = qb * (NW * 16) + w * 16 + i16;                       // this lane's query row (shared by the 4 g-groups)
+#define bufM(i) (smem + 32768 + (i) * 256)
     const uint64_t prow = ((uint64_t)(b * a.heads + h)) * a.L + q;
 #define bufK(i) (smem + (i) * 16384)
 #define bufV(i) (smem + 8192 + (i) * 16384)
@@ -81,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
     for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_part = 0.f;
     const float sc2 = a.scale * LOG2E;
-    const uint32_t salt = pdrop_salt(a.seed, prow);
+    const uint32_t salt = pdrop_salt(pdrop_seedmix(a.seed), prow);
 
     const bf16_t* kbase = a.qkv + tok0 * a.H3 + H + h * HD;
     const bf16_t* vbase = a.qkv + tok0 * a.H3 + 2 * H + h * HD;
@@ -96,6 +112,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
 #define CHUNK_OF(t) ((BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
     at_stage<NW>(kbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufK(0), w, l);
     at_stage<NW>(vbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufV(0), w, l);
+    // the additive key mask of a chunk travels with its K/V tiles (a global load issued where it is consumed costs a full
+    // L2 round trip per key fragment: 4 exposed latencies per chunk)
+    if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(0) * CH, bufM(0), l);
     for (int ch = 0; ch < nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -103,24 +122,35 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_fwd_kernel(AttnArgs a) {
         if (ch + 1 < nch) {
             at_stage<NW>(kbase + (size_t)CHUNK_OF(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
             at_stage<NW>(vbase + (size_t)CHUNK_OF(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
+            if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(ch + 1) * CH, bufM(cur ^ 1), l);
         }
+        float4 mbc[4];
+#pragma unroll
+        for (int fc = 0; fc < 4; ++fc) mbc[fc] = *reinterpret_cast<const float4*>(bufM(cur) + (fc * 16 + g * 4) * 4);
         const char* tK = bufK(cur);
         const char* tV = bufV(cur);
         const int key0 = CHUNK_OF(ch) * CH;
-        // S^T[key][q]: 4 key frags of 16
+        // S^T[key][q]: 4 key frags of 16; all K fragments first, then the MFMAs with the k-step outermost so that
+        // consecutive MFMAs are independent
         f32x4 s[4];
+        {
+            bf16x8 fk[4][2];
+#pragma unroll
+            for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fk[fc][kk] = at_frag(tK, fc * 16 + i16, kk * 4 + g);
+#pragma unroll
+            for (int fc = 0; fc < 4; ++fc) s[fc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int fc = 0; fc < 4; ++fc) s[fc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[fc][kk], fq[kk], s[fc], 0, 0, 0);
+        }
+        // scores in the log2 domain: s2 = (q.k * scale + mask) * log2(e), so exp() is the native v_exp_f32 (2^x)
 #pragma unroll
         for (int fc = 0; fc < 4; ++fc) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 fk = at_frag(tK, fc * 16 + i16, kk * 4 + g);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[kk], acc, 0, 0, 0);
-            }
-            // scores in the log2 domain: s2 = (q.k * scale + mask) * log2(e), so exp() is the native v_exp_f32 (2^x)
-            const float4 mb = *reinterpret_cast<const float4*>(a.mask_bias + tok0 + key0 + fc * 16 + g * 4);
-            s[fc][0] = acc[0] * sc2 + mb.x * LOG2E; s[fc][1] = acc[1] * sc2 + mb.y * LOG2E;
-            s[fc][2] = acc[2] * sc2 + mb.z * LOG2E; s[fc][3] = acc[3] * sc2 + mb.w * LOG2E;
+            s[fc][0] = s[fc][0] * sc2 + mbc[fc].x * LOG2E; s[fc][1] = s[fc][1] * sc2 + mbc[fc].y * LOG2E;
+            s[fc][2] = s[fc][2] * sc2 + mbc[fc].z * LOG2E; s[fc][3] = s[fc][3] * sc2 + mbc[fc].w * LOG2E;
         }
         if (BAND) {
             const int wq_lo = qb * (NW * 16) + w * 16;                  // wave-uniform: chunk wholly inside every row's band?
@@ -218,8 +248,8 @@ __global__ void attn_delta_kernel(const bf16_t* ctx, const bf16_t* dctx, float* 
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
 template <int NW, bool BAND>
-__global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dq_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[32768];
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int H = a.heads * HD;
@@ -240,7 +270,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dq_kernel(AttnArgs a
     }
     const float lse2_q = a.lse[prow] * LOG2E, delta_q = a.delta[prow];
     const float sc2 = a.scale * LOG2E;
-    const uint32_t salt = pdrop_salt(a.seed, prow);
+    const uint32_t salt = pdrop_salt(pdrop_seedmix(a.seed), prow);
     f32x4 dq[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -258,6 +288,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dq_kernel(AttnArgs a
 #define CHUNK_OF(t) ((BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
     at_stage<NW>(kbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufK(0), w, l);
     at_stage<NW>(vbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufV(0), w, l);
+    if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(0) * CH, bufM(0), l);      // key mask rides with the tiles
     for (int ch = 0; ch < nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -265,7 +296,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dq_kernel(AttnArgs a
         if (ch + 1 < nch) {
             at_stage<NW>(kbase + (size_t)CHUNK_OF(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
             at_stage<NW>(vbase + (size_t)CHUNK_OF(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
+            if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(ch + 1) * CH, bufM(cur ^ 1), l);
         }
+        float4 mbc[4];
+#pragma unroll
+        for (int fc = 0; fc < 4; ++fc) mbc[fc] = *reinterpret_cast<const float4*>(bufM(cur) + (fc * 16 + g * 4) * 4);
         const char* tK = bufK(cur);
         const char* tV = bufV(cur);
         const int key0 = CHUNK_OF(ch) * CH;
@@ -275,18 +310,31 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dq_kernel(AttnArgs a
             edge = !(key0 >= wq_lo + 15 - a.window && key0 + CH - 1 <= wq_lo + a.window);
         }
         f32x4 ds[4];
+        f32x4 sacc4[4], pacc4[4];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {                               // two fragment pairs at a time: 4 independent MFMA chains
+            bf16x8 fk[2][2], fv[2][2];
+#pragma unroll
+            for (int f2 = 0; f2 < 2; ++f2)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    fk[f2][kk] = at_frag(tK, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
+                    fv[f2][kk] = at_frag(tV, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
+                }
+#pragma unroll
+            for (int f2 = 0; f2 < 2; ++f2) { sacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f}; pacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int f2 = 0; f2 < 2; ++f2) {
+                    sacc4[hf * 2 + f2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[f2][kk], fq[kk], sacc4[hf * 2 + f2], 0, 0, 0);
+                    pacc4[hf * 2 + f2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[f2][kk], fdo[kk], pacc4[hf * 2 + f2], 0, 0, 0);
+                }
+        }
 #pragma unroll
         for (int fc = 0; fc < 4; ++fc) {
-            f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 fk = at_frag(tK, fc * 16 + i16, kk * 4 + g);
-                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[kk], sacc, 0, 0, 0);
-                bf16x8 fv = at_frag(tV, fc * 16 + i16, kk * 4 + g);
-                pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fdo[kk], pacc, 0, 0, 0);
-            }
-            const float4 mb4 = *reinterpret_cast<const float4*>(a.mask_bias + tok0 + key0 + fc * 16 + g * 4);
-            const float mb[4] = {mb4.x, mb4.y, mb4.z, mb4.w};
+            const f32x4 sacc = sacc4[fc], pacc = pacc4[fc];
+            const float mb[4] = {mbc[fc].x, mbc[fc].y, mbc[fc].z, mbc[fc].w};
             float keepf[4] = {1.f, 1.f, 1.f, 1.f};
             if (a.thresh16) {
 #pragma unroll
@@ -327,8 +375,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dq_kernel(AttnArgs a
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 template <int NW, bool BAND>
-__global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dkv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[32768];
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[32768 + 1024];
+#define bufL(i) (smem + 32768 + (i) * 512)
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     if (BAND) {
@@ -360,6 +409,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dkv_kernel(AttnArgs 
     }
     const float mb2 = a.mask_bias[tok0 + key] * LOG2E;
     const float sc2 = a.scale * LOG2E;
+    const uint32_t seedmix = pdrop_seedmix(a.seed);
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) { dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -376,6 +426,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dkv_kernel(AttnArgs 
     const int nch = c1 - c0 + 1;
     at_stage<NW>(qbase + (size_t)c0 * CH * a.H3, a.H3, bufQ(0), w, l);
     at_stage<NW>(obase + (size_t)c0 * CH * H, H, bufO(0), w, l);
+    // LSE and delta of the chunk's 64 query rows ride with the Q / dO tiles (were 8 exposed global loads per chunk)
+    if (w == 0) at_stage_f32x64(a.lse + bh * a.L + (size_t)c0 * CH, bufL(0), l);
+    if (w == 1) at_stage_f32x64(a.delta + bh * a.L + (size_t)c0 * CH, bufL(0) + 256, l);
     for (int ch = 0; ch < nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -383,6 +436,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dkv_kernel(AttnArgs 
         if (ch + 1 < nch) {
             at_stage<NW>(qbase + (size_t)(c0 + ch + 1) * CH * a.H3, a.H3, bufQ(cur ^ 1), w, l);
             at_stage<NW>(obase + (size_t)(c0 + ch + 1) * CH * H, H, bufO(cur ^ 1), w, l);
+            if (w == 0) at_stage_f32x64(a.lse + bh * a.L + (size_t)(c0 + ch + 1) * CH, bufL(cur ^ 1), l);
+            if (w == 1) at_stage_f32x64(a.delta + bh * a.L + (size_t)(c0 + ch + 1) * CH, bufL(cur ^ 1) + 256, l);
+        }
+        float4 lsc[4], dlc[4];
+#pragma unroll
+        for (int qf = 0; qf < 4; ++qf) {
+            lsc[qf] = *reinterpret_cast<const float4*>(bufL(cur) + (qf * 16 + g * 4) * 4);
+            dlc[qf] = *reinterpret_cast<const float4*>(bufL(cur) + 256 + (qf * 16 + g * 4) * 4);
         }
         const char* tQ = bufQ(cur);
         const char* tO = bufO(cur);
@@ -393,27 +454,39 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attn_bwd_dkv_kernel(AttnArgs 
             edge = !(q0 >= wk_lo + 15 - a.window && q0 + CH - 1 <= wk_lo + a.window);
         }
         f32x4 pd[4], ds[4];     // P_drop[q][key], dS[q][key] : lane key = i16, q = qf*16 + g*4 + r
+        f32x4 sacc4[4], pacc4[4];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {                               // two fragment pairs at a time: 4 independent MFMA chains
+            bf16x8 fqa[2][2], foa[2][2];
+#pragma unroll
+            for (int f2 = 0; f2 < 2; ++f2)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    fqa[f2][kk] = at_frag(tQ, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
+                    foa[f2][kk] = at_frag(tO, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
+                }
+#pragma unroll
+            for (int f2 = 0; f2 < 2; ++f2) { sacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f}; pacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int f2 = 0; f2 < 2; ++f2) {
+                    sacc4[hf * 2 + f2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqa[f2][kk], fk[kk], sacc4[hf * 2 + f2], 0, 0, 0);
+                    pacc4[hf * 2 + f2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(foa[f2][kk], fv[kk], pacc4[hf * 2 + f2], 0, 0, 0);
+                }
+        }
 #pragma unroll
         for (int qf = 0; qf < 4; ++qf) {
-            f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 fqa = at_frag(tQ, qf * 16 + i16, kk * 4 + g);
-                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqa, fk[kk], sacc, 0, 0, 0);
-                bf16x8 foa = at_frag(tO, qf * 16 + i16, kk * 4 + g);
-                pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(foa, fv[kk], pacc, 0, 0, 0);
-            }
+            const f32x4 sacc = sacc4[qf], pacc = pacc4[qf];
             const size_t rbase = bh * a.L + q0 + qf * 16 + g * 4;
-            const float4 ls4 = *reinterpret_cast<const float4*>(a.lse + rbase);
-            const float4 dl4 = *reinterpret_cast<const float4*>(a.delta + rbase);
-            const float ls[4] = {ls4.x, ls4.y, ls4.z, ls4.w}, dl[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+            const float ls[4] = {lsc[qf].x, lsc[qf].y, lsc[qf].z, lsc[qf].w}, dl[4] = {dlc[qf].x, dlc[qf].y, dlc[qf].z, dlc[qf].w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = __builtin_amdgcn_exp2f(sacc[r] * sc2 + mb2 - ls[r] * LOG2E);
                 if (BAND && edge && band_masked(q0 + qf * 16 + g * 4 + r, key, a.window, a.nglobal)) p = 0.f;
                 float keepf = 1.f;
                 if (a.thresh16) {
-                    const uint32_t u = pdrop_bits(pdrop_salt(a.seed, rbase + r), key & ~1);
+                    const uint32_t u = pdrop_bits(pdrop_salt(seedmix, rbase + r), key & ~1);
                     const uint32_t f = (key & 1) ? (u >> 16) : (u & 0xffffu);
                     keepf = f >= a.thresh16 ? a.inv_keep : 0.f;
                 }
