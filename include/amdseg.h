@@ -111,6 +111,29 @@ int amdseg_lf_wsum(const void* x, const float* coef, float* partials, float* y, 
 int amdseg_lf_dx_update(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, void* vt_ws, int B,
                         int L, int H, int heads, int dtype, amdseg_stream_t stream);
 
+/* strided forms of the three O(L) passes above: x / dx rows are ldx elements apart (a column block of a wider matrix);
+ * assign != 0 overwrites dx instead of accumulating.  Used by the PoNet global aggregation below. */
+int amdseg_lf_rowvec_dot_ld(const void* x, int ldx, const float* vec, const float* add_tok, const float* add_bh, float* out, int B, int L,
+                            int H, int heads, int dtype, amdseg_stream_t stream);
+int amdseg_lf_wsum_ld(const void* x, int ldx, const float* coef, float* partials, float* y, int B, int L, int H, int heads, int dtype,
+                      amdseg_stream_t stream);
+int amdseg_lf_dx_update_ld(void* dx, int ldx, int assign, const float* coefA, const float* vecA, const float* coefB, const float* vecB,
+                           void* vt_ws, int B, int L, int H, int heads, int dtype, amdseg_stream_t stream);
+
+/* ---- PoNet token mixing (csrc/ponet.hip) ---------------------------------------------------------------------------
+ * Replaces the pooling branches of modelscope's PoNetSelfAttention as called through
+ * alimeeting4mug/src/models/modeling_ponet.py:68-79 (source NOT in the reference tree: semantics = oracle/ponet_oracle.py,
+ * parity unpinned).  proj [B*L, ld >= 5H] bf16 = (Hq | Hk | Ho | Hl | Hs); run_start / run_end [B*L] int32 = first / last
+ * position (within the sequence) of the token's segment run (segment_ids non-decreasing, padding constant per run);
+ * g [B, H] fp32 global aggregate; part / parg [B*L, H] bf16 / uint16 scratch written by forward and read by backward;
+ * forward writes ctx [B*L, H]; backward writes the Ho, Hl, Hs column blocks of dproj [B*L, ld], E = dctx*Ho [B*L, H] bf16
+ * and uses psum [B*L, H] fp32 scratch.  L <= 65535, H <= 1024. */
+int amdseg_ponet_pool_fwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const float* g,
+                          void* part, void* parg, void* ctx, int B, int L, int H, amdseg_stream_t stream);
+int amdseg_ponet_pool_bwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const float* g,
+                          const void* part, const void* parg, const void* dctx, void* dproj, void* E, float* psum, int B, int L, int H,
+                          amdseg_stream_t stream);
+
 /* ---- HBM-bound row kernels (csrc/elementwise.hip) ---------------------------------------------------------------
  * embeddings + LayerNorm + dropout ([hf] models/bert/modeling_bert.py:53-108); tables are the fp32 masters.
  * pos_ids may be NULL (position = token index % L); z (pre-LN sum), mean, rstd are saved for backward (may be NULL) */
@@ -167,6 +190,10 @@ typedef struct amdseg_bert_cfg {
     int32_t dtype;                  /* AMDSEG_BF16 (train + inference) or AMDSEG_F32 (inference parity mode: the
                                        layer params then point at the fp32 master weights, activations are fp32) */
     int32_t window, nglobal;        /* Longformer layers: band attention (see amdseg_attn_band_fwd); 0, 0 = BERT */
+    int32_t nproj, mixer;           /* mixer 0: softmax attention over the q|k|v projection (nproj 0 or 3).  mixer 1: external
+                                       token mixer (PoNet): the projection is nproj*H wide (acts.qkv, ws.dqkv, wqkv, wqkv_t, bqkv
+                                       sized accordingly), forward phase 1 stops after it and the caller fills acts.ctx;
+                                       the caller fills ws.dqkv from ws.dctx before backward phase 2; phase must be 1 or 2 */
     int32_t phase;                  /* 0 or 3 = whole layer.  1 / 2 = the part before / after the attention context:
                                        forward 1 = QKV projection + attention (writes acts.ctx), 2 = the rest;
                                        backward 1 = from dy down to ws.dctx, 2 = attention backward, dx_in, all weight

@@ -49,14 +49,20 @@ int amdseg_attn_f32_impl(const float* qkv, const float* mask_bias, float* ctx, i
                          float scale, int window, int nglobal, hipStream_t s);
 
 int amdseg_lf_rowvec_dot_impl(const void* x, const float* vec, const float* add_tok, const float* add_bh, float* out, int B, int L,
-                              int H, int heads, int dtype, hipStream_t s);
+                              int H, int heads, int dtype, int ldx, hipStream_t s);
 int amdseg_lf_softmax_fwd_impl(float* s_inout_p, float* pd, float* sp, int rows, int L, float p, uint64_t seed, hipStream_t s);
 int amdseg_lf_softmax_bwd_impl(const float* p_saved, float* dpd_inout_ds, float* pd, int rows, int L, float p, uint64_t seed,
                                hipStream_t s);
 int amdseg_lf_wsum_impl(const void* x, const float* coef, float* partials, float* y, int B, int L, int H, int heads, int dtype,
-                        hipStream_t s);
+                        int ldx, hipStream_t s);
 int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, void* vt_ws,
-                             int B, int L, int H, int heads, int dtype, hipStream_t s);
+                             int B, int L, int H, int heads, int dtype, int ldx, int assign, hipStream_t s);
+
+int amdseg_ponet_pool_fwd_impl(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end,
+                               const float* g, void* part, void* parg, void* ctx, int B, int L, int H, hipStream_t s);
+int amdseg_ponet_pool_bwd_impl(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end,
+                               const float* g, const void* part, const void* parg, const void* dctx, void* dproj, void* E,
+                               float* psum, int B, int L, int H, hipStream_t s);
 
 int amdseg_rowdot_fwd_impl(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
                            hipStream_t s);

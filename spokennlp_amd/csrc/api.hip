@@ -63,7 +63,7 @@ int amdseg_attn_band_f32(const float* qkv, const float* mask_bias, float* ctx, i
 }
 int amdseg_lf_rowvec_dot(const void* x, const float* vec, const float* add_tok, const float* add_bh, float* out, int B, int L, int H,
                          int heads, int dtype, amdseg_stream_t stream) {
-    return amdseg_lf_rowvec_dot_impl(x, vec, add_tok, add_bh, out, B, L, H, heads, dtype, S(stream));
+    return amdseg_lf_rowvec_dot_impl(x, vec, add_tok, add_bh, out, B, L, H, heads, dtype, H, S(stream));
 }
 int amdseg_lf_softmax_fwd(float* s_inout_p, float* pd, float* sp, int rows, int L, float dropout_p, uint64_t seed,
                           amdseg_stream_t stream) {
@@ -75,11 +75,11 @@ int amdseg_lf_softmax_bwd(const float* p_saved, float* dpd_inout_ds, float* pd, 
 }
 int amdseg_lf_wsum(const void* x, const float* coef, float* partials, float* y, int B, int L, int H, int heads, int dtype,
                    amdseg_stream_t stream) {
-    return amdseg_lf_wsum_impl(x, coef, partials, y, B, L, H, heads, dtype, S(stream));
+    return amdseg_lf_wsum_impl(x, coef, partials, y, B, L, H, heads, dtype, H, S(stream));
 }
 int amdseg_lf_dx_update(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, void* vt_ws, int B,
                         int L, int H, int heads, int dtype, amdseg_stream_t stream) {
-    return amdseg_lf_dx_update_impl(dx, coefA, vecA, coefB, vecB, vt_ws, B, L, H, heads, dtype, S(stream));
+    return amdseg_lf_dx_update_impl(dx, coefA, vecA, coefB, vecB, vt_ws, B, L, H, heads, dtype, H, 0, S(stream));
 }
 int amdseg_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                         const float* pos, const float* type, const float* gamma, const float* beta, void* z, void* out,
@@ -118,6 +118,27 @@ int amdseg_cast(const void* x, void* y, size_t n, int dtype_in, int dtype_out, a
 }
 int amdseg_cast_transpose(const float* W, void* Wb, void* Wt, int N, int K, amdseg_stream_t stream) {
     return amdseg_cast_transpose_impl(W, Wb, Wt, N, K, S(stream));
+}
+int amdseg_lf_rowvec_dot_ld(const void* x, int ldx, const float* vec, const float* add_tok, const float* add_bh, float* out, int B, int L,
+                            int H, int heads, int dtype, amdseg_stream_t stream) {
+    return amdseg_lf_rowvec_dot_impl(x, vec, add_tok, add_bh, out, B, L, H, heads, dtype, ldx, S(stream));
+}
+int amdseg_lf_wsum_ld(const void* x, int ldx, const float* coef, float* partials, float* y, int B, int L, int H, int heads, int dtype,
+                      amdseg_stream_t stream) {
+    return amdseg_lf_wsum_impl(x, coef, partials, y, B, L, H, heads, dtype, ldx, S(stream));
+}
+int amdseg_lf_dx_update_ld(void* dx, int ldx, int assign, const float* coefA, const float* vecA, const float* coefB, const float* vecB,
+                           void* vt_ws, int B, int L, int H, int heads, int dtype, amdseg_stream_t stream) {
+    return amdseg_lf_dx_update_impl(dx, coefA, vecA, coefB, vecB, vt_ws, B, L, H, heads, dtype, ldx, assign, S(stream));
+}
+int amdseg_ponet_pool_fwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const float* g,
+                          void* part, void* parg, void* ctx, int B, int L, int H, amdseg_stream_t stream) {
+    return amdseg_ponet_pool_fwd_impl(proj, ld, mask_bias, run_start, run_end, g, part, parg, ctx, B, L, H, S(stream));
+}
+int amdseg_ponet_pool_bwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const float* g,
+                          const void* part, const void* parg, const void* dctx, void* dproj, void* E, float* psum, int B, int L, int H,
+                          amdseg_stream_t stream) {
+    return amdseg_ponet_pool_bwd_impl(proj, ld, mask_bias, run_start, run_end, g, part, parg, dctx, dproj, E, psum, B, L, H, S(stream));
 }
 int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                   amdseg_stream_t stream) {
@@ -160,6 +181,8 @@ static int check_cfg(const amdseg_bert_cfg* c) {
     const long M = (long)c->B * c->L;
     if ((M % 128) || (c->H % 128) || (c->I % 128) || (c->L % 64)) return AMDSEG_ERR_SHAPE;
     if (c->window < 0 || c->nglobal < 0 || c->phase < 0 || c->phase > 3) return AMDSEG_ERR_ARG;
+    if (c->nproj < 0 || c->nproj > 8 || c->mixer < 0 || c->mixer > 1) return AMDSEG_ERR_ARG;
+    if (c->mixer == 1 && (c->dtype != AMDSEG_BF16 || c->phase == 0 || c->phase == 3)) return AMDSEG_ERR_ARG;
     return AMDSEG_OK;
 }
 // phase: 0 or 3 = whole layer; 1 = first part only; 2 = second part only.  The split point is the attention context:
@@ -167,6 +190,8 @@ static int check_cfg(const amdseg_bert_cfg* c) {
 // dctx row between backward phases 1 and 2 (see include/amdseg.h).
 #define PHASE1(c) ((c)->phase != 2)
 #define PHASE2(c) ((c)->phase != 1)
+// width of the fused input projection: 3H (q|k|v) for BERT / Longformer, nproj*H for an external token mixer (PoNet: 5H)
+#define NPROJ(c) (((c)->nproj ? (c)->nproj : 3) * (c)->H)
 
 int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,
                           const float* mask_bias, int li, amdseg_stream_t stream) {
@@ -190,10 +215,12 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         return AMDSEG_OK;
     }
     if (PHASE1(c)) {
-        // q|k|v projection with bias
-        RET_IF(amdseg_gemm_nt_impl(a->x_in, H, p->wqkv, H, a->qkv, 3 * H, M, 3 * H, H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 0, s));
-        RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0),
-                                    c->window, c->nglobal, s));
+        // q|k|v (or the mixer's) projection with bias
+        const int NP = NPROJ(c);
+        RET_IF(amdseg_gemm_nt_impl(a->x_in, H, p->wqkv, H, a->qkv, NP, M, NP, H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 0, s));
+        if (c->mixer == 0)
+            RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0),
+                                        c->window, c->nglobal, s));
     }
     if (!PHASE2(c)) return AMDSEG_OK;
     // attention output dense -> dropout -> +residual -> LN
@@ -235,17 +262,19 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     RET_IF(amdseg_gemm_nt_impl(d_ao, H, p->wo_t, H, w->dctx, H, M, H, H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, s));
     }
     if (!PHASE2(c)) return AMDSEG_OK;
-    RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
-                                site_seed(c->seed, li, 0), c->window, c->nglobal, s));
-    // dx_in = dqkv . Wqkv + dz1
-    RET_IF(amdseg_gemm_nt_impl(w->dqkv, 3 * H, p->wqkv_t, 3 * H, dx_in, H, M, H, 3 * H, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s));
-    RET_IF(amdseg_colsum_impl(w->dqkv, 3 * H, w->partials, g->bqkv, M, 3 * H, acc, c->dtype, s));
+    const int NP = NPROJ(c);
+    if (c->mixer == 0)
+        RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
+                                    site_seed(c->seed, li, 0), c->window, c->nglobal, s));
+    // dx_in = dqkv . Wqkv + dz1   (external mixer: the caller wrote ws.dqkv [M, nproj*H] between the phases)
+    RET_IF(amdseg_gemm_nt_impl(w->dqkv, NP, p->wqkv_t, NP, dx_in, H, M, H, NP, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s));
+    RET_IF(amdseg_colsum_impl(w->dqkv, NP, w->partials, g->bqkv, M, NP, acc, c->dtype, s));
     // all four weight gradients of the layer in one grouped launch: dW = dY^T X
     const void* A[4] = {d_out, w->du, d_ao, w->dqkv};
     const void* Bm[4] = {a->h, a->x1, a->ctx, a->x_in};
     float* C[4] = {g->w2, g->w1, g->wo, g->wqkv};
-    const int lda[4] = {H, I, H, 3 * H}, ldb[4] = {I, H, H, H}, ldc[4] = {I, H, H, H};
-    const int N[4] = {H, I, H, 3 * H}, K[4] = {I, H, H, H};
+    const int lda[4] = {H, I, H, NP}, ldb[4] = {I, H, H, H}, ldc[4] = {I, H, H, H};
+    const int N[4] = {H, I, H, NP}, K[4] = {I, H, H, H};
     RET_IF(amdseg_gemm_tn_grouped_impl(4, A, lda, Bm, ldb, C, ldc, N, K, M, acc, s));
     return AMDSEG_OK;
 }

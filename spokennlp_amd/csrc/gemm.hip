@@ -250,7 +250,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
         __builtin_amdgcn_wave_barrier();                              // wave-private image: only this wave's ds ops matter
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int rr0 = l >> 3, cc = l & 7;                           // lane -> (row within an 8-row group, 16-B chunk)
+#ifdef ABL_C_SMALL
+        bf16_t* cbase = reinterpret_cast<bf16_t*>(a.C) + (size_t)(wr * 64) * a.ldc + wc * 64 + cc * 8;
+#else
         bf16_t* cbase = reinterpret_cast<bf16_t*>(a.C) + (size_t)(m0 + wr * 64) * a.ldc + n0 + wc * 64 + cc * 8;
+#endif
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int r = p * 8 + rr0;
@@ -258,7 +262,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
             *reinterpret_cast<uint4*>(cbase + (size_t)r * a.ldc) = val;
         }
         if (EPI == EPI_BIAS_GELU) {
+#ifdef ABL_C2_SMALL
+            bf16_t* c2base = a.C2 + (size_t)(wr * 64) * a.ldc2 + wc * 64 + cc * 8;      // every tile writes the same 128x128 patch
+#else
             bf16_t* c2base = a.C2 + (size_t)(m0 + wr * 64) * a.ldc2 + n0 + wc * 64 + cc * 8;
+#endif
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int r = p * 8 + rr0;

@@ -27,7 +27,7 @@
 template <typename T>
 __global__ __launch_bounds__(256) void lf_rowvec_dot_kernel(const T* __restrict__ x, const float* __restrict__ vec,
                                                             const float* __restrict__ add_tok, const float* __restrict__ add_bh,
-                                                            float* __restrict__ out, int L, int H, int heads) {
+                                                            float* __restrict__ out, int L, int H, int heads, int ldx) {
     extern __shared__ __attribute__((aligned(16))) float lf_smem[];
     const int b = blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const float* vb = vec + (size_t)b * heads * H;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void lf_rowvec_dot_kernel(const T* __restrict_
     const int nch = H / 8;
     for (int t = 0; t < 16; ++t) {
         const int j = blockIdx.x * 64 + w * 16 + t;
-        const T* xp = x + ((size_t)b * L + j) * H;
+        const T* xp = x + ((size_t)b * L + j) * ldx;
         float xr[LF_MAXCH][8];
 #pragma unroll
         for (int i = 0; i < LF_MAXCH; ++i) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void lf_softmax_bwd_kernel(const float* __rest
 #define LF_SEG 128
 template <typename T>
 __global__ __launch_bounds__(256) void lf_wsum_kernel(const T* __restrict__ x, const float* __restrict__ coef, float* __restrict__ part,
-                                                      int L, int H, int heads, int seglen) {
+                                                      int L, int H, int heads, int seglen, int ldx) {
     __shared__ float cs[LF_MAXHEADS][LF_SEG];
     const int b = blockIdx.y, seg = blockIdx.x, w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int j0 = seg * seglen;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void lf_wsum_kernel(const T* __restrict__ x, c
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[k][i][e] = 0.f;
     for (int t = 0; t < seglen; ++t) {
-        const T* xp = x + ((size_t)b * L + j0 + t) * H;
+        const T* xp = x + ((size_t)b * L + j0 + t) * ldx;
         float xr[LF_MAXCH][8];
 #pragma unroll
         for (int i = 0; i < LF_MAXCH; ++i) {
@@ -199,7 +199,7 @@ __global__ void lf_wsum_reduce_kernel(const float* __restrict__ part, float* __r
 template <typename T>
 __global__ __launch_bounds__(256) void lf_dx_update_kernel(T* __restrict__ dx, const float* __restrict__ coefA, const float* __restrict__ vecA,
                                                            const float* __restrict__ coefB, const float* __restrict__ vecB,
-                                                           int L, int H, int heads) {
+                                                           int L, int H, int heads, int ldx, int assign) {
     extern __shared__ __attribute__((aligned(16))) float lf_smem[];
     const int b = blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int n = heads * H;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void lf_dx_update_kernel(T* __restrict__ dx, c
     const int nch = H / 8;
     for (int t = 0; t < 16; ++t) {
         const int j = blockIdx.x * 64 + w * 16 + t;
-        T* xp = dx + ((size_t)b * L + j) * H;
+        T* xp = dx + ((size_t)b * L + j) * ldx;
         float ca = 0.f, cb = 0.f;                            // lane h holds the two coefficients of head h
         if (l < heads) {
             ca = coefA[((size_t)b * heads + l) * L + j];
@@ -221,7 +221,12 @@ __global__ __launch_bounds__(256) void lf_dx_update_kernel(T* __restrict__ dx, c
         for (int i = 0; i < LF_MAXCH; ++i) {
             const int c = l + 64 * i;
             float v[8];
-            if (c < nch) ld8<T>(xp + c * 8, v);
+            if (c < nch) {
+                if (assign) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                } else ld8<T>(xp + c * 8, v);
+            }
             for (int h = 0; h < heads; ++h) {
                 const float a_ = __shfl(ca, h, 64), b_ = __shfl(cb, h, 64);
                 if (c < nch) {
@@ -258,10 +263,10 @@ __device__ __forceinline__ void split_bf16(const float (&v)[8], bf16x8& hi, bf16
 // per k-step), B = vec as bf16 hi + lo (two MFMAs per k-step keep the fp32 vector exact to 2^-17).  grid (L/64, B)
 __global__ __launch_bounds__(256) void lf_rowvec_dot_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ vec,
                                                                  const float* __restrict__ add_tok, const float* __restrict__ add_bh,
-                                                                 float* __restrict__ out, int L, int H, int heads) {
+                                                                 float* __restrict__ out, int L, int H, int heads, int ldx) {
     const int b = blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
     const int j0 = blockIdx.x * 64 + w * 16;
-    const bf16_t* xp = x + ((size_t)b * L + j0 + i16) * H + g * 8;
+    const bf16_t* xp = x + ((size_t)b * L + j0 + i16) * ldx + g * 8;
     const float* vp = vec + ((size_t)b * heads + (i16 < heads ? i16 : 0)) * H + g * 8;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int nk = H / 32;
@@ -294,13 +299,13 @@ __global__ __launch_bounds__(256) void lf_rowvec_dot_mfma_kernel(const bf16_t* _
 // [64 tokens][64 cols] tile of x staged in a wave-private LDS region by DMA; the product is the attention P.V step with
 // the 16 (padded) heads in place of the queries.  grid (ceil(L/256), H/64, B), 4 waves = 4 consecutive token chunks
 __global__ __launch_bounds__(256) void lf_wsum_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ coef,
-                                                           float* __restrict__ part, int L, int H, int heads) {
+                                                           float* __restrict__ part, int L, int H, int heads, int ldx) {
     __shared__ __attribute__((aligned(16))) char smem[4 * 8192];
     const int b = blockIdx.z, slab = blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
     const int chunk = blockIdx.x * 4 + w, j0 = chunk * 64;
     if (j0 >= L) return;                                   // no block-level barrier below: a wave may leave early
     char* tile = smem + w * 8192;
-    at_stage<1>(x + ((size_t)b * L + j0) * H + slab * 64, H, tile, 0, l);
+    at_stage<1>(x + ((size_t)b * L + j0) * ldx + slab * 64, ldx, tile, 0, l);
     f32x4 s[4];
     const float* cp = coef + ((size_t)b * heads + (i16 < heads ? i16 : 0)) * L + j0 + g * 4;
 #pragma unroll
@@ -349,7 +354,7 @@ __global__ void lf_vt_prep_kernel(const float* __restrict__ vecA, const float* _
 // consecutive columns: 8-byte read-modify-write.  One wave = 32 tokens; grid (L/128, B)
 __global__ __launch_bounds__(256) void lf_dx_update_mfma_kernel(bf16_t* __restrict__ dx, const float* __restrict__ coefA,
                                                                 const float* __restrict__ coefB, const bf16_t* __restrict__ vt,
-                                                                int L, int H, int heads) {
+                                                                int L, int H, int heads, int ldx, int assign) {
     const int b = blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
     const int j0 = blockIdx.x * 128 + w * 32;
     if (j0 >= L) return;
@@ -374,8 +379,9 @@ __global__ __launch_bounds__(256) void lf_dx_update_mfma_kernel(bf16_t* __restri
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fc[t], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            bf16_t* xp = dx + ((size_t)b * L + j0 + t * 16 + i16) * H + ct * 16 + g * 4;
-            const uint2 old = *reinterpret_cast<const uint2*>(xp);
+            bf16_t* xp = dx + ((size_t)b * L + j0 + t * 16 + i16) * ldx + ct * 16 + g * 4;
+            uint2 old = make_uint2(0u, 0u);
+            if (!assign) old = *reinterpret_cast<const uint2*>(xp);
             uint2 nw;
             nw.x = pack2bf(__uint_as_float(old.x << 16) + d[0], __uint_as_float(old.x & 0xffff0000u) + d[1]);
             nw.y = pack2bf(__uint_as_float(old.y << 16) + d[2], __uint_as_float(old.y & 0xffff0000u) + d[3]);
@@ -399,20 +405,20 @@ static inline void lf_drop_params(float p, uint32_t& thresh, float& inv_keep) {
 }
 
 int amdseg_lf_rowvec_dot_impl(const void* x, const float* vec, const float* add_tok, const float* add_bh, float* out, int B, int L,
-                              int H, int heads, int dtype, hipStream_t s) {
-    if (!x || !vec || !out) return AMDSEG_ERR_ARG;
+                              int H, int heads, int dtype, int ldx, hipStream_t s) {
+    if (!x || !vec || !out || ldx < H || (ldx % 8)) return AMDSEG_ERR_ARG;
     int rc = lf_check(B, L, H, heads);
     if (rc) return rc;
     if (L % 64) return AMDSEG_ERR_SHAPE;
     const size_t lds = (size_t)heads * H * 4;
     if (dtype == AMDSEG_BF16 && (H % 32) == 0) {
-        hipLaunchKernelGGL(lf_rowvec_dot_mfma_kernel, dim3(L / 64, B), dim3(256), 0, s, (const bf16_t*)x, vec, add_tok, add_bh, out, L, H, heads);
+        hipLaunchKernelGGL(lf_rowvec_dot_mfma_kernel, dim3(L / 64, B), dim3(256), 0, s, (const bf16_t*)x, vec, add_tok, add_bh, out, L, H, heads, ldx);
     } else if (dtype == AMDSEG_BF16) {
         (void)hipFuncSetAttribute((const void*)lf_rowvec_dot_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(lf_rowvec_dot_kernel<bf16_t>, dim3(L / 64, B), dim3(256), lds, s, (const bf16_t*)x, vec, add_tok, add_bh, out, L, H, heads);
+        hipLaunchKernelGGL(lf_rowvec_dot_kernel<bf16_t>, dim3(L / 64, B), dim3(256), lds, s, (const bf16_t*)x, vec, add_tok, add_bh, out, L, H, heads, ldx);
     } else {
         (void)hipFuncSetAttribute((const void*)lf_rowvec_dot_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(lf_rowvec_dot_kernel<float>, dim3(L / 64, B), dim3(256), lds, s, (const float*)x, vec, add_tok, add_bh, out, L, H, heads);
+        hipLaunchKernelGGL(lf_rowvec_dot_kernel<float>, dim3(L / 64, B), dim3(256), lds, s, (const float*)x, vec, add_tok, add_bh, out, L, H, heads, ldx);
     }
     return amdseg_launch_status();
 }
@@ -435,43 +441,43 @@ int amdseg_lf_softmax_bwd_impl(const float* p_saved, float* dpd_inout_ds, float*
 }
 
 int amdseg_lf_wsum_impl(const void* x, const float* coef, float* partials, float* y, int B, int L, int H, int heads, int dtype,
-                        hipStream_t s) {
-    if (!x || !coef || !partials || !y) return AMDSEG_ERR_ARG;
+                        int ldx, hipStream_t s) {
+    if (!x || !coef || !partials || !y || ldx < H || (ldx % 8)) return AMDSEG_ERR_ARG;
     int rc = lf_check(B, L, H, heads);
     if (rc) return rc;
     int seglen = (L % LF_SEG) ? 64 : LF_SEG;
     int nseg = L / seglen;
     if (dtype == AMDSEG_BF16 && (H % 64) == 0) {
         seglen = 64; nseg = L / 64;
-        hipLaunchKernelGGL(lf_wsum_mfma_kernel, dim3((nseg + 3) / 4, H / 64, B), dim3(256), 0, s, (const bf16_t*)x, coef, partials, L, H, heads);
+        hipLaunchKernelGGL(lf_wsum_mfma_kernel, dim3((nseg + 3) / 4, H / 64, B), dim3(256), 0, s, (const bf16_t*)x, coef, partials, L, H, heads, ldx);
     } else if (dtype == AMDSEG_BF16)
-        hipLaunchKernelGGL(lf_wsum_kernel<bf16_t>, dim3(nseg, B), dim3(256), 0, s, (const bf16_t*)x, coef, partials, L, H, heads, seglen);
+        hipLaunchKernelGGL(lf_wsum_kernel<bf16_t>, dim3(nseg, B), dim3(256), 0, s, (const bf16_t*)x, coef, partials, L, H, heads, seglen, ldx);
     else
-        hipLaunchKernelGGL(lf_wsum_kernel<float>, dim3(nseg, B), dim3(256), 0, s, (const float*)x, coef, partials, L, H, heads, seglen);
+        hipLaunchKernelGGL(lf_wsum_kernel<float>, dim3(nseg, B), dim3(256), 0, s, (const float*)x, coef, partials, L, H, heads, seglen, ldx);
     const int n = heads * H, total = B * n;
     hipLaunchKernelGGL(lf_wsum_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, partials, y, nseg, n, total);
     return amdseg_launch_status();
 }
 
 int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, void* vt_ws,
-                             int B, int L, int H, int heads, int dtype, hipStream_t s) {
-    if (!dx || !coefA || !vecA || !coefB || !vecB) return AMDSEG_ERR_ARG;
+                             int B, int L, int H, int heads, int dtype, int ldx, int assign, hipStream_t s) {
+    if (!dx || !coefA || !vecA || !coefB || !vecB || ldx < H || (ldx % 8)) return AMDSEG_ERR_ARG;
     int rc = lf_check(B, L, H, heads);
     if (rc) return rc;
     if (L % 64) return AMDSEG_ERR_SHAPE;
     if (dtype == AMDSEG_BF16 && vt_ws && (H % 16) == 0) {
         const int total = B * H * 32;
         hipLaunchKernelGGL(lf_vt_prep_kernel, dim3((total + 255) / 256), dim3(256), 0, s, vecA, vecB, (bf16_t*)vt_ws, H, heads, total);
-        hipLaunchKernelGGL(lf_dx_update_mfma_kernel, dim3((L + 127) / 128, B), dim3(256), 0, s, (bf16_t*)dx, coefA, coefB, (const bf16_t*)vt_ws, L, H, heads);
+        hipLaunchKernelGGL(lf_dx_update_mfma_kernel, dim3((L + 127) / 128, B), dim3(256), 0, s, (bf16_t*)dx, coefA, coefB, (const bf16_t*)vt_ws, L, H, heads, ldx, assign);
         return amdseg_launch_status();
     }
     const size_t lds = (size_t)heads * H * 4 * 2;
     if (dtype == AMDSEG_BF16) {
         (void)hipFuncSetAttribute((const void*)lf_dx_update_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(lf_dx_update_kernel<bf16_t>, dim3(L / 64, B), dim3(256), lds, s, (bf16_t*)dx, coefA, vecA, coefB, vecB, L, H, heads);
+        hipLaunchKernelGGL(lf_dx_update_kernel<bf16_t>, dim3(L / 64, B), dim3(256), lds, s, (bf16_t*)dx, coefA, vecA, coefB, vecB, L, H, heads, ldx, assign);
     } else {
         (void)hipFuncSetAttribute((const void*)lf_dx_update_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(lf_dx_update_kernel<float>, dim3(L / 64, B), dim3(256), lds, s, (float*)dx, coefA, vecA, coefB, vecB, L, H, heads);
+        hipLaunchKernelGGL(lf_dx_update_kernel<float>, dim3(L / 64, B), dim3(256), lds, s, (float*)dx, coefA, vecA, coefB, vecB, L, H, heads, ldx, assign);
     }
     return amdseg_launch_status();
 }

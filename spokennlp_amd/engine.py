@@ -32,15 +32,16 @@ def _align(n, a=64):
 class FlatParams:
     """Re-homes the parameters of a module tree into one flat fp32 buffer (+ a flat gradient buffer)."""
 
-    def __init__(self, module, device, encoder_prefix="bert.encoder.layer."):
+    def __init__(self, module, device, encoder_prefix="bert.encoder.layer.", layer_order=None):
+        layer_order = layer_order or LAYER_ORDER
         named = OrderedDict(module.named_parameters())
         order = []
         nlayers = 0
-        while f"{encoder_prefix}{nlayers}.{LAYER_ORDER[0]}" in named:
+        while f"{encoder_prefix}{nlayers}.{layer_order[0]}" in named:
             nlayers += 1
         enc_names = set()
         for i in range(nlayers):
-            for suffix in LAYER_ORDER:
+            for suffix in layer_order:
                 n = f"{encoder_prefix}{i}.{suffix}"
                 order.append(n); enc_names.add(n)
         rest = [n for n in named if n not in enc_names]
@@ -87,7 +88,7 @@ class FlatParams:
 class BertEncoderEngine:
     """Runs embeddings + N BertLayers (+ final dropout) forward and backward on libamdseg kernels."""
 
-    def __init__(self, module, config, device, bert_attr="bert"):
+    def __init__(self, module, config, device, bert_attr="bert", layer_order=None, nproj=3):
         L.load()      # fail loudly right away if the HIP library is absent
         self.cfg = config
         self.device = device
@@ -95,11 +96,14 @@ class BertEncoderEngine:
         if self.H != self.heads * 64:
             raise L.AmdsegError("libamdseg attention kernels need head_dim == 64")
         self.prefix = bert_attr + "."
-        self.fp = FlatParams(module, device, encoder_prefix=self.prefix + "encoder.layer.")
+        self.layer_order = layer_order or LAYER_ORDER
+        self.nproj = nproj                                  # matrices fused into the input projection (q|k|v; PoNet: 5)
+        self.proj_w0, self.proj_b0 = self.layer_order[0], self.layer_order[nproj]
+        self.fp = FlatParams(module, device, encoder_prefix=self.prefix + "encoder.layer.", layer_order=self.layer_order)
         self.nlayers = self.fp.nlayers
         self.shadow = torch.zeros(self.fp.numel, dtype=torch.bfloat16, device=device)
         H, I = self.H, self.I
-        self.shadow_t = [dict(wqkv_t=torch.empty(H, 3 * H, dtype=torch.bfloat16, device=device),
+        self.shadow_t = [dict(wqkv_t=torch.empty(H, nproj * H, dtype=torch.bfloat16, device=device),
                               wo_t=torch.empty(H, H, dtype=torch.bfloat16, device=device),
                               w1_t=torch.empty(H, I, dtype=torch.bfloat16, device=device),
                               w2_t=torch.empty(I, H, dtype=torch.bfloat16, device=device)) for _ in range(self.nlayers)]
@@ -141,26 +145,26 @@ class BertEncoderEngine:
             ps = lambda s: self._p(fp.flat_p, i, s).data_ptr()            # noqa: E731
             gs = lambda s: self._p(fp.flat_g, i, s).data_ptr()            # noqa: E731
             t = self.shadow_t[i]
-            P = L.LayerParams(wqkv=sh("attention.self.query.weight"), wo=sh("attention.output.dense.weight"),
+            P = L.LayerParams(wqkv=sh(self.proj_w0), wo=sh("attention.output.dense.weight"),
                               w1=sh("intermediate.dense.weight"), w2=sh("output.dense.weight"),
                               wqkv_t=t["wqkv_t"].data_ptr(), wo_t=t["wo_t"].data_ptr(), w1_t=t["w1_t"].data_ptr(),
                               w2_t=t["w2_t"].data_ptr(),
-                              bqkv=ps("attention.self.query.bias"), bo=ps("attention.output.dense.bias"),
+                              bqkv=ps(self.proj_b0), bo=ps("attention.output.dense.bias"),
                               b1=ps("intermediate.dense.bias"), b2=ps("output.dense.bias"),
                               ln1_g=ps("attention.output.LayerNorm.weight"), ln1_b=ps("attention.output.LayerNorm.bias"),
                               ln2_g=ps("output.LayerNorm.weight"), ln2_b=ps("output.LayerNorm.bias"))
-            G = L.LayerGrads(wqkv=gs("attention.self.query.weight"), wo=gs("attention.output.dense.weight"),
+            G = L.LayerGrads(wqkv=gs(self.proj_w0), wo=gs("attention.output.dense.weight"),
                              w1=gs("intermediate.dense.weight"), w2=gs("output.dense.weight"),
-                             bqkv=gs("attention.self.query.bias"), bo=gs("attention.output.dense.bias"),
+                             bqkv=gs(self.proj_b0), bo=gs("attention.output.dense.bias"),
                              b1=gs("intermediate.dense.bias"), b2=gs("output.dense.bias"),
                              ln1_g=gs("attention.output.LayerNorm.weight"), ln1_b=gs("attention.output.LayerNorm.bias"),
                              ln2_g=gs("output.LayerNorm.weight"), ln2_b=gs("output.LayerNorm.bias"))
             self.lparams.append(P); self.lgrads.append(G)
             # fp32 parity mode reads the fp32 masters directly (no shadows, no transposes)
             self.lparams32.append(L.LayerParams(
-                wqkv=ps("attention.self.query.weight"), wo=ps("attention.output.dense.weight"),
+                wqkv=ps(self.proj_w0), wo=ps("attention.output.dense.weight"),
                 w1=ps("intermediate.dense.weight"), w2=ps("output.dense.weight"), wqkv_t=None, wo_t=None, w1_t=None, w2_t=None,
-                bqkv=ps("attention.self.query.bias"), bo=ps("attention.output.dense.bias"),
+                bqkv=ps(self.proj_b0), bo=ps("attention.output.dense.bias"),
                 b1=ps("intermediate.dense.bias"), b2=ps("output.dense.bias"),
                 ln1_g=ps("attention.output.LayerNorm.weight"), ln1_b=ps("attention.output.LayerNorm.bias"),
                 ln2_g=ps("output.LayerNorm.weight"), ln2_b=ps("output.LayerNorm.bias")))
@@ -175,8 +179,9 @@ class BertEncoderEngine:
             H = self.H
             for i in range(self.nlayers):
                 t = self.shadow_t[i]
-                qn = self.fp.lp(i, "attention.self.query.weight")
-                Ws.append(self.fp.view(self.fp.flat_p, qn, (3 * H, H))); Wbs.append(self.fp.view(self.shadow, qn, (3 * H, H))); Wts.append(t["wqkv_t"])
+                qn = self.fp.lp(i, self.proj_w0)
+                NP = self.nproj * H
+                Ws.append(self.fp.view(self.fp.flat_p, qn, (NP, H))); Wbs.append(self.fp.view(self.shadow, qn, (NP, H))); Wts.append(t["wqkv_t"])
                 for s_, key in (("attention.output.dense.weight", "wo_t"), ("intermediate.dense.weight", "w1_t"),
                                 ("output.dense.weight", "w2_t")):
                     Ws.append(self._p(self.fp.flat_p, i, s_)); Wbs.append(self._p(self.shadow, i, s_)); Wts.append(t[key])
@@ -202,16 +207,16 @@ class BertEncoderEngine:
             return torch.empty(*s, dtype=dt, device=dev)
 
         A = dict(x=[e(M, H) for _ in range(nsave + 1)] if train else [e(M, H), e(M, H)],
-                 layers=[dict(qkv=e(M, 3 * H), ctx=e(M, H), z1=e(M, H), x1=e(M, H), u=e(M, I), h=e(M, I), z2=e(M, H),
+                 layers=[dict(qkv=e(M, self.nproj * H), ctx=e(M, H), z1=e(M, H), x1=e(M, H), u=e(M, I), h=e(M, I), z2=e(M, H),
                               lse=e(B * self.heads * Lseq, dt=torch.float32), mean1=e(M, dt=torch.float32),
                               rstd1=e(M, dt=torch.float32), mean2=e(M, dt=torch.float32), rstd2=e(M, dt=torch.float32))
                          for _ in range(nsave)],
                  emb_z=e(M, H), emb_mean=e(M, dt=torch.float32), emb_rstd=e(M, dt=torch.float32),
                  mask_bias=e(B, Lseq, dt=torch.float32), out=e(M, H, dt=torch.float32))
         if train:
-            npart = max(ops.ln_partials_numel(M, H), ((M + 127) // 128) * max(I, 3 * H))
+            npart = max(ops.ln_partials_numel(M, H), ((M + 127) // 128) * max(I, self.nproj * H))
             A["ws"] = dict(dz2=e(M, H), dbr2=e(M, H), du=e(M, I), dx1=e(M, H), dz1=e(M, H), dbr1=e(M, H), dctx=e(M, H),
-                           dqkv=e(M, 3 * H), delta=e(B * self.heads * Lseq, dt=torch.float32),
+                           dqkv=e(M, self.nproj * H), delta=e(B * self.heads * Lseq, dt=torch.float32),
                            partials=e(npart, dt=torch.float32), dy=[e(M, H), e(M, H)])
             w = A["ws"]
             A["ws_struct"] = L.LayerWs(**{k: w[k].data_ptr() for k in ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx",
@@ -231,7 +236,7 @@ class BertEncoderEngine:
     def _cfg_struct(self, B, Lseq, p_hidden, p_attn, seed, accumulate):
         return L.BertCfg(B=B, L=Lseq, H=self.H, heads=self.heads, I=self.I, ln_eps=float(self.cfg.layer_norm_eps),
                          p_hidden=p_hidden, p_attn=p_attn, seed=seed, accumulate_grads=1 if accumulate else 0, dtype=L.BF16,
-                         window=0, nglobal=0, phase=0)
+                         window=0, nglobal=0, nproj=0, mixer=0, phase=0)
 
     # ------------------------------------------------------------------------------------------------ forward / backward
     def _emb(self, name):

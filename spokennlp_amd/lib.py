@@ -20,7 +20,7 @@ class BertCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("heads", C.c_int32), ("I", C.c_int32),
                 ("ln_eps", f32), ("p_hidden", f32), ("p_attn", f32), ("seed", u64),
                 ("accumulate_grads", C.c_int32), ("dtype", C.c_int32), ("window", C.c_int32), ("nglobal", C.c_int32),
-                ("phase", C.c_int32)]
+                ("nproj", C.c_int32), ("mixer", C.c_int32), ("phase", C.c_int32)]
 
 
 class LayerParams(C.Structure):
@@ -60,6 +60,11 @@ _PROTOS = {
     "amdseg_lf_softmax_bwd": [vp, vp, vp, i32, i32, f32, u64, vp],
     "amdseg_lf_wsum": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "amdseg_lf_dx_update": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "amdseg_lf_rowvec_dot_ld": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "amdseg_lf_wsum_ld": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "amdseg_lf_dx_update_ld": [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "amdseg_ponet_pool_fwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "amdseg_ponet_pool_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "amdseg_embed_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, u64, i32, vp],
     "amdseg_embed_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "amdseg_add_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, i32, vp],

@@ -109,10 +109,11 @@ def attn_band_f32(qkv, mask_bias, B, Lseq, heads, window, nglobal=1, scale=0.125
 
 # ---- Longformer global row (csrc/longformer.hip): x [B*L, H] bf16/fp32; vec [B, heads, H] fp32; planes [B, heads, L] fp32
 def lf_rowvec_dot(x, vec, B, Lseq, add_tok=None, add_bh=None):
+    """x: [B*L, H] (rows may be strided: a column block of a wider matrix)"""
     heads, H = vec.shape[1], vec.shape[2]
     out = torch.empty((B, heads, Lseq), dtype=torch.float32, device=x.device)
-    rc = L.load().amdseg_lf_rowvec_dot(_p(x), _p(vec), _p(add_tok), _p(add_bh), _p(out), B, Lseq, H, heads, _dt(x), _s())
-    L.check(rc, "amdseg_lf_rowvec_dot")
+    rc = L.load().amdseg_lf_rowvec_dot_ld(_p(x), x.stride(0), _p(vec), _p(add_tok), _p(add_bh), _p(out), B, Lseq, H, heads, _dt(x), _s())
+    L.check(rc, "amdseg_lf_rowvec_dot_ld")
     return out
 
 
@@ -140,18 +141,33 @@ def lf_wsum(x, coef, H, partials=None):
     if partials is None:
         partials = torch.empty((B * (Lseq // 64) * heads * H,), dtype=torch.float32, device=x.device)
     y = torch.empty((B, heads, H), dtype=torch.float32, device=x.device)
-    rc = L.load().amdseg_lf_wsum(_p(x), _p(coef), _p(partials), _p(y), B, Lseq, H, heads, _dt(x), _s())
-    L.check(rc, "amdseg_lf_wsum")
+    rc = L.load().amdseg_lf_wsum_ld(_p(x), x.stride(0), _p(coef), _p(partials), _p(y), B, Lseq, H, heads, _dt(x), _s())
+    L.check(rc, "amdseg_lf_wsum_ld")
     return y
 
 
-def lf_dx_update(dx, coefA, vecA, coefB, vecB, vt_ws=None):
+def lf_dx_update(dx, coefA, vecA, coefB, vecB, vt_ws=None, assign=False):
+    """dx: [B*L, H] rows (may be strided); assign=True overwrites instead of accumulating"""
     B, heads, Lseq = coefA.shape
     H = vecA.shape[2]
     if vt_ws is None and dx.dtype == torch.bfloat16:
         vt_ws = torch.empty(B * H * 32, dtype=torch.bfloat16, device=dx.device)
-    rc = L.load().amdseg_lf_dx_update(_p(dx), _p(coefA), _p(vecA), _p(coefB), _p(vecB), _p(vt_ws), B, Lseq, H, heads, _dt(dx), _s())
-    L.check(rc, "amdseg_lf_dx_update")
+    rc = L.load().amdseg_lf_dx_update_ld(_p(dx), dx.stride(0), 1 if assign else 0, _p(coefA), _p(vecA), _p(coefB), _p(vecB), _p(vt_ws),
+                                         B, Lseq, H, heads, _dt(dx), _s())
+    L.check(rc, "amdseg_lf_dx_update_ld")
+
+
+# ---- PoNet token mixing (csrc/ponet.hip)
+def ponet_pool_fwd(proj, mask_bias, run_start, run_end, g, part, parg, ctx, B, Lseq, H):
+    rc = L.load().amdseg_ponet_pool_fwd(_p(proj), proj.stride(0), _p(mask_bias), _p(run_start), _p(run_end), _p(g), _p(part), _p(parg),
+                                        _p(ctx), B, Lseq, H, _s())
+    L.check(rc, "amdseg_ponet_pool_fwd")
+
+
+def ponet_pool_bwd(proj, mask_bias, run_start, run_end, g, part, parg, dctx, dproj, E, psum, B, Lseq, H):
+    rc = L.load().amdseg_ponet_pool_bwd(_p(proj), proj.stride(0), _p(mask_bias), _p(run_start), _p(run_end), _p(g), _p(part), _p(parg),
+                                        _p(dctx), _p(dproj), _p(E), _p(psum), B, Lseq, H, _s())
+    L.check(rc, "amdseg_ponet_pool_bwd")
 
 
 def embed_ln_fwd(ids, type_ids, pos_ids, word, pos, typ, gamma, beta, Lseq, eps, p=0.0, seed=0, dtype=torch.bfloat16,
