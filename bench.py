@@ -28,15 +28,20 @@ import torch  # noqa: E402
 MFMA_PEAK_TFLOPS = 2500.0       # gfx950 dense bf16 (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
 
 
-def flops_per_seq(L, H, I, layers, train=True, span=None):
-    """algorithmic FLOPs: projections 2*(3H^2 + H^2 + 2HI) + attention 2*(2*span*H) per token per layer
-    (span = L keys for BERT, the 2w+1 band + 1 global key for Longformer)."""
-    per_tok_layer = 2 * (4 * H * H + 2 * H * I) + 4 * (span or L) * H
+def flops_per_seq(L, H, I, layers, train=True, span=None, nproj=3):
+    """algorithmic FLOPs: projections 2*(nproj*H^2 + H^2 + 2HI) + attention 2*(2*span*H) per token per layer
+    (span = L keys for BERT, the 2w+1 band + 1 global key for Longformer, 0 for PoNet whose mixing is O(L) pooling)."""
+    per_tok_layer = 2 * ((nproj + 1) * H * H + 2 * H * I) + 4 * (L if span is None else span) * H
     return per_tok_layer * layers * L * (3 if train else 1)
 
 
 def build(args, device):
     from transformers import BertConfig
+    if args.model == "ponet":           # BASELINE config 4: PoNet-base (12 x 768), chinese vocab 21128 + [EOS], L = 4096
+        from spokennlp_amd.ponet import PoNetConfig, PoNetForTokenClassification
+        cfg = PoNetConfig(vocab_size=21129, num_labels=2, max_position_embeddings=4096)
+        torch.manual_seed(0)
+        return PoNetForTokenClassification(cfg).to(device).train(), cfg
     if args.model == "longformer":      # BASELINE config 5: longformer-base-4096 (+[BOS]), window 512, CLS global
         from transformers import LongformerConfig
         from spokennlp_amd.longformer_for_ts import LongformerWithDAForSentenceLabelingTopicSegmentation as M
@@ -54,7 +59,33 @@ def build(args, device):
     return m, cfg
 
 
+def make_ponet_batches(args, n, seed, device):
+    """synthetic meeting-like documents through the restated PoNet feature builder (paragraph-level segment ids)"""
+    import numpy as np
+    from spokennlp_amd import preprocess as P
+    rng = np.random.default_rng(1234 + seed)
+    eos, cls, pad = 21128, 101, 0
+    docs, labels = [], []
+    for _ in range(max(8, args.seqs_per_gpu * n // 2)):
+        ns = int(rng.integers(300, 600))
+        docs.append([rng.integers(1000, 21000, int(np.clip(rng.lognormal(3.0, 0.5), 3, 100))).tolist() + [eos] for _ in range(ns)])
+        lab = [(0 if rng.random() < 0.03 else (1 if rng.random() < 0.3 else -100)) for _ in range(ns)]     # paragraph ends carry labels
+        lab[-1] = 0
+        labels.append(lab)
+    cols = P.ponet_prepare_features(docs, labels, list(range(len(docs))), args.seq_len, eos, cls, pad, use_paragraph_segment=True)
+    keys = ("input_ids", "attention_mask", "token_type_ids", "segment_ids", "labels")
+    nwin = len(cols["input_ids"])
+    B = args.seqs_per_gpu
+    out = []
+    for i in range(n):
+        idx = [(i * B + k) % nwin for k in range(B)]
+        out.append({k: torch.tensor([cols[k][j] for j in idx], dtype=torch.long, device=device) for k in keys})
+    return out, B
+
+
 def make_batches(args, n, seed, device):
+    if args.model == "ponet":
+        return make_ponet_batches(args, n, seed, device)
     from spokennlp_amd import data
     pairs = args.seqs_per_gpu // 2 if args.workload == "full_da" else args.seqs_per_gpu
     if args.model == "longformer":
@@ -109,6 +140,30 @@ def gemm_roofline(model, args, device):
                 avg_launch_us=round(tot_t / launches * 1e6, 1), per_shape=detail)
 
 
+def pool_roofline(model, args, device):
+    """PoNet config 4: the segment/local max-pool + fusion kernel pair (csrc/ponet.hip) against the HBM roofline;
+    algorithmic bytes = read Hs, Ho, Hl + write ctx = 4 * M * H * 2 B per launch."""
+    from spokennlp_amd import ops
+    eng = model.engine()
+    B, Lq, H = args.seqs_per_gpu, args.seq_len, model.config.hidden_size
+    A = eng._arena(B, Lq, True)
+    la, pn = A["layers"][0], A["pn"]
+    rs, re = eng._run
+    g = torch.zeros(B, H, device=device)
+    f = lambda: ops.ponet_pool_fwd(la["qkv"], A["mask_bias"], rs, re, g, pn["part"][0], pn["parg"][0], la["ctx"], B, Lq, H)   # noqa: E731
+    for _ in range(3):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        f()
+    e1.record(); e1.synchronize()
+    t = e0.elapsed_time(e1) / 20 * 1e-3
+    by = 4.0 * B * Lq * H * 2
+    return dict(bound="hbm", achieved=round(by / t / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(by / t / 8e12, 4), traffic=None,
+                kernel="pn_tree_max_kernel x2 + pn_run_fold_max_kernel + pn_combine_fwd_kernel", avg_launch_us=round(t * 1e6, 1), algorithmic_bytes=by)
+
+
 def cpu_baseline(args):
     """the CPU oracle (validated against the reference's golden vectors) timed on the host cores: bert-base shape,
     forward + backward + AdamW on a bounded sample (a few sequences) -- a reported baseline, not the target."""
@@ -154,7 +209,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="bert", choices=["bert", "longformer"])
+    ap.add_argument("--model", default="bert", choices=["bert", "longformer", "ponet"])
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--seqs-per-gpu", type=int, default=None)
     ap.add_argument("--workload", default="full_da", choices=["full_da", "plain"])
@@ -162,10 +217,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     if args.seq_len is None:
-        args.seq_len = 4096 if args.model == "longformer" else 512
+        args.seq_len = 512 if args.model == "bert" else 4096
     if args.seqs_per_gpu is None:
-        args.seqs_per_gpu = 8 if args.model == "longformer" else 32
-    if args.model == "longformer":
+        args.seqs_per_gpu = 32 if args.model == "bert" else 8
+    if args.model != "bert":
         args.no_cpu_baseline = True       # the cpu_baseline leg times the BERT oracle (headline metric) only
 
     from spokennlp_amd import dp
@@ -209,9 +264,11 @@ def main():
     seqs = args.seqs_per_gpu * world * args.steps
     value = seqs / dt
     fl = flops_per_seq(args.seq_len, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers,
-                       span=514 if args.model == "longformer" else None)
-    name = "bert-base-uncased(+[BOS])" if args.model == "bert" else "longformer-base-4096(+[BOS], window 512, CLS global)"
-    out = dict(metric="train seq/s (512-tok) bert-base topic-seg" if args.model == "bert" else "train seq/s (4096-tok) longformer-base topic-seg",
+                       span={"bert": None, "longformer": 514, "ponet": 0}[args.model], nproj=5 if args.model == "ponet" else 3)
+    name = {"bert": "bert-base-uncased(+[BOS])", "longformer": "longformer-base-4096(+[BOS], window 512, CLS global)",
+            "ponet": "PoNet-base(+[EOS], paragraph segment ids)"}[args.model]
+    out = dict(metric={"bert": "train seq/s (512-tok) bert-base topic-seg", "longformer": "train seq/s (4096-tok) longformer-base topic-seg",
+                       "ponet": "train seq/s (4096-tok) PoNet-base topic-seg"}[args.model],
                value=round(value, 2), unit="seq/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
@@ -223,6 +280,8 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             out["roofline"] = gemm_roofline(model, args, device)
+            if args.model == "ponet":
+                out["pool_roofline"] = pool_roofline(model, args, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

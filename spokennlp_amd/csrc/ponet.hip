@@ -21,6 +21,9 @@ struct PnArgs {
     const float* mask_bias;                    // [M], < 0 = padded token
     const int* run_start; const int* run_end;  // [M] index (within the sequence) of the first / last token of the token's run
     bf16_t* part; unsigned short* parg;        // [M, H] sub-leader rows: partial max of Hs and its argmax token index
+    bf16_t* part2; unsigned short* parg2;      // [M, H] run-leader rows: the folded run maximum / argmax
+    float* psum2;                              // [M, H] run-leader rows: the folded run sum of E
+    bf16_t* partA; unsigned short* pargA; float* psumA;    // [M, H] level-A rows (fan-in 8) of the two trees
     const float* g;                            // [B, H]
     bf16_t* ctx;                               // [M, H]
     const bf16_t* dctx;                        // [M, H]
@@ -55,31 +58,54 @@ __device__ __forceinline__ void pn_fill(float (&v)[NCH][8], float x) {
 }
 
 // ---------------------------------------------------------------------------------------------------- sub-run max of Hs
-__global__ __launch_bounds__(256) void pn_subrun_max_kernel(PnArgs a) {
+// Two tree levels with fan-in 8 (all 8 row loads of a wave in flight; a flat 64-row walk left 2 waves per CU streaming
+// 6 KB at a time: 1.5 TB/s):  level A: token n with (n - run_start) % 8 == 0 reduces Hs rows [n, n+7] of its run into
+// plane A;  level B: token n with (n - run_start) % 64 == 0 reduces the <= 8 plane-A rows n, n+8, .. into `part`.
+template <bool LEVEL_B>
+__global__ __launch_bounds__(256) void pn_tree_max_kernel(PnArgs a) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + w;
     if (n >= a.M || a.mask_bias[n] < 0.f) return;
     const int b = n / a.L, pos = n - b * a.L, rs = a.run_start[n], re = a.run_end[n];
-    if ((pos - rs) % PN_SUB) return;
-    const int nch = a.H >> 3, last = min(pos + PN_SUB - 1, re);
+    constexpr int STRIDE = LEVEL_B ? 8 : 1;
+    if ((pos - rs) % (STRIDE * 8)) return;
+    const int nch = a.H >> 3;
+    float v[8][PN_MAXCH][8]; uint4 pa[8][PN_MAXCH]; bool ok[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int t = pos + k * STRIDE;
+        const size_t row = (size_t)b * a.L + min(t, re);
+        ok[k] = t <= re && a.mask_bias[row] >= 0.f;
+        if (LEVEL_B) {
+            pn_load<PN_MAXCH>(a.partA + row * a.H, nch, l, v[k]);
+#pragma unroll
+            for (int i = 0; i < PN_MAXCH; ++i)
+                if (l + 64 * i < nch) pa[k][i] = *reinterpret_cast<const uint4*>(a.pargA + row * a.H + (l + 64 * i) * 8);
+        } else pn_load<PN_MAXCH>(a.proj + row * a.ld + 4 * a.H, nch, l, v[k]);
+    }
     float mx[PN_MAXCH][8]; unsigned short arg[PN_MAXCH][8];
     pn_fill<PN_MAXCH>(mx, -INFINITY);
 #pragma unroll
     for (int i = 0; i < PN_MAXCH; ++i)
 #pragma unroll
         for (int e = 0; e < 8; ++e) arg[i][e] = (unsigned short)pos;
-    for (int t = pos; t <= last; ++t) {
-        const size_t row = (size_t)b * a.L + t;
-        if (a.mask_bias[row] < 0.f) continue;
-        float v[PN_MAXCH][8];
-        pn_load<PN_MAXCH>(a.proj + row * a.ld + 4 * a.H, nch, l, v);
 #pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i)
+    for (int k = 0; k < 8; ++k) {
+        if (!ok[k]) continue;
+#pragma unroll
+        for (int i = 0; i < PN_MAXCH; ++i) {
+            const uint32_t pw[4] = {pa[k][i].x, pa[k][i].y, pa[k][i].z, pa[k][i].w};
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (v[i][e] > mx[i][e]) { mx[i][e] = v[i][e]; arg[i][e] = (unsigned short)t; }       // first maximum wins
+                if (v[k][i][e] > mx[i][e]) {                                         // first maximum wins
+                    mx[i][e] = v[k][i][e];
+                    arg[i][e] = LEVEL_B ? (unsigned short)((pw[e >> 1] >> ((e & 1) * 16)) & 0xffffu) : (unsigned short)(pos + k);
+                }
+        }
     }
-    pn_store<PN_MAXCH>(a.part + (size_t)n * a.H, nch, l, mx);
+    bf16_t* dv = LEVEL_B ? a.part : a.partA;
+    unsigned short* da = LEVEL_B ? a.parg : a.pargA;
+    pn_store<PN_MAXCH>(dv + (size_t)n * a.H, nch, l, mx);
 #pragma unroll
     for (int i = 0; i < PN_MAXCH; ++i) {
         const int c = l + 64 * i;
@@ -87,15 +113,15 @@ __global__ __launch_bounds__(256) void pn_subrun_max_kernel(PnArgs a) {
             uint4 pk;
             pk.x = arg[i][0] | ((uint32_t)arg[i][1] << 16); pk.y = arg[i][2] | ((uint32_t)arg[i][3] << 16);
             pk.z = arg[i][4] | ((uint32_t)arg[i][5] << 16); pk.w = arg[i][6] | ((uint32_t)arg[i][7] << 16);
-            *reinterpret_cast<uint4*>(a.parg + (size_t)n * a.H + c * 8) = pk;
+            *reinterpret_cast<uint4*>(da + (size_t)n * a.H + c * 8) = pk;
         }
     }
 }
 
-// run max S (and, when ARG, its argmax token) of token row n from the sub-leader rows of its run
+// run max S (and, when ARG, its argmax token) from the sub-leader rows of a run (walked by the run LEADER only)
 template <bool ARG>
-__device__ __forceinline__ void pn_run_max(const PnArgs& a, int b, int rs, int re, int nch, int l, float (&S)[PN_MAXCH][8],
-                                           unsigned short (&arg)[PN_MAXCH][8]) {
+__device__ __forceinline__ void pn_run_max_walk(const PnArgs& a, int b, int rs, int re, int nch, int l, float (&S)[PN_MAXCH][8],
+                                                unsigned short (&arg)[PN_MAXCH][8]) {
     pn_fill<PN_MAXCH>(S, -INFINITY);
     for (int k = rs; k <= re; k += PN_SUB) {
         const size_t row = (size_t)b * a.L + k;
@@ -114,6 +140,83 @@ __device__ __forceinline__ void pn_run_max(const PnArgs& a, int b, int rs, int r
                     S[i][e] = v[i][e];
                     if (ARG) arg[i][e] = (unsigned short)((pw[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
                 }
+        }
+    }
+}
+
+
+// level 2: the run leader (pos == run_start) folds the sub-leader rows of its run into ONE row (part2 / parg2 / psum2 at
+// the leader's row), so that every other token of the run reads a single row
+__global__ __launch_bounds__(256) void pn_run_fold_max_kernel(PnArgs a) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + w;
+    if (n >= a.M || a.mask_bias[n] < 0.f) return;
+    const int b = n / a.L, pos = n - b * a.L, rs = a.run_start[n];
+    if (pos != rs) return;
+    const int nch = a.H >> 3;
+    float S[PN_MAXCH][8]; unsigned short arg[PN_MAXCH][8];
+#pragma unroll
+    for (int i = 0; i < PN_MAXCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) arg[i][e] = (unsigned short)pos;
+    pn_run_max_walk<true>(a, b, rs, a.run_end[n], nch, l, S, arg);
+    pn_store<PN_MAXCH>(a.part2 + (size_t)n * a.H, nch, l, S);
+#pragma unroll
+    for (int i = 0; i < PN_MAXCH; ++i) {
+        const int c = l + 64 * i;
+        if (c < nch) {
+            uint4 pk;
+            pk.x = arg[i][0] | ((uint32_t)arg[i][1] << 16); pk.y = arg[i][2] | ((uint32_t)arg[i][3] << 16);
+            pk.z = arg[i][4] | ((uint32_t)arg[i][5] << 16); pk.w = arg[i][6] | ((uint32_t)arg[i][7] << 16);
+            *reinterpret_cast<uint4*>(a.parg2 + (size_t)n * a.H + c * 8) = pk;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void pn_run_fold_sum_kernel(PnArgs a) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + w;
+    if (n >= a.M || a.mask_bias[n] < 0.f) return;
+    const int b = n / a.L, pos = n - b * a.L, rs = a.run_start[n], re = a.run_end[n];
+    if (pos != rs) return;
+    const int nch = a.H >> 3;
+    float G[PN_MAXCH][8];
+    pn_fill<PN_MAXCH>(G, 0.f);
+    for (int k = rs; k <= re; k += PN_SUB) {
+        const size_t row = (size_t)b * a.L + k;
+        if (a.mask_bias[row] < 0.f) continue;
+#pragma unroll
+        for (int i = 0; i < PN_MAXCH; ++i) {
+            const int c = l + 64 * i;
+            if (c < nch) {
+                float v[8];
+                ld8<float>(a.psum + row * a.H + c * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) G[i][e] += v[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PN_MAXCH; ++i) {
+        const int c = l + 64 * i;
+        if (c < nch) st8<float>(a.psum2 + (size_t)n * a.H + c * 8, G[i]);
+    }
+}
+// single-row read of the folded run maximum (row of the run leader)
+template <bool ARG>
+__device__ __forceinline__ void pn_run_max(const PnArgs& a, int b, int rs, int re, int nch, int l, float (&S)[PN_MAXCH][8],
+                                           unsigned short (&arg)[PN_MAXCH][8]) {
+    const size_t row = (size_t)b * a.L + rs;
+    pn_load<PN_MAXCH>(a.part2 + row * a.H, nch, l, S);
+    if (ARG) {
+#pragma unroll
+        for (int i = 0; i < PN_MAXCH; ++i) {
+            const int c = l + 64 * i;
+            if (c < nch) {
+                const uint4 pk = *reinterpret_cast<const uint4*>(a.parg2 + row * a.H + c * 8);
+                const uint32_t pw[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) arg[i][e] = (unsigned short)((pw[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+            }
         }
     }
 }
@@ -234,27 +337,40 @@ __global__ __launch_bounds__(256) void pn_bwd_token_kernel(PnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------- sub-run sum of E
-__global__ __launch_bounds__(256) void pn_subrun_sum_kernel(PnArgs a) {
+template <bool LEVEL_B>
+__global__ __launch_bounds__(256) void pn_tree_sum_kernel(PnArgs a) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + w;
     if (n >= a.M || a.mask_bias[n] < 0.f) return;
     const int b = n / a.L, pos = n - b * a.L, rs = a.run_start[n], re = a.run_end[n];
-    if ((pos - rs) % PN_SUB) return;
-    const int nch = a.H >> 3, last = min(pos + PN_SUB - 1, re);
+    constexpr int STRIDE = LEVEL_B ? 8 : 1;
+    if ((pos - rs) % (STRIDE * 8)) return;
+    const int nch = a.H >> 3;
+    float v[8][PN_MAXCH][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t row = (size_t)b * a.L + min(pos + k * STRIDE, re);
+        if (LEVEL_B) {
+#pragma unroll
+            for (int i = 0; i < PN_MAXCH; ++i)
+                if (l + 64 * i < nch) ld8<float>(a.psumA + row * a.H + (l + 64 * i) * 8, v[k][i]);
+        } else pn_load<PN_MAXCH>(a.E + row * a.H, nch, l, v[k]);                      // E is 0 on padded rows
+    }
     float sm[PN_MAXCH][8];
     pn_fill<PN_MAXCH>(sm, 0.f);
-    for (int t = pos; t <= last; ++t) {
-        float v[PN_MAXCH][8];
-        pn_load<PN_MAXCH>(a.E + ((size_t)b * a.L + t) * a.H, nch, l, v);          // E is 0 on padded rows
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (pos + k * STRIDE > re) continue;
 #pragma unroll
         for (int i = 0; i < PN_MAXCH; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sm[i][e] += v[i][e];
+            for (int e = 0; e < 8; ++e) sm[i][e] += v[k][i][e];
     }
+    float* dst = LEVEL_B ? a.psum : a.psumA;
 #pragma unroll
     for (int i = 0; i < PN_MAXCH; ++i) {
         const int c = l + 64 * i;
-        if (c < nch) st8<float>(a.psum + (size_t)n * a.H + c * 8, sm[i]);
+        if (c < nch) st8<float>(dst + (size_t)n * a.H + c * 8, sm[i]);
     }
 }
 // dHs_j = [argmax of j's run == j] * (sum of E over the run)
@@ -271,19 +387,10 @@ __global__ __launch_bounds__(256) void pn_bwd_route_kernel(PnArgs a) {
     pn_run_max<true>(a, b, rs, re, nch, l, S, arg);
     float G[PN_MAXCH][8];
     pn_fill<PN_MAXCH>(G, 0.f);
-    for (int k = rs; k <= re; k += PN_SUB) {
-        const size_t row = (size_t)b * a.L + k;
-        if (a.mask_bias[row] < 0.f) continue;
 #pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i) {
-            const int c = l + 64 * i;
-            if (c < nch) {
-                float v[8];
-                ld8<float>(a.psum + row * a.H + c * 8, v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) G[i][e] += v[e];
-            }
-        }
+    for (int i = 0; i < PN_MAXCH; ++i) {
+        const int c = l + 64 * i;
+        if (c < nch) ld8<float>(a.psum2 + ((size_t)b * a.L + rs) * a.H + c * 8, G[i]);
     }
     float out[PN_MAXCH][8];
 #pragma unroll
@@ -301,14 +408,19 @@ static int pn_check(int B, int L, int H, int ld) {
 
 int amdseg_ponet_pool_fwd_impl(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end,
                                const float* g, void* part, void* parg, void* ctx, int B, int L, int H, hipStream_t s) {
+    // part / parg hold THREE [M, H] planes each: sub-leader (64) rows, folded run-leader rows, level-A (8) rows
     if (!proj || !mask_bias || !run_start || !run_end || !g || !part || !parg || !ctx) return AMDSEG_ERR_ARG;
     int rc = pn_check(B, L, H, ld);
     if (rc) return rc;
     PnArgs a = {};
     a.proj = (const bf16_t*)proj; a.ld = ld; a.mask_bias = mask_bias; a.run_start = run_start; a.run_end = run_end; a.g = g;
     a.part = (bf16_t*)part; a.parg = (unsigned short*)parg; a.ctx = (bf16_t*)ctx; a.M = B * L; a.L = L; a.H = H;
+    a.part2 = a.part + (size_t)a.M * H; a.parg2 = a.parg + (size_t)a.M * H;
+    a.partA = a.part + 2 * (size_t)a.M * H; a.pargA = a.parg + 2 * (size_t)a.M * H;
     const dim3 grid((a.M + 3) / 4);
-    hipLaunchKernelGGL(pn_subrun_max_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pn_tree_max_kernel<false>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pn_tree_max_kernel<true>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pn_run_fold_max_kernel, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(pn_combine_fwd_kernel, grid, dim3(256), 0, s, a);
     return amdseg_launch_status();
 }
@@ -323,9 +435,13 @@ int amdseg_ponet_pool_bwd_impl(const void* proj, int ld, const float* mask_bias,
     a.proj = (const bf16_t*)proj; a.ld = ld; a.mask_bias = mask_bias; a.run_start = run_start; a.run_end = run_end; a.g = g;
     a.part = (bf16_t*)part; a.parg = (unsigned short*)parg; a.dctx = (const bf16_t*)dctx; a.dproj = (bf16_t*)dproj;
     a.E = (bf16_t*)E; a.psum = psum; a.M = B * L; a.L = L; a.H = H;
+    a.part2 = a.part + (size_t)a.M * H; a.parg2 = a.parg + (size_t)a.M * H; a.psum2 = psum + (size_t)a.M * H;
+    a.psumA = psum + 2 * (size_t)a.M * H;
     const dim3 grid((a.M + 3) / 4);
     hipLaunchKernelGGL(pn_bwd_token_kernel, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(pn_subrun_sum_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pn_tree_sum_kernel<false>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pn_tree_sum_kernel<true>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pn_run_fold_sum_kernel, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(pn_bwd_route_kernel, grid, dim3(256), 0, s, a);
     return amdseg_launch_status();
 }

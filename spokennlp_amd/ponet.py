@@ -100,12 +100,12 @@ class PoNetEncoderEngine(BertEncoderEngine):
         if "pn" not in A:
             M, H, dev = B * Lseq, self.H, self.device
             nsave = self.nlayers if train else 1
-            A["pn"] = dict(part=[torch.empty(M, H, dtype=torch.bfloat16, device=dev) for _ in range(nsave)],
-                           parg=[torch.empty(M, H, dtype=torch.int16, device=dev) for _ in range(nsave)],
+            A["pn"] = dict(part=[torch.empty(3 * M, H, dtype=torch.bfloat16, device=dev) for _ in range(nsave)],
+                           parg=[torch.empty(3 * M, H, dtype=torch.int16, device=dev) for _ in range(nsave)],
                            lf_partials=torch.empty(B * (Lseq // 64) * self.heads * H, dtype=torch.float32, device=dev),
                            vt=torch.empty(B * H * 32, dtype=torch.bfloat16, device=dev))
             if train:
-                A["pn"].update(E=torch.empty(M, H, dtype=torch.bfloat16, device=dev), psum=torch.empty(M, H, dtype=torch.float32, device=dev),
+                A["pn"].update(E=torch.empty(M, H, dtype=torch.bfloat16, device=dev), psum=torch.empty(3 * M, H, dtype=torch.float32, device=dev),
                                zeros=torch.zeros(B, 1, Lseq, dtype=torch.float32, device=dev))
         return A
 

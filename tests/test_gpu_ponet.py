@@ -62,14 +62,14 @@ def test_pooling_kernels_vs_oracle(dev, B, L, long_run):
     re = torch.flip(torch.cummin(torch.flip(torch.where(torch.cat((diff, one), 1), pos, torch.full_like(pos, L - 1)), (1,)), 1).values, (1,)).int().reshape(-1).to(dev)
     mb = ((1 - am.float()) * -1e30).to(dev)
     projd = proj.to(dev)
-    part = torch.empty(B * L, H, dtype=torch.bfloat16, device=dev); parg = torch.empty(B * L, H, dtype=torch.int16, device=dev)
+    part = torch.empty(3 * B * L, H, dtype=torch.bfloat16, device=dev); parg = torch.empty(3 * B * L, H, dtype=torch.int16, device=dev)
     ctx = torch.empty(B * L, H, dtype=torch.bfloat16, device=dev)
     ops.ponet_pool_fwd(projd, mb, rs, re, g.to(dev), part, parg, ctx, B, L, H)
     err = (ctx.float().cpu().view(B, L, H) - ctx_ref.detach()).abs()
     assert (err <= 0.01 * ctx_ref.detach().abs() + 0.02).all(), err.max().item()
     assert (ctx.float().cpu().view(B, L, H)[~valid] == 0).all()
     dproj = torch.full((B * L, 5 * H), 7.0, dtype=torch.bfloat16, device=dev)
-    E = torch.empty(B * L, H, dtype=torch.bfloat16, device=dev); psum = torch.empty(B * L, H, dtype=torch.float32, device=dev)
+    E = torch.empty(B * L, H, dtype=torch.bfloat16, device=dev); psum = torch.empty(3 * B * L, H, dtype=torch.float32, device=dev)
     ops.ponet_pool_bwd(projd, mb, rs, re, g.to(dev), part, parg, dctx.to(dev), dproj, E, psum, B, L, H)
     d = dproj.float().cpu()
     # bf16-quantised inputs tie now and then; torch.maximum / amax split the gradient among tied maxima while the kernels
