@@ -1,0 +1,43 @@
+"""`run_inference.sh`-equivalent prediction loop on top of the drop-in model (ts_sentence_seq_labeling.py:1119-1210):
+pre-tokenised documents -> feature builder -> batched model forward -> anchor-logit decode at the labelled positions ->
+per-document merge -> prediction file + example-level metrics.  Host glue only; the encoder runs through the model class
+(HIP path), the integer work through spokennlp_amd.preprocess / evaluate."""
+import random
+
+import numpy as np
+import torch
+
+from . import evaluate as E
+from . import preprocess as P
+
+MODEL_COLUMNS = ("input_ids", "attention_mask", "token_type_ids", "labels", "sent_level_labels", "extract_eop_segment_ids",
+                 "eop_index_for_aggregate_batch_eop_features", "sent_pair_orders", "sent_token_mask")
+
+
+def predict_documents(model, docs_sentence_ids, docs_labels, max_seq_length, bos_id, cls_id, pad_id, batch_size=8, device=None,
+                      threshold=0.5, seed=42, tssp_ablation="none"):
+    """returns (documents, metrics): documents = list of per-document dicts (labels / int_labels / predictions / predict_logits
+    [/ eop_pair_cos_sim]) as written by the reference's predict branch; metrics = compute_metric_example_level(...)."""
+    random.seed(seed)                                         # the feature builder draws the DA half from `random`
+    cols = P.prepare_features(docs_sentence_ids, docs_labels, list(range(len(docs_sentence_ids))), max_seq_length, bos_id, cls_id,
+                              pad_id, tssp_ablation=tssp_ablation)
+    n = len(cols["input_ids"])
+    logits_all, cos_all = [], []
+    model.eval()
+    with torch.no_grad():
+        for i in range(0, n, batch_size):
+            idx = list(range(i, min(i + batch_size, n)))
+            pad_n = batch_size - len(idx)
+            idx = idx + [idx[-1]] * pad_n                   # fixed batch shape (tile-aligned); the tail repeats the last sample
+            batch = {k: torch.tensor([cols[k][j] for j in idx], dtype=torch.long, device=device) for k in MODEL_COLUMNS}
+            _, logits, cos = model(**batch)[:3]
+            keep = batch_size - pad_n
+            logits_all.append(logits[:keep].float().cpu().numpy())
+            cos_all.extend(cos[:keep].float().cpu().numpy().tolist())
+    logits_all = np.concatenate(logits_all, 0)
+    labels = np.array(cols["labels"])
+    decoded = P.decode_anchor_predictions(logits_all, labels)
+    example_ids = [e[0] for e in cols["example_id"]]
+    docs = P.merge_windows_to_documents(decoded, example_ids, len(docs_sentence_ids), eop_pair_cos_sim=cos_all)
+    metrics = E.compute_metric_example_level([d["predict_logits"] for d in docs], [d["int_labels"] for d in docs], threshold=threshold)
+    return docs, metrics

@@ -1,0 +1,63 @@
+"""BASELINE config 1 (plumbing): 32 synthetic documents through the whole inference path -- feature builder -> drop-in
+model (HIP encoder, fp32 parity mode) -> decode -> per-document merge -> prediction file -> example-level metrics --
+against the same pipeline with the CPU oracle in place of the model: predicted boundary labels must be identical."""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+class OracleModel:
+    """the oracle behind the model-class call convention (test-side only)"""
+
+    def __init__(self, sd, cfg):
+        self.sd, self.cfg = sd, cfg
+
+    def eval(self):
+        return self
+
+    def __call__(self, **batch):
+        from oracle import bert_ts_oracle as O
+        return O.model_forward(self.sd, self.cfg, batch)
+
+
+def test_32_documents_end_to_end(dev, tmp_path):
+    from oracle import bert_ts_oracle as O
+    from spokennlp_amd import data, inference, preprocess as P
+    from tests.test_oracle_golden import load_case, flags_of
+    from tests.test_gpu_model import build_model
+    z, sd, _, arch = load_case("tiny_L128")
+    flags = flags_of(z, "full_eval")
+    docs = data.synth_docs(32, seed=2024, vocab=arch["vocab_size"], mean_sents=30, sd_sents=10, mean_boundaries=4, mu_tok=1.8, sigma_tok=0.5)
+    bos = arch["vocab_size"] - 1
+    sent_ids = [[s.tolist() for s in d["sentences"]] for d in docs]
+    labels = [[0 if v == 1 else 1 for v in d["labels"]] for d in docs]           # jsonl label 1 (section end) -> "B-EOP" = id 0
+    m = build_model(arch, dict(flags, amdseg_precision="fp32"), sd, dev)
+    m.config.amdseg_precision = "fp32"
+    got_docs, got_metrics = inference.predict_documents(m, sent_ids, labels, 128, bos, data.CLS_ID, data.PAD_ID, batch_size=4, device=dev)
+    ref = OracleModel(sd, O.make_cfg(num_labels=2, **arch, **flags))
+    ref_docs, ref_metrics = inference.predict_documents(ref, sent_ids, labels, 128, bos, data.CLS_ID, data.PAD_ID, batch_size=4, device=None)
+    assert len(got_docs) == 32
+    worst = 0.0
+    for g, r, lab in zip(got_docs, ref_docs, labels):
+        assert g["int_labels"] == r["int_labels"] and g["labels"] == r["labels"]
+        assert g["predictions"] == r["predictions"]                              # predicted boundary labels: bit-exact
+        assert len(g["predictions"]) == len(lab) - 1                             # every sentence but the document's last is predicted once
+        worst = max(worst, float(np.abs(np.array(g["predict_logits"]) - np.array(r["predict_logits"])).max()))
+        assert np.allclose(g["eop_pair_cos_sim"], r["eop_pair_cos_sim"], atol=1e-4)
+    assert worst < 1e-3, worst                                                   # north-star logits tolerance
+    for k, v in ref_metrics.items():
+        assert abs(got_metrics[k] - v) < 1e-9, k
+    path = tmp_path / "predict_synth_max_seq128_ts_score_lt.txt"
+    P.write_prediction_file(str(path), got_docs)
+    lines = open(path).read().splitlines()
+    assert len(lines) == 32 and json.loads(lines[5])["predictions"] == got_docs[5]["predictions"]
+    print("e2e: max|dlogit|", worst, {k: got_metrics[k] for k in ("precision", "recall", "f1")})
