@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from transformers.models.bert.modeling_bert import BertModel, BertPreTrainedModel
 
 from . import lib as L
-from .engine import BertEncoderEngine, EncoderFn, RowDotFn
+from .engine import BertEncoderEngine, EncoderFn, HeadInputsFn, RowDotFn  # noqa: F401
 
 HEAD_DEFAULTS = dict(do_da_ts=False, do_cssl=False, do_tssp=False, ts_loss_weight=1.0, ts_score_predictor="lt",
                      ts_score_predictor_cos_temp=1, focal_loss_gamma=0.0, weight_label_zero=0.5, cl_loss_weight=0.0,
@@ -42,6 +42,19 @@ class _LossCalculator(nn.Module):
         super().__init__()
         self.classifier = nn.Linear(config.hidden_size, config.num_labels)
         self.tssp = _TSSP(config)
+
+
+class _RowRequests:
+    """row lists (indices into the flattened [2B*L, H] encoder output) requested by the heads of one step; all of them are
+    gathered by ONE kernel into one [n, H] matrix and each head works on its slice"""
+
+    def __init__(self):
+        self.rows = []
+
+    def add(self, rows):
+        s = len(self.rows)
+        self.rows.extend(rows)
+        return (s, len(rows))
 
 
 class _IndexUploader:
@@ -149,23 +162,23 @@ class TopicSegHeadsMixin:
 
     # ---- host planning: every index list of the step is built on the host from the (already fetched) label tensors,
     #      packed into ONE pinned buffer and uploaded with ONE async copy; the device math below never synchronises.
-    def _plan_cos(self, up, pos, Lq):
+    def _plan_cos(self, up, req, pos, Lq, off):
         mx = max((len(p) for p in pos), default=0)
         rows_a, rows_b, dst = [], [], []
         for b, p in enumerate(pos):
             n = len(p)
             if n == 0:
                 continue
-            a = [q + b * Lq for q in p]
+            a = [off + q + b * Lq for q in p]
             rows_a += a
             rows_b += a[1:] + a[:1]
             dst += [b * mx + j for j in range(n)]
-        return dict(mx=mx, n=len(rows_a), a=up.add(rows_a), b=up.add(rows_b), dst=up.add(dst))
+        return dict(mx=mx, n=len(rows_a), a=req.add(rows_a), b=req.add(rows_b), dst=up.add(dst))
 
-    def _plan_cssl(self, up, pos, lab, Lq):
+    def _plan_cssl(self, up, req, pos, lab, Lq, off):
         """index lists of cssl.py:118-228 (same Python `random` call sequence as the reference)."""
         cfg = self.config
-        rows = [q + b * Lq for b, p in enumerate(pos) for q in p]
+        rows = [off + q + b * Lq for b, p in enumerate(pos) for q in p]
         seg = _topic_segment_ids(lab)
         if not (len(seg) > 2 and seg[-1] > 0):
             return None
@@ -173,7 +186,7 @@ class TopicSegHeadsMixin:
         total_topic = seg[-1] + 1
         bot = [seg.index(i) for i in range(total_topic)]
         eot = [v - 1 for v in bot[1:]] + [n - 1]
-        plan = dict(level=cfg.cl_anchor_level, n=n, rows=up.add(rows))
+        plan = dict(level=cfg.cl_anchor_level, n=n, rows=req.add(rows))
         if cfg.cl_anchor_level == "eop_matrix":
             plan["seg"] = up.add(seg)
             return plan
@@ -221,39 +234,41 @@ class TopicSegHeadsMixin:
         plan["lists"] = [up.add(ix) for ix in pos_i + neg_i]
         return plan
 
-    def _plan_tssp(self, up, stm_cpu, spo_cpu, Lq):
+    def _plan_tssp(self, up, req, stm_cpu, spo_cpu, Lq, off):
         rows, labs = [], []
         for b in range(stm_cpu.shape[0]):
             idx = (stm_cpu[b] != -100).nonzero(as_tuple=False).flatten().tolist()
-            rows += [q + b * Lq for q in idx]
+            rows += [off + q + b * Lq for q in idx]
             row = spo_cpu[b]
             labs += row[row != -100].tolist()
-        return dict(rows=up.add(rows), labs=up.add(labs), n=len(rows))
+        return dict(rows=req.add(rows), labs=up.add(labs), n=len(rows))
 
-    # ---- device math (no host synchronisation)
-    def _cos_sim(self, seq, up, plan, temp):
+    # ---- device math (no host synchronisation).  `feats` is the ONE gathered [n, H] matrix of the step (HeadInputsFn);
+    #      a plan entry (start, n) is a row slice of it
+    @staticmethod
+    def _rows(feats, h):
+        return feats[h[0]:h[0] + h[1]]
+
+    def _cos_sim(self, feats, up, plan, temp, B):
         """utils.py:111-138: cos(row_i, row_{(i+1)%n}) / temp, padded with -100 to the batch max."""
-        B, Lq, H = seq.shape
-        out = torch.full((B * max(plan["mx"], 1),), -100.0, dtype=seq.dtype, device=seq.device)
+        out = torch.full((B * max(plan["mx"], 1),), -100.0, dtype=feats.dtype, device=feats.device)
         if plan["n"]:
-            flat = seq.reshape(B * Lq, H)
-            xa, xb = flat[up.get(plan["a"])], flat[up.get(plan["b"])]
+            xa, xb = self._rows(feats, plan["a"]), self._rows(feats, plan["b"])
             cs = (xa * xb).sum(-1) if temp == 0 else F.cosine_similarity(xa, xb, dim=-1) / temp
             out = out.index_put((up.get(plan["dst"]),), cs)
         return out.view(B, max(plan["mx"], 1))[:, :plan["mx"]] if plan["mx"] else out.view(B, 1)[:, :0]
 
-    def _cssl(self, seq, up, plan):
+    def _cssl(self, feats_all, up, plan):
         """cssl.py:230-274 with the degenerate amax pooling replaced by the equivalent row gather."""
         cfg = self.config
         if plan is None:
-            return seq.new_zeros(())
-        B, Lq, H = seq.shape
-        feats = seq.reshape(B * Lq, H)[up.get(plan["rows"])]
+            return feats_all.new_zeros(())
+        feats = self._rows(feats_all, plan["rows"])
         n = plan["n"]
         if plan["level"] == "eop_matrix":
             seg_t = up.get(plan["seg"])
             same = seg_t[:, None] == seg_t[None, :]
-            num_mask = same & ~torch.eye(n, dtype=torch.bool, device=seq.device)
+            num_mask = same & ~torch.eye(n, dtype=torch.bool, device=feats.device)
             e = torch.exp(_cos(feats.unsqueeze(1), feats.unsqueeze(0), cfg.cl_temp))
             num = (num_mask * e).sum(0)
             den = num + ((~same) * e).sum(0)
@@ -262,30 +277,29 @@ class TopicSegHeadsMixin:
             cnt = sel.sum().clamp(min=1)
             return (torch.where(sel, -torch.log(torch.where(sel, prob, torch.ones_like(prob))), torch.zeros_like(prob)).sum() / cnt)
         pk = cfg.cl_positive_k
-        anchors = feats if plan["anchors"] is None else feats[up.get(plan["anchors"])]
-        sims = [_cos(anchors, feats[up.get(h)], cfg.cl_temp).unsqueeze(0) for h in plan["lists"]]
+        anchors = feats if plan["anchors"] is None else feats.index_select(0, up.get(plan["anchors"]))
+        sims = [_cos(anchors, feats.index_select(0, up.get(h)), cfg.cl_temp).unsqueeze(0) for h in plan["lists"]]
         e = torch.exp(torch.cat(sims))
         return (-torch.log(e[:pk].sum(0) / e.sum(0))).mean()
 
-    def _tssp(self, da_seq, up, plan):
+    def _tssp(self, feats_all, up, plan):
         """tssp.py:16-36 (returns w * CE; the caller multiplies by w again, loss_calculator.py:71)."""
         cfg = self.config
-        B, Lq, H = da_seq.shape
-        feats = da_seq.reshape(B * Lq, H)[up.get(plan["rows"])]
+        feats = self._rows(feats_all, plan["rows"])
         logits = F.linear(feats, self.loss_calculator.tssp.classifier.weight, self.loss_calculator.tssp.classifier.bias)
         return cfg.tssp_loss_weight * F.cross_entropy(logits.reshape(-1, cfg.num_tssp_labels), up.get(plan["labs"]))
 
-    def _plan_half(self, up, labels_cpu, Lq, da_example_flag, need_cos, stm_cpu=None, spo_cpu=None):
+    def _plan_half(self, up, req, labels_cpu, Lq, off, da_example_flag, need_cos, stm_cpu=None, spo_cpu=None):
         cfg = self.config
         pos, lab = self._labelled_rows(labels_cpu)
         plan = dict(pos=pos, lab=lab, cos=None, cssl=None, tssp=None)
         if need_cos:
-            plan["cos"] = self._plan_cos(up, pos, Lq)
+            plan["cos"] = self._plan_cos(up, req, pos, Lq, off)
         if not da_example_flag and cfg.cl_loss_weight != 0:
-            plan["cssl"] = self._plan_cssl(up, pos, lab, Lq)
+            plan["cssl"] = self._plan_cssl(up, req, pos, lab, Lq, off)
             plan["has_cssl"] = True
         if da_example_flag and cfg.tssp_loss_weight != 0:
-            plan["tssp"] = self._plan_tssp(up, stm_cpu, spo_cpu, Lq)
+            plan["tssp"] = self._plan_tssp(up, req, stm_cpu, spo_cpu, Lq, off)
         if cfg.ts_score_predictor == "cos":
             mx = plan["cos"]["mx"]
             flat = []
@@ -294,12 +308,12 @@ class TopicSegHeadsMixin:
             plan["cos_labels"] = up.add(flat)
         return plan
 
-    def _loss_calculator(self, seq, labels, up, plan, da_example_flag=False):
+    def _loss_calculator(self, logits_half, feats, labels, up, plan, B, da_example_flag=False):
+        """loss_calculator.py:25-73 on the pre-computed classifier logits of this half and the gathered head rows"""
         cfg = self.config
-        cos = self._cos_sim(seq, up, plan["cos"], cfg.ts_score_predictor_cos_temp) if plan["cos"] is not None else None
+        cos = self._cos_sim(feats, up, plan["cos"], cfg.ts_score_predictor_cos_temp, B) if plan["cos"] is not None else None
         if cfg.ts_score_predictor == "lt":
-            clf = self.loss_calculator.classifier
-            logits = RowDotFn.apply(seq, clf.weight, clf.bias)
+            logits = logits_half
             ts = self._ts_loss(logits.reshape(-1, cfg.num_labels), labels.reshape(-1))
         elif cfg.ts_score_predictor == "cos":
             ts = F.binary_cross_entropy_with_logits(cos.reshape(-1), up.get(plan["cos_labels"]).float())
@@ -308,9 +322,9 @@ class TopicSegHeadsMixin:
             raise ValueError("not supported ts_score_predictor %s" % cfg.ts_score_predictor)
         loss = cfg.ts_loss_weight * ts
         if not da_example_flag and cfg.cl_loss_weight != 0:
-            loss = loss + cfg.cl_loss_weight * self._cssl(seq, up, plan["cssl"])
+            loss = loss + cfg.cl_loss_weight * self._cssl(feats, up, plan["cssl"])
         if da_example_flag and cfg.tssp_loss_weight != 0:
-            loss = loss + cfg.tssp_loss_weight * self._tssp(seq, up, plan["tssp"])
+            loss = loss + cfg.tssp_loss_weight * self._tssp(feats, up, plan["tssp"])
         return loss, logits, cos
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -371,24 +385,29 @@ class TopicSegHeadsMixin:
         seq = self.encode(ids, am, tt)
         if ev is not None:
             ev.synchronize()
-        a_seq = seq[:B]
         logits, cos = None, None
         loss = None
         if labels is not None:
             train = self.training and torch.is_grad_enabled()
             need_cos = (not train) or cfg.ts_score_predictor == "cos"
-            up = _IndexUploader(seq.device)
-            a_plan = self._plan_half(up, host["labels"][:, 0], Lq, False, need_cos)
+            up, req = _IndexUploader(seq.device), _RowRequests()
+            a_plan = self._plan_half(up, req, host["labels"][:, 0], Lq, 0, False, need_cos)
             d_plan = None
             if two_pass:
-                d_plan = self._plan_half(up, host["labels"][:, 1], Lq, True, cfg.ts_score_predictor == "cos",
+                d_plan = self._plan_half(up, req, host["labels"][:, 1], Lq, B * Lq, True, cfg.ts_score_predictor == "cos",
                                          stm_cpu=host.get("stm"), spo_cpu=host.get("spo"))
+            rows_h = up.add(req.rows)
             up.flush()
-            a_loss, a_logits, cos = self._loss_calculator(a_seq, labels[:, 0], up, a_plan)
+            # ONE pass over the encoder output for all heads: classifier logits of every token + the gathered rows; its
+            # backward returns ONE dense gradient (no per-head zero-fill / index_put / dense adds)
+            clf = self.loss_calculator.classifier
+            logits_all, feats = HeadInputsFn.apply(seq.reshape(-1, seq.shape[-1]), clf.weight, clf.bias, up.get(rows_h))
+            logits_all = logits_all.view(seq.shape[0], Lq, -1)
+            a_loss, a_logits, cos = self._loss_calculator(logits_all[:B], feats, labels[:, 0], up, a_plan, B)
             loss = a_loss
             logits = torch.cat((a_logits.unsqueeze(1), a_logits.unsqueeze(1)), dim=1)
             if two_pass:
-                d_loss, d_logits, _ = self._loss_calculator(seq[B:], labels[:, 1], up, d_plan, da_example_flag=True)
+                d_loss, d_logits, _ = self._loss_calculator(logits_all[B:], feats, labels[:, 1], up, d_plan, B, da_example_flag=True)
                 loss = loss + d_loss
                 logits = torch.cat((a_logits.unsqueeze(1), d_logits.unsqueeze(1)), dim=1)
             if cos is None:

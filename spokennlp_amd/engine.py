@@ -398,3 +398,27 @@ class RowDotFn(torch.autograd.Function):
         dW = torch.empty_like(W); db = torch.empty(W.shape[0], dtype=torch.float32, device=W.device)
         dx = ops.rowdot_bwd(x2, W, dl2, dW=dW, db=db, need_dx=True)
         return dx.view(ctx.shape), dW, db
+
+
+class HeadInputsFn(torch.autograd.Function):
+    """everything the loss heads read from the encoder output x [M, H] (fp32) in one step: the token classifier
+    logits = x W^T + b over every row (HIP rowdot kernels) and the rows requested by the CSSL / TSSP / cos-sim heads
+    (one gather).  Backward writes ONE dense gradient: the classifier's dx with the head-row gradients scatter-added."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, rows):
+        ctx.save_for_backward(x, W, rows)
+        logits = ops.rowdot_fwd(x, W, b)
+        feats = x.index_select(0, rows) if rows.numel() else x.new_zeros((0, x.shape[1]))
+        return logits, feats
+
+    @staticmethod
+    def backward(ctx, dlogits, dfeats):
+        x, W, rows = ctx.saved_tensors
+        dW = torch.empty_like(W); db = torch.empty(W.shape[0], dtype=torch.float32, device=W.device)
+        if dlogits is None:
+            dlogits = torch.zeros((x.shape[0], W.shape[0]), dtype=torch.float32, device=x.device)
+        dx = ops.rowdot_bwd(x, W, dlogits.contiguous().float(), dW=dW, db=db, need_dx=True)
+        if dfeats is not None and rows.numel():
+            dx.index_add_(0, rows, dfeats.to(dx.dtype))
+        return dx, dW, db, None
