@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--seqs-per-gpu", type=int, default=None)
     ap.add_argument("--workload", default="full_da", choices=["full_da", "plain"])
+    ap.add_argument("--mode", default="train", choices=["train", "infer"], help="infer = forward-only (eval, no_grad) sequences/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -236,8 +237,15 @@ def main():
     total_steps = args.steps + args.warmup
     lr0 = 5e-5
 
+    if args.mode == "infer":
+        model.eval()
+        args.no_cpu_baseline = True
+
     def step(i):
         random.seed(i)
+        if args.mode == "infer":
+            with torch.no_grad():
+                return model(**batches[i % len(batches)])[0]
         loss = model(**batches[i % len(batches)])[0]
         loss.backward()
         eng.finish_grad_sync()
@@ -263,17 +271,18 @@ def main():
         dt = t.item()
     seqs = args.seqs_per_gpu * world * args.steps
     value = seqs / dt
-    fl = flops_per_seq(args.seq_len, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers,
+    fl = flops_per_seq(args.seq_len, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, args.mode == "train",
                        span={"bert": None, "longformer": 514, "ponet": 0}[args.model], nproj=5 if args.model == "ponet" else 3)
     name = {"bert": "bert-base-uncased(+[BOS])", "longformer": "longformer-base-4096(+[BOS], window 512, CLS global)",
             "ponet": "PoNet-base(+[EOS], paragraph segment ids)"}[args.model]
     out = dict(metric={"bert": "train seq/s (512-tok) bert-base topic-seg", "longformer": "train seq/s (4096-tok) longformer-base topic-seg",
-                       "ponet": "train seq/s (4096-tok) PoNet-base topic-seg"}[args.model],
+                       "ponet": "train seq/s (4096-tok) PoNet-base topic-seg"}[args.model].replace("train", args.mode),
                value=round(value, 2), unit="seq/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
                config=dict(workload=f"{name} topic-seg fine-tune, {args.workload}, seq_len={args.seq_len}, "
-                                    f"{args.seqs_per_gpu} seqs/GPU/step ({pairs} samples), fwd+bwd+clip+AdamW, dropout 0.1",
+                                    f"{args.seqs_per_gpu} seqs/GPU/step ({pairs} samples), "
+                                    + ("fwd+bwd+clip+AdamW, dropout 0.1" if args.mode == "train" else "inference forward only (eval, no_grad)"),
                            global_batch=args.seqs_per_gpu * world, seq_len=args.seq_len, parallelism=f"dp{world}"),
                mfma_frac_whole_step=round(value / world * fl / (MFMA_PEAK_TFLOPS * 1e12), 4),
                final_loss=round(float(loss.detach()), 4))

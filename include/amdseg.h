@@ -38,7 +38,7 @@ extern "C" {
 /* epilogues of amdseg_gemm_nt */
 #define AMDSEG_EPI_NONE 0       /* C = A B^T                                                     */
 #define AMDSEG_EPI_BIAS 1       /* C = A B^T + bias[n]                                           */
-#define AMDSEG_EPI_BIAS_GELU 2  /* C2 = A B^T + bias (pre-activation), C = gelu_erf(C2)          */
+#define AMDSEG_EPI_BIAS_GELU 2  /* C2 = A B^T + bias (pre-activation; C2 may be NULL), C = gelu_erf  */
 #define AMDSEG_EPI_ADD_RES 3    /* C = A B^T + R                                                  */
 #define AMDSEG_EPI_GELU_BWD 4   /* C = (A B^T) * gelu_erf'(R)                                     */
 
@@ -213,7 +213,8 @@ typedef struct amdseg_bert_layer_grads {    /* fp32, views into the flat gradien
 
 typedef struct amdseg_bert_layer_acts {     /* caller-owned activations; all but x_in are written by forward */
     const void* x_in;                       /* [M,H] layer input */
-    void *qkv, *ctx, *z1, *x1, *u, *h, *z2, *x_out;   /* [M,3H] [M,H] [M,H] [M,H] [M,I] [M,I] [M,H] [M,H] */
+    void *qkv, *ctx, *z1, *x1, *u, *h, *z2, *x_out;   /* [M,3H] [M,H] [M,H] [M,H] [M,I] [M,I] [M,H] [M,H]; u may be NULL in
+                                                         inference (the pre-activation is only read by backward) */
     float *lse, *mean1, *rstd1, *mean2, *rstd2;       /* [B*heads*L] [M] [M] [M] [M] */
 } amdseg_bert_layer_acts;
 

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
                 }
                 if (EPI == EPI_BIAS_GELU) {
                     uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(stg2 + soff) = pk;                    // pre-activation u, kept for backward
+                    if (a.C2) *reinterpret_cast<uint2*>(stg2 + soff) = pk;          // pre-activation u, kept for backward
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                 } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
             const uint4 val = *reinterpret_cast<const uint4*>(stg + STG_OFF(r, cc));
             *reinterpret_cast<uint4*>(cbase + (size_t)r * a.ldc) = val;
         }
-        if (EPI == EPI_BIAS_GELU) {
+        if (EPI == EPI_BIAS_GELU && a.C2) {                 // inference passes C2 = NULL: single-output GELU
 #ifdef ABL_C2_SMALL
             bf16_t* c2base = a.C2 + (size_t)(wr * 64) * a.ldc2 + wc * 64 + cc * 8;      // every tile writes the same 128x128 patch
 #else
@@ -605,8 +605,11 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     // tile choice (measured at M = 16384, tools/bench_kernels.py): the 256x192 ping-pong kernel wins for long K (its one
     // workgroup per CU pays an exposed prologue + epilogue per tile), the 128x128 kernel (2 workgroups per CU overlap each
     // other's prologue/epilogue) for K <= 768; shapes the small kernel cannot tile always take the ping-pong kernel
-    const bool pp_ok = (a_in.M % PP_BM) == 0 && (a_in.N % PP_BN) == 0;
     const bool small_ok = (a_in.M % BM) == 0 && (a_in.N % BN) == 0;
+    // the ping-pong kernel counts its in-flight stores (two outputs for BIAS_GELU): the single-output form runs on the 128x128 kernel
+    const bool single_gelu = EPI == EPI_BIAS_GELU && !a_in.C2;
+    if (single_gelu && !small_ok) return AMDSEG_ERR_SHAPE;
+    const bool pp_ok = (a_in.M % PP_BM) == 0 && (a_in.N % PP_BN) == 0 && !single_gelu;
     static int pp_min_k = -1;
     if (pp_min_k < 0) { const char* e = getenv("AMDSEG_PP_MIN_K"); pp_min_k = e ? atoi(e) : 1536; }
     if (pp_ok && !(g_force_small_tile && small_ok) && (a_in.K >= pp_min_k || !small_ok || g_force_small_tile < 0)) {
@@ -653,7 +656,7 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
             if (!bias) return AMDSEG_ERR_ARG;
             return out_fp32 ? launch_nt<EPI_BIAS, float>(a, stream) : launch_nt<EPI_BIAS, bf16_t>(a, stream);
         case EPI_BIAS_GELU:
-            if (!bias || !C2 || out_fp32 || (ldc2 % 8)) return AMDSEG_ERR_ARG;
+            if (!bias || out_fp32 || (C2 && (ldc2 % 8))) return AMDSEG_ERR_ARG;       // C2 == NULL: gelu output only (inference)
             return launch_nt<EPI_BIAS_GELU, bf16_t>(a, stream);
         case EPI_ADD_RES:
             if (!R || (ldr % 8)) return AMDSEG_ERR_ARG;

@@ -226,9 +226,10 @@ class BertEncoderEngine:
             la = A["layers"][i if train else 0]
             xin = A["x"][i] if train else A["x"][i % 2]
             xout = A["x"][i + 1] if train else A["x"][(i + 1) % 2]
-            A["acts_struct"].append(L.LayerActs(x_in=xin.data_ptr(), x_out=xout.data_ptr(),
-                                                **{k: la[k].data_ptr() for k in ("qkv", "ctx", "z1", "x1", "u", "h", "z2", "lse",
-                                                                                 "mean1", "rstd1", "mean2", "rstd2")}))
+            ptrs = {k: la[k].data_ptr() for k in ("qkv", "ctx", "z1", "x1", "u", "h", "z2", "lse", "mean1", "rstd1", "mean2", "rstd2")}
+            if not train and not fp32:
+                ptrs["u"] = None                  # inference: the FFN GEMM skips the pre-activation output
+            A["acts_struct"].append(L.LayerActs(x_in=xin.data_ptr(), x_out=xout.data_ptr(), **ptrs))
         A["x_final"] = A["x"][self.nlayers] if train else A["x"][self.nlayers % 2]
         self._arenas[key] = A
         return A
