@@ -56,7 +56,7 @@ __device__ __forceinline__ void at_stage_f32x64(const float* g, char* lds, int l
 
 struct AttnArgs {
     const bf16_t* qkv; const float* mask_bias; bf16_t* ctx; float* lse;
-    const bf16_t* dctx; const float* delta; bf16_t* dqkv;
+    const bf16_t* dctx; float* delta; bf16_t* dqkv;
     int B, L, heads, H3;    // H3 = 3*H row stride of qkv
     float scale, inv_keep; uint32_t thresh16; uint64_t seed;
     int window, nglobal;    // band attention (Longformer): one-sided window W (0 = full attention), leading global tokens G
@@ -268,7 +268,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         fdo[0] = *reinterpret_cast<const bf16x8*>(dp + g * 8);
         fdo[1] = *reinterpret_cast<const bf16x8*>(dp + 32 + g * 8);
     }
-    const float lse2_q = a.lse[prow] * LOG2E, delta_q = a.delta[prow];
+    // delta_q = rowsum(dO * O) of this lane's query row: computed here from the fragments already in registers (was a separate
+    // launch); written out for the dK/dV kernel, which runs after this one on the same stream
+    float delta_q;
+    {
+        const bf16_t* op = a.ctx + (tok0 + q) * H + h * HD;
+        const bf16x8 fo0 = *reinterpret_cast<const bf16x8*>(op + g * 8), fo1 = *reinterpret_cast<const bf16x8*>(op + 32 + g * 8);
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc += __uint_as_float((uint32_t)(uint16_t)fo0[e] << 16) * __uint_as_float((uint32_t)(uint16_t)fdo[0][e] << 16);
+            acc += __uint_as_float((uint32_t)(uint16_t)fo1[e] << 16) * __uint_as_float((uint32_t)(uint16_t)fdo[1][e] << 16);
+        }
+        delta_q = xor_reduce_sum_g(acc);
+        if (g == 0) a.delta[prow] = delta_q;
+    }
+    const float lse2_q = a.lse[prow] * LOG2E;
     const float sc2 = a.scale * LOG2E;
     const uint32_t salt = pdrop_salt(pdrop_seedmix(a.seed), prow);
     f32x4 dq[4];
@@ -562,8 +577,7 @@ int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ct
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = (float*)lse;
     a.dctx = (const bf16_t*)dctx; a.delta = delta; a.dqkv = (bf16_t*)dqkv;
     const size_t total = (size_t)B * L * heads * 8;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)ctx,
-                       (const bf16_t*)dctx, delta, B, L, heads);
+    (void)total;           // delta = rowsum(dO * O) is produced by the dQ kernel (attn_delta_kernel is kept for reference / tests)
     // backward kernels need 144-168 VGPRs: 4-wave workgroups keep 3 waves per SIMD resident (8-wave ones would spill or halve occupancy)
     if (window > 0) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
