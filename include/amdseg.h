@@ -198,7 +198,10 @@ typedef struct amdseg_bert_cfg {
                                        forward 1 = QKV projection + attention (writes acts.ctx), 2 = the rest;
                                        backward 1 = from dy down to ws.dctx, 2 = attention backward, dx_in, all weight
                                        gradients.  A Longformer caller overwrites the global token's ctx row between
-                                       forward phases and consumes + zeroes its dctx row between backward phases. */
+                                       forward phases and consumes + zeroes its dctx row between backward phases.
+                                       Backward only: 6 = phase 2 without the grouped weight-gradient GEMM, 4 = that GEMM
+                                       alone (e.g. on a second stream, under the next layer's backward; the caller orders
+                                       the streams and must not reuse ws before it has run). */
 } amdseg_bert_cfg;
 
 typedef struct amdseg_bert_layer_params {   /* bf16 compute shadows (+ transposes for dgrad), fp32 vectors */

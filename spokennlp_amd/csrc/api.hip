@@ -180,16 +180,20 @@ static int check_cfg(const amdseg_bert_cfg* c) {
     if (c->H != c->heads * 64 || c->B <= 0 || c->L <= 0 || c->I <= 0) return AMDSEG_ERR_SHAPE;
     const long M = (long)c->B * c->L;
     if ((M % 128) || (c->H % 128) || (c->I % 128) || (c->L % 64)) return AMDSEG_ERR_SHAPE;
-    if (c->window < 0 || c->nglobal < 0 || c->phase < 0 || c->phase > 3) return AMDSEG_ERR_ARG;
+    if (c->window < 0 || c->nglobal < 0 || c->phase < 0 || (c->phase > 4 && c->phase != 6)) return AMDSEG_ERR_ARG;
     if (c->nproj < 0 || c->nproj > 8 || c->mixer < 0 || c->mixer > 1) return AMDSEG_ERR_ARG;
-    if (c->mixer == 1 && (c->dtype != AMDSEG_BF16 || c->phase == 0 || c->phase == 3)) return AMDSEG_ERR_ARG;
+    if (c->mixer == 1 && (c->dtype != AMDSEG_BF16 || c->phase == 0 || c->phase == 3 || c->phase > 2)) return AMDSEG_ERR_ARG;
     return AMDSEG_OK;
 }
 // phase: 0 or 3 = whole layer; 1 = first part only; 2 = second part only.  The split point is the attention context:
 // a Longformer caller overwrites the global token's ctx row between forward phases 1 and 2, and consumes / zeroes its
 // dctx row between backward phases 1 and 2 (see include/amdseg.h).
-#define PHASE1(c) ((c)->phase != 2)
-#define PHASE2(c) ((c)->phase != 1)
+// Backward only: 6 = second part WITHOUT the grouped weight-gradient GEMM, 4 = that GEMM alone -- so a caller can run the
+// weight gradients of layer i on a second stream under the backward of layer i-1 (they are off the critical path: nothing
+// reads them before the optimiser step).
+#define PHASE1(c) ((c)->phase == 0 || (c)->phase == 1 || (c)->phase == 3)
+#define PHASE2(c) ((c)->phase == 0 || (c)->phase == 2 || (c)->phase == 3 || (c)->phase == 6)
+#define PHASE_WGRAD(c) ((c)->phase == 0 || (c)->phase == 2 || (c)->phase == 3 || (c)->phase == 4)
 // width of the fused input projection: 3H (q|k|v) for BERT / Longformer, nproj*H for an external token mixer (PoNet: 5H)
 #define NPROJ(c) (((c)->nproj ? (c)->nproj : 3) * (c)->H)
 
@@ -261,14 +265,16 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     // dctx = d_ao . Wo
     RET_IF(amdseg_gemm_nt_impl(d_ao, H, p->wo_t, H, w->dctx, H, M, H, H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, s));
     }
-    if (!PHASE2(c)) return AMDSEG_OK;
     const int NP = NPROJ(c);
+    if (PHASE2(c)) {
     if (c->mixer == 0)
         RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                     site_seed(c->seed, li, 0), c->window, c->nglobal, s));
     // dx_in = dqkv . Wqkv + dz1   (external mixer: the caller wrote ws.dqkv [M, nproj*H] between the phases)
     RET_IF(amdseg_gemm_nt_impl(w->dqkv, NP, p->wqkv_t, NP, dx_in, H, M, H, NP, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s));
     RET_IF(amdseg_colsum_impl(w->dqkv, NP, w->partials, g->bqkv, M, NP, acc, c->dtype, s));
+    }
+    if (!PHASE_WGRAD(c)) return AMDSEG_OK;
     // all four weight gradients of the layer in one grouped launch: dW = dY^T X
     const void* A[4] = {d_out, w->du, d_ao, w->dqkv};
     const void* Bm[4] = {a->h, a->x1, a->ctx, a->x_in};

@@ -118,6 +118,13 @@ class BertEncoderEngine:
                              norm=torch.zeros(1, device=device), partials=torch.empty(2048, device=device))
         self._build_param_structs()
         self.buckets = None
+        import os
+        # opt-in: measured SLOWER on 1 x MI355X (19.7 vs 18.3 ms/step) -- the co-running weight-gradient GEMM and the next
+        # layer's GEMMs evict each other's panels from the XCD L2s; kept for multi-stream experiments
+        self.overlap_wgrad = os.environ.get("AMDSEG_OVERLAP_WGRAD", "0") == "1" and device.type == "cuda"
+        self._wgrad_stream = torch.cuda.Stream(device=device, priority=0) if self.overlap_wgrad else None
+        self._wgrad_done = [None, None]
+        self._wgrad_last = None
 
     def enable_data_parallel(self):
         """overlap per-layer RCCL all-reduce of the flat gradient slices with backward (dp.GradBuckets)."""
@@ -215,12 +222,18 @@ class BertEncoderEngine:
                  mask_bias=e(B, Lseq, dt=torch.float32), out=e(M, H, dt=torch.float32))
         if train:
             npart = max(ops.ln_partials_numel(M, H), ((M + 127) // 128) * max(I, self.nproj * H))
-            A["ws"] = dict(dz2=e(M, H), dbr2=e(M, H), du=e(M, I), dx1=e(M, H), dz1=e(M, H), dbr1=e(M, H), dctx=e(M, H),
-                           dqkv=e(M, self.nproj * H), delta=e(B * self.heads * Lseq, dt=torch.float32),
-                           partials=e(npart, dt=torch.float32), dy=[e(M, H), e(M, H)])
-            w = A["ws"]
-            A["ws_struct"] = L.LayerWs(**{k: w[k].data_ptr() for k in ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx",
-                                                                       "dqkv", "delta", "partials")})
+            def ws_set():
+                return dict(dz2=e(M, H), dbr2=e(M, H), du=e(M, I), dx1=e(M, H), dz1=e(M, H), dbr1=e(M, H), dctx=e(M, H),
+                            dqkv=e(M, self.nproj * H), delta=e(B * self.heads * Lseq, dt=torch.float32),
+                            partials=e(npart, dt=torch.float32))
+
+            # two scratch sets: layer i's weight-gradient GEMM (second stream) still reads set i % 2 while layer i-1's backward
+            # writes the other one
+            A["ws_sets"] = [ws_set(), ws_set()]
+            A["ws_structs"] = [L.LayerWs(**{k: w[k].data_ptr() for k in ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx",
+                                                                          "dqkv", "delta", "partials")}) for w in A["ws_sets"]]
+            A["ws"] = dict(A["ws_sets"][0], dy=[e(M, H), e(M, H)])
+            A["ws_struct"] = A["ws_structs"][0]
         A["acts_struct"] = []
         for i in range(self.nlayers):
             la = A["layers"][i if train else 0]
@@ -294,9 +307,35 @@ class BertEncoderEngine:
         return None
 
     def _layer_backward(self, lib, cfg, A, i, mb, dy, other, s, saved):
-        rc = lib.amdseg_bert_layer_bwd(C.byref(cfg), C.byref(self.lparams[i]), C.byref(self.lgrads[i]),
-                                       C.byref(A["acts_struct"][i]), C.byref(A["ws_struct"]), mb, dy.data_ptr(), other.data_ptr(), i, s)
-        L.check(rc, f"amdseg_bert_layer_bwd[{i}]")
+        """critical path (everything but the weight gradients) on the current stream; the grouped weight-gradient GEMM of this
+        layer on a second, lower-priority stream so that it fills the CUs its single wave of tiles leaves idle and runs under
+        the next layer's backward"""
+        if not self.overlap_wgrad:
+            rc = lib.amdseg_bert_layer_bwd(C.byref(cfg), C.byref(self.lparams[i]), C.byref(self.lgrads[i]),
+                                           C.byref(A["acts_struct"][i]), C.byref(A["ws_struct"]), mb, dy.data_ptr(), other.data_ptr(), i, s)
+            L.check(rc, f"amdseg_bert_layer_bwd[{i}]")
+            return
+        k = i & 1
+        main = torch.cuda.current_stream()
+        if self._wgrad_done[k] is not None:
+            main.wait_event(self._wgrad_done[k])          # scratch set k is free again (its last reader was layer i+2's wgrad)
+        args = (C.byref(cfg), C.byref(self.lparams[i]), C.byref(self.lgrads[i]), C.byref(A["acts_struct"][i]), C.byref(A["ws_structs"][k]),
+                mb, dy.data_ptr(), other.data_ptr(), i)
+        cfg.phase = 1
+        L.check(lib.amdseg_bert_layer_bwd(*args, s), f"amdseg_bert_layer_bwd[{i}].1")
+        cfg.phase = 6
+        L.check(lib.amdseg_bert_layer_bwd(*args, s), f"amdseg_bert_layer_bwd[{i}].6")
+        ev = torch.cuda.Event()
+        ev.record(main)
+        ws = self._wgrad_stream
+        ws.wait_event(ev)
+        cfg.phase = 4
+        L.check(lib.amdseg_bert_layer_bwd(*args, ws.cuda_stream), f"amdseg_bert_layer_bwd[{i}].4")
+        cfg.phase = 0
+        done = torch.cuda.Event()
+        done.record(ws)
+        self._wgrad_done[k] = done
+        self._wgrad_last = done
 
     def backward(self, ctx, dseq, accumulate=True):
         """dseq: fp32 [B, L, H] gradient of the encoder output.  Writes every parameter gradient into flat_g."""
@@ -316,7 +355,11 @@ class BertEncoderEngine:
             self._layer_backward(lib, cfg, A, i, mb, dy, other, s, ctx["layer_saved"][i])
             dy, other = other, dy
             if self.buckets is not None:          # data parallel: this layer's gradient slice is final -> start its all-reduce
-                self.buckets.reduce_layer(i)
+                if self.overlap_wgrad and self._wgrad_last is not None:
+                    with torch.cuda.stream(self._wgrad_stream):      # ... ordered after the weight-gradient GEMM's stream
+                        self.buckets.reduce_layer(i)
+                else:
+                    self.buckets.reduce_layer(i)
         # embeddings: out = dropout(LN(z)); grads of LN affine + the three tables
         if ctx["p_h"] > 0:
             rc = lib.amdseg_dropout(dy.data_ptr(), other.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, L.BF16, L.BF16, s)
@@ -338,6 +381,11 @@ class BertEncoderEngine:
                                   L.BF16, s)
         L.check(rc, "amdseg_embed_bwd")
         self._embed_backward_fixup(pe, pad)
+        if self.overlap_wgrad:                      # every consumer of flat_g (clip, AdamW, torch optimizers) is on the current stream
+            main = torch.cuda.current_stream()
+            for ev in self._wgrad_done:
+                if ev is not None:
+                    main.wait_event(ev)
 
     def _embed_backward_fixup(self, dpos, pad):
         pass
