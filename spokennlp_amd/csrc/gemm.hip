@@ -39,7 +39,6 @@ struct GemmNTArgs {
     int lda, ldb, ldc, ldr, ldc2;
     int M, N, K;
     int tiles_m, tiles_n;
-    int stagger;        // gemm_nt_kernel: units of 6400 clk the second resident workgroup of every CU waits at start
 };
 
 // bijective XCD-aware remap: hardware places workgroup b on XCD b % 8; give each XCD a contiguous tile range
@@ -85,12 +84,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
     const int wr = w >> 1, wc = w & 1;
     const int nwg = a.tiles_m * a.tiles_n;
     const int t = xcd_remap(blockIdx.x, nwg);
-    // De-phase the two workgroups resident on a CU.  Tiles of one launch all take the same time, so the 512 slots would run
-    // in lock step: every CU stores its tile at the same moment (an HBM-write-bound burst with the matrix pipes idle), then
-    // every CU computes (no HBM writes).  Delaying the second slot of each CU by about half a tile makes one workgroup's
-    // output burst overlap the other's K loop for the whole launch (profiles/r01_gemm_experiments.md, store ablation).
-    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(100);
     // grouped tile order inside each XCD's contiguous range: the ~64 tiles resident on one XCD (32 CUs x 2) form a
     // GROUP_M x 8 patch, so each A/B panel fetched into the XCD's 4 MiB L2 is shared by 8 tiles and the resident
     // working set (8 + 8 panels) stays below the L2 size
@@ -250,11 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
         __builtin_amdgcn_wave_barrier();                              // wave-private image: only this wave's ds ops matter
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int rr0 = l >> 3, cc = l & 7;                           // lane -> (row within an 8-row group, 16-B chunk)
-#ifdef ABL_C_SMALL
-        bf16_t* cbase = reinterpret_cast<bf16_t*>(a.C) + (size_t)(wr * 64) * a.ldc + wc * 64 + cc * 8;
-#else
         bf16_t* cbase = reinterpret_cast<bf16_t*>(a.C) + (size_t)(m0 + wr * 64) * a.ldc + n0 + wc * 64 + cc * 8;
-#endif
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int r = p * 8 + rr0;
@@ -262,11 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
             *reinterpret_cast<uint4*>(cbase + (size_t)r * a.ldc) = val;
         }
         if (EPI == EPI_BIAS_GELU && a.C2) {                 // inference passes C2 = NULL: single-output GELU
-#ifdef ABL_C2_SMALL
-            bf16_t* c2base = a.C2 + (size_t)(wr * 64) * a.ldc2 + wc * 64 + cc * 8;      // every tile writes the same 128x128 patch
-#else
             bf16_t* c2base = a.C2 + (size_t)(m0 + wr * 64) * a.ldc2 + n0 + wc * 64 + cc * 8;
-#endif
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int r = p * 8 + rr0;
@@ -626,11 +611,7 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
         hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, OutT>), dim3(T < 256 ? ((T + 7) / 8) * 8 : 256), dim3(512), PP_LDS, s, a);
         return amdseg_launch_status();
     }
-    GemmNTArgs a = a_in;
-    static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("AMDSEG_STAGGER"); stagger = e ? atoi(e) : 0; }
-    a.stagger = stagger;
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a_in.tiles_m * a_in.tiles_n), dim3(256), 0, s, a_in);
     return amdseg_launch_status();
 }
 
@@ -649,7 +630,7 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     a.dbg = g_amdseg_dbg;
 #endif
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldc2 = ldc2; a.M = M; a.N = N; a.K = K;
-    a.tiles_m = M / BM; a.tiles_n = N / BN; a.stagger = 0;
+    a.tiles_m = M / BM; a.tiles_n = N / BN;
     switch (epi) {
         case EPI_NONE: return out_fp32 ? launch_nt<EPI_NONE, float>(a, stream) : launch_nt<EPI_NONE, bf16_t>(a, stream);
         case EPI_BIAS:
