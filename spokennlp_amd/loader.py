@@ -1,0 +1,116 @@
+"""On-disk formats + the device-side input pipeline of the topic-segmentation path.
+
+  * jsonl schema written by the reference's converters (emnlp2023-topic_segmentation/src/preprocess_data.py:129-176) and read
+    by its dataset builders (src/datasets/wiki727k/wiki727k.py:73-85): one JSON object per line with "sentences" (list of
+    str) and "labels" (list of 0/1 or "0"/"1"; 1 = last sentence of a section), optional "file"; the builder maps 1 ->
+    "B-EOP", 0 -> "O" and assigns example_id = line number.
+  * tokenisation is HuggingFace's (third party): every sentence becomes the ids of `bos_token + sentence`
+    (ts_sentence_seq_labeling.py:723-741, add_special_tokens=False, is_split_into_words=True).
+  * windows come from spokennlp_amd.preprocess.prepare_features (bit-exact restatement of the reference closures).
+  * `DevicePrefetcher`: batches are collated into pinned host buffers by a background thread and copied to the GPU on a side
+    stream one batch ahead, so the training loop never waits on host work (at ~3.4 k sequences/s a batch of 32 x 512 tokens
+    x 9 int64 columns is 1.2 MB every 9 ms).
+"""
+import json
+import queue
+import threading
+
+import torch
+
+from . import preprocess as P
+
+LABEL_MAP = {"1": "B-EOP", "0": "O", 1: "B-EOP", 0: "O"}          # wiki727k.py:76
+LABEL_TO_ID = {"B-EOP": 0, "O": 1}
+MODEL_COLUMNS = ("input_ids", "attention_mask", "token_type_ids", "labels", "sent_level_labels", "extract_eop_segment_ids",
+                 "eop_index_for_aggregate_batch_eop_features", "sent_pair_orders", "sent_token_mask")
+
+
+def read_jsonl(path):
+    """yields the dataset builder's examples: dict(example_id, sentences, labels as 'B-EOP' / 'O' strings)"""
+    with open(path, "r") as f:
+        for example_id, line in enumerate(f.readlines()):
+            ex = json.loads(line.strip())
+            if len(ex["sentences"]) != len(ex["labels"]):
+                raise ValueError(f"{path}:{example_id + 1}: {len(ex['sentences'])} sentences but {len(ex['labels'])} labels")
+            yield {"example_id": example_id, "sentences": ex["sentences"], "labels": [LABEL_MAP[l] for l in ex["labels"]]}
+
+
+def write_jsonl(path, documents):
+    """documents: iterable of dict(sentences=[str], labels=[0/1]) (+ optional 'file') -- the converter's output format"""
+    with open(path, "w") as f:
+        f.writelines([json.dumps(d) + "\n" for d in documents])
+
+
+def tokenize_examples(examples, tokenizer):
+    """sentences -> token ids of `[BOS] + sentence` with the caller's HF tokenizer (ts_sentence_seq_labeling.py:726-741).
+    Returns (docs_sentence_ids, docs_label_ids, example_ids) ready for preprocess.prepare_features."""
+    docs, labels, ids = [], [], []
+    for ex in examples:
+        sents = [tokenizer.bos_token + s for s in ex["sentences"]]
+        enc = tokenizer(sents, add_special_tokens=False)["input_ids"]
+        docs.append([list(e) for e in enc])
+        labels.append([LABEL_TO_ID.get(l, -100) for l in ex["labels"]])
+        ids.append(ex["example_id"])
+    return docs, labels, ids
+
+
+def build_features(docs_sentence_ids, docs_label_ids, example_ids, max_seq_length, bos_id, cls_id, pad_id, tssp_ablation="none"):
+    return P.prepare_features(docs_sentence_ids, docs_label_ids, example_ids, max_seq_length, bos_id, cls_id, pad_id,
+                              tssp_ablation=tssp_ablation)
+
+
+def batch_indices(n_samples, batch_size, rank=0, world=1, drop_last=True):
+    """DistributedSampler-style partition without shuffling (rank r takes samples r, r + W, ...), then fixed-size batches"""
+    mine = list(range(rank, n_samples, world))
+    out = [mine[i:i + batch_size] for i in range(0, len(mine), batch_size)]
+    if drop_last and out and len(out[-1]) < batch_size:
+        out.pop()
+    return out
+
+
+class DevicePrefetcher:
+    """iterates dicts of int64 device tensors (B, 2, L) over `features` (the column dict of prepare_features)"""
+
+    def __init__(self, features, batches, device, depth=2, columns=MODEL_COLUMNS):
+        self.features, self.batches, self.device, self.columns = features, batches, torch.device(device), columns
+        self.q = queue.Queue(maxsize=depth)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.thread = threading.Thread(target=self._work, daemon=True)
+        self.thread.start()
+
+    def _collate(self, idx):
+        host = {}
+        for c in self.columns:
+            t = torch.tensor([self.features[c][j] for j in idx], dtype=torch.long)
+            host[c] = t.pin_memory() if self.stream is not None else t
+        return host
+
+    def _work(self):
+        try:
+            for idx in self.batches:
+                host = self._collate(idx)
+                if self.stream is None:
+                    self.q.put((host, None))
+                    continue
+                with torch.cuda.stream(self.stream):
+                    dev = {c: t.to(self.device, non_blocking=True) for c, t in host.items()}
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                self.q.put((dev, ev, host))              # host kept alive until the copy is consumed
+            self.q.put(None)
+        except Exception as e:                            # surface worker failures in the consumer
+            self.q.put(e)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if isinstance(item, Exception):
+                raise item
+            batch, ev = item[0], item[1]
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                for t in batch.values():
+                    t.record_stream(torch.cuda.current_stream(self.device))
+            yield batch

@@ -61,3 +61,28 @@ def test_32_documents_end_to_end(dev, tmp_path):
     lines = open(path).read().splitlines()
     assert len(lines) == 32 and json.loads(lines[5])["predictions"] == got_docs[5]["predictions"]
     print("e2e: max|dlogit|", worst, {k: got_metrics[k] for k in ("precision", "recall", "f1")})
+
+
+def test_prefetcher_feeds_training_steps(dev):
+    """jsonl-shaped documents -> features -> DevicePrefetcher (pinned, side-stream H2D) -> a few training steps"""
+    from spokennlp_amd import data, loader as LD
+    from tests.test_oracle_golden import load_case, flags_of
+    from tests.test_gpu_model import build_model
+    z, sd, _, arch = load_case("tiny_L128")
+    docs = data.synth_docs(12, seed=3, vocab=arch["vocab_size"], mean_sents=30, sd_sents=8, mean_boundaries=4, mu_tok=1.8, sigma_tok=0.5)
+    sent_ids = [[s.tolist() for s in d["sentences"]] for d in docs]
+    labels = [[0 if v == 1 else 1 for v in d["labels"]] for d in docs]
+    random.seed(1)
+    feats = LD.build_features(sent_ids, labels, list(range(len(docs))), 128, arch["vocab_size"] - 1, data.CLS_ID, data.PAD_ID)
+    batches = LD.batch_indices(len(feats["input_ids"]), 2)
+    m = build_model(arch, flags_of(z, "train_full"), sd, dev).train()
+    eng = m.engine()
+    losses = []
+    for step, batch in enumerate(LD.DevicePrefetcher(feats, batches[:6], dev)):
+        assert batch["input_ids"].is_cuda and batch["input_ids"].shape == (2, 2, 128)
+        random.seed(step)
+        loss = m(**batch)[0]
+        loss.backward()
+        eng.adamw_step(5e-5)
+        losses.append(loss.item())
+    assert len(losses) == 6 and all(np.isfinite(losses))
