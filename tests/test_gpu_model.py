@@ -222,3 +222,30 @@ def test_electra_wrapper_vs_reference_golden(dev):
                     c = torch.nn.functional.cosine_similarity(params[n].grad.float().cpu().flatten(), ref.flatten(), dim=0).item()
                     assert c > 0.99, (n, c)
         assert abs(loss.item() - float(z[f"{variant}.loss"])) < 0.05
+
+
+def test_stock_torch_optimizer_loop_like_hf_trainer(dev):
+    """the single-GPU HF Trainer inner loop on the drop-in class: loss.backward(); clip_grad_norm_; optimizer.step();
+    model.zero_grad() (set_to_none=True, Trainer's default) -- parameter gradients are views into the flat buffer, the
+    weights the HIP kernels read follow the optimizer's in-place updates, and training makes progress."""
+    z, sd, batch, arch = load_case("tiny_L64")
+    m = build_model(arch, flags_of(z, "train_full"), sd, dev).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-3)
+    b = to_dev(batch, dev)
+    losses = []
+    for step in range(6):
+        random.seed(0)
+        loss = m(**b)[0]
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        assert torch.isfinite(gn)
+        opt.step()
+        m.zero_grad()                                  # sets .grad = None: the next forward must re-attach the flat views
+        losses.append(loss.item())
+    assert all(p.grad is None for p in m.parameters())
+    assert losses[-1] < losses[0] - 0.05, losses
+    # the bf16 shadows were refreshed from the updated masters: eval logits differ from the initial weights' logits
+    m.eval()
+    with torch.no_grad():
+        _, lg, _ = m(**b)
+    assert (lg.cpu() - torch.from_numpy(z["full_eval.logits"])).abs().max().item() > 0.05
