@@ -19,9 +19,7 @@
 #define BM 128
 #define BN 128
 #define BK 64
-#define GROUP_M 8
-
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_BWD = 4 };
+#include "gemm_epi.h"
 
 #ifdef AMDSEG_PHASE_TIMERS
 #define PT_DECL unsigned long long pt_wait = 0, pt_comp = 0, pt_t0, pt_t1, pt_t2; const unsigned long long pt_start = __builtin_readcyclecounter();
@@ -34,20 +32,6 @@ enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_
 #define PT_B
 #define PT_C
 #endif
-struct GemmNTArgs {
-    const bf16_t* A; const bf16_t* B; void* C; const float* bias; const bf16_t* R; bf16_t* C2; unsigned long long* dbg;
-    int lda, ldb, ldc, ldr, ldc2;
-    int M, N, K;
-    int tiles_m, tiles_n;
-};
-
-// bijective XCD-aware remap: hardware places workgroup b on XCD b % 8; give each XCD a contiguous tile range
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
-
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(void, lds_wave_base), 16, 0, 0);
 }
@@ -591,6 +575,11 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     // workgroup per CU pays an exposed prologue + epilogue per tile), the 128x128 kernel (2 workgroups per CU overlap each
     // other's prologue/epilogue) for K <= 768; shapes the small kernel cannot tile always take the ping-pong kernel
     const bool small_ok = (a_in.M % BM) == 0 && (a_in.N % BN) == 0;
+    static int dp_min_k = -1;
+    if (dp_min_k < 0) { const char* e = getenv("AMDSEG_DP_MIN_K"); dp_min_k = e ? atoi(e) : 1536; }
+    // long K, 256-aligned: the deep-pipeline 256x256 kernel (gemm_dp.hip), ~1.25x the ping-pong kernel on these shapes
+    if ((a_in.M % 256) == 0 && (a_in.N % 256) == 0 && a_in.K >= dp_min_k && !g_force_small_tile && !(EPI == EPI_BIAS_GELU && !a_in.C2 && small_ok))
+        return amdseg_launch_nt_dp<EPI, OutT>(a_in, s);
     // the ping-pong kernel counts its in-flight stores (two outputs for BIAS_GELU): the single-output form runs on the 128x128 kernel
     const bool single_gelu = EPI == EPI_BIAS_GELU && !a_in.C2;
     if (single_gelu && !small_ok) return AMDSEG_ERR_SHAPE;

@@ -1,0 +1,25 @@
+// shared by gemm.hip and gemm_dp.hip: epilogue selectors, launch arguments, tile-order helpers of the NT GEMM kernels
+#pragma once
+#include "common.h"
+
+#define GROUP_M 8
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_BWD = 4 };
+
+struct GemmNTArgs {
+    const bf16_t* A; const bf16_t* B; void* C; const float* bias; const bf16_t* R; bf16_t* C2; unsigned long long* dbg;
+    int lda, ldb, ldc, ldr, ldc2;
+    int M, N, K;
+    int tiles_m, tiles_n;
+};
+
+// bijective XCD-aware remap: hardware places workgroup b on XCD b % 8; give each XCD a contiguous tile range
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+
+// deep-pipeline 256 x 256 kernel (gemm_dp.hip)
+template <int EPI, typename OutT> int amdseg_launch_nt_dp(const GemmNTArgs& a, hipStream_t s);
