@@ -6,9 +6,12 @@
 #define HD 64          // tile width (head dim)
 #define CH 64          // rows per streamed chunk
 
-// universal XOR swizzle for [rows][64] bf16 tiles (128 B rows, 8 chunks of 16 B): conflict-free for both the
-// ds_read_b128 fragment reads (16 rows, one chunk) and the tr_b16 gathers (8 rows x 32 B per half-wave)
-__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
+// XOR swizzle for [rows][64] bf16 tiles (128 B rows, 8 chunks of 16 B): chunk c of row r lives at chunk c ^ swz(r).
+// ds_read_b128 serves a wave in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... = 8 rows at chunk c and the other 8
+// rows of the fragment at chunk c ^ 1; f(p) = p ^ (p in {2,3,4,5}) over the row pair p = (r >> 1) & 7 makes the 16 lanes of a
+// group hit 16 distinct 16-B slots (the earlier (((r>>1)&3)<<1)|((r>>3)&1) had 2-way conflicts on EVERY b128 fragment read --
+// SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE in the GEMM prototype).
+__device__ __forceinline__ int swz(int r) { const int p = (r >> 1) & 7; return p ^ (((p + 2) >> 2) & 1); }
 
 __device__ __forceinline__ void at_glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(void, lds_wave_base), 16, 0, 0);
