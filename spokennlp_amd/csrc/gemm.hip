@@ -577,8 +577,11 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     const bool small_ok = (a_in.M % BM) == 0 && (a_in.N % BN) == 0;
     static int dp_min_k = -1;
     if (dp_min_k < 0) { const char* e = getenv("AMDSEG_DP_MIN_K"); dp_min_k = e ? atoi(e) : 1536; }
-    // long K, 256-aligned: the deep-pipeline 256x256 kernel (gemm_dp.hip), ~1.25x the ping-pong kernel on these shapes
-    if ((a_in.M % 256) == 0 && (a_in.N % 256) == 0 && a_in.K >= dp_min_k && !g_force_small_tile && !(EPI == EPI_BIAS_GELU && !a_in.C2 && small_ok))
+    // 256-aligned long-K shapes: the deep-pipeline 256x256 kernel (gemm_dp.hip).  Measured at M = 16384 against the kernels below:
+    // K = 3072 / 2304: 74-79 / 58 us vs 90 / 68 (ping-pong).  For K = 768 it also wins the back-to-back microbenchmark (QKV 64.5 vs
+    // 72 us, dual-output FFN 129 vs 143, GELU-bwd 106 vs 128) but NOT the training step (18.24 vs 18.17 ms): with cold
+    // operands its single workgroup per CU hides HBM latency worse than two 128x128 workgroups -- AMDSEG_DP_MIN_K selects
+    if ((a_in.M % 256) == 0 && (a_in.N % 256) == 0 && a_in.K >= dp_min_k && !g_force_small_tile)
         return amdseg_launch_nt_dp<EPI, OutT>(a_in, s);
     // the ping-pong kernel counts its in-flight stores (two outputs for BIAS_GELU): the single-output form runs on the 128x128 kernel
     const bool single_gelu = EPI == EPI_BIAS_GELU && !a_in.C2;
