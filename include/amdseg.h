@@ -165,6 +165,9 @@ int amdseg_cast_transpose(const float* W, void* Wb, void* Wt, int N, int K, amds
  * the bf16 compute shadows after the optimiser step ([hf] trainer.py optimizer.step -> next forward) */
 int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                   amdseg_stream_t stream);
+/* test hook: v != 0 routes GEMMs that would take a 256-wide deep-pipeline kernel to the 128 x 128 kernels instead, so both
+ * code paths can be compared on one shape; returns the previous value.  Not part of the reference-facing surface. */
+int amdseg_debug_force_small_tile(int v);
 /* small-C linear heads: logits[M,C] = x[M,H] W[C,H]^T + b, C <= 4
  * (modules/loss_calculator.py:17,42 classifier; modules/tssp.py:14,31) and their backward */
 int amdseg_rowdot_fwd(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,

@@ -36,6 +36,7 @@ int amdseg_colsum_impl(const void* x, int ld, float* partials, float* out, int M
 int amdseg_dropout_impl(const void* x, void* y, size_t n, float p, uint64_t seed, int dtype_in, int dtype_out,
                         hipStream_t s);
 int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K, hipStream_t s);
+int amdseg_set_force_small_tile(int v);
 int amdseg_cast_transpose_batched_impl(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                        hipStream_t s);
 int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_out, hipStream_t s);

@@ -144,6 +144,7 @@ int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb,
                                   amdseg_stream_t stream) {
     return amdseg_cast_transpose_batched_impl(n, W, Wb, Wt, N, K, S(stream));
 }
+int amdseg_debug_force_small_tile(int v) { return amdseg_set_force_small_tile(v); }
 int amdseg_rowdot_fwd(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
                       amdseg_stream_t stream) {
     return amdseg_rowdot_fwd_impl(x, W, b, out, M, H, C, dtype, S(stream));

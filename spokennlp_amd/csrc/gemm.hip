@@ -644,8 +644,6 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
 // ------------------------------------------------------------------------------------------------ gemm_tn
 // Operand tiles are [64 m][128 cols] bf16 (256 B per row, 16 chunks of 16 B); chunk c of row m is stored at slot
 // c ^ ((m & 3) << 2) so the four rows gathered by one ds_read_b64_tr_b16 half-wave fall on disjoint banks.
-struct TNProblem { const bf16_t* A; const bf16_t* B; float* C; int N, Kp, lda, ldb, ldc, tile_begin, tiles_k; };
-struct GemmTNArgs { TNProblem p[AMDSEG_MAX_GROUP]; int nprob, M, accumulate, total_tiles; };
 
 __device__ __forceinline__ void tn_stage(const bf16_t* __restrict__ G, int ld, int m0, int col0, char* lds_tile, int w, int l) {
 #pragma unroll
@@ -779,6 +777,12 @@ int amdseg_gemm_tn_grouped_impl(int nprob, const void* const* A, const int* lda,
     }
     for (int i = nprob; i < AMDSEG_MAX_GROUP; ++i) a.p[i] = a.p[0];
     a.nprob = nprob; a.M = M; a.accumulate = accumulate; a.total_tiles = tiles;
+    // 256 x 128 deep-pipeline kernel (gemm_dp.hip) when every problem tiles by it: ~0.7x the time of the kernel below
+    static int tn_dp = -1;
+    if (tn_dp < 0) { const char* e = getenv("AMDSEG_TN_DP"); tn_dp = e ? atoi(e) : 1; }
+    bool dp = tn_dp && M >= 128 && !g_force_small_tile;
+    for (int i = 0; i < nprob; ++i) dp = dp && (N[i] % 256) == 0;
+    if (dp) return amdseg_launch_tn_dp(a, stream);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles), dim3(256), 0, stream, a);
     return amdseg_launch_status();
 }

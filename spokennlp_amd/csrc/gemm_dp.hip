@@ -193,3 +193,135 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
 #define DP_INST(E, T) template int amdseg_launch_nt_dp<E, T>(const GemmNTArgs&, hipStream_t);
 DP_INST(EPI_NONE, bf16_t) DP_INST(EPI_NONE, float) DP_INST(EPI_BIAS, bf16_t) DP_INST(EPI_BIAS, float) DP_INST(EPI_BIAS_GELU, bf16_t)
 DP_INST(EPI_ADD_RES, bf16_t) DP_INST(EPI_ADD_RES, float) DP_INST(EPI_GELU_BWD, bf16_t)
+
+
+// ==================================================================================================== gemm_tn, deep pipeline
+// Weight gradients  C_p[N_p, K_p] (+)= sum_m A_p[m, N_p] . B_p[m, K_p]  (dW = dY^T X of the encoder's four Linears, one grouped
+// launch per layer; same reference lines as gemm_tn_kernel in gemm.hip).  256(N) x 128(K') tile per 512-thread workgroup:
+//   * 8 waves = 2 N-groups x 4 K'-waves, wave tile 128 x 32 (8 x 2 fragments of v_mfma_f32_16x16x32_bf16, operands swapped
+//     so a lane owns one output row and 4 consecutive columns: 16-B fp32 read-modify-write);
+//   * BOTH operands are k(= token)-strided: [64 m][64] LDS tile images, fragments gathered with ds_read_b64_tr_b16.  k-slot
+//     (g, j) <-> rows kk*32 + g*4 + j and kk*32 + 16 + g*4 + j - 4, so that one 32-lane group touches 8 CONSECUTIVE rows x
+//     32 B, which tn_swz spreads over all 64 banks (rows g*8.. gave 2-way conflicts; SQ_LDS_BANK_CONFLICT = 0 now);
+//   * 3-stage ring of 48 KiB (A 4 images + B 2 images) filled by DMA two K tiles (2 us) ahead, counted vmcnt;
+//   * one phase per K tile: [40 fragment gathers + DMA issue | barrier | 32 MFMAs | barrier], the two N-groups staggered by
+//     one barrier.
+// Measured (tools/ubench/gemm_tn_dp.cpp, M = 16384): 0.9 us per K tile per CU = 4.65 TFLOP/s per CU (57 % of the CU's MFMA
+// peak at 2.0 GHz) vs 3.1 for the 128 x 128 two-barrier kernel.
+#define TN_STG 49152
+#define TN_LDS (3 * TN_STG)
+__device__ __forceinline__ int tn_swz(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
+__device__ __forceinline__ bf16x8 tn_frag(const char* tile, int r0, int col0, int l) {
+    const int i16 = l & 15;
+    const int c = (col0 >> 3) + ((i16 & 3) >> 1);
+    bf16x8 f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = r0 + h * 16 + (i16 >> 2);
+        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4, tile + row * 128 + ((c ^ tn_swz(row)) << 4) + (i16 & 1) * 8));
+        f[h * 4 + 0] = v[0]; f[h * 4 + 1] = v[1]; f[h * 4 + 2] = v[2]; f[h * 4 + 3] = v[3];
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3, wq = w & 3;
+    const int g = l >> 4, i16 = l & 15;
+    const int t = xcd_remap(blockIdx.x, a.total_tiles);      // each XCD walks a contiguous run of tiles (shared A panels)
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < AMDSEG_MAX_GROUP; ++i)
+        if (i < a.nprob && t >= a.p[i].tile_begin) pi = i;
+    const TNProblem P = a.p[pi];
+    const int lt = t - P.tile_begin;
+    const int tn = lt / P.tiles_k, tk = lt % P.tiles_k;
+    const int n0 = tn * 256, k0 = tk * 128;
+#define TN_TILE_A(s, i) (smem + (s) * TN_STG + (i) * 8192)
+#define TN_TILE_B(s, j) (smem + (s) * TN_STG + 32768 + (j) * 8192)
+    int offA[4], offB[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = (wq * 2 + q) * 8 + (l >> 3), c = (l & 7) ^ tn_swz(r);
+        offA[q] = r * P.lda + (wr * 2) * 64 + c * 8;
+        offA[2 + q] = r * P.lda + (wr * 2 + 1) * 64 + c * 8;
+        offB[q] = r * P.ldb + wr * 64 + c * 8;
+    }
+    const bf16_t* pA = P.A + n0;
+    const bf16_t* pB = P.B + k0;
+#define TN_DMA(s, kt) do { const bf16_t* ba = pA + (size_t)(kt) * 64 * P.lda; const bf16_t* bb = pB + (size_t)(kt) * 64 * P.ldb; \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
+            dp_glds16(ba + offA[i * 2 + q], TN_TILE_A(s, wr * 2 + i) + (wq * 2 + q) * 1024); \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) dp_glds16(bb + offB[q], TN_TILE_B(s, wr) + (wq * 2 + q) * 1024); } while (0)
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = a.M / 64;
+    TN_DMA(0, 0);
+    TN_DMA(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();             // stagger: group 1 runs one barrier behind group 0
+    int s = 0, s2 = 2;                                      // stage of K tile kt, stage refilled with K tile kt + 2
+    for (int kt = 0; kt < nk; ++kt) {
+        bf16x8 fa[8][2], fb[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) fb[e][kk] = tn_frag(TN_TILE_B(s, wc >> 1), kk * 32 + g * 4, (wc & 1) * 32 + e * 16, l);
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf) fa[nf][kk] = tn_frag(TN_TILE_A(s, wr * 2 + (nf >> 2)), kk * 32 + g * 4, (nf & 3) * 16, l);
+        }
+        // stage s2 held K tile kt-1: this group read it one phase ago, the other group half a phase later, both retired their
+        // gathers (lgkmcnt(0)) before the barrier that ended that load half
+        if (kt + 2 < nk) TN_DMA(s2, kt + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) acc[nf][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[e][kk], fa[nf][kk], acc[nf][e], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+        s = s == 2 ? 0 : s + 1; s2 = s2 == 2 ? 0 : s2 + 1;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    // epilogue: lane owns row n = nf*16 + i16, columns e*16 + g*4 .. +4 of the wave tile
+#pragma unroll
+    for (int nf = 0; nf < 8; ++nf) {
+        float* crow = P.C + (size_t)(n0 + wr * 128 + nf * 16 + i16) * P.ldc + k0 + wc * 32 + g * 4;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float4 v = make_float4(acc[nf][e][0], acc[nf][e][1], acc[nf][e][2], acc[nf][e][3]);
+            float4* p = reinterpret_cast<float4*>(crow + e * 16);
+            if (a.accumulate) { const float4 o = *p; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *p = v;
+        }
+    }
+}
+
+int amdseg_launch_tn_dp(const GemmTNArgs& a128, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    GemmTNArgs a = a128;                                     // re-tile: 256 x 128 tiles, K' fastest
+    int tiles = 0;
+    for (int i = 0; i < a.nprob; ++i) {
+        a.p[i].tile_begin = tiles; a.p[i].tiles_k = a.p[i].Kp / 128;
+        tiles += (a.p[i].N / 256) * (a.p[i].Kp / 128);
+    }
+    a.total_tiles = tiles;
+    hipLaunchKernelGGL(gemm_tn_dp_kernel, dim3(tiles), dim3(512), TN_LDS, s, a);
+    return amdseg_launch_status();
+}

@@ -155,6 +155,35 @@ def test_gemm_tn_grouped(dev):
         assert rel_err(c, ref) < 2e-6
 
 
+@pytest.mark.parametrize("M", [128, 192, 1024])
+def test_gemm_tn_grouped_dp(dev, M):
+    """256 x 128 deep-pipeline weight-gradient kernel (every N % 256 == 0): ragged K-tile counts (M/64 = 2, 3, 16), strided A
+    (a column block of a wider matrix, like the dQKV slices), overwrite and accumulate, and agreement with the 128 x 128 kernel."""
+    ops = _ops()
+    shapes = [(256, 384), (512, 128), (768, 256), (256, 128)]
+    g = torch.Generator(device="cpu").manual_seed(12)
+    wide = torch.randn(M, 1024, generator=g).to(dev).bfloat16()
+    As = [wide[:, 128:128 + shapes[0][0]]] + [torch.randn(M, n, generator=g).to(dev).bfloat16() for n, _ in shapes[1:]]
+    Bs = [torch.randn(M, k, generator=g).to(dev).bfloat16() for _, k in shapes]
+    Cs = [torch.full((n, k), 7.0, dtype=torch.float32, device=dev) for n, k in shapes]
+    ops.gemm_tn_grouped(As, Bs, Cs, accumulate=False)
+    for a, b, c in zip(As, Bs, Cs):
+        ref = a.float().t() @ b.float()
+        assert rel_err(c, ref) < 2e-6
+    ops.gemm_tn_grouped(As, Bs, Cs, accumulate=True)
+    for a, b, c in zip(As, Bs, Cs):
+        ref = 2 * (a.float().t() @ b.float())
+        assert rel_err(c, ref) < 2e-6
+    old = ops.L.load().amdseg_debug_force_small_tile(1)
+    try:
+        C2 = [torch.empty_like(c) for c in Cs]
+        ops.gemm_tn_grouped(As, Bs, C2, accumulate=False)
+    finally:
+        ops.L.load().amdseg_debug_force_small_tile(old)
+    for a, b, c in zip(As, Bs, C2):
+        assert rel_err(c, a.float().t() @ b.float()) < 2e-6
+
+
 def test_gemm_tn_transpose_detect(dev):
     ops = _ops()
     M, N, K = 64, 128, 256
