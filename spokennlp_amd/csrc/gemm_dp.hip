@@ -198,37 +198,41 @@ DP_INST(EPI_ADD_RES, bf16_t) DP_INST(EPI_ADD_RES, float) DP_INST(EPI_GELU_BWD, b
 // ==================================================================================================== gemm_tn, deep pipeline
 // Weight gradients  C_p[N_p, K_p] (+)= sum_m A_p[m, N_p] . B_p[m, K_p]  (dW = dY^T X of the encoder's four Linears, one grouped
 // launch per layer; same reference lines as gemm_tn_kernel in gemm.hip).  256(N) x 128(K') tile per 512-thread workgroup:
-//   * 8 waves = 2 N-groups x 4 K'-waves, wave tile 128 x 32 (8 x 2 fragments of v_mfma_f32_16x16x32_bf16, operands swapped
-//     so a lane owns one output row and 4 consecutive columns: 16-B fp32 read-modify-write);
 //   * BOTH operands are k(= token)-strided: [64 m][64] LDS tile images, fragments gathered with ds_read_b64_tr_b16.  k-slot
-//     (g, j) <-> rows kk*32 + g*4 + j and kk*32 + 16 + g*4 + j - 4, so that one 32-lane group touches 8 CONSECUTIVE rows x
+//     (g, j) <-> rows kh*32 + g*4 + j and kh*32 + 16 + g*4 + j - 4, so that one 32-lane group touches 8 CONSECUTIVE rows x
 //     32 B, which tn_swz spreads over all 64 banks (rows g*8.. gave 2-way conflicts; SQ_LDS_BANK_CONFLICT = 0 now);
-//   * 3-stage ring of 48 KiB (A 4 images + B 2 images) filled by DMA two K tiles (2 us) ahead, counted vmcnt;
-//   * one phase per K tile: [40 fragment gathers + DMA issue | barrier | 32 MFMAs | barrier], the two N-groups staggered by
-//     one barrier.
-// Measured (tools/ubench/gemm_tn_dp.cpp, M = 16384): 0.9 us per K tile per CU = 4.65 TFLOP/s per CU (57 % of the CU's MFMA
-// peak at 2.0 GHz) vs 3.1 for the 128 x 128 two-barrier kernel.
+//   * 8 waves = 2 K-halves (kh: tokens kh*32..+32 of every 64-token K tile) x 2 N-halves x 2 K'-halves, wave tile 128 x 64 over
+//     half the K tile (8 x 4 fragments of v_mfma_f32_16x16x32_bf16, operands swapped so a lane owns one output row and 4
+//     consecutive columns): 24 gathers per 32 MFMAs; the two K-halves are summed through LDS once, after the K loop;
+//   * software pipeline inside every wave: the fragments of K tile kt+1 are gathered BETWEEN the MFMAs of K tile kt (A
+//     fragments single-buffered: reloaded right after their last MFMA; B fragments double-buffered).  A wave issues only one
+//     ds_read_b64_tr per ~16 clk, so a separate load phase (the first version of this kernel: 40 gathers, barrier, 32 MFMAs,
+//     barrier, two staggered groups) was bound by gather issue: 321 -> 257 us on 256 tiles of M = 16384;
+//   * 3-stage ring of 48 KiB (A 4 images + B 2 images) filled by DMA two to three K tiles ahead, one piece between every
+//     4 MFMAs, counted vmcnt, ONE barrier per K tile;
+//   * the gathers are inline asm: in front of a ds_read_b64_tr_b16 BUILTIN that follows an LDS-DMA the compiler emits
+//     s_waitcnt vmcnt(0) (it cannot prove they do not alias), which drained the whole ring once per K tile.  Their lgkmcnt wait
+//     is explicit (top of every K tile) and ties every fragment register, so nothing derived from a gathered value can be
+//     scheduled before its data arrived (a compiler-inserted v_bfi on a fresh asm result once consumed stale registers).
+// Measured (tools/ubench/gemm_tn_dp.cpp, M = 16384, one tile per CU): 72 tiles 194 us, 256 tiles 257 us = 1071 TFLOP/s
+// (MFMA-only ablation 145 / 157 us; without DMA 169 / 205 us).
 #define TN_STG 49152
 #define TN_LDS (3 * TN_STG)
+typedef int tn_i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int tn_swz(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
-__device__ __forceinline__ bf16x8 tn_frag(const char* tile, int r0, int col0, int l) {
-    const int i16 = l & 15;
-    const int c = (col0 >> 3) + ((i16 & 3) >> 1);
-    bf16x8 f;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int row = r0 + h * 16 + (i16 >> 2);
-        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(bf16x4, tile + row * 128 + ((c ^ tn_swz(row)) << 4) + (i16 & 1) * 8));
-        f[h * 4 + 0] = v[0]; f[h * 4 + 1] = v[1]; f[h * 4 + 2] = v[2]; f[h * 4 + 3] = v[3];
-    }
-    return f;
+// wave-uniform pointer the loop optimiser cannot turn into per-lane 64-bit induction variables (24 VGPRs of DMA addresses otherwise)
+__device__ __forceinline__ const bf16_t* tn_uniform(const bf16_t* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const bf16_t*)(((uint64_t)hi << 32) | lo);
 }
 
 __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 2, wc = w & 3, wq = w & 3;
+    const int dr = w >> 2, wq = w & 3;                       // DMA duty: images 2dr, 2dr+1 of A and dr of B, 8-row pieces 2wq, 2wq+1
+    const int kh = w >> 2, wr = (w >> 1) & 1, wc = w & 1;    // compute role
     const int g = l >> 4, i16 = l & 15;
     const int t = xcd_remap(blockIdx.x, a.total_tiles);      // each XCD walks a contiguous run of tiles (shared A panels)
     int pi = 0;
@@ -245,64 +249,110 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int r = (wq * 2 + q) * 8 + (l >> 3), c = (l & 7) ^ tn_swz(r);
-        offA[q] = r * P.lda + (wr * 2) * 64 + c * 8;
-        offA[2 + q] = r * P.lda + (wr * 2 + 1) * 64 + c * 8;
-        offB[q] = r * P.ldb + wr * 64 + c * 8;
+        offA[q] = r * P.lda + (dr * 2) * 64 + c * 8;
+        offA[2 + q] = r * P.lda + (dr * 2 + 1) * 64 + c * 8;
+        offB[q] = r * P.ldb + dr * 64 + c * 8;
     }
     const bf16_t* pA = P.A + n0;
     const bf16_t* pB = P.B + k0;
-#define TN_DMA(s, kt) do { const bf16_t* ba = pA + (size_t)(kt) * 64 * P.lda; const bf16_t* bb = pB + (size_t)(kt) * 64 * P.ldb; \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
-            dp_glds16(ba + offA[i * 2 + q], TN_TILE_A(s, wr * 2 + i) + (wq * 2 + q) * 1024); \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q) dp_glds16(bb + offB[q], TN_TILE_B(s, wr) + (wq * 2 + q) * 1024); } while (0)
-    f32x4 acc[8][2];
+    // piece j of this wave's DMA duty for K tile kt: j < 4 -> A image 2dr + (j >> 1), 8-row piece 2wq + (j & 1); j >= 4 -> B image dr
+#define TN_DMA_PIECE(s, kt, j) do { if ((j) < 4) dp_glds16(tn_uniform(pA + (size_t)(kt) * 64 * P.lda) + offA[j], TN_TILE_A(s, dr * 2 + ((j) >> 1)) + (wq * 2 + ((j) & 1)) * 1024); \
+        else dp_glds16(tn_uniform(pB + (size_t)(kt) * 64 * P.ldb) + offB[(j) - 4], TN_TILE_B(s, dr) + (wq * 2 + ((j) - 4)) * 1024); } while (0)
+#define TN_DMA(s, kt) do { _Pragma("unroll") for (int j_ = 0; j_ < 6; ++j_) TN_DMA_PIECE(s, kt, j_); } while (0)
+    f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = a.M / 64;
     TN_DMA(0, 0);
-    TN_DMA(1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (nk > 1) TN_DMA(1, 1);
+    if (nk > 2) TN_DMA(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();             // stagger: group 1 runs one barrier behind group 0
-    int s = 0, s2 = 2;                                      // stage of K tile kt, stage refilled with K tile kt + 2
-    for (int kt = 0; kt < nk; ++kt) {
-        bf16x8 fa[8][2], fb[2][2];
+    // lane addresses of the gathers inside stage 0: lane (i16, g) of fragment column block c4 reads rows kh*32 + g*4 + (i16 >> 2) (+16)
+    uint32_t laA[4], laB[4];
+    {
+        const int row = kh * 32 + g * 4 + (i16 >> 2);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) fb[e][kk] = tn_frag(TN_TILE_B(s, wc >> 1), kk * 32 + g * 4, (wc & 1) * 32 + e * 16, l);
-#pragma unroll
-            for (int nf = 0; nf < 8; ++nf) fa[nf][kk] = tn_frag(TN_TILE_A(s, wr * 2 + (nf >> 2)), kk * 32 + g * 4, (nf & 3) * 16, l);
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int c = c4 * 2 + ((i16 & 3) >> 1);
+            const uint32_t o = (uint32_t)(uintptr_t)LDS_PTR(char, smem) + row * 128 + ((c ^ tn_swz(row)) << 4) + (i16 & 1) * 8;
+            laA[c4] = o + wr * 2 * 8192;
+            laB[c4] = o + 32768 + wc * 8192;
         }
-        // stage s2 held K tile kt-1: this group read it one phase ago, the other group half a phase later, both retired their
-        // gathers (lgkmcnt(0)) before the barrier that ended that load half
-        if (kt + 2 < nk) TN_DMA(s2, kt + 2);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int nf = 0; nf < 8; ++nf)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) acc[nf][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[e][kk], fa[nf][kk], acc[nf][e], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
-        s = s == 2 ? 0 : s + 1; s2 = s2 == 2 ? 0 : s2 + 1;
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();
-    // epilogue: lane owns row n = nf*16 + i16, columns e*16 + g*4 .. +4 of the wave tile
+    tn_i32x2 fa[8][2], fb0[4][2], fb1[4][2];
+#define TN_RD(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define TN_LDA(nf) do { TN_RD(fa[nf][0], aA[(nf) & 3], ((nf) >> 2) * 8192); TN_RD(fa[nf][1], aA[(nf) & 3], ((nf) >> 2) * 8192 + 2048); } while (0)
+#define TN_LDB(e, FB) do { TN_RD(FB[e][0], aB[e], 0); TN_RD(FB[e][1], aB[e], 2048); } while (0)
+#define TN_CAT(x) __builtin_bit_cast(bf16x8, __builtin_shufflevector(x[0], x[1], 0, 1, 2, 3))
+#define TN_SB() __builtin_amdgcn_sched_barrier(0)
+#define TN_MF(nf, e, FB) acc[nf][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN_CAT(FB[e]), TN_CAT(fa[nf]), acc[nf][e], 0, 0, 0)
+#define TN_WAIT_FRAGS(FB) asm volatile("s_waitcnt lgkmcnt(0)" \
+        : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), \
+          "+v"(fa[4][0]), "+v"(fa[4][1]), "+v"(fa[5][0]), "+v"(fa[5][1]), "+v"(fa[6][0]), "+v"(fa[6][1]), "+v"(fa[7][0]), "+v"(fa[7][1]), \
+          "+v"(FB[0][0]), "+v"(FB[0][1]), "+v"(FB[1][0]), "+v"(FB[1][1]), "+v"(FB[2][0]), "+v"(FB[2][1]), "+v"(FB[3][0]), "+v"(FB[3][1]) :: "memory")
+    uint32_t aA[4], aB[4];
 #pragma unroll
-    for (int nf = 0; nf < 8; ++nf) {
-        float* crow = P.C + (size_t)(n0 + wr * 128 + nf * 16 + i16) * P.ldc + k0 + wc * 32 + g * 4;
+    for (int c4 = 0; c4 < 4; ++c4) { aA[c4] = laA[c4]; aB[c4] = laB[c4]; }
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float4 v = make_float4(acc[nf][e][0], acc[nf][e][1], acc[nf][e][2], acc[nf][e][3]);
+    for (int e = 0; e < 4; ++e) TN_LDB(e, fb0);
+#pragma unroll
+    for (int nf = 0; nf < 8; ++nf) TN_LDA(nf);
+    int sc = 0, sn = 1;                                     // stages of K tiles kt (free: refilled with kt+3) and kt+1 (gathered now)
+    // K tile kt.  Top: this wave's gathers of tile kt (issued during kt-1) and its DMA pieces of tile kt+1 have landed; after the
+    // barrier that holds for every wave, so stage sn may be read and stage sc (tile kt, now in registers everywhere) refilled.
+#define TN_BODY(FC, FN) do { \
+        TN_WAIT_FRAGS(FC); \
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        TN_SB(); __builtin_amdgcn_s_barrier(); TN_SB(); \
+        const bool dma_ = kt + 3 < nk; \
+        _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4) { aA[c4] = laA[c4] + sn * TN_STG; aB[c4] = laB[c4] + sn * TN_STG; } \
+        __builtin_amdgcn_s_setprio(1); \
+        _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) { \
+            TN_MF(nf, 0, FC); TN_SB(); TN_MF(nf, 1, FC); TN_SB(); TN_LDB(nf, FN); TN_SB(); TN_MF(nf, 2, FC); TN_SB(); TN_MF(nf, 3, FC); TN_SB(); TN_LDA(nf); TN_SB(); \
+            if (nf >= 1 && dma_) { TN_DMA_PIECE(sc, kt + 3, nf - 1); TN_SB(); } } \
+        _Pragma("unroll") for (int nf = 4; nf < 8; ++nf) { \
+            TN_MF(nf, 0, FC); TN_MF(nf, 1, FC); TN_MF(nf, 2, FC); TN_MF(nf, 3, FC); TN_SB(); TN_LDA(nf); TN_SB(); \
+            if (nf <= 6 && dma_) { TN_DMA_PIECE(sc, kt + 3, nf - 1); TN_SB(); } } \
+        __builtin_amdgcn_s_setprio(0); \
+        sc = sc == 2 ? 0 : sc + 1; sn = sn == 2 ? 0 : sn + 1; } while (0)
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        TN_BODY(fb0, fb1);
+        ++kt; TN_BODY(fb1, fb0); --kt;
+    }
+    if (kt < nk) TN_BODY(fb0, fb1);
+    TN_WAIT_FRAGS(fb0);                                     // the last K tile gathered a (never used) tile nk: retire it before
+    TN_WAIT_FRAGS(fb1);                                     // these registers and the ring are reused
+    __builtin_amdgcn_s_barrier();
+    // K-half exchange through LDS: wave (kh, wr, wc) keeps row fragments nf = kh*4 .. +4 and hands the other four to its partner
+    f32x4* xch = reinterpret_cast<f32x4*>(smem) + (size_t)w * 16 * 64;
+    if (kh == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xch[(i * 4 + e) * 64 + l] = acc[4 + i][e];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xch[(i * 4 + e) * 64 + l] = acc[i][e]; acc[i][e] = acc[4 + i][e]; }
+    }
+    __syncthreads();
+    const f32x4* got = reinterpret_cast<const f32x4*>(smem) + (size_t)(w ^ 4) * 16 * 64;
+    // lane owns row n = (kh*4 + i)*16 + i16 and columns e*16 + g*4 .. +4 of the wave tile: 16-B fp32 read-modify-write
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* crow = P.C + (size_t)(n0 + wr * 128 + (kh * 4 + i) * 16 + i16) * P.ldc + k0 + wc * 64 + g * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 o = got[(i * 4 + e) * 64 + l];
+            const f32x4 m = acc[i][e];
+            float4 v = make_float4(m[0] + o[0], m[1] + o[1], m[2] + o[2], m[3] + o[3]);
             float4* p = reinterpret_cast<float4*>(crow + e * 16);
-            if (a.accumulate) { const float4 o = *p; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (a.accumulate) { const float4 c = *p; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
             *p = v;
         }
     }
