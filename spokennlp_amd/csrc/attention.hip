@@ -51,7 +51,7 @@ __device__ __forceinline__ float xor_reduce_sum_g(float v) {
 // 64 consecutive floats (a chunk's key mask / LSE / delta) global -> LDS by DMA, 4 B per lane; issued by ONE wave and
 // covered by the same vmcnt(0) + barrier hand-off as the tiles
 __device__ __forceinline__ void at_stage_f32x64(const float* g, char* lds, int l) {
-    __builtin_amdgcn_global_load_lds(GLB_PTR(g + l), LDS_PTR(void, lds), 4, 0, 0);
+    amdseg_glds4(g + l, lds);
 }
 
 struct AttnArgs {
@@ -115,6 +115,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     // the additive key mask of a chunk travels with its K/V tiles (a global load issued where it is consumed costs a full
     // L2 round trip per key fragment: 4 exposed latencies per chunk)
     if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(0) * CH, bufM(0), l);
+    // a wait the compiler can see: otherwise it places the vmcnt wait for the Q fragments (plain global loads) at their first use
+    // INSIDE the loop, where it drains the chunk prefetch that was just issued, every iteration
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
     for (int ch = 0; ch < nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

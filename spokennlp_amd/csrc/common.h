@@ -17,6 +17,20 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+// LDS-DMA issued as inline asm: 64 lanes x 16 B (or 4 B) from per-lane global addresses to lds_wave_base + lane * size.
+// Why not __builtin_amdgcn_global_load_lds: after the builtin the compiler puts s_waitcnt vmcnt(0) in front of the next LDS READ
+// BUILTIN with a memory operand it cannot disambiguate (ds_read_b64_tr_b16, plain loads in some kernels) -- i.e. it drains the
+// prefetch that was just issued (seen in attention fwd/bwd and the TN GEMM; the waits these kernels need are the explicit
+// counted vmcnt + barrier hand-offs in their loops).  m0 is not allocatable; the compiler re-materialises it before its own uses.
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void amdseg_glds16(const void* g, void* lds_wave_base) {
+    const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(char, lds_wave_base));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(m) : "memory", "m0");
+}
+__device__ __forceinline__ void amdseg_glds4(const void* g, void* lds_wave_base) {
+    const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(char, lds_wave_base));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(m) : "memory", "m0");
+}
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // round-to-nearest-even fp32 -> bf16 (NaN kept quiet)

@@ -14,7 +14,7 @@
 __device__ __forceinline__ int swz(int r) { const int p = (r >> 1) & 7; return p ^ (((p + 2) >> 2) & 1); }
 
 __device__ __forceinline__ void at_glds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(void, lds_wave_base), 16, 0, 0);
+    amdseg_glds16(g, lds_wave_base);
 }
 // stage a [64][64] bf16 tile; `base` points at element (row 0, col 0), rows are row_stride elements apart
 template <int NW>
