@@ -47,6 +47,11 @@ def build(args, device):
         from spokennlp_amd.longformer_for_ts import LongformerWithDAForSentenceLabelingTopicSegmentation as M
         cfg = LongformerConfig(vocab_size=50266, num_labels=2, max_position_embeddings=4098, type_vocab_size=1, pad_token_id=1,
                                attention_window=[512] * 12, layer_norm_eps=1e-5)
+    elif args.model == "bigbird":       # google/bigbird-roberta-base (+[BOS]): 12 x 768, block 64, 3 random blocks, gelu_new
+        from transformers import BigBirdConfig
+        from spokennlp_amd.bigbird_for_ts import BigBirdWithDAForSentenceLabelingTopicSegmentation as M
+        cfg = BigBirdConfig(vocab_size=50359, num_labels=2, max_position_embeddings=4096, attention_type="block_sparse",
+                            block_size=64, num_random_blocks=3)
     else:
         from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
         cfg = BertConfig(vocab_size=30523, num_labels=2)          # bert-base-uncased + [BOS]
@@ -88,7 +93,7 @@ def make_batches(args, n, seed, device):
         return make_ponet_batches(args, n, seed, device)
     from spokennlp_amd import data
     pairs = args.seqs_per_gpu // 2 if args.workload == "full_da" else args.seqs_per_gpu
-    if args.model == "longformer":
+    if args.model in ("longformer", "bigbird"):
         docs = data.synth_docs(max(64, pairs * n * 3), seed=1234 + seed, vocab=50266, mean_sents=160, sd_sents=40)
     else:
         docs = data.synth_docs(max(64, pairs * n // 2), seed=1234 + seed)
@@ -209,7 +214,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="bert", choices=["bert", "longformer", "ponet"])
+    ap.add_argument("--model", default="bert", choices=["bert", "longformer", "ponet", "bigbird"])
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--seqs-per-gpu", type=int, default=None)
     ap.add_argument("--workload", default="full_da", choices=["full_da", "plain"])
@@ -272,11 +277,13 @@ def main():
     seqs = args.seqs_per_gpu * world * args.steps
     value = seqs / dt
     fl = flops_per_seq(args.seq_len, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, args.mode == "train",
-                       span={"bert": None, "longformer": 514, "ponet": 0}[args.model], nproj=5 if args.model == "ponet" else 3)
+                       span={"bert": None, "longformer": 514, "ponet": 0, "bigbird": 8 * 64}[args.model], nproj=5 if args.model == "ponet" else 3)
     name = {"bert": "bert-base-uncased(+[BOS])", "longformer": "longformer-base-4096(+[BOS], window 512, CLS global)",
-            "ponet": "PoNet-base(+[EOS], paragraph segment ids)"}[args.model]
+            "ponet": "PoNet-base(+[EOS], paragraph segment ids)",
+            "bigbird": "bigbird-roberta-base(+[BOS], block-sparse: block 64, 3 random blocks)"}[args.model]
     out = dict(metric={"bert": "train seq/s (512-tok) bert-base topic-seg", "longformer": "train seq/s (4096-tok) longformer-base topic-seg",
-                       "ponet": "train seq/s (4096-tok) PoNet-base topic-seg"}[args.model].replace("train", args.mode),
+                       "ponet": "train seq/s (4096-tok) PoNet-base topic-seg",
+                       "bigbird": "train seq/s (4096-tok) bigbird-base topic-seg"}[args.model].replace("train", args.mode),
                value=round(value, 2), unit="seq/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",

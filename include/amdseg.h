@@ -41,6 +41,7 @@ extern "C" {
 #define AMDSEG_EPI_BIAS_GELU 2  /* C2 = A B^T + bias (pre-activation; C2 may be NULL), C = gelu_erf  */
 #define AMDSEG_EPI_ADD_RES 3    /* C = A B^T + R                                                  */
 #define AMDSEG_EPI_GELU_BWD 4   /* C = (A B^T) * gelu_erf'(R)                                     */
+#define AMDSEG_EPI_ACT_TANH 0x100 /* OR-ed into BIAS_GELU / GELU_BWD: "gelu_new" (tanh form, BigBird's hidden_act) instead of erf */
 
 typedef void* amdseg_stream_t;  /* hipStream_t */
 
@@ -165,6 +166,19 @@ int amdseg_cast_transpose(const float* W, void* Wb, void* Wt, int N, int K, amds
  * the bf16 compute shadows after the optimiser step ([hf] trainer.py optimizer.step -> next forward) */
 int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                   amdseg_stream_t stream);
+/* Block-list attention = BigBird block-sparse attention ([hf] models/big_bird/modeling_big_bird.py
+ * BigBirdBlockSparseAttention.bigbird_block_sparse_attention, reached from the reference through
+ * emnlp2023-topic_segmentation/src/models/bigbird_for_ts.py:27 BigBirdModel).  qkv/ctx/lse/mask_bias as amdseg_attn_fwd (bf16,
+ * head dim 64, L % 64 == 0, mask_bias = -10000 * (1 - attention_mask) as the reference adds it).  Query block i of head h visits
+ * the key blocks klist[(h * L/64 + i) * list_stride + 0 .. kcnt[h * L/64 + i]) in order, duplicates included (one softmax over the
+ * concatenation, as the reference's torch.cat of key blocks); qlist/qcnt are the transposed lists per (head, key block) with the
+ * same multiplicities (device int32 arrays, built by the host mirror spokennlp_amd/bigbird_plan.py).  Rows of padded queries are
+ * zeroed by the caller (reference: context_layer * from_mask). */
+int amdseg_attn_list_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
+                         const int* klist, const int* kcnt, int list_stride, amdseg_stream_t stream);
+int amdseg_attn_list_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                         float* delta_ws, void* dqkv, int B, int L, int heads, float scale, const int* klist, const int* kcnt,
+                         const int* qlist, const int* qcnt, int list_stride, amdseg_stream_t stream);
 /* test hook: v != 0 routes GEMMs that would take a 256-wide deep-pipeline kernel to the 128 x 128 kernels instead, so both
  * code paths can be compared on one shape; returns the previous value.  Not part of the reference-facing surface. */
 int amdseg_debug_force_small_tile(int v);
@@ -205,6 +219,7 @@ typedef struct amdseg_bert_cfg {
                                        Backward only: 6 = phase 2 without the grouped weight-gradient GEMM, 4 = that GEMM
                                        alone (e.g. on a second stream, under the next layer's backward; the caller orders
                                        the streams and must not reuse ws before it has run). */
+    int32_t act;                    /* FFN activation: 0 = exact (erf) GELU "gelu", 1 = "gelu_new" (BigBird) */
 } amdseg_bert_cfg;
 
 typedef struct amdseg_bert_layer_params {   /* bf16 compute shadows (+ transposes for dgrad), fp32 vectors */

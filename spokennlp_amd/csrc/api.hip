@@ -144,6 +144,16 @@ int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb,
                                   amdseg_stream_t stream) {
     return amdseg_cast_transpose_batched_impl(n, W, Wb, Wt, N, K, S(stream));
 }
+int amdseg_attn_list_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
+                         const int* klist, const int* kcnt, int list_stride, amdseg_stream_t stream) {
+    return amdseg_attn_list_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, klist, kcnt, list_stride, S(stream));
+}
+int amdseg_attn_list_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                         float* delta_ws, void* dqkv, int B, int L, int heads, float scale, const int* klist, const int* kcnt,
+                         const int* qlist, const int* qcnt, int list_stride, amdseg_stream_t stream) {
+    return amdseg_attn_list_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, klist, kcnt, qlist, qcnt,
+                                     list_stride, S(stream));
+}
 int amdseg_debug_force_small_tile(int v) { return amdseg_set_force_small_tile(v); }
 int amdseg_rowdot_fwd(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
                       amdseg_stream_t stream) {
@@ -182,7 +192,7 @@ static int check_cfg(const amdseg_bert_cfg* c) {
     const long M = (long)c->B * c->L;
     if ((M % 128) || (c->H % 128) || (c->I % 128) || (c->L % 64)) return AMDSEG_ERR_SHAPE;
     if (c->window < 0 || c->nglobal < 0 || c->phase < 0 || (c->phase > 4 && c->phase != 6)) return AMDSEG_ERR_ARG;
-    if (c->nproj < 0 || c->nproj > 8 || c->mixer < 0 || c->mixer > 1) return AMDSEG_ERR_ARG;
+    if (c->nproj < 0 || c->nproj > 8 || c->mixer < 0 || c->mixer > 1 || c->act < 0 || c->act > 1) return AMDSEG_ERR_ARG;
     if (c->mixer == 1 && (c->dtype != AMDSEG_BF16 || c->phase == 0 || c->phase == 3 || c->phase > 2)) return AMDSEG_ERR_ARG;
     return AMDSEG_OK;
 }
@@ -214,7 +224,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         if (!PHASE2(c)) return AMDSEG_OK;
         RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->ctx, H, (const float*)p->wo, H, (float*)a->z1, H, M, H, H, 1, p->bo, s));
         RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, 0.f, 0, AMDSEG_F32, s));
-        RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->x1, H, (const float*)p->w1, H, (float*)a->h, I, M, I, H, 2, p->b1, s));
+        RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->x1, H, (const float*)p->w1, H, (float*)a->h, I, M, I, H, 2 | (c->act ? AMDSEG_EPI_ACT_TANH : 0), p->b1, s));
         RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->h, I, (const float*)p->w2, I, (float*)a->z2, H, M, H, I, 1, p->b2, s));
         RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, 0.f, 0, AMDSEG_F32, s));
         return AMDSEG_OK;
@@ -233,7 +243,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
                                   site_seed(c->seed, li, 1), c->dtype, s));
     // FFN
-    RET_IF(amdseg_gemm_nt_impl(a->x1, H, p->w1, H, a->h, I, M, I, H, AMDSEG_EPI_BIAS_GELU, p->b1, nullptr, 0, a->u, I, 0, s));
+    RET_IF(amdseg_gemm_nt_impl(a->x1, H, p->w1, H, a->h, I, M, I, H, AMDSEG_EPI_BIAS_GELU | (c->act ? AMDSEG_EPI_ACT_TANH : 0), p->b1, nullptr, 0, a->u, I, 0, s));
     RET_IF(amdseg_gemm_nt_impl(a->h, I, p->w2, I, a->z2, H, M, H, I, AMDSEG_EPI_BIAS, p->b2, nullptr, 0, nullptr, 0, 0, s));
     RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, c->p_hidden,
                                   site_seed(c->seed, li, 2), c->dtype, s));
@@ -256,7 +266,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, w->partials, g->ln2_g, g->ln2_b,
                               g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, c->dtype, s));
     // du = (d_out . W2) * gelu'(u)
-    RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD, nullptr, a->u, I, nullptr, 0, 0, s));
+    RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD | (c->act ? AMDSEG_EPI_ACT_TANH : 0), nullptr, a->u, I, nullptr, 0, 0, s));
     // dx1 = du . W1 + dz2
     RET_IF(amdseg_gemm_nt_impl(w->du, I, p->w1_t, I, w->dx1, H, M, H, I, AMDSEG_EPI_ADD_RES, nullptr, w->dz2, H, nullptr, 0, 0, s));
     RET_IF(amdseg_colsum_impl(w->du, I, w->partials, g->b1, M, I, acc, c->dtype, s));

@@ -60,6 +60,9 @@ struct AttnArgs {
     int B, L, heads, H3;    // H3 = 3*H row stride of qkv
     float scale, inv_keep; uint32_t thresh16; uint64_t seed;
     int window, nglobal;    // band attention (Longformer): one-sided window W (0 = full attention), leading global tokens G
+    // block-list attention (BigBird block-sparse): row (h, block) of klist / qlist holds kcnt / qcnt block indices to visit, in order
+    // and WITH multiplicity (a key block listed twice counts twice in the softmax, as in the reference's concatenated key matrices)
+    const int* klist; const int* kcnt; const int* qlist; const int* qcnt; int list_stride;
 };
 
 // Band ("sliding window + global") visibility, [hf] models/longformer/modeling_longformer.py:524-604 restated as a mask:
@@ -72,7 +75,7 @@ __device__ __forceinline__ bool band_masked(int q, int key, int W, int G) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int NW, bool BAND>
+template <int NW, bool BAND, bool LIST = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
@@ -108,8 +111,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
         c1 = min(c1, (q_hi + a.window) / CH);
         extra = (a.nglobal > 0 && c0 > 0) ? 1 : 0;
     }
-    const int nch = c1 - c0 + 1 + extra;
-#define CHUNK_OF(t) ((BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
+    int nch = c1 - c0 + 1 + extra;
+    const int* lst = nullptr;
+    if (LIST) { const int row = h * (a.L / CH) + qb; nch = a.kcnt[row]; lst = a.klist + (size_t)row * a.list_stride; }
+#define CHUNK_OF(t) (LIST ? lst[t] : (BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
     at_stage<NW>(kbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufK(0), w, l);
     at_stage<NW>(vbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufV(0), w, l);
     // the additive key mask of a chunk travels with its K/V tiles (a global load issued where it is consumed costs a full
@@ -250,7 +255,7 @@ __global__ void attn_delta_kernel(const bf16_t* ctx, const bf16_t* dctx, float* 
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-template <int NW, bool BAND>
+template <int NW, bool BAND, bool LIST = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
@@ -302,8 +307,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         c1 = min(c1, (q_hi + a.window) / CH);
         extra = (a.nglobal > 0 && c0 > 0) ? 1 : 0;
     }
-    const int nch = c1 - c0 + 1 + extra;
-#define CHUNK_OF(t) ((BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
+    int nch = c1 - c0 + 1 + extra;
+    const int* lst = nullptr;
+    if (LIST) { const int row = h * (a.L / CH) + qb; nch = a.kcnt[row]; lst = a.klist + (size_t)row * a.list_stride; }
+#define CHUNK_OF(t) (LIST ? lst[t] : (BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
     at_stage<NW>(kbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufK(0), w, l);
     at_stage<NW>(vbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufV(0), w, l);
     if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(0) * CH, bufM(0), l);      // key mask rides with the tiles
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <int NW, bool BAND>
+template <int NW, bool BAND, bool LIST = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768 + 1024];
 #define bufL(i) (smem + 32768 + (i) * 512)
@@ -441,21 +448,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         c0 = k_lo > a.window ? (k_lo - a.window) / CH : 0;
         c1 = min(c1, (k_hi + a.window) / CH);
     }
-    const int nch = c1 - c0 + 1;
-    at_stage<NW>(qbase + (size_t)c0 * CH * a.H3, a.H3, bufQ(0), w, l);
-    at_stage<NW>(obase + (size_t)c0 * CH * H, H, bufO(0), w, l);
+    int nch = c1 - c0 + 1;
+    const int* lst = nullptr;
+    if (LIST) { const int row = h * (a.L / CH) + kb; nch = a.qcnt[row]; lst = a.qlist + (size_t)row * a.list_stride; }
+#define QCHUNK_OF(t) (LIST ? lst[t] : c0 + (t))
+    at_stage<NW>(qbase + (size_t)QCHUNK_OF(0) * CH * a.H3, a.H3, bufQ(0), w, l);
+    at_stage<NW>(obase + (size_t)QCHUNK_OF(0) * CH * H, H, bufO(0), w, l);
     // LSE and delta of the chunk's 64 query rows ride with the Q / dO tiles (were 8 exposed global loads per chunk)
-    if (w == 0) at_stage_f32x64(a.lse + bh * a.L + (size_t)c0 * CH, bufL(0), l);
-    if (w == 1) at_stage_f32x64(a.delta + bh * a.L + (size_t)c0 * CH, bufL(0) + 256, l);
+    if (w == 0) at_stage_f32x64(a.lse + bh * a.L + (size_t)QCHUNK_OF(0) * CH, bufL(0), l);
+    if (w == 1) at_stage_f32x64(a.delta + bh * a.L + (size_t)QCHUNK_OF(0) * CH, bufL(0) + 256, l);
     for (int ch = 0; ch < nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = ch & 1;
         if (ch + 1 < nch) {
-            at_stage<NW>(qbase + (size_t)(c0 + ch + 1) * CH * a.H3, a.H3, bufQ(cur ^ 1), w, l);
-            at_stage<NW>(obase + (size_t)(c0 + ch + 1) * CH * H, H, bufO(cur ^ 1), w, l);
-            if (w == 0) at_stage_f32x64(a.lse + bh * a.L + (size_t)(c0 + ch + 1) * CH, bufL(cur ^ 1), l);
-            if (w == 1) at_stage_f32x64(a.delta + bh * a.L + (size_t)(c0 + ch + 1) * CH, bufL(cur ^ 1) + 256, l);
+            const int qn = QCHUNK_OF(ch + 1);
+            at_stage<NW>(qbase + (size_t)qn * CH * a.H3, a.H3, bufQ(cur ^ 1), w, l);
+            at_stage<NW>(obase + (size_t)qn * CH * H, H, bufO(cur ^ 1), w, l);
+            if (w == 0) at_stage_f32x64(a.lse + bh * a.L + (size_t)qn * CH, bufL(cur ^ 1), l);
+            if (w == 1) at_stage_f32x64(a.delta + bh * a.L + (size_t)qn * CH, bufL(cur ^ 1) + 256, l);
         }
         float4 lsc[4], dlc[4];
 #pragma unroll
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
         const char* tQ = bufQ(cur);
         const char* tO = bufO(cur);
-        const int q0 = (c0 + ch) * CH;
+        const int q0 = QCHUNK_OF(ch) * CH;
         bool edge = false;
         if (BAND) {
             const int wk_lo = kb * (NW * 16) + w * 16;
@@ -589,5 +600,48 @@ int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ct
         hipLaunchKernelGGL((attn_bwd_dq_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
     }
+    return amdseg_launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------------ block-list attention
+// BigBird block-sparse attention ([hf] models/big_bird/modeling_big_bird.py: bigbird_block_sparse_attention): query block i (64
+// rows) attends to an explicit list of 64-key blocks (global first/last blocks, the 3-block window, the per-head random blocks);
+// the reference concatenates those key blocks and takes ONE softmax over the concatenation, which is what streaming the listed
+// blocks through the online softmax computes -- including blocks that are listed more than once.  klist/kcnt: per (head, query
+// block); qlist/qcnt: the transposed lists per (head, key block) for dK/dV, with the same multiplicities.  No dropout on the
+// probabilities (the reference's block-sparse path has none).
+static int attn_list_check(int L, const int* klist, const int* kcnt, int stride) {
+    if (!klist || !kcnt || stride <= 0) return AMDSEG_ERR_ARG;
+    if (L % CH) return AMDSEG_ERR_SHAPE;
+    return AMDSEG_OK;
+}
+
+int amdseg_attn_list_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
+                              const int* klist, const int* kcnt, int list_stride, hipStream_t s) {
+    if (!qkv || !mask_bias || !ctx) return AMDSEG_ERR_ARG;
+    AttnArgs a = {};
+    int rc = attn_fill(a, B, L, heads, scale, 0.f, 0, 0, 0);
+    if (rc) return rc;
+    if ((rc = attn_list_check(L, klist, kcnt, list_stride))) return rc;
+    a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
+    a.klist = klist; a.kcnt = kcnt; a.list_stride = list_stride;
+    hipLaunchKernelGGL((attn_fwd_kernel<4, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    return amdseg_launch_status();
+}
+
+int amdseg_attn_list_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                              float* delta, void* dqkv, int B, int L, int heads, float scale, const int* klist, const int* kcnt,
+                              const int* qlist, const int* qcnt, int list_stride, hipStream_t s) {
+    if (!qkv || !mask_bias || !ctx || !dctx || !lse || !delta || !dqkv) return AMDSEG_ERR_ARG;
+    AttnArgs a = {};
+    int rc = attn_fill(a, B, L, heads, scale, 0.f, 0, 0, 0);
+    if (rc) return rc;
+    if ((rc = attn_list_check(L, klist, kcnt, list_stride)) || (rc = attn_list_check(L, qlist, qcnt, list_stride))) return rc;
+    a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = (float*)lse;
+    a.dctx = (const bf16_t*)dctx; a.delta = delta; a.dqkv = (bf16_t*)dqkv;
+    a.klist = klist; a.kcnt = kcnt; a.qlist = qlist; a.qcnt = qcnt; a.list_stride = list_stride;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<4, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }

@@ -108,6 +108,21 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     const float er = erf_as_from_e(fabsf(x) * 0.70710678118654752f, e);
     return 0.5f * (1.0f + copysignf(er, x)) + x * 0.39894228040143268f * e;
 }
+// "gelu_new" (tanh approximation; [hf] activations.py NewGELUActivation -- BigBird's default hidden_act) and its derivative
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u));
+    return 0.5f * x * (1.0f + t);
+}
+__device__ __forceinline__ float gelu_tanh_grad_fast(float x) {
+    const float x2 = x * x;
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u));
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 0.134145f * x2);
+}
+// act: 0 = exact (erf) GELU, 1 = gelu_new; wave-uniform
+__device__ __forceinline__ float gelu_act(float x, int act) { return act ? gelu_tanh_fast(x) : gelu_fast(x); }
+__device__ __forceinline__ float gelu_grad_act(float x, int act) { return act ? gelu_tanh_grad_fast(x) : gelu_grad_fast(x); }
 
 // Stateless counter-based dropout RNG: keep(element idx) iff hash(seed, idx) >= threshold.
 // The same (seed, idx) is re-evaluated in backward, so no mask is stored.

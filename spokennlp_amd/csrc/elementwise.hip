@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
                                                            const float* word, const float* pos, const float* type,
                                                            const float* gamma, const float* beta, T* z, T* out, float* mean,
                                                            float* rstd, int M, int L, int H, int vocab, int type_vocab,
-                                                           int npos, float eps, uint32_t thresh, float inv_keep, uint64_t seed) {
+                                                           int npos, float eps, uint32_t thresh, float inv_keep, uint64_t seed,
+                                                           int pre_ln_dropout) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int m = blockIdx.x * ROWS_PER_BLOCK + w;
     if (m >= M) return;
@@ -80,6 +81,12 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
             ld8<float>(type + (size_t)tt * H + ch * 8, d);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[c][e] = (a[e] + d[e]) + b[e];     // (word + type) + position, as the reference
+            // BigBird: LayerNorm(dropout(sum)) ([hf] models/big_bird/modeling_big_bird.py BigBirdEmbeddings.forward); z is then the
+            // dropped sum (the LayerNorm input), which is what ln_bwd needs
+            if (pre_ln_dropout && thresh) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = drop_keep(seed, (uint64_t)m * H + ch * 8 + e, thresh) ? v[c][e] * inv_keep : 0.f;
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float y = (v[c][e] - mu) * rs * gg[e] + bb[e];
-                if (thresh) y = drop_keep(seed, (uint64_t)m * H + ch * 8 + e, thresh) ? y * inv_keep : 0.f;
+                if (thresh && !pre_ln_dropout) y = drop_keep(seed, (uint64_t)m * H + ch * 8 + e, thresh) ? y * inv_keep : 0.f;
                 v[c][e] = y;
             }
         }
@@ -556,14 +563,15 @@ int amdseg_embed_ln_fwd_impl(const int64_t* ids, const int64_t* type_ids, const 
                              const int64_t* pos_ids, float eps, float p, uint64_t seed, int dtype, hipStream_t s) {
     if (!ids || !word || !pos || !type || !gamma || !beta || !out) return AMDSEG_ERR_ARG;
     if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH || L <= 0) return AMDSEG_ERR_SHAPE;
-    uint32_t th; float ik; drop_params(p, th, ik);
+    const int pre = p < 0.f ? 1 : 0;                        // p < 0: dropout(|p|) BEFORE the LayerNorm (BigBird embeddings)
+    uint32_t th; float ik; drop_params(pre ? -p : p, th, ik);
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     if (dtype == AMDSEG_BF16)
         ROWK(embed_ln_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, ids, type_ids, pos_ids, word, pos, type, gamma, beta,
-                           (bf16_t*)z, (bf16_t*)out, mean, rstd, M, L, H, vocab, type_vocab, npos, eps, th, ik, seed);
+                           (bf16_t*)z, (bf16_t*)out, mean, rstd, M, L, H, vocab, type_vocab, npos, eps, th, ik, seed, pre);
     else
         ROWK(embed_ln_fwd_kernel, float, H, grid, dim3(256), 0, s, ids, type_ids, pos_ids, word, pos, type, gamma, beta,
-                           (float*)z, (float*)out, mean, rstd, M, L, H, vocab, type_vocab, npos, eps, th, ik, seed);
+                           (float*)z, (float*)out, mean, rstd, M, L, H, vocab, type_vocab, npos, eps, th, ik, seed, pre);
     return amdseg_launch_status();
 }
 

@@ -207,12 +207,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
                     uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
                     if (a.C2) *reinterpret_cast<uint2*>(stg2 + soff) = pk;          // pre-activation u, kept for backward
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_act(v[e], a.act);
                 } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
                     const float r0 = __uint_as_float(rr[j][q].x << 16), r1 = __uint_as_float(rr[j][q].x & 0xffff0000u);
                     const float r2 = __uint_as_float(rr[j][q].y << 16), r3 = __uint_as_float(rr[j][q].y & 0xffff0000u);
                     if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
-                    else { v[0] *= gelu_grad_fast(r0); v[1] *= gelu_grad_fast(r1); v[2] *= gelu_grad_fast(r2); v[3] *= gelu_grad_fast(r3); }
+                    else { v[0] *= gelu_grad_act(r0, a.act); v[1] *= gelu_grad_act(r1, a.act); v[2] *= gelu_grad_act(r2, a.act); v[3] *= gelu_grad_act(r3, a.act); }
                 }
                 if (STAGED) {
                     uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
@@ -357,13 +357,13 @@ __device__ __forceinline__ void pp_epi_store(const GemmNTArgs& a, const PpEpiReg
                     uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
                     *reinterpret_cast<uint2*>(a.C2 + gm * a.ldc2 + gn) = pk;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = gelu_fast(v[k]);
+                    for (int k = 0; k < 4; ++k) v[k] = gelu_act(v[k], a.act);
                 } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
                     const uint2 r = e.rr[i][j][q];
                     const float r0 = __uint_as_float(r.x << 16), r1 = __uint_as_float(r.x & 0xffff0000u);
                     const float r2 = __uint_as_float(r.y << 16), r3 = __uint_as_float(r.y & 0xffff0000u);
                     if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
-                    else { v[0] *= gelu_grad_fast(r0); v[1] *= gelu_grad_fast(r1); v[2] *= gelu_grad_fast(r2); v[3] *= gelu_grad_fast(r3); }
+                    else { v[0] *= gelu_grad_act(r0, a.act); v[1] *= gelu_grad_act(r1, a.act); v[2] *= gelu_grad_act(r2, a.act); v[3] *= gelu_grad_act(r3, a.act); }
                 }
                 OutT* dst = reinterpret_cast<OutT*>(a.C) + gm * a.ldc + gn;
                 if (sizeof(OutT) == 2) {
@@ -611,12 +611,14 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
                         int epi, const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32,
                         hipStream_t stream) {
     if (!A || !B || !C) return AMDSEG_ERR_ARG;
+    const int act = (epi >> 8) & 1;                         // AMDSEG_EPI_ACT_TANH: gelu_new instead of the erf GELU
+    epi &= 0xff;
     const bool big = (M % PP_BM) == 0 && (N % PP_BN) == 0, small = (M % BM) == 0 && (N % BN) == 0;
     if (M <= 0 || N <= 0 || K <= 0 || !(big || small) || (K % BK)) return AMDSEG_ERR_SHAPE;
     if ((lda % 8) || (ldb % 8) || (ldc % 8)) return AMDSEG_ERR_SHAPE;
     GemmNTArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = bias; a.R = (const bf16_t*)R; a.C2 = (bf16_t*)C2;
-    a.dbg = nullptr;
+    a.dbg = nullptr; a.act = act;
 #if defined(AMDSEG_PHASE_TIMERS) || defined(AMDSEG_CLOCK_PROBE)
     extern unsigned long long* g_amdseg_dbg;
     a.dbg = g_amdseg_dbg;

@@ -140,12 +140,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                 if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) { v[0] += bv[nf].x; v[1] += bv[nf].y; v[2] += bv[nf].z; v[3] += bv[nf].w; }
                 if (EPI == EPI_BIAS_GELU && pass == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_act(v[e], a.act);
                 } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
                     const float r0 = __uint_as_float(rr[nf].x << 16), r1 = __uint_as_float(rr[nf].x & 0xffff0000u);
                     const float r2 = __uint_as_float(rr[nf].y << 16), r3 = __uint_as_float(rr[nf].y & 0xffff0000u);
                     if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
-                    else { v[0] *= gelu_grad_fast(r0); v[1] *= gelu_grad_fast(r1); v[2] *= gelu_grad_fast(r2); v[3] *= gelu_grad_fast(r3); }
+                    else { v[0] *= gelu_grad_act(r0, a.act); v[1] *= gelu_grad_act(r1, a.act); v[2] *= gelu_grad_act(r2, a.act); v[3] *= gelu_grad_act(r3, a.act); }
                 }
                 if (STAGED) {
                     uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);

@@ -11,6 +11,7 @@ struct GemmNTArgs {
     int lda, ldb, ldc, ldr, ldc2;
     int M, N, K;
     int tiles_m, tiles_n;
+    int act;            // GELU flavour of EPI_BIAS_GELU / EPI_GELU_BWD: 0 erf, 1 tanh ("gelu_new")
 };
 
 // bijective XCD-aware remap: hardware places workgroup b on XCD b % 8; give each XCD a contiguous tile range

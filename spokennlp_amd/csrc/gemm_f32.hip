@@ -14,6 +14,7 @@ enum { F32_EPI_NONE = 0, F32_EPI_BIAS = 1, F32_EPI_BIAS_GELU = 2 };
 struct GemmF32Args {
     const float* A; const float* B; float* C; const float* bias;
     int lda, ldb, ldc, M, N, K, tiles_m, tiles_n;
+    int act;
 };
 
 __device__ __forceinline__ void f32_stage(const float* __restrict__ G, int ld, int row0, int k0, char* lds_tile, int w, int l) {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_kernel(GemmF32Args a) {
             for (int r = 0; r < 16; ++r) {
                 const int m = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
                 float v = acc[i][j][r] + bv;
-                if (EPI == F32_EPI_BIAS_GELU) v = gelu_erf(v);
+                if (EPI == F32_EPI_BIAS_GELU) v = a.act ? 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v))) : gelu_erf(v);
                 sm[m * 128 + n] = v;
             }
         }
@@ -106,10 +107,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt_kernel(GemmF32Args a) {
 int amdseg_gemm_f32_nt_impl(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                             int epi, const float* bias, hipStream_t stream) {
     if (!A || !B || !C) return AMDSEG_ERR_ARG;
+    const int act = (epi >> 8) & 1;
+    epi &= 0xff;
     if (M <= 0 || N <= 0 || K <= 0 || (M % 128) || (N % 128) || (K % 32)) return AMDSEG_ERR_SHAPE;
     if ((lda % 4) || (ldb % 4) || (ldc % 4)) return AMDSEG_ERR_SHAPE;
     if (epi != F32_EPI_NONE && !bias) return AMDSEG_ERR_ARG;
-    GemmF32Args a = {A, B, C, bias, lda, ldb, ldc, M, N, K, M / 128, N / 128};
+    GemmF32Args a = {A, B, C, bias, lda, ldb, ldc, M, N, K, M / 128, N / 128, act};
     dim3 grid(a.tiles_m * a.tiles_n);
     switch (epi) {
         case F32_EPI_NONE: hipLaunchKernelGGL(gemm_f32_nt_kernel<F32_EPI_NONE>, grid, dim3(256), 0, stream, a); break;

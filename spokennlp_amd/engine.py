@@ -95,6 +95,14 @@ class BertEncoderEngine:
         self.H, self.I, self.heads = config.hidden_size, config.intermediate_size, config.num_attention_heads
         if self.H != self.heads * 64:
             raise L.AmdsegError("libamdseg attention kernels need head_dim == 64")
+        act = getattr(config, "hidden_act", "gelu")
+        if act == "gelu":
+            self.act = 0                                    # exact erf GELU ([hf] activations.py GELUActivation)
+        elif act in ("gelu_new", "gelu_pytorch_tanh", "gelu_fast"):
+            self.act = 1                                    # the tanh form (three spellings of one formula)
+        else:
+            raise L.AmdsegError(f"hidden_act={act!r} is not implemented in the HIP epilogues (gelu / gelu_new only)")
+        self.emb_dropout_pre_ln = False                     # BigBird: LayerNorm(dropout(sum)) instead of dropout(LayerNorm(sum))
         self.prefix = bert_attr + "."
         self.layer_order = layer_order or LAYER_ORDER
         self.nproj = nproj                                  # matrices fused into the input projection (q|k|v; PoNet: 5)
@@ -250,7 +258,7 @@ class BertEncoderEngine:
     def _cfg_struct(self, B, Lseq, p_hidden, p_attn, seed, accumulate):
         return L.BertCfg(B=B, L=Lseq, H=self.H, heads=self.heads, I=self.I, ln_eps=float(self.cfg.layer_norm_eps),
                          p_hidden=p_hidden, p_attn=p_attn, seed=seed, accumulate_grads=1 if accumulate else 0, dtype=L.BF16,
-                         window=0, nglobal=0, nproj=0, mixer=0, phase=0)
+                         window=0, nglobal=0, nproj=0, mixer=0, phase=0, act=self.act)
 
     # ------------------------------------------------------------------------------------------------ forward / backward
     def _emb(self, name):
@@ -284,7 +292,8 @@ class BertEncoderEngine:
         rc = lib.amdseg_embed_ln_fwd(ids.data_ptr(), tts.data_ptr(), None if pos is None else pos.data_ptr(), we.data_ptr(), pe.data_ptr(), te.data_ptr(),
                                      self._emb("LayerNorm.weight").data_ptr(), self._emb("LayerNorm.bias").data_ptr(),
                                      A["emb_z"].data_ptr(), A["x"][0].data_ptr(), A["emb_mean"].data_ptr(), A["emb_rstd"].data_ptr(),
-                                     M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], eps, p_h, seed * 1000003 + 17, dt, s)
+                                     M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], eps,
+                                     -p_h if self.emb_dropout_pre_ln else p_h, seed * 1000003 + 17, dt, s)
         L.check(rc, "amdseg_embed_ln_fwd")
         mb = A["mask_bias"].data_ptr()
         saved = []
@@ -360,8 +369,8 @@ class BertEncoderEngine:
                         self.buckets.reduce_layer(i)
                 else:
                     self.buckets.reduce_layer(i)
-        # embeddings: out = dropout(LN(z)); grads of LN affine + the three tables
-        if ctx["p_h"] > 0:
+        # embeddings: out = dropout(LN(z)) (BigBird: LN(dropout(z))); grads of LN affine + the three tables
+        if ctx["p_h"] > 0 and not self.emb_dropout_pre_ln:
             rc = lib.amdseg_dropout(dy.data_ptr(), other.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, L.BF16, L.BF16, s)
             L.check(rc, "amdseg_dropout(emb bwd)")
             dy, other = other, dy
@@ -371,6 +380,10 @@ class BertEncoderEngine:
                                g("LayerNorm.weight").data_ptr(), g("LayerNorm.bias").data_ptr(), None, M, self.H, 0.0, 0,
                                1 if accumulate else 0, L.BF16, s)
         L.check(rc, "amdseg_ln_bwd(emb)")
+        if ctx["p_h"] > 0 and self.emb_dropout_pre_ln:
+            rc = lib.amdseg_dropout(other.data_ptr(), dy.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, L.BF16, L.BF16, s)
+            L.check(rc, "amdseg_dropout(emb bwd, pre-LN)")
+            dy, other = other, dy
         we, pe, te = g("word_embeddings.weight"), g("position_embeddings.weight"), g("token_type_embeddings.weight")
         if not accumulate:
             we.zero_(); pe.zero_(); te.zero_()

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("AMDSEG_LIB") or os.path.join(_HERE, "libamdseg.so")
 
 BF16, F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
+EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
 ABI_VERSION = 1
 
 vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
@@ -20,7 +21,7 @@ class BertCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("heads", C.c_int32), ("I", C.c_int32),
                 ("ln_eps", f32), ("p_hidden", f32), ("p_attn", f32), ("seed", u64),
                 ("accumulate_grads", C.c_int32), ("dtype", C.c_int32), ("window", C.c_int32), ("nglobal", C.c_int32),
-                ("nproj", C.c_int32), ("mixer", C.c_int32), ("phase", C.c_int32)]
+                ("nproj", C.c_int32), ("mixer", C.c_int32), ("phase", C.c_int32), ("act", C.c_int32)]
 
 
 class LayerParams(C.Structure):
@@ -74,6 +75,8 @@ _PROTOS = {
     "amdseg_cast": [vp, vp, sz, i32, i32, vp],
     "amdseg_cast_transpose": [vp, vp, vp, i32, i32, vp],
     "amdseg_cast_transpose_batched": [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp],
+    "amdseg_attn_list_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, i32, vp],
+    "amdseg_attn_list_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp],
     "amdseg_debug_force_small_tile": [i32],
     "amdseg_rowdot_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "amdseg_rowdot_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],

@@ -38,13 +38,13 @@ def gemm_nt(A, B, epilogue=EPI_NONE, bias=None, R=None, out=None, out2=None, out
     N = B.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
-    if epilogue == EPI_BIAS_GELU and out2 is None:
+    if (epilogue & 0xff) == EPI_BIAS_GELU and out2 is None:
         out2 = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
     rc = L.load().amdseg_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, epilogue,
                                  _p(bias), _p(R), 0 if R is None else R.stride(0), _p(out2),
                                  0 if out2 is None else out2.stride(0), 1 if out.dtype == torch.float32 else 0, _s())
     L.check(rc, "amdseg_gemm_nt")
-    return (out, out2) if epilogue == EPI_BIAS_GELU else out
+    return (out, out2) if (epilogue & 0xff) == EPI_BIAS_GELU else out
 
 
 def gemm_tn_grouped(As, Bs, Cs, accumulate=False):
@@ -79,6 +79,29 @@ def attn_bwd(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, p=0.0, seed=0, scal
     rc = L.load().amdseg_attn_bwd(_p(qkv), _p(mask_bias), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, Lseq, heads,
                                   scale, p, seed, _s())
     L.check(rc, "amdseg_attn_bwd")
+    return dqkv
+
+
+def attn_list_fwd(qkv, mask_bias, B, Lseq, heads, klist, kcnt, stride, ctx=None, lse=None, scale=0.125):
+    """BigBird block-list attention (amdseg_attn_list_fwd); klist/kcnt: int32 device tensors [heads, L/64, stride] / [heads, L/64]"""
+    H = heads * 64
+    if ctx is None:
+        ctx = torch.empty((B * Lseq, H), dtype=torch.bfloat16, device=qkv.device)
+    if lse is None:
+        lse = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device)
+    rc = L.load().amdseg_attn_list_fwd(_p(qkv), _p(mask_bias), _p(ctx), _p(lse), B, Lseq, heads, scale, _p(klist), _p(kcnt), stride, _s())
+    L.check(rc, "amdseg_attn_list_fwd")
+    return ctx, lse
+
+
+def attn_list_bwd(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, klist, kcnt, qlist, qcnt, stride, dqkv=None, delta=None, scale=0.125):
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    if delta is None:
+        delta = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device)
+    rc = L.load().amdseg_attn_list_bwd(_p(qkv), _p(mask_bias), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, Lseq, heads, scale,
+                                       _p(klist), _p(kcnt), _p(qlist), _p(qcnt), stride, _s())
+    L.check(rc, "amdseg_attn_list_bwd")
     return dqkv
 
 

@@ -194,3 +194,82 @@ def test_electra_train_grads_match_reference():
         if k.startswith("train_full.grad."):
             n = k[len("train_full.grad."):]
             assert np.abs(sd[n].grad.numpy() - z[k]).max() < 5e-5, n
+
+
+# ------------------------------------------------------------------------------------------------ BigBird (f-3)
+from oracle import bigbird_ts_oracle as BO  # noqa: E402
+from spokennlp_amd import bigbird_plan  # noqa: E402
+
+
+def bb_case(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    batch = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in.")}
+    arch = {}
+    for k, v in zip(z["arch_keys"].tolist(), z["arch_vals"].tolist()):
+        try:
+            arch[k] = int(v)
+        except ValueError:
+            arch[k] = v
+    return z, sd, batch, arch
+
+
+@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768", "bb_tiny_L128"])
+@pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
+def test_bigbird_eval_matches_reference(case, variant):
+    """block-sparse attention (eval: the random blocks are block 0, counted 1 + 3 times) for L = 1024 / 768, the full-attention
+    fallback for L = 128; gelu_new; BigBird embeddings"""
+    z, sd, batch, arch = bb_case(case)
+    cfg = O.make_cfg(num_labels=2, hidden_act="gelu_new", **arch, **flags_of(z, variant))
+    random.seed(int(z[f"{variant}.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos, hs = O.model_forward(sd, cfg, batch, return_hidden=True, encode=BO.make_encode(bigbird_plan.rand_blocks, False))
+    assert abs(loss.item() - float(z[f"{variant}.loss"])) < 3e-5
+    assert np.abs(logits.numpy() - z[f"{variant}.logits"]).max() < 3e-5
+    assert np.abs(cos.numpy() - z[f"{variant}.cos"]).max() < 3e-6
+    if variant == "plain_eval":
+        last = len(hs) - 1
+        assert np.abs(hs[last].numpy() - z[f"plain_eval.hidden{last}"]).max() < 3e-5
+
+
+@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768", "bb_tiny_L128"])
+def test_bigbird_train_grads_match_reference(case):
+    """training mode: the reference's numpy-seeded random blocks (per layer, per head) -- both plan procedures"""
+    z, sd, batch, arch = bb_case(case)
+    cfg = O.make_cfg(num_labels=2, hidden_act="gelu_new", **arch, **flags_of(z, "train_full"))
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    random.seed(int(z["train_full.random_seed"]))
+    loss, _, _ = O.model_forward(sd, cfg, batch, encode=BO.make_encode(bigbird_plan.rand_blocks, True))
+    loss.backward()
+    assert abs(loss.item() - float(z["train_full.loss"])) < 3e-5
+    n_checked = 0
+    for k in z.files:
+        if k.startswith("train_full.grad."):
+            n = k[len("train_full.grad."):]
+            g = sd[n].grad
+            g = torch.zeros_like(sd[n]) if g is None else g
+            assert np.abs(g.numpy() - z[k]).max() < 5e-5, n
+            n_checked += 1
+    assert n_checked > 30
+
+
+def test_bigbird_plan_tables():
+    """key lists and their transposes carry the same (query block, key block) pairs with the same multiplicities"""
+    for train in (False, True):
+        t = bigbird_plan.build(1024, 2, 3, seed=1, training=train, max_seqlen=1024)
+        nb = 16
+        for h in range(2):
+            pairs_k = sorted((i, int(t["klist"][h, i, j])) for i in range(nb) for j in range(int(t["kcnt"][h, i])))
+            pairs_q = sorted((int(t["qlist"][h, k, j]), k) for k in range(nb) for j in range(int(t["qcnt"][h, k])))
+            assert pairs_k == pairs_q
+            assert int(t["kcnt"][h, 0]) == nb and int(t["kcnt"][h, 5]) == 8 and int(t["kcnt"][h, 1]) == 7
+        if not train:
+            assert (t["rand"] == 0).all()
+        else:
+            r = t["rand"]
+            assert r.shape == (2, nb - 2, 3) and (r >= 1).all() and (r < nb - 1).all()      # never a global block
+    # the plan procedure for lengths outside {1024, 3072, 4096} keeps random blocks out of the row's own window
+    r = bigbird_plan.rand_blocks(768, 2, 3, seed=0, training=True, max_seqlen=1024)
+    for h in range(2):
+        for i in range(2, 12 - 2):
+            assert not set(r[h, i - 1].tolist()) & {i - 1, i, i + 1}

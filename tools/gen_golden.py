@@ -25,8 +25,9 @@ from transformers import BertConfig  # noqa: E402
 import models.bert_for_ts as ref_bt  # noqa: E402
 import models.longformer_for_ts as ref_lf  # noqa: E402
 import models.electra_for_ts as ref_el  # noqa: E402
+import models.bigbird_for_ts as ref_bb  # noqa: E402
 import models.modules.loss_calculator as ref_lc  # noqa: E402
-from transformers import LongformerConfig, ElectraConfig  # noqa: E402
+from transformers import LongformerConfig, ElectraConfig, BigBirdConfig  # noqa: E402
 from spokennlp_amd import data  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -47,6 +48,7 @@ ref_bt.torch = TorchProxy()
 ref_lc.torch = TorchProxy()
 ref_lf.torch = TorchProxy()
 ref_el.torch = TorchProxy()
+ref_bb.torch = TorchProxy()
 
 FULL = dict(do_da_ts=True, do_cssl=True, do_tssp=True, ts_loss_weight=1.0, ts_score_predictor="lt", ts_score_predictor_cos_temp=1,
             focal_loss_gamma=0.0, weight_label_zero=0.5, cl_loss_weight=0.5, cl_temp=0.1, cl_anchor_level="eop_list",
@@ -57,7 +59,7 @@ PLAIN = dict(do_da_ts=False, do_cssl=False, do_tssp=False, ts_loss_weight=1.0, t
 
 
 def make_model(arch, flags, seed, kind="bert"):
-    C = {"bert": BertConfig, "longformer": LongformerConfig, "electra": ElectraConfig}[kind]
+    C = {"bert": BertConfig, "longformer": LongformerConfig, "electra": ElectraConfig, "bigbird": BigBirdConfig}[kind]
     cfg = C(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **arch)
     for k, v in flags.items():
         setattr(cfg, k, v)
@@ -70,6 +72,8 @@ def make_model(arch, flags, seed, kind="bert"):
         # raises AttributeError as shipped; the harness aliases the attribute (not registered as a sub-module, so the
         # state-dict names stay `electra.*`) to obtain the values the code evidently intends
         object.__setattr__(m, "bert", m.electra)
+    elif kind == "bigbird":
+        m = ref_bb.BigBirdWithDAForSentenceLabelingTopicSegmentation(cfg)
     else:
         m = ref_lf.LongformerWithDAForSentenceLabelingTopicSegmentation(cfg)
     with torch.no_grad():       # O(1) logits so that parity is meaningful
@@ -84,8 +88,12 @@ def make_model(arch, flags, seed, kind="bert"):
 
 
 def run_case(name, arch, L, B, seed, variants, kind="bert"):
-    docs = data.synth_docs(8, seed=seed + 11, vocab=arch["vocab_size"], mean_sents=14, sd_sents=5, mean_boundaries=3,
-                           mu_tok=1.4 + 0.2 * (L > 64), sigma_tok=0.4)
+    if L >= 512:                    # long documents so that the windows are mostly full (one of them ends in padding)
+        docs = data.synth_docs(8, seed=seed + 11, vocab=arch["vocab_size"], mean_sents=L // 9, sd_sents=L // 40, mean_boundaries=6,
+                               mu_tok=1.9, sigma_tok=0.4)
+    else:
+        docs = data.synth_docs(8, seed=seed + 11, vocab=arch["vocab_size"], mean_sents=14, sd_sents=5, mean_boundaries=3,
+                               mu_tok=1.4 + 0.2 * (L > 64), sigma_tok=0.4)
     batch = data.batches_from_docs(docs, L, B, seed=seed)[0]
     if kind == "longformer":        # RoBERTa convention: pad id 1 (position ids depend on it); no real token has id 1
         batch["input_ids"] = torch.where(batch["attention_mask"] == 0, torch.full_like(batch["input_ids"], arch["pad_token_id"]),
@@ -115,7 +123,8 @@ def run_case(name, arch, L, B, seed, variants, kind="bert"):
             out[f"{vname}.loss"] = loss.numpy(); out[f"{vname}.logits"] = logits.numpy(); out[f"{vname}.cos"] = cos.numpy()
             if len(res) > 3 and vname == "plain_eval":
                 for i, h in enumerate(res[3]):
-                    out[f"{vname}.hidden{i}"] = h.numpy()
+                    if L < 512 or i == len(res[3]) - 1:          # long cases: final hidden state only (fixture size)
+                        out[f"{vname}.hidden{i}"] = h.numpy()
         else:
             m.train()
             loss, logits, cos = m(**batch)[:3]
@@ -127,7 +136,7 @@ def run_case(name, arch, L, B, seed, variants, kind="bert"):
                     gn[n] = -1.0
                     continue
                 gn[n] = float(p.grad.norm())
-                if vname.endswith("full"):
+                if vname.endswith("full") and (L < 512 or "embeddings" not in n):
                     out[f"{vname}.grad.{n}"] = p.grad.numpy().copy()
             out[f"{vname}.gradnorm_names"] = np.array(list(gn.keys()))
             out[f"{vname}.gradnorm_vals"] = np.array(list(gn.values()), dtype=np.float64)
@@ -159,7 +168,23 @@ def main():
               max_position_embeddings=130, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2, layer_norm_eps=1e-5)
     run_case("lf_tiny_L64_w8", dict(lf, attention_window=[16, 16]), 64, 2, 2, variants[:3], kind="longformer")
     run_case("lf_tiny_L128_w16", dict(lf, attention_window=[32, 32]), 128, 2, 3, variants[:3], kind="longformer")
+    if "--bigbird" in sys.argv or "--all" in sys.argv:
+        main_bigbird(variants)
+
+
+def main_bigbird(variants):
+    """BigBird ([hf] BigBirdModel under bigbird_for_ts.py:27): block_size 64, 3 random blocks.  L = 1024 takes the reference's
+    "old plan" random-block path, L = 768 the `_get_rand_attn_plan` path, L = 128 falls back to full attention."""
+    bb = dict(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+              max_position_embeddings=1024, type_vocab_size=2, block_size=64, num_random_blocks=3, attention_type="block_sparse",
+              pad_token_id=0, bos_token_id=1, eos_token_id=2, sep_token_id=3)
+    run_case("bb_tiny_L1024", bb, 1024, 1, 6, variants[:3], kind="bigbird")
+    run_case("bb_tiny_L768", bb, 768, 1, 7, variants[:3], kind="bigbird")
+    run_case("bb_tiny_L128", bb, 128, 2, 8, variants[:3], kind="bigbird")
 
 
 if __name__ == "__main__":
-    main()
+    if "--bigbird-only" in sys.argv:
+        main_bigbird([("plain_eval", PLAIN, "eval", 0, {}), ("full_eval", FULL, "eval", 5, {}), ("train_full", FULL, "train", 7, {})])
+    else:
+        main()
