@@ -66,16 +66,18 @@ def encoder_layer(sd, cfg, x, is_global, is_pad, i, prefix=PFX):
     pr = pr.masked_fill(is_pad[:, None, :, None], 0.0)               # rows of padded queries are zeroed (:579)
     ctx = (pr @ v).transpose(1, 2).reshape(B, L, H)
     # global rows: full attention with the *_global projections; every example has the same number of global tokens here
+    # (none at all when LongformerModel is called with global_attention_mask=None: the mmvts text encoder)
     ng = int(is_global[0].sum())
-    gidx = is_global.nonzero(as_tuple=False)                          # (B*ng, 2)
-    xg = x[gidx[:, 0], gidx[:, 1]].view(B, ng, H)
-    qg = heads(lin(xg, "attention.self.query_global") / (d ** 0.5))
-    kg = heads(lin(x, "attention.self.key_global"))
-    vg = heads(lin(x, "attention.self.value_global"))
-    sg = (qg @ kg.transpose(-1, -2)).masked_fill(is_pad[:, None, None, :], torch.finfo(x.dtype).min)
-    pg = torch.softmax(sg.float(), dim=-1)
-    og = (pg @ vg).transpose(1, 2).reshape(B * ng, H)
-    ctx = ctx.index_put((gidx[:, 0], gidx[:, 1]), og)
+    if ng > 0:
+        gidx = is_global.nonzero(as_tuple=False)                          # (B*ng, 2)
+        xg = x[gidx[:, 0], gidx[:, 1]].view(B, ng, H)
+        qg = heads(lin(xg, "attention.self.query_global") / (d ** 0.5))
+        kg = heads(lin(x, "attention.self.key_global"))
+        vg = heads(lin(x, "attention.self.value_global"))
+        sg = (qg @ kg.transpose(-1, -2)).masked_fill(is_pad[:, None, None, :], torch.finfo(x.dtype).min)
+        pg = torch.softmax(sg.float(), dim=-1)
+        og = (pg @ vg).transpose(1, 2).reshape(B * ng, H)
+        ctx = ctx.index_put((gidx[:, 0], gidx[:, 1]), og)
     x1 = layer_norm(lin(ctx, "attention.output.dense") + x, sd[p + "attention.output.LayerNorm.weight"],
                     sd[p + "attention.output.LayerNorm.bias"], cfg.layer_norm_eps)
     h = gelu_erf(lin(x1, "intermediate.dense"))

@@ -29,6 +29,9 @@ class LongformerEncoderEngine(BertEncoderEngine):
             raise L.AmdsegError("attention_window must be >= 2")
         self.pad_id = int(config.pad_token_id)
         self.scale = 1.0 / math.sqrt(64.0)
+        # False: no global token at all -- LongformerModel called with global_attention_mask=None (the mmvts text encoder,
+        # mmvts/src/models/text_encoder/text_encoder.py:73-85 as driven by multi_modal_for_ts.py:173-176): pure band attention
+        self.cls_global = True
 
     # ---- parameters of the global projections (fp32 masters; tiny algebra runs in fp32)
     def _gp(self, flat, i, which, kind):
@@ -44,6 +47,9 @@ class LongformerEncoderEngine(BertEncoderEngine):
     # ---- forward
     def _layer_forward(self, lib, cfg, lp, A, i, mb, s, train):
         B, Lseq, H, heads = cfg.B, cfg.L, self.H, self.heads
+        if not self.cls_global:
+            cfg.window, cfg.nglobal, cfg.phase = self.windows[i], 0, 0
+            return super()._layer_forward(lib, cfg, lp, A, i, mb, s, train)
         cfg.window, cfg.nglobal = self.windows[i], 1
         acts = A["acts_struct"][i]
         cfg.phase = 1
@@ -72,6 +78,9 @@ class LongformerEncoderEngine(BertEncoderEngine):
     # ---- backward
     def _layer_backward(self, lib, cfg, A, i, mb, dy, other, s, saved):
         B, Lseq, H, heads = cfg.B, cfg.L, self.H, self.heads
+        if not self.cls_global:
+            cfg.window, cfg.nglobal, cfg.phase = self.windows[i], 0, 0
+            return super()._layer_backward(lib, cfg, A, i, mb, dy, other, s, saved)
         cfg.window, cfg.nglobal = self.windows[i], 1
         args = (C.byref(cfg), C.byref(self.lparams[i]), C.byref(self.lgrads[i]), C.byref(A["acts_struct"][i]), C.byref(A["ws_struct"]),
                 mb, dy.data_ptr(), other.data_ptr(), i, s)

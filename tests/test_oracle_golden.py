@@ -273,3 +273,45 @@ def test_bigbird_plan_tables():
     for h in range(2):
         for i in range(2, 12 - 2):
             assert not set(r[h, i - 1].tolist()) & {i - 1, i, i + 1}
+
+
+# ------------------------------------------------------------------------------------------------ mmvts text encoder (f-3)
+def mmvts_case(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    ins = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in.")}
+    return z, sd, ins
+
+
+def mmvts_oracle_encode(kind, sd, ids, am, tt):
+    if kind == "bert":
+        cfg = O.make_cfg(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=200,
+                         max_position_embeddings=128, type_vocab_size=2)
+        return O.bert_encode(sd, cfg, ids, am, tt, prefix="text_encoder.")
+    cfg = O.make_cfg(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=200,
+                     max_position_embeddings=258, type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5, attention_window=[32, 64])
+    return LO.longformer_encode(sd, cfg, ids, am, tt, prefix="text_encoder.", global_attention_mask=torch.zeros_like(ids))
+
+
+@pytest.mark.parametrize("case,kind", [("mmvts_text_bert_L128", "bert"), ("mmvts_text_lf_L256", "lf")])
+def test_mmvts_text_encoder_matches_reference(case, kind):
+    """mmvts/src/models/text_encoder/text_encoder.py: BertModel, or LongformerModel WITHOUT any global token (the reference passes
+    global_attention_mask=None); features of valid tokens and the gradients of sum(features * weights)"""
+    z, sd, ins = mmvts_case(case)
+    assert str(z["kind"]) == kind
+    valid = ins["attention_mask"].bool()
+    with torch.no_grad():
+        f = mmvts_oracle_encode(kind, sd, ins["input_ids"], ins["attention_mask"], ins["token_type_ids"])
+    assert (f - torch.from_numpy(z["eval.features"]))[valid].abs().max().item() < 3e-5
+    sd2 = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    f = mmvts_oracle_encode(kind, sd2, ins["input_ids"], ins["attention_mask"], ins["token_type_ids"])
+    (f * ins["loss_weights"]).sum().backward()
+    n_checked = 0
+    for k in z.files:
+        if k.startswith("train.grad."):
+            n = k[len("train.grad."):]
+            g = sd2[n].grad
+            g = torch.zeros_like(sd2[n]) if g is None else g
+            assert np.abs(g.numpy() - z[k]).max() < 1e-4 + 2e-5 * np.abs(z[k]).max(), n      # gradients are O(100) here
+            n_checked += 1
+    assert n_checked > 30

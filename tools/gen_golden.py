@@ -183,8 +183,61 @@ def main_bigbird(variants):
     run_case("bb_tiny_L128", bb, 128, 2, 8, variants[:3], kind="bigbird")
 
 
+def main_mmvts():
+    """mmvts text branch: the reference's TextEncoder (mmvts/src/models/text_encoder/text_encoder.py) over BertModel and over
+    LongformerModel with global_attention_mask=None; eval features + gradients of sum(features * fixed weights) in train mode."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_mmvts_text_encoder", "/root/reference/mmvts/src/models/text_encoder/text_encoder.py")
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    base = dict(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cases = [("mmvts_text_bert_L128", BertConfig(max_position_embeddings=128, type_vocab_size=2, **base), "tiny_bert", 128, 0),
+             ("mmvts_text_lf_L256", LongformerConfig(max_position_embeddings=258, type_vocab_size=1, pad_token_id=1, bos_token_id=0,
+                                                     eos_token_id=2, layer_norm_eps=1e-5, attention_window=[32, 64], **base),
+              "tiny_longformer_zh", 256, 1)]
+    for name, cfg, enc_name, L, pad in cases:
+        cfg.text_encoder_name_or_path, cfg.init_model = enc_name, False
+        torch.manual_seed(21)
+        m = mod.TextEncoder(cfg)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if "LayerNorm.weight" in n:
+                    p.add_(0.1 * torch.randn_like(p))
+                if n.endswith("bias"):
+                    p.add_(0.05 * torch.randn_like(p))
+        g = torch.Generator().manual_seed(5)
+        B = 2
+        ids = torch.randint(3, 200, (B, L), generator=g)
+        am = torch.ones(B, L, dtype=torch.long)
+        am[1, L - 41:] = 0
+        ids = torch.where(am == 0, torch.full_like(ids, pad), ids)
+        tt = torch.zeros(B, L, dtype=torch.long)
+        wts = torch.randn(B, L, cfg.hidden_size, generator=g) * am.unsqueeze(-1)
+        out = {"in.input_ids": ids.numpy(), "in.attention_mask": am.numpy(), "in.token_type_ids": tt.numpy(), "in.loss_weights": wts.numpy(),
+               "kind": np.array(m.encoder_type)}
+        for k, v in m.state_dict().items():
+            if "position_ids" in k or k.endswith("token_type_ids"):
+                continue
+            out["sd." + k] = v.numpy().copy()
+        m.eval()
+        with torch.no_grad():
+            out["eval.features"] = m(ids, attention_mask=am, token_type_ids=tt).numpy()
+        m.train()
+        f = m(ids, attention_mask=am, token_type_ids=tt)
+        (f * wts).sum().backward()
+        out["train.features"] = f.detach().numpy()
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                out["train.grad." + n] = p.grad.numpy().copy()
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    if "--bigbird-only" in sys.argv:
+    if "--mmvts-only" in sys.argv:
+        main_mmvts()
+    elif "--bigbird-only" in sys.argv:
         main_bigbird([("plain_eval", PLAIN, "eval", 0, {}), ("full_eval", FULL, "eval", 5, {}), ("train_full", FULL, "train", 7, {})])
     else:
         main()
