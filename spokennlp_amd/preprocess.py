@@ -370,3 +370,30 @@ def ponet_prepare_features(docs_sentence_ids, docs_labels, example_ids, max_seq_
             else:
                 si += 1
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- PoNet extractive summarisation
+def es_collect_predictions(pred_label_ids, labels, window_num_sentences, example_ids, num_examples, o_id=1):
+    """alimeeting4mug/src/extractive_summarization/ponet_extractive_summarization.py:853-905 (`compute_metrics`, integer part):
+    the argmax label id at every labelled [EOS] of every window, glued back per document in window order.  A window whose last
+    sentence lost its label to the window edge (the feature builder sets the label of a cut-off final [EOS] to -100, :727-733)
+    has one prediction fewer than sentences: the reference appends "O" to both prediction and label (:897-899).
+    pred_label_ids / labels: per window, sequences of length L (labels -100 = not a sentence end);
+    window_num_sentences: per window, the number of sentences it covers (`sentences` column of the feature builder).
+    Returns (per-document predicted ids, per-document label ids)."""
+    preds = [[] for _ in range(num_examples)]
+    golds = [[] for _ in range(num_examples)]
+    for p_row, l_row, nsent, ex in zip(pred_label_ids, labels, window_num_sentences, example_ids):
+        p = [int(p) for p, l in zip(p_row, l_row) if l != -100]
+        g = [int(l) for l in l_row if l != -100]
+        if len(g) < nsent:
+            p.append(o_id); g.append(o_id)
+        if len(p) != nsent:
+            raise ValueError(f"window of document {ex}: {len(p)} labelled sentence ends for {nsent} sentences")
+        preds[ex].extend(p); golds[ex].extend(g)
+    return preds, golds
+
+
+def es_selected_sentences(doc_label_ids, key_id=0):
+    """indices of the sentences labelled as summary sentences ("B-EOP" = id 0 in the reference's label list, :907-912)"""
+    return [i for i, v in enumerate(doc_label_ids) if v == key_id]

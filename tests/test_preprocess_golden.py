@@ -105,3 +105,20 @@ def test_ponet_features_bit_exact(name):
         got, exp = np.array(cols[c], dtype=np.int32), G[name + "." + c]
         assert got.shape == exp.shape and np.array_equal(got, exp), c
     assert [b - a for a, b in cols["sentence_range"]] == G[name + ".num_sentences"].tolist()
+
+
+def test_es_collect_predictions():
+    """extractive summarisation decode (ponet_extractive_summarization.py:853-905): windows -> documents, the appended "O" when a
+    window's last sentence end was cut by the window edge"""
+    feats = P.ponet_prepare_features([[[10, 11, 7], [12, 7], [13, 14, 15, 7], [16, 7]]], [[0, 1, 0, 1]], [0], 8, 7, 2, 0)
+    nwin = len(feats["input_ids"])
+    assert nwin >= 2
+    nsent = [r[1] - r[0] for r in feats["sentence_range"]]
+    pred = [[0 if l != -100 else 5 for l in row] for row in feats["labels"]]          # predict "B-EOP" at every labelled [EOS]
+    preds, golds = P.es_collect_predictions(pred, feats["labels"], nsent, feats["example_id"], 1)
+    assert len(preds[0]) == len(golds[0]) == sum(nsent)
+    lab_flat = [l for row in feats["labels"] for l in row if l != -100]
+    assert sum(1 for v in golds[0] if v in (0, 1)) == len(golds[0]) and len(lab_flat) <= len(golds[0])
+    assert P.es_selected_sentences([0, 1, 1, 0]) == [0, 3]
+    with pytest.raises(ValueError):
+        P.es_collect_predictions(pred, feats["labels"], [n + 2 for n in nsent], feats["example_id"], 1)

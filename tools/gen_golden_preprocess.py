@@ -102,7 +102,13 @@ PONET_CASES = [  # name, n_docs, mean_sents, max_tok, max_seq_length, seed, use_
     ("ponet_L32_para", 3, 12, 8, 32, 1, True, 0.0),
     ("ponet_L64_para_unk", 4, 25, 10, 64, 2, True, 0.4),
     ("ponet_L16_long", 2, 8, 30, 16, 3, False, 0.0),
+    # PoNet extractive summarisation: the same closure name in ponet_extractive_summarization.py:611-768; sentence-level
+    # segment ids, a label on every sentence's [EOS] ("es_" prefix selects that source file)
+    ("es_ponet_L32", 3, 12, 8, 32, 4, False, 0.0),
+    ("es_ponet_L64_unk", 4, 25, 10, 64, 5, False, 0.3),
+    ("es_ponet_L16_long", 2, 8, 30, 16, 6, False, 0.0),
 ]
+ES_SRC = "/root/reference/alimeeting4mug/src/extractive_summarization/ponet_extractive_summarization.py"
 
 
 class PonetStubTokenizer:
@@ -121,13 +127,18 @@ class PonetStubTokenizer:
         return {"input_ids": ids, "token_type_ids": [[0] * len(r) for r in ids], "attention_mask": [[1] * len(r) for r in ids]}
 
 
-def ponet_cases(out, names):
-    tree = ast.parse(open(PONET_SRC).read())
+def _closure(src):
+    tree = ast.parse(open(src).read())
     main_fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main"][0]
     fn = [n for n in ast.walk(main_fn) if isinstance(n, ast.FunctionDef) and n.name == "prepare_input_features"]
     assert len(fn) == 1
-    code = compile(ast.Module(body=fn, type_ignores=[]), "<reference closure>", "exec")
+    return compile(ast.Module(body=fn, type_ignores=[]), "<reference closure>", "exec")
+
+
+def ponet_cases(out, names):
+    codes = {False: _closure(PONET_SRC), True: _closure(ES_SRC)}
     for name, nd, ms, mt, L, seed, para, unk in PONET_CASES:
+        code = codes[name.startswith("es_")]
         ns = dict(tokenizer=PonetStubTokenizer(), target_specical_ids={EOS}, label_to_id={"B-EOP": 0, "O": 1},
                   use_paragraph_segment=para, max_seq_length=L, question_column_name="labels", context_column_name="sentences",
                   example_id_column_name="example_id")
