@@ -108,6 +108,43 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     const float er = erf_as_from_e(fabsf(x) * 0.70710678118654752f, e);
     return 0.5f * (1.0f + copysignf(er, x)) + x * 0.39894228040143268f * e;
 }
+// Two elements at a time on the packed-fp32 VALU ops (v_pk_mul/add/fma_f32): the GELU epilogues are VALU-bound -- at K = 768 the
+// ~25 VALU slots per element of the scalar form cost MORE SIMD time than the 1536 MFMA flops of the element (ablation: 25.6 us
+// of the 114 us FFN-up GEMM, 16.5 us of its GELU' backward).  Same formula and constants as gelu_fast / gelu_grad_fast:
+//   gelu(x)  = h + |h| (1 - q),  gelu'(x) = 1/2 + s (1 - q) + x e / sqrt(2 pi),   h = x/2, s = copysign(1/2, x),
+//   q = poly(t) e,  t = 1 / (1 + p |x| / sqrt 2),  e = exp(-x^2 / 2) = exp2(-x^2 log2(e) / 2)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_pair_core(f32x2 x, f32x2& ax, f32x2& e, f32x2& q) {
+    ax = (f32x2){fabsf(x.x), fabsf(x.y)};
+    const f32x2 x2 = x * x;
+    const f32x2 a = x2 * -0.72134752044448170f;
+    e = (f32x2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const f32x2 d = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
+    const f32x2 t = (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32x2 p = t * 1.061405429f + -1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t + -0.284496736f;
+    p = p * t + 0.254829592f;
+    q = (p * t) * e;
+}
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+#ifdef AMDSEG_ABL_GELU
+    return x * 0.5f;
+#endif
+    f32x2 ax, e, q;
+    gelu_pair_core(x, ax, e, q);
+    const f32x2 h = x * 0.5f, ah = ax * 0.5f;
+    return (h + ah) - ah * q;
+}
+__device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
+#ifdef AMDSEG_ABL_GELU
+    return x + 0.5f;
+#endif
+    f32x2 ax, e, q;
+    gelu_pair_core(x, ax, e, q);
+    const f32x2 s = (f32x2){copysignf(0.5f, x.x), copysignf(0.5f, x.y)};
+    return ((s + 0.5f) - s * q) + (x * e) * 0.39894228040143268f;
+}
 // "gelu_new" (tanh approximation; [hf] activations.py NewGELUActivation -- BigBird's default hidden_act) and its derivative
 __device__ __forceinline__ float gelu_tanh_fast(float x) {
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
@@ -123,6 +160,24 @@ __device__ __forceinline__ float gelu_tanh_grad_fast(float x) {
 // act: 0 = exact (erf) GELU, 1 = gelu_new; wave-uniform
 __device__ __forceinline__ float gelu_act(float x, int act) { return act ? gelu_tanh_fast(x) : gelu_fast(x); }
 __device__ __forceinline__ float gelu_grad_act(float x, int act) { return act ? gelu_tanh_grad_fast(x) : gelu_grad_fast(x); }
+// four values of one accumulator fragment at a time (the erf form runs on the packed ops)
+__device__ __forceinline__ void gelu_act4(float* v, int act) {
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_fast(v[e]);
+    } else {
+        const f32x2 a = gelu_fast2((f32x2){v[0], v[1]}), b = gelu_fast2((f32x2){v[2], v[3]});
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    }
+}
+__device__ __forceinline__ void gelu_grad_mul4(float* v, float r0, float r1, float r2, float r3, int act) {
+    if (act) {
+        v[0] *= gelu_tanh_grad_fast(r0); v[1] *= gelu_tanh_grad_fast(r1); v[2] *= gelu_tanh_grad_fast(r2); v[3] *= gelu_tanh_grad_fast(r3);
+    } else {
+        const f32x2 a = gelu_grad_fast2((f32x2){r0, r1}), b = gelu_grad_fast2((f32x2){r2, r3});
+        v[0] *= a.x; v[1] *= a.y; v[2] *= b.x; v[3] *= b.y;
+    }
+}
 
 // Stateless counter-based dropout RNG: keep(element idx) iff hash(seed, idx) >= threshold.
 // The same (seed, idx) is re-evaluated in backward, so no mask is stored.

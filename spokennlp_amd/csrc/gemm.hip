@@ -60,8 +60,9 @@ __device__ __forceinline__ bf16x8 nt_frag(const char* lds_tile, int r, int c) {
     return *reinterpret_cast<const bf16x8*>(lds_tile + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
 }
 
-template <int EPI, typename OutT>
+template <int EPIX, typename OutT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
+    constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
     __shared__ __attribute__((aligned(16))) char smem[65536];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id as a scalar: LDS bases / M0 stay in SGPRs
@@ -206,13 +207,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
                 if (EPI == EPI_BIAS_GELU) {
                     uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
                     if (a.C2) *reinterpret_cast<uint2*>(stg2 + soff) = pk;          // pre-activation u, kept for backward
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_act(v[e], a.act);
+                    gelu_act4(v, ACT);
                 } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
                     const float r0 = __uint_as_float(rr[j][q].x << 16), r1 = __uint_as_float(rr[j][q].x & 0xffff0000u);
                     const float r2 = __uint_as_float(rr[j][q].y << 16), r3 = __uint_as_float(rr[j][q].y & 0xffff0000u);
                     if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
-                    else { v[0] *= gelu_grad_act(r0, a.act); v[1] *= gelu_grad_act(r1, a.act); v[2] *= gelu_grad_act(r2, a.act); v[3] *= gelu_grad_act(r3, a.act); }
+                    else gelu_grad_mul4(v, r0, r1, r2, r3, ACT);
                 }
                 if (STAGED) {
                     uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
@@ -316,8 +316,9 @@ __device__ __forceinline__ int pp_tile_of(int b, int r, int T) {
 // stores are issued AFTER it, so (in-order vmcnt) the K-step can wait for its DMA with vmcnt(#stores) and leave the stores
 // in flight -- waiting for ~100 KB of stores per tile with vmcnt(0) cost 5.7 us per tile (profiles/r01_gemm_experiments.md)
 struct PpEpiRegs { float4 bv[3][4]; uint2 rr[2][3][4]; };
-template <int EPI>
+template <int EPIX>
 __device__ __forceinline__ void pp_epi_load(const GemmNTArgs& a, PpEpiRegs& e, int m0, int n0, int grp, int wq, int l) {
+    constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
     const int hi = l >> 5;
     if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
 #pragma unroll
@@ -337,9 +338,10 @@ __device__ __forceinline__ void pp_epi_load(const GemmNTArgs& a, PpEpiRegs& e, i
         }
     }
 }
-template <int EPI, typename OutT>
+template <int EPIX, typename OutT>
 __device__ __forceinline__ void pp_epi_store(const GemmNTArgs& a, const PpEpiRegs& e, f32x16 (&acc)[2][3], int m0, int n0, int grp,
                                              int wq, int l) {
+    constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
     const int hi = l >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -356,14 +358,13 @@ __device__ __forceinline__ void pp_epi_store(const GemmNTArgs& a, const PpEpiReg
                 if (EPI == EPI_BIAS_GELU) {
                     uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
                     *reinterpret_cast<uint2*>(a.C2 + gm * a.ldc2 + gn) = pk;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = gelu_act(v[k], a.act);
+                    gelu_act4(v, ACT);
                 } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
                     const uint2 r = e.rr[i][j][q];
                     const float r0 = __uint_as_float(r.x << 16), r1 = __uint_as_float(r.x & 0xffff0000u);
                     const float r2 = __uint_as_float(r.y << 16), r3 = __uint_as_float(r.y & 0xffff0000u);
                     if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
-                    else { v[0] *= gelu_grad_act(r0, a.act); v[1] *= gelu_grad_act(r1, a.act); v[2] *= gelu_grad_act(r2, a.act); v[3] *= gelu_grad_act(r3, a.act); }
+                    else gelu_grad_mul4(v, r0, r1, r2, r3, ACT);
                 }
                 OutT* dst = reinterpret_cast<OutT*>(a.C) + gm * a.ldc + gn;
                 if (sizeof(OutT) == 2) {
@@ -382,10 +383,11 @@ __device__ __forceinline__ void pp_epi_store(const GemmNTArgs& a, const PpEpiReg
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 // number of store instructions pp_epi_store issues per wave
-template <int EPI> struct PpStores { static constexpr int n = (EPI == EPI_BIAS_GELU) ? 48 : 24; };
+template <int EPIX> struct PpStores { static constexpr int n = (EPI_BASE(EPIX) == EPI_BIAS_GELU) ? 48 : 24; };
 
-template <int EPI, typename OutT>
+template <int EPIX, typename OutT>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
+    constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
 // end of K-step s: A(s+1) and B(s+1) must have landed; the younger A(s+2) pieces (4) and this K-step's epilogue stores may fly
 #define PP_WAIT_STAGE(a2, epi)                                                                               \
     do {                                                                                                     \
-        const int S_ = PpStores<EPI>::n;                                                                     \
+        const int S_ = PpStores<EPIX>::n;                                                                     \
         if (epi) {                                                                                           \
             if (a2) { if (S_ == 48) asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); } \
             else { if (S_ == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); } \
@@ -503,10 +505,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
             const char* curB = smem + PP_B_BASE + (s & 1) * PP_B_SLOT;
             // phase 4s: [epilogue of the previous tile] + DMA B(s+1), A(s+2) + mem(s,0)       (G1: mfma(s-1,1))
             const bool epi = pending, a2 = s + 2 < total;
-            if (epi) pp_epi_load<EPI>(a, er, pm0, pn0, grp, wq, l);
+            if (epi) pp_epi_load<EPIX>(a, er, pm0, pn0, grp, wq, l);
             if (s + 1 < total) PP_DMA_B((s + 1) & 1);
             if (a2) PP_DMA_A(sa == 0 ? 2 : sa - 1);            // (s + 2) % 3
-            if (epi) { pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l); pending = false; }
+            if (epi) { pp_epi_store<EPIX, OutT>(a, er, acc, pm0, pn0, grp, wq, l); pending = false; }
             PP_MEM(curA, curB, 0);
             PP_SYNC_MEM();
             // phase 4s+1: mfma(s,0)
@@ -525,8 +527,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
                 if (++cr < ntl) pp_tile_coords(a, pp_tile_of(blockIdx.x, cr, T), cm0, cn0);
             }
         }
-        pp_epi_load<EPI>(a, er, pm0, pn0, grp, wq, l);
-        pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l);
+        pp_epi_load<EPIX>(a, er, pm0, pn0, grp, wq, l);
+        pp_epi_store<EPIX, OutT>(a, er, acc, pm0, pn0, grp, wq, l);
     } else {
         for (int s = 0; s < total; ++s) {
             const char* curA = smem + sa * PP_A_SLOT;
@@ -536,10 +538,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
             PP_SYNC();
             // phase 4s+1: [epilogue of the previous tile] + DMA B(s+1), A(s+2) + mem(s,0)     (G0: mfma(s,0))
             const bool epi = pending, a2 = s + 2 < total;
-            if (epi) pp_epi_load<EPI>(a, er, pm0, pn0, grp, wq, l);
+            if (epi) pp_epi_load<EPIX>(a, er, pm0, pn0, grp, wq, l);
             if (s + 1 < total) PP_DMA_B((s + 1) & 1);
             if (a2) PP_DMA_A(sa == 0 ? 2 : sa - 1);
-            if (epi) { pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l); pending = false; }
+            if (epi) { pp_epi_store<EPIX, OutT>(a, er, acc, pm0, pn0, grp, wq, l); pending = false; }
             PP_MEM(curA, curB, 0);
             PP_SYNC_MEM();
             // phase 4s+2: mfma(s,0)
@@ -557,8 +559,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
             }
         }
         PP_MFMA();                       // trailing mfma(total-1,1)
-        pp_epi_load<EPI>(a, er, pm0, pn0, grp, wq, l);
-        pp_epi_store<EPI, OutT>(a, er, acc, pm0, pn0, grp, wq, l);
+        pp_epi_load<EPIX>(a, er, pm0, pn0, grp, wq, l);
+        pp_epi_store<EPIX, OutT>(a, er, acc, pm0, pn0, grp, wq, l);
     }
 #ifdef AMDSEG_CLOCK_PROBE
     if (a.dbg && tid == 0) {
@@ -569,20 +571,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
 #endif
 }
 
-template <int EPI, typename OutT>
+template <int EPIX, typename OutT>
 static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
+    constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
     // tile choice (measured at M = 16384, tools/bench_kernels.py): the 256x192 ping-pong kernel wins for long K (its one
     // workgroup per CU pays an exposed prologue + epilogue per tile), the 128x128 kernel (2 workgroups per CU overlap each
     // other's prologue/epilogue) for K <= 768; shapes the small kernel cannot tile always take the ping-pong kernel
     const bool small_ok = (a_in.M % BM) == 0 && (a_in.N % BN) == 0;
     static int dp_min_k = -1;
-    if (dp_min_k < 0) { const char* e = getenv("AMDSEG_DP_MIN_K"); dp_min_k = e ? atoi(e) : 1536; }
+    if (dp_min_k < 0) { const char* e = getenv("AMDSEG_DP_MIN_K"); dp_min_k = e ? atoi(e) : 768; }
     // 256-aligned long-K shapes: the deep-pipeline 256x256 kernel (gemm_dp.hip).  Measured at M = 16384 against the kernels below:
     // K = 3072 / 2304: 74-79 / 58 us vs 90 / 68 (ping-pong).  For K = 768 it also wins the back-to-back microbenchmark (QKV 64.5 vs
     // 72 us, dual-output FFN 129 vs 143, GELU-bwd 106 vs 128) but NOT the training step (18.24 vs 18.17 ms): with cold
     // operands its single workgroup per CU hides HBM latency worse than two 128x128 workgroups -- AMDSEG_DP_MIN_K selects
     if ((a_in.M % 256) == 0 && (a_in.N % 256) == 0 && a_in.K >= dp_min_k && !g_force_small_tile)
-        return amdseg_launch_nt_dp<EPI, OutT>(a_in, s);
+        return amdseg_launch_nt_dp<EPIX, OutT>(a_in, s);
     // the ping-pong kernel counts its in-flight stores (two outputs for BIAS_GELU): the single-output form runs on the 128x128 kernel
     const bool single_gelu = EPI == EPI_BIAS_GELU && !a_in.C2;
     if (single_gelu && !small_ok) return AMDSEG_ERR_SHAPE;
@@ -592,7 +595,7 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     if (pp_ok && !(g_force_small_tile && small_ok) && (a_in.K >= pp_min_k || !small_ok || g_force_small_tile < 0)) {
         static bool attr_set = false;          // > 64 KiB of dynamic LDS is opted into once per kernel instantiation
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<EPI, OutT>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<EPIX, OutT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
@@ -600,10 +603,10 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
         GemmNTArgs a = a_in;
         a.tiles_m = a.M / PP_BM; a.tiles_n = a.N / PP_BN;
         const int T = a.tiles_m * a.tiles_n;
-        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, OutT>), dim3(T < 256 ? ((T + 7) / 8) * 8 : 256), dim3(512), PP_LDS, s, a);
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPIX, OutT>), dim3(T < 256 ? ((T + 7) / 8) * 8 : 256), dim3(512), PP_LDS, s, a);
         return amdseg_launch_status();
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), dim3(a_in.tiles_m * a_in.tiles_n), dim3(256), 0, s, a_in);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPIX, OutT>), dim3(a_in.tiles_m * a_in.tiles_n), dim3(256), 0, s, a_in);
     return amdseg_launch_status();
 }
 
@@ -618,7 +621,7 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     if ((lda % 8) || (ldb % 8) || (ldc % 8)) return AMDSEG_ERR_SHAPE;
     GemmNTArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = bias; a.R = (const bf16_t*)R; a.C2 = (bf16_t*)C2;
-    a.dbg = nullptr; a.act = act;
+    a.dbg = nullptr;
 #if defined(AMDSEG_PHASE_TIMERS) || defined(AMDSEG_CLOCK_PROBE)
     extern unsigned long long* g_amdseg_dbg;
     a.dbg = g_amdseg_dbg;
@@ -632,13 +635,13 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
             return out_fp32 ? launch_nt<EPI_BIAS, float>(a, stream) : launch_nt<EPI_BIAS, bf16_t>(a, stream);
         case EPI_BIAS_GELU:
             if (!bias || out_fp32 || (C2 && (ldc2 % 8))) return AMDSEG_ERR_ARG;       // C2 == NULL: gelu output only (inference)
-            return launch_nt<EPI_BIAS_GELU, bf16_t>(a, stream);
+            return act ? launch_nt<EPI_BIAS_GELU_TANH, bf16_t>(a, stream) : launch_nt<EPI_BIAS_GELU, bf16_t>(a, stream);
         case EPI_ADD_RES:
             if (!R || (ldr % 8)) return AMDSEG_ERR_ARG;
             return out_fp32 ? launch_nt<EPI_ADD_RES, float>(a, stream) : launch_nt<EPI_ADD_RES, bf16_t>(a, stream);
         case EPI_GELU_BWD:
             if (!R || out_fp32 || (ldr % 8)) return AMDSEG_ERR_ARG;
-            return launch_nt<EPI_GELU_BWD, bf16_t>(a, stream);
+            return act ? launch_nt<EPI_GELU_BWD_TANH, bf16_t>(a, stream) : launch_nt<EPI_GELU_BWD, bf16_t>(a, stream);
     }
     return AMDSEG_ERR_ARG;
 }

@@ -35,8 +35,9 @@ __device__ __forceinline__ void dp_glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(void, lds_wave_base), 16, 0, 0);
 }
 
-template <int EPI, typename OutT>
+template <int EPIX, typename OutT>
 __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
+    constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,6 +119,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const float4*>(a.bias + n0 + wc * 64 + nf * 16 + g * 4);
     }
+    // the bias goes INTO the accumulators once: recomputing acc + bias in both passes of BIAS_GELU made the compiler keep all
+    // 128 sums of pass 0 alive for pass 1 (common subexpression) next to the 128 accumulators -> 116 spilled VGPRs
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) { acc[mf][nf][0] += bv[nf].x; acc[mf][nf][1] += bv[nf].y; acc[mf][nf][2] += bv[nf].z; acc[mf][nf][3] += bv[nf].w; }
+    }
     constexpr bool STAGED = sizeof(OutT) == 2;
     char* stg = smem + w * 16384;
 #define DP_STG_OFF(r, c16) (((r) >> 6) * 8192 + ((r) & 63) * 128 + ((((c16) ^ (((r) & 63) ^ (((r) & 63) >> 3))) & 7) << 4))
@@ -137,15 +146,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
                 float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
-                if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) { v[0] += bv[nf].x; v[1] += bv[nf].y; v[2] += bv[nf].z; v[3] += bv[nf].w; }
                 if (EPI == EPI_BIAS_GELU && pass == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_act(v[e], a.act);
+                    gelu_act4(v, ACT);
                 } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
                     const float r0 = __uint_as_float(rr[nf].x << 16), r1 = __uint_as_float(rr[nf].x & 0xffff0000u);
                     const float r2 = __uint_as_float(rr[nf].y << 16), r3 = __uint_as_float(rr[nf].y & 0xffff0000u);
                     if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
-                    else { v[0] *= gelu_grad_act(r0, a.act); v[1] *= gelu_grad_act(r1, a.act); v[2] *= gelu_grad_act(r2, a.act); v[3] *= gelu_grad_act(r3, a.act); }
+                    else gelu_grad_mul4(v, r0, r1, r2, r3, ACT);
                 }
                 if (STAGED) {
                     uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
@@ -155,6 +162,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
+            // one row fragment (16 values per lane) at a time: without the fence the scheduler interleaves all 128 GELU
+            // evaluations of a pass and the BIAS_GELU instantiation spills 116 VGPRs next to the 128 accumulators
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (STAGED) {
             __builtin_amdgcn_wave_barrier();
@@ -175,24 +185,26 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     }
 }
 
-template <int EPI, typename OutT>
+template <int EPIX, typename OutT>
 int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
+    constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dp_kernel<EPI, OutT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dp_kernel<EPIX, OutT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     GemmNTArgs a = a_in;
     a.tiles_m = a.M / DP_BM; a.tiles_n = a.N / DP_BN;
-    hipLaunchKernelGGL((gemm_nt_dp_kernel<EPI, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(512), DP_LDS, s, a);
+    hipLaunchKernelGGL((gemm_nt_dp_kernel<EPIX, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(512), DP_LDS, s, a);
     return amdseg_launch_status();
 }
 
 #define DP_INST(E, T) template int amdseg_launch_nt_dp<E, T>(const GemmNTArgs&, hipStream_t);
 DP_INST(EPI_NONE, bf16_t) DP_INST(EPI_NONE, float) DP_INST(EPI_BIAS, bf16_t) DP_INST(EPI_BIAS, float) DP_INST(EPI_BIAS_GELU, bf16_t)
 DP_INST(EPI_ADD_RES, bf16_t) DP_INST(EPI_ADD_RES, float) DP_INST(EPI_GELU_BWD, bf16_t)
+DP_INST(EPI_BIAS_GELU_TANH, bf16_t) DP_INST(EPI_GELU_BWD_TANH, bf16_t)
 
 
 // ==================================================================================================== gemm_tn, deep pipeline

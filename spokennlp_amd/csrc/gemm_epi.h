@@ -4,14 +4,18 @@
 
 #define GROUP_M 8
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_BWD = 4 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_BWD = 4,
+       EPI_BIAS_GELU_TANH = 5, EPI_GELU_BWD_TANH = 6 };     // kernel template values only: the two GELU epilogues with gelu_new
+// the kernels are instantiated on the extended value EPIX; EPI = what the epilogue does, ACT = which GELU (a compile-time constant:
+// a run-time flag became one scalar branch PER ELEMENT in the epilogue)
+#define EPI_BASE(X) ((X) == EPI_BIAS_GELU_TANH ? EPI_BIAS_GELU : (X) == EPI_GELU_BWD_TANH ? EPI_GELU_BWD : (X))
+#define EPI_ACT(X) ((X) >= EPI_BIAS_GELU_TANH ? 1 : 0)
 
 struct GemmNTArgs {
     const bf16_t* A; const bf16_t* B; void* C; const float* bias; const bf16_t* R; bf16_t* C2; unsigned long long* dbg;
     int lda, ldb, ldc, ldr, ldc2;
     int M, N, K;
     int tiles_m, tiles_n;
-    int act;            // GELU flavour of EPI_BIAS_GELU / EPI_GELU_BWD: 0 erf, 1 tanh ("gelu_new")
 };
 
 // bijective XCD-aware remap: hardware places workgroup b on XCD b % 8; give each XCD a contiguous tile range
@@ -23,7 +27,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 
 // deep-pipeline 256 x 256 kernel (gemm_dp.hip)
-template <int EPI, typename OutT> int amdseg_launch_nt_dp(const GemmNTArgs& a, hipStream_t s);
+template <int EPIX, typename OutT> int amdseg_launch_nt_dp(const GemmNTArgs& a, hipStream_t s);
 
 // grouped TN GEMM (weight gradients): launch arguments shared by gemm.hip (128 x 128 kernel) and gemm_dp.hip (256 x 128 kernel)
 struct TNProblem { const bf16_t* A; const bf16_t* B; float* C; int N, Kp, lda, ldb, ldc, tile_begin, tiles_k; };
