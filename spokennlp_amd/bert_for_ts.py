@@ -231,7 +231,8 @@ class TopicSegHeadsMixin:
             plan["anchors"] = up.add(eot)
         else:
             raise ValueError("not supported cl_anchor_level %s " % cfg.cl_anchor_level)
-        plan["lists"] = [up.add(ix) for ix in pos_i + neg_i]
+        lists = pos_i + neg_i                                  # every list has one entry per anchor
+        plan["nlists"], plan["lists"] = len(lists), up.add([v for ix in lists for v in ix])
         return plan
 
     def _plan_tssp(self, up, req, stm_cpu, spo_cpu, Lq, off):
@@ -278,8 +279,13 @@ class TopicSegHeadsMixin:
             return (torch.where(sel, -torch.log(torch.where(sel, prob, torch.ones_like(prob))), torch.zeros_like(prob)).sum() / cnt)
         pk = cfg.cl_positive_k
         anchors = feats if plan["anchors"] is None else feats.index_select(0, up.get(plan["anchors"]))
-        sims = [_cos(anchors, feats.index_select(0, up.get(h)), cfg.cl_temp).unsqueeze(0) for h in plan["lists"]]
-        e = torch.exp(torch.cat(sims))
+        # all positive and negative lists in ONE gather + ONE cosine ([k, n, H] against [1, n, H]): the per-list form cost
+        # ~8 tiny kernels per list forward and twice that backward, a visible slice of a 16 ms step
+        other = feats.index_select(0, up.get(plan["lists"])).view(plan["nlists"], -1, feats.shape[-1])
+        if cfg.cl_temp == 0:                                     # the matrix form of _cos: one list at a time, as before
+            e = torch.exp(torch.cat([_cos(anchors, other[i], 0).unsqueeze(0) for i in range(plan["nlists"])]))
+        else:
+            e = torch.exp(_cos(anchors.unsqueeze(0), other, cfg.cl_temp))
         return (-torch.log(e[:pk].sum(0) / e.sum(0))).mean()
 
     def _tssp(self, feats_all, up, plan):

@@ -186,4 +186,7 @@ def test_bigbird_dropout_step_deterministic(dev):
         gn = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in m.parameters() if p.grad is not None)).item()
         assert math.isfinite(loss.item()) and math.isfinite(gn)
         vals.append((loss.item(), gn))
-    assert vals[0] == vals[1]
+    # same dropout masks, same loss bit for bit; the embedding-table gradients are accumulated with fp32 atomics (as torch's own
+    # embedding backward), so with 12 blocks of rows per table the gradient norm may differ in the last bits between runs
+    assert vals[0][0] == vals[1][0]
+    assert abs(vals[0][1] - vals[1][1]) <= 1e-6 * vals[0][1]
