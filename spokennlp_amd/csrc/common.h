@@ -27,6 +27,12 @@ __device__ __forceinline__ void amdseg_glds16(const void* g, void* lds_wave_base
     const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(char, lds_wave_base));
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(m) : "memory", "m0");
 }
+// the same with the global address split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: no VALU
+// address arithmetic at the issue point (3 instructions per 1-KiB piece inside an MFMA stream)
+__device__ __forceinline__ void amdseg_glds16_saddr(const void* uniform_base, uint32_t lane_byte_offset, void* lds_wave_base) {
+    const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(char, lds_wave_base));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_byte_offset), "s"(uniform_base), "s"(m) : "memory", "m0");
+}
 __device__ __forceinline__ void amdseg_glds4(const void* g, void* lds_wave_base) {
     const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(char, lds_wave_base));
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(m) : "memory", "m0");

@@ -55,19 +55,20 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #define DP_TILE_B(s, i) (smem + (s) * DP_STAGE + (4 + (i)) * 8192)
     const bf16_t* pA = a.A + (size_t)(m0 + wr * 128) * a.lda;                 // this group's A rows
     const bf16_t* pB = a.B + (size_t)(n0 + wr * 128) * a.ldb;                 // this group's DMA duty on B: tile images 2wr, 2wr+1
-    int offA[4], offB[4];                                                     // lane offsets, constant over K (saddr + voffset loads)
+    uint32_t offA[4], offB[4];                                                // lane BYTE offsets, constant over K (saddr + voffset loads)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int r = (wq * 2 + q) * 8 + (l >> 3), c = (l & 7) ^ dp_swz(r);
-            offA[i * 2 + q] = (i * 64 + r) * a.lda + c * 8;
-            offB[i * 2 + q] = (i * 64 + r) * a.ldb + c * 8;
+            offA[i * 2 + q] = ((i * 64 + r) * a.lda + c * 8) * 2;
+            offB[i * 2 + q] = ((i * 64 + r) * a.ldb + c * 8) * 2;
         }
+    // SGPR base + 32-bit lane byte offset: no VALU address arithmetic where the pieces are issued
 #define DP_DMA_A(s, i, kt) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
-        dp_glds16(pA + (kt) * 64 + offA[(i) * 2 + q], DP_TILE_A(s, wr * 2 + (i)) + (wq * 2 + q) * 1024);
+        amdseg_glds16_saddr(pA + (kt) * 64, offA[(i) * 2 + q], DP_TILE_A(s, wr * 2 + (i)) + (wq * 2 + q) * 1024);
 #define DP_DMA_B(s, kt) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
-        dp_glds16(pB + (kt) * 64 + offB[i * 2 + q], DP_TILE_B(s, wr * 2 + i) + (wq * 2 + q) * 1024);
+        amdseg_glds16_saddr(pB + (kt) * 64, offB[i * 2 + q], DP_TILE_B(s, wr * 2 + i) + (wq * 2 + q) * 1024);
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -257,19 +258,19 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
     const int n0 = tn * 256, k0 = tk * 128;
 #define TN_TILE_A(s, i) (smem + (s) * TN_STG + (i) * 8192)
 #define TN_TILE_B(s, j) (smem + (s) * TN_STG + 32768 + (j) * 8192)
-    int offA[4], offB[2];
+    uint32_t offA[4], offB[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int r = (wq * 2 + q) * 8 + (l >> 3), c = (l & 7) ^ tn_swz(r);
-        offA[q] = r * P.lda + (dr * 2) * 64 + c * 8;
-        offA[2 + q] = r * P.lda + (dr * 2 + 1) * 64 + c * 8;
-        offB[q] = r * P.ldb + dr * 64 + c * 8;
+        offA[q] = (r * P.lda + (dr * 2) * 64 + c * 8) * 2;          // byte offsets from the K tile's first row
+        offA[2 + q] = (r * P.lda + (dr * 2 + 1) * 64 + c * 8) * 2;
+        offB[q] = (r * P.ldb + dr * 64 + c * 8) * 2;
     }
     const bf16_t* pA = P.A + n0;
     const bf16_t* pB = P.B + k0;
     // piece j of this wave's DMA duty for K tile kt: j < 4 -> A image 2dr + (j >> 1), 8-row piece 2wq + (j & 1); j >= 4 -> B image dr
-#define TN_DMA_PIECE(s, kt, j) do { if ((j) < 4) dp_glds16(tn_uniform(pA + (size_t)(kt) * 64 * P.lda) + offA[j], TN_TILE_A(s, dr * 2 + ((j) >> 1)) + (wq * 2 + ((j) & 1)) * 1024); \
-        else dp_glds16(tn_uniform(pB + (size_t)(kt) * 64 * P.ldb) + offB[(j) - 4], TN_TILE_B(s, dr) + (wq * 2 + ((j) - 4)) * 1024); } while (0)
+#define TN_DMA_PIECE(s, kt, j) do { if ((j) < 4) amdseg_glds16_saddr(tn_uniform(pA + (size_t)(kt) * 64 * P.lda), offA[j], TN_TILE_A(s, dr * 2 + ((j) >> 1)) + (wq * 2 + ((j) & 1)) * 1024); \
+        else amdseg_glds16_saddr(tn_uniform(pB + (size_t)(kt) * 64 * P.ldb), offB[(j) - 4], TN_TILE_B(s, dr) + (wq * 2 + ((j) - 4)) * 1024); } while (0)
 #define TN_DMA(s, kt) do { _Pragma("unroll") for (int j_ = 0; j_ < 6; ++j_) TN_DMA_PIECE(s, kt, j_); } while (0)
     f32x4 acc[8][4];
 #pragma unroll
@@ -278,9 +279,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = a.M / 64;
     TN_DMA(0, 0);
-    if (nk > 1) TN_DMA(1, 1);
-    if (nk > 2) TN_DMA(2, 2);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TN_DMA(1, min(1, nk - 1));                              // always three tiles (clamped): the vmcnt arithmetic below is uniform
+    TN_DMA(2, min(2, nk - 1));
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // lane addresses of the gathers inside stage 0: lane (i16, g) of fragment column block c4 reads rows kh*32 + g*4 + (i16 >> 2) (+16)
     uint32_t laA[4], laB[4];
@@ -317,17 +318,17 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
     // barrier that holds for every wave, so stage sn may be read and stage sc (tile kt, now in registers everywhere) refilled.
 #define TN_BODY(FC, FN) do { \
         TN_WAIT_FRAGS(FC); \
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          /* every K tile issues 6 pieces: tile kt+1 has landed */ \
         TN_SB(); __builtin_amdgcn_s_barrier(); TN_SB(); \
-        const bool dma_ = kt + 3 < nk; \
+        const int ktd_ = min(kt + 3, nk - 1);          /* past the end: re-fetch the last tile into a stage nobody reads */ \
         _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4) { aA[c4] = laA[c4] + sn * TN_STG; aB[c4] = laB[c4] + sn * TN_STG; } \
         __builtin_amdgcn_s_setprio(1); \
         _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) { \
             TN_MF(nf, 0, FC); TN_SB(); TN_MF(nf, 1, FC); TN_SB(); TN_LDB(nf, FN); TN_SB(); TN_MF(nf, 2, FC); TN_SB(); TN_MF(nf, 3, FC); TN_SB(); TN_LDA(nf); TN_SB(); \
-            if (nf >= 1 && dma_) { TN_DMA_PIECE(sc, kt + 3, nf - 1); TN_SB(); } } \
+            if (nf >= 1) { TN_DMA_PIECE(sc, ktd_, nf - 1); TN_SB(); } } \
         _Pragma("unroll") for (int nf = 4; nf < 8; ++nf) { \
             TN_MF(nf, 0, FC); TN_MF(nf, 1, FC); TN_MF(nf, 2, FC); TN_MF(nf, 3, FC); TN_SB(); TN_LDA(nf); TN_SB(); \
-            if (nf <= 6 && dma_) { TN_DMA_PIECE(sc, kt + 3, nf - 1); TN_SB(); } } \
+            if (nf <= 6) { TN_DMA_PIECE(sc, ktd_, nf - 1); TN_SB(); } } \
         __builtin_amdgcn_s_setprio(0); \
         sc = sc == 2 ? 0 : sc + 1; sn = sn == 2 ? 0 : sn + 1; } while (0)
     int kt = 0;
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
     if (kt < nk) TN_BODY(fb0, fb1);
     TN_WAIT_FRAGS(fb0);                                     // the last K tile gathered a (never used) tile nk: retire it before
     TN_WAIT_FRAGS(fb1);                                     // these registers and the ring are reused
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // ... and the clamped re-fetches of the last tiles
     __builtin_amdgcn_s_barrier();
     // K-half exchange through LDS: wave (kh, wr, wc) keeps row fragments nf = kh*4 .. +4 and hands the other four to its partner
     f32x4* xch = reinterpret_cast<f32x4*>(smem) + (size_t)w * 16 * 64;
