@@ -241,7 +241,8 @@ typedef struct amdseg_bert_layer_acts {     /* caller-owned activations; all but
 
 typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across layers */
     void *dz2, *dbr2, *du, *dx1, *dz1, *dbr1, *dctx, *dqkv;  /* [M,H] [M,H] [M,I] [M,H] [M,H] [M,H] [M,H] [M,3H] */
-    float *delta, *partials;                /* [B*heads*L], max(3*ceil(M/16)*H, ceil(M/128)*max(I,3H)) floats */
+    float *delta, *partials;                /* [B*heads*L]; partials: 6*ceil(M/16)*H + ceil(M/128)*(I + nproj*H) floats (one
+                                               region per deferred reduction: LN2, b1, LN1, bqkv) */
 } amdseg_bert_layer_ws;
 
 int amdseg_bert_layer_fwd(const amdseg_bert_cfg* cfg, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,

@@ -37,6 +37,8 @@ int amdseg_dropout_impl(const void* x, void* y, size_t n, float p, uint64_t seed
                         hipStream_t s);
 int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K, hipStream_t s);
 int amdseg_set_force_small_tile(int v);
+void amdseg_reduce_defer_begin(int accumulate);
+int amdseg_reduce_defer_flush(hipStream_t s);
 int amdseg_attn_list_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                               const int* klist, const int* kcnt, int list_stride, hipStream_t s);
 int amdseg_attn_list_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,

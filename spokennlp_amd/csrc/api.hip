@@ -261,17 +261,28 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     const bool drop = c->p_hidden > 0.f;
     const void* d_out = drop ? w->dbr2 : w->dz2;
     const void* d_ao = drop ? w->dbr1 : w->dz1;
+    // the four second-stage reductions of the layer (LN2, b1, LN1, bqkv) are queued and run as ONE kernel at the end of this
+    // call; each producer therefore gets its own region of ws.partials (include/amdseg.h: amdseg_bert_layer_ws)
+    const int NPd = NPROJ(c);
+    const size_t ln_part = (size_t)3 * ((M + 15) / 16) * H, cs_rows = (size_t)((M + 127) / 128);
+    float* part_ln2 = w->partials;
+    float* part_b1 = part_ln2 + ln_part;
+    float* part_ln1 = part_b1 + cs_rows * I;
+    float* part_bqkv = part_ln1 + ln_part;
+    (void)NPd;
+    amdseg_reduce_defer_begin(acc);
+    struct Flush { hipStream_t s; ~Flush() { amdseg_reduce_defer_flush(s); } } flush_at_exit{s};
     if (PHASE1(c)) {
     // LN2 backward: dz2 (residual grad), d_out = masked dz2 (grad of the FFN output dense), dln2, db2
-    RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, w->partials, g->ln2_g, g->ln2_b,
+    RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, part_ln2, g->ln2_g, g->ln2_b,
                               g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, c->dtype, s));
     // du = (d_out . W2) * gelu'(u)
     RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD | (c->act ? AMDSEG_EPI_ACT_TANH : 0), nullptr, a->u, I, nullptr, 0, 0, s));
     // dx1 = du . W1 + dz2
     RET_IF(amdseg_gemm_nt_impl(w->du, I, p->w1_t, I, w->dx1, H, M, H, I, AMDSEG_EPI_ADD_RES, nullptr, w->dz2, H, nullptr, 0, 0, s));
-    RET_IF(amdseg_colsum_impl(w->du, I, w->partials, g->b1, M, I, acc, c->dtype, s));
+    RET_IF(amdseg_colsum_impl(w->du, I, part_b1, g->b1, M, I, acc, c->dtype, s));
     // LN1 backward
-    RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, w->partials, g->ln1_g,
+    RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, part_ln1, g->ln1_g,
                               g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, c->dtype, s));
     // dctx = d_ao . Wo
     RET_IF(amdseg_gemm_nt_impl(d_ao, H, p->wo_t, H, w->dctx, H, M, H, H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, s));
@@ -283,7 +294,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
                                     site_seed(c->seed, li, 0), c->window, c->nglobal, s));
     // dx_in = dqkv . Wqkv + dz1   (external mixer: the caller wrote ws.dqkv [M, nproj*H] between the phases)
     RET_IF(amdseg_gemm_nt_impl(w->dqkv, NP, p->wqkv_t, NP, dx_in, H, M, H, NP, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s));
-    RET_IF(amdseg_colsum_impl(w->dqkv, NP, w->partials, g->bqkv, M, NP, acc, c->dtype, s));
+    RET_IF(amdseg_colsum_impl(w->dqkv, NP, part_bqkv, g->bqkv, M, NP, acc, c->dtype, s));
     }
     if (!PHASE_WGRAD(c)) return AMDSEG_OK;
     // all four weight gradients of the layer in one grouped launch: dW = dY^T X

@@ -335,8 +335,68 @@ __global__ __launch_bounds__(256) void reduce3_kernel(Reduce3 r, int nblocks, in
         }
     }
 }
+// Several second-stage reductions in ONE launch (blockIdx.y = job): the composite layer backward defers the four of a layer
+// (LN2: dgamma/dbeta/db2, colsum(du), LN1: dgamma/dbeta/dbo, colsum(dqkv) = 8 jobs) to one kernel at its end instead of four
+// ~7 us launches between its GEMMs.  Same arithmetic and summation order as the single-job kernels above.
+#define AMDSEG_MAX_REDUCE_JOBS 12
+struct ReduceJob { const float* part; float* out; int nblocks, stride, offset, n; };
+struct ReduceJobs { ReduceJob job[AMDSEG_MAX_REDUCE_JOBS]; int njobs, accumulate; };
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs jobs) {
+    __shared__ float red[16][64];
+    const ReduceJob j = jobs.job[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= j.n) return;
+    const int cg = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cg * 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const bool vec = (c + 3 < j.n) && ((j.stride & 3) == 0) && ((j.offset & 3) == 0);
+    if (vec) {
+#pragma unroll 4
+        for (int b = ry; b < j.nblocks; b += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(j.part + (size_t)b * j.stride + j.offset + c);
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        }
+    } else {
+        for (int b = ry; b < j.nblocks; b += 16) {
+            const float* p = j.part + (size_t)b * j.stride + j.offset;
+            if (c < j.n) a0 += p[c];
+            if (c + 1 < j.n) a1 += p[c + 1];
+            if (c + 2 < j.n) a2 += p[c + 2];
+            if (c + 3 < j.n) a3 += p[c + 3];
+        }
+    }
+    red[ry][cg * 4 + 0] = a0; red[ry][cg * 4 + 1] = a1; red[ry][cg * 4 + 2] = a2; red[ry][cg * 4 + 3] = a3;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cc = blockIdx.x * 64 + threadIdx.x;
+        if (cc < j.n) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += red[r][threadIdx.x];
+            j.out[cc] = jobs.accumulate ? j.out[cc] + sum : sum;
+        }
+    }
+}
+static thread_local ReduceJobs* g_defer = nullptr;       // set by amdseg_reduce_defer_begin: reductions are queued, not launched
+static ReduceJobs g_defer_store;
+void amdseg_reduce_defer_begin(int accumulate) { g_defer_store.njobs = 0; g_defer_store.accumulate = accumulate; g_defer = &g_defer_store; }
+int amdseg_reduce_defer_flush(hipStream_t s) {
+    ReduceJobs* d = g_defer;
+    g_defer = nullptr;
+    if (!d || d->njobs == 0) return AMDSEG_OK;
+    int nmax = 0;
+    for (int i = 0; i < d->njobs; ++i) nmax = d->job[i].n > nmax ? d->job[i].n : nmax;
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3((nmax + 63) / 64, d->njobs), dim3(256), 0, s, *d);
+    return amdseg_launch_status();
+}
+// true if the job was queued (the caller then must keep `partials` untouched until the flush)
+static inline bool defer_reduce(const float* partials, int nblocks, int stride, int offset, int n, float* out, int accumulate) {
+    if (!g_defer || g_defer->njobs >= AMDSEG_MAX_REDUCE_JOBS || g_defer->accumulate != accumulate) return false;
+    g_defer->job[g_defer->njobs++] = ReduceJob{partials, out, nblocks, stride, offset, n};
+    return true;
+}
 static inline void launch_reduce(const float* partials, int nblocks, int stride, int offset, int n, float* out, int accumulate,
                                  hipStream_t s) {
+    if (defer_reduce(partials, nblocks, stride, offset, n, out, accumulate)) return;
     hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblocks, stride, offset, n, out, accumulate);
 }
 
@@ -625,8 +685,13 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
         Reduce3 r;
         r.part[0] = partials; r.part[1] = partials + (size_t)nblk * H; r.part[2] = partials + (size_t)2 * nblk * H;
         r.out[0] = dgamma; r.out[1] = dbeta; r.out[2] = dbias;
-        if ((H % 4) == 0 && (dgamma || dbeta || dbias))
-            hipLaunchKernelGGL(reduce3_kernel, dim3((H + 63) / 64, 3), dim3(256), 0, s, r, nblk, H, accumulate);
+        if ((H % 4) == 0 && (dgamma || dbeta || dbias)) {
+            bool queued = g_defer != nullptr && g_defer->njobs + 3 <= AMDSEG_MAX_REDUCE_JOBS && g_defer->accumulate == accumulate;
+            if (queued)
+                for (int k = 0; k < 3; ++k)
+                    if (r.out[k]) queued = defer_reduce(r.part[k], nblk, H, 0, H, r.out[k], accumulate) && queued;
+            if (!queued) hipLaunchKernelGGL(reduce3_kernel, dim3((H + 63) / 64, 3), dim3(256), 0, s, r, nblk, H, accumulate);
+        }
     }
     return amdseg_launch_status();
 }
