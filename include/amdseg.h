@@ -59,6 +59,12 @@ int amdseg_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
 int amdseg_gemm_tn_grouped(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                            float* const* C, const int* ldc, const int* N, const int* K, int M, int accumulate,
                            amdseg_stream_t stream);
+/* the same plus the bias gradients of those Linear layers: colsum_out[i][N_i] (+)= sum_m A_i[m, :]  (entries / the array may be
+ *   NULL); colsum_scratch[i]: >= max(ceil(M/128), K_i/128) * N_i floats.  On the 256 x 128 kernel the sums are taken from the GEMM's own A
+ *   fragments (no second pass over dY). */
+int amdseg_gemm_tn_grouped_bias(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                                float* const* C, const int* ldc, const int* N, const int* K, int M, int accumulate,
+                                float* const* colsum_out, float* const* colsum_scratch, amdseg_stream_t stream);
 
 /* fp32 parity-mode GEMM (csrc/gemm_f32.hip): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), epilogue 0 none / 1 bias /
  * 2 bias+gelu_erf; M,N multiples of 128, K multiple of 32.  Same reference lines as amdseg_gemm_nt. */
@@ -241,7 +247,7 @@ typedef struct amdseg_bert_layer_acts {     /* caller-owned activations; all but
 
 typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across layers */
     void *dz2, *dbr2, *du, *dx1, *dz1, *dbr1, *dctx, *dqkv;  /* [M,H] [M,H] [M,I] [M,H] [M,H] [M,H] [M,H] [M,3H] */
-    float *delta, *partials;                /* [B*heads*L]; partials: 6*ceil(M/16)*H + ceil(M/128)*(I + nproj*H) floats (one
+    float *delta, *partials;                /* [B*heads*L]; partials: 6*ceil(M/16)*H + max(ceil(M/128), ceil(H/128))*(I + nproj*H) floats (one
                                                region per deferred reduction: LN2, b1, LN1, bqkv) */
 } amdseg_bert_layer_ws;
 

@@ -38,6 +38,11 @@ int amdseg_dropout_impl(const void* x, void* y, size_t n, float p, uint64_t seed
 int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K, hipStream_t s);
 int amdseg_set_force_small_tile(int v);
 void amdseg_reduce_defer_begin(int accumulate);
+// out[j] (+)= sum_b partials[b * stride + j], j < n (queued if a deferred batch is open)
+void amdseg_reduce_rows(const float* partials, int nblocks, int stride, int n, float* out, int accumulate, hipStream_t s);
+int amdseg_gemm_tn_grouped_bias_impl(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                                     float* const* C, const int* ldc, const int* N, const int* Kp, int M, int accumulate,
+                                     float* const* colsum_out, float* const* colsum_scratch, hipStream_t stream);
 int amdseg_reduce_defer_flush(hipStream_t s);
 int amdseg_attn_list_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                               const int* klist, const int* kcnt, int list_stride, hipStream_t s);

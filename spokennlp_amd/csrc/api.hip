@@ -1,6 +1,7 @@
 // extern "C" surface of libamdseg (declared in include/amdseg.h) + the composite BertLayer forward/backward drivers.
 #include "../../include/amdseg.h"
 #include "amdseg_internal.h"
+#include <algorithm>
 #include "common.h"
 
 #define S(x) ((hipStream_t)(x))
@@ -27,6 +28,11 @@ int amdseg_gemm_tn_grouped(int nprob, const void* const* A, const int* lda, cons
                            float* const* C, const int* ldc, const int* N, const int* K, int M, int accumulate,
                            amdseg_stream_t stream) {
     return amdseg_gemm_tn_grouped_impl(nprob, A, lda, B, ldb, C, ldc, N, K, M, accumulate, S(stream));
+}
+int amdseg_gemm_tn_grouped_bias(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                                float* const* C, const int* ldc, const int* N, const int* K, int M, int accumulate,
+                                float* const* colsum_out, float* const* colsum_scratch, amdseg_stream_t stream) {
+    return amdseg_gemm_tn_grouped_bias_impl(nprob, A, lda, B, ldb, C, ldc, N, K, M, accumulate, colsum_out, colsum_scratch, S(stream));
 }
 int amdseg_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, int epilogue,
                        const float* bias, amdseg_stream_t stream) {
@@ -264,7 +270,8 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     // the four second-stage reductions of the layer (LN2, b1, LN1, bqkv) are queued and run as ONE kernel at the end of this
     // call; each producer therefore gets its own region of ws.partials (include/amdseg.h: amdseg_bert_layer_ws)
     const int NPd = NPROJ(c);
-    const size_t ln_part = (size_t)3 * ((M + 15) / 16) * H, cs_rows = (size_t)((M + 127) / 128);
+    // (bias-gradient regions: ceil(M/128) rows for amdseg_colsum, H/128 rows for the partials of the fused weight-gradient kernel)
+    const size_t ln_part = (size_t)3 * ((M + 15) / 16) * H, cs_rows = (size_t)std::max((M + 127) / 128, (H + 127) / 128);
     float* part_ln2 = w->partials;
     float* part_b1 = part_ln2 + ln_part;
     float* part_ln1 = part_b1 + cs_rows * I;
@@ -280,7 +287,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD | (c->act ? AMDSEG_EPI_ACT_TANH : 0), nullptr, a->u, I, nullptr, 0, 0, s));
     // dx1 = du . W1 + dz2
     RET_IF(amdseg_gemm_nt_impl(w->du, I, p->w1_t, I, w->dx1, H, M, H, I, AMDSEG_EPI_ADD_RES, nullptr, w->dz2, H, nullptr, 0, 0, s));
-    RET_IF(amdseg_colsum_impl(w->du, I, part_b1, g->b1, M, I, acc, c->dtype, s));
+    // (db1 = colsum(du) and dbqkv = colsum(dqkv) come out of the grouped weight-gradient GEMM below)
     // LN1 backward
     RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, part_ln1, g->ln1_g,
                               g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, c->dtype, s));
@@ -294,7 +301,6 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
                                     site_seed(c->seed, li, 0), c->window, c->nglobal, s));
     // dx_in = dqkv . Wqkv + dz1   (external mixer: the caller wrote ws.dqkv [M, nproj*H] between the phases)
     RET_IF(amdseg_gemm_nt_impl(w->dqkv, NP, p->wqkv_t, NP, dx_in, H, M, H, NP, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s));
-    RET_IF(amdseg_colsum_impl(w->dqkv, NP, part_bqkv, g->bqkv, M, NP, acc, c->dtype, s));
     }
     if (!PHASE_WGRAD(c)) return AMDSEG_OK;
     // all four weight gradients of the layer in one grouped launch: dW = dY^T X
@@ -303,7 +309,9 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     float* C[4] = {g->w2, g->w1, g->wo, g->wqkv};
     const int lda[4] = {H, I, H, NP}, ldb[4] = {I, H, H, H}, ldc[4] = {I, H, H, H};
     const int N[4] = {H, I, H, NP}, K[4] = {I, H, H, H};
-    RET_IF(amdseg_gemm_tn_grouped_impl(4, A, lda, Bm, ldb, C, ldc, N, K, M, acc, s));
+    float* cs_out[4] = {nullptr, g->b1, nullptr, g->bqkv};
+    float* cs_scr[4] = {nullptr, part_b1, nullptr, part_bqkv};
+    RET_IF(amdseg_gemm_tn_grouped_bias_impl(4, A, lda, Bm, ldb, C, ldc, N, K, M, acc, cs_out, cs_scr, s));
     return AMDSEG_OK;
 }
 

@@ -400,6 +400,10 @@ static inline void launch_reduce(const float* partials, int nblocks, int stride,
     hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblocks, stride, offset, n, out, accumulate);
 }
 
+void amdseg_reduce_rows(const float* partials, int nblocks, int stride, int n, float* out, int accumulate, hipStream_t s) {
+    launch_reduce(partials, nblocks, stride, 0, n, out, accumulate, s);
+}
+
 // ------------------------------------------------------------------------------------------------ column sums
 // x[M, ld] (first N columns) -> partials[nblk][N]; block = 256 threads = 32 column-chunks(8) x 8 row lanes
 #define CS_ROWS 128

@@ -767,6 +767,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNArgs a) {
 int amdseg_gemm_tn_grouped_impl(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                                 float* const* C, const int* ldc, const int* N, const int* Kp, int M, int accumulate,
                                 hipStream_t stream) {
+    return amdseg_gemm_tn_grouped_bias_impl(nprob, A, lda, B, ldb, C, ldc, N, Kp, M, accumulate, nullptr, nullptr, stream);
+}
+
+// the same, plus optional bias gradients: colsum_out[i] (+)= column sums of A[i] over the M rows (colsum_out[i] may be NULL);
+// colsum_scratch[i]: >= max(ceil(M/128), Kp[i]/128) * N[i] floats, untouched until the queued reductions have run.  With the deep-pipeline
+// kernel the sums come out of the GEMM's own A fragments (no extra pass over dY); otherwise amdseg_colsum runs.
+int amdseg_gemm_tn_grouped_bias_impl(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                                     float* const* C, const int* ldc, const int* N, const int* Kp, int M, int accumulate,
+                                     float* const* colsum_out, float* const* colsum_scratch, hipStream_t stream) {
     if (nprob <= 0 || nprob > AMDSEG_MAX_GROUP || !A || !B || !C) return AMDSEG_ERR_ARG;
     if (M <= 0 || (M % 64)) return AMDSEG_ERR_SHAPE;
     GemmTNArgs a;
@@ -778,6 +787,8 @@ int amdseg_gemm_tn_grouped_impl(int nprob, const void* const* A, const int* lda,
         P.A = (const bf16_t*)A[i]; P.B = (const bf16_t*)B[i]; P.C = C[i];
         P.N = N[i]; P.Kp = Kp[i]; P.lda = lda[i]; P.ldb = ldb[i]; P.ldc = ldc[i];
         P.tile_begin = tiles; P.tiles_k = Kp[i] / 128;
+        P.colsum_part = nullptr;
+        if (colsum_out && colsum_out[i] && !(colsum_scratch && colsum_scratch[i])) return AMDSEG_ERR_ARG;
         tiles += (N[i] / 128) * (Kp[i] / 128);
     }
     for (int i = nprob; i < AMDSEG_MAX_GROUP; ++i) a.p[i] = a.p[0];
@@ -787,7 +798,20 @@ int amdseg_gemm_tn_grouped_impl(int nprob, const void* const* A, const int* lda,
     if (tn_dp < 0) { const char* e = getenv("AMDSEG_TN_DP"); tn_dp = e ? atoi(e) : 1; }
     bool dp = tn_dp && M >= 128 && !g_force_small_tile;
     for (int i = 0; i < nprob; ++i) dp = dp && (N[i] % 256) == 0;
-    if (dp) return amdseg_launch_tn_dp(a, stream);
+    if (dp) {
+        for (int i = 0; i < nprob; ++i)
+            if (colsum_out && colsum_out[i]) a.p[i].colsum_part = colsum_scratch[i];
+        int rc = amdseg_launch_tn_dp(a, stream);
+        if (rc) return rc;
+        for (int i = 0; i < nprob; ++i)                     // out[n] (+)= sum over the K' tiles of the per-tile partials
+            if (colsum_out && colsum_out[i]) amdseg_reduce_rows(colsum_scratch[i], Kp[i] / 128, N[i], N[i], colsum_out[i], accumulate, stream);
+        return amdseg_launch_status();
+    }
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles), dim3(256), 0, stream, a);
+    for (int i = 0; i < nprob; ++i)
+        if (colsum_out && colsum_out[i]) {
+            int rc = amdseg_colsum_impl(A[i], lda[i], colsum_scratch[i], colsum_out[i], M, N[i], accumulate, AMDSEG_BF16, stream);
+            if (rc) return rc;
+        }
     return amdseg_launch_status();
 }

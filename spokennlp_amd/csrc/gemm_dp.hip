@@ -232,6 +232,7 @@ DP_INST(EPI_BIAS_GELU_TANH, bf16_t) DP_INST(EPI_GELU_BWD_TANH, bf16_t)
 #define TN_STG 49152
 #define TN_LDS (3 * TN_STG)
 typedef int tn_i32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 tn_bf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int tn_swz(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
 // wave-uniform pointer the loop optimiser cannot turn into per-lane 64-bit induction variables (24 VGPRs of DMA addresses otherwise)
 __device__ __forceinline__ const bf16_t* tn_uniform(const bf16_t* p) {
@@ -278,6 +279,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = a.M / 64;
+    // fused bias gradient: column sums of A (= dY) for free -- the A fragments are in registers anyway.  Tile (tn, tk) sums the K tiles
+    // kt = tk (mod tiles_k) with v_dot2c_f32_bf16 against (1, 1) (4 per fragment, only the wc == 0 waves, ~1/tiles_k of the K tiles),
+    // writes its partial to colsum_part[tk][n]; the host queues the sum over tk (deterministic second stage)
+    const bool cs_on = P.colsum_part != nullptr && wc == 0;
+    float accb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accb[i] = 0.f;
+    int cs_phase = 0;                                       // kt mod tiles_k
     TN_DMA(0, 0);
     TN_DMA(1, min(1, nk - 1));                              // always three tiles (clamped): the vmcnt arithmetic below is uniform
     TN_DMA(2, min(2, nk - 1));
@@ -302,6 +311,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
 #define TN_CAT(x) __builtin_bit_cast(bf16x8, __builtin_shufflevector(x[0], x[1], 0, 1, 2, 3))
 #define TN_SB() __builtin_amdgcn_sched_barrier(0)
 #define TN_MF(nf, e, FB) acc[nf][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN_CAT(FB[e]), TN_CAT(fa[nf]), acc[nf][e], 0, 0, 0)
+#define TN_DOT2(x, c) __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tn_bf2, x), __builtin_bit_cast(tn_bf2, 0x3f803f80), c, false)
+// (the elements are copied to plain ints first: __builtin_bit_cast applied directly to an ext-vector ELEMENT expression reads element 0
+//  whatever the index -- seen with hipcc 7.2: `bit_cast<bf2>(v.y)` compiled to the same register as `bit_cast<bf2>(v.x)`)
+#define TN_CS(nf) do { const tn_i32x2 c0_ = fa[nf][0], c1_ = fa[nf][1]; const int e0_ = c0_.x, e1_ = c0_.y, e2_ = c1_.x, e3_ = c1_.y; \
+                       accb[nf] = TN_DOT2(e0_, accb[nf]); accb[nf] = TN_DOT2(e1_, accb[nf]); \
+                       accb[nf] = TN_DOT2(e2_, accb[nf]); accb[nf] = TN_DOT2(e3_, accb[nf]); } while (0)
 #define TN_WAIT_FRAGS(FB) asm volatile("s_waitcnt lgkmcnt(0)" \
         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), \
           "+v"(fa[4][0]), "+v"(fa[4][1]), "+v"(fa[5][0]), "+v"(fa[5][1]), "+v"(fa[6][0]), "+v"(fa[6][1]), "+v"(fa[7][0]), "+v"(fa[7][1]), \
@@ -320,14 +335,20 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
         TN_WAIT_FRAGS(FC); \
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          /* every K tile issues 6 pieces: tile kt+1 has landed */ \
         TN_SB(); __builtin_amdgcn_s_barrier(); TN_SB(); \
+        const bool cs_now = cs_on && cs_phase == tk; \
+        cs_phase = cs_phase + 1 == P.tiles_k ? 0 : cs_phase + 1; \
         const int ktd_ = min(kt + 3, nk - 1);          /* past the end: re-fetch the last tile into a stage nobody reads */ \
         _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4) { aA[c4] = laA[c4] + sn * TN_STG; aB[c4] = laB[c4] + sn * TN_STG; } \
         __builtin_amdgcn_s_setprio(1); \
         _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) { \
-            TN_MF(nf, 0, FC); TN_SB(); TN_MF(nf, 1, FC); TN_SB(); TN_LDB(nf, FN); TN_SB(); TN_MF(nf, 2, FC); TN_SB(); TN_MF(nf, 3, FC); TN_SB(); TN_LDA(nf); TN_SB(); \
+            TN_MF(nf, 0, FC); TN_SB(); TN_MF(nf, 1, FC); TN_SB(); TN_LDB(nf, FN); TN_SB(); TN_MF(nf, 2, FC); TN_SB(); TN_MF(nf, 3, FC); TN_SB(); \
+            if (cs_now) { TN_CS(nf); TN_SB(); } \
+            TN_LDA(nf); TN_SB(); \
             if (nf >= 1) { TN_DMA_PIECE(sc, ktd_, nf - 1); TN_SB(); } } \
         _Pragma("unroll") for (int nf = 4; nf < 8; ++nf) { \
-            TN_MF(nf, 0, FC); TN_MF(nf, 1, FC); TN_MF(nf, 2, FC); TN_MF(nf, 3, FC); TN_SB(); TN_LDA(nf); TN_SB(); \
+            TN_MF(nf, 0, FC); TN_MF(nf, 1, FC); TN_MF(nf, 2, FC); TN_MF(nf, 3, FC); TN_SB(); \
+            if (cs_now) { TN_CS(nf); TN_SB(); } \
+            TN_LDA(nf); TN_SB(); \
             if (nf <= 6) { TN_DMA_PIECE(sc, ktd_, nf - 1); TN_SB(); } } \
         __builtin_amdgcn_s_setprio(0); \
         sc = sc == 2 ? 0 : sc + 1; sn = sn == 2 ? 0 : sn + 1; } while (0)
@@ -368,6 +389,27 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
             float4* p = reinterpret_cast<float4*>(crow + e * 16);
             if (a.accumulate) { const float4 c = *p; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
             *p = v;
+        }
+    }
+    if (P.colsum_part != nullptr) {                         // workgroup-uniform
+        __syncthreads();                                    // the K-half exchange above has been read
+        float* csx = reinterpret_cast<float*>(smem);        // [2 wr][8 nf][16] partial sums of the kh = 1 waves
+        if (wc == 0) {
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf) {                // the 4 lane groups hold disjoint token slots of the same column
+                accb[nf] += __shfl_xor(accb[nf], 16, 64);
+                accb[nf] += __shfl_xor(accb[nf], 32, 64);
+            }
+            if (kh == 1 && g == 0) {
+#pragma unroll
+                for (int nf = 0; nf < 8; ++nf) csx[(wr * 8 + nf) * 16 + i16] = accb[nf];
+            }
+        }
+        __syncthreads();
+        if (wc == 0 && kh == 0 && g == 0) {
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf)
+                P.colsum_part[(size_t)tk * P.N + n0 + wr * 128 + nf * 16 + i16] = accb[nf] + csx[(wr * 8 + nf) * 16 + i16];
         }
     }
 }

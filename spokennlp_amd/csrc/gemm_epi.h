@@ -30,6 +30,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <int EPIX, typename OutT> int amdseg_launch_nt_dp(const GemmNTArgs& a, hipStream_t s);
 
 // grouped TN GEMM (weight gradients): launch arguments shared by gemm.hip (128 x 128 kernel) and gemm_dp.hip (256 x 128 kernel)
-struct TNProblem { const bf16_t* A; const bf16_t* B; float* C; int N, Kp, lda, ldb, ldc, tile_begin, tiles_k; };
+struct TNProblem { const bf16_t* A; const bf16_t* B; float* C; int N, Kp, lda, ldb, ldc, tile_begin, tiles_k;
+                   float* colsum_part; };   // optional [tiles_k][N] scratch: per-K'-tile partial column sums of A (bias gradient), dp kernel only
 struct GemmTNArgs { TNProblem p[AMDSEG_MAX_GROUP]; int nprob, M, accumulate, total_tiles; };
 int amdseg_launch_tn_dp(const GemmTNArgs& a128, hipStream_t s);

@@ -229,7 +229,7 @@ class BertEncoderEngine:
                  emb_z=e(M, H), emb_mean=e(M, dt=torch.float32), emb_rstd=e(M, dt=torch.float32),
                  mask_bias=e(B, Lseq, dt=torch.float32), out=e(M, H, dt=torch.float32))
         if train:
-            npart = 2 * ops.ln_partials_numel(M, H) + ((M + 127) // 128) * (I + self.nproj * H)      # include/amdseg.h: amdseg_bert_layer_ws
+            npart = 2 * ops.ln_partials_numel(M, H) + max((M + 127) // 128, (H + 127) // 128) * (I + self.nproj * H)   # amdseg.h: amdseg_bert_layer_ws
             def ws_set():
                 return dict(dz2=e(M, H), dbr2=e(M, H), du=e(M, I), dx1=e(M, H), dz1=e(M, H), dbr1=e(M, H), dctx=e(M, H),
                             dqkv=e(M, self.nproj * H), delta=e(B * self.heads * Lseq, dt=torch.float32),

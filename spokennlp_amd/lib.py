@@ -49,6 +49,8 @@ _PROTOS = {
     "amdseg_gemm_nt": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp],
     "amdseg_gemm_tn_grouped": [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp),
                                C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, i32, vp],
+    "amdseg_gemm_tn_grouped_bias": [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp),
+                                    C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, i32, C.POINTER(vp), C.POINTER(vp), vp],
     "amdseg_gemm_f32_nt": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp],
     "amdseg_attn_f32": [vp, vp, vp, i32, i32, i32, f32, vp],
     "amdseg_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],

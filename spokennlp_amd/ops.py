@@ -47,7 +47,7 @@ def gemm_nt(A, B, epilogue=EPI_NONE, bias=None, R=None, out=None, out2=None, out
     return (out, out2) if (epilogue & 0xff) == EPI_BIAS_GELU else out
 
 
-def gemm_tn_grouped(As, Bs, Cs, accumulate=False):
+def gemm_tn_grouped(As, Bs, Cs, accumulate=False, colsums=None):
     """For each i: Cs[i][N_i,K_i] (+)= As[i]^T @ Bs[i]  (As[i]: [M,N_i] bf16, Bs[i]: [M,K_i] bf16, Cs[i] fp32)."""
     n = len(As)
     M = As[0].shape[0]
@@ -59,8 +59,17 @@ def gemm_tn_grouped(As, Bs, Cs, accumulate=False):
     ic = (C.c_int * n)(*[c.stride(0) for c in Cs])
     nn = (C.c_int * n)(*[a.shape[1] for a in As])
     kk = (C.c_int * n)(*[b.shape[1] for b in Bs])
-    rc = L.load().amdseg_gemm_tn_grouped(n, vpa, ia, vpb, ib, vpc, ic, nn, kk, M, 1 if accumulate else 0, _s())
-    L.check(rc, "amdseg_gemm_tn_grouped")
+    if colsums is None:
+        rc = L.load().amdseg_gemm_tn_grouped(n, vpa, ia, vpb, ib, vpc, ic, nn, kk, M, 1 if accumulate else 0, _s())
+        L.check(rc, "amdseg_gemm_tn_grouped")
+        return Cs
+    # bias gradients: colsums[i] (fp32 [N_i] or None) (+)= column sums of As[i]
+    scratch = [None if c is None else torch.empty(max((M + 127) // 128, b.shape[1] // 128) * a.shape[1], dtype=torch.float32, device=a.device)
+               for a, b, c in zip(As, Bs, colsums)]
+    vpo = (C.c_void_p * n)(*[None if c is None else c.data_ptr() for c in colsums])
+    vps = (C.c_void_p * n)(*[None if c is None else c.data_ptr() for c in scratch])
+    rc = L.load().amdseg_gemm_tn_grouped_bias(n, vpa, ia, vpb, ib, vpc, ic, nn, kk, M, 1 if accumulate else 0, vpo, vps, _s())
+    L.check(rc, "amdseg_gemm_tn_grouped_bias")
     return Cs
 
 

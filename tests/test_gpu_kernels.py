@@ -174,6 +174,19 @@ def test_gemm_tn_grouped_dp(dev, M):
     for a, b, c in zip(As, Bs, Cs):
         ref = 2 * (a.float().t() @ b.float())
         assert rel_err(c, ref) < 2e-6
+    # fused bias gradients (column sums of A from the GEMM's own fragments), two of the four problems, overwrite then accumulate
+    cs = [None, torch.full((shapes[1][0],), 3.0, device=dev), None, torch.full((shapes[3][0],), 3.0, device=dev)]
+    C3 = [torch.empty_like(c) for c in Cs]
+    ops.gemm_tn_grouped(As, Bs, C3, accumulate=False, colsums=cs)
+    for i in (1, 3):
+        ref = As[i].float().sum(0)
+        assert (cs[i] - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item()), i
+    ops.gemm_tn_grouped(As, Bs, C3, accumulate=True, colsums=cs)
+    for i in (1, 3):
+        ref = 2 * As[i].float().sum(0)
+        assert (cs[i] - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item()), i
+    for a, b, c in zip(As, Bs, C3):
+        assert rel_err(c, 2 * (a.float().t() @ b.float())) < 2e-6
     old = ops.L.load().amdseg_debug_force_small_tile(1)
     try:
         C2 = [torch.empty_like(c) for c in Cs]
