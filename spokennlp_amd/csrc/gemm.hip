@@ -584,7 +584,7 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     // K = 3072 / 2304: 74-79 / 58 us vs 90 / 68 (ping-pong).  For K = 768 it also wins the back-to-back microbenchmark (QKV 64.5 vs
     // 72 us, dual-output FFN 129 vs 143, GELU-bwd 106 vs 128) but NOT the training step (18.24 vs 18.17 ms): with cold
     // operands its single workgroup per CU hides HBM latency worse than two 128x128 workgroups -- AMDSEG_DP_MIN_K selects
-    if ((a_in.M % 256) == 0 && (a_in.N % 256) == 0 && a_in.K >= dp_min_k && !g_force_small_tile)
+    if ((a_in.M % 256) == 0 && ((a_in.N % 256) == 0 || (a_in.N % 192) == 0) && a_in.K >= dp_min_k && !g_force_small_tile)
         return amdseg_launch_nt_dp<EPIX, OutT>(a_in, s);
     // the ping-pong kernel counts its in-flight stores (two outputs for BIAS_GELU): the single-output form runs on the 128x128 kernel
     const bool single_gelu = EPI == EPI_BIAS_GELU && !a_in.C2;

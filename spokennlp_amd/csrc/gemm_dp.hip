@@ -35,9 +35,12 @@ __device__ __forceinline__ void dp_glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(void, lds_wave_base), 16, 0, 0);
 }
 
-template <int EPIX, typename OutT>
+// NF = 16-column fragments per column wave: 4 -> 256 x 256 tile, 3 -> 256 x 192 tile (wave tile 128 x 48, three B images per stage)
+// for widths that are multiples of 192 but not of 256.
+template <int EPIX, typename OutT, int NF>
 __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
+    constexpr int BN = NF * 64, WN = NF * 16, STAGE = (4 + NF) * 8192;     // tile width, wave-tile width, bytes per LDS stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -50,11 +53,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     const int gmn = min(a.tiles_m - first_m, GROUP_M);
     const int rem = t - grp * gsz_full;
     const int tm = first_m + rem % gmn, tn = rem / gmn;
-    const int m0 = tm * DP_BM, n0 = tn * DP_BN;
-#define DP_TILE_A(s, i) (smem + (s) * DP_STAGE + (i) * 8192)
-#define DP_TILE_B(s, i) (smem + (s) * DP_STAGE + (4 + (i)) * 8192)
+    const int m0 = tm * DP_BM, n0 = tn * BN;
+#define DP_TILE_A(s, i) (smem + (s) * STAGE + (i) * 8192)
+#define DP_TILE_B(s, i) (smem + (s) * STAGE + (4 + (i)) * 8192)
     const bf16_t* pA = a.A + (size_t)(m0 + wr * 128) * a.lda;                 // this group's A rows
-    const bf16_t* pB = a.B + (size_t)(n0 + wr * 128) * a.ldb;                 // this group's DMA duty on B: tile images 2wr, 2wr+1
+    const bf16_t* pB = a.B + (size_t)(n0 + wr * 128) * a.ldb;                 // this group's DMA duty on B: tile images 2wr, 2wr+1 (NF = 3: group 1 has image 2 only)
+    const bool b2 = NF == 4 || wr == 0;                                       // two B images for this group
+    const bool vm8 = b2;                                                      // pieces per wave and K tile: 4 (A) + 4 or 2 (B)
     uint32_t offA[4], offB[4];                                                // lane BYTE offsets, constant over K (saddr + voffset loads)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -67,26 +72,31 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     // SGPR base + 32-bit lane byte offset: no VALU address arithmetic where the pieces are issued
 #define DP_DMA_A(s, i, kt) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
         amdseg_glds16_saddr(pA + (kt) * 64, offA[(i) * 2 + q], DP_TILE_A(s, wr * 2 + (i)) + (wq * 2 + q) * 1024);
-#define DP_DMA_B(s, kt) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
+#define DP_DMA_B(s, kt) _Pragma("unroll") for (int i = 0; i < 2; ++i) if (i == 0 || b2) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
         amdseg_glds16_saddr(pB + (kt) * 64, offB[i * 2 + q], DP_TILE_B(s, wr * 2 + i) + (wq * 2 + q) * 1024);
-    f32x4 acc[8][4];
+#define DP_WAIT_TILE() do { if (vm8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
+    f32x4 acc[8][NF];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = a.K / 64;
     DP_DMA_A(0, 0, 0) DP_DMA_A(0, 1, 0) DP_DMA_B(0, 0)
-    if (nk > 1) { DP_DMA_A(1, 0, 1) DP_DMA_A(1, 1, 1) DP_DMA_B(1, 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    if (nk > 1) { DP_DMA_A(1, 0, 1) DP_DMA_A(1, 1, 1) DP_DMA_B(1, 1) DP_WAIT_TILE(); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();             // stagger: group 1 runs one barrier behind group 0
-    bf16x8 fa[4][2], fb[4][2];
+    bf16x8 fa[4][2], fb[NF][2];
+    // column e*16 + i16 of the wave's WN columns -> (B image, row): wave-uniform per fragment (WN = 48 straddles images)
+    int fbi[NF], fbr[NF];
+#pragma unroll
+    for (int e = 0; e < NF; ++e) { const int c = wc * WN + e * 16; fbi[e] = c >> 6; fbr[e] = c & 63; }
 #define DP_LOAD_A(s, h) _Pragma("unroll") for (int f = 0; f < 4; ++f) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
         fa[f][kk] = dp_frag(DP_TILE_A(s, wr * 2 + (h)), f * 16 + i16, kk * 4 + g);
-#define DP_LOAD_B(s) _Pragma("unroll") for (int e = 0; e < 4; ++e) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
-        fb[e][kk] = dp_frag(DP_TILE_B(s, wc), e * 16 + i16, kk * 4 + g);
+#define DP_LOAD_B(s) _Pragma("unroll") for (int e = 0; e < NF; ++e) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+        fb[e][kk] = dp_frag(DP_TILE_B(s, fbi[e]), fbr[e] + i16, kk * 4 + g);
 #define DP_MFMA(ah) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int f = 0; f < 4; ++f) \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) \
+        _Pragma("unroll") for (int e = 0; e < NF; ++e) \
         acc[(ah) * 4 + f][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[e][kk], fa[f][kk], acc[(ah) * 4 + f][e], 0, 0, 0);
 #define DP_MID() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
 #define DP_END() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         DP_LOAD_B(s) DP_LOAD_A(s, 0)
         if (kt >= 1 && kt + 1 < nk) { DP_DMA_A(s ^ 1, 1, kt + 1) }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kt >= 1 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt >= 1 && kt + 1 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DP_MID();
         DP_MFMA(0)
         DP_END();
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         DP_LOAD_A(s, 1)
         if (kt + 2 < nk) { DP_DMA_A(s, 0, kt + 2) DP_DMA_B(s, kt + 2) }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 2 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DP_MID();
         DP_MFMA(1)
         DP_END();
@@ -115,10 +125,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 
     // ---- epilogue.  Lane owns row m = mf*16 + i16 and columns nf*16 + g*4 .. +4 of the wave tile.  bf16 results go through a
     // wave-private 16-KiB LDS image (2 x [64 rows][128 B], swizzled) so every global store instruction writes 8 full 128-B lines.
-    float4 bv[4];
+    float4 bv[NF];
     if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const float4*>(a.bias + n0 + wc * 64 + nf * 16 + g * 4);
+        for (int nf = 0; nf < NF; ++nf) bv[nf] = *reinterpret_cast<const float4*>(a.bias + n0 + wc * WN + nf * 16 + g * 4);
     }
     // the bias goes INTO the accumulators once: recomputing acc + bias in both passes of BIAS_GELU made the compiler keep all
     // 128 sums of pass 0 alive for pass 1 (common subexpression) next to the 128 accumulators -> 116 spilled VGPRs
@@ -126,12 +136,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) { acc[mf][nf][0] += bv[nf].x; acc[mf][nf][1] += bv[nf].y; acc[mf][nf][2] += bv[nf].z; acc[mf][nf][3] += bv[nf].w; }
+            for (int nf = 0; nf < NF; ++nf) { acc[mf][nf][0] += bv[nf].x; acc[mf][nf][1] += bv[nf].y; acc[mf][nf][2] += bv[nf].z; acc[mf][nf][3] += bv[nf].w; }
     }
     constexpr bool STAGED = sizeof(OutT) == 2;
     char* stg = smem + w * 16384;
 #define DP_STG_OFF(r, c16) (((r) >> 6) * 8192 + ((r) & 63) * 128 + ((((c16) ^ (((r) & 63) ^ (((r) & 63) >> 3))) & 7) << 4))
-    const int col0 = n0 + wc * 64;
+    const int col0 = n0 + wc * WN;
 #pragma unroll
     for (int pass = 0; pass < (EPI == EPI_BIAS_GELU ? 2 : 1); ++pass) {
         // pass 0 of BIAS_GELU writes the pre-activation (C2), pass 1 the activation; other epilogues have one pass
@@ -139,13 +149,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf) {
             const size_t gm = (size_t)(m0 + wr * 128 + mf * 16 + i16);
-            uint2 rr[4];
+            uint2 rr[NF];
             if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf) rr[nf] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + col0 + nf * 16 + g * 4);
+                for (int nf = 0; nf < NF; ++nf) rr[nf] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + col0 + nf * 16 + g * 4);
             }
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
+            for (int nf = 0; nf < NF; ++nf) {
                 float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
                 if (EPI == EPI_BIAS_GELU && pass == 1) {
                     gelu_act4(v, ACT);
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
             for (int p = 0; p < 16; ++p) {
                 const int r = p * 8 + rr0;
                 const uint4 val = *reinterpret_cast<const uint4*>(stg + DP_STG_OFF(r, cc));
-                *reinterpret_cast<uint4*>(obase + (size_t)r * old) = val;
+                if (NF == 4 || cc < 2 * NF) *reinterpret_cast<uint4*>(obase + (size_t)r * old) = val;      // 48-column wave tile: 6 of the 8 chunks
             }
             __builtin_amdgcn_wave_barrier();              // the image is rewritten by the next pass
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -186,21 +196,36 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     }
 }
 
-template <int EPIX, typename OutT>
-int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
-    constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
+template <int EPIX, typename OutT, int NF>
+static int launch_nt_dp_nf(const GemmNTArgs& a_in, hipStream_t s) {
     static bool attr_set = false;
+    constexpr int LDS = 8 * 16384;          // two stages (NF = 4: exactly this, NF = 3: 112 KiB) or the epilogue's 8 x 16-KiB wave images
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dp_kernel<EPIX, OutT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dp_kernel<EPIX, OutT, NF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     GemmNTArgs a = a_in;
-    a.tiles_m = a.M / DP_BM; a.tiles_n = a.N / DP_BN;
-    hipLaunchKernelGGL((gemm_nt_dp_kernel<EPIX, OutT>), dim3(a.tiles_m * a.tiles_n), dim3(512), DP_LDS, s, a);
+    a.tiles_m = a.M / DP_BM; a.tiles_n = a.N / (NF * 64);
+    hipLaunchKernelGGL((gemm_nt_dp_kernel<EPIX, OutT, NF>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS, s, a);
     return amdseg_launch_status();
 }
+
+// tile width: 256 whenever N allows it, 192 for the other multiples of 192.  Picking 192 for wave quantisation (N = 768: 256 tiles
+// instead of 192, N = 2304: 3 full rounds instead of 2.25) measured NO gain in the training step (QKV 67.1 vs 68.6 us, N = 768
+// K = 3072 78.3 vs 79.8, N = 768 K = 768 27.0 vs 25.0): the chip is clock/power limited under MFMA load, 192 busy CUs run as fast
+// as 256 at 0.75 of the work each.  AMDSEG_DP_BN=192 forces the narrow tile where both fit.
+template <int EPIX, typename OutT>
+int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
+    const bool ok256 = (a_in.N % 256) == 0, ok192 = (a_in.N % 192) == 0;
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("AMDSEG_DP_BN"); force = e ? atoi(e) : 0; }
+    const bool use192 = ok192 && (!ok256 || force == 192);
+    if (use192) return launch_nt_dp_nf<EPIX, OutT, 3>(a_in, s);
+    return launch_nt_dp_nf<EPIX, OutT, 4>(a_in, s);
+}
+
 
 #define DP_INST(E, T) template int amdseg_launch_nt_dp<E, T>(const GemmNTArgs&, hipStream_t);
 DP_INST(EPI_NONE, bf16_t) DP_INST(EPI_NONE, float) DP_INST(EPI_BIAS, bf16_t) DP_INST(EPI_BIAS, float) DP_INST(EPI_BIAS_GELU, bf16_t)

@@ -77,9 +77,20 @@ def test_gemm_nt_epilogues(dev):
     assert rel_err(C, base * gelu_grad(R.float())) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (512, 1024, 1536), (512, 2304, 768), (256, 192, 1024), (768, 3072, 768), (256, 576, 832), (512, 960, 768)])
+def test_gemm_nt_deep_pipeline_kernel_epilogues(dev, M, N, K):
+    """K >= 768, M % 256 == 0 and N % 256 == 0 or N % 192 == 0: the deep-pipeline kernel, 256 x 256 or 256 x 192 tiles (whichever
+    when N is no multiple of 256; K tiles odd and even); all epilogues, fp32 output, exact integers, strided views"""
+    _check_all_epilogues(dev, M, N, K)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 192, 64), (512, 384, 320), (768, 960, 128)])
 def test_gemm_nt_pingpong_kernel_epilogues(dev, M, N, K):
-    """shapes with M % 256 == 0 and N % 192 == 0 take the 256x192 ping-pong kernel; all epilogues + fp32 output."""
+    """shapes with M % 256 == 0 and N % 192 == 0 (K < 768) take the 256x192 ping-pong kernel; all epilogues + fp32 output."""
+    _check_all_epilogues(dev, M, N, K)
+
+
+def _check_all_epilogues(dev, M, N, K):
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(M * 3 + N + K)
     A = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16()
