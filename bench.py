@@ -136,12 +136,12 @@ def gemm_roofline(model, args, device):
         f = 2.0 * M * N * K
         detail.append(dict(N=N, K=K, epi=epi, us=round(t * 1e6, 1), tflops=round(f / t / 1e12, 1)))
         tot_t += t * calls; tot_f += f * calls; launches += calls
-    # HBM bytes per launch from the PMC passes committed in profiles/r01_pmc_gemm_nt.md (2 x FETCH_SIZE + WRITE_SIZE, gfx950
+    # HBM bytes per launch from the PMC passes committed in profiles/r01_pmc_gemm_nt_v2.md (2 x FETCH_SIZE + WRITE_SIZE, gfx950
     # correction applied); PMC counters cannot be read from inside this process, so the figure is quoted only for the
     # configuration it was measured on
-    traffic = 1.94e8 if (M == 16384 and H == 768 and I == 3072) else None
+    traffic = 1.80e8 if (M == 16384 and H == 768 and I == 3072) else None      # profiles/r01_pmc_gemm_nt_v2.md
     return dict(bound="mfma", achieved=round(tot_f / tot_t / 1e12, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(tot_f / tot_t / 1e12 / MFMA_PEAK_TFLOPS, 4), traffic=traffic, kernel="gemm_nt_kernel",
+                frac=round(tot_f / tot_t / 1e12 / MFMA_PEAK_TFLOPS, 4), traffic=traffic, kernel="gemm_nt_dp_kernel",
                 avg_launch_us=round(tot_t / launches * 1e6, 1), per_shape=detail)
 
 
