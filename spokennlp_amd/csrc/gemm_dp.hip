@@ -31,6 +31,14 @@ __device__ __forceinline__ int dp_swz(int r) { const int p = (r >> 1) & 7; retur
 __device__ __forceinline__ bf16x8 dp_frag(const char* tile, int r, int c) {
     return *reinterpret_cast<const bf16x8*>(tile + r * 128 + ((c ^ dp_swz(r)) << 4));
 }
+// B images of the 256-wide tile: fragment e of a column wave reads the PERMUTED rows n = (e >> 1)*32 + (i16 >> 2)*8 + (e & 1)*4 + (i16 & 3),
+// so that a lane's accumulators of the fragment pair (2j, 2j+1) are 8 CONSECUTIVE output columns (g*8 .. +8 of the pair's 32): the
+// epilogue then stores 16 bytes per lane straight from registers (no LDS staging pass).  The row class that the swizzle keys on is
+// u(r) = ((r >> 3) & 3)*2 + ((r >> 1) & 1) = i16 >> 1 of the reading lane, i.e. the same lane-group structure dp_swz was derived for.
+__device__ __forceinline__ int dp_swzB(int r) { const int p = ((r >> 3) & 3) * 2 + ((r >> 1) & 1); return p ^ (((p + 2) >> 2) & 1); }
+__device__ __forceinline__ bf16x8 dp_fragB(const char* tile, int r, int c) {
+    return *reinterpret_cast<const bf16x8*>(tile + r * 128 + ((c ^ dp_swzB(r)) << 4));
+}
 __device__ __forceinline__ void dp_glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(void, lds_wave_base), 16, 0, 0);
 }
@@ -65,9 +73,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int r = (wq * 2 + q) * 8 + (l >> 3), c = (l & 7) ^ dp_swz(r);
+            const int r = (wq * 2 + q) * 8 + (l >> 3), c = (l & 7) ^ dp_swz(r), cb = NF == 4 ? ((l & 7) ^ dp_swzB(r)) : c;
             offA[i * 2 + q] = ((i * 64 + r) * a.lda + c * 8) * 2;
-            offB[i * 2 + q] = ((i * 64 + r) * a.ldb + c * 8) * 2;
+            offB[i * 2 + q] = ((i * 64 + r) * a.ldb + cb * 8) * 2;
         }
     // SGPR base + 32-bit lane byte offset: no VALU address arithmetic where the pieces are issued
 #define DP_DMA_A(s, i, kt) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
@@ -94,7 +102,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #define DP_LOAD_A(s, h) _Pragma("unroll") for (int f = 0; f < 4; ++f) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
         fa[f][kk] = dp_frag(DP_TILE_A(s, wr * 2 + (h)), f * 16 + i16, kk * 4 + g);
 #define DP_LOAD_B(s) _Pragma("unroll") for (int e = 0; e < NF; ++e) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
-        fb[e][kk] = dp_frag(DP_TILE_B(s, fbi[e]), fbr[e] + i16, kk * 4 + g);
+        fb[e][kk] = NF == 4 ? dp_fragB(DP_TILE_B(s, wc), (e >> 1) * 32 + (i16 >> 2) * 8 + (e & 1) * 4 + (i16 & 3), kk * 4 + g) \
+                            : dp_frag(DP_TILE_B(s, fbi[e]), fbr[e] + i16, kk * 4 + g);
 #define DP_MFMA(ah) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int f = 0; f < 4; ++f) \
         _Pragma("unroll") for (int e = 0; e < NF; ++e) \
         acc[(ah) * 4 + f][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[e][kk], fa[f][kk], acc[(ah) * 4 + f][e], 0, 0, 0);
@@ -128,7 +137,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     float4 bv[NF];
     if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) bv[nf] = *reinterpret_cast<const float4*>(a.bias + n0 + wc * WN + nf * 16 + g * 4);
+        for (int nf = 0; nf < NF; ++nf)
+            bv[nf] = *reinterpret_cast<const float4*>(a.bias + n0 + wc * WN + (NF == 4 ? (nf >> 1) * 32 + g * 8 + (nf & 1) * 4 : nf * 16 + g * 4));
     }
     // the bias goes INTO the accumulators once: recomputing acc + bias in both passes of BIAS_GELU made the compiler keep all
     // 128 sums of pass 0 alive for pass 1 (common subexpression) next to the 128 accumulators -> 116 spilled VGPRs
@@ -137,6 +147,53 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) { acc[mf][nf][0] += bv[nf].x; acc[mf][nf][1] += bv[nf].y; acc[mf][nf][2] += bv[nf].z; acc[mf][nf][3] += bv[nf].w; }
+    }
+    if (NF == 4) {
+        // ---- direct epilogue (256-wide tile): lane owns row m = mf*16 + i16 and the 8 consecutive columns ep*32 + g*8 .. +8 of its wave's 64
+#pragma unroll
+        for (int pass = 0; pass < (EPI == EPI_BIAS_GELU ? 2 : 1); ++pass) {
+            if (EPI == EPI_BIAS_GELU && pass == 0 && !a.C2) continue;
+#pragma unroll
+            for (int mf = 0; mf < 8; ++mf) {
+                const size_t gm = (size_t)(m0 + wr * 128 + mf * 16 + i16);
+                uint4 rr[2];
+                if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+#pragma unroll
+                    for (int ep = 0; ep < 2; ++ep) rr[ep] = *reinterpret_cast<const uint4*>(a.R + gm * a.ldr + n0 + wc * 64 + ep * 32 + g * 8);
+                }
+#pragma unroll
+                for (int ep = 0; ep < 2; ++ep) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * ep][r]; v[4 + r] = acc[mf][2 * ep + 1][r]; }
+                    if (EPI == EPI_BIAS_GELU && pass == 1) {
+                        gelu_act4(v, ACT); gelu_act4(v + 4, ACT);
+                    } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+                        const uint32_t rw[4] = {rr[ep].x, rr[ep].y, rr[ep].z, rr[ep].w};
+                        float rf[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { rf[2 * q] = __uint_as_float(rw[q] << 16); rf[2 * q + 1] = __uint_as_float(rw[q] & 0xffff0000u); }
+                        if (EPI == EPI_ADD_RES) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] += rf[q];
+                        } else { gelu_grad_mul4(v, rf[0], rf[1], rf[2], rf[3], ACT); gelu_grad_mul4(v + 4, rf[4], rf[5], rf[6], rf[7], ACT); }
+                    }
+                    const size_t col = (size_t)(n0 + wc * 64 + ep * 32 + g * 8);
+                    if (sizeof(OutT) == 2) {
+                        bf16_t* ob = (EPI == EPI_BIAS_GELU && pass == 0) ? a.C2 : reinterpret_cast<bf16_t*>(a.C);
+                        const int old = (EPI == EPI_BIAS_GELU && pass == 0) ? a.ldc2 : a.ldc;
+                        uint4 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+                        *reinterpret_cast<uint4*>(ob + gm * old + col) = pk;
+                    } else {
+                        float* dst = reinterpret_cast<float*>(a.C) + gm * a.ldc + col;
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
     }
     constexpr bool STAGED = sizeof(OutT) == 2;
     char* stg = smem + w * 16384;
