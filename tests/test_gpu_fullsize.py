@@ -176,3 +176,81 @@ def test_bad_shapes_and_devices_fail_loudly(dev):
     m_cpu, _ = _tiny(torch.device("cpu"))
     with pytest.raises(AmdsegError):
         m_cpu(**batch)
+
+
+# ------------------------------------------------------------------------------------------------ the reference itself at full size
+def _fullsize_case():
+    import numpy as np
+    from tests.util import tiny_state_dict
+    from tests.test_oracle_golden import flags_of
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bert_base_L512.npz"), allow_pickle=False)
+    arch = dict(zip(z["arch_keys"].tolist(), [int(v) for v in z["arch_vals"].tolist()]))
+    sd = tiny_state_dict(arch, seed=int(z["seed"]), std=float(z["std"]))          # regenerated, not stored (430 MB)
+    batch = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in.")}
+    return z, sd, batch, arch, flags_of
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_bert_base_eval_vs_reference_golden(dev, precision):
+    """bert-base shape, L = 512, the run_finetune.sh flags: logits of the REFERENCE wrapper (tools/gen_golden.py --fullsize-only, weights
+    regenerated from their seed) -- north-star tolerance 1e-3 in fp32 parity mode, bf16 within the rounding of 12 layers"""
+    from tests.test_gpu_model import build_model, to_dev
+    z, sd, batch, arch, flags_of = _fullsize_case()
+    m = build_model(arch, flags_of(z, "full_eval"), sd, dev)
+    if precision == "fp32":
+        m.config.amdseg_precision = "fp32"
+    m.eval()
+    random.seed(int(z["full_eval.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos = m(**to_dev(batch, dev))
+    ref = torch.from_numpy(z["full_eval.logits"])
+    lab = batch["labels"] != -100
+    d_all = (logits.cpu() - ref).abs().max().item()
+    d_lab = (logits.cpu() - ref)[lab].abs().max().item()
+    scale = ref.abs().max().item()
+    print(f"bert-base L=512 {precision}: max|dlogit| all {d_all:.2e} labelled {d_lab:.2e} (max|logit| {scale:.2f}), loss {loss.item():.4f} vs {float(z['full_eval.loss']):.4f}")
+    if precision == "fp32":
+        assert d_all < 1e-3 and abs(loss.item() - float(z["full_eval.loss"])) < 1e-3
+        assert torch.equal(logits.cpu()[lab].argmax(-1), ref[lab].argmax(-1))            # boundary decisions bit-exact
+    else:
+        # bf16 activations through 12 layers: ~2^-8 relative per rounding, max over 4 x 512 x 2 logits
+        assert d_all < 0.05 * scale and (logits.cpu() - ref).abs().mean().item() < 0.01 * scale
+        flips = (logits.cpu()[lab].argmax(-1) != ref[lab].argmax(-1)).float().mean().item()
+        assert flips < 0.02
+
+
+def test_bert_base_train_grads_vs_reference_golden(dev):
+    """one train-mode step (dropout 0) at bert-base shape against the reference's loss, per-parameter gradient norms and the bias /
+    LayerNorm gradients of the first and last layer (incl. the bias gradients that come out of the weight-gradient GEMM)"""
+    from tests.test_gpu_model import build_model, to_dev
+    z, sd, batch, arch, flags_of = _fullsize_case()
+    m = build_model(arch, flags_of(z, "train_full"), sd, dev).train()
+    random.seed(int(z["train_full.random_seed"]))
+    loss, logits, cos = m(**to_dev(batch, dev))
+    loss.backward()
+    ref_loss = float(z["train_full.loss"])
+    assert abs(loss.item() - ref_loss) < 0.01 * abs(ref_loss) + 0.05
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for n, v in zip(z["train_full.gradnorm_names"].tolist(), z["train_full.gradnorm_vals"].tolist()):
+        if v <= 1e-6:
+            continue
+        gn = float(params[n].grad.float().norm())
+        worst = max(worst, abs(gn - v) / v)
+        assert abs(gn - v) / v < 0.08, (n, gn, v)
+    checked, bad = 0, []
+    for k in z.files:
+        if k.startswith("train_full.grad."):
+            n = k[len("train_full.grad."):]
+            ref = torch.from_numpy(z[k])
+            if float(ref.norm()) < 1e-6:
+                continue
+            c = torch.nn.functional.cosine_similarity(params[n].grad.float().cpu().flatten(), ref.flatten(), dim=0).item()
+            # q/k bias gradients are sums over 2048 tokens of bf16-rounded dq / dk that nearly cancel (softmax is invariant to a
+            # key bias, the query-bias gradient is a small difference of large terms): the rounding noise of the summands shows
+            lo = 0.9 if ("self.query.bias" in n or "self.key.bias" in n) else 0.985
+            if c <= lo:
+                bad.append((n, round(c, 4)))
+            checked += 1
+    print("bert-base train: worst grad-norm deviation", worst, "full grads checked", checked, "below threshold", bad)
+    assert not bad and checked >= 20

@@ -234,8 +234,52 @@ def main_mmvts():
         print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def main_fullsize():
+    """bert-base shape (12 x 768, vocab 30523, L = 512, 2 samples = 4 sequences, the run_finetune.sh flags): the REFERENCE run on a
+    state dict that tests/util.tiny_state_dict regenerates from its seed on any machine, so only inputs and outputs are stored."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import tiny_state_dict
+    arch = dict(vocab_size=30523, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                max_position_embeddings=512, type_vocab_size=2)
+    sd = tiny_state_dict(arch, seed=20230924, std=0.03)
+    docs = data.synth_docs(6, seed=99, vocab=30523, mean_sents=60, sd_sents=10, mean_boundaries=5)
+    batch = data.batches_from_docs(docs, 512, 2, seed=3)[0]
+    out = {"seed": 20230924, "std": 0.03, "arch_keys": np.array(list(arch)), "arch_vals": np.array([arch[k] for k in arch])}
+    for k, v in batch.items():
+        out["in." + k] = v.numpy()
+    for vname, flags, mode, rseed in (("full_eval", FULL, "eval", 5), ("train_full", FULL, "train", 7)):
+        m, cfg = make_model(arch, flags, 0, "bert")
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected, unexpected
+        random.seed(rseed)
+        if mode == "eval":
+            m.eval()
+            with torch.no_grad():
+                loss, logits, cos = m(**batch)[:3]
+            out[f"{vname}.logits"] = logits.numpy(); out[f"{vname}.cos"] = cos.numpy()
+        else:
+            m.train()
+            loss, logits, cos = m(**batch)[:3]
+            loss.backward()
+            names, norms = [], []
+            for n, p in m.named_parameters():
+                names.append(n); norms.append(-1.0 if p.grad is None else float(p.grad.norm()))
+                if p.grad is not None and (n.endswith("bias") or "LayerNorm" in n) and (".layer.0." in n or ".layer.11." in n or "loss_calculator" in n):
+                    out[f"{vname}.grad.{n}"] = p.grad.numpy().copy()
+            out[f"{vname}.gradnorm_names"] = np.array(names); out[f"{vname}.gradnorm_vals"] = np.array(norms)
+        out[f"{vname}.loss"] = loss.detach().numpy()
+        out[f"{vname}.flags_keys"] = np.array(list(flags.keys())); out[f"{vname}.flags_vals"] = np.array([str(v) for v in flags.values()])
+        out[f"{vname}.random_seed"] = rseed
+        print("bert_base_L512", vname, "loss", float(loss))
+    path = os.path.join(OUT, "bert_base_L512.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    if "--mmvts-only" in sys.argv:
+    if "--fullsize-only" in sys.argv:
+        main_fullsize()
+    elif "--mmvts-only" in sys.argv:
         main_mmvts()
     elif "--bigbird-only" in sys.argv:
         main_bigbird([("plain_eval", PLAIN, "eval", 0, {}), ("full_eval", FULL, "eval", 5, {}), ("train_full", FULL, "train", 7, {})])
