@@ -254,3 +254,72 @@ def test_bert_base_train_grads_vs_reference_golden(dev):
             checked += 1
     print("bert-base train: worst grad-norm deviation", worst, "full grads checked", checked, "below threshold", bad)
     assert not bad and checked >= 20
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_longformer_base_eval_vs_reference_golden(dev, precision):
+    """longformer-base-4096 shape (window 512, [CLS] global), L = 4096, 2 sequences: logits of the REFERENCE wrapper over HF's
+    LongformerModel (tools/gen_golden.py --fullsize-lf-only); weights regenerated from their seed"""
+    import numpy as np
+    from tests.util import longformer_state_dict
+    from tests.test_oracle_golden import flags_of
+    from tests.test_gpu_longformer import build_lf
+    z = np.load(os.path.join(ROOT, "tests", "golden", "longformer_base_L4096.npz"), allow_pickle=False)
+    arch = dict(zip(z["arch_keys"].tolist(), [float(v) if "eps" in k else int(float(v)) for k, v in zip(z["arch_keys"].tolist(), z["arch_vals"].tolist())]))
+    arch.pop("layer_norm_eps")
+    sd = longformer_state_dict(arch, seed=int(z["seed"]), std=float(z["std"]))
+    arch["attention_window"] = [int(v) for v in z["attention_window"]]
+    batch = {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("in.")}
+    m = build_lf(arch, flags_of(z, "full_eval"), sd, dev, precision=precision).eval()
+    random.seed(int(z["full_eval.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos = m(**batch)
+    ref = torch.from_numpy(z["full_eval.logits"])
+    valid = batch["attention_mask"].cpu().bool()
+    lab = (batch["labels"] != -100).cpu()
+    d = (logits.cpu() - ref)[valid].abs().max().item()
+    scale = ref[valid].abs().max().item()
+    print(f"longformer-base L=4096 {precision}: max|dlogit| (valid tokens) {d:.2e} (max|logit| {scale:.2f}), loss {loss.item():.4f} vs {float(z['full_eval.loss']):.4f}")
+    if precision == "fp32":
+        assert d < 1e-3 and abs(loss.item() - float(z["full_eval.loss"])) < 1e-3
+        assert torch.equal(logits.cpu()[lab].argmax(-1), ref[lab].argmax(-1))
+    else:
+        assert d < 0.05 * scale and (logits.cpu() - ref)[valid].abs().mean().item() < 0.01 * scale
+
+
+def test_bigbird_base_eval_vs_reference_golden(dev):
+    """bigbird-roberta-base shape (block-sparse: block 64, 3 random blocks, gelu_new), L = 4096, 2 sequences: logits of the REFERENCE
+    wrapper over HF's BigBirdModel in eval mode (tools/gen_golden.py --fullsize-bb-only); weights regenerated from their seed"""
+    import numpy as np
+    from tests.util import tiny_state_dict
+    from tests.test_oracle_golden import flags_of
+    from tests.test_gpu_bigbird import build_bb
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bigbird_base_L4096.npz"), allow_pickle=False)
+    arch = {}
+    for k, v in zip(z["arch_keys"].tolist(), z["arch_vals"].tolist()):
+        try:
+            arch[k] = int(v)
+        except ValueError:
+            arch[k] = v
+    sd = {k: v for k, v in tiny_state_dict({k: v for k, v in arch.items() if not isinstance(v, str)}, seed=int(z["seed"]), std=float(z["std"])).items()
+          if "pooler" not in k}
+    batch = {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("in.")}
+    from transformers import BigBirdConfig
+    from spokennlp_amd.bigbird_for_ts import BigBirdWithDAForSentenceLabelingTopicSegmentation as M
+    cfg = BigBirdConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **arch)
+    for k, v in flags_of(z, "full_eval").items():
+        setattr(cfg, k, v)
+    m = M(cfg)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected
+    m = m.to(dev).eval()
+    random.seed(int(z["full_eval.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos = m(**batch)
+    ref = torch.from_numpy(z["full_eval.logits"])
+    valid = batch["attention_mask"].cpu().bool()
+    d = (logits.cpu() - ref)[valid].abs()
+    scale = ref[valid].abs().max().item()
+    print(f"bigbird-base L=4096 bf16: max|dlogit| {d.max().item():.2e} mean {d.mean().item():.2e} (max|logit| {scale:.2f}), loss {loss.item():.4f} vs {float(z['full_eval.loss']):.4f}")
+    assert d.max().item() < 0.05 * scale and d.mean().item() < 0.01 * scale
+    assert abs(loss.item() - float(z["full_eval.loss"])) < 0.01 * abs(float(z["full_eval.loss"])) + 0.05

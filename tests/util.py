@@ -30,3 +30,23 @@ def tiny_state_dict(arch, seed=0, std=0.05, clf_std=0.3):
     sd["loss_calculator.classifier.weight"] = w(2, H, sd=clf_std); sd["loss_calculator.classifier.bias"] = w(2)
     sd["loss_calculator.tssp.classifier.weight"] = w(3, H, sd=clf_std); sd["loss_calculator.tssp.classifier.bias"] = w(3)
     return sd
+
+
+def longformer_state_dict(arch, seed=0, std=0.03, clf_std=0.3):
+    """the same for LongformerWithDAForSentenceLabelingTopicSegmentation (`longformer.*` names, *_global projections)"""
+    sd = {}
+    for k, v in tiny_state_dict(arch, seed, std, clf_std).items():
+        if "pooler" in k:                       # the reference builds LongformerModel(add_pooling_layer=False)
+            continue
+        sd[k.replace("bert.", "longformer.", 1) if k.startswith("bert.") else k] = v
+    g = torch.Generator().manual_seed(seed + 1)
+    H = arch["hidden_size"]
+    for i in range(arch["num_hidden_layers"]):
+        p = f"longformer.encoder.layer.{i}.attention.self."
+        for n in ("query_global", "key_global", "value_global"):
+            sd[p + n + ".weight"] = torch.randn(H, H, generator=g) * std
+            sd[p + n + ".bias"] = torch.randn(H, generator=g) * std
+    pad = arch.get("pad_token_id", 1)
+    sd["longformer.embeddings.word_embeddings.weight"][pad] = 0
+    sd["longformer.embeddings.position_embeddings.weight"][pad] = 0
+    return sd

@@ -276,8 +276,78 @@ def main_fullsize():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def main_fullsize_lf():
+    """longformer-base-4096 shape (12 x 768, window 512, vocab 50266, L = 4096, 1 sample = 2 sequences), eval only"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import longformer_state_dict
+    arch = dict(vocab_size=50266, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                max_position_embeddings=4098, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2, layer_norm_eps=1e-5)
+    sd = longformer_state_dict(arch, seed=20230925, std=0.03)
+    docs = data.synth_docs(6, seed=98, vocab=50266, mean_sents=200, sd_sents=30, mean_boundaries=8)
+    batch = data.batches_from_docs(docs, 4096, 1, seed=4)[0]
+    batch["input_ids"] = torch.where(batch["attention_mask"] == 0, torch.ones_like(batch["input_ids"]), batch["input_ids"])
+    batch["input_ids"] = torch.where((batch["input_ids"] == 1) & (batch["attention_mask"] == 1), torch.full_like(batch["input_ids"], 5), batch["input_ids"])
+    akeys = list(arch)
+    out = {"seed": 20230925, "std": 0.03, "arch_keys": np.array(akeys), "arch_vals": np.array([arch[k] for k in akeys]),
+           "attention_window": np.array([512] * 12)}
+    for k, v in batch.items():
+        out["in." + k] = v.numpy()
+    m, cfg = make_model(dict(arch, attention_window=[512] * 12), FULL, 0, "longformer")
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    random.seed(5)
+    m.eval()
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        loss, logits, cos = m(**batch)[:3]
+    print("longformer_base_L4096 full_eval loss", float(loss), "in", round(time.time() - t0, 1), "s; valid tokens", int(batch["attention_mask"].sum()))
+    out["full_eval.logits"] = logits.numpy(); out["full_eval.cos"] = cos.numpy(); out["full_eval.loss"] = loss.numpy()
+    out["full_eval.flags_keys"] = np.array(list(FULL.keys())); out["full_eval.flags_vals"] = np.array([str(v) for v in FULL.values()])
+    out["full_eval.random_seed"] = 5
+    path = os.path.join(OUT, "longformer_base_L4096.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def main_fullsize_bb():
+    """bigbird-roberta-base shape (12 x 768, block 64, 3 random blocks, gelu_new, vocab 50359), L = 4096, 2 sequences, eval only"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import tiny_state_dict
+    arch = dict(vocab_size=50359, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                max_position_embeddings=4096, type_vocab_size=2, block_size=64, num_random_blocks=3, attention_type="block_sparse",
+                pad_token_id=0, bos_token_id=1, eos_token_id=2, sep_token_id=3)
+    num_arch = {k: v for k, v in arch.items() if not isinstance(v, str)}
+    sd = {k: v for k, v in tiny_state_dict(num_arch, seed=20230926, std=0.03).items() if "pooler" not in k}   # BigBirdModel.pooler is a bare Linear, unused here
+    docs = data.synth_docs(6, seed=97, vocab=50359, mean_sents=200, sd_sents=30, mean_boundaries=8)
+    batch = data.batches_from_docs(docs, 4096, 1, seed=6)[0]
+    out = {"seed": 20230926, "std": 0.03, "arch_keys": np.array(list(arch)), "arch_vals": np.array([arch[k] for k in arch])}
+    for k, v in batch.items():
+        out["in." + k] = v.numpy()
+    m, cfg = make_model(arch, FULL, 0, "bigbird")
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    random.seed(5)
+    m.eval()
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        loss, logits, cos = m(**batch)[:3]
+    print("bigbird_base_L4096 full_eval loss", float(loss), "in", round(time.time() - t0, 1), "s; valid tokens", int(batch["attention_mask"].sum()))
+    out["full_eval.logits"] = logits.numpy(); out["full_eval.cos"] = cos.numpy(); out["full_eval.loss"] = loss.numpy()
+    out["full_eval.flags_keys"] = np.array(list(FULL.keys())); out["full_eval.flags_vals"] = np.array([str(v) for v in FULL.values()])
+    out["full_eval.random_seed"] = 5
+    path = os.path.join(OUT, "bigbird_base_L4096.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    if "--fullsize-only" in sys.argv:
+    if "--fullsize-bb-only" in sys.argv:
+        main_fullsize_bb()
+    elif "--fullsize-lf-only" in sys.argv:
+        main_fullsize_lf()
+    elif "--fullsize-only" in sys.argv:
         main_fullsize()
     elif "--mmvts-only" in sys.argv:
         main_mmvts()
