@@ -16,6 +16,13 @@ class A:
 
 
 def main():
+    # split the forward's CPU time into "blocked on the label copy (= previous step still running)" and the rest
+    waits = []
+    _sync = torch.cuda.Event.synchronize
+
+    def timed_sync(self):
+        t = time.perf_counter(); _sync(self); waits.append(time.perf_counter() - t)
+    torch.cuda.Event.synchronize = timed_sync
     dev = torch.device("cuda", 0)
     args = A()
     model, cfg = bench.build(args, dev)
@@ -47,6 +54,8 @@ def main():
     torch.cuda.synchronize()
     gpu = [ev[i].elapsed_time(ev[i + 1]) for i in range(n)]
     f = sum(c[0] for c in cpu) / n * 1e3; b = sum(c[1] for c in cpu) / n * 1e3; o = sum(c[2] for c in cpu) / n * 1e3
+    w = sum(waits[-n:]) / n * 1e3
+    print(f"forward CPU time blocked in Event.synchronize: {w:.2f} ms per step -> host planning + head enqueue = {f - w:.2f} ms")
     print(f"CPU enqueue per step: forward {f:.2f} ms, backward {b:.2f} ms, optimiser {o:.2f} ms, total {f + b + o:.2f} ms;  GPU per step {sum(gpu) / n:.2f} ms")
 
 
