@@ -179,12 +179,13 @@ int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb,
  * the key blocks klist[(h * L/64 + i) * list_stride + 0 .. kcnt[h * L/64 + i]) in order, duplicates included (one softmax over the
  * concatenation, as the reference's torch.cat of key blocks); qlist/qcnt are the transposed lists per (head, key block) with the
  * same multiplicities (device int32 arrays, built by the host mirror spokennlp_amd/bigbird_plan.py).  Rows of padded queries are
- * zeroed by the caller (reference: context_layer * from_mask). */
+ * zeroed by the caller (reference: context_layer * from_mask).  korder / qorder (optional, [heads][L/64]): the block index the r-th
+ * workgroup of a head works on -- sorted by decreasing list length so that the few very long rows (first / last block) start first. */
 int amdseg_attn_list_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
-                         const int* klist, const int* kcnt, int list_stride, amdseg_stream_t stream);
+                         const int* klist, const int* kcnt, int list_stride, const int* korder, amdseg_stream_t stream);
 int amdseg_attn_list_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta_ws, void* dqkv, int B, int L, int heads, float scale, const int* klist, const int* kcnt,
-                         const int* qlist, const int* qcnt, int list_stride, amdseg_stream_t stream);
+                         const int* qlist, const int* qcnt, int list_stride, const int* korder, const int* qorder, amdseg_stream_t stream);
 /* test hook: v != 0 routes GEMMs that would take a 256-wide deep-pipeline kernel to the 128 x 128 kernels instead, so both
  * code paths can be compared on one shape; returns the previous value.  Not part of the reference-facing surface. */
 int amdseg_debug_force_small_tile(int v);

@@ -49,6 +49,7 @@ class BigBirdEncoderEngine(BertEncoderEngine):
                 t = plan.build(Lseq, self.heads, cfg.num_random_blocks, i, train, cfg.max_position_embeddings)
                 per_layer.append(dict(klist=torch.from_numpy(t["klist"]).to(dev), kcnt=torch.from_numpy(t["kcnt"]).to(dev),
                                       qlist=torch.from_numpy(t["qlist"]).to(dev), qcnt=torch.from_numpy(t["qcnt"]).to(dev),
+                                      korder=torch.from_numpy(t["korder"]).to(dev), qorder=torch.from_numpy(t["qorder"]).to(dev),
                                       stride=int(t["stride"])))
                 if not train:                               # eval: no randomness -> every layer shares one plan
                     per_layer = per_layer * self.nlayers
@@ -83,7 +84,7 @@ class BigBirdEncoderEngine(BertEncoderEngine):
         L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].1")
         la = A["layers"][i if train else 0]
         with torch.no_grad():
-            ops.attn_list_fwd(la["qkv"], cur["mb"], cfg.B, cfg.L, self.heads, pl["klist"], pl["kcnt"], pl["stride"], ctx=la["ctx"], lse=la["lse"])
+            ops.attn_list_fwd(la["qkv"], cur["mb"], cfg.B, cfg.L, self.heads, pl["klist"], pl["kcnt"], pl["stride"], ctx=la["ctx"], lse=la["lse"], korder=pl["korder"])
             if not cur["all_valid"]:
                 la["ctx"].mul_(cur["rowmask"])               # reference: context_layer * from_mask
         cfg.phase = 2
@@ -106,7 +107,7 @@ class BigBirdEncoderEngine(BertEncoderEngine):
             if not cur["all_valid"]:
                 ws["dctx"].mul_(cur["rowmask"])
             ops.attn_list_bwd(la["qkv"], cur["mb"], la["ctx"], ws["dctx"], la["lse"], cfg.B, cfg.L, self.heads, pl["klist"], pl["kcnt"],
-                              pl["qlist"], pl["qcnt"], pl["stride"], dqkv=ws["dqkv"], delta=ws["delta"])
+                              pl["qlist"], pl["qcnt"], pl["stride"], dqkv=ws["dqkv"], delta=ws["delta"], korder=pl["korder"], qorder=pl["qorder"])
         cfg.phase = 2
         L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].2")
         cfg.phase, cfg.mixer, cfg.nproj = 0, 0, 0

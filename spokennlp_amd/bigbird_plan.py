@@ -109,7 +109,10 @@ def build(seq_len, num_heads, num_rand_blocks, seed, training, max_seqlen):
     kl[:, :, :nb] = klist
     ql = np.zeros((num_heads, nb, stride), dtype=np.int32)
     ql[:, :, :qlist.shape[2]] = qlist
-    return dict(klist=kl, kcnt=kcnt, qlist=ql, qcnt=qcnt, stride=stride, rand=rand)
+    # launch order: block indices by decreasing list length (stable), per head
+    korder = np.argsort(-kcnt, axis=1, kind="stable").astype(np.int32)
+    qorder = np.argsort(-qcnt, axis=1, kind="stable").astype(np.int32)
+    return dict(klist=kl, kcnt=kcnt, qlist=ql, qcnt=qcnt, stride=stride, rand=rand, korder=korder, qorder=qorder)
 
 
 def min_block_sparse_len(num_rand_blocks, block=BLOCK):

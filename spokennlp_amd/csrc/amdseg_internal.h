@@ -45,10 +45,10 @@ int amdseg_gemm_tn_grouped_bias_impl(int nprob, const void* const* A, const int*
                                      float* const* colsum_out, float* const* colsum_scratch, hipStream_t stream);
 int amdseg_reduce_defer_flush(hipStream_t s);
 int amdseg_attn_list_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
-                              const int* klist, const int* kcnt, int list_stride, hipStream_t s);
+                              const int* klist, const int* kcnt, int list_stride, const int* korder, hipStream_t s);
 int amdseg_attn_list_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                               float* delta, void* dqkv, int B, int L, int heads, float scale, const int* klist, const int* kcnt,
-                              const int* qlist, const int* qcnt, int list_stride, hipStream_t s);
+                              const int* qlist, const int* qcnt, int list_stride, const int* korder, const int* qorder, hipStream_t s);
 int amdseg_cast_transpose_batched_impl(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                        hipStream_t s);
 int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_out, hipStream_t s);

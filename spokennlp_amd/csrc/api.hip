@@ -151,14 +151,14 @@ int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb,
     return amdseg_cast_transpose_batched_impl(n, W, Wb, Wt, N, K, S(stream));
 }
 int amdseg_attn_list_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
-                         const int* klist, const int* kcnt, int list_stride, amdseg_stream_t stream) {
-    return amdseg_attn_list_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, klist, kcnt, list_stride, S(stream));
+                         const int* klist, const int* kcnt, int list_stride, const int* korder, amdseg_stream_t stream) {
+    return amdseg_attn_list_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, klist, kcnt, list_stride, korder, S(stream));
 }
 int amdseg_attn_list_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta_ws, void* dqkv, int B, int L, int heads, float scale, const int* klist, const int* kcnt,
-                         const int* qlist, const int* qcnt, int list_stride, amdseg_stream_t stream) {
+                         const int* qlist, const int* qcnt, int list_stride, const int* korder, const int* qorder, amdseg_stream_t stream) {
     return amdseg_attn_list_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, klist, kcnt, qlist, qcnt,
-                                     list_stride, S(stream));
+                                     list_stride, korder, qorder, S(stream));
 }
 int amdseg_debug_force_small_tile(int v) { return amdseg_set_force_small_tile(v); }
 int amdseg_rowdot_fwd(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,

@@ -63,6 +63,7 @@ struct AttnArgs {
     // block-list attention (BigBird block-sparse): row (h, block) of klist / qlist holds kcnt / qcnt block indices to visit, in order
     // and WITH multiplicity (a key block listed twice counts twice in the softmax, as in the reference's concatenated key matrices)
     const int* klist; const int* kcnt; const int* qlist; const int* qcnt; int list_stride;
+    const int* korder; const int* qorder;   // optional [heads][L/64]: block index handled by the r-th workgroup of a head (longest lists first)
 };
 
 // Band ("sliding window + global") visibility, [hf] models/longformer/modeling_longformer.py:524-604 restated as a mask:
@@ -74,12 +75,30 @@ __device__ __forceinline__ bool band_masked(int q, int key, int W, int G) {
     return key >= G && (d > W || d < -W);
 }
 
+// Walks a block list in order: 64 entries live in one VGPR (lane i holds entry base + i), v_readlane picks the next one; a scalar
+// load per chunk would put a global-memory round trip in front of every chunk's DMA address.
+struct ListWalk {
+    const int* lst; int n, lv, t;
+    __device__ __forceinline__ void init(const int* p, int count, int l) { lst = p; n = count; t = 0; lv = l < n ? p[l] : 0; }
+    __device__ __forceinline__ int next(int l) {            // entry t, then t + 1; entries past the end read as 0
+        if (t > 0 && (t & 63) == 0) lv = (t + l) < n ? lst[t + l] : 0;
+        const int v = __builtin_amdgcn_readlane(lv, t & 63);
+        ++t;
+        return v;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int NW, bool BAND, bool LIST = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    if (LIST) {                                             // 1-D launch, rank-major: the longest lists of every (b, h) are dispatched first
+        const int nbh = a.heads * a.B, r = blockIdx.x / nbh, bh = blockIdx.x % nbh;
+        h = bh % a.heads; b = bh / a.heads;
+        qb = a.korder ? a.korder[h * (a.L / CH) + r] : r;
+    }
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
     const int q = qb * (NW * 16) + w * 16 + i16;                       // this lane's query row (shared by the 4 g-groups)
@@ -113,8 +132,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     }
     int nch = c1 - c0 + 1 + extra;
     const int* lst = nullptr;
-    if (LIST) { const int row = h * (a.L / CH) + qb; nch = a.kcnt[row]; lst = a.klist + (size_t)row * a.list_stride; }
-#define CHUNK_OF(t) (LIST ? lst[t] : (BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
+    ListWalk lw;
+    int c_cur = 0, c_nxt = 0, ch_ = 0;                      // LIST: the chunks of iteration ch_ and ch_ + 1
+    if (LIST) {
+        const int row = h * (a.L / CH) + qb; nch = a.kcnt[row]; lst = a.klist + (size_t)row * a.list_stride;
+        lw.init(lst, nch, l); c_cur = lw.next(l); c_nxt = lw.next(l);
+    }
+    (void)lst;
+#define CHUNK_OF(t) (LIST ? ((t) == ch_ ? c_cur : c_nxt) : (BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
     at_stage<NW>(kbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufK(0), w, l);
     at_stage<NW>(vbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufV(0), w, l);
     // the additive key mask of a chunk travels with its K/V tiles (a global load issued where it is consumed costs a full
@@ -124,6 +149,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     // INSIDE the loop, where it drains the chunk prefetch that was just issued, every iteration
     __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
     for (int ch = 0; ch < nch; ++ch) {
+        ch_ = ch;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = ch & 1;
@@ -213,6 +239,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
                 o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fp, o[d], 0, 0, 0);
             }
         }
+        if (LIST) { c_cur = c_nxt; c_nxt = lw.next(l); }
     }
     const float lsum = xor_reduce_sum_g(l_part);
     float inv = 1.0f / lsum;
@@ -259,7 +286,12 @@ template <int NW, bool BAND, bool LIST = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    if (LIST) {                                             // 1-D launch, rank-major: the longest lists of every (b, h) are dispatched first
+        const int nbh = a.heads * a.B, r = blockIdx.x / nbh, bh = blockIdx.x % nbh;
+        h = bh % a.heads; b = bh / a.heads;
+        qb = a.korder ? a.korder[h * (a.L / CH) + r] : r;
+    }
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
     const int q = qb * (NW * 16) + w * 16 + i16;
@@ -309,12 +341,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     int nch = c1 - c0 + 1 + extra;
     const int* lst = nullptr;
-    if (LIST) { const int row = h * (a.L / CH) + qb; nch = a.kcnt[row]; lst = a.klist + (size_t)row * a.list_stride; }
-#define CHUNK_OF(t) (LIST ? lst[t] : (BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
+    ListWalk lw;
+    int c_cur = 0, c_nxt = 0, ch_ = 0;                      // LIST: the chunks of iteration ch_ and ch_ + 1
+    if (LIST) {
+        const int row = h * (a.L / CH) + qb; nch = a.kcnt[row]; lst = a.klist + (size_t)row * a.list_stride;
+        lw.init(lst, nch, l); c_cur = lw.next(l); c_nxt = lw.next(l);
+    }
+    (void)lst;
+#define CHUNK_OF(t) (LIST ? ((t) == ch_ ? c_cur : c_nxt) : (BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
     at_stage<NW>(kbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufK(0), w, l);
     at_stage<NW>(vbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufV(0), w, l);
     if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(0) * CH, bufM(0), l);      // key mask rides with the tiles
     for (int ch = 0; ch < nch; ++ch) {
+        ch_ = ch;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = ch & 1;
@@ -386,6 +425,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fds, dq[d], 0, 0, 0);
             }
         }
+        if (LIST) { c_cur = c_nxt; c_nxt = lw.next(l); }
     }
     bf16_t* op = a.dqkv + (tok0 + q) * a.H3 + h * HD;
 #pragma unroll
@@ -414,6 +454,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (id < nbh) { kb = 0; bh = id; }
         else { const int r = id - nbh; kb = 1 + r % (nkb - 1); bh = r / (nkb - 1); }
         h = bh % a.heads; b = bh / a.heads;
+    }
+    if (LIST) {                                             // 1-D launch, rank-major: the longest lists first
+        const int nbh = a.heads * a.B, r = blockIdx.x / nbh, bh2 = blockIdx.x % nbh;
+        h = bh2 % a.heads; b = bh2 / a.heads;
+        kb = a.qorder ? a.qorder[h * (a.L / CH) + r] : r;
     }
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
@@ -450,14 +495,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     int nch = c1 - c0 + 1;
     const int* lst = nullptr;
-    if (LIST) { const int row = h * (a.L / CH) + kb; nch = a.qcnt[row]; lst = a.qlist + (size_t)row * a.list_stride; }
-#define QCHUNK_OF(t) (LIST ? lst[t] : c0 + (t))
+    ListWalk lw;
+    int c_cur = 0, c_nxt = 0, ch_ = 0;
+    if (LIST) {
+        const int row = h * (a.L / CH) + kb; nch = a.qcnt[row]; lst = a.qlist + (size_t)row * a.list_stride;
+        lw.init(lst, nch, l); c_cur = lw.next(l); c_nxt = lw.next(l);
+    }
+    (void)lst;
+#define QCHUNK_OF(t) (LIST ? ((t) == ch_ ? c_cur : c_nxt) : c0 + (t))
     at_stage<NW>(qbase + (size_t)QCHUNK_OF(0) * CH * a.H3, a.H3, bufQ(0), w, l);
     at_stage<NW>(obase + (size_t)QCHUNK_OF(0) * CH * H, H, bufO(0), w, l);
     // LSE and delta of the chunk's 64 query rows ride with the Q / dO tiles (were 8 exposed global loads per chunk)
     if (w == 0) at_stage_f32x64(a.lse + bh * a.L + (size_t)QCHUNK_OF(0) * CH, bufL(0), l);
     if (w == 1) at_stage_f32x64(a.delta + bh * a.L + (size_t)QCHUNK_OF(0) * CH, bufL(0) + 256, l);
     for (int ch = 0; ch < nch; ++ch) {
+        ch_ = ch;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = ch & 1;
@@ -536,6 +588,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                 dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, fds, dk[d], 0, 0, 0);
             }
         }
+        if (LIST) { c_cur = c_nxt; c_nxt = lw.next(l); }
     }
     bf16_t* okp = a.dqkv + (tok0 + key) * a.H3 + H + h * HD;
     bf16_t* ovp = a.dqkv + (tok0 + key) * a.H3 + 2 * H + h * HD;
@@ -618,21 +671,21 @@ static int attn_list_check(int L, const int* klist, const int* kcnt, int stride)
 }
 
 int amdseg_attn_list_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
-                              const int* klist, const int* kcnt, int list_stride, hipStream_t s) {
+                              const int* klist, const int* kcnt, int list_stride, const int* korder, hipStream_t s) {
     if (!qkv || !mask_bias || !ctx) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, 0.f, 0, 0, 0);
     if (rc) return rc;
     if ((rc = attn_list_check(L, klist, kcnt, list_stride))) return rc;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
-    a.klist = klist; a.kcnt = kcnt; a.list_stride = list_stride;
-    hipLaunchKernelGGL((attn_fwd_kernel<4, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    a.klist = klist; a.kcnt = kcnt; a.list_stride = list_stride; a.korder = korder;
+    hipLaunchKernelGGL((attn_fwd_kernel<4, false, true>), dim3((L / 64) * heads * B), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }
 
 int amdseg_attn_list_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                               float* delta, void* dqkv, int B, int L, int heads, float scale, const int* klist, const int* kcnt,
-                              const int* qlist, const int* qcnt, int list_stride, hipStream_t s) {
+                              const int* qlist, const int* qcnt, int list_stride, const int* korder, const int* qorder, hipStream_t s) {
     if (!qkv || !mask_bias || !ctx || !dctx || !lse || !delta || !dqkv) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, 0.f, 0, 0, 0);
@@ -640,8 +693,8 @@ int amdseg_attn_list_bwd_impl(const void* qkv, const float* mask_bias, const voi
     if ((rc = attn_list_check(L, klist, kcnt, list_stride)) || (rc = attn_list_check(L, qlist, qcnt, list_stride))) return rc;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = (float*)lse;
     a.dctx = (const bf16_t*)dctx; a.delta = delta; a.dqkv = (bf16_t*)dqkv;
-    a.klist = klist; a.kcnt = kcnt; a.qlist = qlist; a.qcnt = qcnt; a.list_stride = list_stride;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<4, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    a.klist = klist; a.kcnt = kcnt; a.qlist = qlist; a.qcnt = qcnt; a.list_stride = list_stride; a.korder = korder; a.qorder = qorder;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<4, false, true>), dim3((L / 64) * heads * B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, false, true>), dim3((L / 64) * heads * B), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }

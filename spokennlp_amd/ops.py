@@ -91,25 +91,26 @@ def attn_bwd(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, p=0.0, seed=0, scal
     return dqkv
 
 
-def attn_list_fwd(qkv, mask_bias, B, Lseq, heads, klist, kcnt, stride, ctx=None, lse=None, scale=0.125):
+def attn_list_fwd(qkv, mask_bias, B, Lseq, heads, klist, kcnt, stride, ctx=None, lse=None, scale=0.125, korder=None):
     """BigBird block-list attention (amdseg_attn_list_fwd); klist/kcnt: int32 device tensors [heads, L/64, stride] / [heads, L/64]"""
     H = heads * 64
     if ctx is None:
         ctx = torch.empty((B * Lseq, H), dtype=torch.bfloat16, device=qkv.device)
     if lse is None:
         lse = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device)
-    rc = L.load().amdseg_attn_list_fwd(_p(qkv), _p(mask_bias), _p(ctx), _p(lse), B, Lseq, heads, scale, _p(klist), _p(kcnt), stride, _s())
+    rc = L.load().amdseg_attn_list_fwd(_p(qkv), _p(mask_bias), _p(ctx), _p(lse), B, Lseq, heads, scale, _p(klist), _p(kcnt), stride, _p(korder), _s())
     L.check(rc, "amdseg_attn_list_fwd")
     return ctx, lse
 
 
-def attn_list_bwd(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, klist, kcnt, qlist, qcnt, stride, dqkv=None, delta=None, scale=0.125):
+def attn_list_bwd(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, klist, kcnt, qlist, qcnt, stride, dqkv=None, delta=None, scale=0.125,
+                  korder=None, qorder=None):
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
     if delta is None:
         delta = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device)
     rc = L.load().amdseg_attn_list_bwd(_p(qkv), _p(mask_bias), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, Lseq, heads, scale,
-                                       _p(klist), _p(kcnt), _p(qlist), _p(qcnt), stride, _s())
+                                       _p(klist), _p(kcnt), _p(qlist), _p(qcnt), stride, _p(korder), _p(qorder), _s())
     L.check(rc, "amdseg_attn_list_bwd")
     return dqkv
 

@@ -44,13 +44,14 @@ def test_list_attention_fwd_bwd(dev, B, L, heads, train):
     torch.manual_seed(L + heads)
     H = heads * 64
     t = bigbird_plan.build(L, heads, 3, seed=1, training=train, max_seqlen=4096)
-    klist, kcnt, qlist, qcnt = [torch.from_numpy(t[k]).to(dev) for k in ("klist", "kcnt", "qlist", "qcnt")]
+    klist, kcnt, qlist, qcnt, korder, qorder = [torch.from_numpy(t[k]).to(dev) for k in ("klist", "kcnt", "qlist", "qcnt", "korder", "qorder")]
     qkv = torch.randn(B * L, 3 * H, device=dev).bfloat16()
     mask = torch.zeros(B, L, device=dev)
     mask[0, L - 37:] = -10000.0                                   # padded tail in the first sequence, the reference's penalty
     dctx = (torch.randn(B * L, H, device=dev) * 0.5).bfloat16()
-    ctx, lse = ops.attn_list_fwd(qkv, mask, B, L, heads, klist, kcnt, t["stride"])
-    dqkv = ops.attn_list_bwd(qkv, mask, ctx, dctx, lse, B, L, heads, klist, kcnt, qlist, qcnt, t["stride"])
+    ctx, lse = ops.attn_list_fwd(qkv, mask, B, L, heads, klist, kcnt, t["stride"], korder=korder if train else None)
+    dqkv = ops.attn_list_bwd(qkv, mask, ctx, dctx, lse, B, L, heads, klist, kcnt, qlist, qcnt, t["stride"],
+                             korder=korder if train else None, qorder=qorder if train else None)
     ref_ctx, ref_dqkv = list_reference(qkv, mask, B, L, heads, t["klist"], t["kcnt"], dctx)
     assert (ctx.float() - ref_ctx).abs().max().item() < 0.03
     assert torch.isfinite(dqkv.float()).all()
