@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs jobs) {
     }
 }
 static thread_local ReduceJobs* g_defer = nullptr;       // set by amdseg_reduce_defer_begin: reductions are queued, not launched
-static ReduceJobs g_defer_store;
+static thread_local ReduceJobs g_defer_store;
 void amdseg_reduce_defer_begin(int accumulate) { g_defer_store.njobs = 0; g_defer_store.accumulate = accumulate; g_defer = &g_defer_store; }
 int amdseg_reduce_defer_flush(hipStream_t s) {
     ReduceJobs* d = g_defer;
