@@ -149,49 +149,48 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
             for (int nf = 0; nf < NF; ++nf) { acc[mf][nf][0] += bv[nf].x; acc[mf][nf][1] += bv[nf].y; acc[mf][nf][2] += bv[nf].z; acc[mf][nf][3] += bv[nf].w; }
     }
     if (NF == 4) {
-        // ---- direct epilogue (256-wide tile): lane owns row m = mf*16 + i16 and the 8 consecutive columns ep*32 + g*8 .. +8 of its wave's 64
+        // ---- direct epilogue (256-wide tile): lane owns row m = mf*16 + i16 and the 8 consecutive columns ep*32 + g*8 .. +8 of its wave's 64.
+        // BIAS_GELU writes the pre-activation and the activation of a chunk back to back (the stores of one overlap the GELU math of the next)
 #pragma unroll
-        for (int pass = 0; pass < (EPI == EPI_BIAS_GELU ? 2 : 1); ++pass) {
-            if (EPI == EPI_BIAS_GELU && pass == 0 && !a.C2) continue;
+        for (int mf = 0; mf < 8; ++mf) {
+            const size_t gm = (size_t)(m0 + wr * 128 + mf * 16 + i16);
+            uint4 rr[2];
+            if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
 #pragma unroll
-            for (int mf = 0; mf < 8; ++mf) {
-                const size_t gm = (size_t)(m0 + wr * 128 + mf * 16 + i16);
-                uint4 rr[2];
-                if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
-#pragma unroll
-                    for (int ep = 0; ep < 2; ++ep) rr[ep] = *reinterpret_cast<const uint4*>(a.R + gm * a.ldr + n0 + wc * 64 + ep * 32 + g * 8);
-                }
-#pragma unroll
-                for (int ep = 0; ep < 2; ++ep) {
-                    float v[8];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * ep][r]; v[4 + r] = acc[mf][2 * ep + 1][r]; }
-                    if (EPI == EPI_BIAS_GELU && pass == 1) {
-                        gelu_act4(v, ACT); gelu_act4(v + 4, ACT);
-                    } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
-                        const uint32_t rw[4] = {rr[ep].x, rr[ep].y, rr[ep].z, rr[ep].w};
-                        float rf[8];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { rf[2 * q] = __uint_as_float(rw[q] << 16); rf[2 * q + 1] = __uint_as_float(rw[q] & 0xffff0000u); }
-                        if (EPI == EPI_ADD_RES) {
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] += rf[q];
-                        } else { gelu_grad_mul4(v, rf[0], rf[1], rf[2], rf[3], ACT); gelu_grad_mul4(v + 4, rf[4], rf[5], rf[6], rf[7], ACT); }
-                    }
-                    const size_t col = (size_t)(n0 + wc * 64 + ep * 32 + g * 8);
-                    if (sizeof(OutT) == 2) {
-                        bf16_t* ob = (EPI == EPI_BIAS_GELU && pass == 0) ? a.C2 : reinterpret_cast<bf16_t*>(a.C);
-                        const int old = (EPI == EPI_BIAS_GELU && pass == 0) ? a.ldc2 : a.ldc;
-                        uint4 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
-                        *reinterpret_cast<uint4*>(ob + gm * old + col) = pk;
-                    } else {
-                        float* dst = reinterpret_cast<float*>(a.C) + gm * a.ldc + col;
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int ep = 0; ep < 2; ++ep) rr[ep] = *reinterpret_cast<const uint4*>(a.R + gm * a.ldr + n0 + wc * 64 + ep * 32 + g * 8);
             }
+#pragma unroll
+            for (int ep = 0; ep < 2; ++ep) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * ep][r]; v[4 + r] = acc[mf][2 * ep + 1][r]; }
+                const size_t col = (size_t)(n0 + wc * 64 + ep * 32 + g * 8);
+                if (EPI == EPI_BIAS_GELU) {
+                    if (a.C2) {
+                        uint4 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+                        *reinterpret_cast<uint4*>(a.C2 + gm * a.ldc2 + col) = pk;
+                    }
+                    gelu_act4(v, ACT); gelu_act4(v + 4, ACT);
+                } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+                    const uint32_t rw[4] = {rr[ep].x, rr[ep].y, rr[ep].z, rr[ep].w};
+                    float rf[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { rf[2 * q] = __uint_as_float(rw[q] << 16); rf[2 * q + 1] = __uint_as_float(rw[q] & 0xffff0000u); }
+                    if (EPI == EPI_ADD_RES) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += rf[q];
+                    } else { gelu_grad_mul4(v, rf[0], rf[1], rf[2], rf[3], ACT); gelu_grad_mul4(v + 4, rf[4], rf[5], rf[6], rf[7], ACT); }
+                }
+                if (sizeof(OutT) == 2) {
+                    uint4 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + gm * a.ldc + col) = pk;
+                } else {
+                    float* dst = reinterpret_cast<float*>(a.C) + gm * a.ldc + col;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         return;
     }
