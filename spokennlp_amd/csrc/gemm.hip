@@ -580,10 +580,10 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     const bool small_ok = (a_in.M % BM) == 0 && (a_in.N % BN) == 0;
     static int dp_min_k = -1;
     if (dp_min_k < 0) { const char* e = getenv("AMDSEG_DP_MIN_K"); dp_min_k = e ? atoi(e) : 768; }
-    // 256-aligned long-K shapes: the deep-pipeline 256x256 kernel (gemm_dp.hip).  Measured at M = 16384 against the kernels below:
-    // K = 3072 / 2304: 74-79 / 58 us vs 90 / 68 (ping-pong).  For K = 768 it also wins the back-to-back microbenchmark (QKV 64.5 vs
-    // 72 us, dual-output FFN 129 vs 143, GELU-bwd 106 vs 128) but NOT the training step (18.24 vs 18.17 ms): with cold
-    // operands its single workgroup per CU hides HBM latency worse than two 128x128 workgroups -- AMDSEG_DP_MIN_K selects
+    // M % 256 == 0 and N a multiple of 256 (or of 192), K >= 768: the deep-pipeline kernel (gemm_dp.hip).  Measured at M = 16384 against
+    // the kernels below: K = 3072 / 2304: 73 / 56 us vs 90 / 68 (ping-pong); K = 768 (since the LDS-DMA is issued as inline asm and
+    // the GELU epilogues were slimmed): QKV 65 vs 67, dual-output FFN 95 vs 131, GELU-bwd 92 vs 127, N = 768: 24 vs 27; train step
+    // 16.4 vs 16.9 ms.  AMDSEG_DP_MIN_K moves the threshold.
     if ((a_in.M % 256) == 0 && ((a_in.N % 256) == 0 || (a_in.N % 192) == 0) && a_in.K >= dp_min_k && !g_force_small_tile)
         return amdseg_launch_nt_dp<EPIX, OutT>(a_in, s);
     // the ping-pong kernel counts its in-flight stores (two outputs for BIAS_GELU): the single-output form runs on the 128x128 kernel
