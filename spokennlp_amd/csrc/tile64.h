@@ -6,12 +6,17 @@
 #define HD 64          // tile width (head dim)
 #define CH 64          // rows per streamed chunk
 
-// XOR swizzle for [rows][64] bf16 tiles (128 B rows, 8 chunks of 16 B): chunk c of row r lives at chunk c ^ swz(r).
-// ds_read_b128 serves a wave in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... = 8 rows at chunk c and the other 8
-// rows of the fragment at chunk c ^ 1; f(p) = p ^ (p in {2,3,4,5}) over the row pair p = (r >> 1) & 7 makes the 16 lanes of a
-// group hit 16 distinct 16-B slots (the earlier (((r>>1)&3)<<1)|((r>>3)&1) had 2-way conflicts on EVERY b128 fragment read --
-// SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE in the GEMM prototype).
-__device__ __forceinline__ int swz(int r) { const int p = (r >> 1) & 7; return p ^ (((p + 2) >> 2) & 1); }
+// XOR swizzle for [rows][64] bf16 tiles (128 B rows, 8 chunks of 16 B): chunk c of row r lives at chunk c ^ swz(r), swz(r) = 2 * ((r >> 1) & 3).
+// One function that is conflict free for BOTH ways these tiles are read:
+//  * ds_read_b128 fragments (lane = row l&15, chunk kk*4 + (l>>4)) are served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... =
+//    the row pairs p = (r>>1)&7 in {0,1,6,7} at chunk c and {2,3,4,5} at chunk c ^ 1 (and the complement): the 16 lanes hit 16 distinct 16-B
+//    slots iff {s(0),s(1),s(6),s(7)} u {s(2)^1,..,s(5)^1} and {s(2),..,s(5)} u {s(0)^1,s(1)^1,s(6)^1,s(7)^1} both cover 0..7;
+//  * ds_read_b64_tr_b16 gathers touch, per 32-lane group, 8 CONSECUTIVE rows (aligned to 8) x 32 B: conflict free iff s(r) >> 1 takes four
+//    different values over the four row pairs of the group.
+// s = {0,2,4,6,0,2,4,6} satisfies both (exhaustive search over the 2-bit-permutation x low-bit family: 9216 solutions); the earlier
+// (((r>>1)&3)<<1)|((r>>3)&1) failed the first condition (2-way conflicts on every b128 fragment), p ^ (p in {2,3,4,5}) the second
+// (SQ_LDS_BANK_CONFLICT = 22-29 % of SQ_LDS_IDX_ACTIVE in the attention kernels, whose tiles are read both ways).
+__device__ __forceinline__ int swz(int r) { return ((r >> 1) & 3) << 1; }
 
 __device__ __forceinline__ void at_glds16(const void* g, void* lds_wave_base) {
     amdseg_glds16(g, lds_wave_base);
