@@ -38,7 +38,8 @@ def list_reference(qkv, mask_bias, B, L, heads, klist, kcnt, dctx=None):
     return ctx.detach(), qkv.grad
 
 
-@pytest.mark.parametrize("B,L,heads,train", [(2, 1024, 2, False), (2, 1024, 2, True), (1, 768, 4, True), (1, 2048, 2, True)])
+@pytest.mark.parametrize("B,L,heads,train", [(2, 1024, 2, False), (2, 1024, 2, True), (1, 768, 4, True), (1, 2048, 2, True),
+                                             (1, 4096, 2, False)])   # eval lists at L = 4096: key block 0 is visited 250 times (list reload path)
 def test_list_attention_fwd_bwd(dev, B, L, heads, train):
     from spokennlp_amd import ops, bigbird_plan
     torch.manual_seed(L + heads)
@@ -49,6 +50,7 @@ def test_list_attention_fwd_bwd(dev, B, L, heads, train):
     mask = torch.zeros(B, L, device=dev)
     mask[0, L - 37:] = -10000.0                                   # padded tail in the first sequence, the reference's penalty
     dctx = (torch.randn(B * L, H, device=dev) * 0.5).bfloat16()
+    assert L < 4096 or int(t["qcnt"].max()) > 64
     ctx, lse = ops.attn_list_fwd(qkv, mask, B, L, heads, klist, kcnt, t["stride"], korder=korder if train else None)
     dqkv = ops.attn_list_bwd(qkv, mask, ctx, dctx, lse, B, L, heads, klist, kcnt, qlist, qcnt, t["stride"],
                              korder=korder if train else None, qorder=qorder if train else None)
