@@ -187,4 +187,5 @@ def test_longformer_dropout_step_deterministic(dev):
         gn = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in m.parameters())).item()
         assert math.isfinite(loss.item()) and math.isfinite(gn)
         vals.append((loss.item(), gn))
-    assert vals[0] == vals[1]
+    assert vals[0][0] == vals[1][0]                                   # same masks, same loss bit for bit
+    assert abs(vals[0][1] - vals[1][1]) <= 1e-6 * vals[0][1]          # embedding-table grads use fp32 atomics (order may vary)
