@@ -186,6 +186,9 @@ int amdseg_attn_list_fwd(const void* qkv, const float* mask_bias, void* ctx, flo
 int amdseg_attn_list_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta_ws, void* dqkv, int B, int L, int heads, float scale, const int* klist, const int* kcnt,
                          const int* qlist, const int* qcnt, int list_stride, const int* korder, const int* qorder, amdseg_stream_t stream);
+/* fp32 parity-mode list attention (inference): qkv / ctx fp32, same lists; L <= 4096 (at most 64 listed key blocks per query block) */
+int amdseg_attn_list_f32(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, float scale,
+                         const int* klist, const int* kcnt, int list_stride, amdseg_stream_t stream);
 /* test hook: v != 0 routes GEMMs that would take a 256-wide deep-pipeline kernel to the 128 x 128 kernels instead, so both
  * code paths can be compared on one shape; returns the previous value.  Not part of the reference-facing surface. */
 int amdseg_debug_force_small_tile(int v);

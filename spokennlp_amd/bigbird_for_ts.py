@@ -63,12 +63,10 @@ class BigBirdEncoderEngine(BertEncoderEngine):
             self.attention_type = "original_full"           # reference: permanent (set_attention_type), with a logged warning
         if self.attention_type == "block_sparse":
             fp32 = (not train) and getattr(self.cfg, "amdseg_precision", "bf16") == "fp32"
-            if fp32:
-                raise L.AmdsegError("block-sparse BigBird has no fp32 parity kernel; use bf16 (or L <= 704: full attention)")
             valid = (attention_mask == 1)
-            self._cur = dict(plan=self._plan(Lseq, train),
+            self._cur = dict(plan=self._plan(Lseq, train), fp32=fp32,
                              mb=((~valid).to(torch.float32) * -10000.0).reshape(-1).contiguous(),
-                             rowmask=valid.to(torch.bfloat16).reshape(-1, 1).contiguous(),
+                             rowmask=valid.to(torch.float32 if fp32 else torch.bfloat16).reshape(-1, 1).contiguous(),
                              all_valid=bool(valid.all()))
         else:
             self._cur = None
@@ -84,7 +82,10 @@ class BigBirdEncoderEngine(BertEncoderEngine):
         L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].1")
         la = A["layers"][i if train else 0]
         with torch.no_grad():
-            ops.attn_list_fwd(la["qkv"], cur["mb"], cfg.B, cfg.L, self.heads, pl["klist"], pl["kcnt"], pl["stride"], ctx=la["ctx"], lse=la["lse"], korder=pl["korder"])
+            if cur["fp32"]:                                  # parity mode: plain fp32 kernel, same lists
+                ops.attn_list_f32(la["qkv"], cur["mb"], cfg.B, cfg.L, self.heads, pl["klist"], pl["kcnt"], pl["stride"], ctx=la["ctx"])
+            else:
+                ops.attn_list_fwd(la["qkv"], cur["mb"], cfg.B, cfg.L, self.heads, pl["klist"], pl["kcnt"], pl["stride"], ctx=la["ctx"], lse=la["lse"], korder=pl["korder"])
             if not cur["all_valid"]:
                 la["ctx"].mul_(cur["rowmask"])               # reference: context_layer * from_mask
         cfg.phase = 2

@@ -61,6 +61,9 @@ int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ct
 int amdseg_attn_f32_impl(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, int d,
                          float scale, int window, int nglobal, hipStream_t s);
 
+int amdseg_attn_list_f32_impl(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, float scale,
+                              const int* klist, const int* kcnt, int stride, hipStream_t s);
+
 int amdseg_lf_rowvec_dot_impl(const void* x, const float* vec, const float* add_tok, const float* add_bh, float* out, int B, int L,
                               int H, int heads, int dtype, int ldx, hipStream_t s);
 int amdseg_lf_softmax_fwd_impl(float* s_inout_p, float* pd, float* sp, int rows, int L, float p, uint64_t seed, hipStream_t s);

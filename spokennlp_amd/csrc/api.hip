@@ -154,6 +154,10 @@ int amdseg_attn_list_fwd(const void* qkv, const float* mask_bias, void* ctx, flo
                          const int* klist, const int* kcnt, int list_stride, const int* korder, amdseg_stream_t stream) {
     return amdseg_attn_list_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, klist, kcnt, list_stride, korder, S(stream));
 }
+int amdseg_attn_list_f32(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, float scale,
+                         const int* klist, const int* kcnt, int list_stride, amdseg_stream_t stream) {
+    return amdseg_attn_list_f32_impl(qkv, mask_bias, ctx, B, L, heads, scale, klist, kcnt, list_stride, S(stream));
+}
 int amdseg_attn_list_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta_ws, void* dqkv, int B, int L, int heads, float scale, const int* klist, const int* kcnt,
                          const int* qlist, const int* qcnt, int list_stride, const int* korder, const int* qorder, amdseg_stream_t stream) {
@@ -199,7 +203,8 @@ static int check_cfg(const amdseg_bert_cfg* c) {
     if ((M % 128) || (c->H % 128) || (c->I % 128) || (c->L % 64)) return AMDSEG_ERR_SHAPE;
     if (c->window < 0 || c->nglobal < 0 || c->phase < 0 || (c->phase > 4 && c->phase != 6)) return AMDSEG_ERR_ARG;
     if (c->nproj < 0 || c->nproj > 8 || c->mixer < 0 || c->mixer > 1 || c->act < 0 || c->act > 1) return AMDSEG_ERR_ARG;
-    if (c->mixer == 1 && (c->dtype != AMDSEG_BF16 || c->phase == 0 || c->phase == 3 || c->phase > 2)) return AMDSEG_ERR_ARG;
+    if (c->mixer == 1 && (c->phase == 0 || c->phase == 3 || c->phase > 2)) return AMDSEG_ERR_ARG;
+    if (c->mixer == 1 && c->dtype != AMDSEG_BF16 && c->nproj != 0 && c->nproj != 3) return AMDSEG_ERR_ARG;   // fp32 parity mode: q|k|v only
     return AMDSEG_OK;
 }
 // phase: 0 or 3 = whole layer; 1 = first part only; 2 = second part only.  The split point is the attention context:
@@ -225,7 +230,8 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         if (c->p_hidden != 0.f || c->p_attn != 0.f) return AMDSEG_ERR_ARG;
         if (PHASE1(c)) {
             RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->x_in, H, (const float*)p->wqkv, H, (float*)a->qkv, 3 * H, M, 3 * H, H, 1, p->bqkv, s));
-            RET_IF(amdseg_attn_f32_impl((const float*)a->qkv, mask_bias, (float*)a->ctx, c->B, c->L, c->heads, 64, 0.125f, c->window, c->nglobal, s));
+            if (c->mixer == 0)
+                RET_IF(amdseg_attn_f32_impl((const float*)a->qkv, mask_bias, (float*)a->ctx, c->B, c->L, c->heads, 64, 0.125f, c->window, c->nglobal, s));
         }
         if (!PHASE2(c)) return AMDSEG_OK;
         RET_IF(amdseg_gemm_f32_nt_impl((const float*)a->ctx, H, (const float*)p->wo, H, (float*)a->z1, H, M, H, H, 1, p->bo, s));

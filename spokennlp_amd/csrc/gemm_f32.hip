@@ -181,3 +181,60 @@ int amdseg_attn_f32_impl(const float* qkv, const float* mask_bias, float* ctx, i
     hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, qkv, mask_bias, ctx, B, L, heads, scale, window, window > 0 ? nglobal : 0);
     return amdseg_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ fp32 block-list attention
+// BigBird block-sparse attention in fp32 (inference parity mode): for the 64-query block qb of head h ONE softmax over the key
+// blocks klist[h][qb][0 .. kcnt[h][qb]) -- duplicates count once per listing, as in the bf16 kernel (attention.hip, LIST mode)
+// and the reference's gathered-block formulation.  One wave per (b, h, q), lanes own one key of each listed block.
+__global__ __launch_bounds__(256) void attn_list_f32_kernel(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads,
+                                                            float scale, const int* klist, const int* kcnt, int stride) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + w;            // (b*heads + h)*L + q
+    const size_t total = (size_t)B * heads * L;
+    if (row >= total) return;
+    const int q = row % L;
+    const int h = (row / L) % heads;
+    const int b = row / ((size_t)L * heads);
+    const int H = heads * 64, H3 = 3 * H, nb = L / 64;
+    const int* kl = klist + ((size_t)h * nb + (q >> 6)) * stride;
+    const int n = min(kcnt[h * nb + (q >> 6)], F32_MAXS);      // a list never holds more than L/64 <= 64 entries
+    const float qd = qkv[((size_t)b * L + q) * H3 + h * 64 + l];
+    float s[F32_MAXS];
+    float mx = -INFINITY;
+    for (int e = 0; e < F32_MAXS; ++e) {
+        if (e >= n) { s[e] = -INFINITY; continue; }
+        const int j = kl[e] * 64 + l;
+        const float* kp = qkv + ((size_t)b * L + j) * H3 + H + h * 64;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) acc = fmaf(__shfl(qd, d, 64), kp[d], acc);
+        acc = acc * scale + mask_bias[(size_t)b * L + j];
+        s[e] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int e = 0; e < F32_MAXS; ++e) { s[e] = expf(s[e] - mx); sum += s[e]; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    float o = 0.f;
+    for (int e = 0; e < F32_MAXS; ++e) {
+        if (e >= n) break;
+        const float ps = s[e] * inv;
+        const int j0 = kl[e] * 64;
+        for (int jj = 0; jj < 64; ++jj) {
+            const float pj = __shfl(ps, jj, 64);
+            o = fmaf(pj, qkv[((size_t)b * L + j0 + jj) * H3 + 2 * H + h * 64 + l], o);
+        }
+    }
+    ctx[((size_t)b * L + q) * H + h * 64 + l] = o;
+}
+
+int amdseg_attn_list_f32_impl(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, float scale,
+                              const int* klist, const int* kcnt, int stride, hipStream_t s) {
+    if (!qkv || !mask_bias || !ctx || !klist || !kcnt) return AMDSEG_ERR_ARG;
+    if (B <= 0 || heads <= 0 || L <= 0 || (L % 64) || L > 64 * F32_MAXS || stride <= 0) return AMDSEG_ERR_SHAPE;
+    const size_t total = (size_t)B * heads * L;
+    hipLaunchKernelGGL(attn_list_f32_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, qkv, mask_bias, ctx, B, L, heads, scale, klist, kcnt, stride);
+    return amdseg_launch_status();
+}

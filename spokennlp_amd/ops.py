@@ -103,6 +103,15 @@ def attn_list_fwd(qkv, mask_bias, B, Lseq, heads, klist, kcnt, stride, ctx=None,
     return ctx, lse
 
 
+def attn_list_f32(qkv, mask_bias, B, Lseq, heads, klist, kcnt, stride, ctx=None, scale=0.125):
+    """fp32 parity-mode block-list attention (amdseg_attn_list_f32): qkv fp32 [B*L, 3*heads*64] -> ctx fp32 [B*L, heads*64]"""
+    if ctx is None:
+        ctx = torch.empty((B * Lseq, heads * 64), dtype=torch.float32, device=qkv.device)
+    rc = L.load().amdseg_attn_list_f32(_p(qkv), _p(mask_bias), _p(ctx), B, Lseq, heads, scale, _p(klist), _p(kcnt), stride, _s())
+    L.check(rc, "amdseg_attn_list_f32")
+    return ctx
+
+
 def attn_list_bwd(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, klist, kcnt, qlist, qcnt, stride, dqkv=None, delta=None, scale=0.125,
                   korder=None, qorder=None):
     if dqkv is None:

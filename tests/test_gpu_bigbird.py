@@ -65,6 +65,21 @@ def test_list_attention_fwd_bwd(dev, B, L, heads, train):
         assert ((a - b).norm() / b.norm()).item() < 2e-2, name
 
 
+@pytest.mark.parametrize("B,L,heads,train", [(2, 1024, 2, False), (1, 768, 4, True), (1, 4096, 2, False)])
+def test_list_attention_fp32_parity_kernel(dev, B, L, heads, train):
+    """amdseg_attn_list_f32 (inference parity mode) against the plain torch fp32 restatement: 1e-5"""
+    from spokennlp_amd import ops, bigbird_plan
+    torch.manual_seed(L)
+    t = bigbird_plan.build(L, heads, 3, seed=2, training=train, max_seqlen=4096)
+    klist, kcnt = torch.from_numpy(t["klist"]).to(dev), torch.from_numpy(t["kcnt"]).to(dev)
+    qkv = torch.randn(B * L, 3 * heads * 64, device=dev)
+    mask = torch.zeros(B, L, device=dev)
+    mask[0, L - 37:] = -10000.0
+    ctx = ops.attn_list_f32(qkv, mask, B, L, heads, klist, kcnt, t["stride"])
+    ref = list_reference(qkv, mask, B, L, heads, t["klist"], t["kcnt"])
+    assert (ctx - ref).abs().max().item() < 1e-5
+
+
 def test_list_equals_full_attention_when_every_block_is_listed(dev):
     from spokennlp_amd import ops
     B, L, heads = 2, 512, 2
@@ -132,6 +147,21 @@ def test_bigbird_eval_vs_reference_golden(dev, case, variant):
     print(f"{case}/{variant}: max|dlogit| {d:.2e}")
     assert d < 0.08 and abs(loss.item() - float(z[f"{variant}.loss"])) < 0.05
     assert O.decode_predictions(logits.cpu()[:, 0], batch["labels"][:, 0]) == O.decode_predictions(ref[:, 0], batch["labels"][:, 0])
+
+
+@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768"])
+@pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
+def test_bigbird_block_sparse_fp32_parity(dev, case, variant):
+    """block-sparse attention in fp32 parity mode: the north-star tolerance (1e-3) against the reference's logits"""
+    z, sd, batch, arch = bb_case(case)
+    m = build_bb(arch, flags_of(z, variant), sd, dev, precision="fp32").eval()
+    random.seed(int(z[f"{variant}.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos = m(**{k: v.to(dev) for k, v in batch.items()})
+    d = (logits.cpu() - torch.from_numpy(z[f"{variant}.logits"])).abs().max().item()
+    print(f"{case}/{variant} fp32: max|dlogit| {d:.2e}")
+    assert d < 1e-3 and abs(loss.item() - float(z[f"{variant}.loss"])) < 1e-3
+    assert m.engine().attention_type == "block_sparse"
 
 
 def test_bigbird_full_attention_fallback_fp32_parity(dev):
