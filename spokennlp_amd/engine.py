@@ -428,16 +428,44 @@ class BertEncoderEngine:
 
 class EncoderFn(torch.autograd.Function):
     """autograd glue: forward/backward of the whole encoder run in HIP; parameter grads are written straight into
-    the flat gradient buffer (param.grad views), so autograd only carries the activation gradient."""
+    the flat gradient buffer (param.grad views), so autograd only carries the activation gradient.
+
+    The kernels work on 64-token blocks and 128-row GEMM tiles; any other [B, L] the caller hands over (the reference accepts every
+    shape) is padded here with masked pad tokens / fully masked sequences and the output is cut back, which leaves the valid tokens'
+    results unchanged (padded keys are masked exactly as the reference masks its own padding)."""
+
+    @staticmethod
+    def aligned_shape(B, Lq):
+        Lp = -(-Lq // 64) * 64
+        Bp = B
+        while (Bp * Lp) % 128:
+            Bp += 1
+        return Bp, Lp
 
     @staticmethod
     def forward(ctx, trigger, engine, input_ids, attention_mask, token_type_ids, train, seed, p_out):
+        B, Lq = input_ids.shape
+        Bp, Lp = EncoderFn.aligned_shape(B, Lq)
+        ctx.shapes = (B, Lq, Bp, Lp)
+        if (Bp, Lp) != (B, Lq):
+            pad_id = getattr(engine.cfg, "pad_token_id", None) or 0
+            grow = (0, Lp - Lq, 0, Bp - B)
+            input_ids = torch.nn.functional.pad(input_ids, grow, value=pad_id)
+            attention_mask = torch.nn.functional.pad(attention_mask, grow, value=0)
+            token_type_ids = torch.nn.functional.pad(token_type_ids, grow, value=0)
         out, ectx = engine.forward(input_ids, attention_mask, token_type_ids, train, seed, p_out)
         ctx.engine, ctx.ectx = engine, ectx
+        if (Bp, Lp) != (B, Lq):
+            out = out[:B, :Lq].contiguous()
         return out
 
     @staticmethod
     def backward(ctx, dseq):
+        B, Lq, Bp, Lp = ctx.shapes
+        if (Bp, Lp) != (B, Lq):
+            full = dseq.new_zeros((Bp, Lp, dseq.shape[-1]))
+            full[:B, :Lq] = dseq
+            dseq = full
         ctx.engine.backward(ctx.ectx, dseq, accumulate=True)
         return (torch.zeros(1, device=dseq.device),) + (None,) * 7
 

@@ -168,8 +168,9 @@ def test_bad_shapes_and_devices_fail_loudly(dev):
     from spokennlp_amd.lib import AmdsegError
     m, batch = _tiny(dev)
     m.eval()
-    with pytest.raises(AmdsegError):
-        m(**{k: v[:1, :, :40].to(dev) for k, v in batch.items()})        # 2 x 40 tokens: not a multiple of the kernel tiles
+    ids = batch["input_ids"][:1, 0, :40].to(dev)                         # 40 tokens: not a multiple of the kernel tiles -- the wrapper
+    with pytest.raises(AmdsegError):                                     # pads such shapes (EncoderFn), the engine itself refuses them
+        m.engine().forward(ids, torch.ones_like(ids), torch.zeros_like(ids), False)
     with pytest.raises(AmdsegError):
         m(**{k: v.to(dev) for k, v in batch.items()}, output_hidden_states=True)
     from tests.test_gpu_model import build_model  # noqa: F401

@@ -175,6 +175,28 @@ def test_longformer_train_grads_vs_reference_golden(dev, case):
     assert checked > 40
 
 
+def test_longformer_unaligned_length_vs_oracle(dev):
+    """L = 96 (a multiple of the attention window, not of the 64-token kernel block... nor of a 128-row tile): EncoderFn pads with
+    masked pad tokens; fp32 parity mode against the oracle on a fresh batch"""
+    from oracle import bert_ts_oracle as O
+    from oracle import longformer_ts_oracle as LO
+    from spokennlp_amd import data
+    z, sd, _, arch = lf_case("lf_tiny_L128_w16")
+    flags = flags_of(z, "full_eval")
+    docs = data.synth_docs(10, seed=9, vocab=arch["vocab_size"], mean_sents=14, sd_sents=4, mean_boundaries=3, mu_tok=1.6, sigma_tok=0.4)
+    batch = data.batches_from_docs(docs, 96, 3, seed=2)[0]
+    cfg = O.make_cfg(num_labels=2, **arch, **flags); cfg["layer_norm_eps"] = 1e-5
+    random.seed(4)
+    with torch.no_grad():
+        lo, logits_o, cos_o = O.model_forward(sd, cfg, batch, encode=LO.longformer_encode)
+    m = build_lf(arch, flags, sd, dev, precision="fp32").eval()
+    random.seed(4)
+    with torch.no_grad():
+        lm, logits_m, cos_m = m(**{k: v.to(dev) for k, v in batch.items()})
+    assert logits_m.shape == logits_o.shape
+    assert (logits_m.cpu() - logits_o).abs().max().item() < 1e-3 and abs(lm.item() - lo.item()) < 1e-3
+
+
 def test_longformer_dropout_step_deterministic(dev):
     z, sd, batch, arch = lf_case("lf_tiny_L64_w8")
     vals = []

@@ -128,6 +128,53 @@ def test_fresh_inputs_vs_oracle(dev):
         assert c > 0.99, (n, c)
 
 
+@pytest.mark.parametrize("Lq,B", [(100, 3), (50, 3), (72, 1)])
+def test_unaligned_shapes_vs_oracle(dev, Lq, B):
+    """windows that are not a multiple of 64 tokens / batches that do not fill a 128-row tile (the reference takes any shape):
+    EncoderFn pads with masked tokens and cuts the output back -- eval in fp32 parity mode to 1e-3, one bf16 train step"""
+    from oracle import bert_ts_oracle as O
+    from spokennlp_amd import data
+    from tests.util import tiny_state_dict
+    arch = dict(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                max_position_embeddings=128, type_vocab_size=2)
+    flags = dict(do_da_ts=True, do_cssl=True, do_tssp=True, cl_loss_weight=0.5, cl_temp=0.1, cl_anchor_level="eop_list",
+                 cl_positive_k=1, cl_negative_k=3, tssp_loss_weight=1.0)
+    sd = tiny_state_dict(arch, seed=7)
+    docs = data.synth_docs(12, seed=5, vocab=300, mean_sents=14, sd_sents=4, mean_boundaries=3, mu_tok=1.6, sigma_tok=0.4)
+    batch = data.batches_from_docs(docs, Lq, B, seed=3)[0]
+    assert batch["input_ids"].shape == (B, 2, Lq)
+    cfg = O.make_cfg(num_labels=2, **arch, **flags)
+    # eval, fp32 parity mode
+    random.seed(11)
+    with torch.no_grad():
+        lo, logits_o, cos_o = O.model_forward(sd, cfg, batch)
+    m = build_model(arch, flags, sd, dev)
+    m.config.amdseg_precision = "fp32"
+    m.eval()
+    random.seed(11)
+    with torch.no_grad():
+        lm, logits_m, cos_m = m(**to_dev(batch, dev))
+    assert logits_m.shape == logits_o.shape
+    assert (logits_m.cpu() - logits_o).abs().max().item() < 1e-3 and abs(lm.item() - lo.item()) < 1e-3
+    assert (cos_m.cpu() - cos_o).abs().max().item() < 1e-3
+    # one training step on the bf16 path
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    random.seed(12)
+    lo, _, _ = O.model_forward(sdo, cfg, batch)
+    lo.backward()
+    m = build_model(arch, flags, sd, dev).train()
+    random.seed(12)
+    lm, _, _ = m(**to_dev(batch, dev))
+    lm.backward()
+    assert abs(lm.item() - lo.item()) < 0.05 * max(1.0, abs(lo.item()) / 5)
+    for n, p in m.named_parameters():
+        go = sdo[n].grad
+        if go is None or float(go.norm()) < 1e-5:
+            continue
+        c = torch.nn.functional.cosine_similarity(p.grad.float().cpu().flatten(), go.flatten(), dim=0).item()
+        assert c > 0.99, (n, c)
+
+
 def test_dropout_training_step_is_finite_and_deterministic(dev):
     z, sd, batch, arch = load_case("tiny_L64")
     losses = []
