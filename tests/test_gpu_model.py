@@ -299,3 +299,55 @@ def test_stock_torch_optimizer_loop_like_hf_trainer(dev):
     with torch.no_grad():
         _, lg, _ = m(**b)
     assert (lg.cpu() - torch.from_numpy(z["full_eval.logits"])).abs().max().item() > 0.05
+
+
+def test_hf_lifecycle_save_load_resize(dev, tmp_path):
+    """the reference driver's model lifecycle (ts_sentence_seq_labeling.py:188-198,247-257,284; run_inference.sh:19,36):
+    save_pretrained -> AutoConfig/from_pretrained(ignore_mismatched_sizes) -> resize_token_embeddings -> forward, also AFTER the engine
+    has re-homed the parameters into its flat buffer (checkpoints written mid-training must hold every tensor)"""
+    from transformers import AutoConfig
+    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+    z, sd, batch, arch = load_case("tiny_L64")
+    flags = flags_of(z, "full_eval")
+    m = build_model(arch, flags, sd, dev).eval()
+    random.seed(5)                                                        # the CSSL sampler draws from Python's global RNG
+    with torch.no_grad():
+        loss0, logits0, _ = m(**to_dev(batch, dev))                      # engine built: parameters are views of one flat buffer now
+    d1 = tmp_path / "ckpt"
+    m.save_pretrained(d1)
+    cfg = AutoConfig.from_pretrained(d1)
+    assert cfg.do_da_ts == flags["do_da_ts"] and cfg.cl_anchor_level == flags["cl_anchor_level"]
+    m2 = M.from_pretrained(d1, config=cfg, ignore_mismatched_sizes=True)
+    sd2 = m2.state_dict()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), sd2[k]), k
+    m2 = m2.to(dev).eval()
+    random.seed(5)
+    with torch.no_grad():
+        loss1, logits1, _ = m2(**to_dev(batch, dev))
+    assert torch.equal(logits0, logits1) and loss0.item() == loss1.item()
+    # [BOS] is added to the tokenizer and the embedding table grows by one row (:284); old rows keep their values
+    V = m2.config.vocab_size
+    m2.resize_token_embeddings(V + 1)
+    assert m2.bert.embeddings.word_embeddings.weight.shape[0] == V + 1
+    with torch.no_grad():
+        loss2, logits2, _ = m2(**to_dev(batch, dev))                     # the engine notices the replaced parameter and rebuilds
+    assert torch.equal(logits1, logits2)
+    b2 = {k: v.clone() for k, v in batch.items()}
+    b2["input_ids"][:, :, 3] = V                                          # the new id is usable
+    with torch.no_grad():
+        _, logits3, _ = m2(**to_dev(b2, dev))
+    assert torch.isfinite(logits3).all() and not torch.equal(logits3, logits2)
+    # a training step, then a checkpoint: gradients do not leak into the saved tensors, optimiser-updated weights do
+    m2.train()
+    random.seed(0)
+    loss, _, _ = m2(**to_dev(batch, dev))
+    loss.backward()
+    m2.engine().adamw_step(lr=1e-3)
+    d2 = tmp_path / "ckpt2"
+    m2.save_pretrained(d2)
+    m3 = M.from_pretrained(d2, config=AutoConfig.from_pretrained(d2))
+    w2, w3 = m2.state_dict(), m3.state_dict()
+    for k in w2:
+        assert torch.equal(w2[k].cpu(), w3[k]), k
+    assert not torch.equal(w3["bert.encoder.layer.0.output.dense.weight"], sd2["bert.encoder.layer.0.output.dense.weight"])
