@@ -4,6 +4,7 @@
 bf16 fast path: MFMA operands and stored activations are bf16 (2^-9 relative rounding), accumulation / softmax /
 LayerNorm statistics fp32.  Tolerances below are for that path and are asserted together with exact equality of
 the decoded boundary predictions; the fp32 'parity mode' test asserts the north-star 1e-3 on logits."""
+import math
 import os
 import random
 import sys
@@ -351,3 +352,42 @@ def test_hf_lifecycle_save_load_resize(dev, tmp_path):
     for k in w2:
         assert torch.equal(w2[k].cpu(), w3[k]), k
     assert not torch.equal(w3["bert.encoder.layer.0.output.dense.weight"], sd2["bert.encoder.layer.0.output.dense.weight"])
+
+
+def test_real_hf_trainer_train_and_predict(dev, tmp_path):
+    """the actual `transformers.Trainer` (ts_sentence_seq_labeling.py:1077-1085 train, :1132 predict) drives the drop-in class:
+    default collator -> (B,2,L) batches, label_names derived from the forward signature, torch AdamW on the parameter views,
+    predict() returning (logits, cos_sim) as compute_metrics unpacks them (:1019-1021)"""
+    from transformers import Trainer, TrainingArguments, default_data_collator
+    from spokennlp_amd import data
+    z, sd, batch, arch = load_case("tiny_L64")
+    flags = flags_of(z, "train_full")
+    docs = data.synth_docs(24, seed=11, vocab=arch["vocab_size"], mean_sents=10, sd_sents=3, mean_boundaries=2, mu_tok=1.4, sigma_tok=0.3)
+    batches = data.batches_from_docs(docs, 64, 1, seed=4)
+    samples = [{k: v[0] for k, v in b.items()} for b in batches][:16]
+    assert len(samples) >= 8
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(samples)
+
+        def __getitem__(self, i):
+            return samples[i]
+
+    m = build_model(arch, flags, sd, dev)
+    w0 = m.state_dict()["bert.encoder.layer.0.output.dense.weight"].clone()
+    args = TrainingArguments(output_dir=str(tmp_path / "out"), per_device_train_batch_size=4, per_device_eval_batch_size=4, max_steps=4,
+                             learning_rate=1e-3, lr_scheduler_type="linear", max_grad_norm=1.0, gradient_accumulation_steps=2,
+                             report_to=[], save_strategy="no", logging_steps=1, seed=7, dataloader_drop_last=True, remove_unused_columns=True)
+    random.seed(3)
+    tr = Trainer(model=m, args=args, train_dataset=DS(), eval_dataset=DS(), data_collator=default_data_collator)
+    assert set(tr.label_names) == {"labels", "sent_level_labels"}
+    out = tr.train()
+    assert out.global_step == 4 and math.isfinite(out.training_loss)
+    assert not torch.equal(m.state_dict()["bert.encoder.layer.0.output.dense.weight"], w0)
+    pred = tr.predict(DS())
+    logits, cos = pred.predictions
+    assert logits.shape == (len(samples), 2, 64, 2) and cos.shape[0] == len(samples)
+    assert np.isfinite(logits).all()
+    lab = pred.label_ids[0] if isinstance(pred.label_ids, (tuple, list)) else pred.label_ids
+    assert lab.shape == (len(samples), 2, 64)
