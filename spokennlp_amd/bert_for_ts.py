@@ -128,13 +128,7 @@ class TopicSegHeadsMixin:
         """[N, L] int64 -> fp32 [N, L, H] sequence output (after the wrapper's dropout in training)."""
         eng = self.engine()
         train = self.training and torch.is_grad_enabled()
-        if train:
-            p0 = next(iter(eng.fp.params.values()))
-            if p0.grad is None or p0.grad.data_ptr() != eng.fp.view(eng.fp.flat_g, next(iter(eng.fp.params))).data_ptr():
-                eng.fp.flat_g.zero_()
-                eng.fp.attach_grads()
-        return EncoderFn.apply(eng._trigger, eng, input_ids, attention_mask, token_type_ids, train, self._next_seed(),
-                               self.classifier_dropout_p)
+        return eng.encode(input_ids, attention_mask, token_type_ids, train, self._next_seed(), self.classifier_dropout_p)
 
     # ------------------------------------------------------------------------------------------------ heads
     def _ts_loss(self, logits, labels):

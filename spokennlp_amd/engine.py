@@ -142,6 +142,39 @@ class BertEncoderEngine:
             self.buckets = GradBuckets(self.fp)
         return self.buckets is not None
 
+    def ddp_compat(self):
+        """torch.distributed world > 1 WITHOUT the engine's own gradient exchange (`enable_data_parallel`): the caller is assumed to have
+        wrapped the model in torch DistributedDataParallel, as `transformers.Trainer` under `torch.distributed.launch` does
+        (run_finetune.sh:61).  DDP reduces a gradient when autograd accumulates it, so in that case the encoder's parameters are passed
+        through autograd (EncoderFn returns their gradients) instead of being written behind its back into `param.grad` views."""
+        import torch.distributed as dist
+        return self.buckets is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def autograd_param_names(self):
+        """the parameters whose gradients `backward` writes (everything under the encoder attribute except the unused pooler)"""
+        if getattr(self, "_ag_names", None) is None:
+            self._ag_names = [n for n in self.fp.params if n.startswith(self.prefix) and ".pooler." not in n]
+        return self._ag_names
+
+    def encode(self, input_ids, attention_mask, token_type_ids, train, seed, p_out):
+        """differentiable encoder call for the wrappers: [N, L] int64 -> fp32 [N, L, H]"""
+        fp = self.fp
+        if train and self.ddp_compat():
+            lo = fp.flat_g.data_ptr()
+            hi = lo + 4 * fp.numel
+            for p in fp.params.values():                     # no gradient may alias the flat buffer in this mode
+                if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+                    p.grad = None
+            return EncoderFn.apply(self._trigger, self, input_ids, attention_mask, token_type_ids, train, seed, p_out,
+                                   *[fp.params[n] for n in self.autograd_param_names()])
+        if train:
+            n0 = next(iter(fp.params))
+            p0 = fp.params[n0]
+            if p0.grad is None or p0.grad.data_ptr() != fp.view(fp.flat_g, n0).data_ptr():
+                fp.flat_g.zero_()
+                fp.attach_grads()
+        return EncoderFn.apply(self._trigger, self, input_ids, attention_mask, token_type_ids, train, seed, p_out)
+
     def finish_grad_sync(self):
         """reduce the non-encoder slice (embeddings, heads) and wait for every outstanding bucket."""
         if self.buckets is not None:
@@ -443,7 +476,8 @@ class EncoderFn(torch.autograd.Function):
         return Bp, Lp
 
     @staticmethod
-    def forward(ctx, trigger, engine, input_ids, attention_mask, token_type_ids, train, seed, p_out):
+    def forward(ctx, trigger, engine, input_ids, attention_mask, token_type_ids, train, seed, p_out, *params):
+        ctx.nparams = len(params)                           # > 0: DDP-compatible mode (engine.ddp_compat)
         B, Lq = input_ids.shape
         Bp, Lp = EncoderFn.aligned_shape(B, Lq)
         ctx.shapes = (B, Lq, Bp, Lp)
@@ -466,7 +500,15 @@ class EncoderFn(torch.autograd.Function):
             full = dseq.new_zeros((Bp, Lp, dseq.shape[-1]))
             full[:B, :Lq] = dseq
             dseq = full
-        ctx.engine.backward(ctx.ectx, dseq, accumulate=True)
+        eng = ctx.engine
+        if ctx.nparams:
+            # the kernels write this call's gradients into the (zeroed) flat buffer; autograd gets a snapshot, so accumulation over
+            # micro-steps, DDP's reduction hooks and any torch optimiser work on ordinary gradient tensors
+            eng.fp.flat_g.zero_()
+            eng.backward(ctx.ectx, dseq, accumulate=True)
+            snap = eng.fp.flat_g.clone()
+            return (torch.zeros(1, device=dseq.device),) + (None,) * 7 + tuple(eng.fp.view(snap, n) for n in eng.autograd_param_names())
+        eng.backward(ctx.ectx, dseq, accumulate=True)
         return (torch.zeros(1, device=dseq.device),) + (None,) * 7
 
 

@@ -70,11 +70,6 @@ class TextEncoder(nn.Module):
             token_type_ids = torch.zeros_like(input_ids)
         eng = self.engine()
         train = self.training and torch.is_grad_enabled()
-        if train:
-            p0 = next(iter(eng.fp.params.values()))
-            if p0.grad is None or p0.grad.data_ptr() != eng.fp.view(eng.fp.flat_g, next(iter(eng.fp.params))).data_ptr():
-                eng.fp.flat_g.zero_()
-                eng.fp.attach_grads()
         self._step += 1
         seed = (int(self.amdseg_seed) * 1000003 + self._step) & 0x7FFFFFFF
-        return EncoderFn.apply(eng._trigger, eng, input_ids, attention_mask, token_type_ids, train, seed, 0.0)
+        return eng.encode(input_ids, attention_mask, token_type_ids, train, seed, 0.0)

@@ -1,0 +1,86 @@
+"""the reference trains under `python -m torch.distributed.launch` + `transformers.Trainer`, i.e. torch
+DistributedDataParallel around the model (run_finetune.sh:61).  Two ranks share the one GPU of the test box over the gloo backend;
+the drop-in class must then route its encoder gradients through autograd so that DDP's reduction hooks see them
+(engine.ddp_compat).  Expected gradients = mean of the two ranks' single-process gradients on the engine's native path."""
+import os
+import random
+import socket
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+from tests.test_oracle_golden import load_case, flags_of  # noqa: E402
+from tests.test_gpu_model import build_model  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank_batch(batch, rank, dev):
+    return {k: v[rank:rank + 1].to(dev) for k, v in batch.items()}
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(0)
+        z, sd, batch, arch = load_case("tiny_L64")
+        m = build_model(arch, flags_of(z, "train_full"), sd, dev).train()
+        ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)   # HF Trainer's default
+        b = _rank_batch(batch, rank, dev)
+        saved = []
+        for it in range(2):                                  # the second iteration is where a reducer that missed hooks complains
+            ddp.zero_grad(set_to_none=True)
+            random.seed(100 + rank)
+            loss, _, _ = ddp(**b)
+            loss.backward()
+            saved.append(dict(loss=loss.item(), grads={n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}))
+        assert m.engine().ddp_compat()
+        torch.save(saved, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_torch_ddp_reduces_engine_gradients(dev, tmp_path):
+    import torch.multiprocessing as mp
+    z, sd, batch, arch = load_case("tiny_L64")
+    assert batch["input_ids"].shape[0] >= 2
+    # single-process expectation on the native path (gradients written into the flat buffer views)
+    per_rank = []
+    for rank in range(2):
+        m = build_model(arch, flags_of(z, "train_full"), sd, dev).train()
+        random.seed(100 + rank)
+        loss, _, _ = m(**_rank_batch(batch, rank, dev))
+        loss.backward()
+        assert not m.engine().ddp_compat()
+        per_rank.append(dict(loss=loss.item(), grads={n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}))
+        del m
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+    for r in range(2):
+        for it in range(2):
+            assert abs(got[r][it]["loss"] - per_rank[r]["loss"]) <= 1e-6 * abs(per_rank[r]["loss"])
+    names = [n for n in per_rank[0]["grads"] if "pooler" not in n]
+    assert len(names) > 30
+    for it in range(2):
+        for n in names:
+            want = 0.5 * (per_rank[0]["grads"][n] + per_rank[1]["grads"][n])
+            for r in range(2):
+                g = got[r][it]["grads"][n]
+                tol = 1e-5 * max(1e-3, float(want.abs().max()))
+                assert float((g - want).abs().max()) <= tol, (it, r, n)
+        for n in got[0][it]["grads"]:
+            assert "pooler" not in n or float(got[0][it]["grads"][n].abs().max()) == 0.0
