@@ -158,22 +158,38 @@ class BertEncoderEngine:
 
     def encode(self, input_ids, attention_mask, token_type_ids, train, seed, p_out):
         """differentiable encoder call for the wrappers: [N, L] int64 -> fp32 [N, L, H]"""
-        fp = self.fp
         if train and self.ddp_compat():
-            lo = fp.flat_g.data_ptr()
-            hi = lo + 4 * fp.numel
-            for p in fp.params.values():                     # no gradient may alias the flat buffer in this mode
-                if p.grad is not None and lo <= p.grad.data_ptr() < hi:
-                    p.grad = None
-            return EncoderFn.apply(self._trigger, self, input_ids, attention_mask, token_type_ids, train, seed, p_out,
-                                   *[fp.params[n] for n in self.autograd_param_names()])
+            return EncoderFn.apply(self._trigger, self, input_ids, attention_mask, token_type_ids, train, seed, p_out, *self.compat_params())
         if train:
-            n0 = next(iter(fp.params))
-            p0 = fp.params[n0]
-            if p0.grad is None or p0.grad.data_ptr() != fp.view(fp.flat_g, n0).data_ptr():
-                fp.flat_g.zero_()
-                fp.attach_grads()
+            self.attach_grads_if_needed()
         return EncoderFn.apply(self._trigger, self, input_ids, attention_mask, token_type_ids, train, seed, p_out)
+
+    def attach_grads_if_needed(self):
+        """native mode: every param.grad is a view of the flat gradient buffer (re-attached after zero_grad(set_to_none=True))"""
+        fp = self.fp
+        n0 = next(iter(fp.params))
+        p0 = fp.params[n0]
+        if p0.grad is None or p0.grad.data_ptr() != fp.view(fp.flat_g, n0).data_ptr():
+            fp.flat_g.zero_()
+            fp.attach_grads()
+
+    def compat_params(self):
+        """DDP-compatible mode: the parameters handed to autograd; no gradient may alias the flat buffer in this mode"""
+        fp = self.fp
+        lo = fp.flat_g.data_ptr()
+        hi = lo + 4 * fp.numel
+        for p in fp.params.values():
+            if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+                p.grad = None
+        return [fp.params[n] for n in self.autograd_param_names()]
+
+    def compat_backward(self, run_backward):
+        """the kernels write this call's gradients into the (zeroed) flat buffer; autograd gets a snapshot, so accumulation over
+        micro-steps, DDP's reduction hooks and any torch optimiser work on ordinary gradient tensors"""
+        self.fp.flat_g.zero_()
+        run_backward()
+        snap = self.fp.flat_g.clone()
+        return tuple(self.fp.view(snap, n) for n in self.autograd_param_names())
 
     def finish_grad_sync(self):
         """reduce the non-encoder slice (embeddings, heads) and wait for every outstanding bucket."""
@@ -502,12 +518,8 @@ class EncoderFn(torch.autograd.Function):
             dseq = full
         eng = ctx.engine
         if ctx.nparams:
-            # the kernels write this call's gradients into the (zeroed) flat buffer; autograd gets a snapshot, so accumulation over
-            # micro-steps, DDP's reduction hooks and any torch optimiser work on ordinary gradient tensors
-            eng.fp.flat_g.zero_()
-            eng.backward(ctx.ectx, dseq, accumulate=True)
-            snap = eng.fp.flat_g.clone()
-            return (torch.zeros(1, device=dseq.device),) + (None,) * 7 + tuple(eng.fp.view(snap, n) for n in eng.autograd_param_names())
+            grads = eng.compat_backward(lambda: eng.backward(ctx.ectx, dseq, accumulate=True))
+            return (torch.zeros(1, device=dseq.device),) + (None,) * 7 + grads
         eng.backward(ctx.ectx, dseq, accumulate=True)
         return (torch.zeros(1, device=dseq.device),) + (None,) * 7
 

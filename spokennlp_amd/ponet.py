@@ -185,7 +185,8 @@ class PoNetEncoderEngine(BertEncoderEngine):
 
 class _PoNetEncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, trigger, engine, input_ids, attention_mask, token_type_ids, segment_ids, train, seed, p_out):
+    def forward(ctx, trigger, engine, input_ids, attention_mask, token_type_ids, segment_ids, train, seed, p_out, *params):
+        ctx.nparams = len(params)                            # > 0: DDP-compatible mode (engine.ddp_compat)
         engine.set_segments(segment_ids)
         out, ectx = engine.forward(input_ids, attention_mask, token_type_ids, train, seed, p_out)
         ctx.engine, ctx.ectx = engine, ectx
@@ -195,6 +196,9 @@ class _PoNetEncoderFn(torch.autograd.Function):
     def backward(ctx, dseq):
         eng, pn = ctx.engine, ctx.ectx["pn"]
         eng._run, eng._valid, eng._coef_mean = pn["run"], pn["valid"], pn["coef_mean"]
+        if ctx.nparams:
+            grads = eng.compat_backward(lambda: eng.backward(ctx.ectx, dseq, accumulate=True))
+            return (torch.zeros(1, device=dseq.device),) + (None,) * 8 + grads
         eng.backward(ctx.ectx, dseq, accumulate=True)
         return (torch.zeros(1, device=dseq.device),) + (None,) * 8
 
@@ -245,15 +249,13 @@ class PoNetForTokenClassification(PreTrainedModel):
             token_type_ids = torch.zeros_like(input_ids)
         eng = self.engine()
         train = self.training and torch.is_grad_enabled()
-        if train:
-            p0 = next(iter(eng.fp.params.values()))
-            if p0.grad is None or p0.grad.data_ptr() != eng.fp.view(eng.fp.flat_g, next(iter(eng.fp.params))).data_ptr():
-                eng.fp.flat_g.zero_()
-                eng.fp.attach_grads()
+        compat = train and eng.ddp_compat()                 # torch DDP around the model: gradients go through autograd (engine.py)
+        if train and not compat:
+            eng.attach_grads_if_needed()
         self._step_seed += 1
         seed = (int(self.amdseg_seed) * 1000003 + self._step_seed) & 0x7FFFFFFF
         seq = _PoNetEncoderFn.apply(eng._trigger, eng, input_ids.contiguous(), attention_mask.contiguous(), token_type_ids.contiguous(),
-                                    segment_ids.contiguous(), train, seed, self.dropout_p)
+                                    segment_ids.contiguous(), train, seed, self.dropout_p, *(eng.compat_params() if compat else ()))
         logits = RowDotFn.apply(seq, self.classifier.weight, self.classifier.bias)
         loss = None
         if labels is not None:

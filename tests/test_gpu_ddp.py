@@ -30,45 +30,65 @@ def _rank_batch(batch, rank, dev):
     return {k: v[rank:rank + 1].to(dev) for k, v in batch.items()}
 
 
-def _worker(rank, world, port, out_dir):
+def _make(family, rank, dev):
+    """(model in train mode, callable running one forward and returning the loss) for one rank's data"""
+    if family == "bert":
+        z, sd, batch, arch = load_case("tiny_L64")
+        m = build_model(arch, flags_of(z, "train_full"), sd, dev).train()
+        b = _rank_batch(batch, rank, dev)
+
+        def run(model):
+            random.seed(100 + rank)
+            return model(**b)[0]
+        return m, run
+    from tests.test_gpu_ponet import build, make_inputs
+    m, _ = build(dev)
+    m = m.to(dev).train()
+    ids, am, seg, lab = [t.to(dev) for t in make_inputs(2, 64, 11 + rank)]
+
+    def run(model):
+        return model(input_ids=ids, attention_mask=am, segment_ids=seg, labels=lab, return_dict=False)[0]
+    return m, run
+
+
+def _grads(m):
+    return {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+def _worker(rank, world, port, out_dir, family):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda:0")
         torch.cuda.set_device(0)
-        z, sd, batch, arch = load_case("tiny_L64")
-        m = build_model(arch, flags_of(z, "train_full"), sd, dev).train()
+        m, run = _make(family, rank, dev)
         ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)   # HF Trainer's default
-        b = _rank_batch(batch, rank, dev)
         saved = []
         for it in range(2):                                  # the second iteration is where a reducer that missed hooks complains
             ddp.zero_grad(set_to_none=True)
-            random.seed(100 + rank)
-            loss, _, _ = ddp(**b)
+            loss = run(ddp)
             loss.backward()
-            saved.append(dict(loss=loss.item(), grads={n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}))
+            saved.append(dict(loss=loss.item(), grads=_grads(m)))
         assert m.engine().ddp_compat()
         torch.save(saved, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-def test_torch_ddp_reduces_engine_gradients(dev, tmp_path):
+@pytest.mark.parametrize("family", ["bert", "ponet"])
+def test_torch_ddp_reduces_engine_gradients(dev, tmp_path, family):
     import torch.multiprocessing as mp
-    z, sd, batch, arch = load_case("tiny_L64")
-    assert batch["input_ids"].shape[0] >= 2
     # single-process expectation on the native path (gradients written into the flat buffer views)
     per_rank = []
     for rank in range(2):
-        m = build_model(arch, flags_of(z, "train_full"), sd, dev).train()
-        random.seed(100 + rank)
-        loss, _, _ = m(**_rank_batch(batch, rank, dev))
+        m, run = _make(family, rank, dev)
+        loss = run(m)
         loss.backward()
         assert not m.engine().ddp_compat()
-        per_rank.append(dict(loss=loss.item(), grads={n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}))
+        per_rank.append(dict(loss=loss.item(), grads=_grads(m)))
         del m
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), family), nprocs=2, join=True)
     got = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
     for r in range(2):
         for it in range(2):
