@@ -104,3 +104,21 @@ def test_torch_ddp_reduces_engine_gradients(dev, tmp_path, family):
                 assert float((g - want).abs().max()) <= tol, (it, r, n)
         for n in got[0][it]["grads"]:
             assert "pooler" not in n or float(got[0][it]["grads"][n].abs().max()) == 0.0
+
+
+def test_bench_two_ranks_on_one_gpu(dev):
+    """the bench.py N > 1 contract (torchrun env, barrier + max-over-ranks timing, one JSON line from rank 0, per-layer gradient
+    buckets reduced from inside backward) with both ranks on this box's single GPU over gloo (AMDSEG_DIST_BACKEND, dp.init_from_env)"""
+    import json
+    import subprocess
+    env = dict(os.environ, AMDSEG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["final_loss"] == out["final_loss"]
