@@ -178,8 +178,8 @@ int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb,
  * head dim 64, L % 64 == 0, mask_bias = -10000 * (1 - attention_mask) as the reference adds it).  Query block i of head h visits
  * the key blocks klist[(h * L/64 + i) * list_stride + 0 .. kcnt[h * L/64 + i]) in order, duplicates included (one softmax over the
  * concatenation, as the reference's torch.cat of key blocks); qlist/qcnt are the transposed lists per (head, key block) with the
- * same multiplicities (device int32 arrays, built by the host mirror spokennlp_amd/bigbird_plan.py).  Rows of padded queries are
- * zeroed by the caller (reference: context_layer * from_mask).  korder / qorder (optional, [heads][L/64]): the block index the r-th
+ * same multiplicities (device int32 arrays, built by the host mirror spokennlp_amd/bigbird_plan.py).  Rows of padded queries
+ * (mask_bias < 0 at the query's own position) come out zero and carry no gradient (reference: context_layer * from_mask).  korder / qorder (optional, [heads][L/64]): the block index the r-th
  * workgroup of a head works on -- sorted by decreasing list length so that the few very long rows (first / last block) start first. */
 int amdseg_attn_list_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                          const int* klist, const int* kcnt, int list_stride, const int* korder, amdseg_stream_t stream);

@@ -7,7 +7,7 @@ What differs from the BERT engine ([hf] models/big_bird/modeling_big_bird.py):
   * BigBirdEmbeddings: LayerNorm(dropout(word + type + position)) -- dropout BEFORE the LayerNorm;
   * hidden_act "gelu_new" (tanh form) in the FFN -- `amdseg_bert_cfg.act = 1`;
   * attention_type "block_sparse": block-list attention (`amdseg_attn_list_fwd/bwd`, lists from bigbird_plan.py), context rows
-    of padded queries zeroed (`context_layer * from_mask`), additive key mask -10000 * (1 - mask); the random blocks are seeded
+    of padded queries zeroed inside the kernels (`context_layer * from_mask`), additive key mask -10000 * (1 - mask); the random blocks are seeded
     with the layer index and are all block 0 in eval mode, as in the reference;
   * sequences of at most (5 + 2 * num_random_blocks) * block_size tokens switch the model to "original_full" attention FOR
     GOOD (`BigBirdModel.forward` calls `set_attention_type`), which is the BERT attention path;
@@ -65,9 +65,7 @@ class BigBirdEncoderEngine(BertEncoderEngine):
             fp32 = (not train) and getattr(self.cfg, "amdseg_precision", "bf16") == "fp32"
             valid = (attention_mask == 1)
             self._cur = dict(plan=self._plan(Lseq, train), fp32=fp32,
-                             mb=((~valid).to(torch.float32) * -10000.0).reshape(-1).contiguous(),
-                             rowmask=valid.to(torch.float32 if fp32 else torch.bfloat16).reshape(-1, 1).contiguous(),
-                             all_valid=bool(valid.all()))
+                             mb=((~valid).to(torch.float32) * -10000.0).reshape(-1).contiguous())
         else:
             self._cur = None
         return super().forward(input_ids, attention_mask, token_type_ids, train, seed, p_out)
@@ -86,8 +84,8 @@ class BigBirdEncoderEngine(BertEncoderEngine):
                 ops.attn_list_f32(la["qkv"], cur["mb"], cfg.B, cfg.L, self.heads, pl["klist"], pl["kcnt"], pl["stride"], ctx=la["ctx"])
             else:
                 ops.attn_list_fwd(la["qkv"], cur["mb"], cfg.B, cfg.L, self.heads, pl["klist"], pl["kcnt"], pl["stride"], ctx=la["ctx"], lse=la["lse"], korder=pl["korder"])
-            if not cur["all_valid"]:
-                la["ctx"].mul_(cur["rowmask"])               # reference: context_layer * from_mask
+            # rows of padded queries come out zero (reference: context_layer * from_mask) and carry no gradient: the kernels read it
+            # off the key mask of the query's own position
         cfg.phase = 2
         L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].2")
         cfg.phase, cfg.mixer, cfg.nproj = 0, 0, 0
@@ -105,8 +103,6 @@ class BigBirdEncoderEngine(BertEncoderEngine):
         L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].1")
         la, ws = A["layers"][i], A["ws"]
         with torch.no_grad():
-            if not cur["all_valid"]:
-                ws["dctx"].mul_(cur["rowmask"])
             ops.attn_list_bwd(la["qkv"], cur["mb"], la["ctx"], ws["dctx"], la["lse"], cfg.B, cfg.L, self.heads, pl["klist"], pl["kcnt"],
                               pl["qlist"], pl["qcnt"], pl["stride"], dqkv=ws["dqkv"], delta=ws["delta"], korder=pl["korder"], qorder=pl["qorder"])
         cfg.phase = 2

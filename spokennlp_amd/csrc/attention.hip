@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     const float lsum = xor_reduce_sum_g(l_part);
     float inv = 1.0f / lsum;
     float lse_q = (m_run + __builtin_amdgcn_logf(lsum)) * LN2;          // natural-log LSE, as backward expects
-    if (BAND && a.mask_bias[tok0 + q] < 0.f) { inv = 0.f; lse_q = INFINITY; }   // padded query: zero row, p == 0 in backward
+    if ((BAND || LIST) && a.mask_bias[tok0 + q] < 0.f) { inv = 0.f; lse_q = INFINITY; }   // padded query: zero row (Longformer :579, BigBird context_layer * from_mask), p == 0 in backward
     bf16_t* op = a.ctx + (tok0 + q) * H + h * HD;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {

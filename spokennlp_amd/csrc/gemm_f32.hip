@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_list_f32_kernel(const float* qkv, co
     float sum = 0.f;
     for (int e = 0; e < F32_MAXS; ++e) { s[e] = expf(s[e] - mx); sum += s[e]; }
     sum = wave_sum(sum);
-    const float inv = 1.0f / sum;
+    const float inv = mask_bias[(size_t)b * L + q] < 0.f ? 0.f : 1.0f / sum;      // padded query: zero row (context_layer * from_mask)
     float o = 0.f;
     for (int e = 0; e < F32_MAXS; ++e) {
         if (e >= n) break;

@@ -32,6 +32,7 @@ def list_reference(qkv, mask_bias, B, L, heads, klist, kcnt, dctx=None):
             blocks.append(torch.softmax(s, -1) @ v[:, h, idx])
         rows.append(torch.cat(blocks, dim=1))
     ctx = torch.stack(rows, dim=1).transpose(1, 2).reshape(B * L, H)
+    ctx = ctx * (mask_bias.reshape(B * L, 1) >= 0)                   # rows of padded queries are zeroed (context_layer * from_mask)
     if dctx is None:
         return ctx
     ctx.backward(dctx.float())
