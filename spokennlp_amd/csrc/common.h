@@ -198,6 +198,20 @@ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
 }
 // thresh = floor(p * 2^32); keep when rng >= thresh
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) { return rng_u32(seed, idx) >= thresh; }
+// Hidden-state dropout of the row kernels works on 16-B chunks (8 consecutive elements): ONE two-round hash of (seed, chunk index),
+// then one multiply round per element pair, 16 bits per element -- 8 quarter-rate v_mul_lo_u32 per chunk instead of 32 (the
+// per-element hash was a quarter of ln_bwd's time at p = 0.1).  keep element e iff its field >= thresh16, thresh16 = round(p * 2^16);
+// inv_keep = 2^16 / (2^16 - thresh16), so the scaling is unbiased for the realised rate.
+__device__ __forceinline__ void drop8_apply(uint64_t seed, uint64_t chunk, uint32_t thresh16, float inv_keep, float (&v)[8]) {
+    const uint32_t h = rng_u32(seed, chunk);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t x = h ^ (0x9e3779b9u * (uint32_t)(i + 1));
+        x *= 0x7feb352du; x ^= x >> 15;
+        v[2 * i] = (x & 0xffffu) >= thresh16 ? v[2 * i] * inv_keep : 0.f;
+        v[2 * i + 1] = (x >> 16) >= thresh16 ? v[2 * i + 1] * inv_keep : 0.f;
+    }
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -83,10 +83,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
             for (int e = 0; e < 8; ++e) v[c][e] = (a[e] + d[e]) + b[e];     // (word + type) + position, as the reference
             // BigBird: LayerNorm(dropout(sum)) ([hf] models/big_bird/modeling_big_bird.py BigBirdEmbeddings.forward); z is then the
             // dropped sum (the LayerNorm input), which is what ln_bwd needs
-            if (pre_ln_dropout && thresh) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[c][e] = drop_keep(seed, (uint64_t)m * H + ch * 8 + e, thresh) ? v[c][e] * inv_keep : 0.f;
-            }
+            if (pre_ln_dropout && thresh) drop8_apply(seed, (uint64_t)m * nch + ch, thresh, inv_keep, v[c]);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
@@ -103,11 +100,8 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
             float gg[8], bb[8];
             ld8<float>(gamma + ch * 8, gg); ld8<float>(beta + ch * 8, bb);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float y = (v[c][e] - mu) * rs * gg[e] + bb[e];
-                if (thresh && !pre_ln_dropout) y = drop_keep(seed, (uint64_t)m * H + ch * 8 + e, thresh) ? y * inv_keep : 0.f;
-                v[c][e] = y;
-            }
+            for (int e = 0; e < 8; ++e) v[c][e] = (v[c][e] - mu) * rs * gg[e] + bb[e];
+            if (thresh && !pre_ln_dropout) drop8_apply(seed, (uint64_t)m * nch + ch, thresh, inv_keep, v[c]);
         }
     }
     row_store<T, NCH>(out + (size_t)m * H, nch, l, v);
@@ -155,12 +149,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
     for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
         if (ch < nch) {
+            if (thresh) drop8_apply(seed, (uint64_t)m * nch + ch, thresh, inv_keep, v[c]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float y = v[c][e];
-                if (thresh) y = drop_keep(seed, (uint64_t)m * H + ch * 8 + e, thresh) ? y * inv_keep : 0.f;
-                v[c][e] = x[c][e] + y;
-            }
+            for (int e = 0; e < 8; ++e) v[c][e] = x[c][e] + v[c][e];
         }
     }
     row_store<T, NCH>(y_z + (size_t)m * H, nch, l, v);
@@ -191,15 +182,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
     extern __shared__ float red[];         // [3][4 waves][H]
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nch = H >> 3;
-    float gg[NCH][8];
     float ag[NCH][8], ab[NCH][8], abias[NCH][8];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int ch = l + c * 64;
-        if (ch < nch) ld8<float>(gamma + ch * 8, gg[c]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; abias[c][e] = 0.f; if (ch >= nch) gg[c][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; abias[c][e] = 0.f; }
     }
+    // gamma lives in the (still unused) reduction area during the row loop: 16 VGPRs less keeps the kernel at 4 waves per SIMD
+    for (int i = threadIdx.x; i < H; i += 256) red[i] = gamma[i];
+    __syncthreads();
     for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
         const int m = blockIdx.x * LNB_ROWS + rr * 4 + w;
         if (m >= M) break;
@@ -211,13 +202,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
             if (l + c * 64 < nch) {
+                float gg[8];
+                ld8<float>(red + (l + c * 64) * 8, gg);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float xh = (x[c][e] - mu) * rs;
                     x[c][e] = xh;
                     ab[c][e] += g[c][e];
                     ag[c][e] += g[c][e] * xh;
-                    g[c][e] *= gg[c][e];
+                    g[c][e] *= gg[e];
                     s1 += g[c][e];
                     s2 += g[c][e] * xh;
                 }
@@ -236,30 +229,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
             for (int c = 0; c < NCH; ++c) {
                 const int ch = l + c * 64;
                 if (ch < nch) {
+                    if (thresh) drop8_apply(seed, (uint64_t)m * nch + ch, thresh, inv_keep, g[c]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float d = g[c][e];
-                        if (thresh) d = drop_keep(seed, (uint64_t)m * H + ch * 8 + e, thresh) ? d * inv_keep : 0.f;
-                        g[c][e] = d;
-                        abias[c][e] += d;
-                    }
+                    for (int e = 0; e < 8; ++e) abias[c][e] += g[c][e];
                 }
             }
             if (dbranch) row_store<T, NCH>(dbranch + (size_t)m * H, nch, l, g);
         }
     }
     if (!partials) return;
+    __syncthreads();                       // every wave is done reading gamma from `red`
     // cross-wave reduce through LDS, then one partial row per block
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
         if (ch < nch) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                red[(0 * 4 + w) * H + ch * 8 + e] = ag[c][e];
-                red[(1 * 4 + w) * H + ch * 8 + e] = ab[c][e];
-                red[(2 * 4 + w) * H + ch * 8 + e] = abias[c][e];
-            }
+            // 16-B LDS stores (H % 8 == 0): the per-element form compiled to 48 ds_write_b32 at a 32-B lane stride = 8-way bank conflicts
+            st8<float>(red + (0 * 4 + w) * H + ch * 8, ag[c]);
+            st8<float>(red + (1 * 4 + w) * H + ch * 8, ab[c]);
+            st8<float>(red + (2 * 4 + w) * H + ch * 8, abias[c]);
         }
     }
     __syncthreads();
@@ -439,10 +427,7 @@ template <typename TI, typename TO>
 __global__ void dropout_kernel(const TI* x, TO* y, size_t n8, uint32_t thresh, float inv_keep, uint64_t seed) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         float v[8]; ld8<TI>(x + i * 8, v);
-        if (thresh) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = drop_keep(seed, i * 8 + e, thresh) ? v[e] * inv_keep : 0.f;
-        }
+        if (thresh) drop8_apply(seed, i, thresh, inv_keep, v);
         st8<TO>(y + i * 8, v);
     }
 }
@@ -613,12 +598,13 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* x, const float
 
 #define ROWK(K, T, H, ...) do { if ((H) <= 1024) hipLaunchKernelGGL((K<T, 2>), __VA_ARGS__); else hipLaunchKernelGGL((K<T, 4>), __VA_ARGS__); } while (0)
 // ------------------------------------------------------------------------------------------------ launchers
+// 16-bit threshold of drop8_apply (common.h); p >= 1 drops everything (inv_keep 0 instead of inf so that 0 * inv_keep stays 0)
 static inline void drop_params(float p, uint32_t& thresh, float& inv_keep) {
     if (p <= 0.f) { thresh = 0; inv_keep = 1.f; return; }
-    double t = (double)p * 4294967296.0;
-    thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    double t = (double)p * 65536.0 + 0.5;
+    thresh = t >= 65536.0 ? 65536u : (uint32_t)t;
     if (thresh == 0) thresh = 1;
-    inv_keep = (float)(4294967296.0 / (4294967296.0 - (double)thresh));
+    inv_keep = thresh >= 65536u ? 0.f : (float)(65536.0 / (65536.0 - (double)thresh));
 }
 
 int amdseg_embed_ln_fwd_impl(const int64_t* ids, const int64_t* type_ids, const float* word, const float* pos,

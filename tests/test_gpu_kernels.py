@@ -383,7 +383,20 @@ def test_hidden_dropout_consistency(dev):
     assert abs(ybuf.mean().item() - 1.0) < 5e-3
     dy = torch.randn(M, H, device=dev)
     dz, dbr = ops.ln_bwd(dy, ybuf, mean, rstd, gamma, p=p, seed=seed)
-    assert torch.allclose(dbr, dz * keep / (1 - p), rtol=1e-5, atol=1e-6)
+    q = round(p * 65536) / 65536                                  # the realised rate: 16-bit threshold (common.h drop8_apply)
+    assert torch.allclose(dbr, dz * keep / (1 - q), rtol=1e-6, atol=1e-6)
+    # mask quality: the 8 elements of a 16-B chunk come from one hash -- no element position may be favoured, and neighbours inside a
+    # pair / a chunk / across chunks must be independent (joint keep rate = (1-p)^2 within 4 sigma)
+    big = torch.ones(4096, H, device=dev); zb = torch.zeros_like(big)
+    ops.add_ln_fwd(big, zb, gamma, beta, 1e-12, p=p, seed=7)
+    k = (big > 0).float()
+    n = k.shape[0] * (H // 8)
+    per_pos = k.view(-1, H // 8, 8).mean(dim=(0, 1))
+    assert (per_pos - (1 - q)).abs().max().item() < 4 * (q * (1 - q) / n) ** 0.5 + 1e-4
+    for shift in (1, 2, 8, H):                                    # same pair, same chunk, next chunk, next row
+        a, b = k.flatten()[:-shift], k.flatten()[shift:]
+        joint = (a * b).mean().item()
+        assert abs(joint - (1 - q) ** 2) < 4 * (0.09 / a.numel()) ** 0.5 + 2e-4, (shift, joint)
     # a different seed gives a different mask
     yb2 = y.clone(); ops.add_ln_fwd(yb2, x, gamma, beta, 1e-12, p=p, seed=seed + 1)
     assert ((yb2 > 0).float() != keep).float().mean().item() > 0.05
