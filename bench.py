@@ -281,9 +281,8 @@ def main():
     name = {"bert": "bert-base-uncased(+[BOS])", "longformer": "longformer-base-4096(+[BOS], window 512, CLS global)",
             "ponet": "PoNet-base(+[EOS], paragraph segment ids)",
             "bigbird": "bigbird-roberta-base(+[BOS], block-sparse: block 64, 3 random blocks)"}[args.model]
-    out = dict(metric={"bert": "train seq/s (512-tok) bert-base topic-seg", "longformer": "train seq/s (4096-tok) longformer-base topic-seg",
-                       "ponet": "train seq/s (4096-tok) PoNet-base topic-seg",
-                       "bigbird": "train seq/s (4096-tok) bigbird-base topic-seg"}[args.model].replace("train", args.mode),
+    out = dict(metric=f"{args.mode} seq/s ({args.seq_len}-tok) " + {"bert": "bert-base", "longformer": "longformer-base", "ponet": "PoNet-base",
+                                                                 "bigbird": "bigbird-base"}[args.model] + " topic-seg",
                value=round(value, 2), unit="seq/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
