@@ -129,3 +129,13 @@ def test_dense_batch_shape():
     b = data.dense_batch(3, L=512, as_torch=False)
     assert b["input_ids"].shape == (3, 2, 512) and (b["attention_mask"] == 1).all()
     assert ((b["labels"][:, 0] != -100).sum(-1) == 20).all()       # 21 sentences, the last one unlabelled
+
+
+def test_encoder_shape_alignment_rule():
+    """EncoderFn pads [B, L] to 64-token blocks and 128-row tiles (engine.py); the rule itself is host logic"""
+    from spokennlp_amd.engine import EncoderFn
+    for B, L in [(1, 40), (3, 50), (3, 100), (1, 64), (2, 64), (5, 192), (7, 4096), (1, 1)]:
+        Bp, Lp = EncoderFn.aligned_shape(B, L)
+        assert Lp % 64 == 0 and Lp >= L and Lp - L < 64
+        assert Bp >= B and (Bp * Lp) % 128 == 0 and Bp - B <= 1
+    assert EncoderFn.aligned_shape(32, 512) == (32, 512)
