@@ -300,6 +300,14 @@ def test_attn_dropout_fwd_bwd(dev):
     keep = extract_keep_mask(ops, dev, B, L, heads, p, seed)
     frac = 1.0 - keep.mean().item()
     assert abs(frac - p) < 0.01, frac
+    # mask quality: neighbours along the key axis (same hash word / next word) and along the query axis are independent
+    kq = 1.0 - round(p * 65536) / 65536
+    for a_, b_ in ((keep[..., :-1], keep[..., 1:]), (keep[..., :-2], keep[..., 2:]), (keep[..., :-1, :], keep[..., 1:, :]),
+                   (keep[:, :1], keep[:, 1:])):
+        joint = (a_ * b_).mean().item()
+        assert abs(joint - kq * kq) < 4 * (0.09 / a_.numel()) ** 0.5 + 1e-3, joint
+    sig = (0.09 / (B * heads * L)) ** 0.5                              # per key column / query row: B * heads * L samples each
+    assert (keep.mean(dim=(0, 1, 2)) - kq).abs().max().item() < 5 * sig and (keep.mean(dim=(0, 1, 3)) - kq).abs().max().item() < 5 * sig
     th = round(p * 65536)
     inv_keep = 65536.0 / (65536 - th)
     qkv, mb = make_qkv(dev, B, L, heads, 21, pad=False)
