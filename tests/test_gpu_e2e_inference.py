@@ -29,7 +29,8 @@ class OracleModel:
         return O.model_forward(self.sd, self.cfg, batch)
 
 
-def test_32_documents_end_to_end(dev, tmp_path):
+@pytest.mark.parametrize("max_len,bs", [(128, 4), (100, 3)])          # (100, 3): neither a 64-token multiple nor a full 128-row tile
+def test_32_documents_end_to_end(dev, tmp_path, max_len, bs):
     from oracle import bert_ts_oracle as O
     from spokennlp_amd import data, inference, preprocess as P
     from tests.test_oracle_golden import load_case, flags_of
@@ -42,9 +43,9 @@ def test_32_documents_end_to_end(dev, tmp_path):
     labels = [[0 if v == 1 else 1 for v in d["labels"]] for d in docs]           # jsonl label 1 (section end) -> "B-EOP" = id 0
     m = build_model(arch, dict(flags, amdseg_precision="fp32"), sd, dev)
     m.config.amdseg_precision = "fp32"
-    got_docs, got_metrics = inference.predict_documents(m, sent_ids, labels, 128, bos, data.CLS_ID, data.PAD_ID, batch_size=4, device=dev)
+    got_docs, got_metrics = inference.predict_documents(m, sent_ids, labels, max_len, bos, data.CLS_ID, data.PAD_ID, batch_size=bs, device=dev)
     ref = OracleModel(sd, O.make_cfg(num_labels=2, **arch, **flags))
-    ref_docs, ref_metrics = inference.predict_documents(ref, sent_ids, labels, 128, bos, data.CLS_ID, data.PAD_ID, batch_size=4, device=None)
+    ref_docs, ref_metrics = inference.predict_documents(ref, sent_ids, labels, max_len, bos, data.CLS_ID, data.PAD_ID, batch_size=bs, device=None)
     assert len(got_docs) == 32
     worst = 0.0
     for g, r, lab in zip(got_docs, ref_docs, labels):
