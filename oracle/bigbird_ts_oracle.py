@@ -103,16 +103,28 @@ def make_encode(rand_fn, training):
     """rand_fn(seq_len, num_heads, num_rand_blocks, seed, training, max_seqlen) -> [heads, nb-2, r] (bigbird_plan.rand_blocks)."""
 
     def bigbird_encode(sd, cfg, input_ids, attention_mask, token_type_ids, return_all=False, prefix=PFX):
-        B, L = input_ids.shape
-        sparse = getattr(cfg, "attention_type", "block_sparse") == "block_sparse" and L > (5 + 2 * cfg.num_random_blocks) * cfg.block_size
-        if sparse and (L % BLOCK or cfg.block_size != BLOCK):
-            raise ValueError("oracle restates block_size 64 with L % 64 == 0 only")
+        B, L0 = input_ids.shape
+        sparse = getattr(cfg, "attention_type", "block_sparse") == "block_sparse" and L0 > (5 + 2 * cfg.num_random_blocks) * cfg.block_size
+        if sparse and cfg.block_size != BLOCK:
+            raise ValueError("oracle restates block_size 64 only")
+        L = L0
+        if sparse and L0 % BLOCK:
+            # [hf] BigBirdModel._pad_to_block_size: right-pad ids with pad_token_id, mask / token types with 0; the output is cut back
+            # to the original length ([hf] BigBirdModel.forward: sequence_output[:, :-padding_len])
+            pad = BLOCK - L0 % BLOCK
+            F = torch.nn.functional
+            input_ids = F.pad(input_ids, (0, pad), value=int(getattr(cfg, "pad_token_id", 0) or 0))
+            attention_mask = F.pad(attention_mask, (0, pad), value=0)
+            token_type_ids = F.pad(token_type_ids, (0, pad), value=0)
+            L = L0 + pad
         x = embeddings(sd, cfg, input_ids, token_type_ids, prefix)
         hs = [x]
         for i in range(cfg.num_hidden_layers):
             rand = rand_fn(L, cfg.num_attention_heads, cfg.num_random_blocks, i, training, cfg.max_position_embeddings) if sparse else None
             x = encoder_layer(sd, cfg, x, attention_mask, i, rand, prefix)
             hs.append(x)
+        if L != L0:
+            x, hs = x[:, :L0], [h[:, :L0] for h in hs]
         return (x, hs) if return_all else x
 
     return bigbird_encode

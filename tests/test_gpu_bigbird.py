@@ -134,7 +134,7 @@ def build_bb(arch, flags, sd, dev, dropout=0.0, precision=None):
     return m.to(dev)
 
 
-@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768", "bb_tiny_L128"])
+@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768", "bb_tiny_L128", "bb_tiny_L1000"])
 @pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
 def test_bigbird_eval_vs_reference_golden(dev, case, variant):
     from oracle import bert_ts_oracle as O
@@ -150,7 +150,7 @@ def test_bigbird_eval_vs_reference_golden(dev, case, variant):
     assert O.decode_predictions(logits.cpu()[:, 0], batch["labels"][:, 0]) == O.decode_predictions(ref[:, 0], batch["labels"][:, 0])
 
 
-@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768"])
+@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768", "bb_tiny_L1000"])
 @pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
 def test_bigbird_block_sparse_fp32_parity(dev, case, variant):
     """block-sparse attention in fp32 parity mode: the north-star tolerance (1e-3) against the reference's logits"""
@@ -175,7 +175,7 @@ def test_bigbird_full_attention_fallback_fp32_parity(dev):
     assert m.engine().attention_type == "original_full"
 
 
-@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768", "bb_tiny_L128"])
+@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768", "bb_tiny_L128", "bb_tiny_L1000"])
 def test_bigbird_train_grads_vs_reference_golden(dev, case):
     """training mode: per-layer, per-head numpy-seeded random blocks as the reference draws them"""
     z, sd, batch, arch = bb_case(case)

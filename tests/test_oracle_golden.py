@@ -214,7 +214,7 @@ def bb_case(name):
     return z, sd, batch, arch
 
 
-@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768", "bb_tiny_L128"])
+@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768", "bb_tiny_L128", "bb_tiny_L1000"])
 @pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
 def test_bigbird_eval_matches_reference(case, variant):
     """block-sparse attention (eval: the random blocks are block 0, counted 1 + 3 times) for L = 1024 / 768, the full-attention
@@ -232,7 +232,7 @@ def test_bigbird_eval_matches_reference(case, variant):
         assert np.abs(hs[last].numpy() - z[f"plain_eval.hidden{last}"]).max() < 3e-5
 
 
-@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768", "bb_tiny_L128"])
+@pytest.mark.parametrize("case", ["bb_tiny_L1024", "bb_tiny_L768", "bb_tiny_L128", "bb_tiny_L1000"])
 def test_bigbird_train_grads_match_reference(case):
     """training mode: the reference's numpy-seeded random blocks (per layer, per head) -- both plan procedures"""
     z, sd, batch, arch = bb_case(case)

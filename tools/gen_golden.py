@@ -351,6 +351,13 @@ if __name__ == "__main__":
         main_fullsize()
     elif "--mmvts-only" in sys.argv:
         main_mmvts()
+    elif "--bigbird-unaligned-only" in sys.argv:
+        # L = 1000 is not a multiple of block_size: the reference pads to 1024 itself (`_pad_to_block_size`) and cuts the output back
+        bb = dict(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                  max_position_embeddings=1024, type_vocab_size=2, block_size=64, num_random_blocks=3, attention_type="block_sparse",
+                  pad_token_id=0, bos_token_id=1, eos_token_id=2, sep_token_id=3)
+        run_case("bb_tiny_L1000", bb, 1000, 1, 9, [("plain_eval", PLAIN, "eval", 0, {}), ("full_eval", FULL, "eval", 5, {}),
+                                                    ("train_full", FULL, "train", 7, {})], kind="bigbird")
     elif "--bigbird-only" in sys.argv:
         main_bigbird([("plain_eval", PLAIN, "eval", 0, {}), ("full_eval", FULL, "eval", 5, {}), ("train_full", FULL, "train", 7, {})])
     else:
