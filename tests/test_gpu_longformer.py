@@ -128,7 +128,7 @@ def build_lf(arch, flags, sd, dev, dropout=0.0, precision=None):
     return m.to(dev)
 
 
-@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16"])
+@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16", "lf_tiny_L100_w16"])
 @pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_longformer_eval_vs_reference_golden(dev, case, variant, precision):
@@ -149,7 +149,7 @@ def test_longformer_eval_vs_reference_golden(dev, case, variant, precision):
     assert O.decode_predictions(logits.cpu()[:, 0], batch["labels"][:, 0]) == O.decode_predictions(ref[:, 0], batch["labels"][:, 0])
 
 
-@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16"])
+@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16", "lf_tiny_L100_w16"])
 def test_longformer_train_grads_vs_reference_golden(dev, case):
     z, sd, batch, arch = lf_case(case)
     m = build_lf(arch, flags_of(z, "train_full"), sd, dev).train()

@@ -122,7 +122,7 @@ def lf_case(name):
     return z, sd, batch, arch
 
 
-@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16"])
+@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16", "lf_tiny_L100_w16"])
 @pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
 def test_longformer_eval_matches_reference(case, variant):
     z, sd, batch, arch = lf_case(case)
@@ -138,7 +138,7 @@ def test_longformer_eval_matches_reference(case, variant):
             assert np.abs(h.numpy() - z[f"plain_eval.hidden{i}"]).max() < 3e-5, i
 
 
-@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16"])
+@pytest.mark.parametrize("case", ["lf_tiny_L64_w8", "lf_tiny_L128_w16", "lf_tiny_L100_w16"])
 def test_longformer_train_grads_match_reference(case):
     z, sd, batch, arch = lf_case(case)
     cfg = O.make_cfg(num_labels=2, **arch, **flags_of(z, "train_full")); cfg["layer_norm_eps"] = 1e-5
