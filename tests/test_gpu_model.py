@@ -37,7 +37,7 @@ def to_dev(batch, dev):
     return {k: v.to(dev) for k, v in batch.items()}
 
 
-@pytest.mark.parametrize("case", ["tiny_L64", "tiny_L128"])
+@pytest.mark.parametrize("case", ["tiny_L64", "tiny_L128", "tiny_L100_B3"])
 @pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
 def test_eval_vs_reference_golden(dev, case, variant):
     from oracle import bert_ts_oracle as O
@@ -213,7 +213,7 @@ def test_fused_adamw_step_matches_torch(dev):
     assert m.engine().fp.flat_g.abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("case", ["tiny_L64", "tiny_L128"])
+@pytest.mark.parametrize("case", ["tiny_L64", "tiny_L128", "tiny_L100_B3"])
 @pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
 def test_fp32_parity_mode_logits_within_1e3(dev, case, variant):
     """north star: logits within 1e-3 of the fp32 CPU reference, predicted boundary indices bit-exact.

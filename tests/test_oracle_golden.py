@@ -43,7 +43,7 @@ def cfg_for(arch, flags):
     return O.make_cfg(num_labels=2, **arch, **flags)
 
 
-@pytest.mark.parametrize("case", ["tiny_L64", "tiny_L128"])
+@pytest.mark.parametrize("case", ["tiny_L64", "tiny_L128", "tiny_L100_B3"])
 @pytest.mark.parametrize("variant", ["plain_eval", "full_eval"])
 def test_eval_forward_matches_reference(case, variant):
     z, sd, batch, arch = load_case(case)

@@ -364,6 +364,11 @@ if __name__ == "__main__":
                   max_position_embeddings=130, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2, layer_norm_eps=1e-5)
         run_case("lf_tiny_L100_w16", dict(lf, attention_window=[32, 32]), 100, 3, 12,
                  [("plain_eval", PLAIN, "eval", 0, {}), ("full_eval", FULL, "eval", 5, {}), ("train_full", FULL, "train", 7, {})], kind="longformer")
+    elif "--bert-unaligned-only" in sys.argv:
+        arch = dict(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                    max_position_embeddings=128, type_vocab_size=2)
+        run_case("tiny_L100_B3", arch, 100, 3, 13, [("plain_eval", PLAIN, "eval", 0, {}), ("full_eval", FULL, "eval", 5, {}),
+                                                    ("train_full", FULL, "train", 7, {})])
     elif "--bigbird-only" in sys.argv:
         main_bigbird([("plain_eval", PLAIN, "eval", 0, {}), ("full_eval", FULL, "eval", 5, {}), ("train_full", FULL, "train", 7, {})])
     else:
