@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 2   /* 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 3   /* 3: amdseg_adamw chunk_flags; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_OK 0
@@ -199,14 +199,29 @@ int amdseg_rowdot_fwd(const void* x, const float* W, const float* b, float* out,
 int amdseg_rowdot_bwd(const void* x, const float* W, const float* dlogits, void* dx, float* partials, float* dW, float* db,
                       int M, int H, int C, int accumulate, int dtype, amdseg_stream_t stream);
 
-/* ---- optimiser (csrc/optim.hip): torch.optim.AdamW + clip_grad_norm_ semantics over flat fp32 buffers ---------- */
+/* ---- optimiser (csrc/optim.hip): torch.optim.AdamW + clip_grad_norm_ semantics over flat fp32 buffers ----------
+ * chunk_flags (nullable = decay everywhere): one byte per 64 consecutive elements, bit 0 = weight decay applies, bit 1 = frozen
+ * (no update) -- the two parameter groups of [hf] trainer.py:1168-1215 (biases / LayerNorm undecayed) on ONE flat buffer. */
 int amdseg_adamw(float* p, const float* g, float* m, float* v, void* bf16_shadow, size_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int step, const float* grad_scale, int zero_grad,
-                 amdseg_stream_t stream);
+                 const unsigned char* chunk_flags, amdseg_stream_t stream);
 int amdseg_sumsq(const float* x, size_t n, float* partials, float* out, int accumulate, amdseg_stream_t stream);
 int amdseg_clip_coef(const float* sumsq, float max_norm, float extra_scale, float* coef, float* norm,
                      amdseg_stream_t stream);
 int amdseg_scale(float* x, size_t n, const float* coef, amdseg_stream_t stream);
+
+/* ---- measurement plumbing (csrc/prof.h, prof.hip): in-kernel begin/end stamps of the device wall clock for the dominant kernels,
+ * taken INSIDE real training steps.  enable(1) allocates + arms the slots (returns the previous state, < 0 on failure); read() syncs
+ * the device and returns, for one launch class, the summed kernel spans (us), the summed algorithmic work (FLOPs) and the number
+ * of launches since the last reset.  Not part of the reference-facing surface (bench.py's `roofline`). */
+#define AMDSEG_PROF_GEMM_NT 0      /* gemm_nt_dp_kernel: forward + dgrad projection GEMMs */
+#define AMDSEG_PROF_GEMM_TN 1      /* gemm_tn_dp_kernel: grouped weight-gradient GEMM */
+#define AMDSEG_PROF_ATTN_FWD 2
+#define AMDSEG_PROF_ATTN_BWD_DQ 3
+#define AMDSEG_PROF_ATTN_BWD_DKV 4
+int amdseg_prof_enable(int on);
+int amdseg_prof_reset(void);
+int amdseg_prof_read(int cls, double* total_us, double* total_work, long long* launches);
 
 /* ---- composite: one BertLayer forward / backward ([hf] models/bert/modeling_bert.py:374-416) -------------------- */
 typedef struct amdseg_bert_cfg {

@@ -130,6 +130,11 @@ class TopicSegHeadsMixin:
         train = self.training and torch.is_grad_enabled()
         return eng.encode(input_ids, attention_mask, token_type_ids, train, self._next_seed(), self.classifier_dropout_p)
 
+    def no_sync(self):
+        """gradient-accumulation context of the engine's own data parallelism (what `accelerate`/`Trainer` look up on a model that is
+        not wrapped in torch DDP); see BertEncoderEngine.no_sync"""
+        return self.engine().no_sync()
+
     # ------------------------------------------------------------------------------------------------ heads
     def _ts_loss(self, logits, labels):
         cfg = self.config

@@ -86,7 +86,8 @@ int amdseg_rowdot_bwd_impl(const void* x, const float* W, const float* dlogits, 
                            float* db, int M, int H, int C, int accumulate, int dtype, hipStream_t s);
 
 int amdseg_adamw_impl(float* p, const float* g, float* m, float* v, void* shadow, size_t n, float lr, float beta1,
-                      float beta2, float eps, float wd, int step, const float* gscale, int zero_grad, hipStream_t s);
+                      float beta2, float eps, float wd, int step, const float* gscale, int zero_grad,
+                      const unsigned char* chunk_flags, hipStream_t s);
 int amdseg_sumsq_impl(const float* x, size_t n, float* partials, float* out, int accumulate, hipStream_t s);
 int amdseg_clip_coef_impl(const float* sumsq, float max_norm, float extra_scale, float* coef, float* norm, hipStream_t s);
 int amdseg_scale_impl(float* x, size_t n, const float* coef, hipStream_t s);

@@ -175,8 +175,9 @@ int amdseg_rowdot_bwd(const void* x, const float* W, const float* dlogits, void*
 }
 int amdseg_adamw(float* p, const float* g, float* m, float* v, void* bf16_shadow, size_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int step, const float* grad_scale, int zero_grad,
-                 amdseg_stream_t stream) {
-    return amdseg_adamw_impl(p, g, m, v, bf16_shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, S(stream));
+                 const unsigned char* chunk_flags, amdseg_stream_t stream) {
+    return amdseg_adamw_impl(p, g, m, v, bf16_shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, chunk_flags,
+                             S(stream));
 }
 int amdseg_sumsq(const float* x, size_t n, float* partials, float* out, int accumulate, amdseg_stream_t stream) {
     return amdseg_sumsq_impl(x, n, partials, out, accumulate, S(stream));

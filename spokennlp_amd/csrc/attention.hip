@@ -14,6 +14,7 @@
 // saved log-sum-exp.  Dropout uses the stateless (seed, element) hash of common.h, re-evaluated in backward.
 #include "common.h"
 #include "amdseg_internal.h"
+#include "prof.h"
 
 #include "tile64.h"
 #define LOG2E 1.4426950408889634f
@@ -624,12 +625,15 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
     int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
+    // algorithmic FLOPs: QK^T + PV over the visible keys (full: L, band: 2W + 1 + G)
+    const double span = window > 0 ? (double)(2 * window + 1 + a.nglobal) : (double)L;
+    const double work = 4.0 * B * heads * (double)L * span * HD;
     if (window > 0) {
-        if (L % 128 == 0) hipLaunchKernelGGL((attn_fwd_kernel<8, true>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((attn_fwd_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        if (L % 128 == 0) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<8, true>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
+        else AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
     } else {
-        if (L % 128 == 0) hipLaunchKernelGGL((attn_fwd_kernel<8, false>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((attn_fwd_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        if (L % 128 == 0) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<8, false>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
+        else AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
     }
     return amdseg_launch_status();
 }
@@ -646,12 +650,15 @@ int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ct
     const size_t total = (size_t)B * L * heads * 8;
     (void)total;           // delta = rowsum(dO * O) is produced by the dQ kernel (attn_delta_kernel is kept for reference / tests)
     // backward kernels need 144-168 VGPRs: 4-wave workgroups keep 3 waves per SIMD resident (8-wave ones would spill or halve occupancy)
+    // algorithmic FLOPs of backward = 2.5 x forward (dV, dP, dQ, dK + the S recomputation counted once): dQ kernel 3 products, dK/dV 4
+    const double span = window > 0 ? (double)(2 * window + 1 + a.nglobal) : (double)L;
+    const double unit = 2.0 * B * heads * (double)L * span * HD;
     if (window > 0) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, true>), dim3((L / 64) * heads * B), dim3(256), 0, s, a);
+        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_BWD_DQ, 2.0 * unit, (attn_bwd_dq_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_BWD_DKV, 3.0 * unit, (attn_bwd_dkv_kernel<4, true>), dim3((L / 64) * heads * B), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_BWD_DQ, 2.0 * unit, (attn_bwd_dq_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_BWD_DKV, 3.0 * unit, (attn_bwd_dkv_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
     }
     return amdseg_launch_status();
 }

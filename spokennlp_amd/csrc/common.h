@@ -11,6 +11,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define AMDSEG_OK 0
+// launch classes of the in-kernel timer (prof.h / amdseg_prof_read)
+#define AMDSEG_PROF_GEMM_NT 0
+#define AMDSEG_PROF_GEMM_TN 1
+#define AMDSEG_PROF_ATTN_FWD 2
+#define AMDSEG_PROF_ATTN_BWD_DQ 3
+#define AMDSEG_PROF_ATTN_BWD_DKV 4
 #define AMDSEG_ERR_SHAPE 1001      // unsupported / misaligned shape
 #define AMDSEG_ERR_ARG 1002        // null pointer / bad enum
 #define AMDSEG_ERR_LAUNCH 1003     // hip launch error (hipGetLastError non-zero)

@@ -264,7 +264,8 @@ static int launch_nt_dp_nf(const GemmNTArgs& a_in, hipStream_t s) {
     }
     GemmNTArgs a = a_in;
     a.tiles_m = a.M / DP_BM; a.tiles_n = a.N / (NF * 64);
-    hipLaunchKernelGGL((gemm_nt_dp_kernel<EPIX, OutT, NF>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS, s, a);
+    AMDSEG_LAUNCH_PROF(AMDSEG_PROF_GEMM_NT, 2.0 * a.M * a.N * a.K, (gemm_nt_dp_kernel<EPIX, OutT, NF>), dim3(a.tiles_m * a.tiles_n),
+                       dim3(512), LDS, s, a);
     return amdseg_launch_status();
 }
 
@@ -509,6 +510,8 @@ int amdseg_launch_tn_dp(const GemmTNArgs& a128, hipStream_t s) {
         tiles += (a.p[i].N / 256) * (a.p[i].Kp / 128);
     }
     a.total_tiles = tiles;
-    hipLaunchKernelGGL(gemm_tn_dp_kernel, dim3(tiles), dim3(512), TN_LDS, s, a);
+    double work = 0;
+    for (int i = 0; i < a.nprob; ++i) work += 2.0 * a.M * a.p[i].N * a.p[i].Kp;
+    AMDSEG_LAUNCH_PROF(AMDSEG_PROF_GEMM_TN, work, gemm_tn_dp_kernel, dim3(tiles), dim3(512), TN_LDS, s, a);
     return amdseg_launch_status();
 }

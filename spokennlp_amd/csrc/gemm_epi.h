@@ -1,5 +1,6 @@
 // shared by gemm.hip and gemm_dp.hip: epilogue selectors, launch arguments, tile-order helpers of the NT GEMM kernels
 #pragma once
+#include "prof.h"
 #include "common.h"
 
 #define GROUP_M 8

@@ -11,10 +11,19 @@
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n4, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1, float rsqrt_bc2,
-                                                    const float* __restrict__ gscale, int zero_grad) {
+                                                    const float* __restrict__ gscale, int zero_grad,
+                                                    const unsigned char* __restrict__ chunk_flags) {
     const float gs = gscale ? *gscale : 1.0f;
     const float step_size = lr / bc1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        // per 64-element chunk (parameters start on 64-element boundaries of the flat buffer): bit 0 = weight decay applies
+        // (HF Trainer decays neither biases nor LayerNorm weights), bit 1 = frozen parameter (requires_grad = False): untouched
+        const unsigned fl = chunk_flags ? chunk_flags[i >> 4] : 1u;
+        if (fl & 2u) {
+            if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const float decay = (fl & 1u) ? (1.0f - lr * wd) : 1.0f;
         float4 pp = reinterpret_cast<float4*>(p)[i];
         float4 gg = reinterpret_cast<float4*>(g)[i];
         float4 mm = reinterpret_cast<float4*>(m)[i];
@@ -23,7 +32,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float gr = G[e] * gs;
-            P[e] *= (1.0f - lr * wd);
+            P[e] *= decay;
             Mm[e] = beta1 * Mm[e] + (1.0f - beta1) * gr;
             V[e] = beta2 * V[e] + (1.0f - beta2) * gr * gr;
             const float denom = sqrtf(V[e]) * rsqrt_bc2 + eps;
@@ -84,13 +93,14 @@ static inline unsigned stream_grid(size_t n4) {
 }
 
 int amdseg_adamw_impl(float* p, const float* g, float* m, float* v, void* shadow, size_t n, float lr, float beta1,
-                      float beta2, float eps, float wd, int step, const float* gscale, int zero_grad, hipStream_t s) {
+                      float beta2, float eps, float wd, int step, const float* gscale, int zero_grad,
+                      const unsigned char* chunk_flags, hipStream_t s) {
     if (!p || !g || !m || !v) return AMDSEG_ERR_ARG;
     if (n == 0 || (n % 4) || step < 1) return AMDSEG_ERR_SHAPE;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, s, p, (float*)g, m, v, (bf16_t*)shadow, n / 4, lr, beta1,
-                       beta2, eps, wd, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, zero_grad);
+                       beta2, eps, wd, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, zero_grad, chunk_flags);
     return amdseg_launch_status();
 }
 

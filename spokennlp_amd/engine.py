@@ -10,6 +10,8 @@ Memory layout in HBM (one process per GPU):
   activations                 : bf16 [layers][...]   saved-for-backward tensors (~25 KB/token/layer), one arena per M
 """
 import ctypes as C
+import contextlib
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -56,11 +58,14 @@ class FlatParams:
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
         self.params = named
+        self.grad_is_zero = True
         with torch.no_grad():
             for n, p in named.items():
                 v = self.view(self.flat_p, n, p.shape)
                 v.copy_(p.data.to(device=device, dtype=torch.float32))
                 p.data = v
+        self._ptrs = [(p, self.flat_p.data_ptr() + 4 * self.offsets[n], self.flat_g.data_ptr() + 4 * self.offsets[n], n)
+                      for n, p in named.items()]
         self.attach_grads()
 
     def view(self, flat, name, shape=None):
@@ -73,16 +78,53 @@ class FlatParams:
 
     def attach_grads(self):
         for n, p in self.params.items():
-            p.grad = self.view(self.flat_g, n)
+            p.grad = self.view(self.flat_g, n) if p.requires_grad else None
+
+    def reattach_missing_grads(self):
+        """every trainable parameter's .grad must be its view of the flat gradient buffer (the kernels write there).  A gradient that
+        was dropped (`zero_grad(set_to_none=True)`, possibly by an optimiser that covers only a SUBSET of the parameters) or replaced
+        is re-attached and its slice zeroed -- checked for EVERY parameter, not a sentinel."""
+        missing = [(p, n) for p, _, gptr, n in self._ptrs
+                   if p.requires_grad and (p.grad is None or p.grad.data_ptr() != gptr)]
+        if not missing:
+            return 0
+        if len(missing) >= sum(1 for p, *_ in self._ptrs if p.requires_grad):
+            if not self.grad_is_zero:                # the fused AdamW zeroes the buffer in its own pass
+                self.flat_g.zero_()
+                self.grad_is_zero = True
+            for p, n in missing:
+                p.grad = self.view(self.flat_g, n)
+        else:
+            for p, n in missing:
+                v = self.view(self.flat_g, n)
+                v.zero_()
+                p.grad = v
+        return len(missing)
 
     def intact(self):
-        """parameters still alias the flat buffer (False after model.to(...) / external re-materialisation)."""
-        n = next(iter(self.params))
-        p = self.params[n]
-        return p.data_ptr() == self.flat_p.data_ptr() + 4 * self.offsets[n] and p.device == self.flat_p.device
+        """EVERY parameter still aliases its slot of the flat buffer (False after model.to(...), `p.data = new`, a re-initialised head,
+        resize_token_embeddings ...: the owner then rebuilds the engine)."""
+        dev = self.flat_p.device
+        for p, pptr, _, _ in self._ptrs:
+            if p.data_ptr() != pptr or p.device != dev:
+                return False
+        return True
 
     def lp(self, i, suffix):
         return f"{self.encoder_prefix}{i}.{suffix}"
+
+
+_LIVE_ENGINES = weakref.WeakSet()
+_HOOKED = []
+
+
+def _optimizer_stepped(opt, args, kwargs):
+    """global torch.optim post-step hook: SOME optimiser wrote SOME parameters.  torch's fused AdamW (`_fused_adamw_`, the HF Trainer
+    default `adamw_torch_fused`) does not bump the Parameters' version counters, so versions alone miss it."""
+    if getattr(opt, "amdseg_fused", False):          # the engine's own optimiser refreshes the copies itself
+        return
+    for e in list(_LIVE_ENGINES):
+        e._dirty = True
 
 
 class BertEncoderEngine:
@@ -115,8 +157,17 @@ class BertEncoderEngine:
                               wo_t=torch.empty(H, H, dtype=torch.bfloat16, device=device),
                               w1_t=torch.empty(H, I, dtype=torch.bfloat16, device=device),
                               w2_t=torch.empty(I, H, dtype=torch.bfloat16, device=device)) for _ in range(self.nlayers)]
-        self._shadow_version = -1
+        self._shadow_version = None
+        self._dirty = True                                  # the bf16 copies may be behind the fp32 masters (see refresh_shadows)
+        self._fused_owner = False                           # the engine's fused AdamW is the one writing the parameters
+        _LIVE_ENGINES.add(self)
+        if not _HOOKED:
+            from torch.optim.optimizer import register_optimizer_step_post_hook
+            _HOOKED.append(register_optimizer_step_post_hook(_optimizer_stepped))
         self._ct_table = None
+        self._arena_slot = 0
+        self.max_live_arenas = 2                            # training arenas per shape that may be alive between forward and backward
+        self.grad_sync = True                               # False inside no_sync(): accumulate locally, no bucket all-reduce
         self._arenas = {}
         self._trigger = torch.zeros(1, device=device, requires_grad=True)
         self.adam_m = None
@@ -125,6 +176,12 @@ class BertEncoderEngine:
         self._scratch = dict(sumsq=torch.zeros(1, device=device), coef=torch.ones(1, device=device),
                              norm=torch.zeros(1, device=device), partials=torch.empty(2048, device=device))
         self._build_param_structs()
+        mats = set()
+        for i in range(self.nlayers):
+            for sfx in self.layer_order:
+                if sfx.endswith(".weight") and self.fp.params[self.fp.lp(i, sfx)].dim() == 2:
+                    mats.add(self.fp.lp(i, sfx))
+        self._matrix_params = [self.fp.params[n] for n in self.fp.params if n in mats]
         self.buckets = None
         import os
         # opt-in: measured SLOWER on 1 x MI355X (19.7 vs 18.3 ms/step) -- the co-running weight-gradient GEMM and the next
@@ -139,8 +196,22 @@ class BertEncoderEngine:
         import torch.distributed as dist
         from .dp import GradBuckets
         if dist.is_initialized() and dist.get_world_size() > 1:
+            if self.buckets is None:
+                dist.broadcast(self.fp.flat_p, src=0)         # what torch DDP does at construction: every rank starts from rank 0's weights
+                self.refresh_shadows(force=True)
             self.buckets = GradBuckets(self.fp)
         return self.buckets is not None
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """gradient accumulation under the engine's own data parallelism (run_finetune.sh:31,76: gradient_accumulation_steps=2): inside
+        this context backward only accumulates into the flat gradient buffer; the micro-step OUTSIDE it (the last one before the
+        optimiser step) reduces every bucket once, so each bucket carries sum_ranks(sum_microsteps g) exactly once (torch DDP's no_sync)."""
+        old, self.grad_sync = self.grad_sync, False
+        try:
+            yield
+        finally:
+            self.grad_sync = old
 
     def ddp_compat(self):
         """torch.distributed world > 1 WITHOUT the engine's own gradient exchange (`enable_data_parallel`): the caller is assumed to have
@@ -166,12 +237,7 @@ class BertEncoderEngine:
 
     def attach_grads_if_needed(self):
         """native mode: every param.grad is a view of the flat gradient buffer (re-attached after zero_grad(set_to_none=True))"""
-        fp = self.fp
-        n0 = next(iter(fp.params))
-        p0 = fp.params[n0]
-        if p0.grad is None or p0.grad.data_ptr() != fp.view(fp.flat_g, n0).data_ptr():
-            fp.flat_g.zero_()
-            fp.attach_grads()
+        self.fp.reattach_missing_grads()
 
     def compat_params(self):
         """DDP-compatible mode: the parameters handed to autograd; no gradient may alias the flat buffer in this mode"""
@@ -189,11 +255,12 @@ class BertEncoderEngine:
         self.fp.flat_g.zero_()
         run_backward()
         snap = self.fp.flat_g.clone()
+        self.fp.grad_is_zero = False
         return tuple(self.fp.view(snap, n) for n in self.autograd_param_names())
 
     def finish_grad_sync(self):
         """reduce the non-encoder slice (embeddings, heads) and wait for every outstanding bucket."""
-        if self.buckets is not None:
+        if self.buckets is not None and self.grad_sync:
             self.buckets.reduce_rest()
             self.buckets.wait()
 
@@ -233,11 +300,30 @@ class BertEncoderEngine:
                 ln1_g=ps("attention.output.LayerNorm.weight"), ln1_b=ps("attention.output.LayerNorm.bias"),
                 ln2_g=ps("output.LayerNorm.weight"), ln2_b=ps("output.LayerNorm.bias")))
 
+    def _weights_version(self):
+        """changes whenever any encoder matrix was written in place through its Parameter (torch optimisers, load_state_dict,
+        load_best_model_at_end, checkpoint resume).  Each Parameter keeps its OWN version counter after `p.data = view`, so the flat
+        buffer's counter says nothing; the engine's own fused AdamW writes through raw pointers and refreshes explicitly."""
+        v = self.fp.flat_p._version
+        for p in self._matrix_params:
+            v += p._version
+        return v
+
+    def mark_weights_dirty(self):
+        """call after writing encoder weights by a route none of the detectors below can see (`p.data.copy_(...)`, raw pointers)"""
+        self._dirty = True
+
     def refresh_shadows(self, force=False):
-        """bf16 compute copies of the encoder matrices (+ transposes); re-done whenever flat_p was written."""
-        ver = self.fp.flat_p._version
-        if not force and ver == self._shadow_version:
+        """bf16 compute copies of the encoder matrices (+ transposes).  Re-done when the masters MAY have changed:
+          * a matrix Parameter's version counter moved (in-place torch ops, load_state_dict, foreach optimisers),
+          * any torch optimiser stepped (global post-step hook: the fused torch AdamW bumps no version counter),
+          * a training forward ran since the last refresh and the engine's own fused AdamW is not the writer -- whatever updates the
+            weights between two training forwards (third-party optimisers writing through `.data`) is then covered too.
+        The engine's fused AdamW refreshes explicitly (force) right after its pass."""
+        ver = self._weights_version()
+        if not force and not self._dirty and ver == self._shadow_version:
             return
+        self._dirty = False
         if self._ct_table is None:
             Ws, Wbs, Wts, Ns, Ks = [], [], [], [], []
             H = self.H
@@ -256,11 +342,40 @@ class BertEncoderEngine:
         n, pw, pb, pt, pn, pk = self._ct_table
         rc = L.load().amdseg_cast_transpose_batched(n, pw, pb, pt, pn, pk, torch.cuda.current_stream().cuda_stream)
         L.check(rc, "amdseg_cast_transpose_batched")
-        self._shadow_version = self.fp.flat_p._version
+        self._shadow_version = self._weights_version()
 
     # ------------------------------------------------------------------------------------------------ arenas
+    def _acquire_arena(self, B, Lseq, train, fp32=False):
+        """the arena a forward may write.  Inference arenas hold nothing past the call.  A TRAINING arena holds the activations saved for
+        backward, so it stays `busy` from its forward until its backward ran (or its autograd node died); a second training forward at the
+        same shape in between (siamese / contrastive calls, checkpoint recomputation) gets another arena, up to `max_live_arenas`;
+        beyond that the oldest is recycled and ITS backward raises instead of silently reading another call's activations."""
+        if not train:
+            self._arena_slot = 0
+            return self._arena(B, Lseq, train, fp32)
+        pick, oldest = None, None
+        for slot in range(self.max_live_arenas):
+            A = self._arenas.get((B, Lseq, True, fp32, slot))
+            if A is None or not A["busy"]:
+                pick = slot
+                break
+            if oldest is None or A["stamp"] < oldest[1]:
+                oldest = (slot, A["stamp"])
+        self._arena_slot = oldest[0] if pick is None else pick
+        A = self._arena(B, Lseq, train, fp32)
+        self._arena_slot = 0
+        self._arena_clock = getattr(self, "_arena_clock", 0) + 1
+        A["gen"] += 1
+        A["busy"], A["stamp"] = True, self._arena_clock
+        return A
+
+    @staticmethod
+    def _release_arena(A, gen):
+        if A["gen"] == gen:
+            A["busy"] = False
+
     def _arena(self, B, Lseq, train, fp32=False):
-        key = (B, Lseq, train, fp32)
+        key = (B, Lseq, train, fp32, self._arena_slot if train else 0)
         if key in self._arenas:
             return self._arenas[key]
         dev, H, I, M = self.device, self.H, self.I, B * Lseq
@@ -276,7 +391,7 @@ class BertEncoderEngine:
                               rstd1=e(M, dt=torch.float32), mean2=e(M, dt=torch.float32), rstd2=e(M, dt=torch.float32))
                          for _ in range(nsave)],
                  emb_z=e(M, H), emb_mean=e(M, dt=torch.float32), emb_rstd=e(M, dt=torch.float32),
-                 mask_bias=e(B, Lseq, dt=torch.float32), out=e(M, H, dt=torch.float32))
+                 mask_bias=e(B, Lseq, dt=torch.float32), gen=0, busy=False, stamp=0)
         if train:
             npart = 2 * ops.ln_partials_numel(M, H) + max((M + 127) // 128, (H + 127) // 128) * (I + self.nproj * H)   # amdseg.h: amdseg_bert_layer_ws
             def ws_set():
@@ -323,7 +438,9 @@ class BertEncoderEngine:
         fp32 = (not train) and getattr(self.cfg, "amdseg_precision", "bf16") == "fp32"
         if not fp32:
             self.refresh_shadows()
-        A = self._arena(B, Lseq, train, fp32)
+            if train and not self._fused_owner:
+                self._dirty = True                          # an unknown optimiser is expected to write the weights after this step
+        A = self._acquire_arena(B, Lseq, train, fp32)
         dt = L.F32 if fp32 else L.BF16
         p_h = float(self.cfg.hidden_dropout_prob) if train else 0.0
         p_a = float(self.cfg.attention_probs_dropout_prob) if train else 0.0
@@ -348,12 +465,14 @@ class BertEncoderEngine:
         saved = []
         for i in range(self.nlayers):
             saved.append(self._layer_forward(lib, cfg, lparams[i], A, i, mb, s, train))
-        rc = lib.amdseg_dropout(A["x_final"].data_ptr(), A["out"].data_ptr(), M * self.H, p_out if train else 0.0,
+        # the result is a FRESH tensor per call (the caller and autograd keep it; arena buffers are overwritten by the next forward)
+        out = torch.empty(M, self.H, dtype=torch.float32, device=self.device)
+        rc = lib.amdseg_dropout(A["x_final"].data_ptr(), out.data_ptr(), M * self.H, p_out if train else 0.0,
                                 seed * 1000003 + 29, dt, L.F32, s)
         L.check(rc, "amdseg_dropout")
         ctx = dict(B=B, L=Lseq, ids=ids, tts=tts, pos=pos, seed=seed, p_h=p_h, p_a=p_a, p_out=p_out if train else 0.0,
-                   layer_saved=saved)
-        return A["out"].view(B, Lseq, self.H), ctx
+                   layer_saved=saved, arena=A, gen=A["gen"])
+        return out.view(B, Lseq, self.H), ctx
 
     # hooks overridden by the Longformer engine
     def _position_ids(self, input_ids):
@@ -399,7 +518,12 @@ class BertEncoderEngine:
         """dseq: fp32 [B, L, H] gradient of the encoder output.  Writes every parameter gradient into flat_g."""
         B, Lseq = ctx["B"], ctx["L"]
         M = B * Lseq
-        A = self._arena(B, Lseq, True)
+        A = ctx["arena"]
+        self.fp.grad_is_zero = False
+        if A["gen"] != ctx["gen"]:
+            raise L.AmdsegError(f"the activations saved by this forward (B={B}, L={Lseq}) were overwritten: more than "
+                                f"{self.max_live_arenas} training forwards at this shape were alive before their backward ran "
+                                f"(raise engine.max_live_arenas)")
         ws = A["ws"]
         lib = L.load()
         s = torch.cuda.current_stream().cuda_stream
@@ -412,7 +536,7 @@ class BertEncoderEngine:
         for i in reversed(range(self.nlayers)):
             self._layer_backward(lib, cfg, A, i, mb, dy, other, s, ctx["layer_saved"][i])
             dy, other = other, dy
-            if self.buckets is not None:          # data parallel: this layer's gradient slice is final -> start its all-reduce
+            if self.buckets is not None and self.grad_sync:   # data parallel: this layer's gradient slice is final -> start its all-reduce
                 if self.overlap_wgrad and self._wgrad_last is not None:
                     with torch.cuda.stream(self._wgrad_stream):      # ... ordered after the weight-gradient GEMM's stream
                         self.buckets.reduce_layer(i)
@@ -448,6 +572,7 @@ class BertEncoderEngine:
             for ev in self._wgrad_done:
                 if ev is not None:
                     main.wait_event(ev)
+        self._release_arena(A, ctx["gen"])
 
     def _embed_backward_fixup(self, dpos, pad):
         pass
@@ -455,6 +580,7 @@ class BertEncoderEngine:
     # ------------------------------------------------------------------------------------------------ optimiser
     def zero_grad(self):
         self.fp.flat_g.zero_()
+        self.fp.grad_is_zero = True
 
     def grad_norm_and_clip_coef(self, max_norm, extra_scale=1.0):
         sc = self._scratch
@@ -462,16 +588,31 @@ class BertEncoderEngine:
         ops.clip_coef(sc["sumsq"], max_norm, extra_scale, sc["coef"], sc["norm"])
         return sc["norm"], sc["coef"]
 
+    def set_param_flags(self, decay_names=None):
+        """per-parameter optimiser flags for the fused AdamW: `decay_names` = the parameters weight decay applies to (None: all of
+        them; HF Trainer excludes biases and LayerNorm weights, [hf] trainer.py:1168-1215); frozen parameters (requires_grad False,
+        e.g. mmvts `freeze_text_encoder`) are never updated.  Stored as one byte per 64-element chunk of the flat buffer."""
+        fp = self.fp
+        flags = torch.zeros(fp.numel // 64, dtype=torch.uint8)
+        for n, p in fp.params.items():
+            o, c = fp.offsets[n] // 64, (p.numel() + 63) // 64
+            flags[o:o + c] = (1 if (decay_names is None or n in decay_names) else 0) | (0 if p.requires_grad else 2)
+        self._chunk_flags = flags.to(self.device)
+
     def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, grad_scale=1.0,
-                   zero_grad=True):
-        """clip_grad_norm_(max_grad_norm) + torch.optim.AdamW step over the flat buffers, fused; refreshes the bf16 shadows."""
+                   zero_grad=True, coef=None):
+        """clip_grad_norm_(max_grad_norm) + torch.optim.AdamW step over the flat buffers, fused; refreshes the bf16 shadows.
+        `coef`: a device scalar already produced by `grad_norm_and_clip_coef` for these gradients (the Trainer asks for the norm first)."""
         if self.adam_m is None:
             self.adam_m = torch.zeros_like(self.fp.flat_p)
             self.adam_v = torch.zeros_like(self.fp.flat_p)
         self.opt_step += 1
-        _, coef = self.grad_norm_and_clip_coef(max_grad_norm, grad_scale)
+        if coef is None:
+            _, coef = self.grad_norm_and_clip_coef(max_grad_norm, grad_scale)
         ops.adamw(self.fp.flat_p, self.fp.flat_g, self.adam_m, self.adam_v, None, lr, betas[0], betas[1], eps, weight_decay,
-                  self.opt_step, gscale=coef, zero_grad=zero_grad)
+                  self.opt_step, gscale=coef, zero_grad=zero_grad, chunk_flags=getattr(self, "_chunk_flags", None))
+        self.fp.grad_is_zero = bool(zero_grad)
+        self._fused_owner = True
         self.refresh_shadows(force=True)
 
 
@@ -505,6 +646,8 @@ class EncoderFn(torch.autograd.Function):
             token_type_ids = torch.nn.functional.pad(token_type_ids, grow, value=0)
         out, ectx = engine.forward(input_ids, attention_mask, token_type_ids, train, seed, p_out)
         ctx.engine, ctx.ectx = engine, ectx
+        if train:                                           # graph dropped without a backward: the arena is free again
+            weakref.finalize(ctx, BertEncoderEngine._release_arena, ectx["arena"], ectx["gen"])
         if (Bp, Lp) != (B, Lq):
             out = out[:B, :Lq].contiguous()
         return out

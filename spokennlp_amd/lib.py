@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("AMDSEG_LIB") or os.path.join(_HERE, "libamdseg.so")
 BF16, F32 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
 EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
@@ -81,9 +81,12 @@ _PROTOS = {
     "amdseg_attn_list_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, i32, vp, vp],
     "amdseg_attn_list_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp, vp, vp],
     "amdseg_debug_force_small_tile": [i32],
+    "amdseg_prof_enable": [i32],
+    "amdseg_prof_reset": [],
+    "amdseg_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
     "amdseg_rowdot_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "amdseg_rowdot_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "amdseg_adamw": [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, vp, i32, vp],
+    "amdseg_adamw": [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, vp, i32, vp, vp],
     "amdseg_sumsq": [vp, sz, vp, vp, i32, vp],
     "amdseg_clip_coef": [vp, f32, f32, vp, vp, vp],
     "amdseg_scale": [vp, sz, vp, vp],

@@ -319,9 +319,9 @@ def rowdot_bwd(x, W, dlogits, dW=None, db=None, need_dx=True, accumulate=False):
     return dx
 
 
-def adamw(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, gscale=None, zero_grad=False):
+def adamw(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, gscale=None, zero_grad=False, chunk_flags=None):
     rc = L.load().amdseg_adamw(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, beta1, beta2, eps, wd, step,
-                               _p(gscale), 1 if zero_grad else 0, _s())
+                               _p(gscale), 1 if zero_grad else 0, _p(chunk_flags), _s())
     L.check(rc, "amdseg_adamw")
 
 

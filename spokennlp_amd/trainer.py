@@ -1,0 +1,198 @@
+"""The fast path behind the reference's training surface.
+
+The reference trains with `transformers.Trainer` (ts_sentence_seq_labeling.py:43,1077-1094; run_finetune.sh:29-31,61,73-76:
+AdamW lr 5e-5 linear decay, clip 1.0, gradient_accumulation_steps 2, torch DDP across the GPUs of the node).  With the stock
+Trainer the drop-in model classes work, but the optimiser is torch's (a per-tensor / foreach pass over ~200 parameters plus a
+separate clip pass) and multi-GPU goes through torch DDP (`engine.ddp_compat`: a snapshot of the flat gradient per backward).
+
+`Trainer` below is a subclass with the same constructor; swapping the import line in the driver
+    from transformers import Trainer      ->      from spokennlp_amd.trainer import Trainer
+puts the engine's own pieces behind the same loop, nothing else changes (callbacks, checkpoints, evaluation, lr scheduler):
+  * `create_optimizer`  -> `AmdsegFusedAdamW`: ONE HIP pass over the flat fp32 parameter / gradient / moment buffers with the clip
+    coefficient applied inside (no separate scaling pass), HF's decay / no-decay parameter groups as a per-chunk flag byte, gradient
+    zeroing fused, bf16 weight copies refreshed;
+  * `_clip_grad_norm`   -> the HIP sum-of-squares reduction (device scalar, no host sync); the optimiser consumes the coefficient;
+  * multi-GPU           -> the engine's per-layer RCCL all-reduce launched from inside backward (dp.GradBuckets) instead of torch DDP;
+    `gradient_accumulation_steps` > 1 runs the non-final micro-steps under `no_sync()` so every bucket is reduced exactly once.
+"""
+import contextlib
+
+import torch
+import transformers
+
+from . import lib as L
+
+
+class AmdsegFusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled decay, bias correction, eps added to sqrt(v_hat)) executed by `amdseg_adamw` over the
+    engine's flat buffers.  One param group holding every parameter of the model (lr schedulers write `param_groups[0]["lr"]`);
+    `decay_names` selects the parameters weight decay applies to."""
+    amdseg_fused = True
+
+    def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decay_names=None, max_grad_norm=0.0):
+        if not hasattr(model, "engine"):
+            raise L.AmdsegError("AmdsegFusedAdamW needs one of the spokennlp_amd model classes (it steps the engine's flat buffers)")
+        self.model = model
+        self.decay_names = None if decay_names is None else set(decay_names)
+        self.max_grad_norm = float(max_grad_norm or 0.0)
+        self._coef = None
+        self._engine_id = None
+        self._pending_state = None
+        super().__init__([p for p in model.parameters()], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    # ---- engine plumbing
+    def _engine(self):
+        eng = self.model.engine()
+        if id(eng) != self._engine_id:             # first use, or the model rebuilt its engine (parameters were re-materialised)
+            eng.set_param_flags(self.decay_names if self.param_groups[0]["weight_decay"] != 0 else None)
+            self._engine_id = id(eng)
+            if self._pending_state is not None:
+                self._install_state(eng, self._pending_state)
+                self._pending_state = None
+        return eng
+
+    @staticmethod
+    def _world():
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def grad_norm(self, max_norm=None):
+        """total gradient norm as a device scalar (torch.nn.utils.clip_grad_norm_'s return value); keeps the clip coefficient for the
+        coming step().  Under the engine's data parallelism this first waits for the outstanding bucket reductions."""
+        eng = self._engine()
+        eng.finish_grad_sync()
+        scale = 1.0 / self._world() if eng.buckets is not None else 1.0
+        mx = self.max_grad_norm if max_norm is None else float(max_norm)
+        norm, coef = eng.grad_norm_and_clip_coef(mx if mx != float("inf") else 0.0, scale)
+        self._coef = coef
+        return norm
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        eng = self._engine()
+        g = self.param_groups[0]
+        if self._coef is None:
+            self.grad_norm()
+        eng.adamw_step(float(g["lr"]), betas=tuple(g["betas"]), eps=float(g["eps"]), weight_decay=float(g["weight_decay"]),
+                       coef=self._coef, zero_grad=True)
+        self._coef = None
+        return loss
+
+    def zero_grad(self, set_to_none=True):
+        # step() already zeroed the flat gradient buffer inside the AdamW pass; the views stay attached
+        eng = self._engine()
+        if not eng.fp.grad_is_zero:
+            eng.zero_grad()
+
+    # ---- checkpointing (Trainer saves optimizer.state_dict() next to the model): the state is three flat tensors
+    def state_dict(self):
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        groups[0]["params"] = list(range(len(self.param_groups[0]["params"])))
+        eng = self.model._engine if getattr(self.model, "_engine", None) is not None and id(self.model._engine) == self._engine_id else None
+        state = {}
+        if eng is not None and eng.adam_m is not None:
+            state = {"amdseg_flat": {"step": torch.tensor(float(eng.opt_step)), "exp_avg": eng.adam_m, "exp_avg_sq": eng.adam_v,
+                                     "numel": torch.tensor(float(eng.fp.numel))}}
+        elif self._pending_state is not None:
+            state = {"amdseg_flat": self._pending_state}
+        return {"state": state, "param_groups": groups}
+
+    @staticmethod
+    def _install_state(eng, st):
+        if int(st["numel"]) != eng.fp.numel:
+            raise L.AmdsegError("optimizer checkpoint does not match this model's flat parameter layout")
+        eng.adam_m = st["exp_avg"].to(device=eng.device, dtype=torch.float32).clone()
+        eng.adam_v = st["exp_avg_sq"].to(device=eng.device, dtype=torch.float32).clone()
+        eng.opt_step = int(st["step"])
+
+    def load_state_dict(self, state_dict):
+        for g, new in zip(self.param_groups, state_dict["param_groups"]):
+            for k, v in new.items():
+                if k != "params":
+                    g[k] = v
+        st = state_dict.get("state", {}).get("amdseg_flat")
+        if st is not None:
+            eng = self.model._engine if getattr(self.model, "_engine", None) is not None and id(self.model._engine) == self._engine_id else None
+            if eng is not None:
+                self._install_state(eng, st)
+            else:
+                self._pending_state = st
+
+
+class NativeDataParallel(torch.nn.Module):
+    """what `Trainer._wrap_model` returns for multi-GPU training INSTEAD of torch DDP: the same module, with the engine's bucketed
+    gradient exchange switched on and DDP's `no_sync()` contract (accelerate looks it up for gradient accumulation)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+        if not module.engine().enable_data_parallel():
+            raise L.AmdsegError("NativeDataParallel needs an initialised torch.distributed world of size > 1")
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def no_sync(self):
+        return self.module.no_sync()
+
+
+class Trainer(transformers.Trainer):
+    """`transformers.Trainer` with the fused optimiser, HIP gradient norm and native data parallelism (see the module docstring).
+    `amdseg_native=False` keeps the stock behaviour (torch optimiser, torch DDP)."""
+
+    def __init__(self, *args, amdseg_native=True, **kwargs):
+        self.amdseg_native = bool(amdseg_native)
+        super().__init__(*args, **kwargs)
+        self.amdseg_native = self.amdseg_native and hasattr(self.model, "engine")
+
+    def _fused(self):
+        opt = self.optimizer
+        while opt is not None and not isinstance(opt, AmdsegFusedAdamW) and hasattr(opt, "optimizer"):
+            opt = opt.optimizer                 # accelerate's AcceleratedOptimizer wrapper
+        return opt if isinstance(opt, AmdsegFusedAdamW) else None
+
+    def create_optimizer(self, model=None):
+        if not self.amdseg_native or self.optimizer is not None or self.optimizer_cls_and_kwargs is not None:
+            return super().create_optimizer(model)
+        a = self.args
+        if "adamw" not in str(a.optim).lower():
+            raise L.AmdsegError(f"the fused optimiser implements AdamW; --optim {a.optim} needs amdseg_native=False")
+        self.optimizer = AmdsegFusedAdamW(self.model, lr=a.learning_rate, betas=(a.adam_beta1, a.adam_beta2), eps=a.adam_epsilon,
+                                          weight_decay=a.weight_decay, decay_names=self.get_decay_parameter_names(self.model),
+                                          max_grad_norm=a.max_grad_norm)
+        return self.optimizer
+
+    def _wrap_model(self, model, training=True, dataloader=None):
+        import torch.distributed as dist
+        if (self.amdseg_native and training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                and self.args.parallel_mode == transformers.training_args.ParallelMode.DISTRIBUTED):
+            if isinstance(model, NativeDataParallel):
+                return model
+            return NativeDataParallel(self.model)
+        return super()._wrap_model(model, training, dataloader)
+
+    def _clip_grad_norm(self, model):
+        opt = self._fused()
+        if opt is None:
+            return super()._clip_grad_norm(model)
+        return opt.grad_norm(self.args.max_grad_norm)
+
+    def _get_grad_norm(self, model, grad_norm=None):
+        opt = self._fused()
+        if opt is None or grad_norm is not None:
+            return super()._get_grad_norm(model, grad_norm=grad_norm)
+        return opt.grad_norm(float("inf"))
+
+
+@contextlib.contextmanager
+def accumulate(model, sync):
+    """hand-written loops: `with accumulate(model, sync=is_last_micro_step): loss.backward()`"""
+    if sync:
+        yield
+    else:
+        with model.no_sync():
+            yield
