@@ -59,6 +59,7 @@ def build(args, device):
                  cl_anchor_level="eop_list", cl_positive_k=1, cl_negative_k=3, tssp_loss_weight=1.0) if args.workload == "full_da" else {}
     for k, v in flags.items():
         setattr(cfg, k, v)
+    cfg.amdseg_precision = getattr(args, "precision", "bf16")
     torch.manual_seed(0)
     m = M(cfg).to(device).train()
     return m, cfg
@@ -315,6 +316,9 @@ def main():
     ap.add_argument("--seqs-per-gpu", type=int, default=None)
     ap.add_argument("--workload", default="full_da", choices=["full_da", "plain"])
     ap.add_argument("--mode", default="train", choices=["train", "infer"], help="infer = forward-only (eval, no_grad) sequences/s")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "parity", "fp32"],
+                    help="bf16 = the fast path (default); parity = fp32 activations + split-bf16 products (forward and backward, "
+                         "reference-grade numerics); fp32 = exact fp32 MFMA (inference only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--standalone-gemm", action="store_true", help="also time the gemm_nt shapes back to back on warm operands")
@@ -328,6 +332,8 @@ def main():
         args.seqs_per_gpu = 32 if args.model == "bert" else 8
     if args.model != "bert":
         args.no_cpu_baseline = True       # the cpu_baseline leg times the BERT oracle (headline metric) only
+    if args.precision != "bf16":
+        args.no_via_trainer = True
 
     from spokennlp_amd import dp
     rank, world, local = dp.init_from_env()
@@ -388,7 +394,9 @@ def main():
                                                                  "bigbird": "bigbird-base"}[args.model] + " topic-seg",
                value=round(value, 2), unit="seq/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
+               scaling="weak", vs_baseline=None,
+               dtype={"bf16": "bf16", "parity": "f32 (activations fp32, products as split-bf16 MFMA, fp32 accumulate)", "fp32": "f32"}[args.precision],
+               data="synthetic",
                config=dict(workload=f"{name} topic-seg fine-tune, {args.workload}, seq_len={args.seq_len}, "
                                     f"{args.seqs_per_gpu} seqs/GPU/step ({pairs} samples), "
                                     + ("fwd+bwd+clip+AdamW, dropout 0.1" if args.mode == "train" else "inference forward only (eval, no_grad)"),

@@ -26,9 +26,10 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 3   /* 3: amdseg_adamw chunk_flags; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 3   /* 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
+#define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
 #define AMDSEG_OK 0
 #define AMDSEG_ERR_SHAPE 1001
 #define AMDSEG_ERR_ARG 1002
@@ -210,6 +211,20 @@ int amdseg_clip_coef(const float* sumsq, float max_norm, float extra_scale, floa
                      amdseg_stream_t stream);
 int amdseg_scale(float* x, size_t n, const float* coef, amdseg_stream_t stream);
 
+/* ---- "parity" precision (csrc/parity.hip): fp32 activations, fp32-grade contractions on the bf16 MFMA pipes.  x = hi + lo with
+ * hi = bf16(x), lo = bf16(x - hi); a product A . B^T runs as ONE bf16 GEMM over K' = 3K on the images A' = [Ahi | Ahi | Alo],
+ * B' = [Bhi | Blo | Bhi] (amdseg_gemm_nt with out_fp32 = 1).  The reference computes in fp32 throughout
+ * (run_finetune.sh:61-96: no --fp16 / --bf16); this mode is what the 1e-3 logit tolerance of the north star is pinned with, forward AND
+ * backward.  order: 0 = activation / gradient image [hi | hi | lo], 1 = weight image [hi | lo | hi]. */
+int amdseg_split3(const float* x, int ld, void* out_bf16, int M, int K, int order, amdseg_stream_t stream);
+/* W [N,K] fp32 -> [K, 3N] = [Wt_hi | Wt_lo | Wt_hi]: the weight image of the dgrad dX = dY . W written as an NT product */
+int amdseg_split3_transpose(const float* W, void* out_bf16, int N, int K, amdseg_stream_t stream);
+/* fp32 attention ([hf] models/bert/modeling_bert.py:111-136) with saved log-sum-exp and hash dropout; qkv [M,3H] fp32, head_dim 64 */
+int amdseg_pattn_fwd(const float* qkv, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale,
+                     float p_drop, uint64_t seed, amdseg_stream_t stream);
+int amdseg_pattn_bwd(const float* qkv, const float* mask_bias, const float* ctx, const float* dctx, const float* lse, float* delta,
+                     float* dqkv, int B, int L, int heads, float scale, float p_drop, uint64_t seed, amdseg_stream_t stream);
+
 /* ---- measurement plumbing (csrc/prof.h, prof.hip): in-kernel begin/end stamps of the device wall clock for the dominant kernels,
  * taken INSIDE real training steps.  enable(1) allocates + arms the slots (returns the previous state, < 0 on failure); read() syncs
  * the device and returns, for one launch class, the summed kernel spans (us), the summed algorithmic work (FLOPs) and the number
@@ -229,8 +244,10 @@ typedef struct amdseg_bert_cfg {
     float ln_eps, p_hidden, p_attn; /* dropout probabilities (0 in eval) */
     uint64_t seed;                  /* dropout seed of this step; per-layer/site streams are derived from it */
     int32_t accumulate_grads;       /* weight grads: 0 overwrite, 1 add into existing */
-    int32_t dtype;                  /* AMDSEG_BF16 (train + inference) or AMDSEG_F32 (inference parity mode: the
-                                       layer params then point at the fp32 master weights, activations are fp32) */
+    int32_t dtype;                  /* AMDSEG_BF16 (train + inference), AMDSEG_F32 (inference, exact fp32 MFMA: the layer params then
+                                       point at the fp32 master weights, activations are fp32) or AMDSEG_F32S (train + inference, fp32
+                                       activations: params w* = weight images [N,3K] of amdseg_split3(order 1), w*_t = images [K,3N] of
+                                       amdseg_split3_transpose; BERT attention only: window = 0, mixer = 0) */
     int32_t window, nglobal;        /* Longformer layers: band attention (see amdseg_attn_band_fwd); 0, 0 = BERT */
     int32_t nproj, mixer;           /* mixer 0: softmax attention over the q|k|v projection (nproj 0 or 3).  mixer 1: external
                                        token mixer (PoNet): the projection is nproj*H wide (acts.qkv, ws.dqkv, wqkv, wqkv_t, bqkv
@@ -262,12 +279,17 @@ typedef struct amdseg_bert_layer_acts {     /* caller-owned activations; all but
     void *qkv, *ctx, *z1, *x1, *u, *h, *z2, *x_out;   /* [M,3H] [M,H] [M,H] [M,H] [M,I] [M,I] [M,H] [M,H]; u may be NULL in
                                                          inference (the pre-activation is only read by backward) */
     float *lse, *mean1, *rstd1, *mean2, *rstd2;       /* [B*heads*L] [M] [M] [M] [M] */
+    /* AMDSEG_F32S only: bf16 split images [hi | hi | lo] of x_in, ctx, x1 and gelu(u): [M,3H] [M,3H] [M,3H] [M,3I] (written by
+     * forward, read by the GEMMs of forward and by the weight gradients of backward; `h` is unused in that mode) */
+    void *xs, *ctx_s, *x1_s, *h_s;
 } amdseg_bert_layer_acts;
 
 typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across layers */
     void *dz2, *dbr2, *du, *dx1, *dz1, *dbr1, *dctx, *dqkv;  /* [M,H] [M,H] [M,I] [M,H] [M,H] [M,H] [M,H] [M,3H] */
     float *delta, *partials;                /* [B*heads*L]; partials: 6*ceil(M/16)*H + max(ceil(M/128), ceil(H/128))*(I + nproj*H) floats (one
                                                region per deferred reduction: LN2, b1, LN1, bqkv) */
+    /* AMDSEG_F32S only: split images of the four gradient operands d(FFN out), du, d(attention out), dqkv: [M,3H] [M,3I] [M,3H] [M,9H] */
+    void *d_out_s, *du_s, *d_ao_s, *dqkv_s;
 } amdseg_bert_layer_ws;
 
 int amdseg_bert_layer_fwd(const amdseg_bert_cfg* cfg, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,

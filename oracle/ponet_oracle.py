@@ -42,7 +42,24 @@ def embeddings(sd, cfg, input_ids, token_type_ids, prefix=PFX):
     return layer_norm(e, sd[prefix + "embeddings.LayerNorm.weight"], sd[prefix + "embeddings.LayerNorm.bias"], cfg.layer_norm_eps)
 
 
-def pooling(hq, hk, ho, hl, hs, valid, segment_ids, nh):
+def segment_max_runs(hs, valid, segment_ids, ninf):
+    """the segment maximum for NON-DECREASING segment ids (what the feature builder emits, ponet_topic_segmentation.py:564-596): a
+    segment is a contiguous run, so S is one amax per run.  O(L H) instead of the O(L^2 H) mask of `pooling`'s general form; the two are
+    compared on small inputs in tests/test_oracle_golden.py."""
+    B, L, H = hs.shape
+    out = []
+    for b in range(B):
+        seg = segment_ids[b]
+        cuts = [0] + (torch.nonzero(seg[1:] != seg[:-1]).flatten() + 1).tolist() + [L]
+        rows = []
+        for a, e in zip(cuts[:-1], cuts[1:]):
+            v = torch.where(valid[b, a:e, None], hs[b, a:e], torch.full((), ninf, dtype=hs.dtype))
+            rows.append(v.amax(0, keepdim=True).expand(e - a, H))
+        out.append(torch.cat(rows, 0))
+    return torch.stack(out)
+
+
+def pooling(hq, hk, ho, hl, hs, valid, segment_ids, nh, runs=False):
     """the token-mixing block on the five projections ([B, L, H] each); valid [B, L] bool; returns ctx [B, L, H]"""
     B, L, H = hq.shape
     d = H // nh
@@ -55,8 +72,11 @@ def pooling(hq, hk, ho, hl, hs, valid, segment_ids, nh):
     g = torch.einsum("bhj,bjhe->bhe", p, hk.view(B, L, nh, d)).reshape(B, 1, H)
     ninf = torch.finfo(hq.dtype).min
     # segment max over valid tokens with the same id
-    same = (segment_ids[:, :, None] == segment_ids[:, None, :]) & valid[:, None, :]       # [B, n, j]
-    S = torch.stack([torch.where(same[b][:, :, None], hs[b][None, :, :], torch.full((), ninf, dtype=hq.dtype)).amax(1) for b in range(B)])
+    if runs:
+        S = segment_max_runs(hs, valid, segment_ids, ninf)
+    else:
+        same = (segment_ids[:, :, None] == segment_ids[:, None, :]) & valid[:, None, :]       # [B, n, j]
+        S = torch.stack([torch.where(same[b][:, :, None], hs[b][None, :, :], torch.full((), ninf, dtype=hq.dtype)).amax(1) for b in range(B)])
     # local max over valid n-1, n, n+1
     hlm = torch.where(valid[..., None], hl, torch.full((), ninf, dtype=hq.dtype))
     pad = torch.full((B, 1, H), ninf, dtype=hq.dtype)
@@ -65,14 +85,14 @@ def pooling(hq, hk, ho, hl, hs, valid, segment_ids, nh):
     return torch.where(valid[..., None], ctx, torch.zeros((), dtype=ctx.dtype))
 
 
-def encoder_layer(sd, cfg, x, valid, segment_ids, i, prefix=PFX):
+def encoder_layer(sd, cfg, x, valid, segment_ids, i, prefix=PFX, runs=False):
     p = f"{prefix}encoder.layer.{i}."
 
     def lin(t, name):
         return t @ sd[p + name + ".weight"].t() + sd[p + name + ".bias"]
 
     hq, hk, ho, hl, hs = [lin(x, "attention.self." + n) for n in PROJ]
-    ctx = pooling(hq, hk, ho, hl, hs, valid, segment_ids, cfg.num_attention_heads)
+    ctx = pooling(hq, hk, ho, hl, hs, valid, segment_ids, cfg.num_attention_heads, runs=runs)
     x1 = layer_norm(lin(ctx, "attention.output.dense") + x, sd[p + "attention.output.LayerNorm.weight"],
                     sd[p + "attention.output.LayerNorm.bias"], cfg.layer_norm_eps)
     h = gelu_erf(lin(x1, "intermediate.dense"))
@@ -80,19 +100,19 @@ def encoder_layer(sd, cfg, x, valid, segment_ids, i, prefix=PFX):
                       cfg.layer_norm_eps)
 
 
-def ponet_encode(sd, cfg, input_ids, attention_mask, token_type_ids, segment_ids, return_all=False, prefix=PFX):
+def ponet_encode(sd, cfg, input_ids, attention_mask, token_type_ids, segment_ids, return_all=False, prefix=PFX, runs=False):
     valid = attention_mask == 1
     x = embeddings(sd, cfg, input_ids, token_type_ids, prefix)
     hs = [x]
     for i in range(cfg.num_hidden_layers):
-        x = encoder_layer(sd, cfg, x, valid, segment_ids, i, prefix)
+        x = encoder_layer(sd, cfg, x, valid, segment_ids, i, prefix, runs=runs)
         hs.append(x)
     return (x, hs) if return_all else x
 
 
-def token_classification_forward(sd, cfg, input_ids, attention_mask, token_type_ids, segment_ids, labels=None):
+def token_classification_forward(sd, cfg, input_ids, attention_mask, token_type_ids, segment_ids, labels=None, runs=False):
     """modeling_ponet.py:47-109 (eval / dropout 0): returns (loss or None, logits [B, L, num_labels])."""
-    seq = ponet_encode(sd, cfg, input_ids, attention_mask, token_type_ids, segment_ids)
+    seq = ponet_encode(sd, cfg, input_ids, attention_mask, token_type_ids, segment_ids, runs=runs)
     logits = seq @ sd["classifier.weight"].t() + sd["classifier.bias"]
     loss = None
     if labels is not None:

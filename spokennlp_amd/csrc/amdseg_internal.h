@@ -8,6 +8,7 @@
 // dtype codes used across the C-ABI
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
+#define AMDSEG_F32S 2
 
 int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                         int epi, const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32,
@@ -91,3 +92,14 @@ int amdseg_adamw_impl(float* p, const float* g, float* m, float* v, void* shadow
 int amdseg_sumsq_impl(const float* x, size_t n, float* partials, float* out, int accumulate, hipStream_t s);
 int amdseg_clip_coef_impl(const float* sumsq, float max_norm, float extra_scale, float* coef, float* norm, hipStream_t s);
 int amdseg_scale_impl(float* x, size_t n, const float* coef, hipStream_t s);
+
+// parity.hip
+int amdseg_split3_impl(const float* x, int ld, void* out, int M, int K, int order, hipStream_t s);
+int amdseg_split3_transpose_impl(const float* W, void* out, int N, int K, hipStream_t s);
+int amdseg_gelu_fwd_split_impl(const float* u, void* hs, int M, int I, int act, hipStream_t s);
+int amdseg_gelu_bwd_split_impl(float* du, const float* u, void* dus, int M, int I, int act, hipStream_t s);
+int amdseg_add_inplace_impl(float* y, const float* x, size_t n, hipStream_t s);
+int amdseg_pattn_fwd_impl(const float* qkv, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale, float p,
+                          uint64_t seed, hipStream_t s);
+int amdseg_pattn_bwd_impl(const float* qkv, const float* mask_bias, const float* ctx, const float* dctx, const float* lse, float* delta,
+                          float* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed, hipStream_t s);

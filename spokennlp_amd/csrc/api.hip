@@ -190,6 +190,21 @@ int amdseg_scale(float* x, size_t n, const float* coef, amdseg_stream_t stream) 
     return amdseg_scale_impl(x, n, coef, S(stream));
 }
 
+int amdseg_split3(const float* x, int ld, void* out_bf16, int M, int K, int order, amdseg_stream_t stream) {
+    return amdseg_split3_impl(x, ld, out_bf16, M, K, order, S(stream));
+}
+int amdseg_split3_transpose(const float* W, void* out_bf16, int N, int K, amdseg_stream_t stream) {
+    return amdseg_split3_transpose_impl(W, out_bf16, N, K, S(stream));
+}
+int amdseg_pattn_fwd(const float* qkv, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale,
+                     float p_drop, uint64_t seed, amdseg_stream_t stream) {
+    return amdseg_pattn_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, p_drop, seed, S(stream));
+}
+int amdseg_pattn_bwd(const float* qkv, const float* mask_bias, const float* ctx, const float* dctx, const float* lse, float* delta,
+                     float* dqkv, int B, int L, int heads, float scale, float p_drop, uint64_t seed, amdseg_stream_t stream) {
+    return amdseg_pattn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta, dqkv, B, L, heads, scale, p_drop, seed, S(stream));
+}
+
 // ---------------------------------------------------------------------------------------------------- composite layer
 static inline uint64_t site_seed(uint64_t seed, int layer, int site) {
     return seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer * 8 + site + 1) * 0xD1B54A32D192ED03ull;
@@ -198,7 +213,8 @@ static inline uint64_t site_seed(uint64_t seed, int layer, int site) {
 
 static int check_cfg(const amdseg_bert_cfg* c) {
     if (!c) return AMDSEG_ERR_ARG;
-    if (c->dtype != AMDSEG_BF16 && c->dtype != AMDSEG_F32) return AMDSEG_ERR_ARG;
+    if (c->dtype != AMDSEG_BF16 && c->dtype != AMDSEG_F32 && c->dtype != AMDSEG_F32S) return AMDSEG_ERR_ARG;
+    if (c->dtype == AMDSEG_F32S && (c->window != 0 || c->mixer != 0 || (c->nproj != 0 && c->nproj != 3))) return AMDSEG_ERR_ARG;
     if (c->H != c->heads * 64 || c->B <= 0 || c->L <= 0 || c->I <= 0) return AMDSEG_ERR_SHAPE;
     const long M = (long)c->B * c->L;
     if ((M % 128) || (c->H % 128) || (c->I % 128) || (c->L % 64)) return AMDSEG_ERR_SHAPE;
@@ -226,6 +242,29 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     if (!p || !a || !mask_bias) return AMDSEG_ERR_ARG;
     hipStream_t s = S(stream);
     const int M = c->B * c->L, H = c->H, I = c->I;
+    if (c->dtype == AMDSEG_F32S) {
+        // "parity" precision (csrc/parity.hip): fp32 activations, every product as one bf16 GEMM over K' = 3K on split images
+        if (!a->xs || !a->ctx_s || !a->x1_s || !a->h_s || !a->u) return AMDSEG_ERR_ARG;
+        const float* fx = (const float*)a->x_in;
+        if (PHASE1(c)) {
+            RET_IF(amdseg_split3_impl(fx, H, a->xs, M, H, 0, s));
+            RET_IF(amdseg_gemm_nt_impl(a->xs, 3 * H, p->wqkv, 3 * H, a->qkv, 3 * H, M, 3 * H, 3 * H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 1, s));
+            RET_IF(amdseg_pattn_fwd_impl((const float*)a->qkv, mask_bias, (float*)a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn,
+                                         site_seed(c->seed, li, 0), s));
+        }
+        if (!PHASE2(c)) return AMDSEG_OK;
+        RET_IF(amdseg_split3_impl((const float*)a->ctx, H, a->ctx_s, M, H, 0, s));
+        RET_IF(amdseg_gemm_nt_impl(a->ctx_s, 3 * H, p->wo, 3 * H, a->z1, H, M, H, 3 * H, AMDSEG_EPI_BIAS, p->bo, nullptr, 0, nullptr, 0, 1, s));
+        RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
+                                      site_seed(c->seed, li, 1), AMDSEG_F32, s));
+        RET_IF(amdseg_split3_impl((const float*)a->x1, H, a->x1_s, M, H, 0, s));
+        RET_IF(amdseg_gemm_nt_impl(a->x1_s, 3 * H, p->w1, 3 * H, a->u, I, M, I, 3 * H, AMDSEG_EPI_BIAS, p->b1, nullptr, 0, nullptr, 0, 1, s));
+        RET_IF(amdseg_gelu_fwd_split_impl((const float*)a->u, a->h_s, M, I, c->act, s));
+        RET_IF(amdseg_gemm_nt_impl(a->h_s, 3 * I, p->w2, 3 * I, a->z2, H, M, H, 3 * I, AMDSEG_EPI_BIAS, p->b2, nullptr, 0, nullptr, 0, 1, s));
+        RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, c->p_hidden,
+                                      site_seed(c->seed, li, 2), AMDSEG_F32, s));
+        return AMDSEG_OK;
+    }
     if (c->dtype == AMDSEG_F32) {
         // fp32 parity mode (inference): exact-fp32 MFMA GEMMs on the fp32 master weights, fp32 activations, no dropout
         if (c->p_hidden != 0.f || c->p_attn != 0.f) return AMDSEG_ERR_ARG;
@@ -267,7 +306,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
                           const amdseg_bert_layer_acts* a, const amdseg_bert_layer_ws* w, const float* mask_bias,
                           const void* dy, void* dx_in, int li, amdseg_stream_t stream) {
     RET_IF(check_cfg(c));
-    if (c->dtype != AMDSEG_BF16) return AMDSEG_ERR_ARG;      // training runs on the bf16 MFMA path only
+    if (c->dtype != AMDSEG_BF16 && c->dtype != AMDSEG_F32S) return AMDSEG_ERR_ARG;      // training: bf16 fast path or split-bf16 parity
     if (!p || !g || !a || !w || !mask_bias || !dy || !dx_in) return AMDSEG_ERR_ARG;
     hipStream_t s = S(stream);
     const int M = c->B * c->L, H = c->H, I = c->I, acc = c->accumulate_grads;
@@ -286,6 +325,49 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     (void)NPd;
     amdseg_reduce_defer_begin(acc);
     struct Flush { hipStream_t s; ~Flush() { amdseg_reduce_defer_flush(s); } } flush_at_exit{s};
+    if (c->dtype == AMDSEG_F32S) {
+        // "parity" precision: same dataflow in fp32; every GEMM operand goes through its split image (csrc/parity.hip)
+        if (!w->d_out_s || !w->du_s || !w->d_ao_s || !w->dqkv_s || !a->xs || !a->ctx_s || !a->x1_s || !a->h_s) return AMDSEG_ERR_ARG;
+        if (PHASE1(c)) {
+            RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, part_ln2, g->ln2_g, g->ln2_b,
+                                      g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, AMDSEG_F32, s));
+            RET_IF(amdseg_split3_impl((const float*)d_out, H, w->d_out_s, M, H, 0, s));
+            RET_IF(amdseg_gemm_nt_impl(w->d_out_s, 3 * H, p->w2_t, 3 * H, w->du, I, M, I, 3 * H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1, s));
+            RET_IF(amdseg_gelu_bwd_split_impl((float*)w->du, (const float*)a->u, w->du_s, M, I, c->act, s));
+            RET_IF(amdseg_colsum_impl(w->du, I, part_b1, g->b1, M, I, acc, AMDSEG_F32, s));
+            RET_IF(amdseg_gemm_nt_impl(w->du_s, 3 * I, p->w1_t, 3 * I, w->dx1, H, M, H, 3 * I, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1, s));
+            RET_IF(amdseg_add_inplace_impl((float*)w->dx1, (const float*)w->dz2, (size_t)M * H, s));
+            RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, part_ln1, g->ln1_g,
+                                      g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, AMDSEG_F32, s));
+            RET_IF(amdseg_split3_impl((const float*)d_ao, H, w->d_ao_s, M, H, 0, s));
+            RET_IF(amdseg_gemm_nt_impl(w->d_ao_s, 3 * H, p->wo_t, 3 * H, w->dctx, H, M, H, 3 * H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1, s));
+        }
+        if (PHASE2(c)) {
+            RET_IF(amdseg_pattn_bwd_impl((const float*)a->qkv, mask_bias, (const float*)a->ctx, (const float*)w->dctx, a->lse, w->delta,
+                                         (float*)w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0), s));
+            RET_IF(amdseg_split3_impl((const float*)w->dqkv, 3 * H, w->dqkv_s, M, 3 * H, 0, s));
+            RET_IF(amdseg_colsum_impl(w->dqkv, 3 * H, part_bqkv, g->bqkv, M, 3 * H, acc, AMDSEG_F32, s));
+            RET_IF(amdseg_gemm_nt_impl(w->dqkv_s, 9 * H, p->wqkv_t, 9 * H, dx_in, H, M, H, 9 * H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1, s));
+            RET_IF(amdseg_add_inplace_impl((float*)dx_in, (const float*)w->dz1, (size_t)M * H, s));
+        }
+        if (!PHASE_WGRAD(c)) return AMDSEG_OK;
+        // dW = dY^T X = dYhi^T Xhi + dYhi^T Xlo + dYlo^T Xhi: three grouped launches over the hi / lo column blocks of the images
+        const bf16_t* Ai[4] = {(const bf16_t*)w->d_out_s, (const bf16_t*)w->du_s, (const bf16_t*)w->d_ao_s, (const bf16_t*)w->dqkv_s};
+        const bf16_t* Bi[4] = {(const bf16_t*)a->h_s, (const bf16_t*)a->x1_s, (const bf16_t*)a->ctx_s, (const bf16_t*)a->xs};
+        float* C[4] = {g->w2, g->w1, g->wo, g->wqkv};
+        const int N[4] = {H, I, H, 3 * H}, K[4] = {I, H, H, H};
+        int lda[4], ldb[4], ldc[4];
+        for (int i = 0; i < 4; ++i) { lda[i] = 3 * N[i]; ldb[i] = 3 * K[i]; ldc[i] = K[i]; }
+        for (int term = 0; term < 3; ++term) {                      // (hi, hi), (hi, lo), (lo, hi)
+            const void* A[4]; const void* Bm[4];
+            for (int i = 0; i < 4; ++i) {
+                A[i] = Ai[i] + (term == 2 ? 2 * N[i] : 0);
+                Bm[i] = Bi[i] + (term == 1 ? 2 * K[i] : 0);
+            }
+            RET_IF(amdseg_gemm_tn_grouped_impl(4, A, lda, Bm, ldb, C, ldc, N, K, M, term == 0 ? acc : 1, s));
+        }
+        return AMDSEG_OK;
+    }
     if (PHASE1(c)) {
     // LN2 backward: dz2 (residual grad), d_out = masked dz2 (grad of the FFN output dense), dln2, db2
     RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, part_ln2, g->ln2_g, g->ln2_b,

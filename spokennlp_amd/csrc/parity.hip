@@ -1,0 +1,324 @@
+// "parity" precision mode: fp32 activations, every contraction at fp32-grade accuracy on the bf16 MFMA pipes.
+//
+// The reference trains and predicts in fp32 (run_finetune.sh:61-96 has no --fp16 / --bf16); the north star asks for logits within
+// 1e-3 of it.  A single bf16 rounding of the operands misses that by two orders of magnitude (hard part 1).  Here every
+// fp32 operand x is split into two bf16 numbers, hi = bf16(x) and lo = bf16(x - hi) (x = hi + lo to 2^-17 relative), and a product
+// A . B^T is evaluated as  Ahi.Bhi + Ahi.Blo + Alo.Bhi  (the dropped Alo.Blo term is 2^-16 relative) -- as ONE bf16 GEMM over a
+// three times longer K:  A' = [Ahi | Ahi | Alo]  (M x 3K),  B' = [Bhi | Blo | Bhi]  (N x 3K), fp32 accumulation inside the MFMA and
+// an fp32 result.  So the projection / FFN GEMMs of the forward pass and the dgrads of backward run on the SAME deep-pipeline kernel
+// as the fast path (gemm_dp.hip) at K' = 3K, the weight gradients on the grouped TN kernel as three accumulating launches over the
+// hi / lo column blocks; what is new are the HBM-bound producers of the split images below and an fp32 attention (forward with
+// saved log-sum-exp + dropout, backward) on the vector ALUs with LDS-staged 64-row chunks.  The exact v_mfma_f32_32x32x2_f32 kernels
+// of gemm_f32.hip (1/16 of the bf16 rate) remain as the bit-faithful inference reference ("fp32" precision).
+#include "common.h"
+#include "amdseg_internal.h"
+
+// ------------------------------------------------------------------------------------------------ split images
+// out row (3K wide):  order 0 (activation / gradient operand A') = [hi | hi | lo];  order 1 (weight operand B') = [hi | lo | hi]
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+    hi.x = pack2bf(v.x, v.y); hi.y = pack2bf(v.z, v.w);
+    const float r0 = v.x - __uint_as_float(hi.x << 16), r1 = v.y - __uint_as_float(hi.x & 0xffff0000u);
+    const float r2 = v.z - __uint_as_float(hi.y << 16), r3 = v.w - __uint_as_float(hi.y & 0xffff0000u);
+    lo.x = pack2bf(r0, r1); lo.y = pack2bf(r2, r3);
+}
+__device__ __forceinline__ void split_store(bf16_t* orow, int K, int c, const float4 v, int order) {
+    uint2 hi, lo;
+    split4(v, hi, lo);
+    *reinterpret_cast<uint2*>(orow + c) = hi;
+    *reinterpret_cast<uint2*>(orow + K + c) = order ? lo : hi;
+    *reinterpret_cast<uint2*>(orow + 2 * K + c) = order ? hi : lo;
+}
+
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int ld, bf16_t* __restrict__ out, int M, int K, int order) {
+    const int k4 = K >> 2;
+    const size_t total = (size_t)M * k4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / k4;
+        const int c = (int)(i - r * k4) * 4;
+        split_store(out + r * 3 * (size_t)K, K, c, *reinterpret_cast<const float4*>(x + r * ld + c), order);
+    }
+}
+
+// W [N, K] fp32 -> out [K, 3N] = [Wt_hi | Wt_lo | Wt_hi] (the B' operand of a dgrad  dX = dY . W  written as an NT product)
+__global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int N, int K) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = W[(size_t)(n0 + ty + 8 * i) * K + k0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i, n = n0 + tx;
+        const float v = tile[tx][ty + 8 * i];
+        const bf16_t hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+        bf16_t* o = out + (size_t)k * 3 * N;
+        o[n] = hi; o[N + n] = lo; o[2 * N + n] = hi;
+    }
+}
+
+// h = gelu(u) written directly as the split image [M, 3I] (the fp32 h itself is never needed: W2's GEMM and its weight gradient
+// read the image);  backward: du = du * gelu'(u) in place (fp32, for the bias gradient) + its split image
+__device__ __forceinline__ float gelu_exact(float x, int act) {
+    return act ? 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))) : gelu_erf(x);
+}
+__device__ __forceinline__ float gelu_exact_grad(float x, int act) {
+    if (!act) return gelu_erf_grad(x);
+    const float x2 = x * x, t = tanhf(0.7978845608028654f * (x + 0.044715f * x * x2));
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 0.134145f * x2);
+}
+__global__ __launch_bounds__(256) void gelu_fwd_split_kernel(const float* __restrict__ u, bf16_t* __restrict__ hs, int M, int I, int act) {
+    const int k4 = I >> 2;
+    const size_t total = (size_t)M * k4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / k4;
+        const int c = (int)(i - r * k4) * 4;
+        float4 v = *reinterpret_cast<const float4*>(u + r * I + c);
+        v.x = gelu_exact(v.x, act); v.y = gelu_exact(v.y, act); v.z = gelu_exact(v.z, act); v.w = gelu_exact(v.w, act);
+        split_store(hs + r * 3 * (size_t)I, I, c, v, 0);
+    }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_split_kernel(float* __restrict__ du, const float* __restrict__ u, bf16_t* __restrict__ dus,
+                                                             int M, int I, int act) {
+    const int k4 = I >> 2;
+    const size_t total = (size_t)M * k4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / k4;
+        const int c = (int)(i - r * k4) * 4;
+        float4 g = *reinterpret_cast<const float4*>(du + r * I + c);
+        const float4 x = *reinterpret_cast<const float4*>(u + r * I + c);
+        g.x *= gelu_exact_grad(x.x, act); g.y *= gelu_exact_grad(x.y, act); g.z *= gelu_exact_grad(x.z, act); g.w *= gelu_exact_grad(x.w, act);
+        *reinterpret_cast<float4*>(du + r * I + c) = g;
+        split_store(dus + r * 3 * (size_t)I, I, c, g, 0);
+    }
+}
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<float4*>(y)[i];
+        const float4 b = reinterpret_cast<const float4*>(x)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        reinterpret_cast<float4*>(y)[i] = a;
+    }
+}
+
+static inline unsigned ew_grid(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (unsigned)(b > 4096 ? 4096 : (b == 0 ? 1 : b));
+}
+
+int amdseg_split3_impl(const float* x, int ld, void* out, int M, int K, int order, hipStream_t s) {
+    if (!x || !out) return AMDSEG_ERR_ARG;
+    if (M <= 0 || K <= 0 || (K % 4) || (ld % 4)) return AMDSEG_ERR_SHAPE;
+    hipLaunchKernelGGL(split3_kernel, dim3(ew_grid((size_t)M * K / 4)), dim3(256), 0, s, x, ld, (bf16_t*)out, M, K, order);
+    return amdseg_launch_status();
+}
+int amdseg_split3_transpose_impl(const float* W, void* out, int N, int K, hipStream_t s) {
+    if (!W || !out) return AMDSEG_ERR_ARG;
+    if (N <= 0 || K <= 0 || (N % 32) || (K % 32)) return AMDSEG_ERR_SHAPE;
+    hipLaunchKernelGGL(split3_transpose_kernel, dim3(K / 32, N / 32), dim3(256), 0, s, W, (bf16_t*)out, N, K);
+    return amdseg_launch_status();
+}
+int amdseg_gelu_fwd_split_impl(const float* u, void* hs, int M, int I, int act, hipStream_t s) {
+    if (!u || !hs) return AMDSEG_ERR_ARG;
+    if (M <= 0 || I <= 0 || (I % 4)) return AMDSEG_ERR_SHAPE;
+    hipLaunchKernelGGL(gelu_fwd_split_kernel, dim3(ew_grid((size_t)M * I / 4)), dim3(256), 0, s, u, (bf16_t*)hs, M, I, act);
+    return amdseg_launch_status();
+}
+int amdseg_gelu_bwd_split_impl(float* du, const float* u, void* dus, int M, int I, int act, hipStream_t s) {
+    if (!du || !u || !dus) return AMDSEG_ERR_ARG;
+    if (M <= 0 || I <= 0 || (I % 4)) return AMDSEG_ERR_SHAPE;
+    hipLaunchKernelGGL(gelu_bwd_split_kernel, dim3(ew_grid((size_t)M * I / 4)), dim3(256), 0, s, du, u, (bf16_t*)dus, M, I, act);
+    return amdseg_launch_status();
+}
+int amdseg_add_inplace_impl(float* y, const float* x, size_t n, hipStream_t s) {
+    if (!y || !x) return AMDSEG_ERR_ARG;
+    if (n == 0 || (n % 4)) return AMDSEG_ERR_SHAPE;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, s, y, x, n / 4);
+    return amdseg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 attention, forward + backward
+// [hf] models/bert/modeling_bert.py:111-136 (eager_attention_forward): scores = q k^T / 8 + mask, softmax in fp32, dropout on the
+// probabilities, context = P V; backward by the usual recomputation from the saved log-sum-exp.  Vector-ALU kernels (the fp32 MFMA
+// would bring 1/16 of the bf16 rate; these products are 10 % of the layer's FLOPs): a workgroup = 4 waves = 4 consecutive query (or
+// key) rows of one (batch, head); the other side is streamed through LDS in 64-row chunks [64][65] (row stride 65 floats: a lane
+// reading ITS row and all lanes reading ONE row are both conflict-free).  "lane = row of the chunk" for the dot products (the wave's
+// own row broadcast from a VGPR with v_readlane), "lane = feature" for the weighted sums.  Dropout: stateless hash of
+// (seed, flat element index), keep-scale 1 / (1 - p) as torch.
+struct PAttnArgs {
+    const float* qkv; const float* mask_bias; float* ctx; float* lse;
+    const float* dctx; float* delta; float* dqkv;
+    int B, L, heads;
+    float scale, inv_keep; uint32_t thresh; uint64_t seed;
+};
+#define PA_LD 65
+
+__device__ __forceinline__ void pa_stage(float (*dst)[PA_LD], const float* src, int ld) {       // 64 rows x 64 floats, 256 threads
+    const int t = threadIdx.x, r = t >> 2, c0 = (t & 3) * 16;
+    const float* p = src + (size_t)r * ld + c0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 4 * i);
+        dst[r][c0 + 4 * i] = v.x; dst[r][c0 + 4 * i + 1] = v.y; dst[r][c0 + 4 * i + 2] = v.z; dst[r][c0 + 4 * i + 3] = v.w;
+    }
+}
+// sum_d row_reg[d] * chunk[lane][d]   (row_reg: lane d holds element d of the wave's own row)
+__device__ __forceinline__ float pa_dot(float row_reg, const float (*chunk)[PA_LD], int l) {
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d)
+        acc = fmaf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(row_reg), d)), chunk[l][d], acc);
+    return acc;
+}
+// sum_j w[j] * chunk[j][lane]   (w: lane j holds the weight of chunk row j)
+__device__ __forceinline__ float pa_wsum(float w, const float (*chunk)[PA_LD], int l, float acc) {
+#pragma unroll
+    for (int j = 0; j < 64; ++j)
+        acc = fmaf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), j)), chunk[j][l], acc);
+    return acc;
+}
+__device__ __forceinline__ float pa_keep(const PAttnArgs& a, size_t row_bhq, int key) {
+    if (a.thresh == 0) return 1.0f;
+    return drop_keep(a.seed, row_bhq * (size_t)a.L + key, a.thresh) ? a.inv_keep : 0.0f;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void pattn_fwd_kernel(PAttnArgs a) {
+    __shared__ float Cs[64][PA_LD];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
+    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
+    const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
+    const float qreg = base[(size_t)q * H3 + l];
+    const size_t row = ((size_t)b * a.heads + h) * a.L + q;
+    float s[NS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int si = 0; si < NS; ++si) {
+        s[si] = -INFINITY;
+        if (si < ns) {
+            __syncthreads();
+            pa_stage(Cs, base + (size_t)si * 64 * H3 + H, H3);
+            __syncthreads();
+            s[si] = pa_dot(qreg, Cs, l) * a.scale + a.mask_bias[(size_t)b * a.L + si * 64 + l];
+            mx = fmaxf(mx, s[si]);
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int si = 0; si < NS; ++si) { s[si] = si < ns ? expf(s[si] - mx) : 0.f; sum += s[si]; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    float o = 0.f;
+#pragma unroll
+    for (int si = 0; si < NS; ++si) {
+        if (si < ns) {
+            __syncthreads();
+            pa_stage(Cs, base + (size_t)si * 64 * H3 + 2 * H, H3);
+            __syncthreads();
+            o = pa_wsum(s[si] * inv * pa_keep(a, row, si * 64 + l), Cs, l, o);
+        }
+    }
+    a.ctx[((size_t)b * a.L + q) * H + h * 64 + l] = o;
+    if (a.lse && l == 0) a.lse[row] = mx + logf(sum);
+}
+
+// dQ (and delta = dO . O): one pass over the key chunks with K and V chunks both resident
+template <int NS>
+__global__ __launch_bounds__(256) void pattn_bwd_dq_kernel(PAttnArgs a) {
+    __shared__ float Ks[64][PA_LD];
+    __shared__ float Vs[64][PA_LD];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
+    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
+    const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
+    const size_t tok = (size_t)b * a.L + q, row = ((size_t)b * a.heads + h) * a.L + q;
+    const float qreg = base[(size_t)q * H3 + l];
+    const float doreg = a.dctx[tok * H + h * 64 + l];
+    const float delta = wave_sum(doreg * a.ctx[tok * H + h * 64 + l]);
+    const float lse = a.lse[row];
+    if (l == 0) a.delta[row] = delta;
+    float dq = 0.f;
+    for (int si = 0; si < ns; ++si) {
+        __syncthreads();
+        pa_stage(Ks, base + (size_t)si * 64 * H3 + H, H3);
+        pa_stage(Vs, base + (size_t)si * 64 * H3 + 2 * H, H3);
+        __syncthreads();
+        const float sc = pa_dot(qreg, Ks, l) * a.scale + a.mask_bias[(size_t)b * a.L + si * 64 + l];
+        const float p = expf(sc - lse);
+        const float dpd = pa_dot(doreg, Vs, l);
+        const float ds = p * (dpd * pa_keep(a, row, si * 64 + l) - delta);
+        dq = pa_wsum(ds, Ks, l, dq);
+    }
+    a.dqkv[tok * H3 + h * 64 + l] = dq * a.scale;
+}
+
+// dK, dV: workgroup = 4 consecutive keys, streams the query chunks (Q rows and dO rows)
+__global__ __launch_bounds__(256) void pattn_bwd_dkv_kernel(PAttnArgs a) {
+    __shared__ float Qs[64][PA_LD];
+    __shared__ float Ds[64][PA_LD];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
+    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
+    const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
+    const size_t tok = (size_t)b * a.L + j, bh = (size_t)b * a.heads + h;
+    const float kreg = base[(size_t)j * H3 + H + l], vreg = base[(size_t)j * H3 + 2 * H + l];
+    const float mb = a.mask_bias[(size_t)b * a.L + j];
+    float dk = 0.f, dv = 0.f;
+    for (int ci = 0; ci < ns; ++ci) {
+        __syncthreads();
+        pa_stage(Qs, base + (size_t)ci * 64 * H3, H3);
+        pa_stage(Ds, a.dctx + ((size_t)b * a.L + ci * 64) * H + h * 64, H);
+        __syncthreads();
+        const size_t rowi = bh * a.L + ci * 64 + l;                  // query i = ci * 64 + lane
+        const float sc = pa_dot(kreg, Qs, l) * a.scale + mb;
+        const float p = expf(sc - a.lse[rowi]);
+        const float keep = pa_keep(a, rowi, j);
+        const float dpd = pa_dot(vreg, Ds, l);
+        const float ds = p * (dpd * keep - a.delta[rowi]);
+        dv = pa_wsum(p * keep, Ds, l, dv);
+        dk = pa_wsum(ds, Qs, l, dk);
+    }
+    a.dqkv[tok * H3 + H + h * 64 + l] = dk * a.scale;
+    a.dqkv[tok * H3 + 2 * H + h * 64 + l] = dv;
+}
+
+static int pattn_fill(PAttnArgs& a, int B, int L, int heads, float scale, float p, uint64_t seed) {
+    if (B <= 0 || L <= 0 || heads <= 0 || (L % 64) || L > 4096) return AMDSEG_ERR_SHAPE;
+    if (p < 0.f || p >= 1.f) return AMDSEG_ERR_ARG;
+    a.B = B; a.L = L; a.heads = heads; a.scale = scale; a.seed = seed;
+    a.thresh = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
+    if (p > 0.f && a.thresh == 0) a.thresh = 1;
+    a.inv_keep = 1.0f / (1.0f - p);
+    return AMDSEG_OK;
+}
+
+int amdseg_pattn_fwd_impl(const float* qkv, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale, float p,
+                          uint64_t seed, hipStream_t s) {
+    if (!qkv || !mask_bias || !ctx) return AMDSEG_ERR_ARG;
+    PAttnArgs a = {};
+    int rc = pattn_fill(a, B, L, heads, scale, p, seed);
+    if (rc) return rc;
+    a.qkv = qkv; a.mask_bias = mask_bias; a.ctx = ctx; a.lse = lse;
+    const dim3 grid(L / 4, heads, B);
+    const int ns = L / 64;
+    if (ns <= 2) hipLaunchKernelGGL(pattn_fwd_kernel<2>, grid, dim3(256), 0, s, a);
+    else if (ns <= 8) hipLaunchKernelGGL(pattn_fwd_kernel<8>, grid, dim3(256), 0, s, a);
+    else if (ns <= 16) hipLaunchKernelGGL(pattn_fwd_kernel<16>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pattn_fwd_kernel<64>, grid, dim3(256), 0, s, a);
+    return amdseg_launch_status();
+}
+
+int amdseg_pattn_bwd_impl(const float* qkv, const float* mask_bias, const float* ctx, const float* dctx, const float* lse, float* delta,
+                          float* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed, hipStream_t s) {
+    if (!qkv || !mask_bias || !ctx || !dctx || !lse || !delta || !dqkv) return AMDSEG_ERR_ARG;
+    PAttnArgs a = {};
+    int rc = pattn_fill(a, B, L, heads, scale, p, seed);
+    if (rc) return rc;
+    a.qkv = qkv; a.mask_bias = mask_bias; a.ctx = (float*)ctx; a.lse = (float*)lse; a.dctx = dctx; a.delta = delta; a.dqkv = dqkv;
+    const dim3 grid(L / 4, heads, B);
+    hipLaunchKernelGGL(pattn_bwd_dq_kernel<1>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pattn_bwd_dkv_kernel, grid, dim3(256), 0, s, a);
+    return amdseg_launch_status();
+}

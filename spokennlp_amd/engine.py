@@ -309,6 +309,43 @@ class BertEncoderEngine:
             v += p._version
         return v
 
+    # ---- "parity" precision: split-bf16 weight images (csrc/parity.hip), built on first use and refreshed with the bf16 copies
+    supports_parity = True
+
+    def _parity_weights(self):
+        if getattr(self, "_parity", None) is None:
+            if not self.supports_parity or self.nproj != 3:
+                raise L.AmdsegError('amdseg_precision="parity" is implemented for the BERT / ELECTRA encoder (full softmax attention)')
+            H, I, dev = self.H, self.I, self.device
+            bf = dict(dtype=torch.bfloat16, device=dev)
+            self._parity = [dict(wqkv=torch.empty(3 * H, 3 * H, **bf), wo=torch.empty(H, 3 * H, **bf), w1=torch.empty(I, 3 * H, **bf),
+                                 w2=torch.empty(H, 3 * I, **bf), wqkv_t=torch.empty(H, 9 * H, **bf), wo_t=torch.empty(H, 3 * H, **bf),
+                                 w1_t=torch.empty(H, 3 * I, **bf), w2_t=torch.empty(I, 3 * H, **bf)) for _ in range(self.nlayers)]
+            fp = self.fp
+            self.lparams_parity = []
+            for i in range(self.nlayers):
+                ps = lambda s_: self._p(fp.flat_p, i, s_).data_ptr()            # noqa: E731
+                t = self._parity[i]
+                self.lparams_parity.append(L.LayerParams(
+                    wqkv=t["wqkv"].data_ptr(), wo=t["wo"].data_ptr(), w1=t["w1"].data_ptr(), w2=t["w2"].data_ptr(),
+                    wqkv_t=t["wqkv_t"].data_ptr(), wo_t=t["wo_t"].data_ptr(), w1_t=t["w1_t"].data_ptr(), w2_t=t["w2_t"].data_ptr(),
+                    bqkv=ps(self.proj_b0), bo=ps("attention.output.dense.bias"), b1=ps("intermediate.dense.bias"), b2=ps("output.dense.bias"),
+                    ln1_g=ps("attention.output.LayerNorm.weight"), ln1_b=ps("attention.output.LayerNorm.bias"),
+                    ln2_g=ps("output.LayerNorm.weight"), ln2_b=ps("output.LayerNorm.bias")))
+            self._split_parity_weights()
+        return self.lparams_parity
+
+    def _split_parity_weights(self):
+        H = self.H
+        for i in range(self.nlayers):
+            t = self._parity[i]
+            mats = ((self.fp.view(self.fp.flat_p, self.fp.lp(i, self.proj_w0), (3 * H, H)), "wqkv"),
+                    (self._p(self.fp.flat_p, i, "attention.output.dense.weight"), "wo"),
+                    (self._p(self.fp.flat_p, i, "intermediate.dense.weight"), "w1"), (self._p(self.fp.flat_p, i, "output.dense.weight"), "w2"))
+            for W, k in mats:
+                ops.split3(W, t[k], order=1)
+                ops.split3_transpose(W, t[k + "_t"])
+
     def mark_weights_dirty(self):
         """call after writing encoder weights by a route none of the detectors below can see (`p.data.copy_(...)`, raw pointers)"""
         self._dirty = True
@@ -342,6 +379,8 @@ class BertEncoderEngine:
         n, pw, pb, pt, pn, pk = self._ct_table
         rc = L.load().amdseg_cast_transpose_batched(n, pw, pb, pt, pn, pk, torch.cuda.current_stream().cuda_stream)
         L.check(rc, "amdseg_cast_transpose_batched")
+        if getattr(self, "_parity", None) is not None:
+            self._split_parity_weights()
         self._shadow_version = self._weights_version()
 
     # ------------------------------------------------------------------------------------------------ arenas
@@ -379,6 +418,7 @@ class BertEncoderEngine:
         if key in self._arenas:
             return self._arenas[key]
         dev, H, I, M = self.device, self.H, self.I, B * Lseq
+        parity = fp32 == "parity"
         bf = torch.float32 if fp32 else torch.bfloat16
         nsave = self.nlayers if train else 1
 
@@ -392,18 +432,27 @@ class BertEncoderEngine:
                          for _ in range(nsave)],
                  emb_z=e(M, H), emb_mean=e(M, dt=torch.float32), emb_rstd=e(M, dt=torch.float32),
                  mask_bias=e(B, Lseq, dt=torch.float32), gen=0, busy=False, stamp=0)
+        if parity:               # split-bf16 images of the GEMM operands (see csrc/parity.hip); `h` itself is never materialised
+            for la in A["layers"]:
+                la.update(xs=e(M, 3 * H, dt=torch.bfloat16), ctx_s=e(M, 3 * H, dt=torch.bfloat16), x1_s=e(M, 3 * H, dt=torch.bfloat16),
+                          h_s=e(M, 3 * I, dt=torch.bfloat16))
         if train:
             npart = 2 * ops.ln_partials_numel(M, H) + max((M + 127) // 128, (H + 127) // 128) * (I + self.nproj * H)   # amdseg.h: amdseg_bert_layer_ws
             def ws_set():
-                return dict(dz2=e(M, H), dbr2=e(M, H), du=e(M, I), dx1=e(M, H), dz1=e(M, H), dbr1=e(M, H), dctx=e(M, H),
-                            dqkv=e(M, self.nproj * H), delta=e(B * self.heads * Lseq, dt=torch.float32),
-                            partials=e(npart, dt=torch.float32))
+                d = dict(dz2=e(M, H), dbr2=e(M, H), du=e(M, I), dx1=e(M, H), dz1=e(M, H), dbr1=e(M, H), dctx=e(M, H),
+                         dqkv=e(M, self.nproj * H), delta=e(B * self.heads * Lseq, dt=torch.float32),
+                         partials=e(npart, dt=torch.float32))
+                if parity:
+                    d.update(d_out_s=e(M, 3 * H, dt=torch.bfloat16), du_s=e(M, 3 * I, dt=torch.bfloat16),
+                             d_ao_s=e(M, 3 * H, dt=torch.bfloat16), dqkv_s=e(M, 9 * H, dt=torch.bfloat16))
+                return d
 
             # two scratch sets: layer i's weight-gradient GEMM (second stream) still reads set i % 2 while layer i-1's backward
             # writes the other one
             A["ws_sets"] = [ws_set(), ws_set()]
-            A["ws_structs"] = [L.LayerWs(**{k: w[k].data_ptr() for k in ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx",
-                                                                          "dqkv", "delta", "partials")}) for w in A["ws_sets"]]
+            wkeys = ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx", "dqkv", "delta", "partials") + \
+                (("d_out_s", "du_s", "d_ao_s", "dqkv_s") if parity else ())
+            A["ws_structs"] = [L.LayerWs(**{k: w[k].data_ptr() for k in wkeys}) for w in A["ws_sets"]]
             A["ws"] = dict(A["ws_sets"][0], dy=[e(M, H), e(M, H)])
             A["ws_struct"] = A["ws_structs"][0]
         A["acts_struct"] = []
@@ -412,6 +461,8 @@ class BertEncoderEngine:
             xin = A["x"][i] if train else A["x"][i % 2]
             xout = A["x"][i + 1] if train else A["x"][(i + 1) % 2]
             ptrs = {k: la[k].data_ptr() for k in ("qkv", "ctx", "z1", "x1", "u", "h", "z2", "lse", "mean1", "rstd1", "mean2", "rstd2")}
+            if parity:
+                ptrs.update({k: la[k].data_ptr() for k in ("xs", "ctx_s", "x1_s", "h_s")})
             if not train and not fp32:
                 ptrs["u"] = None                  # inference: the FFN GEMM skips the pre-activation output
             A["acts_struct"].append(L.LayerActs(x_in=xin.data_ptr(), x_out=xout.data_ptr(), **ptrs))
@@ -435,8 +486,10 @@ class BertEncoderEngine:
         M = B * Lseq
         if (M % 128) or (Lseq % 64):
             raise L.AmdsegError(f"batch*seq must be a multiple of 128 and seq a multiple of 64 (got B={B}, L={Lseq})")
-        fp32 = (not train) and getattr(self.cfg, "amdseg_precision", "bf16") == "fp32"
-        if not fp32:
+        fp32 = self._precision(train)
+        if fp32 == "parity":
+            self._parity_weights()
+        if fp32 is not True:
             self.refresh_shadows()
             if train and not self._fused_owner:
                 self._dirty = True                          # an unknown optimiser is expected to write the weights after this step
@@ -445,8 +498,8 @@ class BertEncoderEngine:
         p_h = float(self.cfg.hidden_dropout_prob) if train else 0.0
         p_a = float(self.cfg.attention_probs_dropout_prob) if train else 0.0
         cfg = self._cfg_struct(B, Lseq, p_h, p_a, seed, True)
-        cfg.dtype = dt
-        lparams = self.lparams32 if fp32 else self.lparams
+        cfg.dtype = L.F32S if fp32 == "parity" else dt
+        lparams = self.lparams_parity if fp32 == "parity" else (self.lparams32 if fp32 else self.lparams)
         ids = input_ids.reshape(-1).contiguous()
         tts = token_type_ids.reshape(-1).contiguous()
         torch.mul(1.0 - attention_mask.to(torch.float32), -1e30, out=A["mask_bias"])
@@ -471,8 +524,19 @@ class BertEncoderEngine:
                                 seed * 1000003 + 29, dt, L.F32, s)
         L.check(rc, "amdseg_dropout")
         ctx = dict(B=B, L=Lseq, ids=ids, tts=tts, pos=pos, seed=seed, p_h=p_h, p_a=p_a, p_out=p_out if train else 0.0,
-                   layer_saved=saved, arena=A, gen=A["gen"])
+                   layer_saved=saved, arena=A, gen=A["gen"], parity=fp32 == "parity")
         return out.view(B, Lseq, self.H), ctx
+
+    def _precision(self, train):
+        """False = bf16 fast path; True = exact-fp32 MFMA (inference only); "parity" = fp32 activations + split-bf16 contractions
+        (forward and backward).  `config.amdseg_precision`: "bf16" (default) | "fp32" | "parity"; TRAINING with "fp32" runs "parity"
+        (the exact-fp32 kernels have no backward; the split products carry 2^-16 relative error instead of 2^-24)."""
+        want = getattr(self.cfg, "amdseg_precision", "bf16")
+        if want == "bf16":
+            return False
+        if want not in ("fp32", "parity"):
+            raise L.AmdsegError(f"amdseg_precision={want!r}: expected 'bf16', 'fp32' or 'parity'")
+        return "parity" if (train or want == "parity") else True
 
     # hooks overridden by the Longformer engine
     def _position_ids(self, input_ids):
@@ -487,6 +551,11 @@ class BertEncoderEngine:
         """critical path (everything but the weight gradients) on the current stream; the grouped weight-gradient GEMM of this
         layer on a second, lower-priority stream so that it fills the CUs its single wave of tiles leaves idle and runs under
         the next layer's backward"""
+        if cfg.dtype == L.F32S:
+            rc = lib.amdseg_bert_layer_bwd(C.byref(cfg), C.byref(self.lparams_parity[i]), C.byref(self.lgrads[i]),
+                                           C.byref(A["acts_struct"][i]), C.byref(A["ws_struct"]), mb, dy.data_ptr(), other.data_ptr(), i, s)
+            L.check(rc, f"amdseg_bert_layer_bwd[{i}] (parity)")
+            return
         if not self.overlap_wgrad:
             rc = lib.amdseg_bert_layer_bwd(C.byref(cfg), C.byref(self.lparams[i]), C.byref(self.lgrads[i]),
                                            C.byref(A["acts_struct"][i]), C.byref(A["ws_struct"]), mb, dy.data_ptr(), other.data_ptr(), i, s)
@@ -528,9 +597,12 @@ class BertEncoderEngine:
         lib = L.load()
         s = torch.cuda.current_stream().cuda_stream
         cfg = self._cfg_struct(B, Lseq, ctx["p_h"], ctx["p_a"], ctx["seed"], accumulate)
+        adt = L.F32 if ctx.get("parity") else L.BF16            # dtype of the activation gradients
+        if ctx.get("parity"):
+            cfg.dtype = L.F32S
         dseq = dseq.contiguous()
         dy, other = ws["dy"]
-        rc = lib.amdseg_dropout(dseq.data_ptr(), dy.data_ptr(), M * self.H, ctx["p_out"], ctx["seed"] * 1000003 + 29, L.F32, L.BF16, s)
+        rc = lib.amdseg_dropout(dseq.data_ptr(), dy.data_ptr(), M * self.H, ctx["p_out"], ctx["seed"] * 1000003 + 29, L.F32, adt, s)
         L.check(rc, "amdseg_dropout(bwd)")
         mb = A["mask_bias"].data_ptr()
         for i in reversed(range(self.nlayers)):
@@ -544,17 +616,17 @@ class BertEncoderEngine:
                     self.buckets.reduce_layer(i)
         # embeddings: out = dropout(LN(z)) (BigBird: LN(dropout(z))); grads of LN affine + the three tables
         if ctx["p_h"] > 0 and not self.emb_dropout_pre_ln:
-            rc = lib.amdseg_dropout(dy.data_ptr(), other.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, L.BF16, L.BF16, s)
+            rc = lib.amdseg_dropout(dy.data_ptr(), other.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, adt, adt, s)
             L.check(rc, "amdseg_dropout(emb bwd)")
             dy, other = other, dy
         g = lambda n: self.fp.view(self.fp.flat_g, self.prefix + "embeddings." + n)        # noqa: E731
         rc = lib.amdseg_ln_bwd(dy.data_ptr(), A["emb_z"].data_ptr(), A["emb_mean"].data_ptr(), A["emb_rstd"].data_ptr(),
                                self._emb("LayerNorm.weight").data_ptr(), other.data_ptr(), None, ws["partials"].data_ptr(),
                                g("LayerNorm.weight").data_ptr(), g("LayerNorm.bias").data_ptr(), None, M, self.H, 0.0, 0,
-                               1 if accumulate else 0, L.BF16, s)
+                               1 if accumulate else 0, adt, s)
         L.check(rc, "amdseg_ln_bwd(emb)")
         if ctx["p_h"] > 0 and self.emb_dropout_pre_ln:
-            rc = lib.amdseg_dropout(other.data_ptr(), dy.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, L.BF16, L.BF16, s)
+            rc = lib.amdseg_dropout(other.data_ptr(), dy.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, adt, adt, s)
             L.check(rc, "amdseg_dropout(emb bwd, pre-LN)")
             dy, other = other, dy
         we, pe, te = g("word_embeddings.weight"), g("position_embeddings.weight"), g("token_type_embeddings.weight")
@@ -564,7 +636,7 @@ class BertEncoderEngine:
         pos = ctx.get("pos")
         rc = lib.amdseg_embed_bwd(other.data_ptr(), ctx["ids"].data_ptr(), ctx["tts"].data_ptr(), None if pos is None else pos.data_ptr(),
                                   we.data_ptr(), pe.data_ptr(), te.data_ptr(), M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], pad,
-                                  L.BF16, s)
+                                  adt, s)
         L.check(rc, "amdseg_embed_bwd")
         self._embed_backward_fixup(pe, pad)
         if self.overlap_wgrad:                      # every consumer of flat_g (clip, AdamW, torch optimizers) is on the current stream

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AMDSEG_LIB") or os.path.join(_HERE, "libamdseg.so")
 
-BF16, F32 = 0, 1
+BF16, F32, F32S = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
 EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
 ABI_VERSION = 3
@@ -35,11 +35,12 @@ class LayerGrads(C.Structure):
 
 class LayerActs(C.Structure):
     _fields_ = [(n, vp) for n in ("x_in", "qkv", "ctx", "z1", "x1", "u", "h", "z2", "x_out",
-                                  "lse", "mean1", "rstd1", "mean2", "rstd2")]
+                                  "lse", "mean1", "rstd1", "mean2", "rstd2", "xs", "ctx_s", "x1_s", "h_s")]
 
 
 class LayerWs(C.Structure):
-    _fields_ = [(n, vp) for n in ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx", "dqkv", "delta", "partials")]
+    _fields_ = [(n, vp) for n in ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx", "dqkv", "delta", "partials",
+                                  "d_out_s", "du_s", "d_ao_s", "dqkv_s")]
 
 
 # name -> argtypes (restype is always int unless listed in _RESTYPE); mirrors include/amdseg.h one for one
@@ -81,6 +82,10 @@ _PROTOS = {
     "amdseg_attn_list_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, i32, vp, vp],
     "amdseg_attn_list_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp, vp, vp],
     "amdseg_debug_force_small_tile": [i32],
+    "amdseg_split3": [vp, i32, vp, i32, i32, i32, vp],
+    "amdseg_split3_transpose": [vp, vp, i32, i32, vp],
+    "amdseg_pattn_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
+    "amdseg_pattn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_prof_enable": [i32],
     "amdseg_prof_reset": [],
     "amdseg_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],

@@ -21,6 +21,7 @@ GLOBAL_SUFFIXES = ("query_global", "key_global", "value_global")
 
 
 class LongformerEncoderEngine(BertEncoderEngine):
+    supports_parity = False
     def __init__(self, module, config, device, bert_attr="longformer"):
         super().__init__(module, config, device, bert_attr=bert_attr)
         aw = config.attention_window

@@ -338,3 +338,35 @@ def clip_coef(sumsq_t, max_norm, extra_scale, coef, norm=None):
 def scale_(x, coef):
     rc = L.load().amdseg_scale(_p(x), x.numel(), _p(coef), _s())
     L.check(rc, "amdseg_scale")
+
+
+def split3(x, out, order=0):
+    """fp32 [M, K] -> bf16 [M, 3K] split image ([hi | hi | lo] for order 0, [hi | lo | hi] for order 1); csrc/parity.hip"""
+    M, K = x.shape
+    rc = L.load().amdseg_split3(_p(x), x.stride(0), _p(out), M, K, order, _s())
+    L.check(rc, "amdseg_split3")
+    return out
+
+
+def split3_transpose(W, out):
+    N, K = W.shape
+    rc = L.load().amdseg_split3_transpose(_p(W), _p(out), N, K, _s())
+    L.check(rc, "amdseg_split3_transpose")
+    return out
+
+
+def pattn_fwd(qkv, mask_bias, B, Lq, heads, p=0.0, seed=0):
+    H = heads * 64
+    ctx = torch.empty(B * Lq, H, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B * heads * Lq, dtype=torch.float32, device=qkv.device)
+    rc = L.load().amdseg_pattn_fwd(_p(qkv), _p(mask_bias), _p(ctx), _p(lse), B, Lq, heads, 0.125, p, seed, _s())
+    L.check(rc, "amdseg_pattn_fwd")
+    return ctx, lse
+
+
+def pattn_bwd(qkv, mask_bias, ctx, dctx, lse, B, Lq, heads, p=0.0, seed=0):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    rc = L.load().amdseg_pattn_bwd(_p(qkv), _p(mask_bias), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, Lq, heads, 0.125, p, seed, _s())
+    L.check(rc, "amdseg_pattn_bwd")
+    return dqkv

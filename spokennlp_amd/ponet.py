@@ -16,6 +16,7 @@ Engine: the BERT engine with an EXTERNAL token mixer (amdseg_bert_cfg.mixer = 1)
 followed by the shared attention-output / FFN half of the composite layer call.
 """
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -81,6 +82,7 @@ class PoNetModel(nn.Module):
 
 # ------------------------------------------------------------------------------------------------ engine
 class PoNetEncoderEngine(BertEncoderEngine):
+    supports_parity = False
     def __init__(self, module, config, device, bert_attr="ponet"):
         super().__init__(module, config, device, bert_attr=bert_attr, layer_order=PONET_LAYER_ORDER, nproj=5)
         H, heads = self.H, self.heads
@@ -184,16 +186,43 @@ class PoNetEncoderEngine(BertEncoderEngine):
 
 
 class _PoNetEncoderFn(torch.autograd.Function):
+    """as engine.EncoderFn, plus segment_ids.  Any [B, L] is accepted (the reference model takes every shape): windows that do not
+    fill the 64-token blocks / 128-row tiles are padded with masked tokens (their segment id continues the last one; masked tokens
+    take part in no pooling branch) and fully masked sequences, and the output is cut back."""
+
     @staticmethod
     def forward(ctx, trigger, engine, input_ids, attention_mask, token_type_ids, segment_ids, train, seed, p_out, *params):
+        from .engine import EncoderFn
         ctx.nparams = len(params)                            # > 0: DDP-compatible mode (engine.ddp_compat)
-        engine.set_segments(segment_ids)
-        out, ectx = engine.forward(input_ids, attention_mask, token_type_ids, train, seed, p_out)
+        B, Lq = input_ids.shape
+        Bp, Lp = EncoderFn.aligned_shape(B, Lq)
+        ctx.shapes = (B, Lq, Bp, Lp)
+        if (Bp, Lp) != (B, Lq):
+            pad_id = getattr(engine.cfg, "pad_token_id", None) or 0
+            grow = (0, Lp - Lq, 0, Bp - B)
+            input_ids = F.pad(input_ids, grow, value=pad_id)
+            attention_mask = F.pad(attention_mask, grow, value=0)
+            token_type_ids = F.pad(token_type_ids, grow, value=0)
+            seg = F.pad(segment_ids, grow, value=0)
+            if Lp != Lq:
+                seg[:B, Lq:] = segment_ids[:, -1:] + 1
+            segment_ids = seg
+        engine.set_segments(segment_ids.contiguous())
+        out, ectx = engine.forward(input_ids.contiguous(), attention_mask.contiguous(), token_type_ids.contiguous(), train, seed, p_out)
         ctx.engine, ctx.ectx = engine, ectx
+        if train:
+            weakref.finalize(ctx, BertEncoderEngine._release_arena, ectx["arena"], ectx["gen"])
+        if (Bp, Lp) != (B, Lq):
+            out = out[:B, :Lq].contiguous()
         return out
 
     @staticmethod
     def backward(ctx, dseq):
+        B, Lq, Bp, Lp = ctx.shapes
+        if (Bp, Lp) != (B, Lq):
+            full = dseq.new_zeros((Bp, Lp, dseq.shape[-1]))
+            full[:B, :Lq] = dseq
+            dseq = full
         eng, pn = ctx.engine, ctx.ectx["pn"]
         eng._run, eng._valid, eng._coef_mean = pn["run"], pn["valid"], pn["coef_mean"]
         if ctx.nparams:

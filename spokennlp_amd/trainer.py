@@ -146,6 +146,14 @@ class Trainer(transformers.Trainer):
 
     def __init__(self, *args, amdseg_native=True, **kwargs):
         self.amdseg_native = bool(amdseg_native)
+        targs = kwargs.get("args") or next((a for a in args if isinstance(a, transformers.TrainingArguments)), None)
+        if self.amdseg_native and targs is not None and targs.dataloader_pin_memory:
+            # batches arrive in pinned host memory; a blocking `.to(device)` (accelerate's default) makes the host wait for every
+            # kernel queued so far once per step, so the next step's launches start on an idle GPU (measured: 19.1 vs 15.3 ms per
+            # bert-base step).  Asynchronous copies from pinned memory are ordered on the compute stream and safe.
+            ac = getattr(targs, "accelerator_config", None)
+            if ac is not None and hasattr(ac, "non_blocking") and not ac.non_blocking:
+                ac.non_blocking = True
         super().__init__(*args, **kwargs)
         self.amdseg_native = self.amdseg_native and hasattr(self.model, "engine")
 

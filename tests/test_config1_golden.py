@@ -1,0 +1,95 @@
+"""BASELINE config 1 (run_inference.sh on 32 Wiki-727K-shaped documents): golden outputs of the REFERENCE model class
+(tools/gen_golden_config1.py imports it) on the windows the feature builder produces.  CPU: the oracle reproduces the reference's
+logits to fp32 round-off and its decoded boundaries exactly.  GPU (-m gpu): the HIP path in fp32 parity mode is within the north-star
+1e-3 of the reference's logits with bit-exact boundaries; the bf16 fast path decodes the same boundaries wherever the reference's
+decision margin exceeds the bf16 error (margins reported)."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+PLAIN = dict(do_da_ts=False, do_cssl=False, do_tssp=False, cl_loss_weight=0.0, tssp_loss_weight=0.0)
+
+
+def load(name, max_windows=None):
+    from spokennlp_amd import data, preprocess as P
+    from spokennlp_amd.inference import MODEL_COLUMNS
+    from tests.util import tiny_state_dict
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False)
+    arch = dict(zip(z["arch_keys"].tolist(), [int(v) for v in z["arch_vals"].tolist()]))
+    sd = tiny_state_dict(arch, seed=int(z["sd_seed"]), std=float(z["std"]))
+    dk = dict(zip(z["docs_keys"].tolist(), z["docs_vals"].tolist()))
+    for k in ("seed", "mean_sents", "sd_sents"):
+        if k in dk:
+            dk[k] = int(dk[k])
+    docs = data.synth_docs(int(z["ndocs"]), vocab=arch["vocab_size"], **dk)
+    sent_ids = [[s.tolist() for s in d["sentences"]] for d in docs]
+    labels = [[0 if v == 1 else 1 for v in d["labels"]] for d in docs]
+    L = int(z["L"])
+    random.seed(42)
+    cols = P.prepare_features(sent_ids, labels, list(range(len(docs))), L, arch["vocab_size"] - 1, data.CLS_ID, data.PAD_ID)
+    chk = int(np.sum(np.array(cols["input_ids"], dtype=np.int64) * (1 + np.arange(2 * L).reshape(1, 2, L) % 97)))
+    assert chk == int(z["input_ids_checksum"][0]) and len(cols["input_ids"]) == int(z["n_windows"])      # same windows as the reference saw
+    offs = np.concatenate(([0], np.cumsum(z["counts"])))
+    return z, arch, sd, cols, offs, MODEL_COLUMNS, (docs, sent_ids, labels)
+
+
+def run_windows(model_call, cols, columns, bs, device, nmax=None):
+    n = len(cols["input_ids"]) if nmax is None else min(nmax, len(cols["input_ids"]))
+    out_logits, out_cos = [], []
+    for i in range(0, n, bs):
+        idx = list(range(i, min(i + bs, n)))
+        batch = {k: torch.tensor([cols[k][j] for j in idx], dtype=torch.long, device=device) for k in columns}
+        with torch.no_grad():
+            _, logits, cos = model_call(batch)
+        for r, j in enumerate(idx):
+            sel = (batch["labels"][r, 0] != -100)
+            out_logits.append(logits[r, 0][sel].float().cpu().numpy())
+            out_cos.append(cos[r][:int(sel.sum())].float().cpu().numpy())
+    return out_logits, out_cos
+
+
+@pytest.mark.parametrize("name,nmax", [("config1_tiny", None), ("config1_bert_base", 4)])
+def test_oracle_reproduces_reference_on_config1(name, nmax):
+    from oracle import bert_ts_oracle as O
+    z, arch, sd, cols, offs, columns, _ = load(name)
+    cfg = O.make_cfg(num_labels=2, **arch, **PLAIN)
+    lg, cs = run_windows(lambda b: O.model_forward(sd, cfg, b), cols, columns, 4 if nmax is None else 2, None, nmax)
+    for w, (a, c) in enumerate(zip(lg, cs)):
+        ref = z["labelled_logits"][offs[w]:offs[w + 1]]
+        assert np.abs(a - ref).max() < 5e-5, (w, np.abs(a - ref).max())
+        assert (a.argmax(-1) == ref.argmax(-1)).all()
+        assert np.abs(c - z["cos"][offs[w]:offs[w + 1]]).max() < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["config1_tiny", "config1_bert_base"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_hip_path_vs_reference_on_config1(dev, name, precision):
+    from tests.test_gpu_model import build_model
+    z, arch, sd, cols, offs, columns, _ = load(name)
+    m = build_model(arch, dict(PLAIN), sd, dev).eval()
+    m.config.amdseg_precision = precision
+    lg, cs = run_windows(lambda b: m(**b), cols, columns, 4, dev)
+    ref = z["labelled_logits"]
+    got = np.concatenate(lg, 0)
+    assert got.shape == ref.shape
+    d = np.abs(got - ref).max()
+    margin = np.abs(ref[:, 0] - ref[:, 1])
+    same = got.argmax(-1) == ref.argmax(-1)
+    print(f"{name} {precision}: {len(ref)} labelled positions in {len(lg)} windows, max|dlogit| {d:.2e} (max|logit| {np.abs(ref).max():.2f}), "
+          f"boundary decisions equal {same.mean():.4f}, min reference margin {margin.min():.4f}")
+    if precision == "fp32":
+        assert d < 1e-3                                   # north star
+        assert same.all()                                 # predicted boundary indices bit-exact
+        assert np.abs(np.concatenate(cs, 0) - z["cos"]).max() < 1e-3
+    else:
+        assert d < 0.05 * np.abs(ref).max()
+        assert same[margin > 2 * d].all()                 # a flip can only happen inside the bf16 error band
+        assert same.mean() > 0.98

@@ -329,3 +329,101 @@ def test_bigbird_base_eval_vs_reference_golden(dev, precision):
         return
     assert d.max().item() < 0.05 * scale and d.mean().item() < 0.01 * scale
     assert abs(loss.item() - float(z["full_eval.loss"])) < 0.01 * abs(float(z["full_eval.loss"])) + 0.05
+
+
+def test_longformer_base_L4096_train_step_vs_reference_golden(dev):
+    """BASELINE config 5 is a TRAINING configuration: one train-mode step (dropout 0) of longformer-base-4096 (window 512, [CLS] global)
+    at L = 4096 against the REFERENCE's loss, every parameter's gradient norm, and the bias / LayerNorm / *_global gradients of the
+    first and last layer (tools/gen_golden.py --fullsize-lf-train-only; HF LongformerModel fwd + bwd on CPU, 84 s)"""
+    import numpy as np
+    from tests.util import longformer_state_dict
+    from tests.test_oracle_golden import flags_of
+    from tests.test_gpu_longformer import build_lf
+    z = np.load(os.path.join(ROOT, "tests", "golden", "longformer_base_L4096.npz"), allow_pickle=False)
+    arch = dict(zip(z["arch_keys"].tolist(), [float(v) if "eps" in k else int(float(v)) for k, v in zip(z["arch_keys"].tolist(), z["arch_vals"].tolist())]))
+    arch.pop("layer_norm_eps")
+    sd = longformer_state_dict(arch, seed=int(z["seed"]), std=float(z["std"]))
+    arch["attention_window"] = [int(v) for v in z["attention_window"]]
+    batch = {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("in.")}
+    m = build_lf(arch, flags_of(z, "train_full"), sd, dev, precision="bf16").train()
+    random.seed(int(z["train_full.random_seed"]))
+    loss, logits, cos = m(**batch)
+    loss.backward()
+    ref_loss = float(z["train_full.loss"])
+    print(f"longformer-base L=4096 train: loss {loss.item():.4f} vs reference {ref_loss:.4f}")
+    assert abs(loss.item() - ref_loss) < 0.01 * abs(ref_loss) + 0.05
+    lab = (batch["labels"][:, 0] != -100).cpu()
+    ref_lab = torch.from_numpy(z["train_full.logits_anchor_labelled"])
+    got_lab = logits.detach().float().cpu()[:, 0][lab]
+    assert (got_lab - ref_lab).abs().max().item() < 0.05 * ref_lab.abs().max().item()
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for n, v in zip(z["train_full.gradnorm_names"].tolist(), z["train_full.gradnorm_vals"].tolist()):
+        if v <= 1e-6:
+            continue
+        gn = float(params[n].grad.float().norm())
+        worst = max(worst, abs(gn - v) / v)
+        assert abs(gn - v) / v < 0.08, (n, gn, v)
+    checked, bad = 0, []
+    for k in z.files:
+        if k.startswith("train_full.grad."):
+            n = k[len("train_full.grad."):]
+            ref = torch.from_numpy(z[k])
+            if float(ref.norm()) < 1e-6:
+                continue
+            c = torch.nn.functional.cosine_similarity(params[n].grad.float().cpu().flatten(), ref.flatten(), dim=0).item()
+            lo = 0.9 if ("self.query.bias" in n or "self.key.bias" in n or "query_global.bias" in n or "key_global.bias" in n) else 0.985
+            if c <= lo:
+                bad.append((n, round(c, 4)))
+            checked += 1
+    print("longformer-base train: worst grad-norm deviation", worst, "full grads checked", checked, "below threshold", bad)
+    assert not bad and checked >= 20
+
+
+def test_bert_base_parity_precision_vs_reference_golden(dev):
+    """bert-base shape, L = 512, "parity" precision (split-bf16 products, fp32 activations): inference logits within the north-star
+    1e-3 with bit-exact boundary decisions, and ONE TRAINING STEP against the reference: loss, every parameter's gradient norm and the
+    stored first / last layer gradients to <= 1e-3 relative (the bf16 fast path is held to 8 % / cosine 0.985 above)"""
+    from tests.test_gpu_model import build_model, to_dev
+    z, sd, batch, arch, flags_of = _fullsize_case()
+    m = build_model(arch, flags_of(z, "full_eval"), sd, dev)
+    m.config.amdseg_precision = "parity"
+    m.eval()
+    random.seed(int(z["full_eval.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos = m(**to_dev(batch, dev))
+    ref = torch.from_numpy(z["full_eval.logits"])
+    lab = batch["labels"] != -100
+    d_all = (logits.cpu() - ref).abs().max().item()
+    print(f"bert-base L=512 parity eval: max|dlogit| {d_all:.2e} (max|logit| {ref.abs().max().item():.2f}), loss {loss.item():.5f} vs {float(z['full_eval.loss']):.5f}")
+    assert d_all < 1e-3 and abs(loss.item() - float(z["full_eval.loss"])) < 1e-3
+    assert torch.equal(logits.cpu()[lab].argmax(-1), ref[lab].argmax(-1))
+    m.train()
+    random.seed(int(z["train_full.random_seed"]))
+    loss, logits, cos = m(**to_dev(batch, dev))
+    loss.backward()
+    ref_loss = float(z["train_full.loss"])
+    assert abs(loss.item() - ref_loss) < 1e-3 * abs(ref_loss)
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for n, v in zip(z["train_full.gradnorm_names"].tolist(), z["train_full.gradnorm_vals"].tolist()):
+        if v <= 1e-6:
+            continue
+        gn = float(params[n].grad.float().norm())
+        worst = max(worst, abs(gn - v) / v)
+        assert abs(gn - v) / v < 1e-3, (n, gn, v)
+    checked, worst_full = 0, 0.0
+    for k in z.files:
+        if k.startswith("train_full.grad."):
+            n = k[len("train_full.grad."):]
+            ref = torch.from_numpy(z[k])
+            if float(ref.norm()) < 1e-6:
+                continue
+            rel = float((params[n].grad.float().cpu() - ref).norm() / ref.norm())
+            worst_full = max(worst_full, rel)
+            # q/k bias gradients are near-cancelling sums (softmax is invariant to a key bias): relative to their own tiny norm the
+            # fp32-level noise of 2048 summands shows; they are held to 1e-2, everything else to 1e-3
+            assert rel < (1e-2 if ("self.query.bias" in n or "self.key.bias" in n) else 1e-3), (n, rel)
+            checked += 1
+    print(f"bert-base parity train: loss {loss.item():.5f} vs {ref_loss:.5f}; worst grad-norm deviation {worst:.2e}; worst full-gradient relative error {worst_full:.2e} over {checked}")
+    assert checked >= 20

@@ -165,3 +165,200 @@ def test_dropout_step_deterministic(dev):
         vals.append((loss.item(), gn))
     assert vals[0][0] == vals[1][0]
     assert abs(vals[0][1] - vals[1][1]) <= 1e-6 * vals[0][1]          # embedding-table grads use fp32 atomics (order may vary)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 4: PoNet-base, L = 4096
+BASE = dict(vocab_size=21129, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+            max_position_embeddings=4096, type_vocab_size=2)
+
+
+def make_inputs_4096(B, seed, L=4096, vocab=21129):
+    """meeting-like windows: 40-160 ragged paragraph segments per 4096-token window (run_ponet_topic_segmentation.sh:34-61 with
+    use_paragraph_segment), CLS = segment 0, ragged right padding on all but the first sequence, labels at segment ends"""
+    r = random.Random(seed)
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(B, L, dtype=torch.long); am = torch.zeros(B, L, dtype=torch.long)
+    seg = torch.zeros(B, L, dtype=torch.long); lab = torch.full((B, L), -100, dtype=torch.long)
+    for b in range(B):
+        n = L if b == 0 else r.randrange(L // 2, L - 7)
+        ids[b, :n] = torch.randint(5, vocab - 1, (n,), generator=g); am[b, :n] = 1
+        nseg = r.randrange(40, 161)
+        cuts = sorted(r.sample(range(2, n), nseg - 1)) + [n]
+        pos = 1
+        for s, e in enumerate(cuts, start=1):
+            seg[b, pos:e] = s
+            lab[b, e - 1] = r.randrange(2)
+            pos = e
+        seg[b, n:] = nseg + 1
+    return ids, am, seg, lab
+
+
+def build_base(dev, dropout=0.0, clf_std=0.3):
+    from spokennlp_amd.ponet import PoNetForTokenClassification, PoNetConfig
+    cfg = PoNetConfig(num_labels=2, hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout, **BASE)
+    torch.manual_seed(0)
+    m = PoNetForTokenClassification(cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.add_(0.05 * torch.randn_like(p))
+            elif "LayerNorm.weight" in n:
+                p.add_(0.1 * torch.randn_like(p))
+            elif "classifier.weight" in n:
+                p.normal_(0, clf_std)
+            elif p.dim() == 2 and "embeddings" not in n:
+                p.normal_(0, 0.03)
+    return m, cfg
+
+
+@pytest.mark.parametrize("B", [2, 8])
+def test_pooling_kernels_full_size_vs_oracle(dev, B):
+    """config 4 shape: H = 768, L = 4096, 40-160 ragged segments, batch 2 (the script's) and 8: forward of the segment / local
+    max-pool + fusion kernels against the oracle's pooling() (run form), element by element"""
+    from oracle import ponet_oracle as PO
+    from spokennlp_amd import ops
+    L, H, nh = 4096, 768, 12
+    _, am, seg, _ = make_inputs_4096(B, 100 + B)
+    torch.manual_seed(B)
+    proj = torch.randn(B * L, 5 * H).bfloat16()
+    hq, hk, ho, hl, hs = [proj[:, k * H:(k + 1) * H].float().view(B, L, H) for k in range(5)]
+    valid = am == 1
+    ctx_ref = PO.pooling(hq, hk, ho, hl, hs, valid, seg, nh, runs=True)
+    vf = valid.float()
+    qbar = (hq * vf[..., None]).sum(1) / vf.sum(1, keepdim=True)
+    a = torch.einsum("bhe,bjhe->bhj", qbar.view(B, nh, 64), hk.view(B, L, nh, 64)) / 8.0
+    p = torch.softmax(a.masked_fill(~valid[:, None, :], float("-inf")), -1)
+    g = torch.einsum("bhj,bjhe->bhe", p, hk.view(B, L, nh, 64)).reshape(B, H)
+    pos = torch.arange(L).expand(B, L)
+    diff = seg[:, 1:] != seg[:, :-1]
+    one = torch.ones(B, 1, dtype=torch.bool)
+    rs = torch.cummax(torch.where(torch.cat((one, diff), 1), pos, torch.zeros_like(pos)), 1).values.int().reshape(-1).to(dev)
+    re = torch.flip(torch.cummin(torch.flip(torch.where(torch.cat((diff, one), 1), pos, torch.full_like(pos, L - 1)), (1,)), 1).values, (1,)).int().reshape(-1).to(dev)
+    mb = ((1 - am.float()) * -1e30).to(dev)
+    part = torch.empty(3 * B * L, H, dtype=torch.bfloat16, device=dev); parg = torch.empty(3 * B * L, H, dtype=torch.int16, device=dev)
+    ctx = torch.empty(B * L, H, dtype=torch.bfloat16, device=dev)
+    ops.ponet_pool_fwd(proj.to(dev), mb, rs, re, g.to(dev), part, parg, ctx, B, L, H)
+    got = ctx.float().cpu().view(B, L, H)
+    err = (got - ctx_ref).abs()
+    assert (err <= 0.01 * ctx_ref.abs() + 0.02).all(), err.max().item()
+    assert (got[~valid] == 0).all()
+
+
+def test_base_L4096_vs_oracle_and_invariances(dev):
+    """PoNet-base, L = 4096, B = 2 (run_ponet_topic_segmentation.sh:51): logits vs the CPU oracle (bf16 tolerance), and the two
+    size-independent properties of the path: what sits in the PADDING never reaches a valid token's logits, and sequences of a batch
+    do not see each other (batch permutation = output permutation)"""
+    from oracle import ponet_oracle as PO
+    from oracle import bert_ts_oracle as O
+    m, cfg = build_base(dev)
+    sd = {k: v.detach().clone().float() for k, v in m.state_dict().items()}
+    ids, am, seg, lab = make_inputs_4096(2, 7)
+    ocfg = O.make_cfg(num_labels=2, **BASE)
+    with torch.no_grad():
+        _, logits_o = PO.token_classification_forward(sd, ocfg, ids, am, torch.zeros_like(ids), seg, None, runs=True)
+    m = m.to(dev).eval()
+
+    def run(i, a, s):
+        with torch.no_grad():
+            return m(input_ids=i.to(dev), attention_mask=a.to(dev), segment_ids=s.to(dev), return_dict=True).logits.float().cpu()
+    lg = run(ids, am, seg)
+    valid = am == 1
+    scale = logits_o.abs().max().item()
+    d = (lg - logits_o).abs()[valid].max().item()
+    agree = (lg[valid].argmax(-1) == logits_o[valid].argmax(-1)).float().mean().item()
+    print(f"ponet-base L=4096: max|dlogit| {d:.4f} on a logit scale of {scale:.2f}; argmax agreement {agree:.4f}")
+    mean = (lg - logits_o).abs()[valid].mean().item()
+    assert d < 0.05 * scale and mean < 0.01 * scale and agree > 0.98, (d, mean, agree)      # bf16 through 12 layers, as for bert-base L = 512
+    # padding content is invisible
+    ids2, seg2 = ids.clone(), seg.clone()
+    ids2[~valid] = 77
+    seg2[~valid] = seg2.max() + 5
+    assert torch.equal(run(ids2, am, seg2)[valid], lg[valid])
+    # batch permutation
+    lg_p = run(ids.flip(0), am.flip(0), seg.flip(0)).flip(0)
+    assert (lg_p - lg).abs()[valid].max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B", [2, 8])
+def test_base_L4096_train_steps(dev, B):
+    """config 4 training: PoNet-base, 4096-token windows, dropout 0.1, fwd + bwd + clip + fused AdamW; finite gradients on every
+    parameter that takes part, loss goes down on a repeated batch"""
+    m, cfg = build_base(dev, dropout=0.1, clf_std=0.02)
+    m = m.to(dev)
+    ids, am, seg, lab = [t.to(dev) for t in make_inputs_4096(B, 21)]
+
+    def eval_loss():
+        m.eval()
+        with torch.no_grad():
+            v = m(input_ids=ids, attention_mask=am, segment_ids=seg, labels=lab, return_dict=False)[0].item()
+        m.train()
+        return v
+    before = eval_loss()
+    losses = []
+    for it in range(8):
+        loss = m(input_ids=ids, attention_mask=am, segment_ids=seg, labels=lab, return_dict=False)[0]
+        loss.backward()
+        if it == 0:
+            for n, p in m.named_parameters():
+                assert p.grad is not None and torch.isfinite(p.grad).all(), n
+            gn = m.engine().grad_norm_and_clip_coef(1.0)[0].item()
+            assert np.isfinite(gn) and gn > 0
+        # randomly initialised 12-layer post-LN network: Adam's sign-like first steps at the script's 5e-5 overshoot (the script starts
+        # from a pretrained checkpoint); 5e-6 keeps the repeated-batch loss monotone enough to assert on
+        m.engine().adamw_step(5e-6, max_grad_norm=1.0)
+        losses.append(loss.item())
+    after = eval_loss()
+    print("ponet-base L=4096 B=%d train losses" % B, [round(x, 4) for x in losses], "eval loss", round(before, 4), "->", round(after, 4))
+    assert all(np.isfinite(x) for x in losses) and after < before - 0.005
+
+
+def test_base_L4096_batch_additivity(dev):
+    """size-independent check of the B = 8 backward at full size: sequences are independent, so (gradient of the batch-of-8 mean loss) x
+    (its label count) == sum over the four batch-of-2 calls of (their gradient x their label count)"""
+    m, cfg = build_base(dev, dropout=0.0, clf_std=0.05)
+    m = m.to(dev).train()
+    ids, am, seg, lab = [t.to(dev) for t in make_inputs_4096(8, 33)]
+    eng = m.engine()
+    loss8 = m(input_ids=ids, attention_mask=am, segment_ids=seg, labels=lab, return_dict=False)[0]
+    loss8.backward()
+    n8 = int((lab != -100).sum())
+    g8 = eng.fp.flat_g.clone() * n8
+    eng.zero_grad()
+    tot = 0.0
+    for k in range(4):
+        sl = slice(2 * k, 2 * k + 2)
+        nk = int((lab[sl] != -100).sum())
+        lk = m(input_ids=ids[sl], attention_mask=am[sl], segment_ids=seg[sl], labels=lab[sl], return_dict=False)[0]
+        (lk * nk).backward()
+        tot += lk.item() * nk
+    g2 = eng.fp.flat_g.clone()
+    assert abs(tot - loss8.item() * n8) < 2e-3 * abs(tot)
+    rel = float((g8 - g2).norm() / g2.norm())
+    cos = torch.nn.functional.cosine_similarity(g8, g2, dim=0).item()
+    print(f"ponet-base L=4096: batch-of-8 vs 4 x batch-of-2 gradients: relative difference {rel:.3e}, cosine {cos:.6f}")
+    assert cos > 0.999 and rel < 0.05                     # bf16 activations: tile-order differences only
+
+
+def test_unaligned_shapes_vs_oracle(dev):
+    """B = 3, L = 100: the wrapper pads to the kernel tiles itself (masked tokens / a masked sequence) and cuts the output back"""
+    from oracle import ponet_oracle as PO
+    from oracle import bert_ts_oracle as O
+    m, cfg = build(dev)
+    sd = {k: v.detach().clone().float().requires_grad_(True) for k, v in m.state_dict().items()}
+    ids, am, seg, lab = make_inputs(3, 100, 13)
+    ocfg = O.make_cfg(num_labels=2, **ARCH)
+    loss_o, logits_o = PO.token_classification_forward(sd, ocfg, ids, am, torch.zeros_like(ids), seg, lab)
+    loss_o.backward()
+    m = m.to(dev).train()
+    loss, logits = m(input_ids=ids.to(dev), attention_mask=am.to(dev), segment_ids=seg.to(dev), labels=lab.to(dev), return_dict=False)[:2]
+    loss.backward()
+    assert logits.shape == (3, 100, 2)
+    valid = am == 1
+    assert (logits.detach().cpu() - logits_o.detach()).abs()[valid].max().item() < 0.02 * logits_o.abs().max().item() + 0.05
+    assert abs(loss.item() - loss_o.item()) < 0.03
+    for n, p in m.named_parameters():
+        go = sd[n].grad
+        if go is None or float(go.norm()) < 1e-6:
+            continue
+        c = torch.nn.functional.cosine_similarity(p.grad.float().cpu().flatten(), go.flatten(), dim=0).item()
+        assert c > 0.98, (n, c)

@@ -315,3 +315,24 @@ def test_mmvts_text_encoder_matches_reference(case, kind):
             assert np.abs(g.numpy() - z[k]).max() < 1e-4 + 2e-5 * np.abs(z[k]).max(), n      # gradients are O(100) here
             n_checked += 1
     assert n_checked > 30
+
+
+def test_ponet_oracle_run_form_equals_general_form():
+    """the O(L H) run-wise segment maximum used for the 4096-token GPU tests == the general same-id mask form (small case, ragged runs)"""
+    from oracle import ponet_oracle as PO
+    g = torch.Generator().manual_seed(4)
+    B, L, H = 2, 96, 32
+    hq, hk, ho, hl, hs = [torch.randn(B, L, H, generator=g) for _ in range(5)]
+    seg = torch.zeros(B, L, dtype=torch.long)
+    valid = torch.ones(B, L, dtype=torch.bool)
+    for b in range(B):
+        pos, s = 1, 1
+        while pos < L:
+            n = int(torch.randint(1, 17, (1,), generator=g))
+            seg[b, pos:pos + n] = s
+            pos, s = pos + n, s + 1
+    valid[1, 70:] = False
+    seg[1, 70:] = seg[1, 69] + 1
+    a = PO.pooling(hq, hk, ho, hl, hs, valid, seg, 2)
+    b_ = PO.pooling(hq, hk, ho, hl, hs, valid, seg, 2, runs=True)
+    assert torch.equal(a, b_)

@@ -310,6 +310,41 @@ def main_fullsize_lf():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def main_fullsize_lf_train():
+    """ADDS one train step of the reference (loss, every parameter's gradient norm, the bias / LayerNorm / *_global gradients of the first
+    and last layer) on the inputs of longformer_base_L4096.npz to that fixture: BASELINE config 5 is a TRAINING configuration"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import longformer_state_dict
+    path = os.path.join(OUT, "longformer_base_L4096.npz")
+    z = dict(np.load(path, allow_pickle=False))
+    arch = {k: int(v) if float(v) == int(float(v)) else float(v) for k, v in zip(z["arch_keys"].tolist(), z["arch_vals"].tolist())}
+    arch["layer_norm_eps"] = 1e-5
+    sd = longformer_state_dict(arch, seed=int(z["seed"]), std=float(z["std"]))
+    batch = {k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("in.")}
+    m, cfg = make_model(dict(arch, attention_window=[512] * 12), FULL, 0, "longformer")
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    random.seed(7)
+    m.train()
+    import time
+    t0 = time.time()
+    loss, logits, cos = m(**batch)[:3]
+    loss.backward()
+    print("longformer_base_L4096 train_full loss", float(loss), "in", round(time.time() - t0, 1), "s")
+    names, norms = [], []
+    for n, p in m.named_parameters():
+        names.append(n); norms.append(-1.0 if p.grad is None else float(p.grad.norm()))
+        small = n.endswith("bias") or "LayerNorm" in n
+        if p.grad is not None and small and (".layer.0." in n or ".layer.11." in n or "loss_calculator" in n):
+            z[f"train_full.grad.{n}"] = p.grad.numpy().copy()
+    z["train_full.gradnorm_names"] = np.array(names); z["train_full.gradnorm_vals"] = np.array(norms)
+    z["train_full.loss"] = loss.detach().numpy(); z["train_full.logits_anchor_labelled"] = logits.detach()[:, 0][batch["labels"][:, 0] != -100].numpy()
+    z["train_full.flags_keys"] = np.array(list(FULL.keys())); z["train_full.flags_vals"] = np.array([str(v) for v in FULL.values()])
+    z["train_full.random_seed"] = 7
+    np.savez_compressed(path, **z)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main_fullsize_bb():
     """bigbird-roberta-base shape (12 x 768, block 64, 3 random blocks, gelu_new, vocab 50359), L = 4096, 2 sequences, eval only"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -345,6 +380,8 @@ def main_fullsize_bb():
 if __name__ == "__main__":
     if "--fullsize-bb-only" in sys.argv:
         main_fullsize_bb()
+    elif "--fullsize-lf-train-only" in sys.argv:
+        main_fullsize_lf_train()
     elif "--fullsize-lf-only" in sys.argv:
         main_fullsize_lf()
     elif "--fullsize-only" in sys.argv:
