@@ -12,6 +12,7 @@
 // P never leaves registers; k-strided operands are gathered with ds_read_b64_tr_b16, so no transposed copy of
 // K, V, Q or dO is ever written to HBM.  The score matrix is never materialised; backward recomputes it from the
 // saved log-sum-exp.  Dropout uses the stateless (seed, element) hash of common.h, re-evaluated in backward.
+#include <type_traits>
 #include "common.h"
 #include "amdseg_internal.h"
 #include "prof.h"
@@ -35,6 +36,11 @@ __device__ __forceinline__ uint32_t pdrop_bits(uint32_t salt, int key_even) {
     // one multiply round: the argument is already a sum of odd-constant multiples of (row, pair), and v_mul_lo_u32 runs at
     // quarter rate -- the two-round mix32 made dropout a third of the forward kernel's time
     uint32_t x = salt + (uint32_t)(key_even >> 1) * 0x9e3779b9u;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+    return x;
+}
+// the same word as pdrop_bits(salt, key_even) when the caller has already formed  salt + (key_even >> 1) * 0x9e3779b9
+__device__ __forceinline__ uint32_t pdrop_mix(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
     return x;
 }
@@ -119,8 +125,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_part = 0.f;
-    const float sc2 = a.scale * LOG2E;
+    const float sc2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
     const uint32_t salt = pdrop_salt(pdrop_seedmix(a.seed), prow);
+    const uint32_t gsalt = (uint32_t)(g * 2) * 0x9e3779b9u;            // this lane group's keys g*4 .. g*4+3 = key pairs g*2, g*2+1
+    const uint32_t thr_hi = a.thresh16 << 16;
 
     const bf16_t* kbase = a.qkv + tok0 * a.H3 + H + h * HD;
     const bf16_t* vbase = a.qkv + tok0 * a.H3 + 2 * H + h * HD;
@@ -166,7 +174,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
         const char* tV = bufV(cur);
         const int key0 = CHUNK_OF(ch) * CH;
         // S^T[key][q]: 4 key frags of 16; all K fragments first, then the MFMAs with the k-step outermost so that
-        // consecutive MFMAs are independent
+        // consecutive MFMAs are independent.  The accumulators START from the additive key mask (in units of the raw dot product:
+        // mask / scale), so the masked score comes out of the MFMA and no separate scale-and-mask pass over the 16 scores is needed
+        // (this kernel is VALU-bound: ~250 vector instructions per 64-key chunk against 16 MFMAs, profiles/r01_gemm_experiments.md)
         f32x4 s[4];
         {
             bf16x8 fk[4][2];
@@ -175,17 +185,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) fk[fc][kk] = at_frag(tK, fc * 16 + i16, kk * 4 + g);
 #pragma unroll
-            for (int fc = 0; fc < 4; ++fc) s[fc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int fc = 0; fc < 4; ++fc) s[fc] = (f32x4){mbc[fc].x * inv_scale, mbc[fc].y * inv_scale, mbc[fc].z * inv_scale, mbc[fc].w * inv_scale};
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int fc = 0; fc < 4; ++fc) s[fc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[fc][kk], fq[kk], s[fc], 0, 0, 0);
-        }
-        // scores in the log2 domain: s2 = (q.k * scale + mask) * log2(e), so exp() is the native v_exp_f32 (2^x)
-#pragma unroll
-        for (int fc = 0; fc < 4; ++fc) {
-            s[fc][0] = s[fc][0] * sc2 + mbc[fc].x * LOG2E; s[fc][1] = s[fc][1] * sc2 + mbc[fc].y * LOG2E;
-            s[fc][2] = s[fc][2] * sc2 + mbc[fc].z * LOG2E; s[fc][3] = s[fc][3] * sc2 + mbc[fc].w * LOG2E;
         }
         if (BAND) {
             const int wq_lo = qb * (NW * 16) + w * 16;                  // wave-uniform: chunk wholly inside every row's band?
@@ -197,12 +201,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
                         if (band_masked(q, key0 + fc * 16 + g * 4 + r, a.window, a.nglobal)) s[fc][r] = -INFINITY;
             }
         }
-        float cmax = s[0][0];
-#pragma unroll
-        for (int fc = 0; fc < 4; ++fc)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[fc][r]);
-        cmax = xor_reduce_max_g(cmax);
+        // running maximum in the log2 domain (m = max raw score * scale * log2 e; scale > 0): v_max3 chain over the raw scores
+        float cmax = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+        cmax = fmaxf(fmaxf(cmax, s[0][3]), s[1][0]);
+        cmax = fmaxf(fmaxf(cmax, s[1][1]), s[1][2]);
+        cmax = fmaxf(fmaxf(cmax, s[1][3]), s[2][0]);
+        cmax = fmaxf(fmaxf(cmax, s[2][1]), s[2][2]);
+        cmax = fmaxf(fmaxf(cmax, s[2][3]), s[3][0]);
+        cmax = fmaxf(fmaxf(cmax, s[3][1]), s[3][2]);
+        cmax = fmaxf(cmax, s[3][3]);
+        cmax = xor_reduce_max_g(cmax) * sc2;
         if (__any(cmax > m_run)) {                 // wave-uniform: rescale only when some row's running max grew
             const float m_new = fmaxf(m_run, cmax);
             const float alpha = (BAND && m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
@@ -213,21 +221,34 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
         }
-        float psum = 0.f;
         const float m_use = (BAND && m_run == -INFINITY) ? 0.f : m_run;   // a row whose visited keys were all masked so far
-#pragma unroll
-        for (int fc = 0; fc < 4; ++fc)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[fc][r] = __builtin_amdgcn_exp2f(s[fc][r] - m_use); psum += s[fc][r]; }
-        l_part += psum;
-        if (a.thresh16) {
+        // p = 2^(s * scale * log2e - m): packed fp32 fma (two scores per instruction), native 2^x, packed partial sums
+        {
+            const f32x2 sc2v = {sc2, sc2}, negm = {-m_use, -m_use};
+            f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
             for (int fc = 0; fc < 4; ++fc)
 #pragma unroll
                 for (int rp = 0; rp < 2; ++rp) {
-                    const uint32_t u = pdrop_bits(salt, key0 + fc * 16 + g * 4 + rp * 2);
-                    s[fc][rp * 2] = (u & 0xffffu) >= a.thresh16 ? s[fc][rp * 2] * a.inv_keep : 0.f;
-                    s[fc][rp * 2 + 1] = (u >> 16) >= a.thresh16 ? s[fc][rp * 2 + 1] * a.inv_keep : 0.f;
+                    const f32x2 t = (f32x2){s[fc][rp * 2], s[fc][rp * 2 + 1]} * sc2v + negm;
+                    const f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                    ps2 += e;
+                    s[fc][rp * 2] = e.x; s[fc][rp * 2 + 1] = e.y;
+                }
+            l_part += ps2.x + ps2.y;
+        }
+        if (a.thresh16) {
+            // keep-mask: one hash word per key pair, 16 bits per probability.  The high field is compared as the whole word against
+            // thresh << 16, the low field after one shift; dropped entries become 0 and the 1 / keep-rate factor is applied ONCE to
+            // the finished output row (no per-element and / multiply)
+            const uint32_t salt_c = salt + (uint32_t)(key0 >> 1) * 0x9e3779b9u;
+#pragma unroll
+            for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp) {
+                    const uint32_t u = pdrop_mix(salt_c + (uint32_t)((fc * 16 + rp * 2) >> 1) * 0x9e3779b9u + gsalt);
+                    s[fc][rp * 2] = (u << 16) >= thr_hi ? s[fc][rp * 2] : 0.f;
+                    s[fc][rp * 2 + 1] = u >= thr_hi ? s[fc][rp * 2 + 1] : 0.f;
                 }
         }
         // O^T[d][q] += V^T[d][key] P^T[key][q]
@@ -243,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
         if (LIST) { c_cur = c_nxt; c_nxt = lw.next(l); }
     }
     const float lsum = xor_reduce_sum_g(l_part);
-    float inv = 1.0f / lsum;
+    float inv = (a.thresh16 ? a.inv_keep : 1.0f) / lsum;
     float lse_q = (m_run + __builtin_amdgcn_logf(lsum)) * LN2;          // natural-log LSE, as backward expects
     if ((BAND || LIST) && a.mask_bias[tok0 + q] < 0.f) { inv = 0.f; lse_q = INFINITY; }   // padded query: zero row (Longformer :579, BigBird context_layer * from_mask), p == 0 in backward
     bf16_t* op = a.ctx + (tok0 + q) * H + h * HD;
@@ -324,9 +345,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         delta_q = xor_reduce_sum_g(acc);
         if (g == 0) a.delta[prow] = delta_q;
     }
-    const float lse2_q = a.lse[prow] * LOG2E;
-    const float sc2 = a.scale * LOG2E;
+    const float sc2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
+    const float nlse_s = -a.lse[prow] * inv_scale;                      // accumulator start: (mask - lse) / scale, see below
     const uint32_t salt = pdrop_salt(pdrop_seedmix(a.seed), prow);
+    const uint32_t gsalt = (uint32_t)(g * 2) * 0x9e3779b9u;
+    const uint32_t thr_hi = a.thresh16 << 16;
+    const float ikeep = a.thresh16 ? a.inv_keep : 1.0f;
     f32x4 dq[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -386,8 +410,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                     fk[f2][kk] = at_frag(tK, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
                     fv[f2][kk] = at_frag(tV, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
                 }
+            // the score accumulators start from (mask - lse) / scale: p = 2^(acc * scale * log2e) needs ONE multiply per element
+            // after the MFMA instead of scale, mask and lse terms (VALU-bound kernel)
 #pragma unroll
-            for (int f2 = 0; f2 < 2; ++f2) { sacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f}; pacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            for (int f2 = 0; f2 < 2; ++f2) {
+                const float4 m4 = mbc[hf * 2 + f2];
+                sacc4[hf * 2 + f2] = (f32x4){fmaf(m4.x, inv_scale, nlse_s), fmaf(m4.y, inv_scale, nlse_s), fmaf(m4.z, inv_scale, nlse_s), fmaf(m4.w, inv_scale, nlse_s)};
+                pacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -396,24 +426,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                     pacc4[hf * 2 + f2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[f2][kk], fdo[kk], pacc4[hf * 2 + f2], 0, 0, 0);
                 }
         }
+        const f32x2 sc2v = {sc2, sc2}, ikv = {ikeep, ikeep}, ndl = {-delta_q, -delta_q};
+        if (a.thresh16) {                                               // dropped entries: dP = 0 (the 1 / keep-rate factor is ikv below)
+            const uint32_t salt_c = salt + (uint32_t)(key0 >> 1) * 0x9e3779b9u + gsalt;
 #pragma unroll
-        for (int fc = 0; fc < 4; ++fc) {
-            const f32x4 sacc = sacc4[fc], pacc = pacc4[fc];
-            const float mb[4] = {mbc[fc].x, mbc[fc].y, mbc[fc].z, mbc[fc].w};
-            float keepf[4] = {1.f, 1.f, 1.f, 1.f};
-            if (a.thresh16) {
+            for (int fc = 0; fc < 4; ++fc)
 #pragma unroll
                 for (int rp = 0; rp < 2; ++rp) {
-                    const uint32_t u = pdrop_bits(salt, key0 + fc * 16 + g * 4 + rp * 2);
-                    keepf[rp * 2] = (u & 0xffffu) >= a.thresh16 ? a.inv_keep : 0.f;
-                    keepf[rp * 2 + 1] = (u >> 16) >= a.thresh16 ? a.inv_keep : 0.f;
+                    const uint32_t u = pdrop_mix(salt_c + (uint32_t)(fc * 8 + rp) * 0x9e3779b9u);
+                    pacc4[fc][rp * 2] = (u << 16) >= thr_hi ? pacc4[fc][rp * 2] : 0.f;
+                    pacc4[fc][rp * 2 + 1] = u >= thr_hi ? pacc4[fc][rp * 2 + 1] : 0.f;
                 }
-            }
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(sacc[r] * sc2 + mb[r] * LOG2E - lse2_q);
-                if (BAND && edge && band_masked(q, key0 + fc * 16 + g * 4 + r, a.window, a.nglobal)) p = 0.f;
-                ds[fc][r] = p * (pacc[r] * keepf[r] - delta_q);
+        for (int fc = 0; fc < 4; ++fc) {
+            const f32x4 sacc = sacc4[fc];
+            const f32x4 pacc = pacc4[fc];
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {
+                const f32x2 t = (f32x2){sacc[rp * 2], sacc[rp * 2 + 1]} * sc2v;
+                f32x2 pe = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                if (BAND && edge) {
+                    if (band_masked(q, key0 + fc * 16 + g * 4 + rp * 2, a.window, a.nglobal)) pe.x = 0.f;
+                    if (band_masked(q, key0 + fc * 16 + g * 4 + rp * 2 + 1, a.window, a.nglobal)) pe.y = 0.f;
+                }
+                const f32x2 d2 = pe * ((f32x2){pacc[rp * 2], pacc[rp * 2 + 1]} * ikv + ndl);
+                ds[fc][rp * 2] = d2.x; ds[fc][rp * 2 + 1] = d2.y;
             }
         }
         // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
@@ -478,9 +516,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         fv[0] = *reinterpret_cast<const bf16x8*>(vp + g * 8);
         fv[1] = *reinterpret_cast<const bf16x8*>(vp + 32 + g * 8);
     }
-    const float mb2 = a.mask_bias[tok0 + key] * LOG2E;
-    const float sc2 = a.scale * LOG2E;
-    const uint32_t seedmix = pdrop_seedmix(a.seed);
+    const float sc2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
+    const float mbs = a.mask_bias[tok0 + key] * inv_scale;              // accumulator start: (mask - lse_row) / scale, see below
+    // keep-mask word of (row, key): pdrop_bits(pdrop_salt(seedmix, row), key & ~1) = mix(seedmix + row * C1 + (key >> 1) * C2);
+    // the key part is a per-lane constant, the row part one multiply per chunk + compile-time offsets
+    const uint32_t kc = pdrop_seedmix(a.seed) + (uint32_t)(key >> 1) * 0x9e3779b9u;
+    const uint32_t ksh = (key & 1) ? 0u : 16u;                          // this key's 16-bit field, moved to the top of the word
+    const uint32_t thr_hi = a.thresh16 << 16;
+    const float ikeep = a.thresh16 ? a.inv_keep : 1.0f;
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) { dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -547,8 +590,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                     fqa[f2][kk] = at_frag(tQ, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
                     foa[f2][kk] = at_frag(tO, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
                 }
+            // score accumulators start from (mask_key - lse_row) / scale (see the dQ kernel)
 #pragma unroll
-            for (int f2 = 0; f2 < 2; ++f2) { sacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f}; pacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            for (int f2 = 0; f2 < 2; ++f2) {
+                const float4 l4 = lsc[hf * 2 + f2];
+                sacc4[hf * 2 + f2] = (f32x4){fmaf(l4.x, -inv_scale, mbs), fmaf(l4.y, -inv_scale, mbs), fmaf(l4.z, -inv_scale, mbs), fmaf(l4.w, -inv_scale, mbs)};
+                pacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -557,23 +605,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                     pacc4[hf * 2 + f2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(foa[f2][kk], fv[kk], pacc4[hf * 2 + f2], 0, 0, 0);
                 }
         }
+        const f32x2 sc2v = {sc2, sc2}, ikv = {ikeep, ikeep};
+        // (tried and measured slower on this kernel: sharing the hash word of a key pair between lanes 2t / 2t + 1 through DPP,
+        // 86 -> 113 us; a separate copy of the element loop per dropout setting, 86 -> 102 us at 186 VGPRs)
+        const uint32_t rowc = kc + (uint32_t)(bh * a.L + q0 + g * 4) * 0x85ebca6bu;      // + (qf * 16 + r) * C1 per element
 #pragma unroll
         for (int qf = 0; qf < 4; ++qf) {
-            const f32x4 sacc = sacc4[qf], pacc = pacc4[qf];
-            const size_t rbase = bh * a.L + q0 + qf * 16 + g * 4;
-            const float ls[4] = {lsc[qf].x, lsc[qf].y, lsc[qf].z, lsc[qf].w}, dl[4] = {dlc[qf].x, dlc[qf].y, dlc[qf].z, dlc[qf].w};
+            const f32x4 sacc = sacc4[qf];
+            f32x4 pacc = pacc4[qf];
+            const float dl[4] = {dlc[qf].x, dlc[qf].y, dlc[qf].z, dlc[qf].w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(sacc[r] * sc2 + mb2 - ls[r] * LOG2E);
-                if (BAND && edge && band_masked(q0 + qf * 16 + g * 4 + r, key, a.window, a.nglobal)) p = 0.f;
-                float keepf = 1.f;
-                if (a.thresh16) {
-                    const uint32_t u = pdrop_bits(pdrop_salt(seedmix, rbase + r), key & ~1);
-                    const uint32_t f = (key & 1) ? (u >> 16) : (u & 0xffffu);
-                    keepf = f >= a.thresh16 ? a.inv_keep : 0.f;
+            for (int rp = 0; rp < 2; ++rp) {
+                const f32x2 t = (f32x2){sacc[rp * 2], sacc[rp * 2 + 1]} * sc2v;
+                f32x2 pe = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                if (BAND && edge) {
+                    if (band_masked(q0 + qf * 16 + g * 4 + rp * 2, key, a.window, a.nglobal)) pe.x = 0.f;
+                    if (band_masked(q0 + qf * 16 + g * 4 + rp * 2 + 1, key, a.window, a.nglobal)) pe.y = 0.f;
                 }
-                pd[qf][r] = p * keepf;
-                ds[qf][r] = p * (pacc[r] * keepf - dl[r]);
+                f32x2 pk = pe;                                           // P_drop without the 1 / keep-rate factor (applied to dV at the end)
+                if (a.thresh16) {
+                    const bool k0 = (pdrop_mix(rowc + (uint32_t)(qf * 16 + rp * 2) * 0x85ebca6bu) << ksh) >= thr_hi;
+                    const bool k1 = (pdrop_mix(rowc + (uint32_t)(qf * 16 + rp * 2 + 1) * 0x85ebca6bu) << ksh) >= thr_hi;
+                    pk.x = k0 ? pe.x : 0.f; pk.y = k1 ? pe.y : 0.f;
+                    pacc[rp * 2] = k0 ? pacc[rp * 2] : 0.f; pacc[rp * 2 + 1] = k1 ? pacc[rp * 2 + 1] : 0.f;
+                }
+                const f32x2 d2 = pe * ((f32x2){pacc[rp * 2], pacc[rp * 2 + 1]} * ikv - (f32x2){dl[rp * 2], dl[rp * 2 + 1]});
+                pd[qf][rp * 2] = pk.x; pd[qf][rp * 2 + 1] = pk.y;
+                ds[qf][rp * 2] = d2.x; ds[qf][rp * 2 + 1] = d2.y;
             }
         }
         // dV^T[d][key] += dO^T[d][q] P_drop[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
@@ -600,8 +658,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         pk.y = pack2bf(dk[d][2] * a.scale, dk[d][3] * a.scale);
         *reinterpret_cast<uint2*>(okp + d * 16 + g * 4) = pk;
         uint2 pv;
-        pv.x = pack2bf(dv[d][0], dv[d][1]);
-        pv.y = pack2bf(dv[d][2], dv[d][3]);
+        pv.x = pack2bf(dv[d][0] * ikeep, dv[d][1] * ikeep);
+        pv.y = pack2bf(dv[d][2] * ikeep, dv[d][3] * ikeep);
         *reinterpret_cast<uint2*>(ovp + d * 16 + g * 4) = pv;
     }
 }
