@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from transformers.models.bert.modeling_bert import BertModel, BertPreTrainedModel
 
 from . import lib as L
-from .engine import BertEncoderEngine, EncoderFn, HeadInputsFn, RowDotFn  # noqa: F401
+from .engine import BertEncoderEngine, EncoderFn, FusedHeadsFn, HeadInputsFn, RowDotFn  # noqa: F401
 
 HEAD_DEFAULTS = dict(do_da_ts=False, do_cssl=False, do_tssp=False, ts_loss_weight=1.0, ts_score_predictor="lt",
                      ts_score_predictor_cos_temp=1, focal_loss_gamma=0.0, weight_label_zero=0.5, cl_loss_weight=0.0,
@@ -332,6 +332,55 @@ class TopicSegHeadsMixin:
             loss = loss + cfg.tssp_loss_weight * self._tssp(feats, up, plan["tssp"])
         return loss, logits, cos
 
+    # ------------------------------------------------------------------------------------------------ fused training heads
+    def _fused_heads_ok(self, train):
+        """the HIP heads (csrc/heads.hip) cover the training configurations of run_finetune.sh: linear token scores, plain or
+        class-weighted CE, CSSL in list form with a non-zero temperature, TSSP.  Focal loss, the cosine score predictor, the eop_matrix
+        CSSL variant and evaluation (which also returns the cos-sim side output) stay on the torch formulation below."""
+        cfg = self.config
+        return (train and getattr(cfg, "amdseg_fused_heads", True) and cfg.ts_score_predictor == "lt" and cfg.focal_loss_gamma == 0
+                and (cfg.cl_loss_weight == 0 or (cfg.cl_anchor_level in ("eop_list", "eot_list") and cfg.cl_temp != 0
+                                                 and cfg.cl_positive_k + cfg.cl_negative_k <= 16))
+                and cfg.num_labels <= 4 and cfg.num_tssp_labels <= 4)
+
+    def _fused_heads(self, seq, labels, host, B, Lq, two_pass):
+        cfg = self.config
+        up, req = _IndexUploader(seq.device), _RowRequests()
+        pos, lab = self._labelled_rows(host["labels"][:, 0])
+        P = dict(nseg=2 if two_pass else 1, feat_off=0, anchor_off=-1, lists_off=0, n_anchor=0, n_list=0, pk=1, temp=float(cfg.cl_temp) or 1.0,
+                 t_rows_off=0, t_labels_off=0, nt=0, w_ts=float(cfg.ts_loss_weight), w_cl=float(cfg.cl_loss_weight),
+                 w_tssp2=float(cfg.tssp_loss_weight) ** 2)
+        if cfg.cl_loss_weight != 0:
+            cp = self._plan_cssl(up, req, pos, lab, Lq, 0)                  # same `random` call order as the reference (cssl.py:118-228)
+            if cp is not None:
+                s0, n = cp["rows"]
+                P["feat_off"] = up.add(req.rows[s0:s0 + n])[0]
+                P["lists_off"] = cp["lists"][0]
+                P["n_list"], P["pk"] = cp["nlists"], int(cfg.cl_positive_k)
+                if cp["anchors"] is None:
+                    P["n_anchor"] = n
+                else:
+                    P["anchor_off"], P["n_anchor"] = cp["anchors"]
+        use_tssp = two_pass and cfg.tssp_loss_weight != 0
+        if use_tssp:
+            tp = self._plan_tssp(up, req, host["stm"], host["spo"], Lq, B * Lq)
+            s0, n = tp["rows"]
+            P["t_rows_off"], P["t_labels_off"], P["nt"] = up.add(req.rows[s0:s0 + n])[0], tp["labs"][0], n
+        up.flush()
+        labels_all = (torch.cat((labels[:, 0], labels[:, 1])) if two_pass else labels[:, 0]).reshape(-1).contiguous()
+        class_w = None
+        if cfg.weight_label_zero != 0.5:
+            class_w = torch.tensor([cfg.weight_label_zero, 1 - cfg.weight_label_zero], dtype=torch.float32, device=seq.device)
+        clf, tc = self.loss_calculator.classifier, self.loss_calculator.tssp.classifier
+        loss, logits_all = FusedHeadsFn.apply(seq.reshape(-1, seq.shape[-1]), clf.weight, clf.bias, tc.weight if use_tssp else None,
+                                              tc.bias if use_tssp else None, labels_all, up.dev, class_w, P)
+        C_ = logits_all.shape[-1]
+        if two_pass:
+            logits = logits_all.view(2, B, Lq, C_).transpose(0, 1)          # (B, 2, L, C): [anchor, augmented], no copy
+        else:
+            logits = logits_all.view(B, 1, Lq, C_).expand(B, 2, Lq, C_)     # bert_for_ts.py:96: logits[:, 1] duplicates logits[:, 0]
+        return loss, logits
+
     # ------------------------------------------------------------------------------------------------ forward
     def forward(
         self,
@@ -392,6 +441,9 @@ class TopicSegHeadsMixin:
             ev.synchronize()
         logits, cos = None, None
         loss = None
+        if labels is not None and self._fused_heads_ok(self.training and torch.is_grad_enabled()):
+            loss, logits = self._fused_heads(seq, labels, host, B, Lq, two_pass)
+            return (loss, logits, torch.full((B, 1), -100.0, device=seq.device))
         if labels is not None:
             train = self.training and torch.is_grad_enabled()
             need_cos = (not train) or cfg.ts_score_predictor == "cos"

@@ -205,6 +205,24 @@ int amdseg_pattn_bwd(const float* qkv, const float* mask_bias, const float* ctx,
     return amdseg_pattn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta, dqkv, B, L, heads, scale, p_drop, seed, S(stream));
 }
 
+int amdseg_heads_fwd(const float* x, int M, int H, const float* logits, const int64_t* labels, const float* class_w, int C, int nseg,
+                     float* ce_unit, float* out8, float* acc4, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
+                     int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off, long t_labels_off,
+                     int nt, int Ct, float w_ts, float w_cl, float w_tssp2, amdseg_stream_t stream) {
+    return amdseg_heads_fwd_impl(x, M, H, logits, labels, class_w, C, nseg, ce_unit, out8, acc4, idx, feat_off, anchor_off, lists_off, n_anchor,
+                                 n_list, pk, temp, Wt, bt, t_rows_off, t_labels_off, nt, Ct, w_ts, w_cl, w_tssp2, S(stream));
+}
+int amdseg_heads_bwd_ce(const float* gout, int M, int C, int nseg, const float* ce_unit, const float* out8, float w_ts, float* dlogits,
+                        amdseg_stream_t stream) {
+    return amdseg_heads_bwd_ce_impl(gout, M, C, nseg, ce_unit, out8, w_ts, dlogits, S(stream));
+}
+int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float* dx, const int64_t* idx, long feat_off, long anchor_off,
+                          long lists_off, int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
+                          long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, amdseg_stream_t stream) {
+    return amdseg_heads_bwd_rows_impl(gout, x, M, H, dx, idx, feat_off, anchor_off, lists_off, n_anchor, n_list, pk, temp, Wt, bt, t_rows_off,
+                                      t_labels_off, nt, Ct, dWt, dbt, w_cl, w_tssp2, S(stream));
+}
+
 // ---------------------------------------------------------------------------------------------------- composite layer
 static inline uint64_t site_seed(uint64_t seed, int layer, int site) {
     return seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer * 8 + site + 1) * 0xD1B54A32D192ED03ull;

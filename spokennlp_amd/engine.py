@@ -781,3 +781,58 @@ class HeadInputsFn(torch.autograd.Function):
         if dfeats is not None and rows.numel():
             dx.index_add_(0, rows, dfeats.to(dx.dtype))
         return dx, dW, db, None
+
+
+class FusedHeadsFn(torch.autograd.Function):
+    """the training-step loss of the wrapper in one forward and one backward pass of HIP kernels (csrc/heads.hip): classifier logits
+    over every token (rowdot), token cross-entropy per half (anchor | augmented), CSSL InfoNCE over index lists, TSSP Linear + CE.
+    Index lists live in ONE int64 device buffer (`idx`, uploaded once per step); `plan` holds offsets / counts (host ints).
+    Returns (total loss, logits [M, C]); only the loss is differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, Wc, bc, Wt, bt, labels_all, idx, class_w, plan):
+        M, H = x.shape
+        C_ = Wc.shape[0]
+        logits = ops.rowdot_fwd(x, Wc, bc)
+        dev = x.device
+        out8 = torch.empty(8, dtype=torch.float32, device=dev)
+        acc4 = torch.empty(4, dtype=torch.float32, device=dev)
+        unit = torch.empty(M, C_, dtype=torch.float32, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        P = plan
+        rc = L.load().amdseg_heads_fwd(x.data_ptr(), M, H, logits.data_ptr(), labels_all.data_ptr(), None if class_w is None else class_w.data_ptr(),
+                                       C_, P["nseg"], unit.data_ptr(), out8.data_ptr(), acc4.data_ptr(), idx.data_ptr(), P["feat_off"],
+                                       P["anchor_off"], P["lists_off"], P["n_anchor"], P["n_list"], P["pk"], P["temp"],
+                                       None if Wt is None else Wt.data_ptr(), None if bt is None else bt.data_ptr(), P["t_rows_off"],
+                                       P["t_labels_off"], P["nt"], 0 if Wt is None else Wt.shape[0], P["w_ts"], P["w_cl"], P["w_tssp2"], s)
+        L.check(rc, "amdseg_heads_fwd")
+        ctx.save_for_backward(x, Wc, Wt if Wt is not None else x.new_empty(0), bt if bt is not None else x.new_empty(0), idx, unit, out8)
+        ctx.plan, ctx.has_tssp = P, Wt is not None
+        ctx.mark_non_differentiable(logits)
+        return out8[4], logits
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits):
+        x, Wc, Wt, bt, idx, unit, out8 = ctx.saved_tensors
+        P = ctx.plan
+        M, H = x.shape
+        C_ = Wc.shape[0]
+        lib = L.load()
+        s = torch.cuda.current_stream().cuda_stream
+        g = gloss.reshape(1).float().contiguous()
+        dlogits = torch.empty(M, C_, dtype=torch.float32, device=x.device)
+        L.check(lib.amdseg_heads_bwd_ce(g.data_ptr(), M, C_, P["nseg"], unit.data_ptr(), out8.data_ptr(), P["w_ts"], dlogits.data_ptr(), s),
+                "amdseg_heads_bwd_ce")
+        dWc = torch.empty_like(Wc); dbc = torch.empty(C_, dtype=torch.float32, device=x.device)
+        dx = ops.rowdot_bwd(x, Wc, dlogits, dW=dWc, db=dbc, need_dx=True)
+        dWt = dbt = None
+        if ctx.has_tssp:
+            dWt = torch.zeros_like(Wt); dbt = torch.zeros_like(bt)
+        if P["n_anchor"] > 0 or P["nt"] > 0:
+            L.check(lib.amdseg_heads_bwd_rows(g.data_ptr(), x.data_ptr(), M, H, dx.data_ptr(), idx.data_ptr(), P["feat_off"], P["anchor_off"],
+                                              P["lists_off"], P["n_anchor"], P["n_list"], P["pk"], P["temp"],
+                                              Wt.data_ptr() if ctx.has_tssp else None, bt.data_ptr() if ctx.has_tssp else None,
+                                              P["t_rows_off"], P["t_labels_off"], P["nt"], Wt.shape[0] if ctx.has_tssp else 0,
+                                              None if dWt is None else dWt.data_ptr(), None if dbt is None else dbt.data_ptr(),
+                                              P["w_cl"], P["w_tssp2"], s), "amdseg_heads_bwd_rows")
+        return dx, dWc, dbc, dWt, dbt, None, None, None, None

@@ -86,6 +86,11 @@ _PROTOS = {
     "amdseg_split3_transpose": [vp, vp, i32, i32, vp],
     "amdseg_pattn_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_pattn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
+    "amdseg_heads_fwd": [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, C.c_long, C.c_long, C.c_long, i32, i32, i32, f32, vp, vp,
+                         C.c_long, C.c_long, i32, i32, f32, f32, f32, vp],
+    "amdseg_heads_bwd_ce": [vp, i32, i32, i32, vp, vp, f32, vp, vp],
+    "amdseg_heads_bwd_rows": [vp, vp, i32, i32, vp, vp, C.c_long, C.c_long, C.c_long, i32, i32, i32, f32, vp, vp, C.c_long, C.c_long, i32, i32,
+                              vp, vp, f32, f32, vp],
     "amdseg_prof_enable": [i32],
     "amdseg_prof_reset": [],
     "amdseg_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],

@@ -391,3 +391,28 @@ def test_real_hf_trainer_train_and_predict(dev, tmp_path):
     assert np.isfinite(logits).all()
     lab = pred.label_ids[0] if isinstance(pred.label_ids, (tuple, list)) else pred.label_ids
     assert lab.shape == (len(samples), 2, 64)
+
+
+@pytest.mark.parametrize("variant", ["train_full", "train_eot_list", "train_wce"])
+def test_fused_heads_equal_torch_heads(dev, variant):
+    """csrc/heads.hip (token CE + CSSL lists + TSSP in a handful of launches) against the torch formulation of the same heads on the same
+    encoder output: loss and every gradient (the reference goldens pin both paths separately; this pins them to each other tightly)"""
+    z, sd, batch, arch = load_case("tiny_L64")
+    res = {}
+    for fused in (True, False):
+        m = build_model(arch, flags_of(z, variant), sd, dev).train()
+        m.config.amdseg_fused_heads = fused
+        m.config.amdseg_precision = "parity"            # fp32-grade encoder: differences below come from the heads alone
+        random.seed(int(z[f"{variant}.random_seed"]))
+        loss, logits, cos = m(**to_dev(batch, dev))
+        loss.backward()
+        res[fused] = (loss.item(), logits.detach().float().cpu().clone(),
+                      {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert abs(res[True][0] - res[False][0]) < 2e-5 * max(1.0, abs(res[False][0]))
+    assert torch.equal(res[True][1], res[False][1])
+    worst = 0.0
+    for n, g in res[False][2].items():
+        d = float((res[True][2][n] - g).norm()) / max(float(g.norm()), 1e-3)
+        worst = max(worst, d)
+        assert d < 1e-4, (n, d)
+    print(variant, "fused vs torch heads: worst relative gradient difference", worst)
