@@ -37,9 +37,16 @@ def shard_indices(n_items, rank, world):
 
 
 class GradBuckets:
-    """contiguous slices of the flat gradient buffer in the order backward produces them."""
+    """contiguous slices of the flat gradient buffer in the order backward produces them: [layer N-1] ... [layer 0] [embeddings + heads].
 
-    def __init__(self, fp):
+    On a GPU every exchange is issued from a SIDE stream: side waits for the main stream (the slice is final), RCCL reduces it, and the
+    slice's sum of squares is accumulated right behind the reduction -- so after the last bucket the global gradient norm needs no
+    extra pass over the 436 MB buffer, and the main stream (the rest of backward) never waits before `wait()`.
+    `bf16_embeddings` (opt-in, AMDSEG_DP_BF16_EMBED=1): the word-embedding gradient -- 94 MB of the fully exposed tail bucket, produced
+    last -- is exchanged in bf16 (cast, all-reduce, cast back: half the bytes on the xGMI links; the sum of W bf16 values carries 8
+    mantissa bits, so this deviates from torch DDP's fp32 exchange and is off by default)."""
+
+    def __init__(self, fp, bf16_embeddings=None):
         names = list(fp.offsets.keys())
         offs = [fp.offsets[n] for n in names] + [fp.numel]
         first_layer = next(i for i, n in enumerate(names) if n.startswith(fp.encoder_prefix))
@@ -52,19 +59,67 @@ class GradBuckets:
         self.rest_slice = (0, offs[first_layer])
         self.flat_g = fp.flat_g
         self.handles = []
+        self.cuda = fp.flat_g.is_cuda
+        self.side = torch.cuda.Stream(device=fp.flat_g.device) if self.cuda else None
+        self.sumsq = torch.zeros(1, device=fp.flat_g.device)
+        self._partials = torch.empty(2048, device=fp.flat_g.device) if self.cuda else None
+        self._covered = 0                      # elements whose squares are in `sumsq` since the last reset
+        if bf16_embeddings is None:
+            bf16_embeddings = os.environ.get("AMDSEG_DP_BF16_EMBED", "0") == "1"
+        self.word_slice = None
+        if bf16_embeddings:
+            wn = next((n for n in names[:first_layer] if n.endswith("word_embeddings.weight")), None)
+            if wn is not None:
+                o = fp.offsets[wn]
+                self.word_slice = (o, o + fp.params[wn].numel())
+                self._word_bf16 = torch.empty(self.word_slice[1] - o, dtype=torch.bfloat16, device=fp.flat_g.device)
+
+    def reset_norm(self):
+        self.sumsq.zero_()
+        self._covered = 0
+
+    def norm_is_complete(self):
+        return self.cuda and self._covered == self.flat_g.numel()
+
+    def _reduce(self, a, b, group, bf16=False):
+        g = self.flat_g[a:b]
+        if not self.cuda:
+            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            return
+        from . import ops
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            if bf16:
+                self._word_bf16.copy_(g)
+                dist.all_reduce(self._word_bf16, op=dist.ReduceOp.SUM, group=group)
+                g.copy_(self._word_bf16)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)          # stream-ordered on `side`
+            ops.sumsq(g, self.sumsq, self._partials, accumulate=True)
+        self._covered += b - a
 
     def reduce_layer(self, li, group=None):
         a, b = self.layer_slices[li]
-        self.handles.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        self._reduce(a, b, group)
 
     def reduce_rest(self, group=None):
         a, b = self.rest_slice
-        self.handles.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        if self.word_slice is None:
+            self._reduce(a, b, group)
+            return
+        wa, wb = self.word_slice
+        self._reduce(wa, wb, group, bf16=True)
+        if wa > a:
+            self._reduce(a, wa, group)
+        if b > wb:
+            self._reduce(wb, b, group)
 
     def wait(self):
         for h in self.handles:
             h.wait()
         self.handles = []
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
 
 
 def allreduce_grads(engine, group=None):

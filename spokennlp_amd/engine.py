@@ -653,11 +653,17 @@ class BertEncoderEngine:
     def zero_grad(self):
         self.fp.flat_g.zero_()
         self.fp.grad_is_zero = True
+        if self.buckets is not None:
+            self.buckets.reset_norm()
 
     def grad_norm_and_clip_coef(self, max_norm, extra_scale=1.0):
         sc = self._scratch
-        ops.sumsq(self.fp.flat_g, sc["sumsq"], sc["partials"])
-        ops.clip_coef(sc["sumsq"], max_norm, extra_scale, sc["coef"], sc["norm"])
+        if self.buckets is not None and self.buckets.norm_is_complete():
+            ssq = self.buckets.sumsq                   # accumulated bucket by bucket right behind each all-reduce (dp.GradBuckets)
+        else:
+            ssq = sc["sumsq"]
+            ops.sumsq(self.fp.flat_g, ssq, sc["partials"])
+        ops.clip_coef(ssq, max_norm, extra_scale, sc["coef"], sc["norm"])
         return sc["norm"], sc["coef"]
 
     def set_param_flags(self, decay_names=None):
@@ -684,6 +690,8 @@ class BertEncoderEngine:
         ops.adamw(self.fp.flat_p, self.fp.flat_g, self.adam_m, self.adam_v, None, lr, betas[0], betas[1], eps, weight_decay,
                   self.opt_step, gscale=coef, zero_grad=zero_grad, chunk_flags=getattr(self, "_chunk_flags", None))
         self.fp.grad_is_zero = bool(zero_grad)
+        if self.buckets is not None:
+            self.buckets.reset_norm()
         self._fused_owner = True
         self.refresh_shadows(force=True)
 

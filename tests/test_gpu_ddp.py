@@ -122,3 +122,17 @@ def test_bench_two_ranks_on_one_gpu(dev):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["final_loss"] == out["final_loss"]
+
+
+def test_rccl_backend_single_rank_bucketed_exchange(dev):
+    """the RCCL (torch.distributed "nccl") backend itself on this box's one GPU: world_size 1 with the per-layer gradient buckets forced
+    on -- 13 asynchronous RCCL all-reduces per step on slices of the flat gradient buffer, launched from inside backward, followed by the
+    fused clip + AdamW (tools/nccl_single_rank_check.py, the multi-rank code path of bench.py; multi-GPU numbers are the driver's to take)"""
+    import subprocess
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_single_rank_check.py")], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("nccl world=1")][-1]
+    ms, loss = float(line.split("buckets:")[1].split("ms/step")[0]), float(line.rsplit("loss", 1)[1])
+    assert 5.0 < ms < 60.0 and loss == loss

@@ -1,6 +1,6 @@
 import os, sys, random, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
 import torch, torch.distributed as dist
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
