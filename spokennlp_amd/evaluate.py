@@ -163,3 +163,49 @@ def compute_metric_example_level(predictions_logits, labels, label_list=("B-EOP"
             soft.append(pred)
         res.update(compute_window_metric(soft, true_bin, prefix="f1@%d_example_level_" % f1_at_k))
     return res
+
+
+# ---------------------------------------------------------------------------------------------------- alimeeting4mug twins
+def compute_window_metric_alimeeting(predictions, references, prefix=""):
+    """alimeeting4mug/metrics/topic_seg_eval/topic_seg_eval.py:170-237 (== src/utils/challenge_evaluate.py:75-134): the emnlp2023 window
+    metric plus the average number of predicted / true boundaries per example; no `pk` / `wd` complements."""
+    base = compute_window_metric(predictions, references, prefix=prefix)
+    n = len(predictions)
+    flat_p, flat_r = sum(predictions, []), sum(references, [])
+    out = {k: base[k] for k in (prefix + "1-pk", prefix + "1-wd", prefix + "precision", prefix + "recall", prefix + "f1")}
+    out[prefix + "avg_pred_cnt"] = round(sum(flat_p) * 1.0 / n, 2)
+    out[prefix + "avg_true_cnt"] = round(sum(flat_r) * 1.0 / n, 2)
+    return out
+
+
+def topic_segment_score(pos_f1, one_minus_pk, one_minus_wd):
+    """challenge_evaluate.py:137-139: the AliMeeting4MUG ranking score"""
+    return 0.5 * pos_f1 + 0.25 * (one_minus_pk + one_minus_wd)
+
+
+def topic_segment_evaluate_samples(label_samples, pred_samples):
+    """challenge_evaluate.py:165-210 on in-memory samples (the reference reads them from the ModelScope dataset / a jsonl file).
+    label sample: {"meeting_key", "sentences", "paragraph_segment_ids": [{"id"}], "topic_segment_ids": [{"id"}]} (1-based sentence ids);
+    pred sample: {"meeting_key", "topic_segment_ids": [{"id"}]}.  Boundaries are scored at paragraph ends only, the last one dropped."""
+    assert len(label_samples) == len(pred_samples), "NUMBER ERROR."
+    total_preds, total_labels, preds_split, labels_split = [], [], [], []
+    for ls, ps in zip(label_samples, pred_samples):
+        assert ls["meeting_key"] == ps["meeting_key"], "meeting_key error."
+        nsent = len(ls["sentences"])
+        para = set(x["id"] for x in ls["paragraph_segment_ids"])
+        preds, labels = [0] * nsent, [0] * nsent
+        for x in ls["topic_segment_ids"]:
+            labels[x["id"] - 1] = 1
+        for x in ps["topic_segment_ids"]:
+            preds[x["id"] - 1] = 1
+        preds[-1] = 1; labels[-1] = 1
+        labels = [v for i, v in enumerate(labels) if (i + 1) in para]
+        preds = [v for i, v in enumerate(preds) if (i + 1) in para]
+        total_labels.extend(labels[:-1]); total_preds.extend(preds[:-1])
+        labels_split.append(labels[:-1]); preds_split.append(preds[:-1])
+    _, _, pos_f1 = binary_prf(total_labels, total_preds)
+    ws = compute_window_metric_alimeeting(preds_split, labels_split, prefix="test_")
+    out = {"score": topic_segment_score(pos_f1, ws["test_1-pk"], ws["test_1-wd"])}
+    ws.pop("test_avg_pred_cnt"); ws.pop("test_avg_true_cnt")
+    out.update(ws)
+    return out

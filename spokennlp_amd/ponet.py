@@ -76,6 +76,8 @@ class PoNetModel(nn.Module):
         self.embeddings.position_embeddings = nn.Embedding(cfg.max_position_embeddings, H)
         self.embeddings.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, H)
         self.embeddings.LayerNorm = nn.LayerNorm(H, eps=cfg.layer_norm_eps)
+        # the reference driver rewrites this buffer when it extends the position table (ponet_topic_segmentation.py:482)
+        self.embeddings.register_buffer("position_ids", torch.arange(cfg.max_position_embeddings).expand((1, -1)), persistent=False)
         self.encoder = _Named()
         self.encoder.layer = nn.ModuleList([_layer(cfg) for _ in range(cfg.num_hidden_layers)])
 
@@ -264,6 +266,65 @@ class PoNetForTokenClassification(PreTrainedModel):
         if self._engine is None or not self._engine.fp.intact() or self._engine.device != p.device:
             self._engine = PoNetEncoderEngine(self, self.config, p.device, bert_attr="ponet")
         return self._engine
+
+    def no_sync(self):
+        return self.engine().no_sync()
+
+    # ---- the ModelScope-flavoured surface the reference driver / MyTrainer use (modeling_ponet.py:111-119, trainer.py:33-60,
+    #      ponet_topic_segmentation.py:416-418): `from_pretrained(model_name_or_path=..., task=..., revision=...)`, `model.model_dir`,
+    #      `save_pretrained(output_dir, state_dict)`.  Hub download is ModelScope's (no network here): a LOCAL directory is required.
+    model_dir = None
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, *args, model_name_or_path=None, task=None, revision=None, **kwargs):
+        path = pretrained_model_name_or_path if pretrained_model_name_or_path is not None else model_name_or_path
+        if path is None:
+            raise L.AmdsegError("from_pretrained needs a local checkpoint directory (model_name_or_path=...)")
+        import os
+        if not os.path.isdir(path):
+            raise L.AmdsegError(f"{path!r} is not a local directory: ModelScope hub ids (e.g. damo/nlp_ponet_fill-mask_chinese-base) must be "
+                                f"downloaded first, this build has no hub client")
+        wfile = os.path.join(path, "pytorch_model.bin")
+        if os.path.isfile(wfile) and not os.path.isfile(os.path.join(path, "model.safetensors")):
+            # what `save_pretrained(output_dir, state_dict)` below (== the reference's) writes: a bare torch.save of the state dict
+            cfg = kwargs.pop("config", None) or cls.config_class.from_pretrained(path)
+            m = cls(cfg)
+            sd = torch.load(wfile, map_location="cpu")
+            missing, unexpected = m.load_state_dict(sd, strict=False)
+            bad = [k for k in unexpected if "pooler" not in k and "position_ids" not in k]
+            if bad:
+                raise L.AmdsegError(f"unexpected keys in {wfile}: {bad[:5]}")
+        else:
+            m = super().from_pretrained(path, *args, **kwargs)
+        m.model_dir = path
+        return m
+
+    def save_pretrained(self, output_dir, state_dict=None, **kwargs):
+        import os
+        import shutil
+        if state_dict is None and kwargs:
+            return super().save_pretrained(output_dir, **kwargs)          # plain HF call
+        os.makedirs(output_dir, exist_ok=True)
+        torch.save(state_dict if state_dict is not None else self.state_dict(), os.path.join(output_dir, "pytorch_model.bin"))
+        self.config.to_json_file(os.path.join(output_dir, "config.json"))
+        if self.model_dir and os.path.isfile(os.path.join(self.model_dir, "configuration.json")):      # ModelFile.CONFIGURATION
+            shutil.copy(os.path.join(self.model_dir, "configuration.json"), os.path.join(output_dir, "configuration.json"))
+
+    def extend_position_embeddings(self, max_pos):
+        """ponet_topic_segmentation.py:466-482: tile the trained position table up to `max_pos` rows (512 -> 4096 in the script)"""
+        w = self.ponet.embeddings.position_embeddings.weight
+        cur, E = w.shape
+        if max_pos <= cur:
+            return
+        new = w.new_empty(max_pos, E)
+        k = 0
+        while k < max_pos - 1:
+            n = min(cur, max_pos - k)
+            new[k:k + n] = w.data[:n]
+            k += cur
+        w.data = new
+        self.ponet.embeddings.position_ids = torch.arange(max_pos, device=w.device).reshape(1, max_pos)
+        self.config.max_position_embeddings = max_pos
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, segment_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, labels=None, output_attentions=None, output_hidden_states=None, return_dict=None):

@@ -68,3 +68,51 @@ def test_example_level_metrics():
     lg = [[[0.0, 3.0], [3.0, 0.0], [0.0, 3.0], [3.0, 0.0]]]
     r4 = E.compute_metric_example_level(lg, [[0, 1, 1, 0]], threshold=0.5, f1_at_k=1)
     assert r4["f1@1_example_level_f1"] == 1.0 and r4["threshold_0.5_example_level_f1"] == 0.5
+
+
+def test_pk_windowdiff_hand_worked_cases():
+    """Pk (Beeferman et al. 1999) and WindowDiff (Pevzner & Hearst 2002) on cases small enough to enumerate by hand from the papers'
+    definitions -- independent of the implementation, NOT outputs of segeval (absent here; parity with it stays unpinned):
+      reference AABBB (masses 2,3), hypothesis AAABB (3,2): mean reference mass 2.5 -> k = max(2, round(1.25)) = 2, probes (0,2) (1,3) (2,4).
+        same-segment?  ref: no, no, yes   hyp: yes, no, no   -> disagreements on probes 1 and 3 -> Pk = 2/3
+        boundaries in the window: ref 1,1,0   hyp 0,1,1      -> differ on windows 1 and 3     -> WD = 2/3
+      a near miss is penalised less than a miss by WindowDiff only through the window count: reference 4,4 vs hypothesis 8 (no boundary):
+        k = 2, 6 probes; the reference boundary (between units 3|4) lies inside probes (2,4) and (3,5): Pk = WD = 2/6
+      identical segmentations score 0; the all-boundaries hypothesis 1,1,1,1,1,1 against reference 3,3: k = 2 (round-half-even of 1.5),
+        4 probes; every hypothesis probe spans boundaries (never "same"), the reference is "same" only on probe (0,2)... enumerated below."""
+    from spokennlp_amd import evaluate as E
+    assert E.window_size([2, 3]) == 2 and E.window_size([4, 4]) == 2 and E.window_size([3, 3]) == 2 and E.window_size([10, 10]) == 5
+    assert E.window_size([5]) == 2            # round-half-even(2.5) = 2
+    assert abs(E.pk([3, 2], [2, 3]) - 2 / 3) < 1e-12 and abs(E.window_diff([3, 2], [2, 3]) - 2 / 3) < 1e-12
+    assert abs(E.pk([8], [4, 4]) - 2 / 6) < 1e-12 and abs(E.window_diff([8], [4, 4]) - 2 / 6) < 1e-12
+    assert E.pk([4, 4], [4, 4]) == 0.0 and E.window_diff([4, 4], [4, 4]) == 0.0
+    # reference 3,3 = AAABBB, hypothesis all boundaries; probes (0,2) (1,3) (2,4) (3,5):
+    #   ref same? yes, no, no, yes ; hyp same? never -> Pk = 2/4.  boundaries in window: ref 0,1,1,0 ; hyp 2,2,2,2 -> WD = 4/4
+    assert abs(E.pk([1] * 6, [3, 3]) - 0.5) < 1e-12 and abs(E.window_diff([1] * 6, [3, 3]) - 1.0) < 1e-12
+    # WindowDiff >= Pk always (a window with a different boundary count is the only way "same segment?" can differ)
+    import random
+    rng = random.Random(0)
+    for _ in range(200):
+        n = rng.randrange(6, 40)
+        def masses():
+            cuts = sorted(rng.sample(range(1, n), rng.randrange(0, min(6, n - 1))))
+            return [b - a for a, b in zip([0] + cuts, cuts + [n])]
+        h, r = masses(), masses()
+        assert E.window_diff(h, r) >= E.pk(h, r) - 1e-12
+
+
+def test_alimeeting_challenge_scoring():
+    """challenge_evaluate.py:137-210 on two in-memory meetings: boundaries are read at paragraph ends only, the final one is dropped"""
+    from spokennlp_amd import evaluate as E
+    lab = [dict(meeting_key="m1", sentences=list("abcdefgh"), paragraph_segment_ids=[dict(id=i) for i in (2, 4, 6, 8)],
+                topic_segment_ids=[dict(id=4), dict(id=8)]),
+           dict(meeting_key="m2", sentences=list("abcdef"), paragraph_segment_ids=[dict(id=i) for i in (1, 3, 5, 6)],
+                topic_segment_ids=[dict(id=3), dict(id=6)])]
+    pred = [dict(meeting_key="m1", topic_segment_ids=[dict(id=4)]), dict(meeting_key="m2", topic_segment_ids=[dict(id=5)])]
+    out = E.topic_segment_evaluate_samples(lab, pred)
+    # m1: paragraph-end labels [0,1,0|1] -> scored [0,1,0], preds [0,1,0]; m2: labels [0,1,0|1] -> [0,1,0], preds [0,0,1]
+    assert out["test_precision"] == 0.5 and out["test_recall"] == 0.5 and out["test_f1"] == 0.5
+    m1 = E.compute_window_metric_alimeeting([[0, 1, 0]], [[0, 1, 0]], "x_")
+    assert m1["x_1-pk"] == 1.0 and m1["x_avg_pred_cnt"] == 1.0
+    assert abs(out["score"] - E.topic_segment_score(0.5, out["test_1-pk"], out["test_1-wd"])) < 1e-12
+    assert 0.0 <= out["test_1-pk"] <= 1.0

@@ -362,3 +362,54 @@ def test_unaligned_shapes_vs_oracle(dev):
             continue
         c = torch.nn.functional.cosine_similarity(p.grad.float().cpu().flatten(), go.flatten(), dim=0).item()
         assert c > 0.98, (n, c)
+
+
+def test_modelscope_style_surface_and_position_table_extension(dev, tmp_path):
+    """the calls the reference driver / MyTrainer make on the model object (ponet_topic_segmentation.py:416-418,466-482,
+    trainer.py:33-60, modeling_ponet.py:111-119): from_pretrained(model_name_or_path=, task=, revision=) on a local directory,
+    model.model_dir, save_pretrained(output_dir, state_dict), and the IN-PLACE position-table extension done with the reference's own
+    statements AFTER the engine exists (`weight.data = new` must be noticed: the engine re-homes the parameters)"""
+    from oracle import ponet_oracle as PO
+    from oracle import bert_ts_oracle as O
+    from spokennlp_amd.ponet import PoNetForTokenClassification
+    arch = dict(ARCH, max_position_embeddings=64)
+    m, cfg = build(dev)
+    cfg.max_position_embeddings = 64
+    torch.manual_seed(0)
+    m = PoNetForTokenClassification(cfg)
+    d0 = tmp_path / "ckpt0"
+    m.save_pretrained(str(d0), state_dict=m.state_dict())
+    assert (d0 / "pytorch_model.bin").exists() and (d0 / "config.json").exists()
+    m = PoNetForTokenClassification.from_pretrained(model_name_or_path=str(d0), task="fill-mask", revision="v1.1.0")
+    assert m.model_dir == str(d0)
+    m = m.to(dev).eval()
+    ids, am, seg, lab = make_inputs(2, 64, 5)
+    with torch.no_grad():
+        m(input_ids=ids.to(dev), attention_mask=am.to(dev), segment_ids=seg.to(dev))        # engine built at 64 positions
+    eng0 = m.engine()
+    # ---- the reference's statements, verbatim in structure (:471-482)
+    max_pos = 256
+    current_max_pos, embed_size = m.ponet.embeddings.position_embeddings.weight.shape
+    new_pos_embed = m.ponet.embeddings.position_embeddings.weight.new_empty(max_pos, embed_size)
+    k, step = 0, current_max_pos
+    while k < max_pos - 1:
+        new_pos_embed[k:(k + step)] = m.ponet.embeddings.position_embeddings.weight[:]
+        k += step
+    m.ponet.embeddings.position_embeddings.weight.data = new_pos_embed
+    m.ponet.embeddings.position_ids.data = torch.tensor([i for i in range(max_pos)]).reshape(1, max_pos)
+    m.config.max_position_embeddings = max_pos
+    ids, am, seg, lab = make_inputs(2, 256, 6, long_run=True)
+    with torch.no_grad():
+        lg = m(input_ids=ids.to(dev), attention_mask=am.to(dev), segment_ids=seg.to(dev), return_dict=True).logits.float().cpu()
+    assert m.engine() is not eng0
+    sd = {k2: v.detach().float().cpu() for k2, v in m.state_dict().items()}
+    assert sd["ponet.embeddings.position_embeddings.weight"].shape[0] == 256
+    ocfg = O.make_cfg(num_labels=2, **dict(arch, max_position_embeddings=256))
+    with torch.no_grad():
+        _, lo = PO.token_classification_forward(sd, ocfg, ids, am, torch.zeros_like(ids), seg, None)
+    valid = am == 1
+    assert (lg - lo).abs()[valid].max().item() < 0.02 * lo.abs().max().item() + 0.05
+    # the helper does the same tiling
+    m2 = PoNetForTokenClassification.from_pretrained(model_name_or_path=str(d0))
+    m2.extend_position_embeddings(256)
+    assert torch.equal(m2.ponet.embeddings.position_embeddings.weight.data, sd["ponet.embeddings.position_embeddings.weight"])
