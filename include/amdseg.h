@@ -229,14 +229,15 @@ int amdseg_pattn_bwd(const float* qkv, const float* mask_bias, const float* ctx,
  * utils.py:141-182 weighted CE, ignore_index -100; `nseg` equal row segments = anchor half | augmented half, one mean each), CSSL InfoNCE in
  * list form (cssl.py:82-116: anchors x (pk positive + negative) lists of row indices) and TSSP Linear(H, Ct) + CE (tssp.py:16-36).
  *   out8:  [0..1] CE per segment, [2] CSSL, [3] TSSP, [4] total = w_ts * (CE_0 + CE_1) + w_cl * CSSL + w_tssp2 * TSSP, [5..6] 1 / sum of CE
- *          weights per segment (read by backward);  ce_unit [M,C] and acc4 [4] are caller-owned scratch.
+ *          weights per segment (read by backward);  ce_unit [M,C] and acc [16 * ceil(M / 256) + n_anchor + nt] are caller-owned scratch
+ *          (per-wave CE partials and per-row loss terms, summed in a fixed order: the loss is bit-reproducible).
  *   idx:   ONE int64 device buffer holding every index list of the step (built on the host with the reference's `random` call order);
  *          feat_off -> seq row of feature f; anchor_off -> feature index of anchor i (-1: anchor i = feature i); lists_off ->
  *          [n_list][n_anchor] feature indices (the first pk lists are the positives); t_rows_off / t_labels_off -> TSSP rows / classes.
  * Backward: amdseg_heads_bwd_ce writes dlogits [M,C] = d total / d logits * gout[0]; the caller runs amdseg_rowdot_bwd on it (which WRITES
  * dx [M,H]); amdseg_heads_bwd_rows then ADDS the CSSL / TSSP row gradients into dx and ACCUMULATES dWt [Ct,H], dbt [Ct]. */
 int amdseg_heads_fwd(const float* x, int M, int H, const float* logits, const int64_t* labels, const float* class_w, int C, int nseg,
-                     float* ce_unit, float* out8, float* acc4, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
+                     float* ce_unit, float* out8, float* acc, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
                      int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off, long t_labels_off,
                      int nt, int Ct, float w_ts, float w_cl, float w_tssp2, amdseg_stream_t stream);
 int amdseg_heads_bwd_ce(const float* gout, int M, int C, int nseg, const float* ce_unit, const float* out8, float w_ts, float* dlogits,
@@ -244,6 +245,11 @@ int amdseg_heads_bwd_ce(const float* gout, int M, int C, int nseg, const float* 
 int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float* dx, const int64_t* idx, long feat_off, long anchor_off,
                           long lists_off, int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
                           long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, amdseg_stream_t stream);
+
+/* NOTE on additive key masks (`mask_bias` of every attention entry point): 0 for visible keys, a MODERATE negative number for masked ones
+ * (the host mirror uses -30000; the kernels fold mask and log-sum-exp into the fp32 MFMA accumulator start, so a magnitude like 1e30
+ * would cost all fp32 digits of (mask - lse) in rows whose visible keys are all masked).  exp() of a masked score is an exact 0 next to
+ * any real score either way, which is what the reference's finfo.min mask yields. */
 
 /* ---- measurement plumbing (csrc/prof.h, prof.hip): in-kernel begin/end stamps of the device wall clock for the dominant kernels,
  * taken INSIDE real training steps.  enable(1) allocates + arms the slots (returns the previous state, < 0 on failure); read() syncs

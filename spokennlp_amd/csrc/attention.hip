@@ -266,13 +266,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     const float lsum = xor_reduce_sum_g(l_part);
     float inv = (a.thresh16 ? a.inv_keep : 1.0f) / lsum;
     float lse_q = (m_run + __builtin_amdgcn_logf(lsum)) * LN2;          // natural-log LSE, as backward expects
-    if ((BAND || LIST) && a.mask_bias[tok0 + q] < 0.f) { inv = 0.f; lse_q = INFINITY; }   // padded query: zero row (Longformer :579, BigBird context_layer * from_mask), p == 0 in backward
+    const bool padq = (BAND || LIST) && a.mask_bias[tok0 + q] < 0.f;   // padded query: zero row (Longformer :579, BigBird context_layer * from_mask), p == 0 in backward
+    if (padq) { inv = 0.f; lse_q = INFINITY; }
     bf16_t* op = a.ctx + (tok0 + q) * H + h * HD;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         uint2 pk;
-        pk.x = pack2bf(o[d][0] * inv, o[d][1] * inv);
-        pk.y = pack2bf(o[d][2] * inv, o[d][3] * inv);
+        pk.x = padq ? 0u : pack2bf(o[d][0] * inv, o[d][1] * inv);
+        pk.y = padq ? 0u : pack2bf(o[d][2] * inv, o[d][3] * inv);
         *reinterpret_cast<uint2*>(op + d * 16 + g * 4) = pk;
     }
     if (a.lse && g == 0) a.lse[prow] = lse_q;

@@ -27,11 +27,13 @@ struct HeadsArgs {
     float w_ts, w_cl, w_tssp2;
     // backward
     const float* gout; float* dx; float* dWt; float* dbt; float* dlogits;
+    float* row_loss;       // forward scratch: per-anchor CSSL terms [n_anchor] followed by per-row TSSP terms [nt]
 };
 
 // ---------------------------------------------------------------------------------------------------- token cross-entropy
-// one thread per row; per-segment (num, den) accumulated with one atomicAdd pair per wave
-__global__ __launch_bounds__(256) void heads_ce_fwd_kernel(HeadsArgs a, float* acc) {      // acc[seg*2 + {0: sum w nll, 1: sum w}]
+// one thread per row; per-wave (num, den) partials per segment, summed in a fixed order by the finalize kernel (no atomics: the loss
+// is bit-reproducible run to run)
+__global__ __launch_bounds__(256) void heads_ce_fwd_kernel(HeadsArgs a, float* acc) {      // acc[wave][seg*2 + {0: sum w nll, 1: sum w}]
     const int i = blockIdx.x * 256 + threadIdx.x;
     float num = 0.f, den = 0.f;
     int seg = 0;
@@ -60,7 +62,10 @@ __global__ __launch_bounds__(256) void heads_ce_fwd_kernel(HeadsArgs a, float* a
     for (int sg = 0; sg < HEADS_MAXSEG; ++sg) {
         if (sg >= a.nseg) break;
         const float n1 = wave_sum(seg == sg ? num : 0.f), d1 = wave_sum(seg == sg ? den : 0.f);
-        if ((threadIdx.x & 63) == 0 && d1 != 0.f) { atomicAdd(acc + sg * 2, n1); atomicAdd(acc + sg * 2 + 1, d1); }
+        if ((threadIdx.x & 63) == 0) {
+            float* slot = acc + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sg * 2;
+            slot[0] = n1; slot[1] = d1;
+        }
     }
 }
 
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void heads_cssl_kernel(HeadsArgs a) {
         if (k < a.pk) spos += e[k];
     }
     if (!BWD) {
-        if (l == 0) atomicAdd(a.out + 2, -logf(spos / sall) / (float)a.n_anchor);
+        if (l == 0) a.row_loss[i] = -logf(spos / sall);
         return;
     }
     // d loss_i / d cos_k = inv_temp * (e_k / sall - [k < pk] e_k / spos) / n ; chain through the cosine into both rows
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void heads_tssp_kernel(HeadsArgs a) {
         float ly = 0.f;
 #pragma unroll
         for (int c = 0; c < HEADS_MAXC; ++c) if (c < a.Ct && c == y) ly = lg[c];
-        if (l == 0) atomicAdd(a.out + 3, (lse - ly) / (float)a.nt);
+        if (l == 0) a.row_loss[a.n_anchor + i] = lse - ly;
         return;
     }
     const float g = a.gout[0] * a.w_tssp2 / (float)a.nt;
@@ -170,11 +175,31 @@ __global__ __launch_bounds__(256) void heads_tssp_kernel(HeadsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------- combine / CE backward
-__global__ void heads_finalize_kernel(HeadsArgs a, const float* acc) {
+// block-wide sum in a fixed order: thread t adds elements t, t + 256, ...; then the wave / LDS tree
+__device__ __forceinline__ float block_sum_fixed(const float* p, int n, int stride, float* red) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += p[(size_t)i * stride];
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void heads_finalize_kernel(HeadsArgs a, const float* acc, int nwaves) {
+    __shared__ float red[4];
     float tot = 0.f;
+    const float cssl = a.n_anchor > 0 ? block_sum_fixed(a.row_loss, a.n_anchor, 1, red) / (float)a.n_anchor : 0.f;
+    const float tssp = a.nt > 0 ? block_sum_fixed(a.row_loss + a.n_anchor, a.nt, 1, red) / (float)a.nt : 0.f;
+    float num[HEADS_MAXSEG], dens[HEADS_MAXSEG];
     for (int sg = 0; sg < a.nseg; ++sg) {
-        const float den = acc[sg * 2 + 1];
-        const float ce = den != 0.f ? acc[sg * 2] / den : 0.f / 0.f;     // torch: mean over an empty set = nan
+        num[sg] = block_sum_fixed(acc + sg * 2, nwaves, 4, red);
+        dens[sg] = block_sum_fixed(acc + sg * 2 + 1, nwaves, 4, red);
+    }
+    if (threadIdx.x != 0) return;
+    a.out[2] = cssl; a.out[3] = tssp;
+    for (int sg = 0; sg < a.nseg; ++sg) {
+        const float den = dens[sg];
+        const float ce = den != 0.f ? num[sg] / den : 0.f / 0.f;     // torch: mean over an empty set = nan
         a.out[sg] = ce;
         a.out[5 + sg] = den != 0.f ? 1.0f / den : 0.f;
         tot += a.w_ts * ce;
@@ -217,21 +242,21 @@ static HeadsArgs heads_fill(const float* x, int M, int H, const float* logits, c
 }
 
 int amdseg_heads_fwd_impl(const float* x, int M, int H, const float* logits, const int64_t* labels, const float* class_w, int C, int nseg,
-                          float* ce_unit, float* out8, float* acc4, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
+                          float* ce_unit, float* out8, float* acc, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
                           int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
                           long t_labels_off, int nt, int Ct, float w_ts, float w_cl, float w_tssp2, hipStream_t s) {
     HeadsArgs a = heads_fill(x, M, H, logits, labels, class_w, C, nseg, ce_unit, out8, idx, feat_off, anchor_off, lists_off, n_anchor, n_list,
                              pk, temp, Wt, bt, t_rows_off, t_labels_off, nt, Ct, w_ts, w_cl, w_tssp2);
-    if (!acc4) return AMDSEG_ERR_ARG;
+    if (!acc) return AMDSEG_ERR_ARG;
     int rc = heads_check(a);
     if (rc) return rc;
-    hipError_t e = hipMemsetAsync(out8, 0, 8 * sizeof(float), s);
-    if (e == hipSuccess) e = hipMemsetAsync(acc4, 0, 4 * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(heads_ce_fwd_kernel, dim3((M + 255) / 256), dim3(256), 0, s, a, acc4);
+    // acc: [4 * ceil(M / 256)][4] per-wave CE partials, then n_anchor + nt per-row loss terms (amdseg.h: amdseg_heads_acc_floats)
+    const int blocks = (M + 255) / 256, nwaves = blocks * 4;
+    a.row_loss = acc + (size_t)nwaves * 4;
+    hipLaunchKernelGGL(heads_ce_fwd_kernel, dim3(blocks), dim3(256), 0, s, a, acc);
     if (n_anchor > 0) hipLaunchKernelGGL(heads_cssl_kernel<false>, dim3((n_anchor + 3) / 4), dim3(256), 0, s, a);
     if (nt > 0) hipLaunchKernelGGL(heads_tssp_kernel<false>, dim3((nt + 3) / 4), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(heads_finalize_kernel, dim3(1), dim3(1), 0, s, a, (const float*)acc4);
+    hipLaunchKernelGGL(heads_finalize_kernel, dim3(1), dim3(256), 0, s, a, (const float*)acc, nwaves);
     return amdseg_launch_status();
 }
 

@@ -27,6 +27,9 @@ LAYER_ORDER = ["attention.self.query.weight", "attention.self.key.weight", "atte
                "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias"]
 
 
+MASK_BIAS = -30000.0
+
+
 def _align(n, a=64):
     return (n + a - 1) // a * a
 
@@ -502,7 +505,11 @@ class BertEncoderEngine:
         lparams = self.lparams_parity if fp32 == "parity" else (self.lparams32 if fp32 else self.lparams)
         ids = input_ids.reshape(-1).contiguous()
         tts = token_type_ids.reshape(-1).contiguous()
-        torch.mul(1.0 - attention_mask.to(torch.float32), -1e30, out=A["mask_bias"])
+        # additive key mask: 0 / MASK_BIAS.  A moderate magnitude on purpose: exp() of a masked score underflows to an exact 0 next to any
+        # real score (as the reference's finfo.min does), while (mask - lse) and (score - max) keep their fp32 digits in rows whose
+        # visible keys are ALL masked (padded queries of a band, fully padded sequences) -- with -1e30 those differences carry an
+        # absolute error of ~1e23 and exp2 of them is inf (attention.hip folds mask and lse into the MFMA accumulator start)
+        torch.mul(1.0 - attention_mask.to(torch.float32), MASK_BIAS, out=A["mask_bias"])
         lib = L.load()
         s = torch.cuda.current_stream().cuda_stream
         eps = float(self.cfg.layer_norm_eps)
@@ -804,7 +811,7 @@ class FusedHeadsFn(torch.autograd.Function):
         logits = ops.rowdot_fwd(x, Wc, bc)
         dev = x.device
         out8 = torch.empty(8, dtype=torch.float32, device=dev)
-        acc4 = torch.empty(4, dtype=torch.float32, device=dev)
+        acc4 = torch.empty(16 * ((M + 255) // 256) + plan["n_anchor"] + plan["nt"] + 8, dtype=torch.float32, device=dev)
         unit = torch.empty(M, C_, dtype=torch.float32, device=dev)
         s = torch.cuda.current_stream().cuda_stream
         P = plan

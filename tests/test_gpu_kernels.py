@@ -242,7 +242,7 @@ def make_qkv(dev, B, L, heads, seed, pad=True):
         for b in range(B):
             n = L - (b * 37) % (L // 2)
             mask[b, n:] = 0
-    mask_bias = ((1.0 - mask) * -1e30).to(dev)
+    mask_bias = ((1.0 - mask) * -30000.0).to(dev)
     return qkv, mask_bias
 
 

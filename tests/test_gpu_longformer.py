@@ -42,7 +42,7 @@ def test_band_attention_fwd_bwd(dev, B, L, heads, w, G):
     H = heads * 64
     qkv = torch.randn(B * L, 3 * H, device=dev).bfloat16()
     mask = torch.zeros(B, L, device=dev)
-    mask[0, L - 37:] = -1e30                                   # padded tail in the first sequence
+    mask[0, L - 37:] = -30000.0                                   # padded tail in the first sequence
     dctx = (torch.randn(B * L, H, device=dev) * 0.5).bfloat16()
     ctx, lse = ops.attn_band_fwd(qkv, mask, B, L, heads, w, G)
     dqkv = ops.attn_band_bwd(qkv, mask, ctx, dctx, lse, B, L, heads, w, G)
@@ -74,7 +74,7 @@ def test_global_row_kernels(dev, dt):
     B, L, H, heads = 2, 192, 256, 4
     x = torch.randn(B * L, H, device=dev).to(dt)
     vec = torch.randn(B, heads, H, device=dev) * 0.1
-    addt = torch.zeros(B, L, device=dev); addt[1, 150:] = -1e30
+    addt = torch.zeros(B, L, device=dev); addt[1, 150:] = -30000.0
     addb = torch.randn(B, heads, device=dev)
     xf = x.float().view(B, L, H)
     out = ops.lf_rowvec_dot(x, vec, B, L, add_tok=addt, add_bh=addb)
