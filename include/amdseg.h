@@ -225,6 +225,23 @@ int amdseg_pattn_fwd(const float* qkv, const float* mask_bias, float* ctx, float
 int amdseg_pattn_bwd(const float* qkv, const float* mask_bias, const float* ctx, const float* dctx, const float* lse, float* delta,
                      float* dqkv, int B, int L, int heads, float scale, float p_drop, uint64_t seed, amdseg_stream_t stream);
 
+/* ---- Longformer global [CLS] row, the O(heads * H^2) algebra around the O(L) passes above (csrc/lf_global.hip; [hf]
+ * models/longformer/modeling_longformer.py:964-1058 with the key / value projections folded onto the query side):
+ *   q:    qg [B,heads,64] = (Wq x0 + bq) * scale,  r [B,heads,H] = Wk_h^T qg_h          (x0 = row b*L of x, dtype x_dtype)
+ *   out:  ctx[b*L, h*64 + e] = Wv_h y_h + bv_h * sp                                      (y, sp from amdseg_lf_wsum / lf_softmax_fwd)
+ *   bwd_a: dout = dctx[b*L] (then zeroed), dyv = Wv_h^T dout_h, dsp = bv_h . dout_h
+ *   bwd_rest: dqg = Wk_h dr_h * scale;  dWv += dout (x) y, dbv += dout * sp, dWk += qg (x) dr;  dWq += dqg (x) x0, dbq += dqg;
+ *             dx[b*L] += Wq^T dqg      (weight gradients ACCUMULATE into the caller's flat gradient views) */
+int amdseg_lf_global_q(const void* x, int x_dtype, const float* Wq, const float* bq, const float* Wk, float* qg, float* r, int B, int L, int H,
+                       int heads, float scale, amdseg_stream_t stream);
+int amdseg_lf_global_out(const float* Wv, const float* bv, const float* y, const float* sp, void* ctx, int ctx_dtype, int B, int L, int H,
+                         int heads, amdseg_stream_t stream);
+int amdseg_lf_global_bwd_a(void* dctx, int dtype, const float* Wv, const float* bv, float* dout, float* dyv, float* dsp, int B, int L, int H,
+                           int heads, amdseg_stream_t stream);
+int amdseg_lf_global_bwd_rest(const void* x, int x_dtype, void* dx, int dx_dtype, const float* Wq, const float* Wk, const float* qg,
+                              const float* dout, const float* y, const float* sp, const float* dr, float* dqg, float* dWq, float* dbq,
+                              float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads, float scale, amdseg_stream_t stream);
+
 /* ---- fused loss heads of the training step (csrc/heads.hip): token cross-entropy over the classifier logits (loss_calculator.py:25-57,
  * utils.py:141-182 weighted CE, ignore_index -100; `nseg` equal row segments = anchor half | augmented half, one mean each), CSSL InfoNCE in
  * list form (cssl.py:82-116: anchors x (pk positive + negative) lists of row indices) and TSSP Linear(H, Ct) + CE (tssp.py:16-36).

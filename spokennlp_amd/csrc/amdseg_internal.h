@@ -114,3 +114,14 @@ int amdseg_heads_bwd_ce_impl(const float* gout, int M, int C, int nseg, const fl
 int amdseg_heads_bwd_rows_impl(const float* gout, const float* x, int M, int H, float* dx, const int64_t* idx, long feat_off, long anchor_off,
                                long lists_off, int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
                                long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, hipStream_t s);
+
+// lf_global.hip
+int amdseg_lf_global_q_impl(const void* x, int x_dtype, const float* Wq, const float* bq, const float* Wk, float* qg, float* r, int B, int L,
+                            int H, int heads, float scale, hipStream_t s);
+int amdseg_lf_global_out_impl(const float* Wv, const float* bv, const float* y, const float* sp, void* ctx, int ctx_dtype, int B, int L, int H,
+                              int heads, hipStream_t s);
+int amdseg_lf_global_bwd_a_impl(void* dctx, int dtype, const float* Wv, const float* bv, float* dout, float* dyv, float* dsp, int B, int L,
+                                int H, int heads, hipStream_t s);
+int amdseg_lf_global_bwd_rest_impl(const void* x, int x_dtype, void* dx, int dx_dtype, const float* Wq, const float* Wk, const float* qg,
+                                   const float* dout, const float* y, const float* sp, const float* dr, float* dqg, float* dWq, float* dbq,
+                                   float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads, float scale, hipStream_t s);

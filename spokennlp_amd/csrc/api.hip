@@ -205,6 +205,24 @@ int amdseg_pattn_bwd(const float* qkv, const float* mask_bias, const float* ctx,
     return amdseg_pattn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta, dqkv, B, L, heads, scale, p_drop, seed, S(stream));
 }
 
+int amdseg_lf_global_q(const void* x, int x_dtype, const float* Wq, const float* bq, const float* Wk, float* qg, float* r, int B, int L, int H,
+                       int heads, float scale, amdseg_stream_t stream) {
+    return amdseg_lf_global_q_impl(x, x_dtype, Wq, bq, Wk, qg, r, B, L, H, heads, scale, S(stream));
+}
+int amdseg_lf_global_out(const float* Wv, const float* bv, const float* y, const float* sp, void* ctx, int ctx_dtype, int B, int L, int H,
+                         int heads, amdseg_stream_t stream) {
+    return amdseg_lf_global_out_impl(Wv, bv, y, sp, ctx, ctx_dtype, B, L, H, heads, S(stream));
+}
+int amdseg_lf_global_bwd_a(void* dctx, int dtype, const float* Wv, const float* bv, float* dout, float* dyv, float* dsp, int B, int L, int H,
+                           int heads, amdseg_stream_t stream) {
+    return amdseg_lf_global_bwd_a_impl(dctx, dtype, Wv, bv, dout, dyv, dsp, B, L, H, heads, S(stream));
+}
+int amdseg_lf_global_bwd_rest(const void* x, int x_dtype, void* dx, int dx_dtype, const float* Wq, const float* Wk, const float* qg,
+                              const float* dout, const float* y, const float* sp, const float* dr, float* dqg, float* dWq, float* dbq,
+                              float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads, float scale, amdseg_stream_t stream) {
+    return amdseg_lf_global_bwd_rest_impl(x, x_dtype, dx, dx_dtype, Wq, Wk, qg, dout, y, sp, dr, dqg, dWq, dbq, dWk, dWv, dbv, B, L, H, heads,
+                                          scale, S(stream));
+}
 int amdseg_heads_fwd(const float* x, int M, int H, const float* logits, const int64_t* labels, const float* class_w, int C, int nseg,
                      float* ce_unit, float* out8, float* acc, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
                      int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off, long t_labels_off,

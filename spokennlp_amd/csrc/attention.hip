@@ -687,6 +687,12 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
     // algorithmic FLOPs: QK^T + PV over the visible keys (full: L, band: 2W + 1 + G)
     const double span = window > 0 ? (double)(2 * window + 1 + a.nglobal) : (double)L;
     const double work = 4.0 * B * heads * (double)L * span * HD;
+    static int nw4 = -1;
+    if (nw4 < 0) { const char* e = getenv("AMDSEG_ATTN_NW4"); nw4 = e ? atoi(e) : 0; }
+    if (nw4 && window == 0) {
+        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        return amdseg_launch_status();
+    }
     if (window > 0) {
         if (L % 128 == 0) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<8, true>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
         else AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);

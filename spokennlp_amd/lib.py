@@ -86,6 +86,10 @@ _PROTOS = {
     "amdseg_split3_transpose": [vp, vp, i32, i32, vp],
     "amdseg_pattn_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_pattn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
+    "amdseg_lf_global_q": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "amdseg_lf_global_out": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "amdseg_lf_global_bwd_a": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "amdseg_lf_global_bwd_rest": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "amdseg_heads_fwd": [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, C.c_long, C.c_long, C.c_long, i32, i32, i32, f32, vp, vp,
                          C.c_long, C.c_long, i32, i32, f32, f32, f32, vp],
     "amdseg_heads_bwd_ce": [vp, i32, i32, i32, vp, vp, f32, vp, vp],

@@ -58,19 +58,25 @@ class LongformerEncoderEngine(BertEncoderEngine):
         la = A["layers"][i if train else 0]
         x_in = A["x"][i] if train else A["x"][i % 2]
         fp = self.fp.flat_p
+        dev = x_in.device
+        dtx = L.F32 if x_in.dtype == torch.float32 else L.BF16
         with torch.no_grad():
             Wq, bq = self._gp(fp, i, "query_global", "weight"), self._gp(fp, i, "query_global", "bias")
-            Wk = self._gp(fp, i, "key_global", "weight").view(heads, 64, H)
-            Wv, bv = self._gp(fp, i, "value_global", "weight").view(heads, 64, H), self._gp(fp, i, "value_global", "bias").view(heads, 64)
-            x0 = x_in.view(B, Lseq, H)[:, 0, :].float()
-            qg = torch.addmm(bq, x0, Wq.t()).mul_(self.scale).view(B, heads, 64)
-            r = torch.einsum("bhe,hek->bhk", qg, Wk).contiguous()
+            Wk = self._gp(fp, i, "key_global", "weight")
+            Wv, bv = self._gp(fp, i, "value_global", "weight"), self._gp(fp, i, "value_global", "bias")
+            qg = torch.empty(B, heads, 64, dtype=torch.float32, device=dev)
+            r = torch.empty(B, heads, H, dtype=torch.float32, device=dev)
+            # the O(heads * H^2) algebra of the global row runs in csrc/lf_global.hip (2 launches forward, 4 backward; round 1: ~25
+            # rocBLAS / elementwise launches per layer and direction)
+            L.check(lib.amdseg_lf_global_q(x_in.data_ptr(), dtx, Wq.data_ptr(), bq.data_ptr(), Wk.data_ptr(), qg.data_ptr(), r.data_ptr(),
+                                           B, Lseq, H, heads, self.scale, s), "amdseg_lf_global_q")
             scores = ops.lf_rowvec_dot(x_in, r, B, Lseq, add_tok=A["mask_bias"])
             seed = (int(cfg.seed) * 0x9E3779B1 + 7919 * (i + 1)) & 0x7FFFFFFFFFFFFFFF
             p, pd, sp = ops.lf_softmax_fwd(scores, cfg.p_attn, seed)
             y = ops.lf_wsum(x_in, pd, H, A["lf_partials"])
-            out = torch.einsum("bhk,hek->bhe", y, Wv) + bv.unsqueeze(0) * sp.unsqueeze(-1)
-            la["ctx"].view(B, Lseq, H)[:, 0, :] = out.reshape(B, H).to(la["ctx"].dtype)
+            L.check(lib.amdseg_lf_global_out(Wv.data_ptr(), bv.data_ptr(), y.data_ptr(), sp.data_ptr(), la["ctx"].data_ptr(),
+                                             L.F32 if la["ctx"].dtype == torch.float32 else L.BF16, B, Lseq, H, heads, s),
+                    "amdseg_lf_global_out")
         cfg.phase = 2
         L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].2")
         cfg.phase = 0
@@ -88,35 +94,33 @@ class LongformerEncoderEngine(BertEncoderEngine):
         cfg.phase = 1
         L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].1")
         x_in = A["x"][i]
-        dctx = A["ws"]["dctx"].view(B, Lseq, H)
+        dctx = A["ws"]["dctx"]
         fp, fg = self.fp.flat_p, self.fp.flat_g
         qg, r, p, y, sp = saved["qg"], saved["r"], saved["p"], saved["y"], saved["sp"]
+        dev = x_in.device
+        f32 = dict(dtype=torch.float32, device=dev)
         with torch.no_grad():
-            Wq = self._gp(fp, i, "query_global", "weight")
-            Wk = self._gp(fp, i, "key_global", "weight").view(heads, 64, H)
-            Wv, bv = self._gp(fp, i, "value_global", "weight").view(heads, 64, H), self._gp(fp, i, "value_global", "bias").view(heads, 64)
-            dout = dctx[:, 0, :].float().view(B, heads, 64)
-            dctx[:, 0, :].zero_()                   # the band attention's own row 0 was overwritten in forward: no gradient
-            self._gp(fg, i, "value_global", "weight").view(heads, 64, H).add_(torch.einsum("bhe,bhk->hek", dout, y))
-            self._gp(fg, i, "value_global", "bias").view(heads, 64).add_((dout * sp.unsqueeze(-1)).sum(0))
-            dyv = torch.einsum("bhe,hek->bhk", dout, Wv).contiguous()
-            dsp = (dout * bv.unsqueeze(0)).sum(-1).contiguous()
+            Wq, Wk = self._gp(fp, i, "query_global", "weight"), self._gp(fp, i, "key_global", "weight")
+            Wv, bv = self._gp(fp, i, "value_global", "weight"), self._gp(fp, i, "value_global", "bias")
+            dout, dyv, dsp = torch.empty(B, heads, 64, **f32), torch.empty(B, heads, H, **f32), torch.empty(B, heads, **f32)
+            # consumes + zeroes dctx[:, 0] (the band attention's own row 0 was overwritten in forward: no gradient)
+            L.check(lib.amdseg_lf_global_bwd_a(dctx.data_ptr(), L.BF16, Wv.data_ptr(), bv.data_ptr(), dout.data_ptr(), dyv.data_ptr(),
+                                               dsp.data_ptr(), B, Lseq, H, heads, s), "amdseg_lf_global_bwd_a")
             dpd = ops.lf_rowvec_dot(x_in, dyv, B, Lseq, add_bh=dsp)
             ds, pd = ops.lf_softmax_bwd(p, dpd, cfg.p_attn, saved["seed"])
             dr = ops.lf_wsum(x_in, ds, H, A["lf_partials"])
-            self._gp(fg, i, "key_global", "weight").view(heads, 64, H).add_(torch.einsum("bhe,bhk->hek", qg, dr))
-            dqg = torch.einsum("bhk,hek->bhe", dr, Wk).reshape(B, H).mul_(self.scale)
-            x0 = x_in.view(B, Lseq, H)[:, 0, :].float()
-            self._gp(fg, i, "query_global", "weight").addmm_(dqg.t(), x0)
-            self._gp(fg, i, "query_global", "bias").add_(dqg.sum(0))
-            dx0 = dqg @ Wq
         cfg.phase = 2
         L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].2")
         cfg.phase = 0
         with torch.no_grad():
             ops.lf_dx_update(other, pd, dyv, ds, r, A["lf_vt"])
-            row0 = other.view(B, Lseq, H)[:, 0, :]
-            row0.copy_((row0.float() + dx0).to(other.dtype))
+            dqg = torch.empty(B, H, **f32)
+            g = lambda which, kind: self._gp(fg, i, which, kind).data_ptr()          # noqa: E731
+            L.check(lib.amdseg_lf_global_bwd_rest(x_in.data_ptr(), L.BF16, other.data_ptr(), L.BF16, Wq.data_ptr(), Wk.data_ptr(),
+                                                  qg.data_ptr(), dout.data_ptr(), y.data_ptr(), sp.data_ptr(), dr.data_ptr(), dqg.data_ptr(),
+                                                  g("query_global", "weight"), g("query_global", "bias"), g("key_global", "weight"),
+                                                  g("value_global", "weight"), g("value_global", "bias"), B, Lseq, H, heads, self.scale, s),
+                    "amdseg_lf_global_bwd_rest")
 
     def _arena(self, B, Lseq, train, fp32=False):
         A = super()._arena(B, Lseq, train, fp32)
