@@ -181,7 +181,7 @@ def pool_roofline(model, args, device):
     la, pn = A["layers"][0], A["pn"]
     rs, re = eng._run
     g = torch.zeros(B, H, device=device)
-    f = lambda: ops.ponet_pool_fwd(la["qkv"], A["mask_bias"], rs, re, g, pn["part"][0], pn["parg"][0], la["ctx"], B, Lq, H)   # noqa: E731
+    f = lambda: ops.ponet_pool_fwd(la["qkv"], A["mask_bias"], rs, re, eng._work, g, pn["part"][0], pn["parg"][0], la["ctx"], B, Lq, H)   # noqa: E731
     for _ in range(3):
         f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -192,7 +192,7 @@ def pool_roofline(model, args, device):
     t = e0.elapsed_time(e1) / 20 * 1e-3
     by = 4.0 * B * Lq * H * 2
     return dict(bound="hbm", achieved=round(by / t / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(by / t / 8e12, 4), traffic=None,
-                kernel="pn_tree_max_kernel x2 + pn_run_fold_max_kernel + pn_combine_fwd_kernel", avg_launch_us=round(t * 1e6, 1), algorithmic_bytes=by)
+                kernel="pn_a_max_kernel + pn_r_max_kernel + pn_combine_fwd_kernel", avg_launch_us=round(t * 1e6, 1), algorithmic_bytes=by)
 
 
 def host_cpu():

@@ -133,14 +133,17 @@ int amdseg_lf_dx_update_ld(void* dx, int ldx, int assign, const float* coefA, co
  * alimeeting4mug/src/models/modeling_ponet.py:68-79 (source NOT in the reference tree: semantics = oracle/ponet_oracle.py,
  * parity unpinned).  proj [B*L, ld >= 5H] bf16 = (Hq | Hk | Ho | Hl | Hs); run_start / run_end [B*L] int32 = first / last
  * position (within the sequence) of the token's segment run (segment_ids non-decreasing, padding constant per run);
- * g [B, H] fp32 global aggregate; part / parg [3, B*L, H] bf16 / uint16 scratch (64-token sub-leader rows, folded run-leader
- * rows, 8-token tree rows) written by forward and read by backward; forward writes ctx [B*L, H]; backward writes the Ho, Hl, Hs column blocks
- * of dproj [B*L, ld], E = dctx*Ho [B*L, H] bf16 and uses psum [3, B*L, H] fp32 scratch.  L <= 65535, H <= 1024. */
-int amdseg_ponet_pool_fwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const float* g,
-                          void* part, void* parg, void* ctx, int B, int L, int H, amdseg_stream_t stream);
-int amdseg_ponet_pool_bwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const float* g,
-                          const void* part, const void* parg, const void* dctx, void* dproj, void* E, float* psum, int B, int L, int H,
-                          amdseg_stream_t stream);
+ * g [B, H] fp32 global aggregate.  amdseg_ponet_plan builds, once per batch, the two work lists of the kernels in `work` (int32
+ * [2 + 2*B*L]: #level-A leaders, #run leaders, the two lists) from the mask and run_start.  part / parg [2, B*L, H] bf16 / uint16 scratch
+ * (folded run-leader rows, 8-token partial rows) written by forward and read by backward; forward writes ctx [B*L, H]; backward writes the
+ * Ho, Hl, Hs column blocks of dproj [B*L, ld] and dg [B, H] = per-sequence sum of dctx * Ho (the gradient of g), using psum [2, B*L, H]
+ * fp32 scratch.  L <= 65535, L % 8 == 0, H <= 1024. */
+int amdseg_ponet_plan(const float* mask_bias, const int* run_start, int* work, int B, int L, amdseg_stream_t stream);
+int amdseg_ponet_pool_fwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,
+                          const float* g, void* part, void* parg, void* ctx, int B, int L, int H, amdseg_stream_t stream);
+int amdseg_ponet_pool_bwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,
+                          const float* g, const void* part, const void* parg, const void* dctx, void* dproj, float* dg, float* psum, int B,
+                          int L, int H, amdseg_stream_t stream);
 
 /* ---- HBM-bound row kernels (csrc/elementwise.hip) ---------------------------------------------------------------
  * embeddings + LayerNorm + dropout ([hf] models/bert/modeling_bert.py:53-108); tables are the fp32 masters.

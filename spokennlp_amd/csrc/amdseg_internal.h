@@ -75,11 +75,12 @@ int amdseg_lf_wsum_impl(const void* x, const float* coef, float* partials, float
 int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, void* vt_ws,
                              int B, int L, int H, int heads, int dtype, int ldx, int assign, hipStream_t s);
 
-int amdseg_ponet_pool_fwd_impl(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end,
+int amdseg_ponet_plan_impl(const float* mask_bias, const int* run_start, int* work, int B, int L, hipStream_t s);
+int amdseg_ponet_pool_fwd_impl(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,
                                const float* g, void* part, void* parg, void* ctx, int B, int L, int H, hipStream_t s);
-int amdseg_ponet_pool_bwd_impl(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end,
-                               const float* g, const void* part, const void* parg, const void* dctx, void* dproj, void* E,
-                               float* psum, int B, int L, int H, hipStream_t s);
+int amdseg_ponet_pool_bwd_impl(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,
+                               const float* g, const void* part, const void* parg, const void* dctx, void* dproj, float* dg, float* psum,
+                               int B, int L, int H, hipStream_t s);
 
 int amdseg_rowdot_fwd_impl(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
                            hipStream_t s);

@@ -137,14 +137,17 @@ int amdseg_lf_dx_update_ld(void* dx, int ldx, int assign, const float* coefA, co
                            void* vt_ws, int B, int L, int H, int heads, int dtype, amdseg_stream_t stream) {
     return amdseg_lf_dx_update_impl(dx, coefA, vecA, coefB, vecB, vt_ws, B, L, H, heads, dtype, ldx, assign, S(stream));
 }
-int amdseg_ponet_pool_fwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const float* g,
-                          void* part, void* parg, void* ctx, int B, int L, int H, amdseg_stream_t stream) {
-    return amdseg_ponet_pool_fwd_impl(proj, ld, mask_bias, run_start, run_end, g, part, parg, ctx, B, L, H, S(stream));
+int amdseg_ponet_plan(const float* mask_bias, const int* run_start, int* work, int B, int L, amdseg_stream_t stream) {
+    return amdseg_ponet_plan_impl(mask_bias, run_start, work, B, L, S(stream));
 }
-int amdseg_ponet_pool_bwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const float* g,
-                          const void* part, const void* parg, const void* dctx, void* dproj, void* E, float* psum, int B, int L, int H,
-                          amdseg_stream_t stream) {
-    return amdseg_ponet_pool_bwd_impl(proj, ld, mask_bias, run_start, run_end, g, part, parg, dctx, dproj, E, psum, B, L, H, S(stream));
+int amdseg_ponet_pool_fwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,
+                          const float* g, void* part, void* parg, void* ctx, int B, int L, int H, amdseg_stream_t stream) {
+    return amdseg_ponet_pool_fwd_impl(proj, ld, mask_bias, run_start, run_end, work, g, part, parg, ctx, B, L, H, S(stream));
+}
+int amdseg_ponet_pool_bwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,
+                          const float* g, const void* part, const void* parg, const void* dctx, void* dproj, float* dg, float* psum, int B,
+                          int L, int H, amdseg_stream_t stream) {
+    return amdseg_ponet_pool_bwd_impl(proj, ld, mask_bias, run_start, run_end, work, g, part, parg, dctx, dproj, dg, psum, B, L, H, S(stream));
 }
 int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                   amdseg_stream_t stream) {

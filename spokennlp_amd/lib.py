@@ -67,8 +67,9 @@ _PROTOS = {
     "amdseg_lf_rowvec_dot_ld": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "amdseg_lf_wsum_ld": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "amdseg_lf_dx_update_ld": [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "amdseg_ponet_pool_fwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    "amdseg_ponet_pool_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "amdseg_ponet_plan": [vp, vp, vp, i32, i32, vp],
+    "amdseg_ponet_pool_fwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "amdseg_ponet_pool_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "amdseg_embed_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, u64, i32, vp],
     "amdseg_embed_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "amdseg_add_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, i32, vp],

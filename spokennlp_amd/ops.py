@@ -200,16 +200,27 @@ def lf_dx_update(dx, coefA, vecA, coefB, vecB, vt_ws=None, assign=False):
 
 
 # ---- PoNet token mixing (csrc/ponet.hip)
-def ponet_pool_fwd(proj, mask_bias, run_start, run_end, g, part, parg, ctx, B, Lseq, H):
-    rc = L.load().amdseg_ponet_pool_fwd(_p(proj), proj.stride(0), _p(mask_bias), _p(run_start), _p(run_end), _p(g), _p(part), _p(parg),
-                                        _p(ctx), B, Lseq, H, _s())
+def ponet_plan(mask_bias, run_start, B, Lseq):
+    """work lists of the PoNet pooling kernels for one batch (csrc/ponet.hip): int32 [2 + 2*B*L] on the device, no host sync"""
+    work = torch.empty(2 + 2 * B * Lseq, dtype=torch.int32, device=mask_bias.device)
+    rc = L.load().amdseg_ponet_plan(_p(mask_bias), _p(run_start), _p(work), B, Lseq, _s())
+    L.check(rc, "amdseg_ponet_plan")
+    return work
+
+
+def ponet_pool_fwd(proj, mask_bias, run_start, run_end, work, g, part, parg, ctx, B, Lseq, H):
+    rc = L.load().amdseg_ponet_pool_fwd(_p(proj), proj.stride(0), _p(mask_bias), _p(run_start), _p(run_end), _p(work), _p(g), _p(part),
+                                        _p(parg), _p(ctx), B, Lseq, H, _s())
     L.check(rc, "amdseg_ponet_pool_fwd")
 
 
-def ponet_pool_bwd(proj, mask_bias, run_start, run_end, g, part, parg, dctx, dproj, E, psum, B, Lseq, H):
-    rc = L.load().amdseg_ponet_pool_bwd(_p(proj), proj.stride(0), _p(mask_bias), _p(run_start), _p(run_end), _p(g), _p(part), _p(parg),
-                                        _p(dctx), _p(dproj), _p(E), _p(psum), B, Lseq, H, _s())
+def ponet_pool_bwd(proj, mask_bias, run_start, run_end, work, g, part, parg, dctx, dproj, psum, B, Lseq, H):
+    """returns dg [B, H] fp32: the per-sequence sum of dctx * Ho over the valid tokens (gradient of the global aggregate)"""
+    dg = torch.empty(B, H, dtype=torch.float32, device=proj.device)
+    rc = L.load().amdseg_ponet_pool_bwd(_p(proj), proj.stride(0), _p(mask_bias), _p(run_start), _p(run_end), _p(work), _p(g), _p(part),
+                                        _p(parg), _p(dctx), _p(dproj), _p(dg), _p(psum), B, Lseq, H, _s())
     L.check(rc, "amdseg_ponet_pool_bwd")
+    return dg
 
 
 def embed_ln_fwd(ids, type_ids, pos_ids, word, pos, typ, gamma, beta, Lseq, eps, p=0.0, seed=0, dtype=torch.bfloat16,

@@ -100,7 +100,9 @@ def test_torch_ddp_reduces_engine_gradients(dev, tmp_path, family):
             want = 0.5 * (per_rank[0]["grads"][n] + per_rank[1]["grads"][n])
             for r in range(2):
                 g = got[r][it]["grads"][n]
-                tol = 1e-5 * max(1e-3, float(want.abs().max()))
+                # PoNet: the gradient of the global aggregate is accumulated over the runs with fp32 atomics (order varies run to run at
+                # the 1e-7 level; a flipped bf16 rounding downstream shows at 1e-4) -- a missing reduction would be a 50 % error
+                tol = (1e-5 if family == "bert" else 1e-3) * max(1e-3, float(want.abs().max()))
                 assert float((g - want).abs().max()) <= tol, (it, r, n)
         for n in got[0][it]["grads"]:
             assert "pooler" not in n or float(got[0][it]["grads"][n].abs().max()) == 0.0

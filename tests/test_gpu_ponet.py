@@ -64,13 +64,14 @@ def test_pooling_kernels_vs_oracle(dev, B, L, long_run):
     projd = proj.to(dev)
     part = torch.empty(3 * B * L, H, dtype=torch.bfloat16, device=dev); parg = torch.empty(3 * B * L, H, dtype=torch.int16, device=dev)
     ctx = torch.empty(B * L, H, dtype=torch.bfloat16, device=dev)
-    ops.ponet_pool_fwd(projd, mb, rs, re, g.to(dev), part, parg, ctx, B, L, H)
+    work = ops.ponet_plan(mb.reshape(-1), rs, B, L)
+    ops.ponet_pool_fwd(projd, mb, rs, re, work, g.to(dev), part, parg, ctx, B, L, H)
     err = (ctx.float().cpu().view(B, L, H) - ctx_ref.detach()).abs()
     assert (err <= 0.01 * ctx_ref.detach().abs() + 0.02).all(), err.max().item()
     assert (ctx.float().cpu().view(B, L, H)[~valid] == 0).all()
     dproj = torch.full((B * L, 5 * H), 7.0, dtype=torch.bfloat16, device=dev)
-    E = torch.empty(B * L, H, dtype=torch.bfloat16, device=dev); psum = torch.empty(3 * B * L, H, dtype=torch.float32, device=dev)
-    ops.ponet_pool_bwd(projd, mb, rs, re, g.to(dev), part, parg, dctx.to(dev), dproj, E, psum, B, L, H)
+    psum = torch.empty(3 * B * L, H, dtype=torch.float32, device=dev)
+    dg = ops.ponet_pool_bwd(projd, mb, rs, re, work, g.to(dev), part, parg, dctx.to(dev), dproj, psum, B, L, H)
     d = dproj.float().cpu()
     # bf16-quantised inputs tie now and then; torch.maximum / amax split the gradient among tied maxima while the kernels
     # route it to the first one -- compare only where the maximum is unique
@@ -92,9 +93,9 @@ def test_pooling_kernels_vs_oracle(dev, B, L, long_run):
         e = (got - ref).abs()
         assert ok[k].float().mean() > 0.5
         assert (e <= 0.02 * ref.abs() + 0.05)[ok[k]].all(), (k, e[ok[k]].max().item())
-    # E = dctx * Ho on valid rows
-    eref = dctx.float().view(B, L, H) * ho.detach() * valid[..., None]
-    assert ((E.float().cpu().view(B, L, H) - eref).abs() <= 0.01 * eref.abs() + 0.02).all()
+    # dg = sum over the valid rows of dctx * Ho (the gradient of the global aggregate g)
+    eref = (dctx.float().view(B, L, H) * ho.detach() * valid[..., None]).sum(1)
+    assert ((dg.cpu() - eref).abs() <= 1e-3 * eref.abs() + 1e-2).all(), (dg.cpu() - eref).abs().max().item()
 
 
 def build(dev, sd=None, dropout=0.0):
@@ -237,7 +238,7 @@ def test_pooling_kernels_full_size_vs_oracle(dev, B):
     mb = ((1 - am.float()) * -1e30).to(dev)
     part = torch.empty(3 * B * L, H, dtype=torch.bfloat16, device=dev); parg = torch.empty(3 * B * L, H, dtype=torch.int16, device=dev)
     ctx = torch.empty(B * L, H, dtype=torch.bfloat16, device=dev)
-    ops.ponet_pool_fwd(proj.to(dev), mb, rs, re, g.to(dev), part, parg, ctx, B, L, H)
+    ops.ponet_pool_fwd(proj.to(dev), mb, rs, re, ops.ponet_plan(mb.reshape(-1), rs, B, L), g.to(dev), part, parg, ctx, B, L, H)
     got = ctx.float().cpu().view(B, L, H)
     err = (got - ctx_ref).abs()
     assert (err <= 0.01 * ctx_ref.abs() + 0.02).all(), err.max().item()
