@@ -284,6 +284,223 @@ __global__ __launch_bounds__(256) void pattn_bwd_dkv_kernel(PAttnArgs a) {
     a.dqkv[tok * H3 + 2 * H + h * 64 + l] = dv;
 }
 
+// ------------------------------------------------------------------------------------------------ fp32 attention on the fp32 MFMA
+// The same arithmetic as the vector-ALU kernels above, as flash-style kernels on v_mfma_f32_16x16x4_f32 (exact fp32 products and
+// accumulation, 1/16 of the bf16 MFMA rate = the fp32 vector rate, but one instruction does 1024 multiply-adds instead of 64): a
+// workgroup = 4 waves x 16 query (key) rows, the other side streamed through LDS in 64-row chunks [64][68] (row stride 68 floats: both
+// fragment access patterns below hit 64 distinct banks).  TRANSPOSED orientation as in attention.hip: S^T = K Q^T puts the keys on the
+// accumulator rows (lane group g, register r -> key 4g + r of a 16-key tile) and one query per lane column, so max / sum / lse / delta
+// are lane-local plus two xor-shuffles, and the probabilities feed the next product straight from the accumulator registers: the
+// contraction step r of O^T += V^T P^T takes, in lane group g, exactly key 4g + r -- register r of the S^T tile.
+// Operand maps (cdna_hip_programming.md): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D[i = 4 (l >> 4) + r][j = l & 15].
+// Measured at 32 x 12 x 512: forward 1208 -> see profiles/r02_parity_v1, the vector-ALU kernels stay as the reference implementation
+// (AMDSEG_PATTN_VALU=1).
+#define PA2_LD 68
+__device__ __forceinline__ void pa2_stage(float (*dst)[PA2_LD], const float* src, int ld) {      // 64 rows x 64 floats, 256 threads
+    const int t = threadIdx.x, r = t >> 2, c0 = (t & 3) * 16;
+    const float* p = src + (size_t)r * ld + c0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&dst[r][c0 + 4 * i]) = *reinterpret_cast<const float4*>(p + 4 * i);
+}
+__device__ __forceinline__ float pa2_max_g(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float pa2_sum_g(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+__global__ __launch_bounds__(256) void pattn2_fwd_kernel(PAttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ks[64][PA2_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[64][PA2_LD];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
+    const int q = blockIdx.x * 64 + w * 16 + i16, h = blockIdx.y, b = blockIdx.z;
+    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
+    const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
+    const size_t row = ((size_t)b * a.heads + h) * a.L + q;
+    float qf[16];                                             // B operand of S^T = K Q^T: Q[q][4i + g]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) qf[i] = base[(size_t)q * H3 + 4 * i + g];
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_part = 0.f;
+    for (int c = 0; c < ns; ++c) {
+        __syncthreads();
+        pa2_stage(Ks, base + (size_t)c * 64 * H3 + H, H3);
+        pa2_stage(Vs, base + (size_t)c * 64 * H3 + 2 * H, H3);
+        __syncthreads();
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[16 * kt + i16][4 * i + g], qf[i], s[kt], 0, 0, 0);
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const float4 mb = *reinterpret_cast<const float4*>(a.mask_bias + (size_t)b * a.L + c * 64 + 16 * kt + 4 * g);
+            s[kt][0] = fmaf(s[kt][0], a.scale, mb.x); s[kt][1] = fmaf(s[kt][1], a.scale, mb.y);
+            s[kt][2] = fmaf(s[kt][2], a.scale, mb.z); s[kt][3] = fmaf(s[kt][3], a.scale, mb.w);
+            cmax = fmaxf(fmaxf(cmax, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+        }
+        cmax = pa2_max_g(cmax);
+        const float m_new = fmaxf(m_run, cmax);
+        const float alpha = expf(m_run - m_new);              // exp(-inf) = 0 on the first chunk
+        m_run = m_new;
+        l_part *= alpha;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = expf(s[kt][r] - m_run);
+                l_part += pv;
+                s[kt][r] = pv * pa_keep(a, row, c * 64 + 16 * kt + 4 * g + r);
+            }
+        // O^T[d][q] += V^T[d][key] P^T[key][q]: contraction step r of key tile kt = keys 16 kt + 4 g + r
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[16 * kt + 4 * g + r][16 * d + i16], s[kt][r], o[d], 0, 0, 0);
+    }
+    const float lsum = pa2_sum_g(l_part), inv = 1.0f / lsum;
+    float* op = a.ctx + ((size_t)b * a.L + q) * H + h * 64;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) *reinterpret_cast<float4*>(op + 16 * d + 4 * g) = make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv);
+    if (a.lse && g == 0) a.lse[row] = m_run + logf(lsum);
+}
+
+__global__ __launch_bounds__(256) void pattn2_bwd_dq_kernel(PAttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ks[64][PA2_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[64][PA2_LD];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
+    const int q = blockIdx.x * 64 + w * 16 + i16, h = blockIdx.y, b = blockIdx.z;
+    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
+    const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
+    const size_t tok = (size_t)b * a.L + q, row = ((size_t)b * a.heads + h) * a.L + q;
+    float qf[16], dof[16], dl = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        qf[i] = base[(size_t)q * H3 + 4 * i + g];
+        dof[i] = a.dctx[tok * H + h * 64 + 4 * i + g];
+        dl = fmaf(dof[i], a.ctx[tok * H + h * 64 + 4 * i + g], dl);
+    }
+    const float delta = pa2_sum_g(dl), lse = a.lse[row];
+    if (g == 0) a.delta[row] = delta;
+    f32x4 dq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < ns; ++c) {
+        __syncthreads();
+        pa2_stage(Ks, base + (size_t)c * 64 * H3 + H, H3);
+        pa2_stage(Vs, base + (size_t)c * 64 * H3 + 2 * H, H3);
+        __syncthreads();
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[16 * kt + i16][4 * i + g], qf[i], s[kt], 0, 0, 0);
+                dp[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[16 * kt + i16][4 * i + g], dof[i], dp[kt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const float4 mb4 = *reinterpret_cast<const float4*>(a.mask_bias + (size_t)b * a.L + c * 64 + 16 * kt + 4 * g);
+            const float mb[4] = {mb4.x, mb4.y, mb4.z, mb4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = expf(fmaf(s[kt][r], a.scale, mb[r]) - lse);
+                s[kt][r] = pv * (dp[kt][r] * pa_keep(a, row, c * 64 + 16 * kt + 4 * g + r) - delta);       // dS^T[key][q]
+            }
+        }
+        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) dq[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[16 * kt + 4 * g + r][16 * d + i16], s[kt][r], dq[d], 0, 0, 0);
+    }
+    float* op = a.dqkv + tok * H3 + h * 64;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+        *reinterpret_cast<float4*>(op + 16 * d + 4 * g) = make_float4(dq[d][0] * a.scale, dq[d][1] * a.scale, dq[d][2] * a.scale, dq[d][3] * a.scale);
+}
+
+// dK, dV: workgroup = 64 keys (16 per wave, one key per lane column); streams the query chunks (Q rows, dO rows, lse, delta)
+__global__ __launch_bounds__(256) void pattn2_bwd_dkv_kernel(PAttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Qs[64][PA2_LD];
+    __shared__ __attribute__((aligned(16))) float Ds[64][PA2_LD];
+    __shared__ float Ls[64], Dl[64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
+    const int key = blockIdx.x * 64 + w * 16 + i16, h = blockIdx.y, b = blockIdx.z;
+    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
+    const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
+    const size_t tok = (size_t)b * a.L + key, bh = (size_t)b * a.heads + h;
+    float kf[16], vf[16];                                     // B operands: K[key][4i + g], V[key][4i + g]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { kf[i] = base[(size_t)key * H3 + H + 4 * i + g]; vf[i] = base[(size_t)key * H3 + 2 * H + 4 * i + g]; }
+    const float mbk = a.mask_bias[tok];
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int ci = 0; ci < ns; ++ci) {
+        __syncthreads();
+        pa2_stage(Qs, base + (size_t)ci * 64 * H3, H3);
+        pa2_stage(Ds, a.dctx + ((size_t)b * a.L + ci * 64) * H + h * 64, H);
+        if (threadIdx.x < 64) Ls[threadIdx.x] = a.lse[bh * a.L + ci * 64 + threadIdx.x];
+        else if (threadIdx.x < 128) Dl[threadIdx.x - 64] = a.delta[bh * a.L + ci * 64 + threadIdx.x - 64];
+        __syncthreads();
+        f32x4 s[4], dp[4];                                    // S[q][key], dP[q][key]: row q = 16 qt + 4 g + r, column = this lane's key
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) { s[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                s[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[16 * qt + i16][4 * i + g], kf[i], s[qt], 0, 0, 0);
+                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ds[16 * qt + i16][4 * i + g], vf[i], dp[qt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = 16 * qt + 4 * g + r;
+                const float pv = expf(fmaf(s[qt][r], a.scale, mbk) - Ls[qi]);
+                const float keep = pa_keep(a, bh * a.L + ci * 64 + qi, key);
+                s[qt][r] = pv * (dp[qt][r] * keep - Dl[qi]);      // dS[q][key]
+                dp[qt][r] = pv * keep;                            // P_drop[q][key]
+            }
+        // dV^T[d][key] += dO^T[d][q] P_drop[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    dv[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ds[16 * qt + 4 * g + r][16 * d + i16], dp[qt][r], dv[d], 0, 0, 0);
+                    dk[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[16 * qt + 4 * g + r][16 * d + i16], s[qt][r], dk[d], 0, 0, 0);
+                }
+    }
+    float* okp = a.dqkv + tok * H3 + H + h * 64;
+    float* ovp = a.dqkv + tok * H3 + 2 * H + h * 64;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        *reinterpret_cast<float4*>(okp + 16 * d + 4 * g) = make_float4(dk[d][0] * a.scale, dk[d][1] * a.scale, dk[d][2] * a.scale, dk[d][3] * a.scale);
+        *reinterpret_cast<float4*>(ovp + 16 * d + 4 * g) = make_float4(dv[d][0], dv[d][1], dv[d][2], dv[d][3]);
+    }
+}
+
+static bool pattn_use_valu() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("AMDSEG_PATTN_VALU"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 static int pattn_fill(PAttnArgs& a, int B, int L, int heads, float scale, float p, uint64_t seed) {
     if (B <= 0 || L <= 0 || heads <= 0 || (L % 64) || L > 4096) return AMDSEG_ERR_SHAPE;
     if (p < 0.f || p >= 1.f) return AMDSEG_ERR_ARG;
@@ -301,6 +518,10 @@ int amdseg_pattn_fwd_impl(const float* qkv, const float* mask_bias, float* ctx, 
     int rc = pattn_fill(a, B, L, heads, scale, p, seed);
     if (rc) return rc;
     a.qkv = qkv; a.mask_bias = mask_bias; a.ctx = ctx; a.lse = lse;
+    if (!pattn_use_valu()) {
+        hipLaunchKernelGGL(pattn2_fwd_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        return amdseg_launch_status();
+    }
     const dim3 grid(L / 4, heads, B);
     const int ns = L / 64;
     if (ns <= 2) hipLaunchKernelGGL(pattn_fwd_kernel<2>, grid, dim3(256), 0, s, a);
@@ -317,6 +538,11 @@ int amdseg_pattn_bwd_impl(const float* qkv, const float* mask_bias, const float*
     int rc = pattn_fill(a, B, L, heads, scale, p, seed);
     if (rc) return rc;
     a.qkv = qkv; a.mask_bias = mask_bias; a.ctx = (float*)ctx; a.lse = (float*)lse; a.dctx = dctx; a.delta = delta; a.dqkv = dqkv;
+    if (!pattn_use_valu()) {
+        hipLaunchKernelGGL(pattn2_bwd_dq_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(pattn2_bwd_dkv_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        return amdseg_launch_status();
+    }
     const dim3 grid(L / 4, heads, B);
     hipLaunchKernelGGL(pattn_bwd_dq_kernel<1>, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(pattn_bwd_dkv_kernel, grid, dim3(256), 0, s, a);
