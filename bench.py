@@ -110,6 +110,32 @@ def make_batches(args, n, seed, device):
 PROF_CLASSES = (("gemm_nt_dp_kernel", 0), ("gemm_tn_dp_kernel", 1), ("attn_fwd_kernel", 2), ("attn_bwd_dq_kernel", 3), ("attn_bwd_dkv_kernel", 4))
 
 
+def prof_arm():
+    from spokennlp_amd import lib as L
+    lib = L.load()
+    if lib.amdseg_prof_enable(1) < 0:
+        return False
+    lib.amdseg_prof_reset()
+    return True
+
+
+def prof_collect(nsteps):
+    import ctypes as C
+    from spokennlp_amd import lib as L
+    lib = L.load()
+    torch.cuda.synchronize()
+    out = {}
+    for name, cls in PROF_CLASSES:
+        us, work, n = C.c_double(), C.c_double(), C.c_longlong()
+        L.check(lib.amdseg_prof_read(cls, C.byref(us), C.byref(work), C.byref(n)), "amdseg_prof_read")
+        if n.value:
+            out[name] = dict(launches_per_step=round(n.value / nsteps, 2), avg_launch_us=round(us.value / n.value, 2),
+                             us_per_step=round(us.value / nsteps, 1), gflop_per_launch=round(work.value / n.value / 1e9, 3),
+                             achieved=round(work.value / us.value / 1e6, 1), frac=round(work.value / us.value / 1e6 / MFMA_PEAK_TFLOPS, 4))
+    lib.amdseg_prof_enable(0)
+    return out
+
+
 def instep_roofline(step, first_step, nsteps):
     """per-kernel MFMA roofline measured INSIDE real training steps with HIP events: while armed, libamdseg launches the dominant
     kernels through hipExtLaunchKernelGGL with a start and a stop event, which are filled from the dispatch's own completion-signal
@@ -324,7 +350,12 @@ def main():
     ap.add_argument("--standalone-gemm", action="store_true", help="also time the gemm_nt shapes back to back on warm operands")
     ap.add_argument("--via-trainer", action="store_true", help="force the transformers.Trainer leg (default: on for bert, 1 GPU, train)")
     ap.add_argument("--no-via-trainer", action="store_true")
-    ap.add_argument("--prof-steps", type=int, default=10, help="extra steps with the in-kernel launch timer armed (roofline)")
+    ap.add_argument("--prof-steps", type=int, default=10, help="extra steps with the launch timer armed (roofline) when it is not armed "
+                                                               "over the timed region itself")
+    ap.add_argument("--prof-in-timed", action="store_true", help="arm the launch timer over the timed region itself instead of over "
+                                                                 "--prof-steps extra steps after it (measured: the event-carrying launches cost "
+                                                                 "5 % of the step, 15.3 vs 14.5 ms, so `value` would be perturbed; the per-kernel "
+                                                                 "averages are the same either way, 65.1 vs 65.4 us)")
     args = ap.parse_args()
     if args.seq_len is None:
         args.seq_len = 512 if args.model == "bert" else 4096
@@ -369,6 +400,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    prof_timed = (not args.no_roofline) and args.mode == "train" and args.prof_in_timed and prof_arm()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
@@ -406,8 +438,12 @@ def main():
     per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     out["ms_per_step_median"] = round(per_step[len(per_step) // 2], 3)
     prof = None
-    if not args.no_roofline and args.mode == "train":      # every rank runs the extra steps (the exchange is collective); rank 0 reports
+    prof_n = args.steps
+    if prof_timed:                                          # start / stop events of every launch of the timed region itself
+        prof = prof_collect(args.steps)
+    elif not args.no_roofline and args.mode == "train":    # every rank runs the extra steps (the exchange is collective); rank 0 reports
         prof = instep_roofline(step, total_steps, args.prof_steps)
+        prof_n = args.prof_steps
     if rank == 0:
         if prof:
             dom = max(prof, key=lambda k: prof[k]["us_per_step"]) if "gemm_nt_dp_kernel" not in prof else "gemm_nt_dp_kernel"
@@ -415,9 +451,9 @@ def main():
             out["roofline"] = dict(bound="mfma", achieved=d["achieved"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=d["frac"], traffic=None,
                                    kernel=dom, avg_launch_us=d["avg_launch_us"], launches_per_step=d["launches_per_step"],
                                    gflop_per_launch=d["gflop_per_launch"],
-                                   method=f"in-step: HIP start/stop events of every launch (hipExtLaunchKernelGGL) over {args.prof_steps} real "
-                                          f"steps right after the timed region (csrc/prof.h); HBM traffic needs separate rocprofv3 --pmc "
-                                          f"passes: see profiles/",
+                                   method=f"in-step: HIP start/stop events of every launch (hipExtLaunchKernelGGL, csrc/prof.h) over "
+                                          + (f"the {prof_n} steps of the timed region" if prof_timed else f"{prof_n} real steps right after the "
+                                             f"timed region") + "; HBM traffic needs separate rocprofv3 --pmc passes: see profiles/",
                                    kernels=prof)
             if args.standalone_gemm:
                 out["roofline"]["standalone"] = gemm_roofline(model, args, device)
