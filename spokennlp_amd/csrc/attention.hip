@@ -95,6 +95,20 @@ struct ListWalk {
     }
 };
 
+// XCD-aware placement for the 3-D launches (x = row block, y = head, z = batch).  The hardware deals consecutive workgroup ids round-robin
+// over the 8 XCDs, so the row blocks of ONE (batch, head) -- which all stream the same K / V (or Q / dO) rows -- landed on 8 different L2s
+// and every XCD fetched those rows from the fabric on its own: PMC FETCH_SIZE of the dQ kernel was 468 MB per launch against ~110 MB of
+// distinct data (6.2 TB/s over its 75 us: the kernel was fabric-bound, profiles/r02_pmc_instep.md).  Remapped so that workgroup ids
+// xcd, xcd + 8, xcd + 16, ... (= one XCD, in dispatch order) walk the row blocks of the same (batch, head) before moving to the next one.
+__device__ __forceinline__ void attn_xcd_remap(int& rb, int& h, int& b, int heads) {
+    const int nrb = gridDim.x, nbh = gridDim.y * gridDim.z;
+    if (nbh & 7) return;                                    // needs a multiple of 8 (batch, head) pairs; tiny shapes keep the plain order
+    const int id = blockIdx.x + nrb * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = id & 7, t = id >> 3;
+    const int bh = (t / nrb) * 8 + xcd;
+    rb = t % nrb; h = bh % heads; b = bh / heads;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int NW, bool BAND, bool LIST = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
@@ -105,7 +119,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
         const int nbh = a.heads * a.B, r = blockIdx.x / nbh, bh = blockIdx.x % nbh;
         h = bh % a.heads; b = bh / a.heads;
         qb = a.korder ? a.korder[h * (a.L / CH) + r] : r;
-    }
+    } else attn_xcd_remap(qb, h, b, a.heads);
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
     const int q = qb * (NW * 16) + w * 16 + i16;                       // this lane's query row (shared by the 4 g-groups)
@@ -314,7 +328,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         const int nbh = a.heads * a.B, r = blockIdx.x / nbh, bh = blockIdx.x % nbh;
         h = bh % a.heads; b = bh / a.heads;
         qb = a.korder ? a.korder[h * (a.L / CH) + r] : r;
-    }
+    } else attn_xcd_remap(qb, h, b, a.heads);
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
     const int q = qb * (NW * 16) + w * 16 + i16;
@@ -485,6 +499,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #define bufL(i) (smem + 32768 + (i) * 512)
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    if (!BAND && !LIST) attn_xcd_remap(kb, h, b, a.heads);
     if (BAND) {
         // 1-D launch.  The key block holding the global keys sees EVERY query chunk (L/64 instead of ~2W/64 + 1): those
         // B*heads long workgroups come first in dispatch order and land round-robin on all XCDs, so they overlap the
