@@ -218,7 +218,7 @@ def pool_roofline(model, args, device):
     t = e0.elapsed_time(e1) / 20 * 1e-3
     by = 4.0 * B * Lq * H * 2
     return dict(bound="hbm", achieved=round(by / t / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(by / t / 8e12, 4), traffic=None,
-                kernel="pn_a_max_kernel + pn_r_max_kernel + pn_combine_fwd_kernel", avg_launch_us=round(t * 1e6, 1), algorithmic_bytes=by)
+                kernel="pn_zero_kernel + pn_segmax_kernel + pn_combine_fwd_kernel", avg_launch_us=round(t * 1e6, 1), algorithmic_bytes=by)
 
 
 def host_cpu():

@@ -5,424 +5,333 @@
 //   segment max-pooling  S_n = max of Hs over the valid tokens of n's segment (a contiguous run of equal segment_ids),
 //   local max-pooling    L_n = max of Hl over the valid tokens n-1, n, n+1,
 //   fusion               ctx_n = (g + S_n) * Ho_n + L_n        (g = global-attention aggregate, [B, H] fp32, see host mirror)
-// and their backward.  One wave per token row (or per 8 consecutive rows), 16 B per lane (the LayerNorm recipe).
-// Round 2 layout of the work (round 1: five-launch trees whose inactive waves -- 7 of 8 -- still held 130+ VGPRs each while they loaded
-// three words and exited; the forward ran at 0.23 of HBM):
-//   plan      (once per batch)  two compact work lists built with an atomic counter each: LEVEL-A leaders = valid tokens with
-//                               (pos - run_start) % 8 == 0, and RUN leaders = valid tokens with pos == run_start;
-//   forward   pn_a_max  : persistent waves over the level-A list, 8 Hs rows in flight each -> partial max / argmax rows (plane A)
-//             pn_r_max  : persistent waves over the run list, fold the run's plane-A rows (8 in flight) -> S / argmax row of the run
-//             pn_combine: every token: ctx = (g + S) * Ho + max(Hl[n-1..n+1])
-//   backward  pn_bwd_tok: one wave per 8 CONSECUTIVE tokens, Hl and dctx rows kept in a sliding register window (3.75 row loads per
-//                         token instead of 10); writes dHo, dHl, zeroes padded rows, and accumulates E = dctx * Ho per run SEGMENT
-//                         (flushed at run boundaries and at the end of the group) -- E itself is never materialised;
-//             pn_r_sum  : run leaders fold their segment sums -> run total G (and add it into dg, the gradient of the global aggregate)
-//             pn_route  : dHs_j = [argmax of j's run == j] * G.
+// and their backward.
+//
+// Round-2 (second) layout.  The first two versions reduced runs with trees of per-run waves (level-A rows, then one wave per run folding
+// them): the run-level kernels were latency chains -- one wave walks the rows of a 500-token run one dependent load after the other -- and
+// cost 54 + 42 us per layer although they move a few MB; the row kernels used 16 B per lane on 96 chunks per row (H = 768), i.e. half of
+// every second wave instruction idle, at 170-250 VGPRs.  Now:
+//   * every kernel maps a wave to (16 consecutive tokens) x (256 columns): lanes 0-31 walk tokens 0-7, lanes 32-63 tokens 8-15, each lane
+//     owning 8 columns (16 B) -> all lanes busy for H = 768, every row access of a half-wave is 512 contiguous bytes, all row loads of
+//     a stream are issued before the first use (18-30 rows in flight per wave);
+//   * the run maximum is ONE 32-bit word per (run, column):  key = order-preserving image of the bf16 value << 16 | (0xFFFF - position),
+//     folded with atomicMax into the row of the run's first token: value and "first maximum wins" argmax in one commutative, hence
+//     deterministic, reduction -- no tree, no second kernel.  A stream folds its tokens in registers and issues one atomic per run piece
+//     and column (transposed through LDS so that an atomic instruction covers whole 128-B lines);
+//   * backward accumulates E = dctx * Ho per run piece in registers and adds it (fp32 atomicAdd) into the run's row of G; the routing
+//     kernel then writes dHs_j = [argmax == j] * G and adds each run's G into dg.
+//   forward   pn_zero(keys of the run-start rows) -> pn_segmax -> pn_combine
+//   backward  pn_zero(G rows)                     -> pn_bwd_tok -> pn_bwd_route
 // Algorithmic bytes per token: forward read Hs, Ho, Hl + write ctx = 4 * H * 2 B (25.2 MB per 4096-token sequence and layer);
 // backward read dctx, Ho, Hl + write dHo, dHl, dHs = 6 * H * 2 B.
 #include <algorithm>
 #include "common.h"
 #include "amdseg_internal.h"
 
-#define PN_MAXCH 2                // 8-column chunks per lane: H <= 1024
-#define PN_SUB 64
-
 struct PnArgs {
-    const bf16_t* proj; int ld;                // fused projections, row stride (5H)
+    const bf16_t* proj; int ld;                // fused projections, row stride (>= 5H)
     const float* mask_bias;                    // [M], < 0 = padded token
-    const int* run_start; const int* run_end;  // [M] index (within the sequence) of the first / last token of the token's run
-    bf16_t* part; unsigned short* parg;        // [M, H] sub-leader rows: partial max of Hs and its argmax token index
-    bf16_t* part2; unsigned short* parg2;      // [M, H] run-leader rows: the folded run maximum / argmax
-    float* psum2;                              // [M, H] run-leader rows: the folded run sum of E
-    bf16_t* partA; unsigned short* pargA; float* psumA;    // [M, H] level-A rows (fan-in 8) of the two trees
+    const int* run_start;                      // [M] position (within the sequence) of the first token of the token's run
+    uint32_t* keys;                            // [M, H] run maximum keys, row of the run's first token
+    float* G;                                  // [M, H] run sums of E = dctx * Ho, row of the run's first token
     const float* g;                            // [B, H]
     bf16_t* ctx;                               // [M, H]
     const bf16_t* dctx;                        // [M, H]
-    bf16_t* dproj;                             // [M, 5H] gradient of the projections (Ho, Hl, Hs columns written here)
-    bf16_t* E;                                 // unused (round 1: [M, H] dctx * Ho)
-    float* psum;                               // [M, H] segment rows: partial sums of E = dctx * Ho
-    float* dg;                                 // [B, H] gradient of the global aggregate g: sum of E over the valid tokens of a sequence
-    const int* work;                           // plan: [0] #level-A leaders, [1] #run leaders, [2 .. 2+M) level-A list, [2+M .. 2+2M) run list
+    bf16_t* dproj;                             // [M, ld] gradient of the projections (Ho, Hl, Hs column blocks written here)
+    float* dg;                                 // [B, H] gradient of g: sum of E over the valid tokens of a sequence
+    const int* work;                           // plan: [1] = #runs, [2 + M ..) = token index of every run's first token
     int M, L, H;
 };
 
-template <int NCH>
-__device__ __forceinline__ void pn_load(const bf16_t* row, int nch, int l, float (&v)[NCH][8]) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = l + 64 * i;
-        if (c < nch) ld8<bf16_t>(row + c * 8, v[i]);
-    }
+// ---- bf16 <-> order-preserving 16-bit image (unsigned compare == float compare; -0 is folded onto +0)
+__device__ __forceinline__ uint32_t pn_ord(uint32_t bits) {
+    bits = bits == 0x8000u ? 0u : bits;
+    return bits ^ ((bits & 0x8000u) ? 0xffffu : 0x8000u);
 }
-template <int NCH>
-__device__ __forceinline__ void pn_store(bf16_t* row, int nch, int l, const float (&v)[NCH][8]) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = l + 64 * i;
-        if (c < nch) st8<bf16_t>(row + c * 8, v[i]);
-    }
+__device__ __forceinline__ float pn_unord(uint32_t o) {
+    const uint32_t bits = o ^ ((o & 0x8000u) ? 0x8000u : 0xffffu);
+    return __uint_as_float(bits << 16);
 }
-template <int NCH>
-__device__ __forceinline__ void pn_fill(float (&v)[NCH][8], float x) {
+__device__ __forceinline__ void pn_unpack(const uint4& r, float (&v)[8]) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int i = 0; i < NCH; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[i][e] = x;
+    for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(w[q] << 16); v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pn_pack(const float (&v)[8]) {
+    uint4 r; r.x = pack2bf(v[0], v[1]); r.y = pack2bf(v[2], v[3]); r.z = pack2bf(v[4], v[5]); r.w = pack2bf(v[6], v[7]);
+    return r;
 }
 
-// ---------------------------------------------------------------------------------------------------- plan
-__global__ __launch_bounds__(256) void pn_plan_kernel(const float* __restrict__ mask_bias, const int* __restrict__ run_start, int* work, int M, int L) {
+// wave -> (16-token block, 256-column group); lane -> (8-token stream, 8 columns)
+struct PnLane {
+    int n0, b, p0, col, l31, half; bool act, tok; size_t seq0;      // tok: the stream exists (half-wave uniform); act: ... and so do the lane's columns
+    __device__ __forceinline__ bool init(const PnArgs& a) {
+        const int l = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int ncg = (a.H + 255) >> 8, tb = wave / ncg, cg = wave - tb * ncg;
+        half = l >> 5; l31 = l & 31;
+        col = cg * 256 + l31 * 8;
+        n0 = tb * 16 + half * 8;
+        tok = n0 < a.M; act = tok && col < a.H;
+        b = min(n0, a.M - 1) / a.L; p0 = n0 - b * a.L; seq0 = (size_t)b * a.L;
+        return tb * 16 < a.M;                  // wave-uniform: anything to do
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------- plan: the list of run starts
+__global__ __launch_bounds__(256) void pn_plan_kernel(const int* __restrict__ run_start, int* work, int M, int L) {
     const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= M || mask_bias[n] < 0.f) return;
-    const int pos = n % L, rs = run_start[n];
-    if (((pos - rs) & 7) == 0) work[2 + atomicAdd(work, 1)] = n;
-    if (pos == rs) work[2 + M + atomicAdd(work + 1, 1)] = n;
+    if (n >= M) return;
+    if (n % L == run_start[n]) work[2 + M + atomicAdd(work + 1, 1)] = n;
 }
 
-// ---------------------------------------------------------------------------------------------------- level A: max of 8 Hs rows
-__global__ __launch_bounds__(256) void pn_a_max_kernel(PnArgs a) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int nwaves = gridDim.x * 4, count = a.work[0], nch = a.H >> 3;
-    for (int item = blockIdx.x * 4 + w; item < count; item += nwaves) {
-        const int n = a.work[2 + item];
-        const int b = n / a.L, pos = n - b * a.L, re = a.run_end[n];
-        float v[8][PN_MAXCH][8]; bool ok[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const size_t row = (size_t)b * a.L + min(pos + k, re);
-            ok[k] = pos + k <= re && a.mask_bias[row] >= 0.f;
-            pn_load<PN_MAXCH>(a.proj + row * a.ld + 4 * a.H, nch, l, v[k]);
-        }
-        float mx[PN_MAXCH][8]; unsigned short arg[PN_MAXCH][8];
-        pn_fill<PN_MAXCH>(mx, -INFINITY);
-#pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) arg[i][e] = (unsigned short)pos;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (!ok[k]) continue;
-#pragma unroll
-            for (int i = 0; i < PN_MAXCH; ++i)
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (v[k][i][e] > mx[i][e]) { mx[i][e] = v[k][i][e]; arg[i][e] = (unsigned short)(pos + k); }     // first maximum wins
-        }
-        pn_store<PN_MAXCH>(a.partA + (size_t)n * a.H, nch, l, mx);
-#pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i) {
-            const int c = l + 64 * i;
-            if (c < nch) {
-                uint4 pk;
-                pk.x = arg[i][0] | ((uint32_t)arg[i][1] << 16); pk.y = arg[i][2] | ((uint32_t)arg[i][3] << 16);
-                pk.z = arg[i][4] | ((uint32_t)arg[i][5] << 16); pk.w = arg[i][6] | ((uint32_t)arg[i][7] << 16);
-                *reinterpret_cast<uint4*>(a.pargA + (size_t)n * a.H + c * 8) = pk;
-            }
-        }
+// zero the rows of the run starts of a [M, H] 32-bit plane (one wave per run; H % 8 == 0)
+__global__ __launch_bounds__(256) void pn_zero_kernel(uint32_t* plane, const int* work, int M, int H) {
+    const int l = threadIdx.x & 63, count = work[1];
+    for (int item = blockIdx.x * 4 + (threadIdx.x >> 6); item < count; item += gridDim.x * 4) {
+        uint4* row = reinterpret_cast<uint4*>(plane + (size_t)work[2 + M + item] * H);
+        for (int c = l; c < (H >> 2); c += 64) row[c] = make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
-// ---------------------------------------------------------------------------------------------------- run level: fold the plane-A rows
-// run leader n folds rows run_start, run_start + 8, ... <= run_end of plane A (8 rows in flight) into part2 / parg2 at its own row
-__global__ __launch_bounds__(256) void pn_r_max_kernel(PnArgs a) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int nwaves = gridDim.x * 4, count = a.work[1], nch = a.H >> 3;
-    for (int item = blockIdx.x * 4 + w; item < count; item += nwaves) {
-        const int n = a.work[2 + a.M + item];
-        const int b = n / a.L, rs = n - b * a.L, re = a.run_end[n];
-        float S[PN_MAXCH][8]; unsigned short arg[PN_MAXCH][8];
-        pn_fill<PN_MAXCH>(S, -INFINITY);
+// one run piece of a stream -> the run's row, through a half-wave transpose in LDS: lane i holds columns i*8 .. +8 of the half's 256;
+// instruction j then covers columns j*32 + lane = one 128-B line per half-wave (the direct form touches 8 lines with 4 of 32 bytes each)
+template <typename T, typename F>
+__device__ __forceinline__ void pn_flush(T* lds_half, const T (&v)[8], int l31, T* row, int col0, int H, F atomic_op) {
+    *reinterpret_cast<uint4*>(lds_half + l31 * 8) = make_uint4(__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]),
+                                                                __builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3]));
+    *reinterpret_cast<uint4*>(lds_half + l31 * 8 + 4) = make_uint4(__builtin_bit_cast(uint32_t, v[4]), __builtin_bit_cast(uint32_t, v[5]),
+                                                                    __builtin_bit_cast(uint32_t, v[6]), __builtin_bit_cast(uint32_t, v[7]));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave: LDS operations complete in order; this also pins the compiler's order
 #pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) arg[i][e] = (unsigned short)rs;
-        for (int k0 = rs; k0 <= re; k0 += 64) {
-            float v[8][PN_MAXCH][8]; uint4 pa[8][PN_MAXCH]; bool ok[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int t = k0 + 8 * k;
-                const size_t row = (size_t)b * a.L + min(t, re);
-                ok[k] = t <= re && a.mask_bias[row] >= 0.f;              // (a padded level-A position was never written)
-                pn_load<PN_MAXCH>(a.partA + row * a.H, nch, l, v[k]);
-#pragma unroll
-                for (int i = 0; i < PN_MAXCH; ++i)
-                    if (l + 64 * i < nch) pa[k][i] = *reinterpret_cast<const uint4*>(a.pargA + row * a.H + (l + 64 * i) * 8);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (!ok[k]) continue;
-#pragma unroll
-                for (int i = 0; i < PN_MAXCH; ++i) {
-                    const uint32_t pw[4] = {pa[k][i].x, pa[k][i].y, pa[k][i].z, pa[k][i].w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (v[k][i][e] > S[i][e]) { S[i][e] = v[k][i][e]; arg[i][e] = (unsigned short)((pw[e >> 1] >> ((e & 1) * 16)) & 0xffffu); }
-                }
-            }
-        }
-        pn_store<PN_MAXCH>(a.part2 + (size_t)n * a.H, nch, l, S);
-#pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i) {
-            const int c = l + 64 * i;
-            if (c < nch) {
-                uint4 pk;
-                pk.x = arg[i][0] | ((uint32_t)arg[i][1] << 16); pk.y = arg[i][2] | ((uint32_t)arg[i][3] << 16);
-                pk.z = arg[i][4] | ((uint32_t)arg[i][5] << 16); pk.w = arg[i][6] | ((uint32_t)arg[i][7] << 16);
-                *reinterpret_cast<uint4*>(a.parg2 + (size_t)n * a.H + c * 8) = pk;
-            }
-        }
+    for (int j = 0; j < 8; ++j) {
+        const T x = lds_half[j * 32 + l31];
+        if (col0 + j * 32 + l31 < H) atomic_op(row + col0 + j * 32 + l31, x);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the image is rewritten by the next piece
 }
 
-// single-row read of the folded run maximum (row of the run leader)
-template <bool ARG>
-__device__ __forceinline__ void pn_run_max(const PnArgs& a, int b, int rs, int re, int nch, int l, float (&S)[PN_MAXCH][8],
-                                           unsigned short (&arg)[PN_MAXCH][8]) {
-    const size_t row = (size_t)b * a.L + rs;
-    pn_load<PN_MAXCH>(a.part2 + row * a.H, nch, l, S);
-    if (ARG) {
+// ---------------------------------------------------------------------------------------------------- forward 1: run maxima
+__global__ __launch_bounds__(256) void pn_segmax_kernel(PnArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t tr[4][2][256];
+    PnLane q;
+    if (!q.init(a)) return;
+    uint4 raw[8]; int rs[8]; bool ok[8];
 #pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i) {
-            const int c = l + 64 * i;
-            if (c < nch) {
-                const uint4 pk = *reinterpret_cast<const uint4*>(a.parg2 + row * a.H + c * 8);
-                const uint32_t pw[4] = {pk.x, pk.y, pk.z, pk.w};
+    for (int k = 0; k < 8; ++k) {
+        const size_t n = (size_t)min(q.n0 + k, a.M - 1);
+        ok[k] = q.tok && a.mask_bias[n] >= 0.f;            // half-wave uniform: lanes without columns still take part in the transposes
+        rs[k] = a.run_start[n];
+        raw[k] = (ok[k] && q.act) ? *reinterpret_cast<const uint4*>(a.proj + n * a.ld + 4 * a.H + q.col) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint32_t* lds_half = tr[threadIdx.x >> 6][q.half];
+    const int col0 = q.col - q.l31 * 8;
+    uint32_t key[8];
+    int cur = -1;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) arg[i][e] = (unsigned short)((pw[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-            }
+    for (int k = 0; k < 8; ++k) {
+        if (!ok[k]) continue;
+        if (rs[k] != cur) {
+            if (cur >= 0) pn_flush<uint32_t>(lds_half, key, q.l31, a.keys + (q.seq0 + cur) * a.H, col0, a.H, [](uint32_t* p, uint32_t x) { atomicMax(p, x); });
+            cur = rs[k];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) key[e] = 0u;
+        }
+        const uint32_t w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+        const uint32_t low = 0xffffu - (uint32_t)(q.p0 + k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t bits = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+            key[e] = max(key[e], (pn_ord(bits) << 16) | low);
         }
     }
+    if (cur >= 0) pn_flush<uint32_t>(lds_half, key, q.l31, a.keys + (q.seq0 + cur) * a.H, col0, a.H, [](uint32_t* p, uint32_t x) { atomicMax(p, x); });
 }
 
-// ---------------------------------------------------------------------------------------------------- forward fusion
+// the run's S (and, optionally, argmax position) for this lane's 8 columns
+__device__ __forceinline__ void pn_load_S(const PnArgs& a, size_t row, int col, float (&S)[8], int (&arg)[8]) {
+    const uint4 k0 = *reinterpret_cast<const uint4*>(a.keys + row * a.H + col), k1 = *reinterpret_cast<const uint4*>(a.keys + row * a.H + col + 4);
+    const uint32_t w[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { S[e] = pn_unord(w[e] >> 16); arg[e] = 0xffff - (int)(w[e] & 0xffffu); }
+}
+
+// ---------------------------------------------------------------------------------------------------- forward 2: fusion
 __global__ __launch_bounds__(256) void pn_combine_fwd_kernel(PnArgs a) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + w;
-    if (n >= a.M) return;
-    const int nch = a.H >> 3;
-    float out[PN_MAXCH][8];
-    if (a.mask_bias[n] < 0.f) {
-        pn_fill<PN_MAXCH>(out, 0.f);
-        pn_store<PN_MAXCH>(a.ctx + (size_t)n * a.H, nch, l, out);
-        return;
-    }
-    const int b = n / a.L, pos = n - b * a.L;
-    float S[PN_MAXCH][8]; unsigned short dummy[PN_MAXCH][8];
-    pn_run_max<false>(a, b, a.run_start[n], a.run_end[n], nch, l, S, dummy);
-    const bf16_t* prow = a.proj + (size_t)n * a.ld;
-    float ho[PN_MAXCH][8], lm[PN_MAXCH][8], t[PN_MAXCH][8];
-    pn_load<PN_MAXCH>(prow + 2 * a.H, nch, l, ho);
-    pn_load<PN_MAXCH>(prow + 3 * a.H, nch, l, lm);
-    if (pos > 0 && a.mask_bias[n - 1] >= 0.f) {
-        pn_load<PN_MAXCH>(prow - a.ld + 3 * a.H, nch, l, t);
+    PnLane q;
+    if (!q.init(a) || !q.act) return;
+    uint4 ho[8], hl[10]; int rs[8]; bool ok[10];
+    auto valid_at = [&](int p) { return p >= 0 && p < a.L && a.mask_bias[q.seq0 + p] >= 0.f; };
 #pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) lm[i][e] = fmaxf(lm[i][e], t[i][e]);
-    }
-    if (pos + 1 < a.L && a.mask_bias[n + 1] >= 0.f) {
-        pn_load<PN_MAXCH>(prow + a.ld + 3 * a.H, nch, l, t);
-#pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) lm[i][e] = fmaxf(lm[i][e], t[i][e]);
+    for (int k = 0; k < 10; ++k) {                         // Hl rows p0-1 .. p0+8
+        ok[k] = valid_at(q.p0 + k - 1);
+        hl[k] = ok[k] ? *reinterpret_cast<const uint4*>(a.proj + (q.seq0 + q.p0 + k - 1) * a.ld + 3 * a.H + q.col) : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
-    for (int i = 0; i < PN_MAXCH; ++i) {
-        const int c = l + 64 * i;
-        if (c < nch) {
-            float gv[8];
-            ld8<float>(a.g + (size_t)b * a.H + c * 8, gv);
+    for (int k = 0; k < 8; ++k) {
+        const size_t n = (size_t)q.n0 + k;
+        rs[k] = a.run_start[n];
+        ho[k] = ok[k + 1] ? *reinterpret_cast<const uint4*>(a.proj + n * a.ld + 2 * a.H + q.col) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    float gv[8], S[8]; int arg[8];
+    ld8<float>(a.g + (size_t)q.b * a.H + q.col, gv);
+    int cur = -1;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) out[i][e] = (gv[e] + S[i][e]) * ho[i][e] + lm[i][e];
+    for (int k = 0; k < 8; ++k) {
+        float out[8];
+        if (ok[k + 1]) {
+            if (rs[k] != cur) { cur = rs[k]; pn_load_S(a, q.seq0 + cur, q.col, S, arg); }
+            float h[8], x[8], y[8];
+            pn_unpack(ho[k], h); pn_unpack(hl[k + 1], x);
+            if (ok[k]) { pn_unpack(hl[k], y);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], y[e]); }
+            if (ok[k + 2]) { pn_unpack(hl[k + 2], y);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], y[e]); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = (gv[e] + S[e]) * h[e] + x[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = 0.f;
         }
+        *reinterpret_cast<uint4*>(a.ctx + ((size_t)q.n0 + k) * a.H + q.col) = pn_pack(out);
     }
-    pn_store<PN_MAXCH>(a.ctx + (size_t)n * a.H, nch, l, out);
 }
 
-// ---------------------------------------------------------------------------------------------------- backward, 8 consecutive tokens per wave
-// dHo = dctx * (g + S);  dHl_j = sum over the valid neighbours n of j (incl. j) of dctx_n * [first maximum of {Hl_{n-1}, Hl_n, Hl_{n+1}} == j];
-// E = dctx * Ho accumulated per run segment into psum rows (segment = maximal piece of a run inside this group of 8; its row = its first token)
+// ---------------------------------------------------------------------------------------------------- backward 1: token rows
+// dHo = dctx * (g + S);  dHl_j = sum over the valid neighbours m of j (incl. j) of dctx_m * [first maximum of {Hl_{m-1}, Hl_m, Hl_{m+1}} == j];
+// E = dctx * Ho summed per run piece and added into the run's G row.  Padded rows get zero gradients.
 __global__ __launch_bounds__(256) void pn_bwd_tok_kernel(PnArgs a) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int t0 = (blockIdx.x * 4 + w) * 8;                  // first token of the group (L % 8 == 0: a group never straddles sequences)
-    if (t0 >= a.M) return;
-    const int nch = a.H >> 3, b = t0 / a.L, p0 = t0 - b * a.L;
-    const size_t seq0 = (size_t)b * a.L;
-    auto valid_at = [&](int p) { return p >= 0 && p < a.L && a.mask_bias[seq0 + p] >= 0.f; };
-    // sliding windows: hl[k] = Hl row p + k - 2 (k = 0..4), dcw[k] = dctx row p + k - 1 (k = 0..2); -inf / 0 outside the valid range
-    float hl[5][PN_MAXCH][8], dcw[3][PN_MAXCH][8];
-    bool hv[5], dv[3];
+    __shared__ __attribute__((aligned(16))) float tr[4][2][256];
+    PnLane q;
+    if (!q.init(a)) return;
+    uint4 ho[8], hl[12], dc[10]; int rs[8]; bool hv[12];
+    auto valid_at = [&](int p) { return q.tok && p >= 0 && p < a.L && a.mask_bias[q.seq0 + p] >= 0.f; };       // half-wave uniform
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                              // rows p0-2 .. p0+1 (row p0+2 is loaded by the first iteration)
-        hv[k + 1] = valid_at(p0 + k - 2);
-        if (hv[k + 1]) pn_load<PN_MAXCH>(a.proj + (seq0 + p0 + k - 2) * a.ld + 3 * a.H, nch, l, hl[k + 1]); else pn_fill<PN_MAXCH>(hl[k + 1], -INFINITY);
+    for (int k = 0; k < 12; ++k) {                         // Hl rows p0-2 .. p0+9
+        hv[k] = valid_at(q.p0 + k - 2);
+        hl[k] = (hv[k] && q.act) ? *reinterpret_cast<const uint4*>(a.proj + (q.seq0 + q.p0 + k - 2) * a.ld + 3 * a.H + q.col) : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {                              // dctx rows p0-1, p0
-        dv[k + 1] = valid_at(p0 + k - 1);
-        if (dv[k + 1]) pn_load<PN_MAXCH>(a.dctx + (seq0 + p0 + k - 1) * a.H, nch, l, dcw[k + 1]); else pn_fill<PN_MAXCH>(dcw[k + 1], 0.f);
+    for (int k = 0; k < 10; ++k)                           // dctx rows p0-1 .. p0+8 (validity = hv[k + 1])
+        dc[k] = (hv[k + 1] && q.act) ? *reinterpret_cast<const uint4*>(a.dctx + (q.seq0 + q.p0 + k - 1) * a.H + q.col) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t n = (size_t)min(q.n0 + k, a.M - 1);
+        rs[k] = a.run_start[n];
+        ho[k] = (hv[k + 2] && q.act) ? *reinterpret_cast<const uint4*>(a.proj + n * a.ld + 2 * a.H + q.col) : make_uint4(0u, 0u, 0u, 0u);
     }
-    float gv[PN_MAXCH][8];
+    float gv[8], S[8], seg[8]; int arg[8];
 #pragma unroll
-    for (int i = 0; i < PN_MAXCH; ++i)
-        if (l + 64 * i < nch) ld8<float>(a.g + (size_t)b * a.H + (l + 64 * i) * 8, gv[i]);
-    float seg[PN_MAXCH][8], S[PN_MAXCH][8];
-    pn_fill<PN_MAXCH>(seg, 0.f); pn_fill<PN_MAXCH>(S, 0.f);
-    int seg_row = -1, cur_rs = -1;                             // open segment's psum row; run whose S is loaded
-    // (requesting the next token's rows one iteration ahead was tried: 126 -> 200 us, the three extra row buffers push the wave past 256 VGPRs)
-    for (int t = 0; t < 8; ++t) {
-        const int p = p0 + t;
-        const size_t n = seq0 + p;
-        // shift the windows and bring in Hl row p + 2, dctx row p + 1
+    for (int e = 0; e < 8; ++e) { gv[e] = 0.f; S[e] = 0.f; seg[e] = 0.f; }
+    if (q.act) ld8<float>(a.g + (size_t)q.b * a.H + q.col, gv);
+    float* lds_half = tr[threadIdx.x >> 6][q.half];
+    const int col0 = q.col - q.l31 * 8;
+    int cur = -1;
+    // hlf[j] = Hl row p + j - 2 as floats (-inf where invalid), slid one row per token
+    float hlf[5][8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            hv[k] = hv[k + 1];
+    for (int j = 0; j < 4; ++j) {
+        if (hv[j]) pn_unpack(hl[j], hlf[j + 1]);
+        else {
 #pragma unroll
-            for (int i = 0; i < PN_MAXCH; ++i)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) hl[k][i][e] = hl[k + 1][i][e];
+            for (int e = 0; e < 8; ++e) hlf[j + 1][e] = -INFINITY;
         }
-        hv[4] = valid_at(p + 2);
-        if (hv[4]) pn_load<PN_MAXCH>(a.proj + (n + 2) * a.ld + 3 * a.H, nch, l, hl[4]); else pn_fill<PN_MAXCH>(hl[4], -INFINITY);
+    }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            dv[k] = dv[k + 1];
+    for (int k = 0; k < 8; ++k) {
 #pragma unroll
-            for (int i = 0; i < PN_MAXCH; ++i)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dcw[k][i][e] = dcw[k + 1][i][e];
+            for (int e = 0; e < 8; ++e) hlf[j][e] = hlf[j + 1][e];
+        if (hv[k + 4]) pn_unpack(hl[k + 4], hlf[4]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hlf[4][e] = -INFINITY;
         }
-        dv[2] = valid_at(p + 1);
-        if (dv[2]) pn_load<PN_MAXCH>(a.dctx + (n + 1) * a.H, nch, l, dcw[2]); else pn_fill<PN_MAXCH>(dcw[2], 0.f);
-        float ho[PN_MAXCH][8];
-        pn_load<PN_MAXCH>(a.proj + n * a.ld + 2 * a.H, nch, l, ho);
-        bf16_t* drow = a.dproj + n * a.ld;
-        if (!hv[2]) {                                          // padded token: zero gradients, close the open segment
-            float z[PN_MAXCH][8];
-            pn_fill<PN_MAXCH>(z, 0.f);
-            pn_store<PN_MAXCH>(drow + 2 * a.H, nch, l, z); pn_store<PN_MAXCH>(drow + 3 * a.H, nch, l, z); pn_store<PN_MAXCH>(drow + 4 * a.H, nch, l, z);
-            if (seg_row >= 0) {
-#pragma unroll
-                for (int i = 0; i < PN_MAXCH; ++i)
-                    if (l + 64 * i < nch) st8<float>(a.psum + (seq0 + seg_row) * a.H + (l + 64 * i) * 8, seg[i]);
-                seg_row = -1;
+        if (!q.tok) continue;
+        bf16_t* drow = a.dproj + ((size_t)q.n0 + k) * a.ld + q.col;
+        if (!hv[k + 2]) {                                  // padded token: zero gradients
+            if (q.act) {
+                *reinterpret_cast<uint4*>(drow + 2 * a.H) = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(drow + 3 * a.H) = make_uint4(0u, 0u, 0u, 0u);
             }
             continue;
         }
-        const int rs = a.run_start[n];
-        if (rs != cur_rs) {                                    // new run: flush the open segment, load the run's S row
-            if (seg_row >= 0) {
+        if (rs[k] != cur) {
+            if (cur >= 0) pn_flush<float>(lds_half, seg, q.l31, a.G + (q.seq0 + cur) * a.H, col0, a.H, [](float* p, float x) { atomicAdd(p, x); });
+            cur = rs[k];
+            if (q.act) pn_load_S(a, q.seq0 + cur, q.col, S, arg);
 #pragma unroll
-                for (int i = 0; i < PN_MAXCH; ++i)
-                    if (l + 64 * i < nch) st8<float>(a.psum + (seq0 + seg_row) * a.H + (l + 64 * i) * 8, seg[i]);
-            }
-            pn_fill<PN_MAXCH>(seg, 0.f);
-            seg_row = p; cur_rs = rs;
-            pn_load<PN_MAXCH>(a.part2 + (seq0 + rs) * a.H, nch, l, S);
-        } else if (seg_row < 0) { pn_fill<PN_MAXCH>(seg, 0.f); seg_row = p; }
-        float o1[PN_MAXCH][8], dl[PN_MAXCH][8];
-        pn_fill<PN_MAXCH>(dl, 0.f);
+            for (int e = 0; e < 8; ++e) seg[e] = 0.f;
+        }
+        float d[3][8], h[8], o1[8], dl[8];
+        pn_unpack(dc[k], d[0]); pn_unpack(dc[k + 1], d[1]); pn_unpack(dc[k + 2], d[2]);        // dctx of the neighbours p-1, p, p+1 (0 where invalid)
+        pn_unpack(ho[k], h);
 #pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i)
+        for (int e = 0; e < 8; ++e) {
+            o1[e] = d[1][e] * (gv[e] + S[e]);
+            seg[e] += d[1][e] * h[e];
+            dl[e] = 0.f;
+        }
+        // neighbour m = p + j - 1 (j = 0..2) has the window hlf[j], hlf[j+1], hlf[j+2]; this token is hlf[2]
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (!hv[k + 1 + j]) continue;                  // the neighbour itself must be a valid token
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float d = dcw[1][i][e];
-                o1[i][e] = d * (gv[i][e] + S[i][e]);
-                seg[i][e] += d * ho[i][e];
+                const float x0 = hlf[j][e], x1 = hlf[j + 1][e], x2 = hlf[j + 2][e];
+                const int am = (x0 >= x1 && x0 >= x2) ? j : ((x1 >= x2) ? j + 1 : j + 2);      // first maximum of the window
+                if (am == 2) dl[e] += d[j][e];
             }
-        // local max-pool backward: neighbour m = p + k - 1 (k = 0..2) has the window hl[k], hl[k+1], hl[k+2]; this token is hl[2]
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (!hv[k + 1]) continue;                          // the neighbour itself must be a valid token
-#pragma unroll
-            for (int i = 0; i < PN_MAXCH; ++i)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float x0 = hl[k][i][e], x1 = hl[k + 1][i][e], x2 = hl[k + 2][i][e];
-                    const int am = (x0 >= x1 && x0 >= x2) ? k : ((x1 >= x2) ? k + 1 : k + 2);      // first maximum of the window
-                    if (am == 2) dl[i][e] += dcw[k][i][e];
-                }
         }
-        pn_store<PN_MAXCH>(drow + 2 * a.H, nch, l, o1);
-        pn_store<PN_MAXCH>(drow + 3 * a.H, nch, l, dl);
+        if (q.act) {
+            *reinterpret_cast<uint4*>(drow + 2 * a.H) = pn_pack(o1);
+            *reinterpret_cast<uint4*>(drow + 3 * a.H) = pn_pack(dl);
+        }
     }
-    if (seg_row >= 0) {
-#pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i)
-            if (l + 64 * i < nch) st8<float>(a.psum + (seq0 + seg_row) * a.H + (l + 64 * i) * 8, seg[i]);
-    }
+    if (cur >= 0) pn_flush<float>(lds_half, seg, q.l31, a.G + (q.seq0 + cur) * a.H, col0, a.H, [](float* p, float x) { atomicAdd(p, x); });
 }
 
-// run leader: G = sum of the run's segment rows (run_start and every later multiple of 8 up to run_end) -> psum2[leader]; dg[b] += G
-__global__ __launch_bounds__(256) void pn_r_sum_kernel(PnArgs a) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int nwaves = gridDim.x * 4, count = a.work[1], nch = a.H >> 3;
-    for (int item = blockIdx.x * 4 + w; item < count; item += nwaves) {
-        const int n = a.work[2 + a.M + item];
-        const int b = n / a.L, rs = n - b * a.L, re = a.run_end[n];
-        float G[PN_MAXCH][8];
-        pn_fill<PN_MAXCH>(G, 0.f);
-        for (int k = rs; k <= re; k = (k & ~7) + 8) {
-            const size_t row = (size_t)b * a.L + k;
-            if (a.mask_bias[row] < 0.f) continue;              // (runs of valid tokens never contain padding; defensive)
-#pragma unroll
-            for (int i = 0; i < PN_MAXCH; ++i) {
-                const int c = l + 64 * i;
-                if (c < nch) {
-                    float v[8];
-                    ld8<float>(a.psum + row * a.H + c * 8, v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) G[i][e] += v[e];
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < PN_MAXCH; ++i) {
-            const int c = l + 64 * i;
-            if (c < nch) {
-                st8<float>(a.psum2 + (size_t)n * a.H + c * 8, G[i]);
-                if (a.dg)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) atomicAdd(a.dg + (size_t)b * a.H + c * 8 + e, G[i][e]);
-            }
-        }
-    }
-}
-
-// dHs_j = [argmax of j's run == j] * (sum of E over the run)
+// ---------------------------------------------------------------------------------------------------- backward 2: routing
+// dHs_j = [argmax of j's run == j] * G(run);  every run start also adds its G row into dg
 __global__ __launch_bounds__(256) void pn_bwd_route_kernel(PnArgs a) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + w;
-    if (j >= a.M || a.mask_bias[j] < 0.f) return;                       // padded rows were zeroed by pn_bwd_token_kernel
-    const int b = j / a.L, pos = j - b * a.L, rs = a.run_start[j], re = a.run_end[j], nch = a.H >> 3;
-    float S[PN_MAXCH][8]; unsigned short arg[PN_MAXCH][8];
+    __shared__ __attribute__((aligned(16))) float tr[4][2][256];
+    PnLane q;
+    if (!q.init(a)) return;
+    float S[8], G[8]; int arg[8];
 #pragma unroll
-    for (int i = 0; i < PN_MAXCH; ++i)
+    for (int e = 0; e < 8; ++e) { G[e] = 0.f; arg[e] = -1; }
+    float* lds_half = tr[threadIdx.x >> 6][q.half];
+    const int col0 = q.col - q.l31 * 8;
+    int cur = -1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) arg[i][e] = 0xffffu;
-    pn_run_max<true>(a, b, rs, re, nch, l, S, arg);
-    float G[PN_MAXCH][8];
-    pn_fill<PN_MAXCH>(G, 0.f);
+    for (int k = 0; k < 8; ++k) {
+        if (!q.tok) continue;
+        const size_t n = (size_t)q.n0 + k;
+        const int rs = a.run_start[n], pos = q.p0 + k;
+        float out[8];
 #pragma unroll
-    for (int i = 0; i < PN_MAXCH; ++i) {
-        const int c = l + 64 * i;
-        if (c < nch) ld8<float>(a.psum2 + ((size_t)b * a.L + rs) * a.H + c * 8, G[i]);
+        for (int e = 0; e < 8; ++e) out[e] = 0.f;
+        if (rs != cur) {
+            cur = rs;
+            if (q.act) { pn_load_S(a, q.seq0 + cur, q.col, S, arg); ld8<float>(a.G + (q.seq0 + cur) * a.H + q.col, G); }
+        }
+        if (pos == rs && a.dg) pn_flush<float>(lds_half, G, q.l31, a.dg + (size_t)q.b * a.H, col0, a.H, [](float* p, float x) { atomicAdd(p, x); });
+        if (a.mask_bias[n] >= 0.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = arg[e] == pos ? G[e] : 0.f;
+        }
+        if (q.act) *reinterpret_cast<uint4*>(a.dproj + n * a.ld + 4 * a.H + q.col) = pn_pack(out);
     }
-    float out[PN_MAXCH][8];
-#pragma unroll
-    for (int i = 0; i < PN_MAXCH; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) out[i][e] = (arg[i][e] == (unsigned short)pos) ? G[i][e] : 0.f;
-    pn_store<PN_MAXCH>(a.dproj + (size_t)j * a.ld + 4 * a.H, nch, l, out);
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers
 static int pn_check(int B, int L, int H, int ld) {
-    if (B <= 0 || L <= 0 || L > 65535 || (L % 8) || H <= 0 || (H % 8) || H > 8 * 64 * PN_MAXCH || ld < 5 * H || (ld % 8)) return AMDSEG_ERR_SHAPE;
+    if (B <= 0 || L <= 0 || L > 65535 || (L % 8) || H <= 0 || (H % 8) || ld < 5 * H || (ld % 8)) return AMDSEG_ERR_SHAPE;
     return AMDSEG_OK;
 }
-#define PN_PERSIST_BLOCKS 512           // 2048 waves = what the chip holds at ~180 VGPRs per wave (2 per SIMD): no second round of launches
+static int pn_grid(int M, int H) { return ((M + 15) / 16 * ((H + 255) / 256) + 3) / 4; }
 
 int amdseg_ponet_plan_impl(const float* mask_bias, const int* run_start, int* work, int B, int L, hipStream_t s) {
     if (!mask_bias || !run_start || !work) return AMDSEG_ERR_ARG;
@@ -430,44 +339,42 @@ int amdseg_ponet_plan_impl(const float* mask_bias, const int* run_start, int* wo
     hipError_t e = hipMemsetAsync(work, 0, 2 * sizeof(int), s);
     if (e != hipSuccess) return (int)e;
     const int M = B * L;
-    hipLaunchKernelGGL(pn_plan_kernel, dim3((M + 255) / 256), dim3(256), 0, s, mask_bias, run_start, work, M, L);
+    hipLaunchKernelGGL(pn_plan_kernel, dim3((M + 255) / 256), dim3(256), 0, s, run_start, work, M, L);
     return amdseg_launch_status();
 }
 
 int amdseg_ponet_pool_fwd_impl(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,
                                const float* g, void* part, void* parg, void* ctx, int B, int L, int H, hipStream_t s) {
-    // part / parg hold TWO [M, H] planes each: folded run-leader rows (read by every token of the run, and by backward), level-A rows
-    if (!proj || !mask_bias || !run_start || !run_end || !work || !g || !part || !parg || !ctx) return AMDSEG_ERR_ARG;
+    // part: [M, H] 32-bit keys (run maximum | argmax) in the rows of the run starts, read again by backward; parg: unused since round 2
+    if (!proj || !mask_bias || !run_start || !work || !g || !part || !ctx) return AMDSEG_ERR_ARG;
+    (void)run_end; (void)parg;
     int rc = pn_check(B, L, H, ld);
     if (rc) return rc;
     PnArgs a = {};
-    a.proj = (const bf16_t*)proj; a.ld = ld; a.mask_bias = mask_bias; a.run_start = run_start; a.run_end = run_end; a.g = g; a.work = work;
-    a.ctx = (bf16_t*)ctx; a.M = B * L; a.L = L; a.H = H;
-    a.part2 = (bf16_t*)part; a.parg2 = (unsigned short*)parg;
-    a.partA = a.part2 + (size_t)a.M * H; a.pargA = a.parg2 + (size_t)a.M * H;
-    const int pb = std::min(PN_PERSIST_BLOCKS, (a.M + 3) / 4);
-    hipLaunchKernelGGL(pn_a_max_kernel, dim3(pb), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(pn_r_max_kernel, dim3(pb), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(pn_combine_fwd_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
+    a.proj = (const bf16_t*)proj; a.ld = ld; a.mask_bias = mask_bias; a.run_start = run_start; a.g = g; a.work = work;
+    a.ctx = (bf16_t*)ctx; a.M = B * L; a.L = L; a.H = H; a.keys = (uint32_t*)part;
+    hipLaunchKernelGGL(pn_zero_kernel, dim3(std::min(512, (a.M + 3) / 4)), dim3(256), 0, s, a.keys, work, a.M, H);
+    hipLaunchKernelGGL(pn_segmax_kernel, dim3(pn_grid(a.M, H)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pn_combine_fwd_kernel, dim3(pn_grid(a.M, H)), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }
 
 int amdseg_ponet_pool_bwd_impl(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,
                                const float* g, const void* part, const void* parg, const void* dctx, void* dproj, float* dg, float* psum,
                                int B, int L, int H, hipStream_t s) {
-    // psum: two [M, H] fp32 planes (segment rows, folded run-leader rows); dg [B, H] is ZEROED here and receives the per-sequence sum of dctx * Ho
-    if (!proj || !mask_bias || !run_start || !run_end || !work || !g || !part || !parg || !dctx || !dproj || !dg || !psum) return AMDSEG_ERR_ARG;
+    // psum: [M, H] fp32, the run sums G in the rows of the run starts; dg [B, H] is ZEROED here and receives the per-sequence sum of dctx * Ho
+    if (!proj || !mask_bias || !run_start || !work || !g || !part || !dctx || !dproj || !dg || !psum) return AMDSEG_ERR_ARG;
+    (void)run_end; (void)parg;
     int rc = pn_check(B, L, H, ld);
     if (rc) return rc;
     PnArgs a = {};
-    a.proj = (const bf16_t*)proj; a.ld = ld; a.mask_bias = mask_bias; a.run_start = run_start; a.run_end = run_end; a.g = g; a.work = work;
-    a.dctx = (const bf16_t*)dctx; a.dproj = (bf16_t*)dproj; a.psum = psum; a.dg = dg; a.M = B * L; a.L = L; a.H = H;
-    a.part2 = (bf16_t*)part; a.parg2 = (unsigned short*)parg; a.psum2 = psum + (size_t)a.M * H;
+    a.proj = (const bf16_t*)proj; a.ld = ld; a.mask_bias = mask_bias; a.run_start = run_start; a.g = g; a.work = work;
+    a.dctx = (const bf16_t*)dctx; a.dproj = (bf16_t*)dproj; a.G = psum; a.dg = dg; a.M = B * L; a.L = L; a.H = H;
+    a.keys = (uint32_t*)part;
     hipError_t e = hipMemsetAsync(dg, 0, (size_t)B * H * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
-    const int pb = std::min(PN_PERSIST_BLOCKS, (a.M + 3) / 4);
-    hipLaunchKernelGGL(pn_bwd_tok_kernel, dim3((a.M / 8 + 3) / 4), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(pn_r_sum_kernel, dim3(pb), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(pn_bwd_route_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pn_zero_kernel, dim3(std::min(512, (a.M + 3) / 4)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(a.G), work, a.M, H);
+    hipLaunchKernelGGL(pn_bwd_tok_kernel, dim3(pn_grid(a.M, H)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pn_bwd_route_kernel, dim3(pn_grid(a.M, H)), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }
