@@ -133,11 +133,13 @@ int amdseg_lf_dx_update_ld(void* dx, int ldx, int assign, const float* coefA, co
  * alimeeting4mug/src/models/modeling_ponet.py:68-79 (source NOT in the reference tree: semantics = oracle/ponet_oracle.py,
  * parity unpinned).  proj [B*L, ld >= 5H] bf16 = (Hq | Hk | Ho | Hl | Hs); run_start / run_end [B*L] int32 = first / last
  * position (within the sequence) of the token's segment run (segment_ids non-decreasing, padding constant per run);
- * g [B, H] fp32 global aggregate.  amdseg_ponet_plan builds, once per batch, the two work lists of the kernels in `work` (int32
- * [2 + 2*B*L]: #level-A leaders, #run leaders, the two lists) from the mask and run_start.  part / parg [2, B*L, H] bf16 / uint16 scratch
- * (folded run-leader rows, 8-token partial rows) written by forward and read by backward; forward writes ctx [B*L, H]; backward writes the
- * Ho, Hl, Hs column blocks of dproj [B*L, ld] and dg [B, H] = per-sequence sum of dctx * Ho (the gradient of g), using psum [2, B*L, H]
- * fp32 scratch.  L <= 65535, L % 8 == 0, H <= 1024. */
+ * g [B, H] fp32 global aggregate.  amdseg_ponet_plan builds, once per batch, the list of run starts in `work` (int32 [2 + 2*B*L]:
+ * work[1] = number of runs, work[2 + B*L ..) = token index of every run's first token) from run_start.  part = [B*L, H] 32-bit words:
+ * forward leaves, in the row of a run's first token, key = order-preserving image of the bf16 run maximum << 16 | (0xFFFF - argmax
+ * position) per column (folded with atomicMax: deterministic), read again by backward; parg is unused (kept for call compatibility, may
+ * be NULL); forward writes ctx [B*L, H]; backward writes the Ho, Hl, Hs column blocks of dproj [B*L, ld] and dg [B, H] = per-sequence
+ * sum of dctx * Ho (the gradient of g; zeroed here), using psum = [B*L, H] fp32 scratch (run sums, fp32 atomicAdd: run-to-run differences
+ * in the last bit).  run_end is not read.  L <= 65535, L % 8 == 0, H % 8 == 0. */
 int amdseg_ponet_plan(const float* mask_bias, const int* run_start, int* work, int B, int L, amdseg_stream_t stream);
 int amdseg_ponet_pool_fwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,
                           const float* g, void* part, void* parg, void* ctx, int B, int L, int H, amdseg_stream_t stream);

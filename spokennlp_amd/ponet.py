@@ -104,12 +104,15 @@ class PoNetEncoderEngine(BertEncoderEngine):
         if "pn" not in A:
             M, H, dev = B * Lseq, self.H, self.device
             nsave = self.nlayers if train else 1
-            A["pn"] = dict(part=[torch.empty(3 * M, H, dtype=torch.bfloat16, device=dev) for _ in range(nsave)],
-                           parg=[torch.empty(3 * M, H, dtype=torch.int16, device=dev) for _ in range(nsave)],
+            # part: the [M, H] 32-bit run-maximum keys of a layer (value | argmax, csrc/ponet.hip), kept for backward; parg: unused since the
+            # key layout (one dummy shared by all layers keeps the C-ABI call shape)
+            dummy = torch.empty(8, H, dtype=torch.int16, device=dev)
+            A["pn"] = dict(part=[torch.empty(2 * M, H, dtype=torch.bfloat16, device=dev) for _ in range(nsave)],
+                           parg=[dummy for _ in range(nsave)],
                            lf_partials=torch.empty(B * (Lseq // 64) * self.heads * H, dtype=torch.float32, device=dev),
                            vt=torch.empty(B * H * 32, dtype=torch.bfloat16, device=dev))
             if train:
-                A["pn"].update(E=torch.empty(M, H, dtype=torch.bfloat16, device=dev), psum=torch.empty(3 * M, H, dtype=torch.float32, device=dev),
+                A["pn"].update(E=torch.empty(M, H, dtype=torch.bfloat16, device=dev), psum=torch.empty(M, H, dtype=torch.float32, device=dev),
                                zeros=torch.zeros(B, 1, Lseq, dtype=torch.float32, device=dev))
         return A
 
