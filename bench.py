@@ -329,7 +329,8 @@ def via_trainer(args, device, nsteps=30, nwarm=8, nan_filter=False):
     return dict(value=round(args.seqs_per_gpu * nsteps / dt, 1), unit="seq/s", ms_per_step=round(dt / nsteps * 1e3, 3), steps=nsteps,
                 logging_nan_inf_filter=nan_filter,
                 surface="spokennlp_amd.trainer.Trainer(transformers.Trainer): default collator + dataloader, fused AdamW, HIP grad norm; "
-                        "logging_nan_inf_filter=True (the TrainingArguments default) makes Trainer read the loss on the host every step")
+                        "logging_nan_inf_filter=True (the TrainingArguments default) is evaluated on the device by the subclass (the stock loop "
+                        "reads the loss on the host every step)")
 
 
 def main():

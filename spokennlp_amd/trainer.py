@@ -157,6 +157,28 @@ class Trainer(transformers.Trainer):
         super().__init__(*args, **kwargs)
         self.amdseg_native = self.amdseg_native and hasattr(self.model, "engine")
 
+    def training_step(self, model, inputs, num_items_in_batch=None):
+        """`logging_nan_inf_filter` (a TrainingArguments default) makes the stock loop evaluate `torch.isnan(loss) or torch.isinf(loss)` in
+        Python once per step ([hf] trainer.py, `_inner_training_loop`): a host read of a device scalar that drains the launch queue
+        (bert-base: 19.0 vs 16.0 ms per step).  The same substitution -- a non-finite step loss is replaced, for the LOGGED running loss
+        only, by the average since the last log -- is done here on the device and the host-side check is switched off for this run."""
+        loss = super().training_step(model, inputs, num_items_in_batch)
+        if self.amdseg_native and hasattr(self, "_tr_loss") and hasattr(self, "_globalstep_last_logged"):
+            if self.args.logging_nan_inf_filter:
+                self.args.logging_nan_inf_filter = False
+                self._amdseg_nan_filter = True
+            if getattr(self, "_amdseg_nan_filter", False):
+                loss = filter_nonfinite(loss, self._tr_loss, 1 + self.state.global_step - self._globalstep_last_logged)
+        return loss
+
+    def train(self, *args, **kwargs):
+        try:
+            return super().train(*args, **kwargs)
+        finally:
+            if getattr(self, "_amdseg_nan_filter", False):         # hand the caller's TrainingArguments back unchanged
+                self.args.logging_nan_inf_filter = True
+                self._amdseg_nan_filter = False
+
     def _fused(self):
         opt = self.optimizer
         while opt is not None and not isinstance(opt, AmdsegFusedAdamW) and hasattr(opt, "optimizer"):
@@ -194,6 +216,13 @@ class Trainer(transformers.Trainer):
         if opt is None or grad_norm is not None:
             return super()._get_grad_norm(model, grad_norm=grad_norm)
         return opt.grad_norm(float("inf"))
+
+
+def filter_nonfinite(loss, tr_loss, steps_since_log):
+    """device-side form of the stock loop's `logging_nan_inf_filter` branch: tr_loss += tr_loss / steps_since_log when the step loss
+    is nan / inf, += loss otherwise -- returned as the value to add"""
+    avg = (tr_loss / steps_since_log).to(device=loss.device, dtype=loss.dtype)
+    return torch.where(torch.isfinite(loss), loss, avg)
 
 
 @contextlib.contextmanager

@@ -116,3 +116,15 @@ def test_alimeeting_challenge_scoring():
     assert m1["x_1-pk"] == 1.0 and m1["x_avg_pred_cnt"] == 1.0
     assert abs(out["score"] - E.topic_segment_score(0.5, out["test_1-pk"], out["test_1-wd"])) < 1e-12
     assert 0.0 <= out["test_1-pk"] <= 1.0
+
+
+def test_trainer_device_side_nan_filter_matches_the_stock_formula():
+    """spokennlp_amd.trainer.filter_nonfinite == the `logging_nan_inf_filter` branch of transformers.Trainer._inner_training_loop:
+    a nan / inf step loss adds tr_loss / (1 + global_step - last_logged), a finite one adds itself"""
+    import torch
+    from spokennlp_amd.trainer import filter_nonfinite
+    tr_loss = torch.tensor(6.0)
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        assert float(filter_nonfinite(torch.tensor(bad), tr_loss, 3)) == 2.0
+    assert float(filter_nonfinite(torch.tensor(1.25), tr_loss, 3)) == 1.25
+    assert filter_nonfinite(torch.tensor(1.0, dtype=torch.bfloat16), tr_loss, 4).dtype == torch.bfloat16

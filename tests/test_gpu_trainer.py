@@ -224,3 +224,43 @@ def test_fused_trainer_native_dp_two_ranks(dev, tmp_path):
         if k in sd:
             moved = max(moved, (a[k] - sd[k]).abs().max().item())
     assert moved > 1e-4
+
+
+def test_nan_inf_filter_runs_on_the_device_and_logs_like_the_stock_loop(dev, tmp_path):
+    """`logging_nan_inf_filter=True` (the TrainingArguments default): the subclass substitutes non-finite step losses on the device
+    (no host read per step) and hands the arguments back unchanged; with a NaN injected from the 3rd micro-batch on, every logged
+    loss equals the stock loop's"""
+    from transformers import Trainer as HFTrainer, default_data_collator
+    from spokennlp_amd.trainer import Trainer
+    z, sd, batch, arch = load_case("tiny_L64")
+    flags = flags_of(z, "train_full")
+    ds = _DS(_samples(arch))
+    logs = {}
+    for name, base in (("stock", HFTrainer), ("fused", Trainer)):
+        class Inject(base):
+            calls = 0
+            seen_flag = []
+
+            def compute_loss(self, model, inputs, *a, **kw):
+                out = super().compute_loss(model, inputs, *a, **kw)
+                type(self).calls += 1
+                type(self).seen_flag.append(self.args.logging_nan_inf_filter)
+                if type(self).calls >= 3:
+                    out = (out[0] * float("nan"),) + tuple(out[1:]) if isinstance(out, tuple) else out * float("nan")
+                return out
+
+        m = build_model(arch, flags, sd, dev)
+        random.seed(3)
+        args = _args(tmp_path / name)
+        assert args.logging_nan_inf_filter
+        tr = Inject(model=m, args=args, train_dataset=ds, data_collator=default_data_collator)
+        out = tr.train()
+        assert args.logging_nan_inf_filter                       # handed back unchanged
+        if name == "fused":
+            assert Inject.seen_flag[0] and not any(Inject.seen_flag[1:])      # switched off inside the first training step
+        logs[name] = [h["loss"] for h in tr.state.log_history if "loss" in h]
+        logs[name + "_final"] = out.training_loss
+    assert len(logs["stock"]) == len(logs["fused"]) == 4
+    for a, b in zip(logs["stock"], logs["fused"]):
+        assert math.isfinite(a) and math.isfinite(b) and abs(a - b) <= 2e-3 * max(1.0, abs(a)), logs
+    assert abs(logs["stock_final"] - logs["fused_final"]) <= 2e-3 * max(1.0, abs(logs["stock_final"]))
