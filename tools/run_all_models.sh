@@ -1,0 +1,18 @@
+#!/bin/bash
+# secondary configurations of the bench in one GPU-box session -> gpurun_out/<tag>_models.txt (one JSON line each, trimmed)
+TAG=${1:-r02}
+OUT=gpurun_out/${TAG}_models.txt
+: > $OUT
+run() { echo "## bench.py $*" >> $OUT; python bench.py --no-cpu-baseline --no-via-trainer "$@" 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+r=d.get('roofline') or {}
+print(json.dumps({k:d.get(k) for k in ('metric','value','ms_per_step','dtype','mfma_frac_whole_step')} | {'roofline_frac': r.get('frac'), 'pool_roofline': (d.get('pool_roofline') or {}).get('frac')}))" >> $OUT; }
+run --mode infer --steps 40 --warmup 10
+run --mode infer --precision fp32 --steps 10 --warmup 3
+run --precision parity --steps 10 --warmup 3
+run --model longformer --steps 10 --warmup 3
+run --model ponet --steps 10 --warmup 3
+run --model bigbird --steps 10 --warmup 3
+run --workload plain --steps 40 --warmup 10
+cat $OUT
