@@ -37,11 +37,53 @@ def make_inputs(B, L, seed, long_run=False):
 
 @pytest.mark.parametrize("B,L,long_run", [(2, 64, False), (2, 256, True)])
 def test_pooling_kernels_vs_oracle(dev, B, L, long_run):
+    _, am, seg, _ = make_inputs(B, L, 3, long_run)
+    _check_pooling(dev, B, L, 128, 2, am, seg)
+
+
+def _runs(B, L, lengths):
+    """segment ids from a repeating list of run lengths"""
+    seg = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        pos, s, i = 0, 0, b
+        while pos < L:
+            ln = lengths[i % len(lengths)]
+            seg[b, pos:pos + ln] = s
+            pos, s, i = pos + ln, s + 1, i + 1
+    return seg
+
+
+@pytest.mark.parametrize("case", ["L24_straddle", "H320", "left_pad", "one_run", "unit_runs", "H64"])
+def test_pooling_kernels_structure_cases(dev, case):
+    """the paths of the round-2 pooling layout that regular inputs do not reach: streams / workgroups that straddle sequences (L % 16,
+    L % 64 != 0), column groups that are not full (H % 256 != 0), a run whose first token is padded, one run per sequence (every stream
+    boundary piece merges), one-token runs (every piece is interior), H smaller than the meta-data lanes"""
+    torch.manual_seed(5)
+    if case == "L24_straddle":
+        B, L, H = 5, 24, 128
+        seg = _runs(B, L, [5, 9, 3, 7]); am = torch.ones(B, L, dtype=torch.long); am[1, 17:] = 0; am[3, 20:] = 0
+    elif case == "H320":
+        B, L, H = 2, 64, 320
+        seg = _runs(B, L, [11, 6, 20]); am = torch.ones(B, L, dtype=torch.long); am[0, 50:] = 0
+    elif case == "left_pad":
+        B, L, H = 2, 64, 128
+        seg = _runs(B, L, [16, 10, 25]); am = torch.ones(B, L, dtype=torch.long); am[0, :5] = 0; am[1, :18] = 0; am[1, 60:] = 0
+    elif case == "one_run":
+        B, L, H = 2, 512, 128
+        seg = torch.zeros(B, L, dtype=torch.long); am = torch.ones(B, L, dtype=torch.long); am[1, 300:] = 0
+    elif case == "unit_runs":
+        B, L, H = 2, 128, 128
+        seg = torch.arange(L).expand(B, L).clone(); am = torch.ones(B, L, dtype=torch.long); am[0, 100:] = 0
+    else:
+        B, L, H = 2, 64, 64
+        seg = _runs(B, L, [7, 13]); am = torch.ones(B, L, dtype=torch.long); am[1, 40:] = 0
+    _check_pooling(dev, B, L, H, H // 64, am, seg)
+
+
+def _check_pooling(dev, B, L, H, nh, am, seg):
     from oracle import ponet_oracle as PO
     from spokennlp_amd import ops
     torch.manual_seed(L)
-    H, nh = 128, 2
-    _, am, seg, _ = make_inputs(B, L, 3, long_run)
     proj = torch.randn(B * L, 5 * H).bfloat16()
     hq, hk, ho, hl, hs = [proj[:, k * H:(k + 1) * H].float().view(B, L, H).requires_grad_(True) for k in range(5)]
     valid = am == 1
