@@ -109,14 +109,30 @@ __device__ __forceinline__ void attn_xcd_remap(int& rb, int& h, int& b, int head
     rb = t % nrb; h = bh % heads; b = bh / heads;
 }
 
+// The 1-D launches (block lists, band dK/dV): workgroup id -> (rank r of the row block inside its pair, (batch, head) pair) such that one XCD
+// (ids = xcd mod 8, in dispatch order) works through ONE pair at a time, its longest blocks first.  The previous rank-major order (all pairs
+// at rank r before rank r + 1) kept 12 pairs' K / V (or Q / dO) in flight per XCD -- 12 MB against a 4-MB L2 -- and the band dK/dV order
+// put neighbouring key blocks, which stream the same Q / dO chunks, on 8 different XCDs: PMC FETCH_SIZE 1.07 GB per launch against 0.2 GB
+// of distinct data at L = 4096 (profiles/r02_pmc_longformer.txt).
+// The `nfirst` longest blocks of EVERY pair (the global key block of the band, the two global blocks of a block list: 6-8 x the work of the
+// others) still go out first, rank-major, so that they run under the short ones instead of forming a tail (pair-at-a-time for all ranks:
+// 251 -> 237 seq/s at longformer-base although the traffic fell); pair bh sits on XCD bh % 8 in both parts.
+__device__ __forceinline__ void attn_1d_order(int id, int nblk, int nbh, int nfirst, int& r, int& bh) {
+    if ((nbh & 7) || id < nfirst * nbh) { r = id / nbh; bh = id - r * nbh; return; }
+    id -= nfirst * nbh;
+    const int xcd = id & 7, t = id >> 3, rest = nblk - nfirst;
+    r = nfirst + t % rest; bh = (t / rest) * 8 + xcd;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int NW, bool BAND, bool LIST = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    if (LIST) {                                             // 1-D launch, rank-major: the longest lists of every (b, h) are dispatched first
-        const int nbh = a.heads * a.B, r = blockIdx.x / nbh, bh = blockIdx.x % nbh;
+    if (LIST) {                                             // 1-D launch: one (b, h) at a time per XCD, its longest lists first
+        int r, bh;
+        attn_1d_order(blockIdx.x, a.L / (NW * 16), a.heads * a.B, 2, r, bh);
         h = bh % a.heads; b = bh / a.heads;
         qb = a.korder ? a.korder[h * (a.L / CH) + r] : r;
     } else attn_xcd_remap(qb, h, b, a.heads);
@@ -324,8 +340,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    if (LIST) {                                             // 1-D launch, rank-major: the longest lists of every (b, h) are dispatched first
-        const int nbh = a.heads * a.B, r = blockIdx.x / nbh, bh = blockIdx.x % nbh;
+    if (LIST) {                                             // 1-D launch: one (b, h) at a time per XCD, its longest lists first
+        int r, bh;
+        attn_1d_order(blockIdx.x, a.L / (NW * 16), a.heads * a.B, 2, r, bh);
         h = bh % a.heads; b = bh / a.heads;
         qb = a.korder ? a.korder[h * (a.L / CH) + r] : r;
     } else attn_xcd_remap(qb, h, b, a.heads);
@@ -504,14 +521,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         // 1-D launch.  The key block holding the global keys sees EVERY query chunk (L/64 instead of ~2W/64 + 1): those
         // B*heads long workgroups come first in dispatch order and land round-robin on all XCDs, so they overlap the
         // short ones instead of forming a tail on one XCD (block ids = 0 mod 64 all map to XCD 0 in a 3-D launch).
-        const int nkb = a.L / (NW * 16), nbh = a.heads * a.B, id = blockIdx.x;
+        // Round 2: one (b, h) at a time per XCD (attn_1d_order), its global key block first; the long workgroup then runs under the
+        // next pairs' short ones.
         int bh;
-        if (id < nbh) { kb = 0; bh = id; }
-        else { const int r = id - nbh; kb = 1 + r % (nkb - 1); bh = r / (nkb - 1); }
+        attn_1d_order(blockIdx.x, a.L / (NW * 16), a.heads * a.B, 1, kb, bh);
         h = bh % a.heads; b = bh / a.heads;
     }
-    if (LIST) {                                             // 1-D launch, rank-major: the longest lists first
-        const int nbh = a.heads * a.B, r = blockIdx.x / nbh, bh2 = blockIdx.x % nbh;
+    if (LIST) {                                             // 1-D launch: one (b, h) at a time per XCD, its longest lists first
+        int r, bh2;
+        attn_1d_order(blockIdx.x, a.L / (NW * 16), a.heads * a.B, 2, r, bh2);
         h = bh2 % a.heads; b = bh2 / a.heads;
         kb = a.qorder ? a.qorder[h * (a.L / CH) + r] : r;
     }
