@@ -305,11 +305,25 @@ __device__ __forceinline__ void pa2_stage(float (*dst)[PA2_LD], const float* src
 __device__ __forceinline__ float pa2_max_g(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float pa2_sum_g(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
+
+// XCD-aware placement (as attn_xcd_remap in attention.hip): the row blocks of one (batch, head) stream the same fp32 K / V (or Q / dO) rows;
+// workgroup ids xcd, xcd + 8, ... (one XCD, in dispatch order) walk one pair's row blocks before the next pair
+__device__ __forceinline__ void pa2_xcd_remap(int& rb, int& h, int& b) {
+    const int nrb = gridDim.x, heads = gridDim.y, nbh = gridDim.y * gridDim.z;
+    rb = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
+    if (nbh & 7) return;
+    const int id = blockIdx.x + nrb * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = id & 7, t = id >> 3, bh = (t / nrb) * 8 + xcd;
+    rb = t % nrb; h = bh % heads; b = bh / heads;
+}
+
 __global__ __launch_bounds__(256) void pattn2_fwd_kernel(PAttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[64][PA2_LD];
     __shared__ __attribute__((aligned(16))) float Vs[64][PA2_LD];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
-    const int q = blockIdx.x * 64 + w * 16 + i16, h = blockIdx.y, b = blockIdx.z;
+    int rb_, h, b;
+    pa2_xcd_remap(rb_, h, b);
+    const int q = rb_ * 64 + w * 16 + i16;
     const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
     const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
     const size_t row = ((size_t)b * a.heads + h) * a.L + q;
@@ -376,7 +390,9 @@ __global__ __launch_bounds__(256) void pattn2_bwd_dq_kernel(PAttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[64][PA2_LD];
     __shared__ __attribute__((aligned(16))) float Vs[64][PA2_LD];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
-    const int q = blockIdx.x * 64 + w * 16 + i16, h = blockIdx.y, b = blockIdx.z;
+    int rb_, h, b;
+    pa2_xcd_remap(rb_, h, b);
+    const int q = rb_ * 64 + w * 16 + i16;
     const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
     const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
     const size_t tok = (size_t)b * a.L + q, row = ((size_t)b * a.heads + h) * a.L + q;
@@ -437,7 +453,9 @@ __global__ __launch_bounds__(256) void pattn2_bwd_dkv_kernel(PAttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ds[64][PA2_LD];
     __shared__ float Ls[64], Dl[64];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
-    const int key = blockIdx.x * 64 + w * 16 + i16, h = blockIdx.y, b = blockIdx.z;
+    int rb_, h, b;
+    pa2_xcd_remap(rb_, h, b);
+    const int key = rb_ * 64 + w * 16 + i16;
     const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
     const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
     const size_t tok = (size_t)b * a.L + key, bh = (size_t)b * a.heads + h;
