@@ -722,12 +722,14 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
     const double work = 4.0 * B * heads * (double)L * span * HD;
     static int nw4 = -1;
     if (nw4 < 0) { const char* e = getenv("AMDSEG_ATTN_NW4"); nw4 = e ? atoi(e) : 0; }
-    if (nw4 && window == 0) {
+    if ((nw4 & 1) && window == 0) {
         AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
         return amdseg_launch_status();
     }
     if (window > 0) {
-        if (L % 128 == 0) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<8, true>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
+        // band: 64-query workgroups visit (64 + 2W) / 64 = 9 chunks at W = 256, 128-query ones 10 -- measured 152 vs 172 us per layer at
+        // longformer-base (full attention is the other way round: 8 waves share every K / V tile)
+        if (L % 128 == 0 && (nw4 & 2)) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<8, true>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
         else AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
     } else {
         if (L % 128 == 0) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<8, false>), dim3(L / 128, heads, B), dim3(512), 0, s, a);

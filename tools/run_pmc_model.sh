@@ -9,6 +9,6 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $CTR -d /tmp/pmc_${CTR} -o run -- python bench.py --model $MODEL --no-cpu-baseline --no-via-trainer --no-roofline --steps 2 --warmup 1 > /dev/null 2> gpurun_out/${TAG}_pmc_${MODEL}_${CTR}.err
   DB=$(find /tmp/pmc_${CTR} -name "*.db" | head -1)
   echo "## pass: --pmc $CTR (python bench.py --model $MODEL --steps 2 --warmup 1)" >> $OUT
-  python tools/pmc_summary.py "$DB" | grep -E "attn_|^\| kernel|^\|---" >> $OUT
+  python tools/pmc_summary.py "$DB" | head -${PMC_ROWS:-40} >> $OUT
 done
 cat $OUT
