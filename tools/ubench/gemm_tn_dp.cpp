@@ -206,10 +206,12 @@ static float bf2f(bf16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f
 static bf16_t f2b(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (bf16_t)(u >> 16); }
 
 int main() {
-    const int M = 16384;
-    int shapes[][4] = {{768, 3072, 1, 0}, {2304, 1536, 1, 0}, {3072, 2048, 1, 0}, {4096, 2048, 1, 0}};
+    // {N, K', remap, accumulate-run, M}: the last two rows emulate a stream-K split of the encoder layer's 216 tiles over 256 CUs
+    // (216 tiles x 256 K tiles  vs  256 tiles x 216 K tiles: what an ideal split could reach, no fix-up cost)
+    int shapes[][5] = {{768, 3072, 1, 0, 16384}, {2304, 1536, 1, 0, 16384}, {3072, 2048, 1, 0, 16384}, {4096, 2048, 1, 0, 16384},
+                       {2304, 3072, 1, 0, 16384}, {4096, 2048, 1, 0, 13824}};
     for (auto& sh : shapes) {
-        const int N = sh[0], Kp = sh[1];
+        const int N = sh[0], Kp = sh[1], M = sh[4];
         std::vector<bf16_t> hA((size_t)M * N), hB((size_t)M * Kp);
         srand(2);
         for (auto& v : hA) v = f2b((rand() / (float)RAND_MAX - 0.5f) * 0.2f);
