@@ -33,6 +33,20 @@ class LongformerEncoderEngine(BertEncoderEngine):
         # False: no global token at all -- LongformerModel called with global_attention_mask=None (the mmvts text encoder,
         # mmvts/src/models/text_encoder/text_encoder.py:73-85 as driven by multi_modal_for_ts.py:173-176): pure band attention
         self.cls_global = True
+        # the global-row chain (a dozen small, latency-bound launches per layer and direction plus three HBM passes) runs on a second
+        # stream under the layer's big kernels: forward under the QKV GEMM + band attention, backward under the attention backward
+        # and the weight-gradient GEMM.  AMDSEG_LF_OVERLAP=0 keeps everything on one stream.
+        import os
+        self.lf_overlap = os.environ.get("AMDSEG_LF_OVERLAP", "1") != "0" and device.type == "cuda"
+        self._lf_side = torch.cuda.Stream(device=device) if self.lf_overlap else None
+
+    def _on_both(self, main, *tensors):
+        """tensors created while one stream was current and read on the other: tell the caching allocator"""
+        if self._lf_side is None:
+            return
+        for t in tensors:
+            if t is not None:
+                t.record_stream(main); t.record_stream(self._lf_side)
 
     # ---- parameters of the global projections (fp32 masters; tiny algebra runs in fp32)
     def _gp(self, flat, i, which, kind):
@@ -53,14 +67,17 @@ class LongformerEncoderEngine(BertEncoderEngine):
             return super()._layer_forward(lib, cfg, lp, A, i, mb, s, train)
         cfg.window, cfg.nglobal = self.windows[i], 1
         acts = A["acts_struct"][i]
-        cfg.phase = 1
-        L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].1")
         la = A["layers"][i if train else 0]
         x_in = A["x"][i] if train else A["x"][i % 2]
         fp = self.fp.flat_p
         dev = x_in.device
         dtx = L.F32 if x_in.dtype == torch.float32 else L.BF16
-        with torch.no_grad():
+        main = torch.cuda.current_stream()
+        side = self._lf_side if self.lf_overlap else main
+        if side is not main:
+            fork = torch.cuda.Event(); fork.record(main); side.wait_event(fork)          # x_in is complete
+        with torch.no_grad(), torch.cuda.stream(side):
+            ss = side.cuda_stream
             Wq, bq = self._gp(fp, i, "query_global", "weight"), self._gp(fp, i, "query_global", "bias")
             Wk = self._gp(fp, i, "key_global", "weight")
             Wv, bv = self._gp(fp, i, "value_global", "weight"), self._gp(fp, i, "value_global", "bias")
@@ -69,14 +86,23 @@ class LongformerEncoderEngine(BertEncoderEngine):
             # the O(heads * H^2) algebra of the global row runs in csrc/lf_global.hip (2 launches forward, 4 backward; round 1: ~25
             # rocBLAS / elementwise launches per layer and direction)
             L.check(lib.amdseg_lf_global_q(x_in.data_ptr(), dtx, Wq.data_ptr(), bq.data_ptr(), Wk.data_ptr(), qg.data_ptr(), r.data_ptr(),
-                                           B, Lseq, H, heads, self.scale, s), "amdseg_lf_global_q")
+                                           B, Lseq, H, heads, self.scale, ss), "amdseg_lf_global_q")
             scores = ops.lf_rowvec_dot(x_in, r, B, Lseq, add_tok=A["mask_bias"])
             seed = (int(cfg.seed) * 0x9E3779B1 + 7919 * (i + 1)) & 0x7FFFFFFFFFFFFFFF
             p, pd, sp = ops.lf_softmax_fwd(scores, cfg.p_attn, seed)
             y = ops.lf_wsum(x_in, pd, H, A["lf_partials"])
+        # the band attention writes its own row 0 of ctx; the global row then overwrites it
+        cfg.phase = 1
+        L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].1")
+        if side is not main:
+            attn_done = torch.cuda.Event(); attn_done.record(main); side.wait_event(attn_done)
+        with torch.no_grad(), torch.cuda.stream(side):
             L.check(lib.amdseg_lf_global_out(Wv.data_ptr(), bv.data_ptr(), y.data_ptr(), sp.data_ptr(), la["ctx"].data_ptr(),
-                                             L.F32 if la["ctx"].dtype == torch.float32 else L.BF16, B, Lseq, H, heads, s),
+                                             L.F32 if la["ctx"].dtype == torch.float32 else L.BF16, B, Lseq, H, heads, side.cuda_stream),
                     "amdseg_lf_global_out")
+        if side is not main:
+            done = torch.cuda.Event(); done.record(side); main.wait_event(done)
+            self._on_both(main, qg, r, scores, p, pd, sp, y)
         cfg.phase = 2
         L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].2")
         cfg.phase = 0
@@ -99,28 +125,43 @@ class LongformerEncoderEngine(BertEncoderEngine):
         qg, r, p, y, sp = saved["qg"], saved["r"], saved["p"], saved["y"], saved["sp"]
         dev = x_in.device
         f32 = dict(dtype=torch.float32, device=dev)
+        main = torch.cuda.current_stream()
+        side = self._lf_side if self.lf_overlap else main
         with torch.no_grad():
             Wq, Wk = self._gp(fp, i, "query_global", "weight"), self._gp(fp, i, "key_global", "weight")
             Wv, bv = self._gp(fp, i, "value_global", "weight"), self._gp(fp, i, "value_global", "bias")
             dout, dyv, dsp = torch.empty(B, heads, 64, **f32), torch.empty(B, heads, H, **f32), torch.empty(B, heads, **f32)
-            # consumes + zeroes dctx[:, 0] (the band attention's own row 0 was overwritten in forward: no gradient)
+            # consumes + zeroes dctx[:, 0] (the band attention's own row 0 was overwritten in forward: no gradient); on the main stream:
+            # the attention backward below reads dctx
             L.check(lib.amdseg_lf_global_bwd_a(dctx.data_ptr(), L.BF16, Wv.data_ptr(), bv.data_ptr(), dout.data_ptr(), dyv.data_ptr(),
                                                dsp.data_ptr(), B, Lseq, H, heads, s), "amdseg_lf_global_bwd_a")
+        if side is not main:
+            e1 = torch.cuda.Event(); e1.record(main); side.wait_event(e1)
+        with torch.no_grad(), torch.cuda.stream(side):          # ... under the band attention backward
             dpd = ops.lf_rowvec_dot(x_in, dyv, B, Lseq, add_bh=dsp)
             ds, pd = ops.lf_softmax_bwd(p, dpd, cfg.p_attn, saved["seed"])
             dr = ops.lf_wsum(x_in, ds, H, A["lf_partials"])
-        cfg.phase = 2
+        cfg.phase = 6 if side is not main else 2                # attention backward + dx GEMM (+ the weight gradients when single-stream)
         L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].2")
-        cfg.phase = 0
-        with torch.no_grad():
+        if side is not main:
+            e3 = torch.cuda.Event(); e3.record(main); side.wait_event(e3)       # `other` (dx of the layer) is complete
+        with torch.no_grad(), torch.cuda.stream(side):          # ... under the grouped weight-gradient GEMM
             ops.lf_dx_update(other, pd, dyv, ds, r, A["lf_vt"])
             dqg = torch.empty(B, H, **f32)
             g = lambda which, kind: self._gp(fg, i, which, kind).data_ptr()          # noqa: E731
             L.check(lib.amdseg_lf_global_bwd_rest(x_in.data_ptr(), L.BF16, other.data_ptr(), L.BF16, Wq.data_ptr(), Wk.data_ptr(),
                                                   qg.data_ptr(), dout.data_ptr(), y.data_ptr(), sp.data_ptr(), dr.data_ptr(), dqg.data_ptr(),
                                                   g("query_global", "weight"), g("query_global", "bias"), g("key_global", "weight"),
-                                                  g("value_global", "weight"), g("value_global", "bias"), B, Lseq, H, heads, self.scale, s),
+                                                  g("value_global", "weight"), g("value_global", "bias"), B, Lseq, H, heads, self.scale,
+                                                  side.cuda_stream),
                     "amdseg_lf_global_bwd_rest")
+        if side is not main:
+            e4 = torch.cuda.Event(); e4.record(side)
+            cfg.phase = 4
+            L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].4")
+            main.wait_event(e4)
+            self._on_both(main, dout, dyv, dsp, dpd, ds, pd, dr, dqg)
+        cfg.phase = 0
 
     def _arena(self, B, Lseq, train, fp32=False):
         A = super()._arena(B, Lseq, train, fp32)
