@@ -141,11 +141,11 @@ class LongformerEncoderEngine(BertEncoderEngine):
             dpd = ops.lf_rowvec_dot(x_in, dyv, B, Lseq, add_bh=dsp)
             ds, pd = ops.lf_softmax_bwd(p, dpd, cfg.p_attn, saved["seed"])
             dr = ops.lf_wsum(x_in, ds, H, A["lf_partials"])
-        cfg.phase = 6 if side is not main else 2                # attention backward + dx GEMM (+ the weight gradients when single-stream)
+        cfg.phase = 6 if side is not main else 2               # attention backward + dx GEMM (+ the weight gradients when single-stream)
         L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].2")
         if side is not main:
-            e3 = torch.cuda.Event(); e3.record(main); side.wait_event(e3)       # `other` (dx of the layer) is complete
-        with torch.no_grad(), torch.cuda.stream(side):          # ... under the grouped weight-gradient GEMM
+            e3 = torch.cuda.Event(); e3.record(main); side.wait_event(e3)      # `other` (dx of the layer) is complete
+        with torch.no_grad(), torch.cuda.stream(side):         # ... under the grouped weight-gradient GEMM
             ops.lf_dx_update(other, pd, dyv, ds, r, A["lf_vt"])
             dqg = torch.empty(B, H, **f32)
             g = lambda which, kind: self._gp(fg, i, which, kind).data_ptr()          # noqa: E731

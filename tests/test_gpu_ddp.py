@@ -41,6 +41,17 @@ def _make(family, rank, dev):
             random.seed(100 + rank)
             return model(**b)[0]
         return m, run
+    if family == "longformer":          # the global-row chain runs on a second stream (longformer_engine.lf_overlap)
+        from tests.test_oracle_golden import lf_case
+        from tests.test_gpu_longformer import build_lf
+        z, sd, batch, arch = lf_case("lf_tiny_L128_w16")
+        m = build_lf(arch, flags_of(z, "train_full"), sd, dev).train()
+        b = _rank_batch(batch, rank, dev)
+
+        def run(model):
+            random.seed(100 + rank)
+            return model(**b)[0]
+        return m, run
     from tests.test_gpu_ponet import build, make_inputs
     m, _ = build(dev)
     m = m.to(dev).train()
@@ -76,7 +87,7 @@ def _worker(rank, world, port, out_dir, family):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("family", ["bert", "ponet"])
+@pytest.mark.parametrize("family", ["bert", "ponet", "longformer"])
 def test_torch_ddp_reduces_engine_gradients(dev, tmp_path, family):
     import torch.multiprocessing as mp
     # single-process expectation on the native path (gradients written into the flat buffer views)
@@ -102,7 +113,7 @@ def test_torch_ddp_reduces_engine_gradients(dev, tmp_path, family):
                 g = got[r][it]["grads"][n]
                 # PoNet: the gradient of the global aggregate is accumulated over the runs with fp32 atomics (order varies run to run at
                 # the 1e-7 level; a flipped bf16 rounding downstream shows at 1e-4) -- a missing reduction would be a 50 % error
-                tol = (1e-5 if family == "bert" else 1e-3) * max(1e-3, float(want.abs().max()))
+                tol = (1e-3 if family == "ponet" else 1e-5) * max(1e-3, float(want.abs().max()))
                 assert float((g - want).abs().max()) <= tol, (it, r, n)
         for n in got[0][it]["grads"]:
             assert "pooler" not in n or float(got[0][it]["grads"][n].abs().max()) == 0.0

@@ -211,3 +211,31 @@ def test_longformer_dropout_step_deterministic(dev):
         vals.append((loss.item(), gn))
     assert vals[0][0] == vals[1][0]                                   # same masks, same loss bit for bit
     assert abs(vals[0][1] - vals[1][1]) <= 1e-6 * vals[0][1]          # embedding-table grads use fp32 atomics (order may vary)
+
+
+def test_global_row_side_stream_changes_nothing(dev):
+    """the global-row chain on its second stream (the default) against the single-stream order: same kernels, same inputs.  Not asserted
+    bit for bit: the loss heads scatter their row gradients with fp32 atomics, whose order (1e-7) now and then flips a bf16 rounding of
+    the encoder's incoming gradient -- two runs of the SAME configuration differ by ~1e-4 of a gradient's scale (tools/dbg/lf_overlap_bits.py);
+    a missing stream dependency would be orders of magnitude above the 2e-3 allowed here"""
+    z, sd, batch, arch = lf_case("lf_tiny_L128_w16")
+    res = {}
+    for overlap in (True, False):
+        m = build_lf(arch, flags_of(z, "train_full"), sd, dev, dropout=0.1).train()
+        eng = m.engine()
+        assert eng.lf_overlap                                # default on a GPU
+        eng.lf_overlap = overlap
+        outs = []
+        for it in range(3):
+            m.zero_grad(set_to_none=False)
+            random.seed(7 + it)
+            loss = m(**{k: v.to(dev) for k, v in batch.items()})[0]
+            loss.backward()
+            outs.append((loss.item(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+        res[overlap] = outs
+    for (l0, g0), (l1, g1) in zip(res[True], res[False]):
+        assert l0 == l1
+        for n in g0:
+            # an embedding row's gradient IS one bf16 row of the encoder's dx: a flipped rounding shows as one bf16 ulp (2^-8 of the element)
+            tol = 1e-2 if "embeddings" in n else 2e-3
+            assert float((g0[n] - g1[n]).abs().max()) <= tol * max(1e-3, float(g0[n].abs().max())), n
