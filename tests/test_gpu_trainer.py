@@ -264,3 +264,41 @@ def test_nan_inf_filter_runs_on_the_device_and_logs_like_the_stock_loop(dev, tmp
     for a, b in zip(logs["stock"], logs["fused"]):
         assert math.isfinite(a) and math.isfinite(b) and abs(a - b) <= 2e-3 * max(1.0, abs(a)), logs
     assert abs(logs["stock_final"] - logs["fused_final"]) <= 2e-3 * max(1.0, abs(logs["stock_final"]))
+
+
+def test_trainer_interleaved_evaluation_and_checkpoint(dev, tmp_path):
+    """the subclass under the loop shapes a real run has: evaluation every 2 steps (the eval dataloader keeps accelerate's device placement,
+    the train batches take the side-stream copy), a checkpoint in between, gradient accumulation 2, logging with the device-side NaN filter"""
+    import json
+    from transformers import default_data_collator
+    from spokennlp_amd.trainer import Trainer
+    z, sd, batch, arch = load_case("tiny_L64")
+    flags = flags_of(z, "train_full")
+    samples = _samples(arch, n=24)
+    m = build_model(arch, flags, sd, dev)
+    random.seed(3)
+    args = _args(tmp_path, max_steps=4, eval_strategy="steps", eval_steps=2, save_strategy="steps", save_steps=2, save_total_limit=1,
+                 per_device_eval_batch_size=4)
+    seen = {}
+
+    def metrics(p):
+        seen["n"] = seen.get("n", 0) + 1
+        return {"n_pred": float(len(p.predictions[0]))}
+
+    tr = Trainer(model=m, args=args, train_dataset=_DS(samples[:16]), eval_dataset=_DS(samples[16:]), data_collator=default_data_collator,
+                 compute_metrics=metrics)
+    out = tr.train()
+    assert out.global_step == 4 and math.isfinite(out.training_loss)
+    evals = [h for h in tr.state.log_history if "eval_loss" in h]
+    assert len(evals) == 2 and all(math.isfinite(h["eval_loss"]) for h in evals) and seen["n"] == 2
+    assert getattr(tr, "_amdseg_side_copy", False)                     # the train batches went through the copy stream
+    ck = [d for d in os.listdir(tmp_path) if d.startswith("checkpoint-")]
+    assert ck == ["checkpoint-4"]
+    st = json.load(open(tmp_path / ck[0] / "trainer_state.json"))
+    assert st["global_step"] == 4
+    # the saved weights are the live ones (the engine re-homed the parameters into its flat buffer long before the save)
+    from safetensors.torch import load_file
+    saved = load_file(str(tmp_path / ck[0] / "model.safetensors"))
+    live = m.state_dict()
+    k = "bert.encoder.layer.0.attention.self.query.weight"
+    assert torch.equal(saved[k].cpu(), live[k].detach().cpu())
