@@ -140,6 +140,10 @@ class NativeDataParallel(torch.nn.Module):
         return self.module.no_sync()
 
 
+import inspect as _inspect
+_TRAINING_STEP_TAKES_COUNT = len(_inspect.signature(transformers.Trainer.training_step).parameters) >= 4
+
+
 class Trainer(transformers.Trainer):
     """`transformers.Trainer` with the fused optimiser, HIP gradient norm and native data parallelism (see the module docstring).
     `amdseg_native=False` keeps the stock behaviour (torch optimiser, torch DDP)."""
@@ -162,7 +166,10 @@ class Trainer(transformers.Trainer):
         Python once per step ([hf] trainer.py, `_inner_training_loop`): a host read of a device scalar that drains the launch queue
         (bert-base: 19.0 vs 16.0 ms per step).  The same substitution -- a non-finite step loss is replaced, for the LOGGED running loss
         only, by the average since the last log -- is done here on the device and the host-side check is switched off for this run."""
-        loss = super().training_step(model, inputs, num_items_in_batch)
+        if _TRAINING_STEP_TAKES_COUNT:
+            loss = super().training_step(model, inputs, num_items_in_batch)
+        else:                                                   # transformers < 4.46 (the reference pins 4.26): two arguments
+            loss = super().training_step(model, inputs)
         if self.amdseg_native and hasattr(self, "_tr_loss") and hasattr(self, "_globalstep_last_logged"):
             if self.args.logging_nan_inf_filter:
                 self.args.logging_nan_inf_filter = False
