@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 3   /* 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 4   /* 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -310,6 +310,13 @@ typedef struct amdseg_bert_cfg {
                                        alone (e.g. on a second stream, under the next layer's backward; the caller orders
                                        the streams and must not reuse ws before it has run). */
     int32_t act;                    /* FFN activation: 0 = exact (erf) GELU "gelu", 1 = "gelu_new" (BigBird) */
+    const int32_t* kend;            /* optional device [B] (full attention, bf16 path): every key at a position >= kend[b] carries a
+                                       mask <= -5000 (trailing padding).  The attention kernels then do not visit the 64-key chunks past
+                                       it -- they contribute exact zeros, results are bit-identical -- and write dK = dV = 0 there.
+                                       kend[b] == 0 (no unmasked key) and NULL keep every chunk. */
+    const int32_t* seq_order;       /* optional device [B] (with kend): a permutation of the sequences, longest visible length first; the
+                                       attention launches then dispatch their workgroups in that order so that the short sequences fill
+                                       the tail (results do not depend on it) */
 } amdseg_bert_cfg;
 
 typedef struct amdseg_bert_layer_params {   /* bf16 compute shadows (+ transposes for dgrad), fp32 vectors */

@@ -71,6 +71,8 @@ struct AttnArgs {
     // and WITH multiplicity (a key block listed twice counts twice in the softmax, as in the reference's concatenated key matrices)
     const int* klist; const int* kcnt; const int* qlist; const int* qcnt; int list_stride;
     const int* korder; const int* qorder;   // optional [heads][L/64]: block index handled by the r-th workgroup of a head (longest lists first)
+    const int* kend;                        // optional [B] (full attention): keys at positions >= kend[b] are all masked (<= -5000); 0 = none unmasked
+    const int* seq_order;                   // optional [B] with kend: the sequence the b-th group of workgroups works on (longest first)
 };
 
 // Band ("sliding window + global") visibility, [hf] models/longformer/modeling_longformer.py:524-604 restated as a mask:
@@ -124,6 +126,17 @@ __device__ __forceinline__ void attn_1d_order(int id, int nblk, int nbh, int nfi
     r = nfirst + t % rest; bh = (t / rest) * 8 + xcd;
 }
 
+// Trailing padding (AttnArgs.kend, handed down by the composite layer call from amdseg_bert_cfg.kend).  A key whose additive mask is
+// <= -5000 has exp(score + mask - max) == 0 EXACTLY in fp32 whenever its row sees at least one unmasked key, so the 64-key chunks past the
+// last unmasked key of a sequence add exact zeros to every sum (forward, dQ) and the key blocks there get dK = dV = 0: not visiting them
+// changes no bit.  kend[b] == 0 (no unmasked key: the softmax is uniform over the masked keys, as in the reference) keeps every chunk.
+// (A per-workgroup scan of the mask row instead of the precomputed kend cost as much as the skipped chunks saved.)
+__device__ __forceinline__ int attn_visible_chunks(const AttnArgs& a, int b, int nch) {
+    if (!a.kend) return nch;
+    const int ke = a.kend[b];
+    return ke > 0 ? min(nch, (ke + CH - 1) / CH) : nch;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int NW, bool BAND, bool LIST = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
@@ -136,6 +149,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
         h = bh % a.heads; b = bh / a.heads;
         qb = a.korder ? a.korder[h * (a.L / CH) + r] : r;
     } else attn_xcd_remap(qb, h, b, a.heads);
+    // sequences in decreasing visible length (list scheduling: with ~3 workgroups per slot the short ones must come LAST to fill the tail;
+    // in batch order skipping 16 % of the chunks shortened the launch by 1-6 %)
+    if (!BAND && !LIST && a.seq_order) b = a.seq_order[b];
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
     const int q = qb * (NW * 16) + w * 16 + i16;                       // this lane's query row (shared by the 4 g-groups)
@@ -170,6 +186,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
         extra = (a.nglobal > 0 && c0 > 0) ? 1 : 0;
     }
     int nch = c1 - c0 + 1 + extra;
+    if (!BAND && !LIST) nch = attn_visible_chunks(a, b, nch);
     const int* lst = nullptr;
     ListWalk lw;
     int c_cur = 0, c_nxt = 0, ch_ = 0;                      // LIST: the chunks of iteration ch_ and ch_ + 1
@@ -346,6 +363,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         h = bh % a.heads; b = bh / a.heads;
         qb = a.korder ? a.korder[h * (a.L / CH) + r] : r;
     } else attn_xcd_remap(qb, h, b, a.heads);
+    // sequences in decreasing visible length (list scheduling: with ~3 workgroups per slot the short ones must come LAST to fill the tail;
+    // in batch order skipping 16 % of the chunks shortened the launch by 1-6 %)
+    if (!BAND && !LIST && a.seq_order) b = a.seq_order[b];
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
     const int q = qb * (NW * 16) + w * 16 + i16;
@@ -397,6 +417,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         extra = (a.nglobal > 0 && c0 > 0) ? 1 : 0;
     }
     int nch = c1 - c0 + 1 + extra;
+    if (!BAND && !LIST) nch = attn_visible_chunks(a, b, nch);
     const int* lst = nullptr;
     ListWalk lw;
     int c_cur = 0, c_nxt = 0, ch_ = 0;                      // LIST: the chunks of iteration ch_ and ch_ + 1
@@ -516,7 +537,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #define bufL(i) (smem + 32768 + (i) * 512)
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    if (!BAND && !LIST) attn_xcd_remap(kb, h, b, a.heads);
+    if (!BAND && !LIST) { attn_xcd_remap(kb, h, b, a.heads); if (a.seq_order) b = a.seq_order[b]; }
     if (BAND) {
         // 1-D launch.  The key block holding the global keys sees EVERY query chunk (L/64 instead of ~2W/64 + 1): those
         // B*heads long workgroups come first in dispatch order and land round-robin on all XCDs, so they overlap the
@@ -537,6 +558,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     const size_t tok0 = (size_t)b * a.L;
     const int key = kb * (NW * 16) + w * 16 + i16;                    // this lane's key row
     const uint64_t bh = (uint64_t)(b * a.heads + h);
+    if (!BAND && !LIST && a.kend) {                         // a key block wholly in the trailing padding: dK = dV = 0 exactly
+        const int ke = a.kend[b];
+        if (ke > 0 && kb * (NW * 16) >= ke) {
+            const int Hq = a.heads * HD;
+            bf16_t* okp0 = a.dqkv + (tok0 + key) * a.H3 + Hq + h * HD;
+            bf16_t* ovp0 = a.dqkv + (tok0 + key) * a.H3 + 2 * Hq + h * HD;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                *reinterpret_cast<uint2*>(okp0 + d * 16 + g * 4) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(ovp0 + d * 16 + g * 4) = make_uint2(0u, 0u);
+            }
+            return;
+        }
+    }
 #define bufQ(i) (smem + (i) * 16384)
 #define bufO(i) (smem + 8192 + (i) * 16384)
 
@@ -711,11 +746,12 @@ static int attn_fill(AttnArgs& a, int B, int L, int heads, float scale, float p,
 }
 
 int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,
-                         float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s) {
+                         float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order) {
     if (!qkv || !mask_bias || !ctx) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
+    a.kend = window > 0 ? nullptr : kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
     // algorithmic FLOPs: QK^T + PV over the visible keys (full: L, band: 2W + 1 + G)
     const double span = window > 0 ? (double)(2 * window + 1 + a.nglobal) : (double)L;
@@ -740,11 +776,12 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
 
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
-                         int window, int nglobal, hipStream_t s) {
+                         int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order) {
     if (!qkv || !mask_bias || !ctx || !dctx || !lse || !delta || !dqkv) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
+    a.kend = window > 0 ? nullptr : kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = (float*)lse;
     a.dctx = (const bf16_t*)dctx; a.delta = delta; a.dqkv = (bf16_t*)dqkv;
     const size_t total = (size_t)B * L * heads * 8;

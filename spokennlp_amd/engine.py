@@ -168,6 +168,8 @@ class BertEncoderEngine:
             from torch.optim.optimizer import register_optimizer_step_post_hook
             _HOOKED.append(register_optimizer_step_post_hook(_optimizer_stepped))
         self._ct_table = None
+        import os as _os
+        self.skip_padded_chunks = _os.environ.get("AMDSEG_ATTN_NOSKIP", "0") != "1"
         self._arena_slot = 0
         self.max_live_arenas = 2                            # training arenas per shape that may be alive between forward and backward
         self.grad_sync = True                               # False inside no_sync(): accumulate locally, no bucket all-reduce
@@ -510,6 +512,15 @@ class BertEncoderEngine:
         # visible keys are ALL masked (padded queries of a band, fully padded sequences) -- with -1e30 those differences carry an
         # absolute error of ~1e23 and exp2 of them is inf (attention.hip folds mask and lse into the MFMA accumulator start)
         torch.mul(1.0 - attention_mask.to(torch.float32), MASK_BIAS, out=A["mask_bias"])
+        # trailing padding: (last unmasked key) + 1 per sequence; the full-attention kernels do not visit the chunks past it (they add
+        # exact zeros: include/amdseg.h amdseg_bert_cfg.kend).  Computed once per forward, kept with the arena for backward.
+        if "kend" not in A or A["kend"].numel() != B:
+            A["kend"] = torch.empty(B, dtype=torch.int32, device=self.device)
+            A["kend_pos"] = torch.arange(1, Lseq + 1, dtype=torch.int32, device=self.device)
+        torch.amax((attention_mask != 0).to(torch.int32) * A["kend_pos"], dim=1, out=A["kend"])
+        A["seq_order"] = torch.argsort(A["kend"], descending=True, stable=True).to(torch.int32)     # longest first (dispatch order)
+        cfg.kend = A["kend"].data_ptr() if self.skip_padded_chunks else None
+        cfg.seq_order = A["seq_order"].data_ptr() if self.skip_padded_chunks else None
         lib = L.load()
         s = torch.cuda.current_stream().cuda_stream
         eps = float(self.cfg.layer_norm_eps)
@@ -604,6 +615,8 @@ class BertEncoderEngine:
         lib = L.load()
         s = torch.cuda.current_stream().cuda_stream
         cfg = self._cfg_struct(B, Lseq, ctx["p_h"], ctx["p_a"], ctx["seed"], accumulate)
+        cfg.kend = A["kend"].data_ptr() if (self.skip_padded_chunks and "kend" in A) else None
+        cfg.seq_order = A["seq_order"].data_ptr() if (self.skip_padded_chunks and "seq_order" in A) else None
         adt = L.F32 if ctx.get("parity") else L.BF16            # dtype of the activation gradients
         if ctx.get("parity"):
             cfg.dtype = L.F32S

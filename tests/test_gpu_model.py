@@ -416,3 +416,46 @@ def test_fused_heads_equal_torch_heads(dev, variant):
         worst = max(worst, d)
         assert d < 1e-4, (n, d)
     print(variant, "fused vs torch heads: worst relative gradient difference", worst)
+
+
+def test_trailing_padding_chunks_are_skipped_without_changing_a_bit(dev):
+    """amdseg_bert_cfg.kend / seq_order: the full-attention kernels do not visit the 64-key chunks past a sequence's last unmasked key and
+    walk the sequences longest first.  The skipped chunks contribute exact zeros, so the forward result is bit-identical; the backward is
+    compared up to the atomics noise of the heads / embedding scatters (see test_global_row_side_stream_changes_nothing)"""
+    from transformers import BertConfig
+    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+    torch.manual_seed(0)
+    cfg = BertConfig(vocab_size=300, hidden_size=128, num_attention_heads=2, num_hidden_layers=2, intermediate_size=256,
+                     max_position_embeddings=512, num_labels=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    m = M(cfg).to(dev)
+    B, L = 8, 256                                             # 16 (batch, head) pairs: the XCD-aware placement is active too
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(5, 300, (B, 1, L), generator=g)
+    lens = [256, 200, 130, 64, 63, 256, 1, 129]
+    am = torch.zeros(B, 1, L, dtype=torch.long)
+    for b, n in enumerate(lens):
+        am[b, 0, :n] = 1
+    labels = torch.full((B, 1, L), -100)
+    for b, n in enumerate(lens):
+        labels[b, 0, 0:n:7] = torch.randint(0, 2, (len(range(0, n, 7)),), generator=g)
+    batch = {k: v.to(dev) for k, v in dict(input_ids=ids, attention_mask=am, token_type_ids=torch.zeros_like(ids), labels=labels).items()}
+    eng = m.engine()
+    outs = {}
+    for skip in (True, False):
+        eng.skip_padded_chunks = skip
+        m.eval()
+        with torch.no_grad():
+            _, logits, _ = m(**batch)
+        m.train()
+        m.zero_grad(set_to_none=False)
+        random.seed(5)
+        m._step_seed = 100                                    # the wrapper's dropout seed counts training forwards: same seed for both runs
+        loss = m(**batch)[0]
+        loss.backward()
+        outs[skip] = (logits.clone(), loss.item(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert torch.equal(outs[True][0], outs[False][0])         # forward: bit-identical, padded positions included
+    assert outs[True][1] == outs[False][1]                    # ... with dropout as well
+    for n, ga in outs[True][2].items():
+        gb = outs[False][2][n]
+        tol = 1e-2 if "embeddings" in n else 2e-3
+        assert float((ga - gb).abs().max()) <= tol * max(1e-3, float(ga.abs().max())), n
