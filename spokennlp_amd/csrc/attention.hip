@@ -179,11 +179,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     const bf16_t* kbase = a.qkv + tok0 * a.H3 + H + h * HD;
     const bf16_t* vbase = a.qkv + tok0 * a.H3 + 2 * H + h * HD;
     int c0 = 0, c1 = a.L / CH - 1, extra = 0;
+    bool pad_block = false;
     if (BAND) {
         const int q_lo = qb * (NW * 16), q_hi = q_lo + NW * 16 - 1;
         c0 = q_lo > a.window ? (q_lo - a.window) / CH : 0;
         c1 = min(c1, (q_hi + a.window) / CH);
         extra = (a.nglobal > 0 && c0 > 0) ? 1 : 0;
+        if (a.kend && a.kend[b] > 0) {                      // trailing padding (kend, see attn_visible_chunks): chunks past it add exact zeros;
+            const int ke = a.kend[b];                       // a query block wholly inside it is a block of zero rows ([hf] longformer :579)
+            pad_block = q_lo >= ke;
+            c1 = min(c1, (ke - 1) / CH);
+        }
+    }
+    if (BAND && pad_block) {                                // (workgroup-uniform) every row of the block is a padded query: zero rows, LSE = +inf
+        bf16_t* op0 = a.ctx + (tok0 + q) * H + h * HD;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) *reinterpret_cast<uint2*>(op0 + d * 16 + g * 4) = make_uint2(0u, 0u);
+        if (a.lse && g == 0) a.lse[prow] = INFINITY;
+        return;
     }
     int nch = c1 - c0 + 1 + extra;
     if (!BAND && !LIST) nch = attn_visible_chunks(a, b, nch);
@@ -410,11 +423,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const bf16_t* kbase = a.qkv + tok0 * a.H3 + H + h * HD;
     const bf16_t* vbase = a.qkv + tok0 * a.H3 + 2 * H + h * HD;
     int c0 = 0, c1 = a.L / CH - 1, extra = 0;
+    bool pad_block = false;
     if (BAND) {
         const int q_lo = qb * (NW * 16), q_hi = q_lo + NW * 16 - 1;
         c0 = q_lo > a.window ? (q_lo - a.window) / CH : 0;
         c1 = min(c1, (q_hi + a.window) / CH);
         extra = (a.nglobal > 0 && c0 > 0) ? 1 : 0;
+        if (a.kend && a.kend[b] > 0) {                      // trailing padding (kend, see attn_visible_chunks): chunks past it add exact zeros;
+            const int ke = a.kend[b];                       // a query block wholly inside it is a block of zero rows ([hf] longformer :579)
+            pad_block = q_lo >= ke;
+            c1 = min(c1, (ke - 1) / CH);
+        }
+    }
+    if (BAND && pad_block) {                                // padded query rows: p == 0 in backward (LSE = +inf) -> dQ = 0; delta finite for dK/dV
+        bf16_t* op0 = a.dqkv + (tok0 + q) * a.H3 + h * HD;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) *reinterpret_cast<uint2*>(op0 + d * 16 + g * 4) = make_uint2(0u, 0u);
+        if (g == 0) a.delta[prow] = 0.f;
+        return;
     }
     int nch = c1 - c0 + 1 + extra;
     if (!BAND && !LIST) nch = attn_visible_chunks(a, b, nch);
@@ -606,6 +632,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         c0 = k_lo > a.window ? (k_lo - a.window) / CH : 0;
         c1 = min(c1, (k_hi + a.window) / CH);
     }
+    if (BAND && a.kend && a.kend[b] > 0) {                  // padded query rows have p == 0 (LSE = +inf): their chunks add exact zeros; a key block
+        const int ke = a.kend[b];                           // past the last unmasked key gets dK = dV = 0 (the loop below is empty for it)
+        c1 = min(c1, (ke - 1) / CH);
+        if (kb * (NW * 16) >= ke) c1 = c0 - 1;
+    }
     int nch = c1 - c0 + 1;
     const int* lst = nullptr;
     ListWalk lw;
@@ -751,7 +782,7 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
-    a.kend = window > 0 ? nullptr : kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order;
+    a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
     // algorithmic FLOPs: QK^T + PV over the visible keys (full: L, band: 2W + 1 + G)
     const double span = window > 0 ? (double)(2 * window + 1 + a.nglobal) : (double)L;
@@ -781,7 +812,7 @@ int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ct
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
-    a.kend = window > 0 ? nullptr : kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order;
+    a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = (float*)lse;
     a.dctx = (const bf16_t*)dctx; a.delta = delta; a.dqkv = (bf16_t*)dqkv;
     const size_t total = (size_t)B * L * heads * 8;

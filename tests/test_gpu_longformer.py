@@ -239,3 +239,47 @@ def test_global_row_side_stream_changes_nothing(dev):
             # an embedding row's gradient IS one bf16 row of the encoder's dx: a flipped rounding shows as one bf16 ulp (2^-8 of the element)
             tol = 1e-2 if "embeddings" in n else 2e-3
             assert float((g0[n] - g1[n]).abs().max()) <= tol * max(1e-3, float(g0[n].abs().max())), n
+
+
+def test_band_padding_is_skipped_without_changing_the_forward(dev):
+    """amdseg_bert_cfg.kend on the band kernels: query blocks wholly inside the trailing padding are written as zero rows without being
+    computed ([hf] :579 zeroes them anyway), key chunks past the last unmasked key are not visited, dK = dV = 0 there: the forward is
+    bit-identical with and without (engine.skip_padded_chunks), the backward equal up to the atomics noise of the heads / embeddings"""
+    from transformers import LongformerConfig
+    from spokennlp_amd.longformer_for_ts import LongformerWithDAForSentenceLabelingTopicSegmentation as M
+    torch.manual_seed(0)
+    cfg = LongformerConfig(vocab_size=300, hidden_size=128, num_attention_heads=2, num_hidden_layers=2, intermediate_size=256,
+                           max_position_embeddings=1030, num_labels=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                           attention_window=[128, 128], pad_token_id=1, type_vocab_size=1, layer_norm_eps=1e-5)
+    m = M(cfg).to(dev)
+    B, L = 4, 1024
+    g = torch.Generator().manual_seed(2)
+    lens = [1024, 700, 129, 321]
+    ids = torch.randint(5, 300, (B, 1, L), generator=g)
+    am = torch.zeros(B, 1, L, dtype=torch.long)
+    labels = torch.full((B, 1, L), -100)
+    for b, n in enumerate(lens):
+        am[b, 0, :n] = 1
+        ids[b, 0, n:] = 1
+        labels[b, 0, 1:n:9] = torch.randint(0, 2, (len(range(1, n, 9)),), generator=g)
+    batch = {k: v.to(dev) for k, v in dict(input_ids=ids, attention_mask=am, labels=labels).items()}
+    eng = m.engine()
+    outs = {}
+    for skip in (True, False):
+        eng.skip_padded_chunks = skip
+        m.eval()
+        with torch.no_grad():
+            _, logits, _ = m(**batch)
+        m.train()
+        m.zero_grad(set_to_none=False)
+        random.seed(5)
+        m._step_seed = 100
+        loss = m(**batch)[0]
+        loss.backward()
+        outs[skip] = (logits.clone(), loss.item(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert outs[True][1] == outs[False][1]
+    for n, ga in outs[True][2].items():
+        gb = outs[False][2][n]
+        tol = 1e-2 if "embeddings" in n else 2e-3
+        assert float((ga - gb).abs().max()) <= tol * max(1e-3, float(ga.abs().max())), n
