@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 4   /* 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 5   /* 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -169,6 +169,9 @@ int amdseg_ln_bwd(const void* dy, const void* z, const float* mean, const float*
 /* out[N] (+)= column sums of x[M, ld];  partials = workspace of ceil(M/128)*N floats  (bias gradients) */
 int amdseg_colsum(const void* x, int ld, float* partials, float* out, int M, int N, int accumulate, int dtype,
                   amdseg_stream_t stream);
+/* *guard = 1 if any element of x (fp32 [B*L, H], H % 4 == 0) in a row at a position >= kend[b] is not an exact zero (NaN counts), else 0:
+   the check behind amdseg_bert_cfg.pad_guard.  Reads only those rows.  (No reference counterpart: the reference computes the padded rows.) */
+int amdseg_pad_rows_guard(const float* x, const int32_t* kend, int B, int L, int H, int32_t* guard, amdseg_stream_t stream);
 int amdseg_dropout(const void* x, void* y, size_t n, float p, uint64_t seed, int dtype_in, int dtype_out,
                    amdseg_stream_t stream);
 int amdseg_cast(const void* x, void* y, size_t n, int dtype_in, int dtype_out, amdseg_stream_t stream);
@@ -317,6 +320,16 @@ typedef struct amdseg_bert_cfg {
     const int32_t* seq_order;       /* optional device [B] (with kend): a permutation of the sequences, longest visible length first; the
                                        attention launches then dispatch their workgroups in that order so that the short sequences fill
                                        the tail (results do not depend on it) */
+    const int32_t* pad_guard;       /* backward, bf16 path, softmax-attention layers (mixer 0); optional, needs kend.  Device int written by
+                                       amdseg_pad_rows_guard() on the gradient the backward starts from: 0 = every row at a position >=
+                                       kend[b] of that gradient is an exact zero.  Such rows stay exact zeros through every layer (a
+                                       masked key gets p = 0, so dK = dV = 0; its own query row has dctx = 0, so dQ = 0; LayerNorm, GELU
+                                       and dropout backward map 0 to 0), so with *pad_guard == 0 the input-gradient GEMMs skip the K loop
+                                       of 256-row tiles made of them (L % 256 == 0) and the weight-gradient GEMM walks only pad_runs:
+                                       bit-identical results, less work.  *pad_guard != 0 or NULL: dense. */
+    const int32_t* pad_runs;        /* with pad_guard: device [B][2] = {first, end} runs of 64-token tiles t (rows 64t .. 64t+63) that hold a
+                                       position < kend -- per sequence b with kend[b] > 0: {b*L/64, b*L/64 + ceil(kend[b]/64)}; L % 64 == 0 */
+    const int32_t* pad_counts;      /* with pad_guard: device int[2] = {tiles in those runs, number of runs} */
 } amdseg_bert_cfg;
 
 typedef struct amdseg_bert_layer_params {   /* bf16 compute shadows (+ transposes for dgrad), fp32 vectors */

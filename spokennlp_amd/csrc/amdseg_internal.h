@@ -12,7 +12,7 @@
 
 int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                         int epi, const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32,
-                        hipStream_t stream);
+                        hipStream_t stream, const int* zkend = nullptr, const int* zguard = nullptr, int zL = 0);
 int amdseg_gemm_tn_grouped_impl(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                                 float* const* C, const int* ldc, const int* N, const int* Kp, int M, int accumulate,
                                 hipStream_t stream);
@@ -43,7 +43,8 @@ void amdseg_reduce_defer_begin(int accumulate);
 void amdseg_reduce_rows(const float* partials, int nblocks, int stride, int n, float* out, int accumulate, hipStream_t s);
 int amdseg_gemm_tn_grouped_bias_impl(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                                      float* const* C, const int* ldc, const int* N, const int* Kp, int M, int accumulate,
-                                     float* const* colsum_out, float* const* colsum_scratch, hipStream_t stream);
+                                     float* const* colsum_out, float* const* colsum_scratch, hipStream_t stream,
+                                     const int* runs = nullptr, const int* counts = nullptr, const int* zguard = nullptr);
 int amdseg_reduce_defer_flush(hipStream_t s);
 int amdseg_attn_list_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                               const int* klist, const int* kcnt, int list_stride, const int* korder, hipStream_t s);
@@ -52,6 +53,7 @@ int amdseg_attn_list_bwd_impl(const void* qkv, const float* mask_bias, const voi
                               const int* qlist, const int* qcnt, int list_stride, const int* korder, const int* qorder, hipStream_t s);
 int amdseg_cast_transpose_batched_impl(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                        hipStream_t s);
+int amdseg_pad_rows_guard_impl(const float* x, const int* kend, int B, int L, int H, int* guard, hipStream_t s);
 int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_out, hipStream_t s);
 
 int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,

@@ -119,6 +119,9 @@ int amdseg_dropout(const void* x, void* y, size_t n, float p, uint64_t seed, int
                    amdseg_stream_t stream) {
     return amdseg_dropout_impl(x, y, n, p, seed, dtype_in, dtype_out, S(stream));
 }
+int amdseg_pad_rows_guard(const float* x, const int32_t* kend, int B, int L, int H, int32_t* guard, amdseg_stream_t stream) {
+    return amdseg_pad_rows_guard_impl(x, kend, B, L, H, guard, S(stream));
+}
 int amdseg_cast(const void* x, void* y, size_t n, int dtype_in, int dtype_out, amdseg_stream_t stream) {
     return amdseg_cast_impl(x, y, n, dtype_in, dtype_out, S(stream));
 }
@@ -407,20 +410,23 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         }
         return AMDSEG_OK;
     }
+    // rows of trailing padding carry exact-zero gradients all the way down (amdseg.h, amdseg_bert_cfg.pad_guard): the dgrad GEMMs skip
+    // their all-padding row tiles, the weight-gradient GEMM walks only the listed token tiles
+#define ZPAD (c->pad_guard ? c->kend : nullptr), c->pad_guard, c->L
     if (PHASE1(c)) {
     // LN2 backward: dz2 (residual grad), d_out = masked dz2 (grad of the FFN output dense), dln2, db2
     RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, part_ln2, g->ln2_g, g->ln2_b,
                               g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, c->dtype, s));
     // du = (d_out . W2) * gelu'(u)
-    RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD | (c->act ? AMDSEG_EPI_ACT_TANH : 0), nullptr, a->u, I, nullptr, 0, 0, s));
+    RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD | (c->act ? AMDSEG_EPI_ACT_TANH : 0), nullptr, a->u, I, nullptr, 0, 0, s, ZPAD));
     // dx1 = du . W1 + dz2
-    RET_IF(amdseg_gemm_nt_impl(w->du, I, p->w1_t, I, w->dx1, H, M, H, I, AMDSEG_EPI_ADD_RES, nullptr, w->dz2, H, nullptr, 0, 0, s));
+    RET_IF(amdseg_gemm_nt_impl(w->du, I, p->w1_t, I, w->dx1, H, M, H, I, AMDSEG_EPI_ADD_RES, nullptr, w->dz2, H, nullptr, 0, 0, s, ZPAD));
     // (db1 = colsum(du) and dbqkv = colsum(dqkv) come out of the grouped weight-gradient GEMM below)
     // LN1 backward
     RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, part_ln1, g->ln1_g,
                               g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, c->dtype, s));
     // dctx = d_ao . Wo
-    RET_IF(amdseg_gemm_nt_impl(d_ao, H, p->wo_t, H, w->dctx, H, M, H, H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, s));
+    RET_IF(amdseg_gemm_nt_impl(d_ao, H, p->wo_t, H, w->dctx, H, M, H, H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, s, ZPAD));
     }
     const int NP = NPROJ(c);
     if (PHASE2(c)) {
@@ -428,7 +434,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                     site_seed(c->seed, li, 0), c->window, c->nglobal, s, c->kend, c->seq_order));
     // dx_in = dqkv . Wqkv + dz1   (external mixer: the caller wrote ws.dqkv [M, nproj*H] between the phases)
-    RET_IF(amdseg_gemm_nt_impl(w->dqkv, NP, p->wqkv_t, NP, dx_in, H, M, H, NP, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s));
+    RET_IF(amdseg_gemm_nt_impl(w->dqkv, NP, p->wqkv_t, NP, dx_in, H, M, H, NP, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s, ZPAD));
     }
     if (!PHASE_WGRAD(c)) return AMDSEG_OK;
     // all four weight gradients of the layer in one grouped launch: dW = dY^T X
@@ -439,7 +445,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     const int N[4] = {H, I, H, NP}, K[4] = {I, H, H, H};
     float* cs_out[4] = {nullptr, g->b1, nullptr, g->bqkv};
     float* cs_scr[4] = {nullptr, part_b1, nullptr, part_bqkv};
-    RET_IF(amdseg_gemm_tn_grouped_bias_impl(4, A, lda, Bm, ldb, C, ldc, N, K, M, acc, cs_out, cs_scr, s));
+    RET_IF(amdseg_gemm_tn_grouped_bias_impl(4, A, lda, Bm, ldb, C, ldc, N, K, M, acc, cs_out, cs_scr, s, c->pad_runs, c->pad_counts, c->pad_guard));
     return AMDSEG_OK;
 }
 

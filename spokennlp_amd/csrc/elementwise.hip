@@ -718,6 +718,34 @@ int amdseg_dropout_impl(const void* x, void* y, size_t n, float p, uint64_t seed
     return amdseg_launch_status();
 }
 
+// *guard = 1 if any element of a row at a position >= kend[b] is not an exact zero (NaN counts), else 0.  One wave per row; rows in front
+// of kend leave at once, so the pass reads only the padded rows (reference: none -- this is the run-time check behind the
+// amdseg_bert_cfg.pad_* fields: the backward may drop work on rows whose gradient is an exact zero only after it has looked)
+__global__ __launch_bounds__(256) void pad_rows_guard_kernel(const float* __restrict__ x, const int* __restrict__ kend, int L, int H, int M,
+                                                             int* __restrict__ guard) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (row >= M) return;
+    const int b = row / L, p = row - b * L;
+    if (p < kend[b]) return;
+    const float* r = x + (size_t)row * H;
+    bool nz = false;
+    for (int c = l * 4; c < H; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(r + c);
+        nz |= !(v.x == 0.f) | !(v.y == 0.f) | !(v.z == 0.f) | !(v.w == 0.f);
+    }
+    if (__ballot(nz) != 0ull && l == 0) atomicOr(guard, 1);
+}
+
+int amdseg_pad_rows_guard_impl(const float* x, const int* kend, int B, int L, int H, int* guard, hipStream_t s) {
+    if (!x || !kend || !guard) return AMDSEG_ERR_ARG;
+    if (B <= 0 || L <= 0 || H <= 0 || (H % 4)) return AMDSEG_ERR_SHAPE;
+    hipError_t e = hipMemsetAsync(guard, 0, sizeof(int), s);
+    if (e != hipSuccess) return (int)e;
+    const int M = B * L;
+    hipLaunchKernelGGL(pad_rows_guard_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, kend, L, H, M, guard);
+    return amdseg_launch_status();
+}
+
 int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_out, hipStream_t s) {
     return amdseg_dropout_impl(x, y, n, 0.f, 0, dtype_in, dtype_out, s);
 }

@@ -612,7 +612,7 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
 
 int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                         int epi, const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32,
-                        hipStream_t stream) {
+                        hipStream_t stream, const int* zkend, const int* zguard, int zL) {
     if (!A || !B || !C) return AMDSEG_ERR_ARG;
     const int act = (epi >> 8) & 1;                         // AMDSEG_EPI_ACT_TANH: gelu_new instead of the erf GELU
     epi &= 0xff;
@@ -628,6 +628,8 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
 #endif
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldc2 = ldc2; a.M = M; a.N = N; a.K = K;
     a.tiles_m = M / BM; a.tiles_n = N / BN;
+    const bool zok = zkend && zguard && zL > 0 && (zL % PP_BM) == 0 && (M % zL) == 0;      // a 256-row tile lies inside one sequence
+    a.zkend = zok ? zkend : nullptr; a.zguard = zok ? zguard : nullptr; a.zL = zok ? zL : 0;
     switch (epi) {
         case EPI_NONE: return out_fp32 ? launch_nt<EPI_NONE, float>(a, stream) : launch_nt<EPI_NONE, bf16_t>(a, stream);
         case EPI_BIAS:
@@ -775,7 +777,8 @@ int amdseg_gemm_tn_grouped_impl(int nprob, const void* const* A, const int* lda,
 // kernel the sums come out of the GEMM's own A fragments (no extra pass over dY); otherwise amdseg_colsum runs.
 int amdseg_gemm_tn_grouped_bias_impl(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                                      float* const* C, const int* ldc, const int* N, const int* Kp, int M, int accumulate,
-                                     float* const* colsum_out, float* const* colsum_scratch, hipStream_t stream) {
+                                     float* const* colsum_out, float* const* colsum_scratch, hipStream_t stream,
+                                     const int* runs, const int* counts, const int* zguard) {
     if (nprob <= 0 || nprob > AMDSEG_MAX_GROUP || !A || !B || !C) return AMDSEG_ERR_ARG;
     if (M <= 0 || (M % 64)) return AMDSEG_ERR_SHAPE;
     GemmTNArgs a;
@@ -793,6 +796,8 @@ int amdseg_gemm_tn_grouped_bias_impl(int nprob, const void* const* A, const int*
     }
     for (int i = nprob; i < AMDSEG_MAX_GROUP; ++i) a.p[i] = a.p[0];
     a.nprob = nprob; a.M = M; a.accumulate = accumulate; a.total_tiles = tiles;
+    const bool zok = runs && counts && zguard;
+    a.runs = zok ? runs : nullptr; a.counts = zok ? counts : nullptr; a.zguard = zok ? zguard : nullptr;
     // 256 x 128 deep-pipeline kernel (gemm_dp.hip) when every problem tiles by it: ~0.7x the time of the kernel below
     static int tn_dp = -1;
     if (tn_dp < 0) { const char* e = getenv("AMDSEG_TN_DP"); tn_dp = e ? atoi(e) : 1; }

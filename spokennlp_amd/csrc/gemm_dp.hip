@@ -89,6 +89,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = a.K / 64;
+    bool ztile = false;                                       // workgroup-uniform: every row of this tile's A is an exact zero
+    if (a.zkend) { const int zb = m0 / a.zL; ztile = (m0 - zb * a.zL) >= a.zkend[zb] && *a.zguard == 0; }
+    if (!ztile) {
     DP_DMA_A(0, 0, 0) DP_DMA_A(0, 1, 0) DP_DMA_B(0, 0)
     if (nk > 1) { DP_DMA_A(1, 0, 1) DP_DMA_A(1, 1, 1) DP_DMA_B(1, 1) DP_WAIT_TILE(); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         DP_END();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();             // group 0 pays back the stagger barrier: every LDS read is retired now
+    }
 
     // ---- epilogue.  Lane owns row m = mf*16 + i16 and columns nf*16 + g*4 .. +4 of the wave tile.  bf16 results go through a
     // wave-private 16-KiB LDS image (2 x [64 rows][128 B], swizzled) so every global store instruction writes 8 full 128-B lines.
@@ -323,6 +327,12 @@ __device__ __forceinline__ const bf16_t* tn_uniform(const bf16_t* p) {
     return (const bf16_t*)(((uint64_t)hi << 32) | lo);
 }
 
+__device__ __forceinline__ const int* tn_uniform_i(const int* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const int*)(((uint64_t)hi << 32) | lo);
+}
+
 __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63;
@@ -360,7 +370,26 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nk = a.M / 64;
+    // K loop: all M / 64 token tiles, or only the caller's runs of tiles that are not known zeros.  Only the DMA prefetch needs tile
+    // indices (the compute side consumes the ring in order), so ONE wave-uniform iterator walks the runs: (it_cur, it_end) = the run being
+    // prefetched, refilled by a scalar load once per run (waited for inside its own asm, right after the top-of-tile lgkmcnt(0): the
+    // compiler turns loads behind the "memory"-clobbering asm of this kernel into vector loads, whose vmcnt wait would drain the ring)
+    const int* runs = a.runs;
+    if (runs && __builtin_amdgcn_readfirstlane(*a.zguard) != 0) runs = nullptr;
+    int nk = a.M / 64, it_cur = 0, it_end = nk, it_r = 0, it_nr = 1;
+    if (runs) {
+        nk = __builtin_amdgcn_readfirstlane(a.counts[0]); it_nr = __builtin_amdgcn_readfirstlane(a.counts[1]);
+        it_cur = it_nr > 0 ? __builtin_amdgcn_readfirstlane(runs[0]) : 0;
+        it_end = it_nr > 0 ? __builtin_amdgcn_readfirstlane(runs[1]) : 1;
+    }
+    // t = the next tile to prefetch, ph = t mod tiles_k (which K' tile of the row sums its columns: below); past the last tile it keeps
+    // returning the last one (re-fetched into a stage nobody reads)
+    int it_ph = it_cur % P.tiles_k;
+#define TN_NEXT(t, ph) do { t = it_cur; ph = it_ph; \
+        if (it_cur + 1 < it_end) { ++it_cur; it_ph = it_ph + 1 == P.tiles_k ? 0 : it_ph + 1; } \
+        else if (it_r + 1 < it_nr) { ++it_r; tn_i32x2 rv_; \
+            asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rv_) : "s"(tn_uniform_i(runs + 2 * it_r)) : "memory"); \
+            it_cur = rv_.x; it_end = rv_.y; it_ph = it_cur % P.tiles_k; } } while (0)
     // fused bias gradient: column sums of A (= dY) for free -- the A fragments are in registers anyway.  Tile (tn, tk) sums the K tiles
     // kt = tk (mod tiles_k) with v_dot2c_f32_bf16 against (1, 1) (4 per fragment, only the wc == 0 waves, ~1/tiles_k of the K tiles),
     // writes its partial to colsum_part[tk][n]; the host queues the sum over tk (deterministic second stage)
@@ -368,10 +397,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
     float accb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) accb[i] = 0.f;
-    int cs_phase = 0;                                       // kt mod tiles_k
-    TN_DMA(0, 0);
-    TN_DMA(1, min(1, nk - 1));                              // always three tiles (clamped): the vmcnt arithmetic below is uniform
-    TN_DMA(2, min(2, nk - 1));
+    int ph0, ph1, ph2;                                      // (token tile mod tiles_k) of the K tiles kt, kt+1, kt+2 (set by the prefetch iterator)
+    { int t0_, t1_, t2_; TN_NEXT(t0_, ph0); TN_NEXT(t1_, ph1); TN_NEXT(t2_, ph2);   // always three tiles (clamped): the vmcnt arithmetic below is uniform
+      TN_DMA(0, t0_); TN_DMA(1, t1_); TN_DMA(2, t2_); }
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // lane addresses of the gathers inside stage 0: lane (i16, g) of fragment column block c4 reads rows kh*32 + g*4 + (i16 >> 2) (+16)
@@ -417,9 +445,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
         TN_WAIT_FRAGS(FC); \
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          /* every K tile issues 6 pieces: tile kt+1 has landed */ \
         TN_SB(); __builtin_amdgcn_s_barrier(); TN_SB(); \
-        const bool cs_now = cs_on && cs_phase == tk; \
-        cs_phase = cs_phase + 1 == P.tiles_k ? 0 : cs_phase + 1; \
-        const int ktd_ = min(kt + 3, nk - 1);          /* past the end: re-fetch the last tile into a stage nobody reads */ \
+        const bool cs_now = cs_on && ph0 == tk; \
+        ph0 = ph1; ph1 = ph2; \
+        int ktd_; TN_NEXT(ktd_, ph2);                  /* tile of iteration kt + 3 */ \
         _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4) { aA[c4] = laA[c4] + sn * TN_STG; aB[c4] = laB[c4] + sn * TN_STG; } \
         __builtin_amdgcn_s_setprio(1); \
         _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) { \

@@ -17,6 +17,9 @@ struct GemmNTArgs {
     int lda, ldb, ldc, ldr, ldc2;
     int M, N, K;
     int tiles_m, tiles_n;
+    // optional (deep-pipeline kernel only): rows >= zkend[row / zL] of A are known to be exact zeros (activation gradients of trailing
+    // padding) unless *zguard != 0 -- a 256-row tile made of such rows skips its K loop and runs the epilogue on zero accumulators
+    const int* zkend; const int* zguard; int zL;
 };
 
 // bijective XCD-aware remap: hardware places workgroup b on XCD b % 8; give each XCD a contiguous tile range
@@ -33,5 +36,8 @@ template <int EPIX, typename OutT> int amdseg_launch_nt_dp(const GemmNTArgs& a, 
 // grouped TN GEMM (weight gradients): launch arguments shared by gemm.hip (128 x 128 kernel) and gemm_dp.hip (256 x 128 kernel)
 struct TNProblem { const bf16_t* A; const bf16_t* B; float* C; int N, Kp, lda, ldb, ldc, tile_begin, tiles_k;
                    float* colsum_part; };   // optional [tiles_k][N] scratch: per-K'-tile partial column sums of A (bias gradient), dp kernel only
-struct GemmTNArgs { TNProblem p[AMDSEG_MAX_GROUP]; int nprob, M, accumulate, total_tiles; };
+struct GemmTNArgs { TNProblem p[AMDSEG_MAX_GROUP]; int nprob, M, accumulate, total_tiles;
+                    // optional (deep-pipeline kernel only): runs[r] = {first, end} (r < counts[1]) = the runs of 64-token K tiles whose A
+                    // rows are not all exact zeros, counts[0] tiles in all; ignored (every tile walked) when *zguard != 0
+                    const int* runs; const int* counts; const int* zguard; };
 int amdseg_launch_tn_dp(const GemmTNArgs& a128, hipStream_t s);

@@ -170,6 +170,10 @@ class BertEncoderEngine:
         self._ct_table = None
         import os as _os
         self.skip_padded_chunks = _os.environ.get("AMDSEG_ATTN_NOSKIP", "0") != "1"
+        # backward: rows of trailing padding have exact-zero gradients; GEMM tiles made of them are dropped after a run-time check of the
+        # incoming gradient (amdseg_bert_cfg.pad_guard).  Softmax-attention encoders only (BERT, Longformer band); AMDSEG_PAD_ROWS_DENSE=1 = off
+        self.skip_padded_rows_bwd = self.skip_padded_chunks and _os.environ.get("AMDSEG_PAD_ROWS_DENSE", "0") != "1"
+        self._pad_guard = None
         self._arena_slot = 0
         self.max_live_arenas = 2                            # training arenas per shape that may be alive between forward and backward
         self.grad_sync = True                               # False inside no_sync(): accumulate locally, no bucket all-reduce
@@ -521,6 +525,17 @@ class BertEncoderEngine:
         A["seq_order"] = torch.argsort(A["kend"], descending=True, stable=True).to(torch.int32)     # longest first (dispatch order)
         cfg.kend = A["kend"].data_ptr() if self.skip_padded_chunks else None
         cfg.seq_order = A["seq_order"].data_ptr() if self.skip_padded_chunks else None
+        if train and self.skip_padded_rows_bwd:
+            # per sequence with a visible key: the run of 64-token tiles that hold a position < kend (what the weight-gradient GEMM of the
+            # backward walks: amdseg_bert_cfg.pad_runs), sequences without one last; device side, no host read
+            nt = Lseq // 64
+            if "pad_seq_tile0" not in A or A["pad_seq_tile0"].numel() != B:
+                A["pad_seq_tile0"] = torch.arange(0, B * nt, nt, dtype=torch.int32, device=self.device)
+            nv = (A["kend"] + 63) // 64
+            order = torch.argsort((nv == 0).to(torch.int8), stable=True)
+            first = A["pad_seq_tile0"][order]
+            A["pad_runs"] = torch.stack((first, first + nv[order]), dim=1).contiguous()
+            A["pad_counts"] = torch.stack((nv.sum(), (nv > 0).sum())).to(torch.int32)
         lib = L.load()
         s = torch.cuda.current_stream().cuda_stream
         eps = float(self.cfg.layer_norm_eps)
@@ -621,6 +636,16 @@ class BertEncoderEngine:
         if ctx.get("parity"):
             cfg.dtype = L.F32S
         dseq = dseq.contiguous()
+        if self.skip_padded_rows_bwd and not ctx.get("parity") and "pad_runs" in A and cfg.kend and (self.H % 4) == 0:
+            # rows of trailing padding: is their incoming gradient an exact zero (it is whenever the loss ignores them)?  Then it stays
+            # zero through every layer and the GEMMs of the backward drop those rows (include/amdseg.h, amdseg_bert_cfg.pad_guard)
+            if self._pad_guard is None:
+                self._pad_guard = torch.zeros(1, dtype=torch.int32, device=self.device)
+            L.check(lib.amdseg_pad_rows_guard(dseq.data_ptr(), A["kend"].data_ptr(), B, Lseq, self.H, self._pad_guard.data_ptr(), s),
+                    "amdseg_pad_rows_guard")
+            cfg.pad_guard = self._pad_guard.data_ptr()
+            cfg.pad_runs = A["pad_runs"].data_ptr()
+            cfg.pad_counts = A["pad_counts"].data_ptr()
         dy, other = ws["dy"]
         rc = lib.amdseg_dropout(dseq.data_ptr(), dy.data_ptr(), M * self.H, ctx["p_out"], ctx["seed"] * 1000003 + 29, L.F32, adt, s)
         L.check(rc, "amdseg_dropout(bwd)")

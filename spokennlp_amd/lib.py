@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("AMDSEG_LIB") or os.path.join(_HERE, "libamdseg.so")
 BF16, F32, F32S = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
 EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
@@ -21,7 +21,7 @@ class BertCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("heads", C.c_int32), ("I", C.c_int32),
                 ("ln_eps", f32), ("p_hidden", f32), ("p_attn", f32), ("seed", u64),
                 ("accumulate_grads", C.c_int32), ("dtype", C.c_int32), ("window", C.c_int32), ("nglobal", C.c_int32),
-                ("nproj", C.c_int32), ("mixer", C.c_int32), ("phase", C.c_int32), ("act", C.c_int32), ("kend", vp), ("seq_order", vp)]
+                ("nproj", C.c_int32), ("mixer", C.c_int32), ("phase", C.c_int32), ("act", C.c_int32), ("kend", vp), ("seq_order", vp), ("pad_guard", vp), ("pad_runs", vp), ("pad_counts", vp)]
 
 
 class LayerParams(C.Structure):
@@ -75,6 +75,7 @@ _PROTOS = {
     "amdseg_add_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, i32, vp],
     "amdseg_ln_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u64, i32, i32, vp],
     "amdseg_colsum": [vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "amdseg_pad_rows_guard": [vp, vp, i32, i32, i32, vp, vp],
     "amdseg_dropout": [vp, vp, sz, f32, u64, i32, i32, vp],
     "amdseg_cast": [vp, vp, sz, i32, i32, vp],
     "amdseg_cast_transpose": [vp, vp, vp, i32, i32, vp],

@@ -93,6 +93,7 @@ class PoNetEncoderEngine(BertEncoderEngine):
             hm[h, h * 64:(h + 1) * 64] = 1.0
         self.headmask = hm
         self._seg = None
+        self.skip_padded_rows_bwd = False         # pooling mixer: the zero-gradient argument of amdseg_bert_cfg.pad_guard is made for softmax attention
 
     def set_segments(self, segment_ids):
         self._seg = segment_ids

@@ -459,3 +459,55 @@ def test_trailing_padding_chunks_are_skipped_without_changing_a_bit(dev):
         gb = outs[False][2][n]
         tol = 1e-2 if "embeddings" in n else 2e-3
         assert float((ga - gb).abs().max()) <= tol * max(1e-3, float(ga.abs().max())), n
+
+
+@pytest.mark.gpu
+def test_backward_drops_the_rows_of_trailing_padding_without_changing_a_bit(dev):
+    """amdseg_bert_cfg.pad_guard / pad_runs: when the gradient the backward starts from is an exact zero on the rows of trailing padding,
+    those rows stay zero through every layer, the weight-gradient GEMM walks only the token tiles in front of kend and the input-gradient
+    GEMMs skip their all-padding 256-row tiles.  Driven at the engine (a fixed incoming gradient: no atomic scatter in front of the encoder
+    layers), the layer gradients must be bit-identical with the switch on and off.  With one non-zero element on a padded row the device-side
+    guard must fall back to the dense walk."""
+    from transformers import BertConfig
+    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+    torch.manual_seed(0)
+    cfg = BertConfig(vocab_size=300, hidden_size=768, num_attention_heads=12, num_hidden_layers=2, intermediate_size=3072,
+                     max_position_embeddings=512, num_labels=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    m = M(cfg).to(dev)
+    eng = m.engine()
+    B, L = 4, 512
+    lens = [512, 300, 200, 1]                                 # 256-row tiles made of padding: the second halves of sequences 2 and 3
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(5, 300, (B, L), generator=g).to(dev)
+    am = torch.zeros(B, L, dtype=torch.long)
+    for b, n in enumerate(lens):
+        am[b, :n] = 1
+    am = am.to(dev)
+    tt = torch.zeros_like(ids)
+    dseq0 = torch.randn(B, L, 768, generator=g).to(dev) * am[:, :, None].float()
+    layer_names = [n for n in eng.fp.offsets if ".encoder.layer." in n]
+    assert layer_names
+
+    def run(skip, dseq):
+        eng.skip_padded_rows_bwd = skip
+        _, ectx = eng.forward(ids, am, tt, True, seed=7, p_out=0.1)
+        eng.backward(ectx, dseq, accumulate=False)
+        torch.cuda.synchronize()
+        return {n: eng.fp.view(eng.fp.flat_g, n).clone() for n in layer_names}, int(eng._pad_guard.item()) if skip else None
+
+    on, guard = run(True, dseq0)
+    off, _ = run(False, dseq0)
+    assert guard == 0
+    for n in layer_names:
+        assert torch.equal(on[n], off[n]), n
+        assert float(on[n].abs().max()) > 0
+    dseq1 = dseq0.clone()
+    dseq1[2, 400, 5] = 1e-3                                   # a caller whose loss does look at a padded row
+    on1, guard1 = run(True, dseq1)
+    off1, _ = run(False, dseq1)
+    assert guard1 == 1
+    differs = 0
+    for n in layer_names:
+        assert torch.equal(on1[n], off1[n]), n
+        differs += int(not torch.equal(on1[n], on[n]))
+    assert differs > 0                                        # ... and that row's gradient did arrive in the weights
