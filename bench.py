@@ -446,6 +446,20 @@ def main():
         prof = instep_roofline(step, total_steps, args.prof_steps)
         prof_n = args.prof_steps
     if rank == 0:
+        if prof and "gemm_tn_dp_kernel" in prof and args.model in ("bert", "longformer") and args.precision == "bf16":
+            # the weight-gradient GEMM's flops above are the reference's arithmetic (every token row); the rows of trailing padding are exact
+            # zeros in dY and their 64-token tiles are not multiplied (amdseg_bert_cfg.pad_runs): say how much of the work was executed
+            eng = (model.module if hasattr(model, "module") else model).engine()
+            if getattr(eng, "skip_padded_rows_bwd", False):
+                am = torch.cat([b["attention_mask"].reshape(-1, args.seq_len) for b in batches]).cpu()
+                kend = ((am != 0).long() * torch.arange(1, args.seq_len + 1)[None, :]).amax(dim=1)
+                f = float(((kend + 63) // 64).sum()) / (am.shape[0] * (args.seq_len // 64))
+                t = prof["gemm_tn_dp_kernel"]
+                t["token_tiles_walked_frac"] = round(f, 4)
+                t["achieved_executed"] = round(t["achieved"] * f, 1)
+                t["frac_executed"] = round(t["frac"] * f, 4)
+                t["note"] = ("achieved / frac count the reference's flops (all token rows); the 64-token tiles of trailing padding hold exact-zero "
+                             "dY rows and are skipped -- *_executed count only the tiles that were multiplied")
         if prof:
             dom = max(prof, key=lambda k: prof[k]["us_per_step"]) if "gemm_nt_dp_kernel" not in prof else "gemm_nt_dp_kernel"
             d = prof[dom]

@@ -37,7 +37,6 @@ class BigBirdEncoderEngine(BertEncoderEngine):
         if not getattr(config, "use_bias", True):
             raise L.AmdsegError("use_bias=False is not implemented")
         self.emb_dropout_pre_ln = True
-        self.skip_padded_rows_bwd = False         # list attention: not wired (amdseg_bert_cfg.pad_guard)
         self.attention_type = getattr(config, "attention_type", "block_sparse")
         self._plans = {}
         self._cur = None

@@ -93,7 +93,8 @@ class PoNetEncoderEngine(BertEncoderEngine):
             hm[h, h * 64:(h + 1) * 64] = 1.0
         self.headmask = hm
         self._seg = None
-        self.skip_padded_rows_bwd = False         # pooling mixer: the zero-gradient argument of amdseg_bert_cfg.pad_guard is made for softmax attention
+        # amdseg_bert_cfg.pad_guard holds for the pooling mixer too: a padded token n has dctx_n = 0, so dHo_n = 0; it is no valid neighbour /
+        # run member, so no local or segment maximum routes a gradient to it; it is a masked key of the global aggregation (p = 0): dproj_n = 0
 
     def set_segments(self, segment_ids):
         self._seg = segment_ids

@@ -224,3 +224,41 @@ def test_bigbird_dropout_step_deterministic(dev):
     # embedding backward), so with 12 blocks of rows per table the gradient norm may differ in the last bits between runs
     assert vals[0][0] == vals[1][0]
     assert abs(vals[0][1] - vals[1][1]) <= 1e-6 * vals[0][1]
+
+
+def test_backward_drops_the_rows_of_trailing_padding_without_changing_a_bit(dev):
+    """amdseg_bert_cfg.pad_guard with block-sparse (list) attention: masked keys get p = 0 in the list kernels as in the full ones, so the
+    rows of trailing padding carry exact-zero gradients; engine level, fixed incoming gradient: layer gradients bit-identical on / off"""
+    from transformers import BigBirdConfig
+    from spokennlp_amd.bigbird_for_ts import BigBirdWithDAForSentenceLabelingTopicSegmentation as M
+    cfg = BigBirdConfig(num_labels=2, vocab_size=300, hidden_size=768, num_attention_heads=12, num_hidden_layers=2, intermediate_size=3072,
+                        max_position_embeddings=1024, block_size=64, num_random_blocks=3, attention_type="block_sparse",
+                        hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    torch.manual_seed(0)
+    m = M(cfg).to(dev)
+    eng = m.engine()
+    B, L = 4, 1024
+    lens = [1024, 900, 500, 130]
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(5, 300, (B, L), generator=g).to(dev)
+    am = torch.zeros(B, L, dtype=torch.long)
+    for b, n in enumerate(lens):
+        am[b, :n] = 1
+    am = am.to(dev)
+    tt = torch.zeros_like(ids)
+    dseq = torch.randn(B, L, 768, generator=g).to(dev) * am[:, :, None].float()
+    names = [n for n in eng.fp.offsets if ".encoder.layer." in n]
+
+    def run(skip):
+        eng.skip_padded_rows_bwd = skip
+        _, ectx = eng.forward(ids, am, tt, True, seed=7, p_out=0.1)
+        eng.backward(ectx, dseq, accumulate=False)
+        torch.cuda.synchronize()
+        return {n: eng.fp.view(eng.fp.flat_g, n).clone() for n in names}
+
+    on = run(True)
+    assert int(eng._pad_guard.item()) == 0
+    off = run(False)
+    for n in names:
+        assert float(on[n].abs().max()) > 0
+        assert torch.equal(on[n], off[n]), n

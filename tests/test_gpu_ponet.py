@@ -456,3 +456,50 @@ def test_modelscope_style_surface_and_position_table_extension(dev, tmp_path):
     m2 = PoNetForTokenClassification.from_pretrained(model_name_or_path=str(d0))
     m2.extend_position_embeddings(256)
     assert torch.equal(m2.ponet.embeddings.position_embeddings.weight.data, sd["ponet.embeddings.position_embeddings.weight"])
+
+
+def test_backward_drops_the_rows_of_trailing_padding(dev):
+    """amdseg_bert_cfg.pad_guard with the pooling mixer: a padded token gets no gradient from the pooling backward (no valid neighbour, no run
+    member, a masked key of the global aggregation), so the rows of trailing padding are exact zeros in every activation gradient and the
+    backward GEMMs drop them.  Engine level, fixed incoming gradient, switch on / off: the layer gradients agree to the noise of the pooling
+    backward's fp32 atomics; the padded rows of the dense run's workspaces are looked at directly."""
+    from spokennlp_amd.ponet import PoNetForTokenClassification, PoNetConfig
+    arch = dict(BASE, num_hidden_layers=2)
+    cfg = PoNetConfig(num_labels=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, **arch)
+    torch.manual_seed(0)
+    m = PoNetForTokenClassification(cfg).to(dev)
+    eng = m.engine()
+    B, L = 4, 1024
+    ids, am, seg, _ = make_inputs_4096(B, 11, L=L)
+    ids, am, seg = ids.to(dev), am.to(dev), seg.to(dev)
+    tt = torch.zeros_like(ids)
+    g = torch.Generator().manual_seed(2)
+    dseq = torch.randn(B, L, 768, generator=g).to(dev) * am[:, :, None].float()
+    names = [n for n in eng.fp.offsets if ".encoder.layer." in n]
+
+    def run(skip):
+        eng.skip_padded_rows_bwd = skip
+        eng.set_segments(seg)
+        _, ectx = eng.forward(ids, am, tt, True, seed=7, p_out=0.1)
+        A = ectx["arena"]
+        eng.backward(ectx, dseq, accumulate=False)
+        torch.cuda.synchronize()
+        return {n: eng.fp.view(eng.fp.flat_g, n).clone() for n in names}, A
+
+    on, _ = run(True)
+    assert int(eng._pad_guard.item()) == 0
+    on2, _ = run(True)
+    off, _ = run(False)
+    off2, A = run(False)
+    pad = (torch.arange(L, device=dev)[None, :] >= A["kend"][:, None].long()).reshape(-1)
+    assert int(pad.sum()) > 256
+    for name in ("dqkv", "du", "dctx", "dz1", "dz2", "dx1"):
+        rows = A["ws"][name].reshape(B * L, -1)[pad]
+        assert int((rows != 0).sum()) == 0, name
+    # the pooling backward sums with fp32 atomics and rounds to bf16: two runs of the SAME setting differ by a few bf16 flips; the two
+    # settings must not differ by more than that
+    for n in names:
+        scale = float(off[n].abs().max())
+        assert scale > 0
+        noise = max(float((on[n] - on2[n]).abs().max()), float((off[n] - off2[n]).abs().max()))
+        assert float((on[n] - off[n]).abs().max()) <= max(3 * noise, 3e-3 * scale), (n, noise, scale)   # (a dropped live tile: >= 1/64 of the sum)

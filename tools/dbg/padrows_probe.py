@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import bench
 dev = torch.device("cuda:0")
 fam = sys.argv[1] if len(sys.argv) > 1 else "bert"
-args = argparse.Namespace(model=fam, workload="full_da", seq_len=512 if fam == "bert" else 4096, seqs_per_gpu=32 if fam == "bert" else 4,
+args = argparse.Namespace(model=fam, workload="full_da", seq_len=512 if fam == "bert" else 4096, seqs_per_gpu=32 if fam == "bert" else (8 if fam == "ponet" else 4),
                           mode="train", precision="bf16")
 model, cfg = bench.build(args, dev)
 eng = model.engine()
