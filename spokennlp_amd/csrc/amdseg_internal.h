@@ -60,7 +60,8 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
                          float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr);
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
-                         int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr);
+                         int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,
+                         const int* qguard = nullptr);
 int amdseg_attn_f32_impl(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, int d,
                          float scale, int window, int nglobal, hipStream_t s);
 

@@ -432,7 +432,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     if (PHASE2(c)) {
     if (c->mixer == 0)
         RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
-                                    site_seed(c->seed, li, 0), c->window, c->nglobal, s, c->kend, c->seq_order));
+                                    site_seed(c->seed, li, 0), c->window, c->nglobal, s, c->kend, c->seq_order, c->pad_guard));
     // dx_in = dqkv . Wqkv + dz1   (external mixer: the caller wrote ws.dqkv [M, nproj*H] between the phases)
     RET_IF(amdseg_gemm_nt_impl(w->dqkv, NP, p->wqkv_t, NP, dx_in, H, M, H, NP, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s, ZPAD));
     }

@@ -73,6 +73,8 @@ struct AttnArgs {
     const int* korder; const int* qorder;   // optional [heads][L/64]: block index handled by the r-th workgroup of a head (longest lists first)
     const int* kend;                        // optional [B] (full attention): keys at positions >= kend[b] are all masked (<= -5000); 0 = none unmasked
     const int* seq_order;                   // optional [B] with kend: the sequence the b-th group of workgroups works on (longest first)
+    const int* qguard;                      // optional (backward, with kend): *qguard == 0 <=> the dctx rows at positions >= kend[b] are exact zeros
+                                            // (amdseg_bert_cfg.pad_guard): those query rows get dQ = 0 and add nothing to dK / dV, so they are not visited
 };
 
 // Band ("sliding window + global") visibility, [hf] models/longformer/modeling_longformer.py:524-604 restated as a mask:
@@ -386,6 +388,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #define bufK(i) (smem + (i) * 16384)
 #define bufV(i) (smem + 8192 + (i) * 16384)
 
+    if (!BAND && !LIST && a.qguard && a.kend) {             // (workgroup-uniform) a query block of trailing padding whose dO rows are exact zeros:
+        const int ke = a.kend[b];                           // delta = rowsum(dO * O) = 0, dS = P * (dP - delta) = 0, dQ = 0
+        if (ke > 0 && qb * (NW * 16) >= ke && *a.qguard == 0) {
+            bf16_t* op0 = a.dqkv + (tok0 + q) * a.H3 + h * HD;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) *reinterpret_cast<uint2*>(op0 + d * 16 + g * 4) = make_uint2(0u, 0u);
+            if (g == 0) a.delta[prow] = 0.f;
+            return;
+        }
+    }
     bf16x8 fq[2], fdo[2];
     {
         const bf16_t* qp = a.qkv + (tok0 + q) * a.H3 + h * HD;
@@ -637,6 +649,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         c1 = min(c1, (ke - 1) / CH);
         if (kb * (NW * 16) >= ke) c1 = c0 - 1;
     }
+    if (!BAND && !LIST && a.qguard && a.kend) {             // query chunks of trailing padding with exact-zero dO rows (AttnArgs.qguard): dP = 0 and
+        const int ke = a.kend[b];                           // delta = 0 there, so they add exact zeros to dK and dV
+        if (ke > 0 && *a.qguard == 0) c1 = min(c1, (ke - 1) / CH);
+    }
     int nch = c1 - c0 + 1;
     const int* lst = nullptr;
     ListWalk lw;
@@ -782,7 +798,7 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
-    a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order;
+    a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order; a.qguard = nullptr;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
     // algorithmic FLOPs: QK^T + PV over the visible keys (full: L, band: 2W + 1 + G)
     const double span = window > 0 ? (double)(2 * window + 1 + a.nglobal) : (double)L;
@@ -807,12 +823,12 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
 
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
-                         int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order) {
+                         int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order, const int* qguard) {
     if (!qkv || !mask_bias || !ctx || !dctx || !lse || !delta || !dqkv) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
-    a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order;
+    a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order; a.qguard = (window > 0 || !kend) ? nullptr : qguard;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = (float*)lse;
     a.dctx = (const bf16_t*)dctx; a.delta = delta; a.dqkv = (bf16_t*)dqkv;
     const size_t total = (size_t)B * L * heads * 8;
