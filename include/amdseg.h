@@ -169,6 +169,12 @@ int amdseg_ln_bwd(const void* dy, const void* z, const float* mean, const float*
 /* out[N] (+)= column sums of x[M, ld];  partials = workspace of ceil(M/128)*N floats  (bias gradients) */
 int amdseg_colsum(const void* x, int ld, float* partials, float* out, int M, int N, int accumulate, int dtype,
                   amdseg_stream_t stream);
+/* The padding plan of a batch, computed on the device from the int64 attention mask [B, L] (L % 64 == 0, B <= 8192): kend[B], seq_order[B],
+   pad_runs[B][2], pad_counts[2] as amdseg_bert_cfg documents them, and (mask_bias != NULL) the additive key mask
+   mask_bias[b, p] = (1 - mask[b, p]) * bias ([hf] modeling_utils.py get_extended_attention_mask; the reference has no plan: it multiplies
+   the padded positions like any other) */
+int amdseg_pad_plan(const int64_t* attention_mask, int B, int L, int32_t* kend, int32_t* seq_order, int32_t* pad_runs, int32_t* pad_counts,
+                    float* mask_bias, float bias, amdseg_stream_t stream);
 /* *guard = 1 if any element of x (fp32 [B*L, H], H % 4 == 0) in a row at a position >= kend[b] is not an exact zero (NaN counts), else 0:
    the check behind amdseg_bert_cfg.pad_guard.  Reads only those rows.  (No reference counterpart: the reference computes the padded rows.) */
 int amdseg_pad_rows_guard(const float* x, const int32_t* kend, int B, int L, int H, int32_t* guard, amdseg_stream_t stream);

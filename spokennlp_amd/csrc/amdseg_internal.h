@@ -31,7 +31,8 @@ int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamm
                            hipStream_t s);
 int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                        void* dz, void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M,
-                       int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s);
+                       int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s,
+                       const int* zkend = nullptr, const int* zguard = nullptr, int zL = 0);
 int amdseg_colsum_impl(const void* x, int ld, float* partials, float* out, int M, int N, int accumulate, int dtype,
                        hipStream_t s);
 int amdseg_dropout_impl(const void* x, void* y, size_t n, float p, uint64_t seed, int dtype_in, int dtype_out,
@@ -53,6 +54,8 @@ int amdseg_attn_list_bwd_impl(const void* qkv, const float* mask_bias, const voi
                               const int* qlist, const int* qcnt, int list_stride, const int* korder, const int* qorder, hipStream_t s);
 int amdseg_cast_transpose_batched_impl(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                        hipStream_t s);
+int amdseg_pad_plan_impl(const int64_t* mask, int B, int L, int* kend, int* seq_order, int* runs, int* counts, float* mask_bias, float bias,
+                         hipStream_t s);
 int amdseg_pad_rows_guard_impl(const float* x, const int* kend, int B, int L, int H, int* guard, hipStream_t s);
 int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_out, hipStream_t s);
 

@@ -119,6 +119,10 @@ int amdseg_dropout(const void* x, void* y, size_t n, float p, uint64_t seed, int
                    amdseg_stream_t stream) {
     return amdseg_dropout_impl(x, y, n, p, seed, dtype_in, dtype_out, S(stream));
 }
+int amdseg_pad_plan(const int64_t* attention_mask, int B, int L, int32_t* kend, int32_t* seq_order, int32_t* pad_runs, int32_t* pad_counts,
+                    float* mask_bias, float bias, amdseg_stream_t stream) {
+    return amdseg_pad_plan_impl(attention_mask, B, L, kend, seq_order, pad_runs, pad_counts, mask_bias, bias, S(stream));
+}
 int amdseg_pad_rows_guard(const float* x, const int32_t* kend, int B, int L, int H, int32_t* guard, amdseg_stream_t stream) {
     return amdseg_pad_rows_guard_impl(x, kend, B, L, H, guard, S(stream));
 }
@@ -416,7 +420,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     if (PHASE1(c)) {
     // LN2 backward: dz2 (residual grad), d_out = masked dz2 (grad of the FFN output dense), dln2, db2
     RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, part_ln2, g->ln2_g, g->ln2_b,
-                              g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, c->dtype, s));
+                              g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, c->dtype, s, ZPAD));
     // du = (d_out . W2) * gelu'(u)
     RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD | (c->act ? AMDSEG_EPI_ACT_TANH : 0), nullptr, a->u, I, nullptr, 0, 0, s, ZPAD));
     // dx1 = du . W1 + dz2
@@ -424,7 +428,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     // (db1 = colsum(du) and dbqkv = colsum(dqkv) come out of the grouped weight-gradient GEMM below)
     // LN1 backward
     RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, part_ln1, g->ln1_g,
-                              g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, c->dtype, s));
+                              g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, c->dtype, s, ZPAD));
     // dctx = d_ao . Wo
     RET_IF(amdseg_gemm_nt_impl(d_ao, H, p->wo_t, H, w->dctx, H, M, H, H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, s, ZPAD));
     }

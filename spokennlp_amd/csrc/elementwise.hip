@@ -178,8 +178,11 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, const float* mean, const float* rstd,
                                                      const float* gamma, T* dz, T* dbranch, float* partials, int M, int H,
-                                                     uint32_t thresh, float inv_keep, uint64_t seed) {
+                                                     uint32_t thresh, float inv_keep, uint64_t seed,
+                                                     const int* zkend, const int* zguard, int zL) {
     extern __shared__ float red[];         // [3][4 waves][H]
+    // rows of trailing padding whose dy is a known exact zero (amdseg_bert_cfg.pad_guard): dz = dbranch = 0, nothing added to the column sums
+    const bool zskip = zkend != nullptr && *zguard == 0;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nch = H >> 3;
     float ag[NCH][8], ab[NCH][8], abias[NCH][8];
@@ -195,6 +198,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
         const int m = blockIdx.x * LNB_ROWS + rr * 4 + w;
         if (m >= M) break;
         float g[NCH][8], x[NCH][8];
+        if (zskip) {                                        // (wave-uniform)
+            const int zb = m / zL;
+            if (m - zb * zL >= zkend[zb]) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[c][e] = 0.f;
+                row_store<T, NCH>(dz + (size_t)m * H, nch, l, g);
+                if (dbranch) row_store<T, NCH>(dbranch + (size_t)m * H, nch, l, g);
+                continue;
+            }
+        }
         row_load<T, NCH>(dy + (size_t)m * H, nch, l, g);
         row_load<T, NCH>(z + (size_t)m * H, nch, l, x);
         const float mu = mean[m], rs = rstd[m];
@@ -658,8 +673,10 @@ int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamm
 
 int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                        void* dz, void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M,
-                       int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s) {
+                       int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s,
+                       const int* zkend, const int* zguard, int zL) {
     if (!dy || !z || !mean || !rstd || !gamma || !dz) return AMDSEG_ERR_ARG;
+    if (!zkend || !zguard || zL <= 0 || (M % zL)) { zkend = nullptr; zguard = nullptr; zL = 1; }
     if ((dgamma || dbeta || dbias) && !partials) return AMDSEG_ERR_ARG;
     if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
     uint32_t th; float ik; drop_params(p, th, ik);
@@ -667,10 +684,10 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
     const size_t shm = (size_t)3 * 4 * H * sizeof(float);
     if (dtype == AMDSEG_BF16)
         ROWK(ln_bwd_kernel, bf16_t, H, dim3(nblk), dim3(256), shm, s, (const bf16_t*)dy, (const bf16_t*)z, mean, rstd,
-                           gamma, (bf16_t*)dz, (bf16_t*)dbranch, partials, M, H, th, ik, seed);
+                           gamma, (bf16_t*)dz, (bf16_t*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL);
     else
         ROWK(ln_bwd_kernel, float, H, dim3(nblk), dim3(256), shm, s, (const float*)dy, (const float*)z, mean, rstd, gamma,
-                           (float*)dz, (float*)dbranch, partials, M, H, th, ik, seed);
+                           (float*)dz, (float*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL);
     if (partials) {
         Reduce3 r;
         r.part[0] = partials; r.part[1] = partials + (size_t)nblk * H; r.part[2] = partials + (size_t)2 * nblk * H;
@@ -734,6 +751,59 @@ __global__ __launch_bounds__(256) void pad_rows_guard_kernel(const float* __rest
         nz |= !(v.x == 0.f) | !(v.y == 0.f) | !(v.z == 0.f) | !(v.w == 0.f);
     }
     if (__ballot(nz) != 0ull && l == 0) atomicOr(guard, 1);
+}
+
+// The per-batch padding plan the layer calls take (amdseg_bert_cfg.kend / seq_order / pad_runs / pad_counts) from the attention mask, on the
+// device: kend[b] = (last position with a non-zero mask) + 1; seq_order = the sequences by decreasing kend (stable); runs = {first, end} 64-token
+// tiles in front of kend for every sequence with kend > 0 (in batch order); counts = {tiles in the runs, runs}.
+__global__ __launch_bounds__(256) void pad_kend_kernel(const int64_t* __restrict__ mask, int L, int* __restrict__ kend,
+                                                       float* __restrict__ mask_bias, float bias) {
+    __shared__ int part[4];
+    const int b = blockIdx.x, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    int ke = 0;
+    for (int p = threadIdx.x; p < L; p += 256) {
+        const int64_t mv = mask[(size_t)b * L + p];
+        if (mv != 0) ke = p + 1;                                   // p grows: the last hit of this lane
+        if (mask_bias) mask_bias[(size_t)b * L + p] = (1.0f - (float)mv) * bias;    // the additive key mask, as the host mirror computed it
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ke = max(ke, __shfl_xor(ke, o, 64));
+    if (l == 0) part[w] = ke;
+    __syncthreads();
+    if (threadIdx.x == 0) kend[b] = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+__global__ __launch_bounds__(1024) void pad_plan_kernel(const int* __restrict__ kend, int B, int L, int* __restrict__ seq_order,
+                                                        int* __restrict__ runs, int* __restrict__ counts) {
+    extern __shared__ int sk[];
+    for (int b = threadIdx.x; b < B; b += blockDim.x) sk[b] = kend[b];
+    __syncthreads();
+    const int nt = L / 64;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int ke = sk[b];
+        int rank = 0, live = 0;
+        for (int j = 0; j < B; ++j) {
+            const int kj = sk[j];
+            rank += (kj > ke) || (kj == ke && j < b);
+            live += (j < b) && kj > 0;
+        }
+        seq_order[rank] = b;
+        if (ke > 0) { runs[2 * live] = b * nt; runs[2 * live + 1] = b * nt + (ke + 63) / 64; }
+    }
+    if (threadIdx.x == 0) {
+        int tiles = 0, nr = 0;
+        for (int j = 0; j < B; ++j) if (sk[j] > 0) { tiles += (sk[j] + 63) / 64; ++nr; }
+        counts[0] = tiles; counts[1] = nr;
+    }
+}
+
+int amdseg_pad_plan_impl(const int64_t* mask, int B, int L, int* kend, int* seq_order, int* runs, int* counts, float* mask_bias, float bias,
+                         hipStream_t s) {
+    if (!mask || !kend || !seq_order || !runs || !counts) return AMDSEG_ERR_ARG;
+    if (B <= 0 || B > 8192 || L <= 0 || (L % 64)) return AMDSEG_ERR_SHAPE;
+    hipLaunchKernelGGL(pad_kend_kernel, dim3(B), dim3(256), 0, s, mask, L, kend, mask_bias, bias);
+    hipLaunchKernelGGL(pad_plan_kernel, dim3(1), dim3(B < 1024 ? ((B + 63) / 64) * 64 : 1024), (size_t)B * sizeof(int), s, kend, B, L, seq_order,
+                       runs, counts);
+    return amdseg_launch_status();
 }
 
 int amdseg_pad_rows_guard_impl(const float* x, const int* kend, int B, int L, int H, int* guard, hipStream_t s) {

@@ -515,27 +515,24 @@ class BertEncoderEngine:
         # real score (as the reference's finfo.min does), while (mask - lse) and (score - max) keep their fp32 digits in rows whose
         # visible keys are ALL masked (padded queries of a band, fully padded sequences) -- with -1e30 those differences carry an
         # absolute error of ~1e23 and exp2 of them is inf (attention.hip folds mask and lse into the MFMA accumulator start)
-        torch.mul(1.0 - attention_mask.to(torch.float32), MASK_BIAS, out=A["mask_bias"])
-        # trailing padding: (last unmasked key) + 1 per sequence; the full-attention kernels do not visit the chunks past it (they add
-        # exact zeros: include/amdseg.h amdseg_bert_cfg.kend).  Computed once per forward, kept with the arena for backward.
+        # ... and the padding plan (include/amdseg.h amdseg_pad_plan): kend = (last unmasked key) + 1 per sequence -- the attention kernels do not
+        # visit the chunks past it (they add exact zeros) --, the sequences by decreasing kend (dispatch order), and for the backward the
+        # runs of 64-token tiles in front of kend (amdseg_bert_cfg.pad_runs).  One launch pair per forward, kept with the arena for backward.
         if "kend" not in A or A["kend"].numel() != B:
             A["kend"] = torch.empty(B, dtype=torch.int32, device=self.device)
-            A["kend_pos"] = torch.arange(1, Lseq + 1, dtype=torch.int32, device=self.device)
-        torch.amax((attention_mask != 0).to(torch.int32) * A["kend_pos"], dim=1, out=A["kend"])
-        A["seq_order"] = torch.argsort(A["kend"], descending=True, stable=True).to(torch.int32)     # longest first (dispatch order)
+            A["seq_order"] = torch.empty(B, dtype=torch.int32, device=self.device)
+            A["pad_runs"] = torch.zeros(B, 2, dtype=torch.int32, device=self.device)
+            A["pad_counts"] = torch.zeros(2, dtype=torch.int32, device=self.device)
+        am64 = attention_mask
+        if am64.dtype.is_floating_point:                    # soft masks: the host formula (kend from "non-zero")
+            torch.mul(1.0 - attention_mask.to(torch.float32), MASK_BIAS, out=A["mask_bias"])
+            am64 = attention_mask != 0
+        am64 = am64.to(torch.int64).contiguous()
+        L.check(L.load().amdseg_pad_plan(am64.data_ptr(), B, Lseq, A["kend"].data_ptr(), A["seq_order"].data_ptr(), A["pad_runs"].data_ptr(),
+                                         A["pad_counts"].data_ptr(), None if attention_mask.dtype.is_floating_point else A["mask_bias"].data_ptr(),
+                                         MASK_BIAS, torch.cuda.current_stream().cuda_stream), "amdseg_pad_plan")
         cfg.kend = A["kend"].data_ptr() if self.skip_padded_chunks else None
         cfg.seq_order = A["seq_order"].data_ptr() if self.skip_padded_chunks else None
-        if train and self.skip_padded_rows_bwd:
-            # per sequence with a visible key: the run of 64-token tiles that hold a position < kend (what the weight-gradient GEMM of the
-            # backward walks: amdseg_bert_cfg.pad_runs), sequences without one last; device side, no host read
-            nt = Lseq // 64
-            if "pad_seq_tile0" not in A or A["pad_seq_tile0"].numel() != B:
-                A["pad_seq_tile0"] = torch.arange(0, B * nt, nt, dtype=torch.int32, device=self.device)
-            nv = (A["kend"] + 63) // 64
-            order = torch.argsort((nv == 0).to(torch.int8), stable=True)
-            first = A["pad_seq_tile0"][order]
-            A["pad_runs"] = torch.stack((first, first + nv[order]), dim=1).contiguous()
-            A["pad_counts"] = torch.stack((nv.sum(), (nv > 0).sum())).to(torch.int32)
         lib = L.load()
         s = torch.cuda.current_stream().cuda_stream
         eps = float(self.cfg.layer_norm_eps)

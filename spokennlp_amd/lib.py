@@ -75,6 +75,7 @@ _PROTOS = {
     "amdseg_add_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, i32, vp],
     "amdseg_ln_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u64, i32, i32, vp],
     "amdseg_colsum": [vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "amdseg_pad_plan": [vp, i32, i32, vp, vp, vp, vp, vp, f32, vp],
     "amdseg_pad_rows_guard": [vp, vp, i32, i32, i32, vp, vp],
     "amdseg_dropout": [vp, vp, sz, f32, u64, i32, i32, vp],
     "amdseg_cast": [vp, vp, sz, i32, i32, vp],
