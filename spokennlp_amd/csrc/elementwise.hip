@@ -181,10 +181,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
                                                      uint32_t thresh, float inv_keep, uint64_t seed,
                                                      const int* zkend, const int* zguard, int zL) {
     extern __shared__ float red[];         // [3][4 waves][H]
-    // rows of trailing padding whose dy is a known exact zero (amdseg_bert_cfg.pad_guard): dz = dbranch = 0, nothing added to the column sums
-    const bool zskip = zkend != nullptr && *zguard == 0;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nch = H >> 3;
+    // rows of trailing padding whose dy is a known exact zero (amdseg_bert_cfg.pad_guard): dz = dbranch = 0, nothing added to the column sums
+    // (decided per BLOCK of 16 consecutive rows, zL % 16 == 0: a per-row branch inside the row loop kept the compiler from hoisting the next
+    //  row's loads over the current row's arithmetic: 30.4 -> 32.9 us)
+    if (zkend != nullptr && *zguard == 0) {
+        const int m0 = blockIdx.x * LNB_ROWS, zb = m0 / zL;
+        if (m0 - zb * zL >= zkend[zb]) {
+            float zero[NCH][8];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) zero[c][e] = 0.f;
+            for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+                const int m = m0 + rr * 4 + w;
+                if (m >= M) break;
+                row_store<T, NCH>(dz + (size_t)m * H, nch, l, zero);
+                if (dbranch) row_store<T, NCH>(dbranch + (size_t)m * H, nch, l, zero);
+            }
+            if (partials)
+                for (int i = threadIdx.x; i < 3 * H; i += 256) {
+                    const int k = i / H, c = i - k * H;
+                    partials[((size_t)k * gridDim.x + blockIdx.x) * H + c] = 0.f;
+                }
+            return;
+        }
+    }
     float ag[NCH][8], ab[NCH][8], abias[NCH][8];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -198,18 +221,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
         const int m = blockIdx.x * LNB_ROWS + rr * 4 + w;
         if (m >= M) break;
         float g[NCH][8], x[NCH][8];
-        if (zskip) {                                        // (wave-uniform)
-            const int zb = m / zL;
-            if (m - zb * zL >= zkend[zb]) {
-#pragma unroll
-                for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) g[c][e] = 0.f;
-                row_store<T, NCH>(dz + (size_t)m * H, nch, l, g);
-                if (dbranch) row_store<T, NCH>(dbranch + (size_t)m * H, nch, l, g);
-                continue;
-            }
-        }
         row_load<T, NCH>(dy + (size_t)m * H, nch, l, g);
         row_load<T, NCH>(z + (size_t)m * H, nch, l, x);
         const float mu = mean[m], rs = rstd[m];
@@ -274,22 +285,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
 }
 
 // out[c] (+)= sum_b partials[b*stride + offset + c]   (deterministic second stage)
-// block = 16 float4 column groups (64 columns) x 16 row lanes; each lane strides over the partial rows, LDS tree at the end
+// block = RED_CG float4 column groups (RED_COLS = 32 columns = one 128-B line per partial row) x RED_ROWS = 32 row lanes; each lane strides over
+// the partial rows, LDS tree at the end.  (Was 64 columns x 16 lanes: the LayerNorm jobs of a layer -- 6 x 768 columns of 1024 partial rows,
+// 19 MB -- ran on 72 workgroups with 64 dependent trips each: 12 us per layer; now 144 workgroups x 32 trips.)
+#define RED_CG 8
+#define RED_COLS 32
+#define RED_ROWS 32
 __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float* partials, int nblocks, int stride, int offset,
                                                                       int n, float* out, int accumulate) {
-    __shared__ float red[16][64];
-    const int cg = threadIdx.x & 15, ry = threadIdx.x >> 4;
-    const int c = blockIdx.x * 64 + cg * 4;
+    __shared__ float red[RED_ROWS][RED_COLS];
+    const int cg = threadIdx.x & (RED_CG - 1), ry = threadIdx.x / RED_CG;
+    const int c = blockIdx.x * RED_COLS + cg * 4;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const bool vec = (c + 3 < n) && ((stride & 3) == 0) && ((offset & 3) == 0);
     if (vec) {
 #pragma unroll 4
-        for (int b = ry; b < nblocks; b += 16) {
+        for (int b = ry; b < nblocks; b += RED_ROWS) {
             const float4 v = *reinterpret_cast<const float4*>(partials + (size_t)b * stride + offset + c);
             a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
         }
     } else {
-        for (int b = ry; b < nblocks; b += 16) {
+        for (int b = ry; b < nblocks; b += RED_ROWS) {
             const float* p = partials + (size_t)b * stride + offset;
             if (c < n) a0 += p[c];
             if (c + 1 < n) a1 += p[c + 1];
@@ -299,12 +315,12 @@ __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const floa
     }
     red[ry][cg * 4 + 0] = a0; red[ry][cg * 4 + 1] = a1; red[ry][cg * 4 + 2] = a2; red[ry][cg * 4 + 3] = a3;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < RED_COLS) {
+        const int cc = blockIdx.x * RED_COLS + threadIdx.x;
         if (cc < n) {
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sum += red[r][threadIdx.x];
+            for (int r = 0; r < RED_ROWS; ++r) sum += red[r][threadIdx.x];
             out[cc] = accumulate ? out[cc] + sum : sum;
         }
     }
@@ -312,28 +328,28 @@ __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const floa
 // three reductions in one launch (LayerNorm backward: dgamma, dbeta, dbias); blockIdx.y selects the output
 struct Reduce3 { const float* part[3]; float* out[3]; };
 __global__ __launch_bounds__(256) void reduce3_kernel(Reduce3 r, int nblocks, int n, int accumulate) {
-    __shared__ float red[16][64];
+    __shared__ float red[RED_ROWS][RED_COLS];
     float* out = r.out[blockIdx.y];
     if (!out) return;
     const float* partials = r.part[blockIdx.y];
-    const int cg = threadIdx.x & 15, ry = threadIdx.x >> 4;
-    const int c = blockIdx.x * 64 + cg * 4;
+    const int cg = threadIdx.x & (RED_CG - 1), ry = threadIdx.x / RED_CG;
+    const int c = blockIdx.x * RED_COLS + cg * 4;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c + 3 < n) {
 #pragma unroll 4
-        for (int b = ry; b < nblocks; b += 16) {
+        for (int b = ry; b < nblocks; b += RED_ROWS) {
             const float4 v = *reinterpret_cast<const float4*>(partials + (size_t)b * n + c);
             a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
         }
     }
     red[ry][cg * 4 + 0] = a0; red[ry][cg * 4 + 1] = a1; red[ry][cg * 4 + 2] = a2; red[ry][cg * 4 + 3] = a3;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < RED_COLS) {
+        const int cc = blockIdx.x * RED_COLS + threadIdx.x;
         if (cc < n) {
             float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) sum += red[q][threadIdx.x];
+            for (int q = 0; q < RED_ROWS; ++q) sum += red[q][threadIdx.x];
             out[cc] = accumulate ? out[cc] + sum : sum;
         }
     }
@@ -345,21 +361,21 @@ __global__ __launch_bounds__(256) void reduce3_kernel(Reduce3 r, int nblocks, in
 struct ReduceJob { const float* part; float* out; int nblocks, stride, offset, n; };
 struct ReduceJobs { ReduceJob job[AMDSEG_MAX_REDUCE_JOBS]; int njobs, accumulate; };
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs jobs) {
-    __shared__ float red[16][64];
+    __shared__ float red[RED_ROWS][RED_COLS];
     const ReduceJob j = jobs.job[blockIdx.y];
-    if ((int)blockIdx.x * 64 >= j.n) return;
-    const int cg = threadIdx.x & 15, ry = threadIdx.x >> 4;
-    const int c = blockIdx.x * 64 + cg * 4;
+    if ((int)blockIdx.x * RED_COLS >= j.n) return;
+    const int cg = threadIdx.x & (RED_CG - 1), ry = threadIdx.x / RED_CG;
+    const int c = blockIdx.x * RED_COLS + cg * 4;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const bool vec = (c + 3 < j.n) && ((j.stride & 3) == 0) && ((j.offset & 3) == 0);
     if (vec) {
 #pragma unroll 4
-        for (int b = ry; b < j.nblocks; b += 16) {
+        for (int b = ry; b < j.nblocks; b += RED_ROWS) {
             const float4 v = *reinterpret_cast<const float4*>(j.part + (size_t)b * j.stride + j.offset + c);
             a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
         }
     } else {
-        for (int b = ry; b < j.nblocks; b += 16) {
+        for (int b = ry; b < j.nblocks; b += RED_ROWS) {
             const float* p = j.part + (size_t)b * j.stride + j.offset;
             if (c < j.n) a0 += p[c];
             if (c + 1 < j.n) a1 += p[c + 1];
@@ -369,12 +385,12 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceJobs jobs) {
     }
     red[ry][cg * 4 + 0] = a0; red[ry][cg * 4 + 1] = a1; red[ry][cg * 4 + 2] = a2; red[ry][cg * 4 + 3] = a3;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < RED_COLS) {
+        const int cc = blockIdx.x * RED_COLS + threadIdx.x;
         if (cc < j.n) {
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sum += red[r][threadIdx.x];
+            for (int r = 0; r < RED_ROWS; ++r) sum += red[r][threadIdx.x];
             j.out[cc] = jobs.accumulate ? j.out[cc] + sum : sum;
         }
     }
@@ -388,7 +404,7 @@ int amdseg_reduce_defer_flush(hipStream_t s) {
     if (!d || d->njobs == 0) return AMDSEG_OK;
     int nmax = 0;
     for (int i = 0; i < d->njobs; ++i) nmax = d->job[i].n > nmax ? d->job[i].n : nmax;
-    hipLaunchKernelGGL(reduce_jobs_kernel, dim3((nmax + 63) / 64, d->njobs), dim3(256), 0, s, *d);
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3((nmax + RED_COLS - 1) / RED_COLS, d->njobs), dim3(256), 0, s, *d);
     return amdseg_launch_status();
 }
 // true if the job was queued (the caller then must keep `partials` untouched until the flush)
@@ -400,7 +416,7 @@ static inline bool defer_reduce(const float* partials, int nblocks, int stride, 
 static inline void launch_reduce(const float* partials, int nblocks, int stride, int offset, int n, float* out, int accumulate,
                                  hipStream_t s) {
     if (defer_reduce(partials, nblocks, stride, offset, n, out, accumulate)) return;
-    hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partials, nblocks, stride, offset, n, out, accumulate);
+    hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((n + RED_COLS - 1) / RED_COLS), dim3(256), 0, s, partials, nblocks, stride, offset, n, out, accumulate);
 }
 
 void amdseg_reduce_rows(const float* partials, int nblocks, int stride, int n, float* out, int accumulate, hipStream_t s) {
@@ -676,7 +692,7 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
                        int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s,
                        const int* zkend, const int* zguard, int zL) {
     if (!dy || !z || !mean || !rstd || !gamma || !dz) return AMDSEG_ERR_ARG;
-    if (!zkend || !zguard || zL <= 0 || (M % zL)) { zkend = nullptr; zguard = nullptr; zL = 1; }
+    if (!zkend || !zguard || zL <= 0 || (M % zL) || (zL % LNB_ROWS)) { zkend = nullptr; zguard = nullptr; zL = 1; }
     if ((dgamma || dbeta || dbias) && !partials) return AMDSEG_ERR_ARG;
     if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
     uint32_t th; float ik; drop_params(p, th, ik);
@@ -697,7 +713,7 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
             if (queued)
                 for (int k = 0; k < 3; ++k)
                     if (r.out[k]) queued = defer_reduce(r.part[k], nblk, H, 0, H, r.out[k], accumulate) && queued;
-            if (!queued) hipLaunchKernelGGL(reduce3_kernel, dim3((H + 63) / 64, 3), dim3(256), 0, s, r, nblk, H, accumulate);
+            if (!queued) hipLaunchKernelGGL(reduce3_kernel, dim3((H + RED_COLS - 1) / RED_COLS, 3), dim3(256), 0, s, r, nblk, H, accumulate);
         }
     }
     return amdseg_launch_status();
