@@ -171,7 +171,7 @@ class BertEncoderEngine:
         import os as _os
         self.skip_padded_chunks = _os.environ.get("AMDSEG_ATTN_NOSKIP", "0") != "1"
         # backward: rows of trailing padding have exact-zero gradients; GEMM tiles made of them are dropped after a run-time check of the
-        # incoming gradient (amdseg_bert_cfg.pad_guard).  Softmax-attention encoders only (BERT, Longformer band); AMDSEG_PAD_ROWS_DENSE=1 = off
+        # incoming gradient (amdseg_bert_cfg.pad_guard).  Every encoder family (the argument per mixer: DESIGN.md section 8); AMDSEG_PAD_ROWS_DENSE=1 = off
         self.skip_padded_rows_bwd = self.skip_padded_chunks and _os.environ.get("AMDSEG_PAD_ROWS_DENSE", "0") != "1"
         self._pad_guard = None
         self._arena_slot = 0
