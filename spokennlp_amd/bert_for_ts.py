@@ -107,6 +107,20 @@ class TopicSegHeadsMixin:
     == electra_for_ts.py / bigbird_for_ts.py): the anchor/augmented split, LossCalculator, CSSL, TSSP, cos-sim output.
     The concrete class provides `engine()` (the HIP encoder engine over its HF parameter container)."""
 
+    def amdseg_set_host_twins(self, pairs):
+        """pairs: name -> (device tensor, the host tensor it was copied from).  A training loop that uploads the batch itself (spokennlp_amd.
+        trainer.Trainer) leaves them here; forward() then reads label-like tensors from the host original instead of copying them back.
+        Matched by identity of the device tensor, replaced every step."""
+        import weakref
+        self._amdseg_host_twins = {id(d): (weakref.ref(d), h) for d, h in pairs.values()}
+
+    def _host_twin(self, t):
+        tw = getattr(self, "_amdseg_host_twins", None)
+        if not tw or t is None:
+            return None
+        e = tw.get(id(t))
+        return e[1] if e is not None and e[0]() is t else None
+
     def _init_heads(self, config, classifier_dropout):
         self.classifier_dropout_p = float(classifier_dropout)
         self.loss_calculator = _LossCalculator(config)
@@ -421,6 +435,13 @@ class TopicSegHeadsMixin:
             if need_tssp:
                 fetch["stm"] = sent_token_mask[:, 1]
                 fetch["spo"] = sent_pair_orders[:, 1]
+            # a caller that moved this batch to the device itself may have left the host originals (amdseg_set_host_twins): no copy back, no wait
+            tw_l, tw_m, tw_o = self._host_twin(labels), self._host_twin(sent_token_mask), self._host_twin(sent_pair_orders)
+            if tw_l is not None and (not need_tssp or (tw_m is not None and tw_o is not None)):
+                fetch = {}
+                host["labels"] = tw_l
+                if need_tssp:
+                    host["stm"], host["spo"] = tw_m[:, 1], tw_o[:, 1]
             for k, t in fetch.items():
                 if t.is_cuda:
                     h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
@@ -428,7 +449,7 @@ class TopicSegHeadsMixin:
                     host[k] = h
                 else:
                     host[k] = t
-            if labels.is_cuda:
+            if labels.is_cuda and fetch:
                 ev = torch.cuda.Event()
                 ev.record()
         if two_pass:   # anchor + augmented sequences in one encoder pass of 2B sequences

@@ -210,6 +210,15 @@ class Trainer(transformers.Trainer):
             main.wait_event(ev)
             for t in moved:
                 t.record_stream(main)                                  # freed blocks wait for the compute stream's readers
+            # the model's heads build their index lists on the host from the label-like tensors: hand it the host originals of this batch, so
+            # it does not copy them back and WAIT for that copy (a wait for the previous step's GPU work: the host could never run more than one
+            # forward ahead, and every host hiccup reached the GPU)
+            m = self.model
+            while hasattr(m, "module"):
+                m = m.module
+            if hasattr(m, "amdseg_set_host_twins"):
+                m.amdseg_set_host_twins({k: (out[k], v) for k, v in inputs.items()
+                                         if isinstance(v, torch.Tensor) and v.device.type == "cpu" and out[k] is not v})
             inputs = out
         return super()._prepare_inputs(inputs)
 

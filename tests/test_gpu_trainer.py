@@ -302,3 +302,40 @@ def test_trainer_interleaved_evaluation_and_checkpoint(dev, tmp_path):
     live = m.state_dict()
     k = "bert.encoder.layer.0.attention.self.query.weight"
     assert torch.equal(saved[k].cpu(), live[k].detach().cpu())
+
+
+def test_trainer_hands_the_host_labels_to_the_model_no_copy_back(dev, tmp_path, monkeypatch):
+    """`Trainer._prepare_inputs` uploads the pinned batch itself and leaves the host originals with the model (`amdseg_set_host_twins`): the
+    heads build their index lists from those instead of copying the labels back and waiting for that copy (= for the previous step's GPU
+    work).  Same seeds: the logged losses agree with and without the hand-over, and with it no forward waits on an event."""
+    from transformers import default_data_collator
+    from spokennlp_amd.trainer import Trainer
+    from spokennlp_amd.bert_for_ts import TopicSegHeadsMixin
+    z, sd, batch, arch = load_case("tiny_L64")
+    flags = flags_of(z, "train_full")
+    ds = _DS(_samples(arch))
+    waits = {"n": 0}
+    real_sync = torch.cuda.Event.synchronize
+
+    def counting_sync(self):
+        waits["n"] += 1
+        return real_sync(self)
+    monkeypatch.setattr(torch.cuda.Event, "synchronize", counting_sync)
+    logs = {}
+    for mode in ("twins", "copy_back"):
+        if mode == "copy_back":
+            monkeypatch.setattr(TopicSegHeadsMixin, "amdseg_set_host_twins", lambda self, pairs: None)
+        m = build_model(arch, flags, sd, dev, dropout=0.1)
+        m.amdseg_seed = 5
+        random.seed(3)
+        tr = Trainer(model=m, args=_args(tmp_path / mode, dataloader_pin_memory=True, gradient_accumulation_steps=1, max_steps=6),
+                     train_dataset=ds, data_collator=default_data_collator)
+        waits["n"] = 0
+        tr.train()
+        logs[mode] = ([h["loss"] for h in tr.state.log_history if "loss" in h], waits["n"])
+        assert getattr(tr, "_amdseg_side_copy", False)
+    assert len(logs["twins"][0]) == 6 and logs["twins"][0][0] == logs["copy_back"][0][0]        # first step: the same bits
+    for a, b in zip(logs["twins"][0], logs["copy_back"][0]):                                      # later: the atomic scatters' run-to-run noise
+        assert abs(a - b) <= 2e-3 * abs(b), logs                                                  # (Adam at lr 1e-3 amplifies it step by step)
+    assert logs["copy_back"][1] >= 6                         # one wait per forward without the hand-over ...
+    assert logs["twins"][1] <= logs["copy_back"][1] - 6      # ... none with it
