@@ -184,17 +184,26 @@ class Trainer(transformers.Trainer):
         the optimiser of step i and the embedding kernel of step i + 1 with the compute units idle (~0.8 ms of a 14.4 ms bert-base step).
         Here the shard hands out the pinned host batch and `_prepare_inputs` copies it on a side stream -- the host runs ~9 ms ahead of
         the GPU, so the copy finishes under step i's kernels and the compute stream only waits on an event that has long fired."""
-        dl = super().get_train_dataloader()
-        self._amdseg_side_copy = False
+        return self._host_batches(super().get_train_dataloader())
+
+    def get_eval_dataloader(self, eval_dataset=None):
+        return self._host_batches(super().get_eval_dataloader(eval_dataset))
+
+    def get_test_dataloader(self, test_dataset):
+        return self._host_batches(super().get_test_dataloader(test_dataset))
+
+    def _host_batches(self, dl):
         if (self.amdseg_native and self.args.dataloader_pin_memory and torch.cuda.is_available() and self.args.device.type == "cuda"
                 and type(dl).__name__ == "DataLoaderShard" and getattr(dl, "device", None) is not None):
             dl.device = None
             self._amdseg_side_copy = True
-            self._amdseg_copy_stream = torch.cuda.Stream(device=self.args.device)
+            if getattr(self, "_amdseg_copy_stream", None) is None:
+                self._amdseg_copy_stream = torch.cuda.Stream(device=self.args.device)
         return dl
 
     def _prepare_inputs(self, inputs):
-        if getattr(self, "_amdseg_side_copy", False) and isinstance(inputs, dict) and self.model.training:
+        if (getattr(self, "_amdseg_side_copy", False) and isinstance(inputs, dict)
+                and any(isinstance(v, torch.Tensor) and v.device.type == "cpu" for v in inputs.values())):
             dev = self.args.device
             main = torch.cuda.current_stream(dev)
             moved = []
