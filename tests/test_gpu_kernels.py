@@ -516,3 +516,55 @@ def test_attn_f32(dev, B, L, heads):
     assert rc == 0
     ref, _ = attn_ref(q32, mb, B, L, heads)
     assert (ctx - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,L", [(1, 64), (5, 128), (32, 512), (100, 192), (4, 4096)])
+def test_pad_plan_and_guard(dev, B, L):
+    """amdseg_pad_plan (kend / seq_order / pad_runs / pad_counts / additive mask from the int64 attention mask) against the same quantities
+    written out in torch, with interior zeros, fully padded and full sequences; amdseg_pad_rows_guard against a host loop"""
+    from spokennlp_amd import lib as Lb
+    lib = Lb.load()
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    lens = torch.randint(0, L + 1, (B,), generator=g)
+    lens[0] = L
+    if B > 2:
+        lens[1] = 0
+        lens[2] = 1
+    am = (torch.arange(L)[None, :] < lens[:, None]).long()
+    if B > 3:
+        am[3, : int(lens[3]) // 2] = 0                        # interior zeros do not move kend
+        am[3, 0] = 1 if lens[3] > 0 else 0
+    am_d = am.to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    kend = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    order = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    runs = torch.full((B, 2), -1, dtype=torch.int32, device=dev)
+    counts = torch.full((2,), -1, dtype=torch.int32, device=dev)
+    mb = torch.full((B, L), 7.0, device=dev)
+    Lb.check(lib.amdseg_pad_plan(am_d.data_ptr(), B, L, kend.data_ptr(), order.data_ptr(), runs.data_ptr(), counts.data_ptr(), mb.data_ptr(),
+                                 -30000.0, s), "amdseg_pad_plan")
+    ke = ((am != 0).long() * torch.arange(1, L + 1)[None, :]).amax(dim=1)
+    assert torch.equal(kend.cpu().long(), ke)
+    assert torch.equal(order.cpu().long(), torch.argsort(ke, descending=True, stable=True))
+    nv = (ke + 63) // 64
+    live = [b for b in range(B) if ke[b] > 0]
+    assert counts.cpu().tolist() == [int(nv.sum()), len(live)]
+    exp_runs = [[b * (L // 64), b * (L // 64) + int(nv[b])] for b in live]
+    assert runs.cpu()[: len(live)].tolist() == exp_runs
+    assert torch.equal(mb.cpu(), (1.0 - am.float()) * -30000.0)
+    assert lib.amdseg_pad_plan(am_d.data_ptr(), B, L + 1, kend.data_ptr(), order.data_ptr(), runs.data_ptr(), counts.data_ptr(), None, 0.0, s) != 0
+    # guard: exact zeros on the rows at positions >= kend <=> 0
+    H = 64
+    x = torch.randn(B, L, H, generator=g).to(dev)
+    pad = (torch.arange(L, device=dev)[None, :] >= kend[:, None].long())
+    x[pad] = 0
+    guard = torch.full((1,), 5, dtype=torch.int32, device=dev)
+    Lb.check(lib.amdseg_pad_rows_guard(x.data_ptr(), kend.data_ptr(), B, L, H, guard.data_ptr(), s), "amdseg_pad_rows_guard")
+    assert int(guard.item()) == 0
+    if int(pad.sum()) > 0:
+        bi, pi = [int(v[0]) for v in torch.nonzero(pad, as_tuple=True)]
+        for val in (1e-30, float("nan"), -0.0):
+            x2 = x.clone()
+            x2[bi, pi, H - 1] = val
+            Lb.check(lib.amdseg_pad_rows_guard(x2.data_ptr(), kend.data_ptr(), B, L, H, guard.data_ptr(), s), "amdseg_pad_rows_guard")
+            assert int(guard.item()) == (0 if val == 0 else 1), val
