@@ -511,3 +511,12 @@ def test_backward_drops_the_rows_of_trailing_padding_without_changing_a_bit(dev)
         assert torch.equal(on1[n], off1[n]), n
         differs += int(not torch.equal(on1[n], on[n]))
     assert differs > 0                                        # ... and that row's gradient did arrive in the weights
+    # nothing but padding (no visible key anywhere, an all-zero incoming gradient): zero runs, the weight-gradient GEMM's K loop is empty
+    am_keep = am.clone()
+    am.zero_()
+    on0, guard0 = run(True, torch.zeros_like(dseq0))
+    off0, _ = run(False, torch.zeros_like(dseq0))
+    am.copy_(am_keep)
+    assert guard0 == 0
+    for n in layer_names:
+        assert torch.equal(on0[n], off0[n]) and float(on0[n].abs().max()) == 0.0, n
