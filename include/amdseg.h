@@ -184,7 +184,8 @@ int amdseg_cast(const void* x, void* y, size_t n, int dtype_in, int dtype_out, a
 /* fp32 master W[N,K] -> bf16 Wb[N,K] and bf16 transpose Wt[K,N] (either may be NULL); N,K multiples of 64 */
 int amdseg_cast_transpose(const float* W, void* Wb, void* Wt, int N, int K, amdseg_stream_t stream);
 /* the same for n matrices in one launch (host pointer tables; Wb or Wt may be NULL as a whole): the per-step refresh of
- * the bf16 compute shadows after the optimiser step ([hf] trainer.py optimizer.step -> next forward) */
+ * the bf16 compute shadows after the optimiser step ([hf] trainer.py optimizer.step -> next forward).  W == NULL as a whole: the
+ * bf16 copies Wb are the INPUT (amdseg_adamw wrote them through its `shadow` argument) and only the transposes Wt are written */
 int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                   amdseg_stream_t stream);
 /* Block-list attention = BigBird block-sparse attention ([hf] models/big_bird/modeling_big_bird.py

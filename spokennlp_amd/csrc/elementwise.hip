@@ -510,6 +510,12 @@ __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(CastTranspo
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = ty * 4 + i;
+        if (!W) {                                           // transposes only, from the bf16 copies (written by the fused AdamW pass)
+            const uint2 q = *reinterpret_cast<const uint2*>(Wb + (size_t)(n0 + r) * K + k0 + tx * 4);
+            tile[r][tx * 4 + 0] = (bf16_t)(q.x & 0xffffu); tile[r][tx * 4 + 1] = (bf16_t)(q.x >> 16);
+            tile[r][tx * 4 + 2] = (bf16_t)(q.y & 0xffffu); tile[r][tx * 4 + 3] = (bf16_t)(q.y >> 16);
+            continue;
+        }
         const float4 v = *reinterpret_cast<const float4*>(W + (size_t)(n0 + r) * K + k0 + tx * 4);
         const bf16_t b0 = f2bf(v.x), b1 = f2bf(v.y), b2 = f2bf(v.z), b3 = f2bf(v.w);
         tile[r][tx * 4 + 0] = b0; tile[r][tx * 4 + 1] = b1; tile[r][tx * 4 + 2] = b2; tile[r][tx * 4 + 3] = b3;
@@ -845,15 +851,15 @@ int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K,
 
 int amdseg_cast_transpose_batched_impl(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                        hipStream_t s) {
-    if (n <= 0 || !W || !N || !K || (!Wb && !Wt)) return AMDSEG_ERR_ARG;
+    if (n <= 0 || !N || !K || (!Wb && !Wt) || (!W && !(Wb && Wt))) return AMDSEG_ERR_ARG;      // W == NULL: Wb is the input, Wt the output
     for (int base = 0; base < n; base += CT_MAXB) {
         CastTransposeBatch b = {};
         b.n = n - base < CT_MAXB ? n - base : CT_MAXB;
         int tiles = 0;
         for (int i = 0; i < b.n; ++i) {
             const int j = base + i;
-            if (!W[j] || N[j] <= 0 || K[j] <= 0 || (N[j] % 64) || (K[j] % 64)) return AMDSEG_ERR_SHAPE;
-            b.W[i] = W[j]; b.Wb[i] = Wb ? (bf16_t*)Wb[j] : nullptr; b.Wt[i] = Wt ? (bf16_t*)Wt[j] : nullptr;
+            if ((W && !W[j]) || (!W && (!Wb[j] || !Wt[j])) || N[j] <= 0 || K[j] <= 0 || (N[j] % 64) || (K[j] % 64)) return AMDSEG_ERR_SHAPE;
+            b.W[i] = W ? W[j] : nullptr; b.Wb[i] = Wb ? (bf16_t*)Wb[j] : nullptr; b.Wt[i] = Wt ? (bf16_t*)Wt[j] : nullptr;
             b.N[i] = N[j]; b.K[i] = K[j]; b.tile0[i] = tiles;
             tiles += (N[j] / 64) * (K[j] / 64);
         }

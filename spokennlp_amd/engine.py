@@ -359,7 +359,7 @@ class BertEncoderEngine:
         """call after writing encoder weights by a route none of the detectors below can see (`p.data.copy_(...)`, raw pointers)"""
         self._dirty = True
 
-    def refresh_shadows(self, force=False):
+    def refresh_shadows(self, force=False, copies_done=False):
         """bf16 compute copies of the encoder matrices (+ transposes).  Re-done when the masters MAY have changed:
           * a matrix Parameter's version counter moved (in-place torch ops, load_state_dict, foreach optimisers),
           * any torch optimiser stepped (global post-step hook: the fused torch AdamW bumps no version counter),
@@ -386,7 +386,8 @@ class BertEncoderEngine:
                               (C.c_void_p * n)(*[w.data_ptr() for w in Wts]), (C.c_int * n)(*[w.shape[0] for w in Ws]),
                               (C.c_int * n)(*[w.shape[1] for w in Ws]))
         n, pw, pb, pt, pn, pk = self._ct_table
-        rc = L.load().amdseg_cast_transpose_batched(n, pw, pb, pt, pn, pk, torch.cuda.current_stream().cuda_stream)
+        # copies_done: the fused AdamW has just written the bf16 copies -> transposes only, read from them (half the bytes of the masters)
+        rc = L.load().amdseg_cast_transpose_batched(n, None if copies_done else pw, pb, pt, pn, pk, torch.cuda.current_stream().cuda_stream)
         L.check(rc, "amdseg_cast_transpose_batched")
         if getattr(self, "_parity", None) is not None:
             self._split_parity_weights()
@@ -729,13 +730,15 @@ class BertEncoderEngine:
         self.opt_step += 1
         if coef is None:
             _, coef = self.grad_norm_and_clip_coef(max_grad_norm, grad_scale)
-        ops.adamw(self.fp.flat_p, self.fp.flat_g, self.adam_m, self.adam_v, None, lr, betas[0], betas[1], eps, weight_decay,
-                  self.opt_step, gscale=coef, zero_grad=zero_grad, chunk_flags=getattr(self, "_chunk_flags", None))
+        # the bf16 compute copies ride the AdamW pass (its `shadow` output); what is left for the refresh are the transposes, made from them
+        ride = getattr(self, "_parity", None) is None
+        ops.adamw(self.fp.flat_p, self.fp.flat_g, self.adam_m, self.adam_v, self.shadow if ride else None, lr, betas[0], betas[1], eps,
+                  weight_decay, self.opt_step, gscale=coef, zero_grad=zero_grad, chunk_flags=getattr(self, "_chunk_flags", None))
         self.fp.grad_is_zero = bool(zero_grad)
         if self.buckets is not None:
             self.buckets.reset_norm()
         self._fused_owner = True
-        self.refresh_shadows(force=True)
+        self.refresh_shadows(force=True, copies_done=ride)
 
 
 class EncoderFn(torch.autograd.Function):

@@ -15,4 +15,9 @@ run --model longformer --steps 10 --warmup 3
 run --model ponet --steps 10 --warmup 3
 run --model bigbird --steps 10 --warmup 3
 run --workload plain --steps 40 --warmup 10
+run --model longformer --mode infer --steps 20 --warmup 5
+run --model ponet --mode infer --steps 20 --warmup 5
+run --model bigbird --mode infer --steps 20 --warmup 5
+run --model longformer --seq-len 2048 --seqs-per-gpu 4 --steps 20 --warmup 5
+run --model bigbird --seq-len 2048 --seqs-per-gpu 4 --steps 20 --warmup 5
 cat $OUT
