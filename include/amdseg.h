@@ -154,6 +154,9 @@ int amdseg_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64
                         const float* pos, const float* type, const float* gamma, const float* beta, void* z, void* out,
                         float* mean, float* rstd, int M, int L, int H, int vocab, int type_vocab, int npos, float eps,
                         float dropout_p, uint64_t seed, int dtype, amdseg_stream_t stream);
+/* scatter of dz [M, H] into the three tables (fp32 atomics; rows with ids == pad_id add nothing to dword).  type_vocab < 0: the table has
+   -type_vocab rows and row 0 of dtype_emb ALREADY holds the column sum of dz over all rows (amdseg_ln_bwd's dbias output of the embedding
+   LayerNorm): rows of type t != 0 move their gradient from row 0 to row t, rows of type 0 add nothing (no hot-row atomics) */
 int amdseg_embed_bwd(const void* dz, const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, float* dword,
                      float* dpos, float* dtype_emb, int M, int L, int H, int vocab, int type_vocab, int npos, int pad_id,
                      int dtype, amdseg_stream_t stream);

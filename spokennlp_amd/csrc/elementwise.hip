@@ -108,28 +108,54 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
 }
 
 // scatter the embedding-sum gradient dz[M,H] into the three tables
+#define EMB_ROWS 16
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* dz, const int64_t* ids, const int64_t* type_ids,
                                                         const int64_t* pos_ids, float* dword, float* dpos, float* dtype,
                                                         int M, int L, int H, int vocab, int type_vocab, int npos, int pad_id) {
-    // block = 64 consecutive rows x one 256-column slab; type-embedding grads are reduced in LDS first (2-16 hot rows)
+    // block = EMB_ROWS consecutive rows x one 256-column slab; type-embedding grads are reduced in LDS first (2-16 hot rows).
+    // (64 rows per block = 64 dependent load -> atomic trips on 3 workgroups per CU: 99 us at M = 16384; 16 rows: see DESIGN section 8)
+    // type_vocab < 0: |type_vocab| rows, and row 0 of dtype ALREADY holds the column sum of dz over all rows (the caller let amdseg_ln_bwd write
+    // it as its dbias): a row of type t != 0 then moves its g from row 0 to row t, a row of type 0 adds nothing.  The usual inputs (one
+    // segment: every type id 0) then issue no type atomics at all -- they were 256-512 same-address atomics per column (385 us at M = 32768)
     __shared__ float tacc[4][256];
+    const bool t0sum = type_vocab < 0;
+    if (t0sum) type_vocab = -type_vocab;
     const int c = blockIdx.y * 256 + threadIdx.x;
-    const int r0 = blockIdx.x * 64;
+    const int r0 = blockIdx.x * EMB_ROWS;
     for (int t = 0; t < 4; ++t) tacc[t][threadIdx.x] = 0.f;
     if (c >= H) return;
-    for (int r = r0; r < r0 + 64 && r < M; ++r) {
+    for (int r = r0; r < r0 + EMB_ROWS && r < M; ++r) {
         const float g = Act<T>::ld(dz + (size_t)r * H + c);
+        if (g == 0.f) continue;                             // adds nothing anywhere.  The rows of trailing padding are exact zeros, and
+                                                            // with RoBERTa-style position ids they ALL point at one position row (padding_idx)
         int64_t id = ids[r];
         if (id >= 0 && id < vocab && id != pad_id) unsafeAtomicAdd(dword + (size_t)id * H + c, g);
-        int64_t pp = pos_ids ? pos_ids[r] : (int64_t)(r % L);
-        if (pp >= 0 && pp < npos) unsafeAtomicAdd(dpos + (size_t)pp * H + c, g);
+        if (pos_ids) {                                      // (default positions r % L: embed_bwd_pos_kernel, no atomics)
+            const int64_t pp = pos_ids[r];
+            if (pp >= 0 && pp < npos) unsafeAtomicAdd(dpos + (size_t)pp * H + c, g);
+        }
         int64_t tt = type_ids ? type_ids[r] : 0;
+        if (t0sum) {
+            if (tt == 0) continue;
+            tacc[0][threadIdx.x] -= g;                      // (also for ids outside the table: the forward clamps, the reference would raise)
+        }
         if (tt >= 0 && tt < 4 && tt < type_vocab) tacc[tt][threadIdx.x] += g;
         else if (tt >= 4 && tt < type_vocab) unsafeAtomicAdd(dtype + (size_t)tt * H + c, g);
     }
     for (int t = 0; t < 4 && t < type_vocab; ++t)
         if (tacc[t][threadIdx.x] != 0.f) unsafeAtomicAdd(dtype + (size_t)t * H + c, tacc[t][threadIdx.x]);
+}
+
+// default position ids (row r of the batch sits at position r % L): dpos[p] += sum over the B sequences of dz[b*L + p] -- every (p, column) has
+// one owner, so plain adds in batch order (deterministic) instead of B atomics per element (half of the scatter's atomic traffic)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const T* __restrict__ dz, float* __restrict__ dpos, int M, int L, int H, int npos) {
+    const int c = blockIdx.y * 256 + threadIdx.x, p = blockIdx.x;
+    if (c >= H || p >= npos) return;
+    float acc = 0.f;
+    for (int r = p; r < M; r += L) acc += Act<T>::ld(dz + (size_t)r * H + c);
+    dpos[(size_t)p * H + c] += acc;
 }
 
 // ------------------------------------------------------------------------------------------------ dropout + residual + LN
@@ -667,13 +693,17 @@ int amdseg_embed_bwd_impl(const void* dz, const int64_t* ids, const int64_t* typ
                            int npos, int pad_id, int dtype, hipStream_t s) {
     if (!dz || !ids || !dword || !dpos || !dtype_emb) return AMDSEG_ERR_ARG;
     if (M <= 0 || H <= 0) return AMDSEG_ERR_SHAPE;
-    dim3 grid((M + 63) / 64, (H + 255) / 256);
-    if (dtype == AMDSEG_BF16)
+    if (L <= 0) return AMDSEG_ERR_SHAPE;
+    dim3 grid((M + EMB_ROWS - 1) / EMB_ROWS, (H + 255) / 256), gridp(L < M ? L : M, (H + 255) / 256);
+    if (dtype == AMDSEG_BF16) {
         hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dz, ids, type_ids, pos_ids, dword, dpos,
                            dtype_emb, M, L, H, vocab, type_vocab, npos, pad_id);
-    else
+        if (!pos_ids) hipLaunchKernelGGL(embed_bwd_pos_kernel<bf16_t>, gridp, dim3(256), 0, s, (const bf16_t*)dz, dpos, M, L, H, npos);
+    } else {
         hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dz, ids, type_ids, pos_ids, dword, dpos,
                            dtype_emb, M, L, H, vocab, type_vocab, npos, pad_id);
+        if (!pos_ids) hipLaunchKernelGGL(embed_bwd_pos_kernel<float>, gridp, dim3(256), 0, s, (const float*)dz, dpos, M, L, H, npos);
+    }
     return amdseg_launch_status();
 }
 

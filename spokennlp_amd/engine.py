@@ -663,23 +663,26 @@ class BertEncoderEngine:
             L.check(rc, "amdseg_dropout(emb bwd)")
             dy, other = other, dy
         g = lambda n: self.fp.view(self.fp.flat_g, self.prefix + "embeddings." + n)        # noqa: E731
+        we, pe, te = g("word_embeddings.weight"), g("position_embeddings.weight"), g("token_type_embeddings.weight")
+        if not accumulate:
+            we.zero_(); pe.zero_(); te.zero_()
+        # the LayerNorm backward's third column sum (its "dbias" = colsum of dz) IS the gradient of token-type row 0 when every row has type 0
+        # (one-segment inputs); amdseg_embed_bwd then only moves the rows of other types out of it (type_vocab < 0) -- no hot-row atomics
+        type0_sum = not (ctx["p_h"] > 0 and self.emb_dropout_pre_ln)      # (pre-LN dropout: dz is masked AFTER this LayerNorm backward)
         rc = lib.amdseg_ln_bwd(dy.data_ptr(), A["emb_z"].data_ptr(), A["emb_mean"].data_ptr(), A["emb_rstd"].data_ptr(),
                                self._emb("LayerNorm.weight").data_ptr(), other.data_ptr(), None, ws["partials"].data_ptr(),
-                               g("LayerNorm.weight").data_ptr(), g("LayerNorm.bias").data_ptr(), None, M, self.H, 0.0, 0,
-                               1 if accumulate else 0, adt, s)
+                               g("LayerNorm.weight").data_ptr(), g("LayerNorm.bias").data_ptr(), te.data_ptr() if type0_sum else None,
+                               M, self.H, 0.0, 0, 1 if accumulate else 0, adt, s)
         L.check(rc, "amdseg_ln_bwd(emb)")
         if ctx["p_h"] > 0 and self.emb_dropout_pre_ln:
             rc = lib.amdseg_dropout(other.data_ptr(), dy.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, adt, adt, s)
             L.check(rc, "amdseg_dropout(emb bwd, pre-LN)")
             dy, other = other, dy
-        we, pe, te = g("word_embeddings.weight"), g("position_embeddings.weight"), g("token_type_embeddings.weight")
-        if not accumulate:
-            we.zero_(); pe.zero_(); te.zero_()
         pad = self.cfg.pad_token_id if getattr(self.cfg, "pad_token_id", None) is not None else -1
         pos = ctx.get("pos")
         rc = lib.amdseg_embed_bwd(other.data_ptr(), ctx["ids"].data_ptr(), ctx["tts"].data_ptr(), None if pos is None else pos.data_ptr(),
-                                  we.data_ptr(), pe.data_ptr(), te.data_ptr(), M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], pad,
-                                  adt, s)
+                                  we.data_ptr(), pe.data_ptr(), te.data_ptr(), M, Lseq, self.H, we.shape[0],
+                                  -te.shape[0] if type0_sum else te.shape[0], pe.shape[0], pad, adt, s)
         L.check(rc, "amdseg_embed_bwd")
         self._embed_backward_fixup(pe, pad)
         if self.overlap_wgrad:                      # every consumer of flat_g (clip, AdamW, torch optimizers) is on the current stream
