@@ -267,8 +267,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
                     s2 += g[c][e] * xh;
                 }
             }
-        s1 = wave_sum(s1) / (float)H;
-        s2 = wave_sum(s2) / (float)H;
+        s1 = wave_sum_dpp(s1) / (float)H;
+        s2 = wave_sum_dpp(s2) / (float)H;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
             if (l + c * 64 < nch) {
