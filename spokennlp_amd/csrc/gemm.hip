@@ -584,8 +584,21 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     // the kernels below: K = 3072 / 2304: 73 / 56 us vs 90 / 68 (ping-pong); K = 768 (since the LDS-DMA is issued as inline asm and
     // the GELU epilogues were slimmed): QKV 65 vs 67, dual-output FFN 95 vs 131, GELU-bwd 92 vs 127, N = 768: 24 vs 27; train step
     // 16.4 vs 16.9 ms.  AMDSEG_DP_MIN_K moves the threshold.
-    if ((a_in.M % 256) == 0 && ((a_in.N % 256) == 0 || (a_in.N % 192) == 0) && a_in.K >= dp_min_k && !g_force_small_tile)
-        return amdseg_launch_nt_dp<EPIX, OutT>(a_in, s);
+    if ((a_in.M % 256) == 0 && ((a_in.N % 256) == 0 || (a_in.N % 192) == 0) && a_in.K >= dp_min_k && !g_force_small_tile) {
+        // small M (the per-GPU batches run_finetune.sh ships with: 4 x 2048 or 8 x 512 tokens): the 256-row tiles no longer fill 256 CUs
+        // (M = 8192, N = 768: 128 workgroups) and the 128 x 128 kernel's four times as many workgroups, two per CU, win although it is
+        // ~1.4 x slower per flop.  Rounds of workgroups x relative time per round; measured with every GEMM forced small: bert-base at
+        // 8 sequences per step 1114 -> 1210 seq/s, longformer-base 4 x 2048 323 -> 330; at M = 16384 the deep-pipeline kernel wins everywhere.
+        const int t_dp = (a_in.M / 256) * ((a_in.N % 256) == 0 ? a_in.N / 256 : a_in.N / 192);
+        const int t_sm = (a_in.M / BM) * (a_in.N / BN);
+        const float c_dp = (float)((t_dp + 255) / 256), c_sm = 0.715f * (float)((t_sm + 511) / 512);
+        static int adaptive = -1;
+        if (adaptive < 0) { const char* e = getenv("AMDSEG_NT_ADAPTIVE"); adaptive = e ? atoi(e) : 1; }
+        if (!(adaptive && small_ok && c_sm < c_dp))
+            return amdseg_launch_nt_dp<EPIX, OutT>(a_in, s);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPIX, OutT>), dim3(a_in.tiles_m * a_in.tiles_n), dim3(256), 0, s, a_in);
+        return amdseg_launch_status();
+    }
     // the ping-pong kernel counts its in-flight stores (two outputs for BIAS_GELU): the single-output form runs on the 128x128 kernel
     const bool single_gelu = EPI == EPI_BIAS_GELU && !a_in.C2;
     if (single_gelu && !small_ok) return AMDSEG_ERR_SHAPE;
