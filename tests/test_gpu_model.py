@@ -511,6 +511,21 @@ def test_backward_drops_the_rows_of_trailing_padding_without_changing_a_bit(dev)
         assert torch.equal(on1[n], off1[n]), n
         differs += int(not torch.equal(on1[n], on[n]))
     assert differs > 0                                        # ... and that row's gradient did arrive in the weights
+    # gradient accumulation: a second micro-batch with other lengths ADDS into the same buffers (accumulate = 1 in every kernel)
+    def run_accum(skip):
+        eng.skip_padded_rows_bwd = skip
+        am2 = torch.zeros_like(am)
+        for b, n in enumerate([64, 512, 129, 300]):
+            am2[b, :n] = 1
+        for i, (mask, seed) in enumerate(((am, 7), (am2, 8))):
+            _, ectx = eng.forward(ids, mask, tt, True, seed=seed, p_out=0.1)
+            eng.backward(ectx, dseq0 * mask[:, :, None].float(), accumulate=i > 0)
+        torch.cuda.synchronize()
+        return {n: eng.fp.view(eng.fp.flat_g, n).clone() for n in layer_names}
+    acc_on, acc_off = run_accum(True), run_accum(False)
+    for n in layer_names:
+        assert torch.equal(acc_on[n], acc_off[n]), n
+        assert not torch.equal(acc_on[n], on[n])
     # nothing but padding (no visible key anywhere, an all-zero incoming gradient): zero runs, the weight-gradient GEMM's K loop is empty
     am_keep = am.clone()
     am.zero_()
