@@ -107,9 +107,10 @@ int amdseg_gelu_fwd_split_impl(const float* u, void* hs, int M, int I, int act, 
 int amdseg_gelu_bwd_split_impl(float* du, const float* u, void* dus, int M, int I, int act, hipStream_t s);
 int amdseg_add_inplace_impl(float* y, const float* x, size_t n, hipStream_t s);
 int amdseg_pattn_fwd_impl(const float* qkv, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale, float p,
-                          uint64_t seed, hipStream_t s);
+                          uint64_t seed, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr);
 int amdseg_pattn_bwd_impl(const float* qkv, const float* mask_bias, const float* ctx, const float* dctx, const float* lse, float* delta,
-                          float* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed, hipStream_t s);
+                          float* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed, hipStream_t s, const int* kend = nullptr,
+                          const int* seq_order = nullptr, const int* qguard = nullptr);
 
 // heads.hip
 int amdseg_heads_fwd_impl(const float* x, int M, int H, const float* logits, const int64_t* labels, const float* class_w, int C, int nseg,

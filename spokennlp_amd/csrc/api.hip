@@ -296,7 +296,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
             RET_IF(amdseg_split3_impl(fx, H, a->xs, M, H, 0, s));
             RET_IF(amdseg_gemm_nt_impl(a->xs, 3 * H, p->wqkv, 3 * H, a->qkv, 3 * H, M, 3 * H, 3 * H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 1, s));
             RET_IF(amdseg_pattn_fwd_impl((const float*)a->qkv, mask_bias, (float*)a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn,
-                                         site_seed(c->seed, li, 0), s));
+                                         site_seed(c->seed, li, 0), s, c->kend, c->seq_order));
         }
         if (!PHASE2(c)) return AMDSEG_OK;
         RET_IF(amdseg_split3_impl((const float*)a->ctx, H, a->ctx_s, M, H, 0, s));
@@ -390,7 +390,8 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         }
         if (PHASE2(c)) {
             RET_IF(amdseg_pattn_bwd_impl((const float*)a->qkv, mask_bias, (const float*)a->ctx, (const float*)w->dctx, a->lse, w->delta,
-                                         (float*)w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0), s));
+                                         (float*)w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0), s, c->kend, c->seq_order,
+                                         c->pad_guard));
             RET_IF(amdseg_split3_impl((const float*)w->dqkv, 3 * H, w->dqkv_s, M, 3 * H, 0, s));
             RET_IF(amdseg_colsum_impl(w->dqkv, 3 * H, part_bqkv, g->bqkv, M, 3 * H, acc, AMDSEG_F32, s));
             RET_IF(amdseg_gemm_nt_impl(w->dqkv_s, 9 * H, p->wqkv_t, 9 * H, dx_in, H, M, H, 9 * H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1, s));
@@ -410,7 +411,8 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
                 A[i] = Ai[i] + (term == 2 ? 2 * N[i] : 0);
                 Bm[i] = Bi[i] + (term == 1 ? 2 * K[i] : 0);
             }
-            RET_IF(amdseg_gemm_tn_grouped_impl(4, A, lda, Bm, ldb, C, ldc, N, K, M, term == 0 ? acc : 1, s));
+            RET_IF(amdseg_gemm_tn_grouped_bias_impl(4, A, lda, Bm, ldb, C, ldc, N, K, M, term == 0 ? acc : 1, nullptr, nullptr, s, c->pad_runs,
+                                                    c->pad_counts, c->pad_guard));
         }
         return AMDSEG_OK;
     }

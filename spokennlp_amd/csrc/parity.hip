@@ -150,8 +150,16 @@ struct PAttnArgs {
     const float* dctx; float* delta; float* dqkv;
     int B, L, heads;
     float scale, inv_keep; uint32_t thresh; uint64_t seed;
+    // trailing padding, as AttnArgs in attention.hip (pattn2 kernels): keys at positions >= kend[b] are masked (exp() == 0 exactly in fp32
+    // too) -> their chunks are not visited; seq_order = dispatch order (longest first); *qguard == 0: the dctx rows there are exact zeros
+    const int* kend; const int* seq_order; const int* qguard;
 };
 #define PA_LD 65
+__device__ __forceinline__ int pa2_visible_chunks(const PAttnArgs& a, int b, int ns) {
+    if (!a.kend) return ns;
+    const int ke = a.kend[b];
+    return ke > 0 ? min(ns, (ke + 63) >> 6) : ns;
+}
 
 __device__ __forceinline__ void pa_stage(float (*dst)[PA_LD], const float* src, int ld) {       // 64 rows x 64 floats, 256 threads
     const int t = threadIdx.x, r = t >> 2, c0 = (t & 3) * 16;
@@ -323,8 +331,9 @@ __global__ __launch_bounds__(256) void pattn2_fwd_kernel(PAttnArgs a) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
     int rb_, h, b;
     pa2_xcd_remap(rb_, h, b);
+    if (a.seq_order) b = a.seq_order[b];
     const int q = rb_ * 64 + w * 16 + i16;
-    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
+    const int H = a.heads * 64, H3 = 3 * H, ns = pa2_visible_chunks(a, b, a.L / 64);
     const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
     const size_t row = ((size_t)b * a.heads + h) * a.L + q;
     float qf[16];                                             // B operand of S^T = K Q^T: Q[q][4i + g]
@@ -392,10 +401,21 @@ __global__ __launch_bounds__(256) void pattn2_bwd_dq_kernel(PAttnArgs a) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
     int rb_, h, b;
     pa2_xcd_remap(rb_, h, b);
+    if (a.seq_order) b = a.seq_order[b];
     const int q = rb_ * 64 + w * 16 + i16;
-    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
+    const int H = a.heads * 64, H3 = 3 * H, ns = pa2_visible_chunks(a, b, a.L / 64);
     const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
     const size_t tok = (size_t)b * a.L + q, row = ((size_t)b * a.heads + h) * a.L + q;
+    if (a.qguard && a.kend) {                               // (workgroup-uniform) a query block of trailing padding with exact-zero dO rows: dQ = 0, delta = 0
+        const int ke = a.kend[b];
+        if (ke > 0 && rb_ * 64 >= ke && *a.qguard == 0) {
+            float* op0 = a.dqkv + tok * H3 + h * 64;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) *reinterpret_cast<float4*>(op0 + 16 * d + 4 * g) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g == 0) a.delta[row] = 0.f;
+            return;
+        }
+    }
     float qf[16], dof[16], dl = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -455,10 +475,26 @@ __global__ __launch_bounds__(256) void pattn2_bwd_dkv_kernel(PAttnArgs a) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
     int rb_, h, b;
     pa2_xcd_remap(rb_, h, b);
+    if (a.seq_order) b = a.seq_order[b];
     const int key = rb_ * 64 + w * 16 + i16;
-    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
+    const int H = a.heads * 64, H3 = 3 * H;
+    int ns = a.L / 64;
     const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
     const size_t tok = (size_t)b * a.L + key, bh = (size_t)b * a.heads + h;
+    if (a.kend) {
+        const int ke = a.kend[b];
+        if (ke > 0 && rb_ * 64 >= ke) {                     // a key block wholly in the trailing padding: p == 0 for every query -> dK = dV = 0
+            float* okp0 = a.dqkv + tok * H3 + H + h * 64;
+            float* ovp0 = a.dqkv + tok * H3 + 2 * H + h * 64;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                *reinterpret_cast<float4*>(okp0 + 16 * d + 4 * g) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(ovp0 + 16 * d + 4 * g) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
+        if (ke > 0 && a.qguard && *a.qguard == 0) ns = min(ns, (ke + 63) >> 6);      // query chunks of padding: dO = 0 and delta = 0 there
+    }
     float kf[16], vf[16];                                     // B operands: K[key][4i + g], V[key][4i + g]
 #pragma unroll
     for (int i = 0; i < 16; ++i) { kf[i] = base[(size_t)key * H3 + H + 4 * i + g]; vf[i] = base[(size_t)key * H3 + 2 * H + 4 * i + g]; }
@@ -530,12 +566,13 @@ static int pattn_fill(PAttnArgs& a, int B, int L, int heads, float scale, float 
 }
 
 int amdseg_pattn_fwd_impl(const float* qkv, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale, float p,
-                          uint64_t seed, hipStream_t s) {
+                          uint64_t seed, hipStream_t s, const int* kend, const int* seq_order) {
     if (!qkv || !mask_bias || !ctx) return AMDSEG_ERR_ARG;
     PAttnArgs a = {};
     int rc = pattn_fill(a, B, L, heads, scale, p, seed);
     if (rc) return rc;
     a.qkv = qkv; a.mask_bias = mask_bias; a.ctx = ctx; a.lse = lse;
+    a.kend = kend; a.seq_order = kend ? seq_order : nullptr;
     if (!pattn_use_valu()) {
         hipLaunchKernelGGL(pattn2_fwd_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
         return amdseg_launch_status();
@@ -550,12 +587,14 @@ int amdseg_pattn_fwd_impl(const float* qkv, const float* mask_bias, float* ctx, 
 }
 
 int amdseg_pattn_bwd_impl(const float* qkv, const float* mask_bias, const float* ctx, const float* dctx, const float* lse, float* delta,
-                          float* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed, hipStream_t s) {
+                          float* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed, hipStream_t s, const int* kend,
+                          const int* seq_order, const int* qguard) {
     if (!qkv || !mask_bias || !ctx || !dctx || !lse || !delta || !dqkv) return AMDSEG_ERR_ARG;
     PAttnArgs a = {};
     int rc = pattn_fill(a, B, L, heads, scale, p, seed);
     if (rc) return rc;
     a.qkv = qkv; a.mask_bias = mask_bias; a.ctx = (float*)ctx; a.lse = (float*)lse; a.dctx = dctx; a.delta = delta; a.dqkv = dqkv;
+    a.kend = kend; a.seq_order = kend ? seq_order : nullptr; a.qguard = kend ? qguard : nullptr;
     if (!pattn_use_valu()) {
         hipLaunchKernelGGL(pattn2_bwd_dq_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
         hipLaunchKernelGGL(pattn2_bwd_dkv_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);

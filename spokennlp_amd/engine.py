@@ -634,7 +634,7 @@ class BertEncoderEngine:
         if ctx.get("parity"):
             cfg.dtype = L.F32S
         dseq = dseq.contiguous()
-        if self.skip_padded_rows_bwd and not ctx.get("parity") and "pad_runs" in A and cfg.kend and (self.H % 4) == 0:
+        if self.skip_padded_rows_bwd and "pad_runs" in A and cfg.kend and (self.H % 4) == 0:
             # rows of trailing padding: is their incoming gradient an exact zero (it is whenever the loss ignores them)?  Then it stays
             # zero through every layer and the GEMMs of the backward drop those rows (include/amdseg.h, amdseg_bert_cfg.pad_guard)
             if self._pad_guard is None:

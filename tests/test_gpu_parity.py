@@ -179,3 +179,45 @@ def test_parity_training_loop_and_mode_switch(dev):
             outs[prec] = m(**b)[1].float().cpu()
     assert (outs["parity"] - outs["fp32"]).abs().max().item() < 1e-3
     assert (outs["bf16"] - outs["fp32"]).abs().max().item() < 0.1
+
+
+def test_parity_precision_skips_trailing_padding_without_changing_a_bit(dev):
+    """the fp32 attention kernels (pattn2) and the three split-bf16 weight-gradient launches take the same padding plan as the bf16 path
+    (amdseg_bert_cfg.kend / seq_order / pad_guard / pad_runs): encoder output and layer gradients bit-identical with the plan on and off"""
+    from transformers import BertConfig
+    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+    torch.manual_seed(0)
+    cfg = BertConfig(vocab_size=300, hidden_size=768, num_attention_heads=12, num_hidden_layers=2, intermediate_size=3072,
+                     max_position_embeddings=512, num_labels=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    cfg.amdseg_precision = "parity"
+    m = M(cfg).to(dev)
+    eng = m.engine()
+    B, L = 4, 512
+    lens = [512, 300, 200, 1]
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(5, 300, (B, L), generator=g).to(dev)
+    am = torch.zeros(B, L, dtype=torch.long)
+    for b, n in enumerate(lens):
+        am[b, :n] = 1
+    am = am.to(dev)
+    tt = torch.zeros_like(ids)
+    dseq = torch.randn(B, L, 768, generator=g).to(dev) * am[:, :, None].float()
+    names = [n for n in eng.fp.offsets if ".encoder.layer." in n]
+
+    def run(skip):
+        eng.skip_padded_chunks = skip
+        eng.skip_padded_rows_bwd = skip
+        out, ectx = eng.forward(ids, am, tt, True, seed=7, p_out=0.1)
+        assert ectx.get("parity")
+        out = out.clone()
+        eng.backward(ectx, dseq, accumulate=False)
+        torch.cuda.synchronize()
+        return out, {n: eng.fp.view(eng.fp.flat_g, n).clone() for n in names}
+
+    out_on, on = run(True)
+    assert int(eng._pad_guard.item()) == 0
+    out_off, off = run(False)
+    assert torch.equal(out_on, out_off)
+    for n in names:
+        assert float(on[n].abs().max()) > 0
+        assert torch.equal(on[n], off[n]), n
