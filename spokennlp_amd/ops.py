@@ -239,10 +239,12 @@ def embed_ln_fwd(ids, type_ids, pos_ids, word, pos, typ, gamma, beta, Lseq, eps,
     return out, z, mean, rstd
 
 
-def embed_bwd(dz, ids, type_ids, pos_ids, dword, dpos, dtyp, Lseq, pad_id=-1):
+def embed_bwd(dz, ids, type_ids, pos_ids, dword, dpos, dtyp, Lseq, pad_id=-1, type0_holds_colsum=False):
+    """type0_holds_colsum: row 0 of dtyp already holds the column sum of dz (include/amdseg.h: type_vocab < 0)"""
     M, H = dz.shape
     rc = L.load().amdseg_embed_bwd(_p(dz), _p(ids), _p(type_ids), _p(pos_ids), _p(dword), _p(dpos), _p(dtyp), M, Lseq, H,
-                                   dword.shape[0], dtyp.shape[0], dpos.shape[0], pad_id, _dt(dz), _s())
+                                   dword.shape[0], -dtyp.shape[0] if type0_holds_colsum else dtyp.shape[0], dpos.shape[0], pad_id,
+                                   _dt(dz), _s())
     L.check(rc, "amdseg_embed_bwd")
 
 

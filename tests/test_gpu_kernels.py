@@ -346,6 +346,18 @@ def test_embed_ln_fwd_bwd(dev, dtype):
     assert (dword - rw).abs().max().item() < 1e-4
     assert (dpos - rp).abs().max().item() < 1e-4
     assert (dtyp - rt).abs().max().item() < 1e-3
+    # type_vocab < 0: row 0 arrives holding colsum(dz) (the embedding LayerNorm backward's third column sum); rows of other types move out of it.
+    # Explicit position ids (the atomic path) and rows that are exact zeros (they add nothing anywhere)
+    dz2 = dz.clone(); dz2[5] = 0; dz2[70] = 0
+    pos_ids = torch.randint(0, L, (B * L,), generator=g).to(dev)
+    for tt2 in (tt, torch.zeros_like(tt)):
+        dword2 = torch.zeros_like(word); dpos2 = torch.zeros_like(pos); dtyp2 = torch.zeros_like(typ)
+        dtyp2[0] = dz2.float().sum(0)
+        ops.embed_bwd(dz2, ids, tt2, pos_ids, dword2, dpos2, dtyp2, L, pad_id=0, type0_holds_colsum=True)
+        rw2 = torch.zeros_like(word).index_add_(0, ids, dz2.float()); rw2[0] = 0
+        assert (dword2 - rw2).abs().max().item() < 1e-4
+        assert (dpos2 - torch.zeros_like(pos).index_add_(0, pos_ids, dz2.float())).abs().max().item() < 1e-4
+        assert (dtyp2 - torch.zeros_like(typ).index_add_(0, tt2, dz2.float())).abs().max().item() < 1e-3
 
 
 @pytest.mark.parametrize("dtype,H", [(torch.bfloat16, 768), (torch.float32, 768), (torch.bfloat16, 128), (torch.float32, 1024)])
