@@ -487,6 +487,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():     # (also the group accelerate opens for the Trainer leg under torchrun)
         torch.distributed.destroy_process_group()
 
 
