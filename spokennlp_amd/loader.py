@@ -69,10 +69,14 @@ def batch_indices(n_samples, batch_size, rank=0, world=1, drop_last=True):
 
 
 class DevicePrefetcher:
-    """iterates dicts of int64 device tensors (B, 2, L) over `features` (the column dict of prepare_features)"""
+    """iterates dicts of int64 device tensors (B, 2, L) over `features` (the column dict of prepare_features).
+    `model`: the drop-in model the batches are fed to -- before a batch is handed out, the host originals of its tensors are left with it
+    (`amdseg_set_host_twins`), so its loss heads read the label-like tensors from the host copy instead of copying them back from the device
+    and waiting for the previous step's GPU work (as spokennlp_amd.trainer.Trainer does for the HF loop)."""
 
-    def __init__(self, features, batches, device, depth=2, columns=MODEL_COLUMNS):
+    def __init__(self, features, batches, device, depth=2, columns=MODEL_COLUMNS, model=None):
         self.features, self.batches, self.device, self.columns = features, batches, torch.device(device), columns
+        self.model = model
         self.q = queue.Queue(maxsize=depth)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self.thread = threading.Thread(target=self._work, daemon=True)
@@ -113,4 +117,6 @@ class DevicePrefetcher:
                 torch.cuda.current_stream(self.device).wait_event(ev)
                 for t in batch.values():
                     t.record_stream(torch.cuda.current_stream(self.device))
+                if self.model is not None and hasattr(self.model, "amdseg_set_host_twins"):
+                    self.model.amdseg_set_host_twins({c: (batch[c], item[2][c]) for c in batch})
             yield batch

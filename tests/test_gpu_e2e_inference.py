@@ -87,3 +87,24 @@ def test_prefetcher_feeds_training_steps(dev):
         eng.adamw_step(5e-5)
         losses.append(loss.item())
     assert len(losses) == 6 and all(np.isfinite(losses))
+    # the same with the host originals handed to the model (no copy back of the labels, no event wait in forward): same first loss
+    m2 = build_model(arch, flags_of(z, "train_full"), sd, dev).train()
+    waits = {"n": 0}
+    real_sync = torch.cuda.Event.synchronize
+
+    def counting_sync(self):
+        waits["n"] += 1
+        return real_sync(self)
+    torch.cuda.Event.synchronize = counting_sync
+    try:
+        losses2 = []
+        for step, batch in enumerate(LD.DevicePrefetcher(feats, batches[:6], dev, model=m2)):
+            random.seed(step)
+            loss = m2(**batch)[0]
+            loss.backward()
+            m2.engine().adamw_step(5e-5)
+            losses2.append(loss.item())
+    finally:
+        torch.cuda.Event.synchronize = real_sync
+    assert waits["n"] == 0 and losses2[0] == losses[0]
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(losses, losses2))
