@@ -442,6 +442,25 @@ def test_colsum_dropout_cast_transpose(dev):
     Wb = torch.empty(192, 320, dtype=torch.bfloat16, device=dev); Wt = torch.empty(320, 192, dtype=torch.bfloat16, device=dev)
     ops.cast_transpose(W, Wb, Wt)
     assert torch.equal(Wb, W.bfloat16()) and torch.equal(Wt, W.bfloat16().t().contiguous())
+    # batched form; with W == NULL the bf16 copies are the input (they rode the AdamW pass) and only the transposes are written
+    import ctypes as C
+    from spokennlp_amd import lib as Lb
+    lib = Lb.load()
+    Ws = [torch.randn(128, 64, generator=g).to(dev), torch.randn(64, 256, generator=g).to(dev)]
+    Wbs = [torch.empty(w.shape, dtype=torch.bfloat16, device=dev) for w in Ws]
+    Wts = [torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=dev) for w in Ws]
+    tab = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])        # noqa: E731
+    Ns, Ks = (C.c_int * 2)(128, 64), (C.c_int * 2)(64, 256)
+    s = torch.cuda.current_stream().cuda_stream
+    Lb.check(lib.amdseg_cast_transpose_batched(2, tab(Ws), tab(Wbs), tab(Wts), Ns, Ks, s), "amdseg_cast_transpose_batched")
+    for w, wb, wt in zip(Ws, Wbs, Wts):
+        assert torch.equal(wb, w.bfloat16()) and torch.equal(wt, w.bfloat16().t().contiguous())
+    for wt in Wts:
+        wt.zero_()
+    Lb.check(lib.amdseg_cast_transpose_batched(2, None, tab(Wbs), tab(Wts), Ns, Ks, s), "amdseg_cast_transpose_batched(copies in)")
+    for wb, wt in zip(Wbs, Wts):
+        assert torch.equal(wt, wb.t().contiguous())
+    assert lib.amdseg_cast_transpose_batched(2, None, None, tab(Wts), Ns, Ks, s) != 0
 
 
 @pytest.mark.parametrize("dtype,C", [(torch.float32, 2), (torch.bfloat16, 3)])
