@@ -529,6 +529,8 @@ class BertEncoderEngine:
             torch.mul(1.0 - attention_mask.to(torch.float32), MASK_BIAS, out=A["mask_bias"])
             am64 = attention_mask != 0
         am64 = am64.to(torch.int64).contiguous()
+        if B > 8192:
+            raise L.AmdsegError(f"more than 8192 sequences in one forward (got {B}): split the batch (amdseg_pad_plan)")
         L.check(L.load().amdseg_pad_plan(am64.data_ptr(), B, Lseq, A["kend"].data_ptr(), A["seq_order"].data_ptr(), A["pad_runs"].data_ptr(),
                                          A["pad_counts"].data_ptr(), None if attention_mask.dtype.is_floating_point else A["mask_bias"].data_ptr(),
                                          MASK_BIAS, torch.cuda.current_stream().cuda_stream), "amdseg_pad_plan")
