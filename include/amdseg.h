@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 5   /* 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 6   /* 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -76,7 +76,8 @@ int amdseg_attn_f32(const float* qkv, const float* mask_bias, float* ctx, int B,
                     amdseg_stream_t stream);
 
 /* ---- fused attention (csrc/attention.hip), head_dim 64, L multiple of 64 -----------------------------------------
- * qkv [B*L, 3*heads*64] bf16 (q|k|v), mask_bias [B, L] fp32 additive key mask (0 or a large negative),
+ * qkv [B*L, 3*heads*64] bf16 (q|k|v), mask_bias [B, L] fp32 additive key mask (0 or a large negative); scale is folded into the
+ * register-resident operand (exact for a power of two such as 1/8; one more bf16 rounding of q / k otherwise),
  * ctx [B*L, heads*64] bf16, lse [B, heads, L] fp32 (saved for backward; may be NULL for inference).
  *   replaces eager_attention_forward ([hf] models/bert/modeling_bert.py:111-136) and its backward. */
 int amdseg_attn_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
@@ -84,6 +85,21 @@ int amdseg_attn_fwd(const void* qkv, const float* mask_bias, void* ctx, float* l
 int amdseg_attn_bwd(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                     float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, uint64_t seed,
                     amdseg_stream_t stream);
+
+/* Dropout on the attention probabilities, decided ONCE per layer and step (ABI 6).  amdseg_attn_fwd / _bwd evaluate a stateless hash of
+ * (seed, row, key) per element in each of their three kernels; these kernels are VALU-bound and that hash is ~45 % of their vector
+ * instructions.  amdseg_attn_keepmask writes the keep decisions of one layer -- Bernoulli(1 - round(p * 2^16) / 2^16) bits, the same realised
+ * rate as the hash -- into `keep` (amdseg_attn_keepmask_bytes(B, L, heads) = 2 * B * heads * L * L / 8 bytes) in the two lane-mask layouts the
+ * kernels consume (csrc/attention.hip, "dropout keep masks": layout A for forward and dQ, its bit transpose B for dK / dV); the _keep forms of
+ * forward and backward read them with scalar loads and apply them with one v_cndmask per probability.  kend: optional [B] as in
+ * amdseg_bert_cfg.kend (chunks past it are not generated); keep == NULL or dropout_p == 0 falls back to the hash path.  Full attention only. */
+size_t amdseg_attn_keepmask_bytes(int B, int L, int heads);
+int amdseg_attn_keepmask(void* keep, int B, int L, int heads, float dropout_p, uint64_t seed, const int32_t* kend, amdseg_stream_t stream);
+int amdseg_attn_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
+                         float dropout_p, const void* keep, amdseg_stream_t stream);
+int amdseg_attn_bwd_keep(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                         float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, const void* keep,
+                         amdseg_stream_t stream);
 
 /* ---- Longformer attention (csrc/attention.hip band variants + csrc/longformer.hip global row) -------------------
  * Replaces LongformerSelfAttention.forward ([hf] models/longformer/modeling_longformer.py:482-640: sliding chunks
@@ -360,6 +376,10 @@ typedef struct amdseg_bert_layer_acts {     /* caller-owned activations; all but
     /* AMDSEG_F32S only: bf16 split images [hi | hi | lo] of x_in, ctx, x1 and gelu(u): [M,3H] [M,3H] [M,3H] [M,3I] (written by
      * forward, read by the GEMMs of forward and by the weight gradients of backward; `h` is unused in that mode) */
     void *xs, *ctx_s, *x1_s, *h_s;
+    /* optional (bf16 path, full attention, p_attn > 0): amdseg_attn_keepmask_bytes(B, L, heads) bytes per layer.  Forward fills it with this
+     * step's dropout keep masks (amdseg_attn_keepmask) and all three attention kernels read them instead of hashing; backward must get the
+     * buffer its forward wrote.  NULL: the stateless hash path. */
+    void* keep;
 } amdseg_bert_layer_acts;
 
 typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across layers */

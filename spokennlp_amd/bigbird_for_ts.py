@@ -38,6 +38,7 @@ class BigBirdEncoderEngine(BertEncoderEngine):
             raise L.AmdsegError("use_bias=False is not implemented")
         self.emb_dropout_pre_ln = True
         self.attention_type = getattr(config, "attention_type", "block_sparse")
+        self.attn_keepmask = self.attn_keepmask and self.attention_type == "original_full"      # the block-list kernels have no dropout
         self._plans = {}
         self._cur = None
 

@@ -60,11 +60,14 @@ int amdseg_pad_rows_guard_impl(const float* x, const int* kend, int B, int L, in
 int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_out, hipStream_t s);
 
 int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,
-                         float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr);
+                         float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,
+                         const void* keep = nullptr);
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
                          int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,
-                         const int* qguard = nullptr);
+                         const int* qguard = nullptr, const void* keep = nullptr);
+size_t amdseg_attn_keepmask_bytes_impl(int B, int L, int heads);
+int amdseg_attn_keepmask_impl(void* keep, int B, int L, int heads, float p, uint64_t seed, const int* kend, hipStream_t s);
 int amdseg_attn_f32_impl(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, int d,
                          float scale, int window, int nglobal, hipStream_t s);
 

@@ -51,6 +51,20 @@ int amdseg_attn_bwd(const void* qkv, const float* mask_bias, const void* ctx, co
                     amdseg_stream_t stream) {
     return amdseg_attn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, seed, 0, 0, S(stream));
 }
+size_t amdseg_attn_keepmask_bytes(int B, int L, int heads) { return amdseg_attn_keepmask_bytes_impl(B, L, heads); }
+int amdseg_attn_keepmask(void* keep, int B, int L, int heads, float dropout_p, uint64_t seed, const int32_t* kend, amdseg_stream_t stream) {
+    return amdseg_attn_keepmask_impl(keep, B, L, heads, dropout_p, seed, kend, S(stream));
+}
+int amdseg_attn_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
+                         float dropout_p, const void* keep, amdseg_stream_t stream) {
+    return amdseg_attn_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, dropout_p, 0, 0, 0, S(stream), nullptr, nullptr, keep);
+}
+int amdseg_attn_bwd_keep(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                         float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, const void* keep,
+                         amdseg_stream_t stream) {
+    return amdseg_attn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, 0, 0, 0, S(stream), nullptr,
+                                nullptr, nullptr, keep);
+}
 int amdseg_attn_band_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                          float dropout_p, uint64_t seed, int window, int nglobal, amdseg_stream_t stream) {
     if (window <= 0) return AMDSEG_ERR_ARG;
@@ -331,9 +345,13 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         // q|k|v (or the mixer's) projection with bias
         const int NP = NPROJ(c);
         RET_IF(amdseg_gemm_nt_impl(a->x_in, H, p->wqkv, H, a->qkv, NP, M, NP, H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 0, s));
-        if (c->mixer == 0)
+        if (c->mixer == 0) {
+            // dropout on the probabilities: decided once per layer here, read by the forward and the two backward kernels (acts.keep)
+            const void* keep = (a->keep && c->p_attn > 0.f && c->window == 0) ? a->keep : nullptr;
+            if (keep) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s));
             RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0),
-                                        c->window, c->nglobal, s, c->kend, c->seq_order));
+                                        c->window, c->nglobal, s, c->kend, c->seq_order, keep));
+        }
     }
     if (!PHASE2(c)) return AMDSEG_OK;
     // attention output dense -> dropout -> +residual -> LN
@@ -438,7 +456,8 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     if (PHASE2(c)) {
     if (c->mixer == 0)
         RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
-                                    site_seed(c->seed, li, 0), c->window, c->nglobal, s, c->kend, c->seq_order, c->pad_guard));
+                                    site_seed(c->seed, li, 0), c->window, c->nglobal, s, c->kend, c->seq_order, c->pad_guard,
+                                    (c->p_attn > 0.f && c->window == 0) ? a->keep : nullptr));
     // dx_in = dqkv . Wqkv + dz1   (external mixer: the caller wrote ws.dqkv [M, nproj*H] between the phases)
     RET_IF(amdseg_gemm_nt_impl(w->dqkv, NP, p->wqkv_t, NP, dx_in, H, M, H, NP, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s, ZPAD));
     }

@@ -75,6 +75,8 @@ struct AttnArgs {
     const int* seq_order;                   // optional [B] with kend: the sequence the b-th group of workgroups works on (longest first)
     const int* qguard;                      // optional (backward, with kend): *qguard == 0 <=> the dctx rows at positions >= kend[b] are exact zeros
                                             // (amdseg_bert_cfg.pad_guard): those query rows get dQ = 0 and add nothing to dK / dV, so they are not visited
+    const uint64_t* keepA;                  // dropout keep bits written by attn_keepmask_kernel (KM instantiations), lane-mask layouts A (forward,
+    const uint64_t* keepB;                  // dQ) and B (dK/dV), see "dropout keep masks" below
 };
 
 // Band ("sliding window + global") visibility, [hf] models/longformer/modeling_longformer.py:524-604 restated as a mask:
@@ -139,8 +141,108 @@ __device__ __forceinline__ int attn_visible_chunks(const AttnArgs& a, int b, int
     return ke > 0 ? min(nch, (ke + CH - 1) / CH) : nch;
 }
 
+// ------------------------------------------------------------------------------------------------ dropout keep masks
+// The stateless hash above is evaluated per element in all three kernels: ~85 of the forward kernel's ~186 vector instructions per 64-key
+// chunk (8 hash words, 16 compares, 16 selects), the same again in dQ and more in dK/dV -- and these kernels are VALU-bound.  The KM
+// instantiations read the keep decisions instead, computed ONCE per layer and step by attn_keepmask_kernel and stored exactly as the
+// consumers' v_cndmask wants them: one 64-bit LANE MASK per accumulator register.  The S^T accumulators of a wave are 16 registers
+// (fragment fc, element r) x 64 lanes (i16 = row within the wave's 16, g = l >> 4), so the masks of one (16 rows, 64-key chunk) cell are 16
+// words = 128 B, fetched with two scalar loads (no vector instruction, no VGPR) and applied with ONE v_cndmask per element.
+//   layout A (forward, dQ: lane = query row):  word [bh][q / 16][key / 64][fc * 4 + r], bit g * 16 + i16  <->  q = 16 (q/16) + i16,
+//                                              key = 64 (key/64) + fc * 16 + g * 4 + r
+//   layout B (dK/dV: lane = key row):          word [bh][key / 16][q / 64][qf * 4 + r], bit g * 16 + i16  <->  key = 16 (key/16) + i16,
+//                                              q = 64 (q/64) + qf * 16 + g * 4 + r
+// B is the bit transpose of A in two index digits.  The generator makes the bits of a 64 x 64 (query, key) block bit-sliced -- each lane
+// holds 64 Bernoulli(keep) bits, built from 16-bit-precision comparisons evaluated 64 at a time with AND / OR on xorshift words, the same
+// realised rate (65536 - thresh16) / 65536 as the hash path -- writes them as the block's 64 A words, then exchanges two lane-index bits with
+// two word-index bits (two DPP butterfly steps) and swaps two 2-bit digits inside the word (two delta swaps) to get the 64 B words.
+// ~250 vector instructions per 4096 elements, against ~250 per 1024 elements and kernel for the hash.
+__device__ __forceinline__ uint32_t km_xs32(uint32_t x) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; }
+__device__ __forceinline__ uint64_t km_delta_swap(uint64_t v, uint64_t m, int d) {   // swaps the bits selected by m with the bits d above them
+    const uint64_t t = ((v >> d) ^ v) & m;
+    return v ^ t ^ (t << d);
+}
+// lane <-> word exchange of index bit j (j = 1, 2) of a 32-bit half: new[X][p] = old[X with bit j := p_j][p with bit j := X_j]
+template <int J>
+__device__ __forceinline__ uint32_t km_exchange(uint32_t x, bool upper) {
+    constexpr uint32_t M = J == 1 ? 0x55555555u : 0x33333333u;                      // positions whose bit j is clear
+    const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, J == 1 ? 0xB1 : 0x4E, 0xf, 0xf, true);   // lane ^ j (quad_perm)
+    return upper ? ((x & ~M) | ((y >> J) & M)) : ((x & M) | ((y << J) & ~M));
+}
+
+struct KeepMaskArgs {
+    uint64_t* A; uint64_t* Bm;
+    int B, L, heads; uint32_t thresh16; uint64_t seed;
+    const int* kend;                        // optional [B]: chunks past the last unmasked key are never read by the consumers (attn_visible_chunks)
+};
+
+// one wave per (bh, 64-query block, group of KM_CG key chunks)
+#define KM_CG 4
+__global__ __launch_bounds__(256) void attn_keepmask_kernel(KeepMaskArgs a) {
+    const int l = threadIdx.x & 63;
+    const int nblk = a.L / CH, ngrp = (nblk + KM_CG - 1) / KM_CG;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int total = a.B * a.heads * nblk * ngrp;
+    if (wid >= total) return;
+    const int grp = wid % ngrp, qblk = (wid / ngrp) % nblk, bh = wid / (ngrp * nblk);
+    int nvis = nblk;
+    if (a.kend) { const int ke = a.kend[bh / a.heads]; if (ke > 0) nvis = min(nblk, (ke + CH - 1) / CH); }
+    // two xorshift32 streams per lane (the low and the high half of the lane's 64 bits), seeded by a strong hash of (seed, wave, lane)
+    uint32_t xl = mix32((uint32_t)a.seed ^ mix32((uint32_t)(a.seed >> 32) + 0x9e3779b9u + (uint32_t)wid * 128u + (uint32_t)l));
+    uint32_t xh = mix32(xl ^ (0x85ebca6bu + (uint32_t)l));
+    xl |= xl == 0; xh |= xh == 0;
+    const int lowbit = __builtin_ctz(a.thresh16 | 0x10000u);
+    const int qa = l >> 4, ka = (l >> 2) & 3, c2 = l & 3;             // A: lane = (qa, ka, kc); B after the exchange: lane = (qa, ka, qc)
+    const size_t rows16 = (size_t)a.L / 16;
+    for (int cc = 0; cc < KM_CG; ++cc) {
+        const int chunk = grp * KM_CG + cc;
+        if (chunk >= nvis) break;
+        // keep <=> u >= thresh16 for a uniform 16-bit u, evaluated bit-serially from the lowest set bit of the threshold upwards on 64 lanes x
+        // 64 independent u's at once: ge = t_i ? (u_i & ge) : (u_i | ge)
+        uint32_t lo = 0xffffffffu, hi = 0xffffffffu;
+        for (int i = lowbit; i < 16; ++i) {
+            xl = km_xs32(xl); xh = km_xs32(xh);
+            if ((a.thresh16 >> i) & 1) { lo &= xl; hi &= xh; } else { lo |= xl; hi |= xh; }
+        }
+        // A: lane (qa, ka, kc) holds word (w = qa, fc = ka, r = kc) with bits (g = kb, i16 = (qb, qc))
+        a.A[(((size_t)bh * rows16 + (size_t)qblk * 4 + qa) * nblk + chunk) * 16 + ka * 4 + c2] = ((uint64_t)hi << 32) | lo;
+        // exchange the lane digit kc with the word digit qc ...
+        lo = km_exchange<1>(lo, l & 1); hi = km_exchange<1>(hi, l & 1);
+        lo = km_exchange<2>(lo, l & 2); hi = km_exchange<2>(hi, l & 2);
+        // ... and swap the two upper 2-bit digits of the bit index, (kb, qb, kc) -> (qb, kb, kc): a 4 x 4 transpose of the word's nibbles
+        uint64_t v = ((uint64_t)hi << 32) | lo;
+        v = km_delta_swap(v, 0x0000F0F00000F0F0ull, 12);
+        v = km_delta_swap(v, 0x00000000FF00FF00ull, 24);
+        // B: lane (qa, ka, qc) holds word (w' = ka, qf = qa, r' = qc) with bits (g' = qb, i16' = (kb, kc))
+        a.Bm[(((size_t)bh * rows16 + (size_t)chunk * 4 + ka) * nblk + qblk) * 16 + qa * 4 + c2] = v;
+    }
+}
+
+// consumer side.  The words sit in the constant address space so that the (wave-uniform) loads are scalar loads; inverse_ballot turns a
+// wave-uniform 64-bit word into the lane predicate of a select, i.e. v_cndmask with that SGPR pair as its mask operand.
+typedef const __attribute__((address_space(4))) uint64_t* km_cptr;
+struct KeepWords { uint64_t m[16]; };
+__device__ __forceinline__ void km_load(KeepWords& k, const uint64_t* base, size_t cell) {
+    km_cptr p = (km_cptr)(uintptr_t)(base + cell * 16);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k.m[i] = p[i];
+}
+__device__ __forceinline__ float km_sel(float x, uint64_t lanes) {     // lane's bit set ? x : 0  ->  v_cndmask_b32 v, 0, v, s[n:n+1]
+    // (the builtin, not inline asm: the compiler does not give an asm statement the wait states a read of a fresh MFMA result needs)
+    return __builtin_amdgcn_inverse_ballot_w64(lanes) ? x : 0.f;
+}
+
+// eight bf16 values times s, rounded back to bf16 (exact for a power of two)
+__device__ __forceinline__ bf16x8 frag_scale(bf16x8 f, float s) {
+    union { bf16x8 v; uint32_t u[4]; } x, y;
+    x.v = f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y.u[i] = pack2bf(__uint_as_float(x.u[i] << 16) * s, __uint_as_float(x.u[i] & 0xffff0000u) * s);
+    return y.v;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
-template <int NW, bool BAND, bool LIST = false>
+template <int NW, bool BAND, bool LIST = false, bool KM = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
@@ -163,17 +265,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
 #define bufV(i) (smem + 8192 + (i) * 16384)
 
     // Q as the B operand of S^T = K Q^T : lane holds Q[q][kk*32 + g*8 .. +8]
+    // The softmax scale is folded into the Q fragments: exact for a power of two (head_dim 64: 1/8; scores bit-identical to scaling them
+    // afterwards), one more bf16 rounding of q otherwise.  The additive key mask then starts the MFMA accumulators as it comes out of LDS --
+    // no mask / scale multiplies per chunk (8 packed multiplies of this VALU-bound loop)
     bf16x8 fq[2];
     {
         const bf16_t* qp = a.qkv + (tok0 + q) * a.H3 + h * HD;
-        fq[0] = *reinterpret_cast<const bf16x8*>(qp + g * 8);
-        fq[1] = *reinterpret_cast<const bf16x8*>(qp + 32 + g * 8);
+        fq[0] = frag_scale(*reinterpret_cast<const bf16x8*>(qp + g * 8), a.scale);
+        fq[1] = frag_scale(*reinterpret_cast<const bf16x8*>(qp + 32 + g * 8), a.scale);
     }
     f32x4 o[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_part = 0.f;
-    const float sc2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
+    const float sc2 = LOG2E;
     const uint32_t salt = pdrop_salt(pdrop_seedmix(a.seed), prow);
     const uint32_t gsalt = (uint32_t)(g * 2) * 0x9e3779b9u;            // this lane group's keys g*4 .. g*4+3 = key pairs g*2, g*2+1
     const uint32_t thr_hi = a.thresh16 << 16;
@@ -211,6 +316,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     }
     (void)lst;
 #define CHUNK_OF(t) (LIST ? ((t) == ch_ ? c_cur : c_nxt) : (BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
+    KeepWords kw;
+    const size_t kcell0 = (((size_t)(b * a.heads + h)) * (a.L / 16) + (size_t)qb * NW + __builtin_amdgcn_readfirstlane(w)) * (a.L / CH);
+    if (KM && nch > 0) km_load(kw, a.keepA, kcell0 + CHUNK_OF(0));
     at_stage<NW>(kbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufK(0), w, l);
     at_stage<NW>(vbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufV(0), w, l);
     // the additive key mask of a chunk travels with its K/V tiles (a global load issued where it is consumed costs a full
@@ -236,8 +344,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
         const char* tV = bufV(cur);
         const int key0 = CHUNK_OF(ch) * CH;
         // S^T[key][q]: 4 key frags of 16; all K fragments first, then the MFMAs with the k-step outermost so that
-        // consecutive MFMAs are independent.  The accumulators START from the additive key mask (in units of the raw dot product:
-        // mask / scale), so the masked score comes out of the MFMA and no separate scale-and-mask pass over the 16 scores is needed
+        // consecutive MFMAs are independent.  The accumulators START from the additive key mask (the scale sits in Q), so the masked
+        // score comes out of the MFMA and no separate scale-and-mask pass over the 16 scores is needed
         // (this kernel is VALU-bound: ~250 vector instructions per 64-key chunk against 16 MFMAs, profiles/r01_gemm_experiments.md)
         f32x4 s[4];
         {
@@ -247,7 +355,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) fk[fc][kk] = at_frag(tK, fc * 16 + i16, kk * 4 + g);
 #pragma unroll
-            for (int fc = 0; fc < 4; ++fc) s[fc] = (f32x4){mbc[fc].x * inv_scale, mbc[fc].y * inv_scale, mbc[fc].z * inv_scale, mbc[fc].w * inv_scale};
+            for (int fc = 0; fc < 4; ++fc) s[fc] = (f32x4){mbc[fc].x, mbc[fc].y, mbc[fc].z, mbc[fc].w};
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -299,7 +407,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
                 }
             l_part += ps2.x + ps2.y;
         }
-        if (a.thresh16) {
+        if (KM) {
+            // keep decisions of this (16 rows, chunk) cell as 16 lane masks in SGPRs (attn_keepmask_kernel): one select per probability
+#pragma unroll
+            for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[fc][r] = km_sel(s[fc][r], kw.m[fc * 4 + r]);
+        } else if (a.thresh16) {
             // keep-mask: one hash word per key pair, 16 bits per probability.  The high field is compared as the whole word against
             // thresh << 16, the low field after one shift; dropped entries become 0 and the 1 / keep-rate factor is applied ONCE to
             // the finished output row (no per-element and / multiply)
@@ -324,6 +438,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
             }
         }
         if (LIST) { c_cur = c_nxt; c_nxt = lw.next(l); }
+        if (KM && ch + 1 < nch) {
+            // the next chunk's words, issued behind the last LDS wait of this iteration: scalar loads share lgkmcnt with the LDS and return out
+            // of order, so an LDS wait with one of them in flight has to be lgkmcnt(0) and would sit out the load's latency
+            asm volatile("" ::: "memory");
+            km_load(kw, a.keepA, kcell0 + CHUNK_OF(ch + 1));
+        }
     }
     const float lsum = xor_reduce_sum_g(l_part);
     float inv = (a.thresh16 ? a.inv_keep : 1.0f) / lsum;
@@ -367,7 +487,7 @@ __global__ void attn_delta_kernel(const bf16_t* ctx, const bf16_t* dctx, float* 
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-template <int NW, bool BAND, bool LIST = false>
+template <int NW, bool BAND, bool LIST = false, bool KM = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
@@ -401,8 +521,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     bf16x8 fq[2], fdo[2];
     {
         const bf16_t* qp = a.qkv + (tok0 + q) * a.H3 + h * HD;
-        fq[0] = *reinterpret_cast<const bf16x8*>(qp + g * 8);
-        fq[1] = *reinterpret_cast<const bf16x8*>(qp + 32 + g * 8);
+        fq[0] = frag_scale(*reinterpret_cast<const bf16x8*>(qp + g * 8), a.scale);           // the scale folded into Q, as in the forward kernel
+        fq[1] = frag_scale(*reinterpret_cast<const bf16x8*>(qp + 32 + g * 8), a.scale);
         const bf16_t* dp = a.dctx + (tok0 + q) * H + h * HD;
         fdo[0] = *reinterpret_cast<const bf16x8*>(dp + g * 8);
         fdo[1] = *reinterpret_cast<const bf16x8*>(dp + 32 + g * 8);
@@ -422,8 +542,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         delta_q = xor_reduce_sum_g(acc);
         if (g == 0) a.delta[prow] = delta_q;
     }
-    const float sc2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
-    const float nlse_s = -a.lse[prow] * inv_scale;                      // accumulator start: (mask - lse) / scale, see below
+    const float sc2 = LOG2E;
+    const float nlse_s = -a.lse[prow];                                  // accumulator start: mask - lse, see below
     const uint32_t salt = pdrop_salt(pdrop_seedmix(a.seed), prow);
     const uint32_t gsalt = (uint32_t)(g * 2) * 0x9e3779b9u;
     const uint32_t thr_hi = a.thresh16 << 16;
@@ -465,6 +585,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     (void)lst;
 #define CHUNK_OF(t) (LIST ? ((t) == ch_ ? c_cur : c_nxt) : (BAND && extra && (t) == 0) ? 0 : c0 + (t) - extra)
+    KeepWords kw;
+    const size_t kcell0 = (((size_t)(b * a.heads + h)) * (a.L / 16) + (size_t)qb * NW + __builtin_amdgcn_readfirstlane(w)) * (a.L / CH);
+    if (KM && nch > 0) km_load(kw, a.keepA, kcell0 + CHUNK_OF(0));
     at_stage<NW>(kbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufK(0), w, l);
     at_stage<NW>(vbase + (size_t)CHUNK_OF(0) * CH * a.H3, a.H3, bufV(0), w, l);
     if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(0) * CH, bufM(0), l);      // key mask rides with the tiles
@@ -501,12 +624,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                     fk[f2][kk] = at_frag(tK, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
                     fv[f2][kk] = at_frag(tV, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
                 }
-            // the score accumulators start from (mask - lse) / scale: p = 2^(acc * scale * log2e) needs ONE multiply per element
+            // the score accumulators start from mask - lse (the scale sits in Q): p = 2^(acc * log2e) needs ONE multiply per element
             // after the MFMA instead of scale, mask and lse terms (VALU-bound kernel)
 #pragma unroll
             for (int f2 = 0; f2 < 2; ++f2) {
                 const float4 m4 = mbc[hf * 2 + f2];
-                sacc4[hf * 2 + f2] = (f32x4){fmaf(m4.x, inv_scale, nlse_s), fmaf(m4.y, inv_scale, nlse_s), fmaf(m4.z, inv_scale, nlse_s), fmaf(m4.w, inv_scale, nlse_s)};
+                const f32x2 n2 = {nlse_s, nlse_s};
+                const f32x2 lo2 = (f32x2){m4.x, m4.y} + n2, hi2 = (f32x2){m4.z, m4.w} + n2;                  // packed add
+                sacc4[hf * 2 + f2] = (f32x4){lo2.x, lo2.y, hi2.x, hi2.y};
                 pacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -518,7 +643,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 }
         }
         const f32x2 sc2v = {sc2, sc2}, ikv = {ikeep, ikeep}, ndl = {-delta_q, -delta_q};
-        if (a.thresh16) {                                               // dropped entries: dP = 0 (the 1 / keep-rate factor is ikv below)
+        if (KM) {                                                       // dropped entries: dP = 0, from the stored lane masks (layout A)
+#pragma unroll
+            for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pacc4[fc][r] = km_sel(pacc4[fc][r], kw.m[fc * 4 + r]);
+        } else if (a.thresh16) {                                        // dropped entries: dP = 0 (the 1 / keep-rate factor is ikv below)
             const uint32_t salt_c = salt + (uint32_t)(key0 >> 1) * 0x9e3779b9u + gsalt;
 #pragma unroll
             for (int fc = 0; fc < 4; ++fc)
@@ -556,6 +686,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             }
         }
         if (LIST) { c_cur = c_nxt; c_nxt = lw.next(l); }
+        if (KM && ch + 1 < nch) {                                       // behind the last LDS wait of the iteration (see the forward kernel)
+            asm volatile("" ::: "memory");
+            km_load(kw, a.keepA, kcell0 + CHUNK_OF(ch + 1));
+        }
     }
     bf16_t* op = a.dqkv + (tok0 + q) * a.H3 + h * HD;
 #pragma unroll
@@ -569,7 +703,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <int NW, bool BAND, bool LIST = false>
+template <int NW, bool BAND, bool LIST = false, bool KM = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768 + 1024];
 #define bufL(i) (smem + 32768 + (i) * 512)
@@ -617,14 +751,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     bf16x8 fk[2], fv[2];
     {
         const bf16_t* kp = a.qkv + (tok0 + key) * a.H3 + H + h * HD;
-        fk[0] = *reinterpret_cast<const bf16x8*>(kp + g * 8);
-        fk[1] = *reinterpret_cast<const bf16x8*>(kp + 32 + g * 8);
+        fk[0] = frag_scale(*reinterpret_cast<const bf16x8*>(kp + g * 8), a.scale);           // the softmax scale, folded into this side's
+        fk[1] = frag_scale(*reinterpret_cast<const bf16x8*>(kp + 32 + g * 8), a.scale);      // register-resident operand (K here, Q in fwd / dQ)
         const bf16_t* vp = a.qkv + (tok0 + key) * a.H3 + 2 * H + h * HD;
         fv[0] = *reinterpret_cast<const bf16x8*>(vp + g * 8);
         fv[1] = *reinterpret_cast<const bf16x8*>(vp + 32 + g * 8);
     }
-    const float sc2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
-    const float mbs = a.mask_bias[tok0 + key] * inv_scale;              // accumulator start: (mask - lse_row) / scale, see below
+    const float sc2 = LOG2E;
+    const float mbs = a.mask_bias[tok0 + key];                          // accumulator start: mask - lse_row, see below
     // keep-mask word of (row, key): pdrop_bits(pdrop_salt(seedmix, row), key & ~1) = mix(seedmix + row * C1 + (key >> 1) * C2);
     // the key part is a per-lane constant, the row part one multiply per chunk + compile-time offsets
     const uint32_t kc = pdrop_seedmix(a.seed) + (uint32_t)(key >> 1) * 0x9e3779b9u;
@@ -663,6 +797,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     (void)lst;
 #define QCHUNK_OF(t) (LIST ? ((t) == ch_ ? c_cur : c_nxt) : c0 + (t))
+    KeepWords kw;
+    const size_t kcell0 = ((size_t)bh * (a.L / 16) + (size_t)kb * NW + __builtin_amdgcn_readfirstlane(w)) * (a.L / CH);
+    if (KM && nch > 0) km_load(kw, a.keepB, kcell0 + QCHUNK_OF(0));
     at_stage<NW>(qbase + (size_t)QCHUNK_OF(0) * CH * a.H3, a.H3, bufQ(0), w, l);
     at_stage<NW>(obase + (size_t)QCHUNK_OF(0) * CH * H, H, bufO(0), w, l);
     // LSE and delta of the chunk's 64 query rows ride with the Q / dO tiles (were 8 exposed global loads per chunk)
@@ -706,11 +843,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                     fqa[f2][kk] = at_frag(tQ, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
                     foa[f2][kk] = at_frag(tO, (hf * 2 + f2) * 16 + i16, kk * 4 + g);
                 }
-            // score accumulators start from (mask_key - lse_row) / scale (see the dQ kernel)
+            // score accumulators start from mask_key - lse_row (see the dQ kernel)
 #pragma unroll
             for (int f2 = 0; f2 < 2; ++f2) {
                 const float4 l4 = lsc[hf * 2 + f2];
-                sacc4[hf * 2 + f2] = (f32x4){fmaf(l4.x, -inv_scale, mbs), fmaf(l4.y, -inv_scale, mbs), fmaf(l4.z, -inv_scale, mbs), fmaf(l4.w, -inv_scale, mbs)};
+                const f32x2 m2 = {mbs, mbs};
+                const f32x2 lo2 = m2 - (f32x2){l4.x, l4.y}, hi2 = m2 - (f32x2){l4.z, l4.w};                  // packed add
+                sacc4[hf * 2 + f2] = (f32x4){lo2.x, lo2.y, hi2.x, hi2.y};
                 pacc4[hf * 2 + f2] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -739,7 +878,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                     if (band_masked(q0 + qf * 16 + g * 4 + rp * 2 + 1, key, a.window, a.nglobal)) pe.y = 0.f;
                 }
                 f32x2 pk = pe;                                           // P_drop without the 1 / keep-rate factor (applied to dV at the end)
-                if (a.thresh16) {
+                if (KM) {                                                // stored lane masks (layout B: lane = key row)
+                    const uint64_t m0 = kw.m[qf * 4 + rp * 2], m1 = kw.m[qf * 4 + rp * 2 + 1];
+                    pk.x = km_sel(pe.x, m0); pk.y = km_sel(pe.y, m1);
+                    pacc[rp * 2] = km_sel(pacc[rp * 2], m0); pacc[rp * 2 + 1] = km_sel(pacc[rp * 2 + 1], m1);
+                } else if (a.thresh16) {
                     const bool k0 = (pdrop_mix(rowc + (uint32_t)(qf * 16 + rp * 2) * 0x85ebca6bu) << ksh) >= thr_hi;
                     const bool k1 = (pdrop_mix(rowc + (uint32_t)(qf * 16 + rp * 2 + 1) * 0x85ebca6bu) << ksh) >= thr_hi;
                     pk.x = k0 ? pe.x : 0.f; pk.y = k1 ? pe.y : 0.f;
@@ -764,6 +907,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             }
         }
         if (LIST) { c_cur = c_nxt; c_nxt = lw.next(l); }
+        if (KM && ch + 1 < nch) {                                       // behind the last LDS wait of the iteration (see the forward kernel)
+            asm volatile("" ::: "memory");
+            km_load(kw, a.keepB, kcell0 + QCHUNK_OF(ch + 1));
+        }
     }
     bf16_t* okp = a.dqkv + (tok0 + key) * a.H3 + H + h * HD;
     bf16_t* ovp = a.dqkv + (tok0 + key) * a.H3 + 2 * H + h * HD;
@@ -792,14 +939,40 @@ static int attn_fill(AttnArgs& a, int B, int L, int heads, float scale, float p,
     return AMDSEG_OK;
 }
 
+// size in bytes of the keep-mask buffer of one layer (layout A, then layout B)
+size_t amdseg_attn_keepmask_bytes_impl(int B, int L, int heads) { return (size_t)B * heads * L * (size_t)L / 8 * 2; }
+
+// the keep masks of one attention layer and step (both layouts); the hash seed is the one the hash path would take
+int amdseg_attn_keepmask_impl(void* keep, int B, int L, int heads, float p, uint64_t seed, const int* kend, hipStream_t s) {
+    if (!keep) return AMDSEG_ERR_ARG;
+    AttnArgs a = {};
+    int rc = attn_fill(a, B, L, heads, 0.125f, p, seed, 0, 0);
+    if (rc) return rc;
+    KeepMaskArgs k = {};
+    k.A = (uint64_t*)keep; k.Bm = k.A + (size_t)B * heads * L * (size_t)L / 64;
+    k.B = B; k.L = L; k.heads = heads; k.thresh16 = a.thresh16; k.seed = seed; k.kend = kend;
+    const int nblk = L / CH, ngrp = (nblk + KM_CG - 1) / KM_CG;
+    const long waves = (long)B * heads * nblk * ngrp;
+    hipLaunchKernelGGL(attn_keepmask_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, k);
+    return amdseg_launch_status();
+}
+
 int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,
-                         float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order) {
+                         float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order,
+                         const void* keep) {
     if (!qkv || !mask_bias || !ctx) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
     a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order; a.qguard = nullptr;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
+    a.keepA = (const uint64_t*)keep; a.keepB = a.keepA ? a.keepA + (size_t)B * heads * L * (size_t)L / 64 : nullptr;
+    if (keep && a.thresh16 && window == 0) {                // dropout decisions read from the layer's keep masks (attn_keepmask_kernel)
+        const double work_km = 4.0 * B * heads * (double)L * (double)L * HD;
+        if (L % 128 == 0) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work_km, (attn_fwd_kernel<8, false, false, true>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
+        else AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work_km, (attn_fwd_kernel<4, false, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        return amdseg_launch_status();
+    }
     // algorithmic FLOPs: QK^T + PV over the visible keys (full: L, band: 2W + 1 + G)
     const double span = window > 0 ? (double)(2 * window + 1 + a.nglobal) : (double)L;
     const double work = 4.0 * B * heads * (double)L * span * HD;
@@ -823,7 +996,7 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
 
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
-                         int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order, const int* qguard) {
+                         int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order, const int* qguard, const void* keep) {
     if (!qkv || !mask_bias || !ctx || !dctx || !lse || !delta || !dqkv) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
@@ -831,6 +1004,13 @@ int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ct
     a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order; a.qguard = (window > 0 || !kend) ? nullptr : qguard;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = (float*)lse;
     a.dctx = (const bf16_t*)dctx; a.delta = delta; a.dqkv = (bf16_t*)dqkv;
+    a.keepA = (const uint64_t*)keep; a.keepB = a.keepA ? a.keepA + (size_t)B * heads * L * (size_t)L / 64 : nullptr;
+    if (keep && a.thresh16 && window == 0) {                // the forward's keep masks again (layout A for dQ, layout B for dK/dV)
+        const double unit_km = 2.0 * B * heads * (double)L * (double)L * HD;
+        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_BWD_DQ, 2.0 * unit_km, (attn_bwd_dq_kernel<4, false, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_BWD_DKV, 3.0 * unit_km, (attn_bwd_dkv_kernel<4, false, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        return amdseg_launch_status();
+    }
     const size_t total = (size_t)B * L * heads * 8;
     (void)total;           // delta = rowsum(dO * O) is produced by the dQ kernel (attn_delta_kernel is kept for reference / tests)
     // backward kernels need 144-168 VGPRs: 4-wave workgroups keep 3 waves per SIMD resident (8-wave ones would spill or halve occupancy)

@@ -174,6 +174,9 @@ class BertEncoderEngine:
         # incoming gradient (amdseg_bert_cfg.pad_guard).  Every encoder family (the argument per mixer: DESIGN.md section 8); AMDSEG_PAD_ROWS_DENSE=1 = off
         self.skip_padded_rows_bwd = self.skip_padded_chunks and _os.environ.get("AMDSEG_PAD_ROWS_DENSE", "0") != "1"
         self._pad_guard = None
+        # attention-probability dropout decided once per layer (amdseg_attn_keepmask, acts.keep) instead of hashed per element in three kernels;
+        # full softmax attention only (the band / list / pooling engines switch it off); AMDSEG_ATTN_HASH=1 keeps the hash path
+        self.attn_keepmask = _os.environ.get("AMDSEG_ATTN_HASH", "0") != "1"
         self._arena_slot = 0
         self.max_live_arenas = 2                            # training arenas per shape that may be alive between forward and backward
         self.grad_sync = True                               # False inside no_sync(): accumulate locally, no bucket all-reduce
@@ -442,6 +445,10 @@ class BertEncoderEngine:
                          for _ in range(nsave)],
                  emb_z=e(M, H), emb_mean=e(M, dt=torch.float32), emb_rstd=e(M, dt=torch.float32),
                  mask_bias=e(B, Lseq, dt=torch.float32), gen=0, busy=False, stamp=0)
+        if train and not fp32 and self.attn_keepmask and float(self.cfg.attention_probs_dropout_prob) > 0:
+            nbytes = L.load().amdseg_attn_keepmask_bytes(B, Lseq, self.heads)
+            for la in A["layers"]:
+                la["keep"] = e(nbytes, dt=torch.uint8)
         if parity:               # split-bf16 images of the GEMM operands (see csrc/parity.hip); `h` itself is never materialised
             for la in A["layers"]:
                 la.update(xs=e(M, 3 * H, dt=torch.bfloat16), ctx_s=e(M, 3 * H, dt=torch.bfloat16), x1_s=e(M, 3 * H, dt=torch.bfloat16),
@@ -473,6 +480,8 @@ class BertEncoderEngine:
             ptrs = {k: la[k].data_ptr() for k in ("qkv", "ctx", "z1", "x1", "u", "h", "z2", "lse", "mean1", "rstd1", "mean2", "rstd2")}
             if parity:
                 ptrs.update({k: la[k].data_ptr() for k in ("xs", "ctx_s", "x1_s", "h_s")})
+            if "keep" in la:
+                ptrs["keep"] = la["keep"].data_ptr()
             if not train and not fp32:
                 ptrs["u"] = None                  # inference: the FFN GEMM skips the pre-activation output
             A["acts_struct"].append(L.LayerActs(x_in=xin.data_ptr(), x_out=xout.data_ptr(), **ptrs))

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("AMDSEG_LIB") or os.path.join(_HERE, "libamdseg.so")
 BF16, F32, F32S = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
 EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
@@ -35,7 +35,7 @@ class LayerGrads(C.Structure):
 
 class LayerActs(C.Structure):
     _fields_ = [(n, vp) for n in ("x_in", "qkv", "ctx", "z1", "x1", "u", "h", "z2", "x_out",
-                                  "lse", "mean1", "rstd1", "mean2", "rstd2", "xs", "ctx_s", "x1_s", "h_s")]
+                                  "lse", "mean1", "rstd1", "mean2", "rstd2", "xs", "ctx_s", "x1_s", "h_s", "keep")]
 
 
 class LayerWs(C.Structure):
@@ -56,6 +56,10 @@ _PROTOS = {
     "amdseg_attn_f32": [vp, vp, vp, i32, i32, i32, f32, vp],
     "amdseg_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
+    "amdseg_attn_keepmask_bytes": [i32, i32, i32],
+    "amdseg_attn_keepmask": [vp, i32, i32, i32, f32, u64, vp, vp],
+    "amdseg_attn_fwd_keep": [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],
+    "amdseg_attn_bwd_keep": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],
     "amdseg_attn_band_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, i32, vp],
     "amdseg_attn_band_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, i32, vp],
     "amdseg_attn_band_f32": [vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
@@ -111,7 +115,7 @@ _PROTOS = {
     "amdseg_bert_layer_bwd": [C.POINTER(BertCfg), C.POINTER(LayerParams), C.POINTER(LayerGrads), C.POINTER(LayerActs),
                               C.POINTER(LayerWs), vp, vp, vp, i32, vp],
 }
-_RESTYPE = {"amdseg_error_string": C.c_char_p}
+_RESTYPE = {"amdseg_error_string": C.c_char_p, "amdseg_attn_keepmask_bytes": C.c_size_t}
 
 EXPORTS = tuple(_PROTOS)
 _lib = None

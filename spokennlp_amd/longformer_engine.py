@@ -29,6 +29,7 @@ class LongformerEncoderEngine(BertEncoderEngine):
         if any(w <= 0 for w in self.windows):
             raise L.AmdsegError("attention_window must be >= 2")
         self.pad_id = int(config.pad_token_id)
+        self.attn_keepmask = False                          # band attention keeps the stateless dropout hash (keep masks: full attention only)
         self.scale = 1.0 / math.sqrt(64.0)
         # False: no global token at all -- LongformerModel called with global_attention_mask=None (the mmvts text encoder,
         # mmvts/src/models/text_encoder/text_encoder.py:73-85 as driven by multi_modal_for_ts.py:173-176): pure band attention

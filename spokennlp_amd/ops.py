@@ -91,6 +91,30 @@ def attn_bwd(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, p=0.0, seed=0, scal
     return dqkv
 
 
+def attn_keepmask(B, Lseq, heads, p, seed, device, kend=None):
+    """dropout keep masks of one attention layer (amdseg_attn_keepmask): uint8 buffer holding layout A then layout B"""
+    lib = L.load()
+    keep = torch.empty(lib.amdseg_attn_keepmask_bytes(B, Lseq, heads), dtype=torch.uint8, device=device)
+    L.check(lib.amdseg_attn_keepmask(_p(keep), B, Lseq, heads, p, seed, _p(kend), _s()), "amdseg_attn_keepmask")
+    return keep
+
+
+def attn_fwd_keep(qkv, mask_bias, B, Lseq, heads, p, keep, need_lse=True, scale=0.125):
+    H = heads * 64
+    ctx = torch.empty((B * Lseq, H), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device) if need_lse else None
+    L.check(L.load().amdseg_attn_fwd_keep(_p(qkv), _p(mask_bias), _p(ctx), _p(lse), B, Lseq, heads, scale, p, _p(keep), _s()), "amdseg_attn_fwd_keep")
+    return ctx, lse
+
+
+def attn_bwd_keep(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, p, keep, scale=0.125):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device)
+    L.check(L.load().amdseg_attn_bwd_keep(_p(qkv), _p(mask_bias), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, Lseq, heads,
+                                          scale, p, _p(keep), _s()), "amdseg_attn_bwd_keep")
+    return dqkv
+
+
 def attn_list_fwd(qkv, mask_bias, B, Lseq, heads, klist, kcnt, stride, ctx=None, lse=None, scale=0.125, korder=None):
     """BigBird block-list attention (amdseg_attn_list_fwd); klist/kcnt: int32 device tensors [heads, L/64, stride] / [heads, L/64]"""
     H = heads * 64

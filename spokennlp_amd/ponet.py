@@ -92,6 +92,7 @@ class PoNetEncoderEngine(BertEncoderEngine):
         for h in range(heads):
             hm[h, h * 64:(h + 1) * 64] = 1.0
         self.headmask = hm
+        self.attn_keepmask = False                          # no softmax attention in this encoder
         self._seg = None
         # amdseg_bert_cfg.pad_guard holds for the pooling mixer too: a padded token n has dctx_n = 0, so dHo_n = 0; it is no valid neighbour /
         # run member, so no local or segment maximum routes a gradient to it; it is a masked key of the global aggregation (p = 0): dproj_n = 0

@@ -1,0 +1,138 @@
+"""Attention-probability dropout decided once per layer (amdseg_attn_keepmask, include/amdseg.h ABI 6): the two lane-mask layouts hold the
+SAME Bernoulli matrix, its statistics are those of the stateless hash path (same realised rate, independent neighbours), and the three
+attention kernels reading it compute what a torch reference computes with that mask.  Replaces, on the training path, the per-element
+hash of [hf] models/bert/modeling_bert.py:111-136's `nn.functional.dropout(attn_weights)`."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_kernels import attn_ref, make_qkv, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from spokennlp_amd import ops
+    return ops
+
+
+def unpack_keep(keep, B, L, heads):
+    """uint8 device buffer -> (keep from layout A, keep from layout B), both bool [B*heads, L(query), L(key)] (the layouts are documented in
+    csrc/attention.hip, 'dropout keep masks')"""
+    w = keep.cpu().numpy().view(np.uint64)
+    BH = B * heads
+    n = BH * L * L // 64
+    bits = ((w[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+    # A: word [bh][q/16][key/64][fc][r], bit [g][i16]  <->  q = 16 (q/16) + i16, key = 64 (key/64) + 16 fc + 4 g + r
+    a = bits[:n].reshape(BH, L // 16, L // 64, 4, 4, 4, 16)             # bh, R16, C, fc, r, g, i16
+    a = a.transpose(0, 1, 6, 2, 3, 5, 4).reshape(BH, L, L)              # bh, (R16, i16), (C, fc, g, r)
+    # B: word [bh][key/16][q/64][qf][r], bit [g][i16]  <->  key = 16 (key/16) + i16, q = 64 (q/64) + 16 qf + 4 g + r
+    b = bits[n:].reshape(BH, L // 16, L // 64, 4, 4, 4, 16)             # bh, K16, QC, qf, r, g, i16
+    b = b.transpose(0, 2, 3, 5, 4, 1, 6).reshape(BH, L, L)              # bh, (QC, qf, g, r), (K16, i16)
+    return torch.from_numpy(a.copy()), torch.from_numpy(b.copy())
+
+
+@pytest.mark.parametrize("B,L,heads,p", [(2, 128, 2, 0.1), (1, 512, 3, 0.1), (3, 192, 1, 0.25), (1, 64, 1, 0.5)])
+def test_keepmask_layouts_agree_and_statistics(dev, B, L, heads, p):
+    ops = _ops()
+    keep = ops.attn_keepmask(B, L, heads, p, 1234, dev)
+    ka, kb = unpack_keep(keep, B, L, heads)
+    assert torch.equal(ka, kb)                                          # layout B is the transpose of layout A, bit for bit
+    k = ka.float()
+    th = round(p * 65536)
+    kq = 1.0 - th / 65536.0                                             # the realised keep rate of the hash path as well
+    n = k.numel()
+    assert abs(k.mean().item() - kq) < 4 * (kq * (1 - kq) / n) ** 0.5 + 1e-4
+    # neighbours along the key axis, the query axis, the two diagonals and between heads are independent
+    pairs = [(k[..., :-1], k[..., 1:]), (k[..., :-2], k[..., 2:]), (k[:, :-1, :], k[:, 1:, :]), (k[:, :-16, :], k[:, 16:, :]),
+             (k[:, :-1, :-1], k[:, 1:, 1:]), (k[..., :-4], k[..., 4:]), (k[..., :-16], k[..., 16:])]
+    if B * heads > 1:
+        pairs.append((k[:1], k[1:2]))
+    if L > 64:
+        pairs.append((k[..., :-64], k[..., 64:]))
+        pairs.append((k[:, :-64, :], k[:, 64:, :]))
+    for a_, b_ in pairs:
+        joint = (a_ * b_).mean().item()
+        assert abs(joint - kq * kq) < 5 * (kq * kq * (1 - kq * kq) / a_.numel()) ** 0.5 + 2e-4, joint
+    # every key column and every query row sees the rate
+    sig = (kq * (1 - kq) / (B * heads * L)) ** 0.5
+    assert (k.mean(dim=(0, 1)) - kq).abs().max().item() < 5.5 * sig
+    assert (k.mean(dim=(0, 2)) - kq).abs().max().item() < 5.5 * sig
+    # the same seed gives the same masks, another seed other ones
+    assert torch.equal(ops.attn_keepmask(B, L, heads, p, 1234, dev), keep)
+    k2, _ = unpack_keep(ops.attn_keepmask(B, L, heads, p, 1235, dev), B, L, heads)
+    assert abs((k2.float() * k).mean().item() - kq * kq) < 5 * (kq * kq * (1 - kq * kq) / n) ** 0.5 + 2e-4
+
+
+def test_keepmask_forward_applies_exactly_these_bits(dev):
+    """q = k = 0 makes the probabilities uniform and one-hot V rows make the output row q the dropped-out probability row: the mask the
+    forward kernel APPLIES is the unpacked layout A (extract_keep_mask of test_gpu_kernels.py, on the _keep entry point)."""
+    ops = _ops()
+    B, L, heads, p = 2, 256, 2, 0.1
+    keep = ops.attn_keepmask(B, L, heads, p, 99, dev)
+    ka, _ = unpack_keep(keep, B, L, heads)
+    mb = torch.zeros(B, L, device=dev)
+    seen = torch.zeros(B, heads, L, L)
+    for blk in range(L // 64):
+        qkv = torch.zeros(B, L, 3, heads, 64, device=dev)
+        for j in range(64):
+            qkv[:, blk * 64 + j, 2, :, j] = 1.0
+        ctx, _ = ops.attn_fwd_keep(qkv.view(B * L, -1).bfloat16(), mb, B, L, heads, p, keep)
+        o = ctx.float().view(B, L, heads, 64).permute(0, 2, 1, 3)
+        seen[:, :, :, blk * 64:(blk + 1) * 64] = (o > 0).float().cpu()
+    assert torch.equal(seen.view(B * heads, L, L).bool(), ka)
+
+
+@pytest.mark.parametrize("B,L,heads,pad", [(2, 128, 2, False), (2, 512, 3, True), (1, 192, 1, False)])
+def test_keepmask_forward_backward_vs_torch(dev, B, L, heads, pad):
+    ops = _ops()
+    p, seed = 0.1, 4321
+    keep = ops.attn_keepmask(B, L, heads, p, seed, dev)
+    ka, _ = unpack_keep(keep, B, L, heads)
+    km = ka.view(B, heads, L, L).float().to(dev)
+    th = round(p * 65536)
+    inv_keep = 65536.0 / (65536 - th)
+    qkv, mb = make_qkv(dev, B, L, heads, 21, pad=pad)
+    g = torch.Generator(device="cpu").manual_seed(22)
+    dctx = torch.randn(B * L, heads * 64, generator=g).to(dev).bfloat16()
+    ctx, lse = ops.attn_fwd_keep(qkv, mb, B, L, heads, p, keep)
+    q32 = qkv.float().requires_grad_(True)
+    ref, _ = attn_ref(q32, mb, B, L, heads, keep=km, inv_keep=inv_keep)
+    assert rel_err(ctx, ref) < 8e-3
+    dqkv = ops.attn_bwd_keep(qkv, mb, ctx, dctx, lse, B, L, heads, p, keep)
+    ref.backward(dctx.float())
+    H = heads * 64
+    for i, name in enumerate(["dq", "dk", "dv"]):                       # per section: dq reads layout A, dk / dv layout B
+        assert rel_err(dqkv[:, i * H:(i + 1) * H], q32.grad[:, i * H:(i + 1) * H]) < 2e-2, name
+
+
+def test_keepmask_p0_and_null_fall_back_to_the_hash_path(dev):
+    ops = _ops()
+    B, L, heads = 2, 128, 2
+    qkv, mb = make_qkv(dev, B, L, heads, 5)
+    ctx0, lse0 = ops.attn_fwd(qkv, mb, B, L, heads, p=0.0)
+    keep = ops.attn_keepmask(B, L, heads, 0.1, 7, dev)
+    ctx1, lse1 = ops.attn_fwd_keep(qkv, mb, B, L, heads, 0.0, keep)    # p = 0: no dropout whatever the buffer holds
+    assert torch.equal(ctx0, ctx1) and torch.equal(lse0, lse1)
+    ctx2, _ = ops.attn_fwd_keep(qkv, mb, B, L, heads, 0.1, None)        # no buffer: hash path with seed 0
+    ctx3, _ = ops.attn_fwd(qkv, mb, B, L, heads, p=0.1, seed=0)
+    assert torch.equal(ctx2, ctx3)
+
+
+def test_keepmask_with_kend_skips_only_unread_chunks(dev):
+    """chunks past a sequence's last unmasked key are not generated (the kernels never read them); everything in front of kend is the same
+    stream of bits whether or not kend is given -- per (wave, chunk group), so compare through the kernels, not bit by bit"""
+    ops = _ops()
+    B, L, heads, p = 2, 256, 2, 0.1
+    qkv, mb = make_qkv(dev, B, L, heads, 5, pad=True)
+    kend = torch.tensor([int((mb[b] == 0).nonzero().max()) + 1 for b in range(B)], dtype=torch.int32, device=dev)
+    keep = torch.zeros(_ops().attn_keepmask(B, L, heads, p, 3, dev).numel(), dtype=torch.uint8, device=dev)
+    from spokennlp_amd import lib as Lb
+    Lb.check(Lb.load().amdseg_attn_keepmask(keep.data_ptr(), B, L, heads, p, 3, kend.data_ptr(), torch.cuda.current_stream().cuda_stream), "keepmask")
+    ka, kb = unpack_keep(keep, B, L, heads)
+    ka = ka.view(B, heads, L, L); kb = kb.view(B, heads, L, L)
+    for b in range(B):
+        nvis = -(-int(kend[b]) // 64) * 64
+        assert torch.equal(ka[b, :, :, :nvis], kb[b, :, :, :nvis])
+        assert abs(ka[b, :, :, :nvis].float().mean().item() - 0.9) < 0.01
+        assert not ka[b, :, :, nvis:].any() and not kb[b, :, :, nvis:].any()        # untouched (the buffer was zeroed)

@@ -49,6 +49,16 @@ def main():
             ctx, lse = ops.attn_fwd(qkv, mb, B, L, heads, p=p, seed=1)
             t = timeit(lambda: ops.attn_bwd(qkv, mb, ctx, dctx, lse, B, L, heads, p=p, seed=1))
             print(f"attn_bwd p={p}: {t*1e6:8.1f} us  {2.5*fl/t/1e12:7.1f} TF (5 matmul-equivalents)")
+        # dropout decided once per layer (amdseg_attn_keepmask): the generator and the three kernels reading its lane masks
+        p = 0.1
+        t = timeit(lambda: ops.attn_keepmask(B, L, heads, p, 1, dev))
+        print(f"attn_keepmask (both layouts, {B * heads * L * L / 4 / 1e6:.1f} MB): {t*1e6:8.1f} us")
+        keep = ops.attn_keepmask(B, L, heads, p, 1, dev)
+        t = timeit(lambda: ops.attn_fwd_keep(qkv, mb, B, L, heads, p, keep))
+        print(f"attn_fwd_keep p={p}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF")
+        ctx, lse = ops.attn_fwd_keep(qkv, mb, B, L, heads, p, keep)
+        t = timeit(lambda: ops.attn_bwd_keep(qkv, mb, ctx, dctx, lse, B, L, heads, p, keep))
+        print(f"attn_bwd_keep p={p}: {t*1e6:8.1f} us  {2.5*fl/t/1e12:7.1f} TF (5 matmul-equivalents)")
     if "rows" in which:
         y = torch.randn(M, H, device=dev).bfloat16(); x = torch.randn(M, H, device=dev).bfloat16()
         g = torch.ones(H, device=dev); b = torch.zeros(H, device=dev)
