@@ -174,6 +174,7 @@ struct KeepMaskArgs {
     uint64_t* A; uint64_t* Bm;
     int B, L, heads; uint32_t thresh16; uint64_t seed;
     const int* kend;                        // optional [B]: chunks past the last unmasked key are never read by the consumers (attn_visible_chunks)
+    uint32_t tn[16];                        // per threshold bit i: 0 if bit i of thresh16 is set, ~0 otherwise (host-filled, see the kernel)
 };
 
 // one wave per (bh, 64-query block, group of KM_CG key chunks)
@@ -181,7 +182,7 @@ struct KeepMaskArgs {
 __global__ __launch_bounds__(256) void attn_keepmask_kernel(KeepMaskArgs a) {
     const int l = threadIdx.x & 63;
     const int nblk = a.L / CH, ngrp = (nblk + KM_CG - 1) / KM_CG;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the index arithmetic below is scalar
     const int total = a.B * a.heads * nblk * ngrp;
     if (wid >= total) return;
     const int grp = wid % ngrp, qblk = (wid / ngrp) % nblk, bh = wid / (ngrp * nblk);
@@ -191,7 +192,6 @@ __global__ __launch_bounds__(256) void attn_keepmask_kernel(KeepMaskArgs a) {
     uint32_t xl = mix32((uint32_t)a.seed ^ mix32((uint32_t)(a.seed >> 32) + 0x9e3779b9u + (uint32_t)wid * 128u + (uint32_t)l));
     uint32_t xh = mix32(xl ^ (0x85ebca6bu + (uint32_t)l));
     xl |= xl == 0; xh |= xh == 0;
-    const int lowbit = __builtin_ctz(a.thresh16 | 0x10000u);
     const int qa = l >> 4, ka = (l >> 2) & 3, c2 = l & 3;             // A: lane = (qa, ka, kc); B after the exchange: lane = (qa, ka, qc)
     const size_t rows16 = (size_t)a.L / 16;
     for (int cc = 0; cc < KM_CG; ++cc) {
@@ -199,10 +199,15 @@ __global__ __launch_bounds__(256) void attn_keepmask_kernel(KeepMaskArgs a) {
         if (chunk >= nvis) break;
         // keep <=> u >= thresh16 for a uniform 16-bit u, evaluated bit-serially from the lowest set bit of the threshold upwards on 64 lanes x
         // 64 independent u's at once: ge = t_i ? (u_i & ge) : (u_i | ge)
+        // = majority(u_i, ge, tn_i) with tn_i = t_i ? 0 : ~0 -- ONE v_bitop3 per half and round.  tn comes from the kernel arguments (SGPRs):
+        // written as a select on the threshold bit the optimiser turns it back into and + or + v_cndmask (3 instructions).  Rounds below the
+        // lowest set bit of the threshold leave ge at all ones, so all 16 rounds run unconditionally
         uint32_t lo = 0xffffffffu, hi = 0xffffffffu;
-        for (int i = lowbit; i < 16; ++i) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
             xl = km_xs32(xl); xh = km_xs32(xh);
-            if ((a.thresh16 >> i) & 1) { lo &= xl; hi &= xh; } else { lo |= xl; hi |= xh; }
+            lo = (xl & lo) | (a.tn[i] & (xl | lo));
+            hi = (xh & hi) | (a.tn[i] & (xh | hi));
         }
         // A: lane (qa, ka, kc) holds word (w = qa, fc = ka, r = kc) with bits (g = kb, i16 = (qb, qc))
         a.A[(((size_t)bh * rows16 + (size_t)qblk * 4 + qa) * nblk + chunk) * 16 + ka * 4 + c2] = ((uint64_t)hi << 32) | lo;
@@ -380,8 +385,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
         cmax = fmaxf(fmaxf(cmax, s[2][3]), s[3][0]);
         cmax = fmaxf(fmaxf(cmax, s[3][1]), s[3][2]);
         cmax = fmaxf(cmax, s[3][3]);
-        cmax = xor_reduce_max_g(cmax) * sc2;
-        if (__any(cmax > m_run)) {                 // wave-uniform: rescale only when some row's running max grew
+        cmax *= sc2;
+        // wave-uniform: rescale only when some row's running max grew -- i.e. when some LANE's own 16 scores exceed its row's running maximum;
+        // the exchange between the four lanes of a row (two LDS-crossbar round trips on the loop's critical path) happens only then
+        if (__any(cmax > m_run)) {
+            cmax = xor_reduce_max_g(cmax);
             const float m_new = fmaxf(m_run, cmax);
             const float alpha = (BAND && m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
@@ -951,6 +959,7 @@ int amdseg_attn_keepmask_impl(void* keep, int B, int L, int heads, float p, uint
     KeepMaskArgs k = {};
     k.A = (uint64_t*)keep; k.Bm = k.A + (size_t)B * heads * L * (size_t)L / 64;
     k.B = B; k.L = L; k.heads = heads; k.thresh16 = a.thresh16; k.seed = seed; k.kend = kend;
+    for (int i = 0; i < 16; ++i) k.tn[i] = ((a.thresh16 >> i) & 1) ? 0u : 0xffffffffu;
     const int nblk = L / CH, ngrp = (nblk + KM_CG - 1) / KM_CG;
     const long waves = (long)B * heads * nblk * ngrp;
     hipLaunchKernelGGL(attn_keepmask_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, k);
