@@ -221,6 +221,52 @@ def pool_roofline(model, args, device):
                 kernel="pn_zero_kernel + pn_segmax_kernel + pn_combine_fwd_kernel", avg_launch_us=round(t * 1e6, 1), algorithmic_bytes=by)
 
 
+def dp_record(eng, world, device, sync_marks, step, first_step, args):
+    """what the N > 1 line says about its own gradient exchange (every rank runs this: it holds collectives; rank 0 prints it):
+    the backend and world size as the collective library sees them (an all-reduce of ones), the buckets of one step, the EXPOSED
+    communication per step (compute-stream time between the end of backward and the start of clip + AdamW, i.e. the tail bucket's
+    all-reduce plus whatever of the per-layer buckets had not finished under backward), and the same step with the word-embedding
+    gradient -- 94 MB of that tail -- exchanged in bf16 (AMDSEG_DP_BF16_EMBED=1, off by default)."""
+    import torch.distributed as dist
+    from spokennlp_amd.dp import GradBuckets
+    ones = torch.ones(1, device=device)
+    dist.all_reduce(ones)
+    b = eng.buckets
+    sizes = [(hi - lo) * 4 for lo, hi in b.layer_slices] + [(b.rest_slice[1] - b.rest_slice[0]) * 4]
+    exposed = sorted(e0.elapsed_time(e1) for e0, e1 in sync_marks)
+    rec = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), allreduce_of_ones=float(ones.item()),
+               buckets_per_step=len(sizes), bytes_per_step=int(sum(sizes)), tail_bucket_bytes=int(sizes[-1]),
+               layer_bucket_bytes=int(sizes[0]), bucket_order="encoder layers last to first from inside backward (side stream), then embeddings + heads",
+               exposed_comm_ms_per_step=round(sum(exposed) / max(len(exposed), 1), 3),
+               exposed_comm_ms_median=round(exposed[len(exposed) // 2], 3) if exposed else None,
+               exposed_comm_method="HIP events on the compute stream around finish_grad_sync() (tail bucket issue + wait for every bucket), "
+                                   "timed region average")
+    try:
+        if dist.get_backend() == "nccl":
+            rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                                   # noqa: BLE001 -- version probing must never cost the bench line
+        rec["rccl_version"] = f"unavailable ({type(e).__name__})"
+    # the same steps with the word-embedding gradient in bf16 on the wire
+    nextra = max(4, min(10, args.steps))
+    old = eng.buckets
+    eng.buckets = GradBuckets(eng.fp, bf16_embeddings=True)
+    torch.cuda.synchronize(); dist.barrier()
+    n0 = len(sync_marks)
+    t0 = time.perf_counter()
+    for i in range(first_step, first_step + nextra):
+        step(i)
+    torch.cuda.synchronize(); dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=device)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ex = [e0.elapsed_time(e1) for e0, e1 in sync_marks[n0:]]
+    ws = eng.buckets.word_slice or (0, 0)
+    word = ws[1] - ws[0]
+    rec["bf16_embed"] = dict(steps=nextra, ms_per_step=round(dt.item() / nextra * 1e3, 3), exposed_comm_ms_per_step=round(sum(ex) / len(ex), 3),
+                             tail_bucket_bytes_on_wire=int(sizes[-1] - 2 * word))
+    eng.buckets = old
+    return rec
+
+
 def host_cpu():
     """(model string, physical cores, logical CPUs) of the box this runs on"""
     model, phys = "unknown CPU", None
@@ -384,6 +430,10 @@ def main():
         model.eval()
         args.no_cpu_baseline = True
 
+    # world > 1: the exposed part of the gradient exchange = what the compute stream spends between the end of backward and the start of
+    # clip + AdamW (the tail bucket -- embeddings + heads, produced last -- is issued there, then every outstanding bucket is waited for)
+    sync_marks = []
+
     def step(i):
         random.seed(i)
         if args.mode == "infer":
@@ -391,7 +441,14 @@ def main():
                 return model(**batches[i % len(batches)])[0]
         loss = model(**batches[i % len(batches)])[0]
         loss.backward()
-        eng.finish_grad_sync()
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            eng.finish_grad_sync()
+            e1.record()
+            sync_marks.append((e0, e1))
+        else:
+            eng.finish_grad_sync()
         lr = lr0 * max(0.0, (total_steps - i) / total_steps)        # linear decay, no warm-up (run_finetune.sh:73)
         eng.adamw_step(lr, max_grad_norm=1.0, grad_scale=1.0 / world)
         return loss
@@ -401,6 +458,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    sync_marks.clear()
     prof_timed = (not args.no_roofline) and args.mode == "train" and args.prof_in_timed and prof_arm()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -438,6 +496,8 @@ def main():
                final_loss=round(float(loss.detach()), 4))
     per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     out["ms_per_step_median"] = round(per_step[len(per_step) // 2], 3)
+    if world > 1 and args.mode == "train":
+        out["dp"] = dp_record(eng, world, device, sync_marks, step, total_steps, args)
     prof = None
     prof_n = args.steps
     if prof_timed:                                          # start / stop events of every launch of the timed region itself

@@ -355,7 +355,10 @@ class TopicSegHeadsMixin:
         return (train and getattr(cfg, "amdseg_fused_heads", True) and cfg.ts_score_predictor == "lt" and cfg.focal_loss_gamma == 0
                 and (cfg.cl_loss_weight == 0 or (cfg.cl_anchor_level in ("eop_list", "eot_list") and cfg.cl_temp != 0
                                                  and cfg.cl_positive_k + cfg.cl_negative_k <= 16))
-                and cfg.num_labels <= 4 and cfg.num_tssp_labels <= 4)
+                and cfg.num_labels <= 4 and cfg.num_tssp_labels <= 4
+                # the class-weight vector of the reference has two entries (loss_calculator.py: [w0, 1 - w0]); with more labels torch raises
+                # a weight-size error -- leave that configuration to the torch heads so it still does
+                and (cfg.num_labels == 2 or getattr(cfg, "weight_label_zero", 0.5) == 0.5))
 
     def _fused_heads(self, seq, labels, host, B, Lq, two_pass):
         cfg = self.config

@@ -180,6 +180,7 @@ class BertEncoderEngine:
         self._arena_slot = 0
         self.max_live_arenas = 2                            # training arenas per shape that may be alive between forward and backward
         self.grad_sync = True                               # False inside no_sync(): accumulate locally, no bucket all-reduce
+        self._rest_reduced = False                          # finish_grad_sync() ran for the gradients now in the flat buffer
         self._arenas = {}
         self._trigger = torch.zeros(1, device=device, requires_grad=True)
         self.adam_m = None
@@ -272,9 +273,12 @@ class BertEncoderEngine:
 
     def finish_grad_sync(self):
         """reduce the non-encoder slice (embeddings, heads) and wait for every outstanding bucket."""
-        if self.buckets is not None and self.grad_sync:
+        if self.buckets is not None and self.grad_sync and not self._rest_reduced:
+            # once per optimiser step: a second call (a logging callback asking for the norm again, grad_norm(inf) and grad_norm(max)) would
+            # all-reduce the embeddings + heads slice again, i.e. multiply it by the world size
             self.buckets.reduce_rest()
             self.buckets.wait()
+            self._rest_reduced = True
 
     # ------------------------------------------------------------------------------------------------ parameters
     def _p(self, flat, i, suffix):
@@ -631,6 +635,7 @@ class BertEncoderEngine:
         M = B * Lseq
         A = ctx["arena"]
         self.fp.grad_is_zero = False
+        self._rest_reduced = False
         if A["gen"] != ctx["gen"]:
             raise L.AmdsegError(f"the activations saved by this forward (B={B}, L={Lseq}) were overwritten: more than "
                                 f"{self.max_live_arenas} training forwards at this shape were alive before their backward ran "
@@ -710,6 +715,7 @@ class BertEncoderEngine:
     def zero_grad(self):
         self.fp.flat_g.zero_()
         self.fp.grad_is_zero = True
+        self._rest_reduced = False
         if self.buckets is not None:
             self.buckets.reset_norm()
 
@@ -749,6 +755,7 @@ class BertEncoderEngine:
         ops.adamw(self.fp.flat_p, self.fp.flat_g, self.adam_m, self.adam_v, self.shadow if ride else None, lr, betas[0], betas[1], eps,
                   weight_decay, self.opt_step, gscale=coef, zero_grad=zero_grad, chunk_flags=getattr(self, "_chunk_flags", None))
         self.fp.grad_is_zero = bool(zero_grad)
+        self._rest_reduced = False
         if self.buckets is not None:
             self.buckets.reset_norm()
         self._fused_owner = True

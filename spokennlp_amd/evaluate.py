@@ -73,16 +73,19 @@ def binary_prf(references, predictions):
     return p, r, f
 
 
-def compute_window_metric(predictions, references, prefix=""):
-    """seqeval.py:173-237.  predictions / references: per example a 0/1 list, 1 = end sentence of a topic."""
+def compute_window_metric(predictions, references, prefix="", strict=False):
+    """seqeval.py:173-237.  predictions / references: per example a 0/1 list, 1 = end sentence of a topic.
+    strict: a malformed example (mass mismatch, empty list) raises instead of being dropped from the means -- the behaviour of the
+    alimeeting4mug twin (challenge_evaluate.py:105-111: `print(i, e); raise RuntimeError`); the emnlp2023 function swallows it (:214-215)."""
     one_pk, one_wd = [], []
-    for y_pred, y_true in zip(predictions, references):
+    for i, (y_pred, y_true) in enumerate(zip(predictions, references)):
         try:
             pm, tm = mass_from_start_label_sequence(y_pred), mass_from_start_label_sequence(y_true)
             assert sum(pm) == sum(tm)
             one_pk.append(1 - pk(pm, tm)); one_wd.append(1 - window_diff(pm, tm))
-        except Exception:       # the reference swallows per-example failures the same way (:214-215)
-            pass
+        except Exception as e:  # the emnlp2023 reference swallows per-example failures the same way (:214-215)
+            if strict:
+                raise RuntimeError(f"window metric: example {i} is malformed ({type(e).__name__}: {e})") from e
     t_pk = round(float(np.array(one_pk).mean()), 4)
     t_wd = round(float(np.array(one_wd).mean()), 4)
     flat_p, flat_r = sum(predictions, []), sum(references, [])
@@ -169,8 +172,10 @@ def compute_metric_example_level(predictions_logits, labels, label_list=("B-EOP"
 def compute_window_metric_alimeeting(predictions, references, prefix=""):
     """alimeeting4mug/metrics/topic_seg_eval/topic_seg_eval.py:170-237 (== src/utils/challenge_evaluate.py:75-134): the emnlp2023 window
     metric plus the average number of predicted / true boundaries per example; no `pk` / `wd` complements."""
-    base = compute_window_metric(predictions, references, prefix=prefix)
     n = len(predictions)
+    if n == 0:
+        raise ValueError("compute_window_metric_alimeeting: no examples")
+    base = compute_window_metric(predictions, references, prefix=prefix, strict=True)      # challenge_evaluate.py:105-111 re-raises
     flat_p, flat_r = sum(predictions, []), sum(references, [])
     out = {k: base[k] for k in (prefix + "1-pk", prefix + "1-wd", prefix + "precision", prefix + "recall", prefix + "f1")}
     out[prefix + "avg_pred_cnt"] = round(sum(flat_p) * 1.0 / n, 2)

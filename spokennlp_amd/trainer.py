@@ -29,27 +29,87 @@ class AmdsegFusedAdamW(torch.optim.Optimizer):
     `decay_names` selects the parameters weight decay applies to."""
     amdseg_fused = True
 
-    def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decay_names=None, max_grad_norm=0.0):
+    def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decay_names=None, max_grad_norm=0.0,
+                 param_groups=None):
+        """`param_groups` (optional): torch-style groups over THIS model's parameters, as HF's `create_optimizer` builds them (decay /
+        no-decay).  The one HIP pass has ONE learning rate, (beta1, beta2) and eps: groups that differ in any of them (layer-wise lr decay,
+        a head with its own lr) are refused loudly instead of silently collapsing to the first group's values; groups that differ only in
+        `weight_decay` (some value / 0) become the per-chunk decay flag."""
         if not hasattr(model, "engine"):
             raise L.AmdsegError("AmdsegFusedAdamW needs one of the spokennlp_amd model classes (it steps the engine's flat buffers)")
         self.model = model
+        if param_groups is not None:
+            lr, betas, eps, weight_decay, decay_names = self._collapse_groups(model, param_groups, dict(lr=lr, betas=betas, eps=eps,
+                                                                                                        weight_decay=weight_decay))
         self.decay_names = None if decay_names is None else set(decay_names)
         self.max_grad_norm = float(max_grad_norm or 0.0)
         self._coef = None
-        self._engine_id = None
+        self._engine_ref = None
+        self._flag_key = None
         self._pending_state = None
         super().__init__([p for p in model.parameters()], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @staticmethod
+    def _collapse_groups(model, groups, defaults):
+        names = {id(p): n for n, p in model.named_parameters()}
+        groups = [dict(defaults, **g) for g in groups]
+        for k in ("lr", "betas", "eps"):
+            vals = {tuple(g[k]) if isinstance(g[k], (list, tuple)) else g[k] for g in groups}
+            if len(vals) > 1:
+                raise L.AmdsegError(f"AmdsegFusedAdamW runs one pass with ONE {k}; the parameter groups ask for {sorted(map(str, vals))}. "
+                                    f"Use a torch optimiser (Trainer(amdseg_native=False)) for per-group {k}.")
+        wds = sorted({float(g["weight_decay"]) for g in groups})
+        nonzero = [w for w in wds if w != 0.0]
+        if len(nonzero) > 1:
+            raise L.AmdsegError(f"AmdsegFusedAdamW supports one weight-decay value plus 0 (decay flag per parameter); got {wds}")
+        decay = set()
+        for g in groups:
+            for p_ in g["params"]:
+                if id(p_) not in names:
+                    raise L.AmdsegError("AmdsegFusedAdamW: a parameter group holds a tensor that is not a parameter of this model")
+                if float(g["weight_decay"]) != 0.0:
+                    decay.add(names[id(p_)])
+        g0 = groups[0]
+        return g0["lr"], tuple(g0["betas"]), g0["eps"], (nonzero[0] if nonzero else 0.0), (decay if nonzero else None)
+
+    def add_param_group(self, param_group):
+        if getattr(self, "param_groups", None):            # torch.optim.Optimizer.__init__ adds the first (only) group through here
+            raise L.AmdsegError("AmdsegFusedAdamW holds every parameter of the model in one group (one lr / betas / eps for the flat pass); "
+                                "a second group would be ignored by the kernel")
+        super().add_param_group(param_group)
 
     # ---- engine plumbing
     def _engine(self):
         eng = self.model.engine()
-        if id(eng) != self._engine_id:             # first use, or the model rebuilt its engine (parameters were re-materialised)
-            eng.set_param_flags(self.decay_names if self.param_groups[0]["weight_decay"] != 0 else None)
-            self._engine_id = id(eng)
+        old = self._engine_ref() if self._engine_ref is not None else None
+        # frozen / decay flags follow the CURRENT requires_grad pattern (a head unfrozen mid-training must start to move)
+        key = (self.param_groups[0]["weight_decay"] != 0, tuple(p.requires_grad for p in eng.fp.params.values()))
+        if eng is not old:                         # first use, or the model rebuilt its engine (parameters were re-materialised)
+            last = getattr(self, "_last", None)    # moments of the engine stepped last (kept alive here: the old engine may be gone already)
+            if last is not None and eng.adam_m is None:
+                # resize_token_embeddings / model.to / `p.data = new` mid-training: keep the moments and the step count when the flat
+                # layout is unchanged; otherwise say so instead of silently restarting the bias correction from zero
+                if last["layout"] == (eng.fp.numel, tuple(eng.fp.offsets.items())):
+                    eng.adam_m = last["m"].to(eng.device); eng.adam_v = last["v"].to(eng.device); eng.opt_step = last["step"]
+                else:
+                    import warnings
+                    warnings.warn("spokennlp_amd: the model rebuilt its parameter storage with a different layout (resized embeddings?); "
+                                  "the AdamW moments and step count restart from zero", RuntimeWarning, stacklevel=3)
+            import weakref
+            self._engine_ref = weakref.ref(eng)
+            self._flag_key = None
             if self._pending_state is not None:
                 self._install_state(eng, self._pending_state)
                 self._pending_state = None
+        if key != self._flag_key:
+            eng.set_param_flags(self.decay_names if key[0] else None)
+            self._flag_key = key
         return eng
+
+    def _live_engine(self):
+        """the engine this optimiser last stepped, if the model still runs on it"""
+        eng = self._engine_ref() if self._engine_ref is not None else None
+        return eng if eng is not None and getattr(self.model, "_engine", None) is eng else None
 
     @staticmethod
     def _world():
@@ -80,6 +140,7 @@ class AmdsegFusedAdamW(torch.optim.Optimizer):
         eng.adamw_step(float(g["lr"]), betas=tuple(g["betas"]), eps=float(g["eps"]), weight_decay=float(g["weight_decay"]),
                        coef=self._coef, zero_grad=True)
         self._coef = None
+        self._last = dict(m=eng.adam_m, v=eng.adam_v, step=eng.opt_step, layout=(eng.fp.numel, tuple(eng.fp.offsets.items())))
         return loss
 
     def zero_grad(self, set_to_none=True):
@@ -92,7 +153,7 @@ class AmdsegFusedAdamW(torch.optim.Optimizer):
     def state_dict(self):
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
         groups[0]["params"] = list(range(len(self.param_groups[0]["params"])))
-        eng = self.model._engine if getattr(self.model, "_engine", None) is not None and id(self.model._engine) == self._engine_id else None
+        eng = self._live_engine()
         state = {}
         if eng is not None and eng.adam_m is not None:
             state = {"amdseg_flat": {"step": torch.tensor(float(eng.opt_step)), "exp_avg": eng.adam_m, "exp_avg_sq": eng.adam_v,
@@ -116,7 +177,7 @@ class AmdsegFusedAdamW(torch.optim.Optimizer):
                     g[k] = v
         st = state_dict.get("state", {}).get("amdseg_flat")
         if st is not None:
-            eng = self.model._engine if getattr(self.model, "_engine", None) is not None and id(self.model._engine) == self._engine_id else None
+            eng = self._live_engine()
             if eng is not None:
                 self._install_state(eng, st)
             else:
@@ -148,8 +209,18 @@ class Trainer(transformers.Trainer):
     """`transformers.Trainer` with the fused optimiser, HIP gradient norm and native data parallelism (see the module docstring).
     `amdseg_native=False` keeps the stock behaviour (torch optimiser, torch DDP)."""
 
+    # the private hooks of transformers.Trainer this subclass overrides; a release that lacks one of them would run the stock clip
+    # (`accelerator.clip_grad_norm_` on the flat-buffer views) BEFORE the engine's tail bucket is reduced -- silently wrong gradients
+    _NATIVE_HOOKS = ("_clip_grad_norm", "_get_grad_norm", "get_decay_parameter_names", "_wrap_model", "_prepare_inputs", "create_optimizer")
+
     def __init__(self, *args, amdseg_native=True, **kwargs):
         self.amdseg_native = bool(amdseg_native)
+        if self.amdseg_native:
+            missing = [h for h in self._NATIVE_HOOKS if not hasattr(transformers.Trainer, h)]
+            if missing:
+                raise L.AmdsegError(f"spokennlp_amd.trainer.Trainer(amdseg_native=True) overrides transformers.Trainer.{', '.join(missing)}, which "
+                                    f"transformers {transformers.__version__} does not have (tested with 5.x); pass amdseg_native=False to train "
+                                    f"with the stock optimiser / torch DDP on the same model classes")
         targs = kwargs.get("args") or next((a for a in args if isinstance(a, transformers.TrainingArguments)), None)
         if self.amdseg_native and targs is not None and targs.dataloader_pin_memory:
             # batches arrive in pinned host memory; a blocking `.to(device)` (accelerate's default) makes the host wait for every
@@ -168,7 +239,7 @@ class Trainer(transformers.Trainer):
         only, by the average since the last log -- is done here on the device and the host-side check is switched off for this run."""
         if _TRAINING_STEP_TAKES_COUNT:
             loss = super().training_step(model, inputs, num_items_in_batch)
-        else:                                                   # transformers < 4.46 (the reference pins 4.26): two arguments
+        else:                                                   # transformers < 4.46: two arguments
             loss = super().training_step(model, inputs)
         if self.amdseg_native and hasattr(self, "_tr_loss") and hasattr(self, "_globalstep_last_logged"):
             if self.args.logging_nan_inf_filter:
@@ -246,7 +317,7 @@ class Trainer(transformers.Trainer):
         return opt if isinstance(opt, AmdsegFusedAdamW) else None
 
     def create_optimizer(self, model=None):
-        if not self.amdseg_native or self.optimizer is not None or self.optimizer_cls_and_kwargs is not None:
+        if not self.amdseg_native or self.optimizer is not None or getattr(self, "optimizer_cls_and_kwargs", None) is not None:
             return super().create_optimizer(model)
         a = self.args
         if "adamw" not in str(a.optim).lower():

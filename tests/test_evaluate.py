@@ -128,3 +128,19 @@ def test_trainer_device_side_nan_filter_matches_the_stock_formula():
         assert float(filter_nonfinite(torch.tensor(bad), tr_loss, 3)) == 2.0
     assert float(filter_nonfinite(torch.tensor(1.25), tr_loss, 3)) == 1.25
     assert filter_nonfinite(torch.tensor(1.0, dtype=torch.bfloat16), tr_loss, 4).dtype == torch.bfloat16
+
+
+def test_alimeeting_window_metric_is_strict_like_its_reference():
+    """(round-2 advisor) challenge_evaluate.py:105-111 prints the failing example and raises RuntimeError; the emnlp2023 twin
+    (seqeval.py:214-215) swallows it.  An empty input is an error, not a ZeroDivisionError / nan mean."""
+    import pytest
+    from spokennlp_amd import evaluate as E
+    good_p, good_r = [[0, 1, 0, 1], [1, 0, 0, 1]], [[0, 1, 0, 1], [0, 0, 1, 1]]
+    out = E.compute_window_metric_alimeeting(good_p, good_r, prefix="t_")
+    assert out["t_avg_pred_cnt"] == 2.0 and out["t_avg_true_cnt"] == 2.0 and 0.0 <= out["t_1-pk"] <= 1.0
+    bad_p, bad_r = good_p + [[0, 1]], good_r + [[0, 1, 1]]               # mass mismatch in the third example
+    with pytest.raises(RuntimeError, match="example 2"):
+        E.compute_window_metric_alimeeting(bad_p, bad_r)
+    assert E.compute_window_metric(bad_p, bad_r)["1-pk"] == E.compute_window_metric(good_p, good_r)["1-pk"]   # emnlp2023: dropped silently
+    with pytest.raises(ValueError):
+        E.compute_window_metric_alimeeting([], [])

@@ -135,6 +135,12 @@ def test_bench_two_ranks_on_one_gpu(dev):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["final_loss"] == out["final_loss"]
+    # the N > 1 line describes its own exchange: backend / world as the collective library sees them, the buckets, the exposed communication
+    d = out["dp"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["allreduce_of_ones"] == 2.0
+    assert d["buckets_per_step"] == 13 and d["bytes_per_step"] > 4e8 and d["tail_bucket_bytes"] > 9e7
+    assert d["exposed_comm_ms_per_step"] > 0 and d["bf16_embed"]["ms_per_step"] > 0
+    assert d["bf16_embed"]["tail_bucket_bytes_on_wire"] == d["tail_bucket_bytes"] - 2 * 30523 * 768
 
 
 def test_rccl_backend_single_rank_bucketed_exchange(dev):

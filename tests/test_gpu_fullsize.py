@@ -427,3 +427,72 @@ def test_bert_base_parity_precision_vs_reference_golden(dev):
             checked += 1
     print(f"bert-base parity train: loss {loss.item():.5f} vs {ref_loss:.5f}; worst grad-norm deviation {worst:.2e}; worst full-gradient relative error {worst_full:.2e} over {checked}")
     assert checked >= 20
+
+
+def test_longformer_base_L4096_batch_of_eight_sequences(dev):
+    """BASELINE config 5 names bs = 8 at L = 4096; the reference-pinned cases above run ONE sample (2 sequences).  Here the golden sample
+    rides in a batch of 4 samples = 8 sequences of 4096 tokens (M = 32768 rows: the bench's longformer shape) next to three synthetic
+    documents of other lengths: its logits must not depend on its batch neighbours, on its position in the batch or on what sits in the
+    padding, and a training step at that batch (dropout 0.1, clip + fused AdamW) must be finite, reproducible and reduce the loss."""
+    import numpy as np
+    from tests.util import longformer_state_dict
+    from tests.test_oracle_golden import flags_of
+    from tests.test_gpu_longformer import build_lf
+    from spokennlp_amd import data
+    z = np.load(os.path.join(ROOT, "tests", "golden", "longformer_base_L4096.npz"), allow_pickle=False)
+    arch = dict(zip(z["arch_keys"].tolist(), [float(v) if "eps" in k else int(float(v)) for k, v in zip(z["arch_keys"].tolist(), z["arch_vals"].tolist())]))
+    arch.pop("layer_norm_eps")
+    sd = longformer_state_dict(arch, seed=int(z["seed"]), std=float(z["std"]))
+    arch["attention_window"] = [int(v) for v in z["attention_window"]]
+    gold = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in.")}
+    docs = data.synth_docs(12, seed=77, vocab=arch["vocab_size"], mean_sents=150, sd_sents=50)
+    syn = data.batches_from_docs(docs, 4096, 3, seed=5)[0]
+    syn["input_ids"] = torch.where(syn["attention_mask"] == 0, torch.ones_like(syn["input_ids"]), syn["input_ids"])    # RoBERTa pad id
+    assert set(syn) == set(gold)
+    batch4 = {k: torch.cat([gold[k], syn[k]], dim=0) for k in gold}
+    assert batch4["input_ids"].shape == (4, 2, 4096)
+    lens = batch4["attention_mask"][:, 0].sum(-1).tolist()
+    assert len(set(lens)) >= 3                              # ragged
+    m = build_lf(arch, flags_of(z, "full_eval"), sd, dev, precision="bf16").eval()
+
+    def run(b):
+        random.seed(int(z["full_eval.random_seed"]))
+        with torch.no_grad():
+            return m(**{k: v.to(dev) for k, v in b.items()})[1].float().cpu()
+
+    alone = run(gold)
+    valid = gold["attention_mask"][0].bool()
+    ref = torch.from_numpy(z["full_eval.logits"])
+    scale = ref[0][valid].abs().max().item()
+    assert (alone[0] - ref[0])[valid].abs().max().item() < 0.05 * scale            # (the pinned case again, as the anchor of this test)
+    in4 = run(batch4)
+    assert torch.equal(in4[0][valid], alone[0][valid])                              # batch neighbours change no bit of a valid token's logits
+    perm = [2, 0, 3, 1]
+    moved = run({k: v[perm] for k, v in batch4.items()})
+    for new, old in enumerate(perm):
+        vmask = batch4["attention_mask"][old].bool()
+        assert torch.equal(moved[new][vmask], in4[old][vmask])                      # nor does the position in the batch
+    junk = {k: v.clone() for k, v in batch4.items()}
+    pad = junk["attention_mask"] == 0
+    junk["input_ids"][pad] = 4242 % arch["vocab_size"]
+    j4 = run(junk)
+    for i in range(4):
+        vmask = batch4["attention_mask"][i].bool()
+        assert torch.equal(j4[i][vmask], in4[i][vmask])                             # nor the content of the padding
+    # a training step at this batch
+    mt = build_lf(arch, flags_of(z, "train_full"), sd, dev, dropout=0.1, precision="bf16").train()
+    bd = {k: v.to(dev) for k, v in batch4.items()}
+    losses = []
+    for it in range(3):
+        random.seed(11)
+        loss = mt(**bd)[0]
+        loss.backward()
+        g = mt.engine().fp.flat_g
+        assert torch.isfinite(loss) and bool(torch.isfinite(g).all())
+        if it == 0:
+            gn0 = float(g.norm())
+            assert gn0 > 0
+        mt.engine().adamw_step(2e-5, max_grad_norm=1.0)
+        losses.append(float(loss))
+    print("longformer-base 8 x 4096 train losses", losses)
+    assert losses[2] < losses[0]
