@@ -157,6 +157,39 @@ __device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
     const f32x2 s = (f32x2){copysignf(0.5f, x.x), copysignf(0.5f, x.y)};
     return ((s + 0.5f) - s * q) + (x * e) * 0.39894228040143268f;
 }
+// ---- the form the bf16 GEMM epilogues use.  They are VALU-bound (two waves per SIMD evaluating 128 GELUs per lane with the matrix pipe
+// idle; ~33 us of the 99-us FFN-up GEMM, profiles/r01_gemm_experiments.md) and that time cannot be hidden under another wave's MFMAs
+// (profiles/r03_gemm_epilogue_overlap.md), so what is left is fewer instructions per element.  gelu(x) = x Phi(x) with
+//     Phi(x) ~ sigmoid(x (a + b x^2 + c x^4)),   (a, b, c) = (1.5950157686, 0.0740112920, -0.0007030336)
+// a minimax fit to the erf form on |x| <= 9 (x^2 clamped at 64, where Phi is 0 / 1 to fp32 precision): max |error| 2.5e-5 in gelu, 1.1e-4
+// in its derivative -- against a bf16 output rounding of 2^-9 relative (the tanh form "gelu_new" with the same cost is off by 4.7e-4).
+// One exp2 and one rcp per element instead of exp2 + rcp + a 5-term polynomial: ~14 instead of ~22 issue slots per element forward, ~19
+// instead of ~24 for the derivative.  The fp32 / parity paths keep the exact erf (gemm_f32.hip, parity.hip).
+#ifndef AMDSEG_GELU_ERF_EPILOGUE
+#define GELU_SIG_A (-1.5950157685725626f * 1.4426950408889634f)      // the constants carry -log2(e): the sigmoid is 1 / (1 + exp2(.))
+#define GELU_SIG_B (-0.07401129204482199f * 1.4426950408889634f)
+#define GELU_SIG_C (0.0007030335771565074f * 1.4426950408889634f)
+__device__ __forceinline__ void gelu_sig_core(f32x2 x, f32x2& r, f32x2& x2c) {       // r = Phi(x)
+    const f32x2 x2 = x * x;
+    x2c = (f32x2){fminf(x2.x, 64.f), fminf(x2.y, 64.f)};
+    const f32x2 w = x * ((x2c * GELU_SIG_C + GELU_SIG_B) * x2c + GELU_SIG_A);
+    const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)} + 1.0f;
+    r = (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+__device__ __forceinline__ f32x2 gelu_sig2(f32x2 x) {
+    f32x2 r, x2c;
+    gelu_sig_core(x, r, x2c);
+    return x * r;
+}
+__device__ __forceinline__ f32x2 gelu_sig_grad2(f32x2 x) {           // d/dx [x Phi] = Phi + x Phi (1 - Phi) s'(x), s' = a + 3 b x^2 + 5 c x^4
+    f32x2 r, x2c;
+    gelu_sig_core(x, r, x2c);
+    const f32x2 sp = (x2c * (-5.0f * GELU_SIG_C * 0.6931471805599453f) + (-3.0f * GELU_SIG_B * 0.6931471805599453f)) * x2c
+                     + (-GELU_SIG_A * 0.6931471805599453f);
+    return (r - r * r) * (x * sp) + r;
+}
+#endif
+
 // "gelu_new" (tanh approximation; [hf] activations.py NewGELUActivation -- BigBird's default hidden_act) and its derivative
 __device__ __forceinline__ float gelu_tanh_fast(float x) {
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
@@ -178,7 +211,11 @@ __device__ __forceinline__ void gelu_act4(float* v, int act) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_fast(v[e]);
     } else {
+#ifndef AMDSEG_GELU_ERF_EPILOGUE
+        const f32x2 a = gelu_sig2((f32x2){v[0], v[1]}), b = gelu_sig2((f32x2){v[2], v[3]});
+#else
         const f32x2 a = gelu_fast2((f32x2){v[0], v[1]}), b = gelu_fast2((f32x2){v[2], v[3]});
+#endif
         v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
     }
 }
@@ -186,7 +223,11 @@ __device__ __forceinline__ void gelu_grad_mul4(float* v, float r0, float r1, flo
     if (act) {
         v[0] *= gelu_tanh_grad_fast(r0); v[1] *= gelu_tanh_grad_fast(r1); v[2] *= gelu_tanh_grad_fast(r2); v[3] *= gelu_tanh_grad_fast(r3);
     } else {
+#ifndef AMDSEG_GELU_ERF_EPILOGUE
+        const f32x2 a = gelu_sig_grad2((f32x2){r0, r1}), b = gelu_sig_grad2((f32x2){r2, r3});
+#else
         const f32x2 a = gelu_grad_fast2((f32x2){r0, r1}), b = gelu_grad_fast2((f32x2){r2, r3});
+#endif
         v[0] *= a.x; v[1] *= a.y; v[2] *= b.x; v[3] *= b.y;
     }
 }

@@ -584,6 +584,9 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     // the kernels below: K = 3072 / 2304: 73 / 56 us vs 90 / 68 (ping-pong); K = 768 (since the LDS-DMA is issued as inline asm and
     // the GELU epilogues were slimmed): QKV 65 vs 67, dual-output FFN 95 vs 131, GELU-bwd 92 vs 127, N = 768: 24 vs 27; train step
     // 16.4 vs 16.9 ms.  AMDSEG_DP_MIN_K moves the threshold.
+    // (a persistent 128 x 256 variant that runs the GELU epilogue of tile i under the main loop of tile i + 1 was built and measured: the
+    // slices cost their full time there too -- the two waves of a SIMD share its VALU issue and matrix pipe -- and the half-height tile's
+    // main loop is 40 % slower: tools/ubench/gemm_hp_experiment.hip, profiles/r03_gemm_epilogue_overlap.md)
     if ((a_in.M % 256) == 0 && ((a_in.N % 256) == 0 || (a_in.N % 192) == 0) && a_in.K >= dp_min_k && !g_force_small_tile) {
         // small M (the per-GPU batches run_finetune.sh ships with: 4 x 2048 or 8 x 512 tokens): the 256-row tiles no longer fill 256 CUs
         // (M = 8192, N = 768: 128 workgroups) and the 128 x 128 kernel's four times as many workgroups, two per CU, win although it is
