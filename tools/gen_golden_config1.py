@@ -3,7 +3,7 @@
 32 synthetic Wiki-727K-shaped documents windowed by the feature builder (which tests/golden/preprocess.npz pins bit-exactly to the
 reference's own closures).  Stores inputs' recipe + the reference's outputs only: anchor logits at the labelled positions of every
 window, the cos-sim side output, and the per-document predictions the decode (ts_sentence_seq_labeling.py:1138-1191) derives from them.
-Two cases: a tiny model on all 32 documents (L = 128) and the bert-base shape on the first 6 documents (L = 512).
+Two cases, both on all 32 documents: a tiny model (L = 128) and the bert-base shape (L = 512).
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden_config1.py
 """
 import os
@@ -36,7 +36,7 @@ CASES = {
                          docs=dict(seed=2024, mean_sents=30, sd_sents=10, mean_boundaries=4, mu_tok=1.8, sigma_tok=0.5)),
     "config1_bert_base": dict(arch=dict(vocab_size=30523, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                                         intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2), sd_seed=20230927,
-                              std=0.03, ndocs=6, L=512, bs=2, docs=dict(seed=2025, mean_sents=52, sd_sents=25, mean_boundaries=5.23)),
+                              std=0.03, ndocs=32, L=512, bs=2, docs=dict(seed=2025, mean_sents=52, sd_sents=25, mean_boundaries=5.23)),
 }
 
 
