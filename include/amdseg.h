@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 6   /* 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 6   /* 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -100,6 +100,18 @@ int amdseg_attn_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, flo
 int amdseg_attn_bwd_keep(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, const void* keep,
                          amdseg_stream_t stream);
+
+/* "Parity" precision attention on the bf16 matrix cores (csrc/attention_split.hip): every contraction of amdseg_attn_fwd / _bwd as a
+ * split-bf16 product (x = hi + lo; hi.hi + hi.lo + lo.hi), fp32 softmax, accumulators and outputs.  qs = the amdseg_split3 image of the fp32
+ * q|k|v projection: [B*L, ldq] bf16 with the hi parts at columns [0, 3*heads*64) and the lo parts at [lo_q, lo_q + 3*heads*64) (order 0:
+ * ldq = 9H, lo_q = 6H); dos = the same for d(ctx) ([B*L, ldo], lo at lo_o; 3H / 2H); ctx, dqkv, lse, delta fp32.  dropout_p > 0 reads the
+ * decisions from `keep` (amdseg_attn_keepmask; full attention only); window > 0 = the Longformer band (nglobal as amdseg_attn_band_fwd).
+ * Replaces the same reference lines as amdseg_attn_fwd at the precision the reference runs in (run_finetune.sh:61-96: fp32). */
+int amdseg_sattn_fwd(const void* qs, int ldq, int lo_q, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale,
+                     float dropout_p, const void* keep, int window, int nglobal, amdseg_stream_t stream);
+int amdseg_sattn_bwd(const void* qs, int ldq, int lo_q, const float* mask_bias, const float* ctx, const void* dos, int ldo, int lo_o,
+                     const float* lse, float* delta_ws, float* dqkv, int B, int L, int heads, float scale, float dropout_p, const void* keep,
+                     int window, int nglobal, amdseg_stream_t stream);
 
 /* ---- Longformer attention (csrc/attention.hip band variants + csrc/longformer.hip global row) -------------------
  * Replaces LongformerSelfAttention.forward ([hf] models/longformer/modeling_longformer.py:482-640: sliding chunks
@@ -380,6 +392,10 @@ typedef struct amdseg_bert_layer_acts {     /* caller-owned activations; all but
      * step's dropout keep masks (amdseg_attn_keepmask) and all three attention kernels read them instead of hashing; backward must get the
      * buffer its forward wrote.  NULL: the stateless hash path. */
     void* keep;
+    /* optional, AMDSEG_F32S: bf16 split image [M, 9H] = [hi | hi | lo] of the fp32 q|k|v projection (amdseg_split3 layout).  When given (and
+     * ws.dctx_s for backward) the attention runs on the bf16 matrix cores as three split products (csrc/attention_split.hip) instead of the
+     * fp32-MFMA kernels of csrc/parity.hip; forward writes it, backward reads it (acts.qkv itself is then only forward scratch). */
+    void* qkv_s;
 } amdseg_bert_layer_acts;
 
 typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across layers */
@@ -388,6 +404,7 @@ typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across
                                                region per deferred reduction: LN2, b1, LN1, bqkv) */
     /* AMDSEG_F32S only: split images of the four gradient operands d(FFN out), du, d(attention out), dqkv: [M,3H] [M,3I] [M,3H] [M,9H] */
     void *d_out_s, *du_s, *d_ao_s, *dqkv_s;
+    void* dctx_s;                           /* optional, AMDSEG_F32S with acts.qkv_s: split image [M, 3H] of d(ctx) (scratch) */
 } amdseg_bert_layer_ws;
 
 int amdseg_bert_layer_fwd(const amdseg_bert_cfg* cfg, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,

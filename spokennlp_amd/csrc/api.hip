@@ -65,6 +65,16 @@ int amdseg_attn_bwd_keep(const void* qkv, const float* mask_bias, const void* ct
     return amdseg_attn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, 0, 0, 0, S(stream), nullptr,
                                 nullptr, nullptr, keep);
 }
+int amdseg_sattn_fwd(const void* qs, int ldq, int lo_q, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale,
+                     float dropout_p, const void* keep, int window, int nglobal, amdseg_stream_t stream) {
+    return amdseg_sattn_fwd_impl(qs, ldq, lo_q, mask_bias, ctx, lse, B, L, heads, scale, dropout_p, keep, window, nglobal, S(stream));
+}
+int amdseg_sattn_bwd(const void* qs, int ldq, int lo_q, const float* mask_bias, const float* ctx, const void* dos, int ldo, int lo_o,
+                     const float* lse, float* delta_ws, float* dqkv, int B, int L, int heads, float scale, float dropout_p, const void* keep,
+                     int window, int nglobal, amdseg_stream_t stream) {
+    return amdseg_sattn_bwd_impl(qs, ldq, lo_q, mask_bias, ctx, dos, ldo, lo_o, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, keep, window,
+                                 nglobal, S(stream));
+}
 int amdseg_attn_band_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                          float dropout_p, uint64_t seed, int window, int nglobal, amdseg_stream_t stream) {
     if (window <= 0) return AMDSEG_ERR_ARG;
@@ -309,6 +319,13 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         if (PHASE1(c)) {
             RET_IF(amdseg_split3_impl(fx, H, a->xs, M, H, 0, s));
             RET_IF(amdseg_gemm_nt_impl(a->xs, 3 * H, p->wqkv, 3 * H, a->qkv, 3 * H, M, 3 * H, 3 * H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 1, s));
+            if (a->qkv_s && (c->p_attn == 0.f || a->keep)) {
+                // attention as split-bf16 products on the bf16 matrix cores (attention_split.hip); dropout from this layer's keep masks
+                RET_IF(amdseg_split3_impl((const float*)a->qkv, 3 * H, a->qkv_s, M, 3 * H, 0, s));
+                if (c->p_attn > 0.f) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s));
+                RET_IF(amdseg_sattn_fwd_impl(a->qkv_s, 9 * H, 6 * H, mask_bias, (float*)a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn,
+                                             c->p_attn > 0.f ? a->keep : nullptr, 0, 0, s, c->kend, c->seq_order));
+            } else
             RET_IF(amdseg_pattn_fwd_impl((const float*)a->qkv, mask_bias, (float*)a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                          site_seed(c->seed, li, 0), s, c->kend, c->seq_order));
         }
@@ -407,6 +424,12 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
             RET_IF(amdseg_gemm_nt_impl(w->d_ao_s, 3 * H, p->wo_t, 3 * H, w->dctx, H, M, H, 3 * H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1, s));
         }
         if (PHASE2(c)) {
+            if (a->qkv_s && w->dctx_s && (c->p_attn == 0.f || a->keep)) {
+                RET_IF(amdseg_split3_impl((const float*)w->dctx, H, w->dctx_s, M, H, 0, s));
+                RET_IF(amdseg_sattn_bwd_impl(a->qkv_s, 9 * H, 6 * H, mask_bias, (const float*)a->ctx, w->dctx_s, 3 * H, 2 * H, a->lse, w->delta,
+                                             (float*)w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn, c->p_attn > 0.f ? a->keep : nullptr, 0, 0, s,
+                                             c->kend, c->seq_order, c->pad_guard));
+            } else
             RET_IF(amdseg_pattn_bwd_impl((const float*)a->qkv, mask_bias, (const float*)a->ctx, (const float*)w->dctx, a->lse, w->delta,
                                          (float*)w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0), s, c->kend, c->seq_order,
                                          c->pad_guard));

@@ -449,7 +449,14 @@ class BertEncoderEngine:
                          for _ in range(nsave)],
                  emb_z=e(M, H), emb_mean=e(M, dt=torch.float32), emb_rstd=e(M, dt=torch.float32),
                  mask_bias=e(B, Lseq, dt=torch.float32), gen=0, busy=False, stamp=0)
-        if train and not fp32 and self.attn_keepmask and float(self.cfg.attention_probs_dropout_prob) > 0:
+        # "parity" precision: attention as split-bf16 products (csrc/attention_split.hip) needs the split image of q|k|v per layer;
+        # AMDSEG_PATTN_F32=1 keeps the fp32-MFMA attention of csrc/parity.hip
+        import os as _os2
+        split_attn = parity and self.attn_keepmask and _os2.environ.get("AMDSEG_PATTN_F32", "0") != "1"
+        if split_attn:
+            for la in A["layers"]:
+                la["qkv_s"] = e(M, 9 * H, dt=torch.bfloat16)
+        if train and (not fp32 or split_attn) and self.attn_keepmask and float(self.cfg.attention_probs_dropout_prob) > 0:
             nbytes = L.load().amdseg_attn_keepmask_bytes(B, Lseq, self.heads)
             for la in A["layers"]:
                 la["keep"] = e(nbytes, dt=torch.uint8)
@@ -466,13 +473,15 @@ class BertEncoderEngine:
                 if parity:
                     d.update(d_out_s=e(M, 3 * H, dt=torch.bfloat16), du_s=e(M, 3 * I, dt=torch.bfloat16),
                              d_ao_s=e(M, 3 * H, dt=torch.bfloat16), dqkv_s=e(M, 9 * H, dt=torch.bfloat16))
+                    if split_attn:
+                        d["dctx_s"] = e(M, 3 * H, dt=torch.bfloat16)
                 return d
 
             # two scratch sets: layer i's weight-gradient GEMM (second stream) still reads set i % 2 while layer i-1's backward
             # writes the other one
             A["ws_sets"] = [ws_set(), ws_set()]
             wkeys = ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx", "dqkv", "delta", "partials") + \
-                (("d_out_s", "du_s", "d_ao_s", "dqkv_s") if parity else ())
+                (("d_out_s", "du_s", "d_ao_s", "dqkv_s") if parity else ()) + (("dctx_s",) if split_attn else ())
             A["ws_structs"] = [L.LayerWs(**{k: w[k].data_ptr() for k in wkeys}) for w in A["ws_sets"]]
             A["ws"] = dict(A["ws_sets"][0], dy=[e(M, H), e(M, H)])
             A["ws_struct"] = A["ws_structs"][0]
@@ -486,6 +495,8 @@ class BertEncoderEngine:
                 ptrs.update({k: la[k].data_ptr() for k in ("xs", "ctx_s", "x1_s", "h_s")})
             if "keep" in la:
                 ptrs["keep"] = la["keep"].data_ptr()
+            if "qkv_s" in la:
+                ptrs["qkv_s"] = la["qkv_s"].data_ptr()
             if not train and not fp32:
                 ptrs["u"] = None                  # inference: the FFN GEMM skips the pre-activation output
             A["acts_struct"].append(L.LayerActs(x_in=xin.data_ptr(), x_out=xout.data_ptr(), **ptrs))

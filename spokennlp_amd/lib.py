@@ -35,12 +35,12 @@ class LayerGrads(C.Structure):
 
 class LayerActs(C.Structure):
     _fields_ = [(n, vp) for n in ("x_in", "qkv", "ctx", "z1", "x1", "u", "h", "z2", "x_out",
-                                  "lse", "mean1", "rstd1", "mean2", "rstd2", "xs", "ctx_s", "x1_s", "h_s", "keep")]
+                                  "lse", "mean1", "rstd1", "mean2", "rstd2", "xs", "ctx_s", "x1_s", "h_s", "keep", "qkv_s")]
 
 
 class LayerWs(C.Structure):
     _fields_ = [(n, vp) for n in ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx", "dqkv", "delta", "partials",
-                                  "d_out_s", "du_s", "d_ao_s", "dqkv_s")]
+                                  "d_out_s", "du_s", "d_ao_s", "dqkv_s", "dctx_s")]
 
 
 # name -> argtypes (restype is always int unless listed in _RESTYPE); mirrors include/amdseg.h one for one
@@ -60,6 +60,8 @@ _PROTOS = {
     "amdseg_attn_keepmask": [vp, i32, i32, i32, f32, u64, vp, vp],
     "amdseg_attn_fwd_keep": [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],
     "amdseg_attn_bwd_keep": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],
+    "amdseg_sattn_fwd": [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
+    "amdseg_sattn_bwd": [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
     "amdseg_attn_band_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, i32, vp],
     "amdseg_attn_band_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, i32, vp],
     "amdseg_attn_band_f32": [vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],

@@ -392,6 +392,27 @@ def split3_transpose(W, out):
     return out
 
 
+def sattn_fwd(qkv, mask_bias, B, Lq, heads, p=0.0, keep=None, window=0, nglobal=0):
+    """"parity" precision attention on split-bf16 products (amdseg_sattn_fwd): qkv fp32 [B*L, 3H] -> (ctx fp32, lse, the split image)"""
+    H = heads * 64
+    qs = split3(qkv, torch.empty(B * Lq, 9 * H, dtype=torch.bfloat16, device=qkv.device))
+    ctx = torch.empty(B * Lq, H, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B * heads * Lq, dtype=torch.float32, device=qkv.device)
+    L.check(L.load().amdseg_sattn_fwd(_p(qs), 9 * H, 6 * H, _p(mask_bias), _p(ctx), _p(lse), B, Lq, heads, 0.125, p, _p(keep), window, nglobal, _s()),
+            "amdseg_sattn_fwd")
+    return ctx, lse, qs
+
+
+def sattn_bwd(qs, mask_bias, ctx, dctx, lse, B, Lq, heads, p=0.0, keep=None, window=0, nglobal=0):
+    H = heads * 64
+    dos = split3(dctx, torch.empty(B * Lq, 3 * H, dtype=torch.bfloat16, device=dctx.device))
+    dqkv = torch.empty(B * Lq, 3 * H, dtype=torch.float32, device=dctx.device)
+    delta = torch.empty_like(lse)
+    L.check(L.load().amdseg_sattn_bwd(_p(qs), 9 * H, 6 * H, _p(mask_bias), _p(ctx), _p(dos), 3 * H, 2 * H, _p(lse), _p(delta), _p(dqkv), B, Lq,
+                                      heads, 0.125, p, _p(keep), window, nglobal, _s()), "amdseg_sattn_bwd")
+    return dqkv
+
+
 def pattn_fwd(qkv, mask_bias, B, Lq, heads, p=0.0, seed=0):
     H = heads * 64
     ctx = torch.empty(B * Lq, H, dtype=torch.float32, device=qkv.device)

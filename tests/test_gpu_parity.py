@@ -79,6 +79,87 @@ def test_fp32_attention_forward_backward_vs_autograd(dev, B, Lq, heads):
     assert (dqkv.double() - qkv.grad).abs().max().item() < 5e-5 * max(1.0, qkv.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("B,Lq,heads", [(2, 128, 2), (1, 512, 3), (3, 192, 1)])
+def test_split_bf16_attention_forward_backward_vs_autograd(dev, B, Lq, heads):
+    """amdseg_sattn_fwd / _bwd (csrc/attention_split.hip: every contraction as hi.hi + hi.lo + lo.hi on the bf16 matrix cores) against fp64
+    autograd: errors at the fp32 level, same bounds as the fp32-MFMA kernels they replace in the "parity" training step"""
+    from spokennlp_amd import ops
+    torch.manual_seed(Lq)
+    H = heads * 64
+    qkv = torch.randn(B * Lq, 3 * H, device=dev, dtype=torch.float64).requires_grad_(True)
+    am = torch.ones(B, Lq, device=dev); am[-1, Lq - 37:] = 0
+    mb = ((1 - am) * -30000.0)
+    dctx = torch.randn(B * Lq, H, device=dev)
+    ref = _attn_ref(qkv, mb.double(), B, Lq, heads)
+    ref.backward(dctx.double())
+    q32 = qkv.detach().float().contiguous()
+    ctx, lse, qs = ops.sattn_fwd(q32, mb, B, Lq, heads)
+    err = (ctx.double() - ref.detach()).abs().max().item()
+    ctx_f32, lse_f32 = ops.pattn_fwd(q32, mb, B, Lq, heads)
+    print(f"split-bf16 attention fwd max err {err:.2e} (fp32-MFMA kernel: {(ctx_f32.double() - ref.detach()).abs().max().item():.2e})")
+    assert err < 5e-5
+    assert (lse - lse_f32).abs().max().item() < 1e-4
+    dqkv = ops.sattn_bwd(qs, mb, ctx, dctx, lse, B, Lq, heads)
+    scale = max(1.0, qkv.grad.abs().max().item())
+    for i, name in enumerate(("dq", "dk", "dv")):
+        e = (dqkv[:, i * H:(i + 1) * H].double() - qkv.grad[:, i * H:(i + 1) * H]).abs().max().item()
+        assert e < 1e-4 * scale, (name, e)
+
+
+def test_split_bf16_attention_with_keep_masks(dev):
+    """dropout read from the layer's keep masks (amdseg_attn_keepmask): forward and all three gradients against autograd with the unpacked mask"""
+    from spokennlp_amd import ops
+    from tests.test_gpu_keepmask import unpack_keep
+    torch.manual_seed(5)
+    B, Lq, heads, p = 2, 256, 2, 0.1
+    H = heads * 64
+    keep = ops.attn_keepmask(B, Lq, heads, p, 99, dev)
+    ka, _ = unpack_keep(keep, B, Lq, heads)
+    km = ka.view(B, heads, Lq, Lq).double().to(dev)
+    inv_keep = 65536.0 / (65536 - round(p * 65536))
+    qkv = torch.randn(B * Lq, 3 * H, device=dev, dtype=torch.float64).requires_grad_(True)
+    mb = torch.zeros(B, Lq, device=dev)
+    q, k, v = [t.view(B, Lq, heads, 64).transpose(1, 2) for t in qkv.view(B, Lq, 3 * H).split(H, -1)]
+    pr = torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) * km * inv_keep
+    ref = (pr @ v).transpose(1, 2).reshape(B * Lq, H)
+    dctx = torch.randn(B * Lq, H, device=dev)
+    ref.backward(dctx.double())
+    q32 = qkv.detach().float().contiguous()
+    ctx, lse, qs = ops.sattn_fwd(q32, mb, B, Lq, heads, p=p, keep=keep)
+    assert (ctx.double() - ref.detach()).abs().max().item() < 5e-5
+    dqkv = ops.sattn_bwd(qs, mb, ctx, dctx, lse, B, Lq, heads, p=p, keep=keep)
+    assert (dqkv.double() - qkv.grad).abs().max().item() < 1e-4 * max(1.0, qkv.grad.abs().max().item())
+    from spokennlp_amd import lib as Lb
+    with pytest.raises(Lb.AmdsegError):                    # dropout without the masks: refused, not silently undropped
+        ops.sattn_fwd(q32, mb, B, Lq, heads, p=p, keep=None)
+
+
+@pytest.mark.parametrize("Lq,window,ng", [(256, 32, 1), (512, 64, 1), (256, 48, 0)])
+def test_split_bf16_band_attention_vs_autograd(dev, Lq, window, ng):
+    """the Longformer band (|i - j| <= window or j < nglobal; padded query rows zeroed) in split-bf16 precision, forward and backward"""
+    from spokennlp_amd import ops
+    torch.manual_seed(window)
+    B, heads = 2, 2
+    H = heads * 64
+    qkv = torch.randn(B * Lq, 3 * H, device=dev, dtype=torch.float64).requires_grad_(True)
+    am = torch.ones(B, Lq, device=dev); am[-1, Lq - 70:] = 0
+    mb = ((1 - am) * -30000.0)
+    idx = torch.arange(Lq, device=dev)
+    vis = ((idx[None, :] - idx[:, None]).abs() <= window) | (idx[None, :] < ng)
+    q, k, v = [t.view(B, Lq, heads, 64).transpose(1, 2) for t in qkv.view(B, Lq, 3 * H).split(H, -1)]
+    s_ = q @ k.transpose(-1, -2) / 8.0 + mb.double().view(B, 1, 1, Lq)
+    s_ = s_.masked_fill(~vis[None, None], float("-inf"))
+    ref = (torch.softmax(s_, -1) @ v).transpose(1, 2).reshape(B, Lq, H) * am.double()[:, :, None]
+    ref = ref.reshape(B * Lq, H)
+    dctx = torch.randn(B * Lq, H, device=dev)
+    ref.backward(dctx.double())
+    q32 = qkv.detach().float().contiguous()
+    ctx, lse, qs = ops.sattn_fwd(q32, mb, B, Lq, heads, window=window, nglobal=ng)
+    assert (ctx.double() - ref.detach()).abs().max().item() < 5e-5
+    dqkv = ops.sattn_bwd(qs, mb, ctx, dctx, lse, B, Lq, heads, window=window, nglobal=ng)
+    assert (dqkv.double() - qkv.grad).abs().max().item() < 1e-4 * max(1.0, qkv.grad.abs().max().item())
+
+
 def test_fp32_attention_dropout_is_consistent_between_forward_and_backward(dev):
     """with the keep-mask fixed by the seed, ctx is LINEAR in V: <dctx, ctx(V)> == <dV, V> (adjoint identity) pins that backward applies
     the same mask as forward; the realised keep rate and the 1/(1-p) scaling are checked on a constant-V probe"""
