@@ -42,6 +42,8 @@ extern "C" {
 #define AMDSEG_EPI_BIAS_GELU 2  /* C2 = A B^T + bias (pre-activation; C2 may be NULL), C = gelu_erf  */
 #define AMDSEG_EPI_ADD_RES 3    /* C = A B^T + R                                                  */
 #define AMDSEG_EPI_GELU_BWD 4   /* C = (A B^T) * gelu_erf'(R)                                     */
+#define AMDSEG_EPI_BIAS_SPLIT 5 /* C = bf16 hi of (A B^T + bias), C2 = bf16 lo = bf16(value - hi): the result as a split-bf16 image ("parity"
+                                   precision, amdseg_sattn_*); M % 256 == 0, N % 256 == 0, K >= 128 (other shapes: AMDSEG_ERR_SHAPE)   */
 #define AMDSEG_EPI_ACT_TANH 0x100 /* OR-ed into BIAS_GELU / GELU_BWD: "gelu_new" (tanh form, BigBird's hidden_act) instead of erf */
 
 typedef void* amdseg_stream_t;  /* hipStream_t */

@@ -35,6 +35,7 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
                        const int* zkend = nullptr, const int* zguard = nullptr, int zL = 0);
 int amdseg_colsum_impl(const void* x, int ld, float* partials, float* out, int M, int N, int accumulate, int dtype,
                        hipStream_t s);
+int amdseg_colsum_split_impl(const void* x, int ld, int lo_off, float* partials, float* out, int M, int N, int accumulate, hipStream_t s);
 int amdseg_dropout_impl(const void* x, void* y, size_t n, float p, uint64_t seed, int dtype_in, int dtype_out,
                         hipStream_t s);
 int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K, hipStream_t s);
@@ -73,7 +74,8 @@ int amdseg_sattn_fwd_impl(const void* qs, int ldq, int lo_q, const float* mask_b
                           float p, const void* keep, int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr);
 int amdseg_sattn_bwd_impl(const void* qs, int ldq, int lo_q, const float* mask_bias, const float* ctx, const void* dos, int ldo, int lo_o,
                           const float* lse, float* delta, float* dqkv, int B, int L, int heads, float scale, float p, const void* keep, int window,
-                          int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr, const int* qguard = nullptr);
+                          int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr, const int* qguard = nullptr,
+                          void* dqs_image = nullptr, int ldd = 0);
 int amdseg_attn_f32_impl(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, int d,
                          float scale, int window, int nglobal, hipStream_t s);
 

@@ -318,10 +318,17 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         const float* fx = (const float*)a->x_in;
         if (PHASE1(c)) {
             RET_IF(amdseg_split3_impl(fx, H, a->xs, M, H, 0, s));
+            const bool split_attn = a->qkv_s && (c->p_attn == 0.f || a->keep);
+            // the projection written straight as the split image the attention reads (hi block | unused | lo block), where the 256 x 256 GEMM tiles it
+            const bool fused_qkv = split_attn && (M % 256) == 0 && ((3 * H) % 256) == 0;
+            if (fused_qkv)
+                RET_IF(amdseg_gemm_nt_impl(a->xs, 3 * H, p->wqkv, 3 * H, a->qkv_s, 9 * H, M, 3 * H, 3 * H, AMDSEG_EPI_BIAS_SPLIT, p->bqkv, nullptr, 0,
+                                           (bf16_t*)a->qkv_s + 6 * H, 9 * H, 0, s));
+            else
             RET_IF(amdseg_gemm_nt_impl(a->xs, 3 * H, p->wqkv, 3 * H, a->qkv, 3 * H, M, 3 * H, 3 * H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 1, s));
-            if (a->qkv_s && (c->p_attn == 0.f || a->keep)) {
+            if (split_attn) {
                 // attention as split-bf16 products on the bf16 matrix cores (attention_split.hip); dropout from this layer's keep masks
-                RET_IF(amdseg_split3_impl((const float*)a->qkv, 3 * H, a->qkv_s, M, 3 * H, 0, s));
+                if (!fused_qkv) RET_IF(amdseg_split3_impl((const float*)a->qkv, 3 * H, a->qkv_s, M, 3 * H, 0, s));
                 if (c->p_attn > 0.f) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s));
                 RET_IF(amdseg_sattn_fwd_impl(a->qkv_s, 9 * H, 6 * H, mask_bias, (float*)a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                              c->p_attn > 0.f ? a->keep : nullptr, 0, 0, s, c->kend, c->seq_order));
@@ -426,15 +433,18 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         if (PHASE2(c)) {
             if (a->qkv_s && w->dctx_s && (c->p_attn == 0.f || a->keep)) {
                 RET_IF(amdseg_split3_impl((const float*)w->dctx, H, w->dctx_s, M, H, 0, s));
+                // ... whose backward writes d(q|k|v) as the [hi | hi | lo] image the next GEMMs read; the bias gradient is summed from the image
                 RET_IF(amdseg_sattn_bwd_impl(a->qkv_s, 9 * H, 6 * H, mask_bias, (const float*)a->ctx, w->dctx_s, 3 * H, 2 * H, a->lse, w->delta,
-                                             (float*)w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn, c->p_attn > 0.f ? a->keep : nullptr, 0, 0, s,
-                                             c->kend, c->seq_order, c->pad_guard));
-            } else
+                                             nullptr, c->B, c->L, c->heads, 0.125f, c->p_attn, c->p_attn > 0.f ? a->keep : nullptr, 0, 0, s,
+                                             c->kend, c->seq_order, c->pad_guard, w->dqkv_s, 9 * H));
+                RET_IF(amdseg_colsum_split_impl(w->dqkv_s, 9 * H, 6 * H, part_bqkv, g->bqkv, M, 3 * H, acc, s));
+            } else {
             RET_IF(amdseg_pattn_bwd_impl((const float*)a->qkv, mask_bias, (const float*)a->ctx, (const float*)w->dctx, a->lse, w->delta,
                                          (float*)w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0), s, c->kend, c->seq_order,
                                          c->pad_guard));
             RET_IF(amdseg_split3_impl((const float*)w->dqkv, 3 * H, w->dqkv_s, M, 3 * H, 0, s));
             RET_IF(amdseg_colsum_impl(w->dqkv, 3 * H, part_bqkv, g->bqkv, M, 3 * H, acc, AMDSEG_F32, s));
+            }
             RET_IF(amdseg_gemm_nt_impl(w->dqkv_s, 9 * H, p->wqkv_t, 9 * H, dx_in, H, M, H, 9 * H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1, s));
             RET_IF(amdseg_add_inplace_impl((float*)dx_in, (const float*)w->dz1, (size_t)M * H, s));
         }

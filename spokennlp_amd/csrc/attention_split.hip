@@ -20,6 +20,8 @@ struct SAttnArgs {
     const float* mask_bias; float* ctx; float* lse;
     const bf16_t* dos; int ldo, lo_o;
     float* delta; float* dqkv;
+    bf16_t* dqs; int ldd;                   // optional: write d(q|k|v) as the split image [B*L][ldd] = [hi | hi | lo] (blocks 3H wide: the A operand
+                                            // of the next split GEMMs) instead of fp32 dqkv
     int B, L, heads;
     float scale, inv_keep; uint32_t thresh16;
     int window, nglobal;
@@ -40,6 +42,15 @@ __device__ __forceinline__ void sa_split8(const f32x4& a, const f32x4& b, bf16x8
         Lo.u[i] = pack2bf(x[2 * i] - __uint_as_float(H.u[i] << 16), x[2 * i + 1] - __uint_as_float(H.u[i] & 0xffff0000u));
     }
     hi = H.v; lo = Lo.v;
+}
+// four consecutive gradient values: fp32 to `f`, or as hi | hi | lo to the image position `img` (blocks W apart)
+__device__ __forceinline__ void sa_store4(float* f, bf16_t* img, int W, float x0, float x1, float x2, float x3) {
+    if (!img) { *reinterpret_cast<float4*>(f) = make_float4(x0, x1, x2, x3); return; }
+    uint2 hi, lo;
+    hi.x = pack2bf(x0, x1); hi.y = pack2bf(x2, x3);
+    lo.x = pack2bf(x0 - __uint_as_float(hi.x << 16), x1 - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = pack2bf(x2 - __uint_as_float(hi.y << 16), x3 - __uint_as_float(hi.y & 0xffff0000u));
+    *reinterpret_cast<uint2*>(img) = hi; *reinterpret_cast<uint2*>(img + W) = hi; *reinterpret_cast<uint2*>(img + 2 * W) = lo;
 }
 // acc += Ahi.Bhi + Ahi.Blo + Alo.Bhi   (A = the LDS-side fragment, B = the register-side one)
 #define SA_MFMA3(acc, ah, al, bh, bl) do { \
@@ -240,12 +251,13 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_dq_kernel(SAttnArgs a) {
     const size_t tok0 = (size_t)b * a.L;
     const int q = qb * (NW * 16) + w * 16 + i16;
     const uint64_t prow = ((uint64_t)(b * a.heads + h)) * a.L + q;
-    float* dqp = a.dqkv + (tok0 + q) * (size_t)(3 * H) + h * HD;
+    float* dqp = a.dqkv ? a.dqkv + (tok0 + q) * (size_t)(3 * H) + h * HD : nullptr;
+    bf16_t* dqi = a.dqs ? a.dqs + (tok0 + q) * (size_t)a.ldd + h * HD : nullptr;
     if (!BAND && a.qguard && a.kend) {                      // a query block of trailing padding whose dO rows are exact zeros: dQ = 0, delta = 0
         const int ke = a.kend[b];
         if (ke > 0 && qb * (NW * 16) >= ke && *a.qguard == 0) {
 #pragma unroll
-            for (int d = 0; d < 4; ++d) *reinterpret_cast<float4*>(dqp + d * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int d = 0; d < 4; ++d) sa_store4(dqp + d * 16 + g * 4, dqi ? dqi + d * 16 + g * 4 : nullptr, 3 * H, 0.f, 0.f, 0.f, 0.f);
             if (g == 0) a.delta[prow] = 0.f;
             return;
         }
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_dq_kernel(SAttnArgs a) {
     }
     if (BAND && pad_block) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) *reinterpret_cast<float4*>(dqp + d * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int d = 0; d < 4; ++d) sa_store4(dqp + d * 16 + g * 4, dqi ? dqi + d * 16 + g * 4 : nullptr, 3 * H, 0.f, 0.f, 0.f, 0.f);
         if (g == 0) a.delta[prow] = 0.f;
         return;
     }
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_dq_kernel(SAttnArgs a) {
     }
 #pragma unroll
     for (int d = 0; d < 4; ++d)
-        *reinterpret_cast<float4*>(dqp + d * 16 + g * 4) = make_float4(dq[d][0] * a.scale, dq[d][1] * a.scale, dq[d][2] * a.scale, dq[d][3] * a.scale);
+        sa_store4(dqp + d * 16 + g * 4, dqi ? dqi + d * 16 + g * 4 : nullptr, 3 * H, dq[d][0] * a.scale, dq[d][1] * a.scale, dq[d][2] * a.scale, dq[d][3] * a.scale);
 #undef CHUNK_OF
 }
 
@@ -414,15 +426,17 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_dkv_kernel(SAttnArgs a) {
     const size_t tok0 = (size_t)b * a.L;
     const int key = kb * (NW * 16) + w * 16 + i16;
     const uint64_t bh64 = (uint64_t)(b * a.heads + h);
-    float* dkp = a.dqkv + (tok0 + key) * (size_t)(3 * H) + H + h * HD;
-    float* dvp = a.dqkv + (tok0 + key) * (size_t)(3 * H) + 2 * H + h * HD;
+    float* dkp = a.dqkv ? a.dqkv + (tok0 + key) * (size_t)(3 * H) + H + h * HD : nullptr;
+    float* dvp = a.dqkv ? a.dqkv + (tok0 + key) * (size_t)(3 * H) + 2 * H + h * HD : nullptr;
+    bf16_t* dki = a.dqs ? a.dqs + (tok0 + key) * (size_t)a.ldd + H + h * HD : nullptr;
+    bf16_t* dvi = a.dqs ? a.dqs + (tok0 + key) * (size_t)a.ldd + 2 * H + h * HD : nullptr;
     if (!BAND && a.kend) {
         const int ke = a.kend[b];
         if (ke > 0 && kb * (NW * 16) >= ke) {               // a key block wholly in the trailing padding: dK = dV = 0 exactly
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                *reinterpret_cast<float4*>(dkp + d * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(dvp + d * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                sa_store4(dkp + d * 16 + g * 4, dki ? dki + d * 16 + g * 4 : nullptr, 3 * H, 0.f, 0.f, 0.f, 0.f);
+                sa_store4(dvp + d * 16 + g * 4, dvi ? dvi + d * 16 + g * 4 : nullptr, 3 * H, 0.f, 0.f, 0.f, 0.f);
             }
             return;
         }
@@ -565,8 +579,8 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_dkv_kernel(SAttnArgs a) {
     }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        *reinterpret_cast<float4*>(dkp + d * 16 + g * 4) = make_float4(dk[d][0] * a.scale, dk[d][1] * a.scale, dk[d][2] * a.scale, dk[d][3] * a.scale);
-        *reinterpret_cast<float4*>(dvp + d * 16 + g * 4) = make_float4(dv[d][0] * ikeep, dv[d][1] * ikeep, dv[d][2] * ikeep, dv[d][3] * ikeep);
+        sa_store4(dkp + d * 16 + g * 4, dki ? dki + d * 16 + g * 4 : nullptr, 3 * H, dk[d][0] * a.scale, dk[d][1] * a.scale, dk[d][2] * a.scale, dk[d][3] * a.scale);
+        sa_store4(dvp + d * 16 + g * 4, dvi ? dvi + d * 16 + g * 4 : nullptr, 3 * H, dv[d][0] * ikeep, dv[d][1] * ikeep, dv[d][2] * ikeep, dv[d][3] * ikeep);
     }
 }
 
@@ -608,13 +622,15 @@ int amdseg_sattn_fwd_impl(const void* qs, int ldq, int lo_q, const float* mask_b
 
 int amdseg_sattn_bwd_impl(const void* qs, int ldq, int lo_q, const float* mask_bias, const float* ctx, const void* dos, int ldo, int lo_o,
                           const float* lse, float* delta, float* dqkv, int B, int L, int heads, float scale, float p, const void* keep, int window,
-                          int nglobal, hipStream_t s, const int* kend, const int* seq_order, const int* qguard) {
-    if (!qs || !mask_bias || !ctx || !dos || !lse || !delta || !dqkv) return AMDSEG_ERR_ARG;
+                          int nglobal, hipStream_t s, const int* kend, const int* seq_order, const int* qguard, void* dqs_image, int ldd) {
+    if (!qs || !mask_bias || !ctx || !dos || !lse || !delta || (!dqkv && !dqs_image)) return AMDSEG_ERR_ARG;
+    if (dqs_image && ldd < 9 * heads * HD) return AMDSEG_ERR_SHAPE;
     SAttnArgs a = {};
     int rc = sattn_fill(a, B, L, heads, scale, p, window, nglobal, keep);
     if (rc) return rc;
     a.qs = (const bf16_t*)qs; a.ldq = ldq; a.lo_q = lo_q; a.mask_bias = mask_bias; a.ctx = (float*)ctx; a.lse = (float*)lse;
-    a.dos = (const bf16_t*)dos; a.ldo = ldo; a.lo_o = lo_o; a.delta = delta; a.dqkv = dqkv;
+    a.dos = (const bf16_t*)dos; a.ldo = ldo; a.lo_o = lo_o; a.delta = delta; a.dqkv = dqs_image ? nullptr : dqkv;
+    a.dqs = (bf16_t*)dqs_image; a.ldd = ldd;
     a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order; a.qguard = (window > 0 || !kend) ? nullptr : qguard;
     const dim3 grid(L / 64, heads, B);
     if (window > 0) {

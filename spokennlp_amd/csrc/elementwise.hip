@@ -452,8 +452,10 @@ void amdseg_reduce_rows(const float* partials, int nblocks, int stride, int n, f
 // ------------------------------------------------------------------------------------------------ column sums
 // x[M, ld] (first N columns) -> partials[nblk][N]; block = 256 threads = 32 column-chunks(8) x 8 row lanes
 #define CS_ROWS 128
+// lo_off != 0: x is a split-bf16 image, the value of column c is x[c] + x[lo_off + c] ("parity" precision: bias gradients from the image the
+// backward already holds, no fp32 copy of the gradient)
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* x, int ld, float* partials, int M, int N) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, int ld, float* partials, int M, int N, int lo_off = 0) {
     __shared__ float red[8][256];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int col = (blockIdx.y * 32 + cx) * 8;
@@ -462,6 +464,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, int ld, float* 
         const int r1 = min(M, (int)(blockIdx.x + 1) * CS_ROWS);
         for (int r = blockIdx.x * CS_ROWS + ry; r < r1; r += 8) {
             float v[8]; ld8<T>(x + (size_t)r * ld + col, v);
+            if (lo_off) {
+                float u[8]; ld8<T>(x + (size_t)r * ld + lo_off + col, u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += u[e];
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += v[e];
         }
@@ -765,6 +772,15 @@ int amdseg_colsum_impl(const void* x, int ld, float* partials, float* out, int M
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, partials, M, N);
     else
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, partials, M, N);
+    launch_reduce(partials, nblk, N, 0, N, out, accumulate, s);
+    return amdseg_launch_status();
+}
+
+int amdseg_colsum_split_impl(const void* x, int ld, int lo_off, float* partials, float* out, int M, int N, int accumulate, hipStream_t s) {
+    if (!x || !partials || !out) return AMDSEG_ERR_ARG;
+    if (M <= 0 || N <= 0 || (N % 8) || (ld % 8) || (lo_off % 8) || lo_off <= 0) return AMDSEG_ERR_SHAPE;
+    const int nblk = (M + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nblk, (N + 255) / 256), dim3(256), 0, s, (const bf16_t*)x, ld, partials, M, N, lo_off);
     launch_reduce(partials, nblk, N, 0, N, out, accumulate, s);
     return amdseg_launch_status();
 }

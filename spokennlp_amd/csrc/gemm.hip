@@ -660,6 +660,10 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
         case EPI_GELU_BWD:
             if (!R || out_fp32 || (ldr % 8)) return AMDSEG_ERR_ARG;
             return act ? launch_nt<EPI_GELU_BWD_TANH, bf16_t>(a, stream) : launch_nt<EPI_GELU_BWD, bf16_t>(a, stream);
+        case 5:                                             // AMDSEG_EPI_BIAS_SPLIT: the 256 x 256 deep-pipeline kernel only
+            if (!bias || !C2 || out_fp32 || (ldc2 % 8)) return AMDSEG_ERR_ARG;
+            if ((M % 256) || (N % 256) || K < 128) return AMDSEG_ERR_SHAPE;
+            return amdseg_launch_nt_dp<EPI_BIAS_SPLIT, bf16_t>(a, stream);
     }
     return AMDSEG_ERR_ARG;
 }

@@ -139,14 +139,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     // ---- epilogue.  Lane owns row m = mf*16 + i16 and columns nf*16 + g*4 .. +4 of the wave tile.  bf16 results go through a
     // wave-private 16-KiB LDS image (2 x [64 rows][128 B], swizzled) so every global store instruction writes 8 full 128-B lines.
     float4 bv[NF];
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
             bv[nf] = *reinterpret_cast<const float4*>(a.bias + n0 + wc * WN + (NF == 4 ? (nf >> 1) * 32 + g * 8 + (nf & 1) * 4 : nf * 16 + g * 4));
     }
     // the bias goes INTO the accumulators once: recomputing acc + bias in both passes of BIAS_GELU made the compiler keep all
     // 128 sums of pass 0 alive for pass 1 (common subexpression) next to the 128 accumulators -> 116 spilled VGPRs
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT) {
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
@@ -169,6 +169,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * ep][r]; v[4 + r] = acc[mf][2 * ep + 1][r]; }
                 const size_t col = (size_t)(n0 + wc * 64 + ep * 32 + g * 8);
+                if (EPI == EPI_BIAS_SPLIT) {                   // x = hi + lo, both bf16: C <- hi, C2 <- lo (same row / column)
+                    uint4 hi; hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]); hi.z = pack2bf(v[4], v[5]); hi.w = pack2bf(v[6], v[7]);
+                    const uint32_t hw[4] = {hi.x, hi.y, hi.z, hi.w};
+                    uint4 lo;
+                    uint32_t lw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) lw[q] = pack2bf(v[2 * q] - __uint_as_float(hw[q] << 16), v[2 * q + 1] - __uint_as_float(hw[q] & 0xffff0000u));
+                    lo.x = lw[0]; lo.y = lw[1]; lo.z = lw[2]; lo.w = lw[3];
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + gm * a.ldc + col) = hi;
+                    *reinterpret_cast<uint4*>(a.C2 + gm * a.ldc2 + col) = lo;
+                    continue;
+                }
                 if (EPI == EPI_BIAS_GELU) {
                     if (a.C2) {
                         uint4 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
@@ -291,7 +303,7 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
 #define DP_INST(E, T) template int amdseg_launch_nt_dp<E, T>(const GemmNTArgs&, hipStream_t);
 DP_INST(EPI_NONE, bf16_t) DP_INST(EPI_NONE, float) DP_INST(EPI_BIAS, bf16_t) DP_INST(EPI_BIAS, float) DP_INST(EPI_BIAS_GELU, bf16_t)
 DP_INST(EPI_ADD_RES, bf16_t) DP_INST(EPI_ADD_RES, float) DP_INST(EPI_GELU_BWD, bf16_t)
-DP_INST(EPI_BIAS_GELU_TANH, bf16_t) DP_INST(EPI_GELU_BWD_TANH, bf16_t)
+DP_INST(EPI_BIAS_GELU_TANH, bf16_t) DP_INST(EPI_GELU_BWD_TANH, bf16_t) DP_INST(EPI_BIAS_SPLIT, bf16_t)
 
 
 // ==================================================================================================== gemm_tn, deep pipeline

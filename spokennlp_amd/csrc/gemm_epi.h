@@ -6,7 +6,9 @@
 #define GROUP_M 8
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_BWD = 4,
-       EPI_BIAS_GELU_TANH = 5, EPI_GELU_BWD_TANH = 6 };     // kernel template values only: the two GELU epilogues with gelu_new
+       EPI_BIAS_GELU_TANH = 5, EPI_GELU_BWD_TANH = 6,       // kernel template values only: the two GELU epilogues with gelu_new
+       EPI_BIAS_SPLIT = 7 };                                // C = bf16 hi of (A B^T + bias), C2 = bf16 lo = bf16(x - hi): the result as a split image
+                                                            // ("parity" precision: the consumer is another split-bf16 product), 256-wide dp kernel only
 // the kernels are instantiated on the extended value EPIX; EPI = what the epilogue does, ACT = which GELU (a compile-time constant:
 // a run-time flag became one scalar branch PER ELEMENT in the epilogue)
 #define EPI_BASE(X) ((X) == EPI_BIAS_GELU_TANH ? EPI_BIAS_GELU : (X) == EPI_GELU_BWD_TANH ? EPI_GELU_BWD : (X))

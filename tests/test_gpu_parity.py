@@ -54,6 +54,26 @@ def test_split_gemm_is_fp32_grade(dev):
     assert err < 2e-4 * ref.abs().max().item() / 10 and err < err_bf / 50
 
 
+def test_gemm_bias_split_epilogue_writes_the_split_image(dev):
+    """AMDSEG_EPI_BIAS_SPLIT: C <- bf16 hi, C2 <- bf16 lo of (A B^T + bias) -- what amdseg_split3 would make of the fp32 result, without the
+    fp32 round trip; the shapes the 256 x 256 kernel does not tile are refused (the caller then runs GEMM + split3)"""
+    from spokennlp_amd import lib as L, ops
+    torch.manual_seed(2)
+    M, N, K = 512, 768, 384
+    A = torch.randn(M, K, device=dev).bfloat16(); B = (torch.randn(N, K, device=dev) * 0.05).bfloat16(); bias = torch.randn(N, device=dev)
+    img = torch.zeros(M, 3 * N, dtype=torch.bfloat16, device=dev)
+    s_ = torch.cuda.current_stream().cuda_stream
+    rc = L.load().amdseg_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, img.data_ptr(), 3 * N, M, N, K, 5, bias.data_ptr(), None, 0,
+                                 img[:, 2 * N:].data_ptr(), 3 * N, 0, s_)
+    assert rc == 0
+    ref32 = ops.gemm_nt(A, B, ops.EPI_BIAS, bias=bias, out_dtype=torch.float32)
+    want = ops.split3(ref32, torch.empty(M, 3 * N, dtype=torch.bfloat16, device=dev), order=0)
+    assert torch.equal(img[:, :N], want[:, :N]) and torch.equal(img[:, 2 * N:], want[:, 2 * N:]) and float(img[:, N:2 * N].abs().max()) == 0.0
+    rc = L.load().amdseg_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, img.data_ptr(), 3 * N, 384, 128, K, 5, bias.data_ptr(), None, 0,
+                                 img[:, 2 * N:].data_ptr(), 3 * N, 0, s_)
+    assert rc == 1001                                       # AMDSEG_ERR_SHAPE
+
+
 def _attn_ref(qkv, mask_bias, B, Lq, heads):
     H = heads * 64
     q, k, v = [t.view(B, Lq, heads, 64).transpose(1, 2) for t in qkv.view(B, Lq, 3 * H).split(H, -1)]
