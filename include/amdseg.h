@@ -97,6 +97,9 @@ int amdseg_attn_bwd(const void* qkv, const float* mask_bias, const void* ctx, co
  * amdseg_bert_cfg.kend (chunks past it are not generated); keep == NULL or dropout_p == 0 falls back to the hash path.  Full attention only. */
 size_t amdseg_attn_keepmask_bytes(int B, int L, int heads);
 int amdseg_attn_keepmask(void* keep, int B, int L, int heads, float dropout_p, uint64_t seed, const int32_t* kend, amdseg_stream_t stream);
+/* the same for band attention (amdseg_sattn_* with window > 0): only the (64-query block, 64-key chunk) cells inside the band, plus chunk 0
+ * when nglobal > 0, are written (the buffer has the full-attention size) */
+int amdseg_attn_keepmask_band(void* keep, int B, int L, int heads, float dropout_p, uint64_t seed, int window, int nglobal, amdseg_stream_t stream);
 int amdseg_attn_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                          float dropout_p, const void* keep, amdseg_stream_t stream);
 int amdseg_attn_bwd_keep(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,

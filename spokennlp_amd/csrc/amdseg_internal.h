@@ -68,7 +68,8 @@ int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ct
                          int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,
                          const int* qguard = nullptr, const void* keep = nullptr);
 size_t amdseg_attn_keepmask_bytes_impl(int B, int L, int heads);
-int amdseg_attn_keepmask_impl(void* keep, int B, int L, int heads, float p, uint64_t seed, const int* kend, hipStream_t s);
+int amdseg_attn_keepmask_impl(void* keep, int B, int L, int heads, float p, uint64_t seed, const int* kend, hipStream_t s, int window = 0,
+                              int nglobal = 0);
 // attention_split.hip: "parity" precision attention on split-bf16 images (hi at column 0, lo at column lo_*) -- full and band
 int amdseg_sattn_fwd_impl(const void* qs, int ldq, int lo_q, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale,
                           float p, const void* keep, int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr);

@@ -55,6 +55,10 @@ size_t amdseg_attn_keepmask_bytes(int B, int L, int heads) { return amdseg_attn_
 int amdseg_attn_keepmask(void* keep, int B, int L, int heads, float dropout_p, uint64_t seed, const int32_t* kend, amdseg_stream_t stream) {
     return amdseg_attn_keepmask_impl(keep, B, L, heads, dropout_p, seed, kend, S(stream));
 }
+int amdseg_attn_keepmask_band(void* keep, int B, int L, int heads, float dropout_p, uint64_t seed, int window, int nglobal, amdseg_stream_t stream) {
+    if (window <= 0) return AMDSEG_ERR_ARG;
+    return amdseg_attn_keepmask_impl(keep, B, L, heads, dropout_p, seed, nullptr, S(stream), window, nglobal);
+}
 int amdseg_attn_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                          float dropout_p, const void* keep, amdseg_stream_t stream) {
     return amdseg_attn_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, dropout_p, 0, 0, 0, S(stream), nullptr, nullptr, keep);
@@ -284,7 +288,7 @@ static inline uint64_t site_seed(uint64_t seed, int layer, int site) {
 static int check_cfg(const amdseg_bert_cfg* c) {
     if (!c) return AMDSEG_ERR_ARG;
     if (c->dtype != AMDSEG_BF16 && c->dtype != AMDSEG_F32 && c->dtype != AMDSEG_F32S) return AMDSEG_ERR_ARG;
-    if (c->dtype == AMDSEG_F32S && (c->window != 0 || c->mixer != 0 || (c->nproj != 0 && c->nproj != 3))) return AMDSEG_ERR_ARG;
+    if (c->dtype == AMDSEG_F32S && (c->mixer != 0 || (c->nproj != 0 && c->nproj != 3))) return AMDSEG_ERR_ARG;   // (band: needs acts.qkv_s, checked there)
     if (c->H != c->heads * 64 || c->B <= 0 || c->L <= 0 || c->I <= 0) return AMDSEG_ERR_SHAPE;
     const long M = (long)c->B * c->L;
     if ((M % 128) || (c->H % 128) || (c->I % 128) || (c->L % 64)) return AMDSEG_ERR_SHAPE;
@@ -319,6 +323,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         if (PHASE1(c)) {
             RET_IF(amdseg_split3_impl(fx, H, a->xs, M, H, 0, s));
             const bool split_attn = a->qkv_s && (c->p_attn == 0.f || a->keep);
+            if (c->window > 0 && !split_attn) return AMDSEG_ERR_ARG;      // the fp32-MFMA kernels of parity.hip have no band form
             // the projection written straight as the split image the attention reads (hi block | unused | lo block), where the 256 x 256 GEMM tiles it
             const bool fused_qkv = split_attn && (M % 256) == 0 && ((3 * H) % 256) == 0;
             if (fused_qkv)
@@ -329,9 +334,10 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
             if (split_attn) {
                 // attention as split-bf16 products on the bf16 matrix cores (attention_split.hip); dropout from this layer's keep masks
                 if (!fused_qkv) RET_IF(amdseg_split3_impl((const float*)a->qkv, 3 * H, a->qkv_s, M, 3 * H, 0, s));
-                if (c->p_attn > 0.f) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s));
+                if (c->p_attn > 0.f) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s,
+                                                                      c->window, c->nglobal));
                 RET_IF(amdseg_sattn_fwd_impl(a->qkv_s, 9 * H, 6 * H, mask_bias, (float*)a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn,
-                                             c->p_attn > 0.f ? a->keep : nullptr, 0, 0, s, c->kend, c->seq_order));
+                                             c->p_attn > 0.f ? a->keep : nullptr, c->window, c->nglobal, s, c->kend, c->seq_order));
             } else
             RET_IF(amdseg_pattn_fwd_impl((const float*)a->qkv, mask_bias, (float*)a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                          site_seed(c->seed, li, 0), s, c->kend, c->seq_order));
@@ -435,10 +441,11 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
                 RET_IF(amdseg_split3_impl((const float*)w->dctx, H, w->dctx_s, M, H, 0, s));
                 // ... whose backward writes d(q|k|v) as the [hi | hi | lo] image the next GEMMs read; the bias gradient is summed from the image
                 RET_IF(amdseg_sattn_bwd_impl(a->qkv_s, 9 * H, 6 * H, mask_bias, (const float*)a->ctx, w->dctx_s, 3 * H, 2 * H, a->lse, w->delta,
-                                             nullptr, c->B, c->L, c->heads, 0.125f, c->p_attn, c->p_attn > 0.f ? a->keep : nullptr, 0, 0, s,
-                                             c->kend, c->seq_order, c->pad_guard, w->dqkv_s, 9 * H));
+                                             nullptr, c->B, c->L, c->heads, 0.125f, c->p_attn, c->p_attn > 0.f ? a->keep : nullptr, c->window,
+                                             c->nglobal, s, c->kend, c->seq_order, c->pad_guard, w->dqkv_s, 9 * H));
                 RET_IF(amdseg_colsum_split_impl(w->dqkv_s, 9 * H, 6 * H, part_bqkv, g->bqkv, M, 3 * H, acc, s));
             } else {
+            if (c->window > 0) return AMDSEG_ERR_ARG;
             RET_IF(amdseg_pattn_bwd_impl((const float*)a->qkv, mask_bias, (const float*)a->ctx, (const float*)w->dctx, a->lse, w->delta,
                                          (float*)w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0), s, c->kend, c->seq_order,
                                          c->pad_guard));

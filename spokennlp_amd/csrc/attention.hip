@@ -47,6 +47,7 @@ struct KeepMaskArgs {
     uint64_t* A; uint64_t* Bm;
     int B, L, heads; uint32_t thresh16; uint64_t seed;
     const int* kend;                        // optional [B]: chunks past the last unmasked key are never read by the consumers (attn_visible_chunks)
+    int window, nglobal;                    // band attention (window > 0): only the (query block, key chunk) cells its kernels visit are generated
     uint32_t tn[16];                        // per threshold bit i: 0 if bit i of thresh16 is set, ~0 otherwise (host-filled, see the kernel)
 };
 
@@ -70,6 +71,11 @@ __global__ __launch_bounds__(256) void attn_keepmask_kernel(KeepMaskArgs a) {
     for (int cc = 0; cc < KM_CG; ++cc) {
         const int chunk = grp * KM_CG + cc;
         if (chunk >= nvis) break;
+        if (a.window > 0) {                                 // the band around the query block, + chunk 0 when it holds global keys
+            const int q_lo = qblk * CH, q_hi = q_lo + CH - 1;
+            const bool in_band = chunk * CH + CH - 1 >= q_lo - a.window && chunk * CH <= q_hi + a.window;
+            if (!in_band && !(a.nglobal > 0 && chunk == 0)) continue;
+        }
         // keep <=> u >= thresh16 for a uniform 16-bit u, evaluated bit-serially from the lowest set bit of the threshold upwards on 64 lanes x
         // 64 independent u's at once: ge = t_i ? (u_i & ge) : (u_i | ge)
         // = majority(u_i, ge, tn_i) with tn_i = t_i ? 0 : ~0 -- ONE v_bitop3 per half and round.  tn comes from the kernel arguments (SGPRs):
@@ -803,14 +809,15 @@ static int attn_fill(AttnArgs& a, int B, int L, int heads, float scale, float p,
 size_t amdseg_attn_keepmask_bytes_impl(int B, int L, int heads) { return (size_t)B * heads * L * (size_t)L / 8 * 2; }
 
 // the keep masks of one attention layer and step (both layouts); the hash seed is the one the hash path would take
-int amdseg_attn_keepmask_impl(void* keep, int B, int L, int heads, float p, uint64_t seed, const int* kend, hipStream_t s) {
+int amdseg_attn_keepmask_impl(void* keep, int B, int L, int heads, float p, uint64_t seed, const int* kend, hipStream_t s, int window, int nglobal) {
     if (!keep) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, 0.125f, p, seed, 0, 0);
     if (rc) return rc;
     KeepMaskArgs k = {};
     k.A = (uint64_t*)keep; k.Bm = k.A + (size_t)B * heads * L * (size_t)L / 64;
-    k.B = B; k.L = L; k.heads = heads; k.thresh16 = a.thresh16; k.seed = seed; k.kend = kend;
+    k.B = B; k.L = L; k.heads = heads; k.thresh16 = a.thresh16; k.seed = seed; k.kend = window > 0 ? nullptr : kend;
+    k.window = window; k.nglobal = window > 0 ? nglobal : 0;
     for (int i = 0; i < 16; ++i) k.tn[i] = ((a.thresh16 >> i) & 1) ? 0u : 0xffffffffu;
     const int nblk = L / CH, ngrp = (nblk + KM_CG - 1) / KM_CG;
     const long waves = (long)B * heads * nblk * ngrp;

@@ -12,7 +12,7 @@
 // [0, 3H) and the lo parts at [lo_q, lo_q + 3H); dos [B*L][ldo] likewise for dO -- so K / V (Q / dO) tiles are staged hi and lo by the same
 // LDS-DMA as in attention.hip (4 tiles of [64][64] bf16 per stage instead of 2, two stages = 64 KiB); ctx, dqkv, lse, delta are fp32.
 // Structure, orientation (S^T = K Q^T ...), chunk skipping (kend / seq_order / qguard), band visibility and the keep-mask layouts are
-// those of attention.hip; dropout is read from the layer's keep masks only (no hash path here).
+// those of attention.hip; dropout is read from the layer's keep masks only (no hash path here; band: the cells its kernels visit).
 #include "attention_common.h"
 
 struct SAttnArgs {
@@ -591,7 +591,7 @@ static int sattn_fill(SAttnArgs& a, int B, int L, int heads, float scale, float 
     a.B = B; a.L = L; a.heads = heads; a.scale = scale; a.window = window; a.nglobal = window > 0 ? nglobal : 0;
     uint32_t th = (uint32_t)(p * 65536.0f + 0.5f);
     if (p > 0.f && th == 0) th = 1;
-    if (th && (!keep || window > 0)) return AMDSEG_ERR_ARG;   // dropout here is read from the layer's keep masks (amdseg_attn_keepmask: full attention)
+    if (th && !keep) return AMDSEG_ERR_ARG;                   // dropout here is read from the layer's keep masks (amdseg_attn_keepmask)
     a.thresh16 = th;
     a.inv_keep = th ? 65536.0f / (float)(65536u - th) : 1.0f;
     a.keepA = (const uint64_t*)keep; a.keepB = a.keepA ? a.keepA + (size_t)B * heads * L * (size_t)L / 64 : nullptr;
@@ -614,7 +614,8 @@ int amdseg_sattn_fwd_impl(const void* qs, int ldq, int lo_q, const float* mask_b
     a.qs = (const bf16_t*)qs; a.ldq = ldq; a.lo_q = lo_q; a.mask_bias = mask_bias; a.ctx = ctx; a.lse = lse;
     a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order;
     const dim3 grid(L / 64, heads, B);
-    if (window > 0) SA_LAUNCH((sattn_fwd_kernel<true, false>), grid);
+    if (window > 0 && a.thresh16) SA_LAUNCH((sattn_fwd_kernel<true, true>), grid);
+    else if (window > 0) SA_LAUNCH((sattn_fwd_kernel<true, false>), grid);
     else if (a.thresh16) SA_LAUNCH((sattn_fwd_kernel<false, true>), grid);
     else SA_LAUNCH((sattn_fwd_kernel<false, false>), grid);
     return amdseg_launch_status();
@@ -633,7 +634,10 @@ int amdseg_sattn_bwd_impl(const void* qs, int ldq, int lo_q, const float* mask_b
     a.dqs = (bf16_t*)dqs_image; a.ldd = ldd;
     a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order; a.qguard = (window > 0 || !kend) ? nullptr : qguard;
     const dim3 grid(L / 64, heads, B);
-    if (window > 0) {
+    if (window > 0 && a.thresh16) {
+        SA_LAUNCH((sattn_bwd_dq_kernel<true, true>), grid);
+        SA_LAUNCH((sattn_bwd_dkv_kernel<true, true>), dim3((L / 64) * heads * B));
+    } else if (window > 0) {
         SA_LAUNCH((sattn_bwd_dq_kernel<true, false>), grid);
         SA_LAUNCH((sattn_bwd_dkv_kernel<true, false>), dim3((L / 64) * heads * B));
     } else if (a.thresh16) {

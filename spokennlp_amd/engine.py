@@ -327,6 +327,7 @@ class BertEncoderEngine:
 
     # ---- "parity" precision: split-bf16 weight images (csrc/parity.hip), built on first use and refreshed with the bf16 copies
     supports_parity = True
+    parity_needs_split_attn = False                         # band attention exists in split-bf16 form only (no fp32-MFMA fallback)
 
     def _parity_weights(self):
         if getattr(self, "_parity", None) is None:
@@ -452,11 +453,11 @@ class BertEncoderEngine:
         # "parity" precision: attention as split-bf16 products (csrc/attention_split.hip) needs the split image of q|k|v per layer;
         # AMDSEG_PATTN_F32=1 keeps the fp32-MFMA attention of csrc/parity.hip
         import os as _os2
-        split_attn = parity and self.attn_keepmask and _os2.environ.get("AMDSEG_PATTN_F32", "0") != "1"
+        split_attn = parity and (self.parity_needs_split_attn or _os2.environ.get("AMDSEG_PATTN_F32", "0") != "1")
         if split_attn:
             for la in A["layers"]:
                 la["qkv_s"] = e(M, 9 * H, dt=torch.bfloat16)
-        if train and (not fp32 or split_attn) and self.attn_keepmask and float(self.cfg.attention_probs_dropout_prob) > 0:
+        if train and float(self.cfg.attention_probs_dropout_prob) > 0 and ((not fp32 and self.attn_keepmask) or split_attn):
             nbytes = L.load().amdseg_attn_keepmask_bytes(B, Lseq, self.heads)
             for la in A["layers"]:
                 la["keep"] = e(nbytes, dt=torch.uint8)

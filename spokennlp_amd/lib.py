@@ -58,6 +58,7 @@ _PROTOS = {
     "amdseg_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_attn_keepmask_bytes": [i32, i32, i32],
     "amdseg_attn_keepmask": [vp, i32, i32, i32, f32, u64, vp, vp],
+    "amdseg_attn_keepmask_band": [vp, i32, i32, i32, f32, u64, i32, i32, vp],
     "amdseg_attn_fwd_keep": [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],
     "amdseg_attn_bwd_keep": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],
     "amdseg_sattn_fwd": [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],

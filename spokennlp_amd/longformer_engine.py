@@ -21,7 +21,10 @@ GLOBAL_SUFFIXES = ("query_global", "key_global", "value_global")
 
 
 class LongformerEncoderEngine(BertEncoderEngine):
-    supports_parity = False
+    # "parity" precision (fp32 activations, split-bf16 contractions): the projections as in the BERT engine, the band attention on the
+    # split-bf16 kernels of csrc/attention_split.hip, the global row in fp32 (its O(L) passes take fp32 rows)
+    supports_parity = True
+    parity_needs_split_attn = True
     def __init__(self, module, config, device, bert_attr="longformer"):
         super().__init__(module, config, device, bert_attr=bert_attr)
         aw = config.attention_window
@@ -116,8 +119,10 @@ class LongformerEncoderEngine(BertEncoderEngine):
             cfg.window, cfg.nglobal, cfg.phase = self.windows[i], 0, 0
             return super()._layer_backward(lib, cfg, A, i, mb, dy, other, s, saved)
         cfg.window, cfg.nglobal = self.windows[i], 1
-        args = (C.byref(cfg), C.byref(self.lparams[i]), C.byref(self.lgrads[i]), C.byref(A["acts_struct"][i]), C.byref(A["ws_struct"]),
+        lp = self.lparams_parity[i] if cfg.dtype == L.F32S else self.lparams[i]
+        args = (C.byref(cfg), C.byref(lp), C.byref(self.lgrads[i]), C.byref(A["acts_struct"][i]), C.byref(A["ws_struct"]),
                 mb, dy.data_ptr(), other.data_ptr(), i, s)
+        adt = L.F32 if cfg.dtype == L.F32S else L.BF16          # dtype of activations and activation gradients
         cfg.phase = 1
         L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].1")
         x_in = A["x"][i]
@@ -134,7 +139,7 @@ class LongformerEncoderEngine(BertEncoderEngine):
             dout, dyv, dsp = torch.empty(B, heads, 64, **f32), torch.empty(B, heads, H, **f32), torch.empty(B, heads, **f32)
             # consumes + zeroes dctx[:, 0] (the band attention's own row 0 was overwritten in forward: no gradient); on the main stream:
             # the attention backward below reads dctx
-            L.check(lib.amdseg_lf_global_bwd_a(dctx.data_ptr(), L.BF16, Wv.data_ptr(), bv.data_ptr(), dout.data_ptr(), dyv.data_ptr(),
+            L.check(lib.amdseg_lf_global_bwd_a(dctx.data_ptr(), adt, Wv.data_ptr(), bv.data_ptr(), dout.data_ptr(), dyv.data_ptr(),
                                                dsp.data_ptr(), B, Lseq, H, heads, s), "amdseg_lf_global_bwd_a")
         if side is not main:
             e1 = torch.cuda.Event(); e1.record(main); side.wait_event(e1)
@@ -150,7 +155,7 @@ class LongformerEncoderEngine(BertEncoderEngine):
             ops.lf_dx_update(other, pd, dyv, ds, r, A["lf_vt"])
             dqg = torch.empty(B, H, **f32)
             g = lambda which, kind: self._gp(fg, i, which, kind).data_ptr()          # noqa: E731
-            L.check(lib.amdseg_lf_global_bwd_rest(x_in.data_ptr(), L.BF16, other.data_ptr(), L.BF16, Wq.data_ptr(), Wk.data_ptr(),
+            L.check(lib.amdseg_lf_global_bwd_rest(x_in.data_ptr(), adt, other.data_ptr(), adt, Wq.data_ptr(), Wk.data_ptr(),
                                                   qg.data_ptr(), dout.data_ptr(), y.data_ptr(), sp.data_ptr(), dr.data_ptr(), dqg.data_ptr(),
                                                   g("query_global", "weight"), g("query_global", "bias"), g("key_global", "weight"),
                                                   g("value_global", "weight"), g("value_global", "bias"), B, Lseq, H, heads, self.scale,

@@ -331,6 +331,54 @@ def test_bigbird_base_eval_vs_reference_golden(dev, precision):
     assert abs(loss.item() - float(z["full_eval.loss"])) < 0.01 * abs(float(z["full_eval.loss"])) + 0.05
 
 
+def test_longformer_base_L4096_train_step_parity_precision_vs_reference_golden(dev):
+    """the same step in "parity" precision (fp32 activations, split-bf16 contractions incl. the band attention): the reference's loss to 1e-3
+    relative, every gradient norm to 1e-3, the stored first / last layer gradients (biases, LayerNorm, *_global) to 1e-3 relative"""
+    import numpy as np
+    from tests.util import longformer_state_dict
+    from tests.test_oracle_golden import flags_of
+    from tests.test_gpu_longformer import build_lf
+    z = np.load(os.path.join(ROOT, "tests", "golden", "longformer_base_L4096.npz"), allow_pickle=False)
+    arch = dict(zip(z["arch_keys"].tolist(), [float(v) if "eps" in k else int(float(v)) for k, v in zip(z["arch_keys"].tolist(), z["arch_vals"].tolist())]))
+    arch.pop("layer_norm_eps")
+    sd = longformer_state_dict(arch, seed=int(z["seed"]), std=float(z["std"]))
+    arch["attention_window"] = [int(v) for v in z["attention_window"]]
+    batch = {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("in.")}
+    m = build_lf(arch, flags_of(z, "train_full"), sd, dev, precision="parity").train()
+    random.seed(int(z["train_full.random_seed"]))
+    loss, logits, cos = m(**batch)
+    loss.backward()
+    ref_loss = float(z["train_full.loss"])
+    assert abs(loss.item() - ref_loss) < 1e-3 * abs(ref_loss)
+    lab = (batch["labels"][:, 0] != -100).cpu()
+    ref_lab = torch.from_numpy(z["train_full.logits_anchor_labelled"])
+    dl = (logits.detach().float().cpu()[:, 0][lab] - ref_lab).abs().max().item()
+    assert dl < 1e-3
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for n, v in zip(z["train_full.gradnorm_names"].tolist(), z["train_full.gradnorm_vals"].tolist()):
+        if v <= 1e-6:
+            continue
+        gn = float(params[n].grad.float().norm())
+        worst = max(worst, abs(gn - v) / v)
+        assert abs(gn - v) / v < 1e-3, (n, gn, v)
+    worst_rel, checked = 0.0, 0
+    for k in z.files:
+        if k.startswith("train_full.grad."):
+            n = k[len("train_full.grad."):]
+            ref = torch.from_numpy(z[k])
+            if float(ref.norm()) < 1e-6:
+                continue
+            rel = float((params[n].grad.float().cpu() - ref).norm() / ref.norm())
+            # q / k bias gradients: near-cancelling sums over 4096 tokens (softmax is invariant to a key bias)
+            bound = 1e-2 if ("self.query.bias" in n or "self.key.bias" in n or "query_global.bias" in n or "key_global.bias" in n) else 1e-3
+            assert rel < bound, (n, rel)
+            worst_rel = max(worst_rel, rel); checked += 1
+    print(f"longformer-base L=4096 parity train: loss {loss.item():.5f} vs {ref_loss:.5f}, max|dlogit| {dl:.2e}, worst grad-norm deviation "
+          f"{worst:.2e}, worst relative error of {checked} stored gradients {worst_rel:.2e}")
+    assert checked >= 20
+
+
 def test_longformer_base_L4096_train_step_vs_reference_golden(dev):
     """BASELINE config 5 is a TRAINING configuration: one train-mode step (dropout 0) of longformer-base-4096 (window 512, [CLS] global)
     at L = 4096 against the REFERENCE's loss, every parameter's gradient norm, and the bias / LayerNorm / *_global gradients of the
