@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 6   /* 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 6   /* 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -224,6 +224,14 @@ int amdseg_cast_transpose(const float* W, void* Wb, void* Wt, int N, int K, amds
  * bf16 copies Wb are the INPUT (amdseg_adamw wrote them through its `shadow` argument) and only the transposes Wt are written */
 int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                   amdseg_stream_t stream);
+/* "were these weights written behind the library's back?", answered on the device.  amdseg_weights_changed: 64-bit content checksum of
+ * x[0 .. nbytes) (nbytes % 16 == 0) against the one taken by the previous call; *changed = 1 if it differs (always on the first call);
+ * state = 16 bytes of zero-initialised device memory owned by the caller, one per buffer.  amdseg_cast_transpose_batched_if: the batched
+ * refresh as a no-op when *only_if == 0.  Together: an inference forward re-derives the bf16 compute copies after ANY write to the fp32
+ * masters (`p.data.copy_`, raw pointers), at ~80 us per 340 MB instead of a host read or a manual `mark_weights_dirty()`. */
+int amdseg_weights_changed(const void* x, size_t nbytes, void* state, int32_t* changed, amdseg_stream_t stream);
+int amdseg_cast_transpose_batched_if(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
+                                     const int32_t* only_if, amdseg_stream_t stream);
 /* Block-list attention = BigBird block-sparse attention ([hf] models/big_bird/modeling_big_bird.py
  * BigBirdBlockSparseAttention.bigbird_block_sparse_attention, reached from the reference through
  * emnlp2023-topic_segmentation/src/models/bigbird_for_ts.py:27 BigBirdModel).  qkv/ctx/lse/mask_bias as amdseg_attn_fwd (bf16,

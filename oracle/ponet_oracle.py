@@ -59,8 +59,23 @@ def segment_max_runs(hs, valid, segment_ids, ninf):
     return torch.stack(out)
 
 
-def pooling(hq, hk, ho, hl, hs, valid, segment_ids, nh, runs=False):
-    """the token-mixing block on the five projections ([B, L, H] each); valid [B, L] bool; returns ctx [B, L, H]"""
+def special_positions(valid):
+    """[B, L] bool: position 0 ([CLS]) and the last valid position ([SEP]) of every sequence"""
+    B, L = valid.shape
+    sp = torch.zeros_like(valid)
+    sp[:, 0] = True
+    last = (valid.long() * torch.arange(1, L + 1)[None, :]).amax(1) - 1
+    for b in range(B):
+        if last[b] >= 0:
+            sp[b, last[b]] = True
+    return sp & valid
+
+
+def pooling(hq, hk, ho, hl, hs, valid, segment_ids, nh, runs=False, pool_valid=None):
+    """the token-mixing block on the five projections ([B, L, H] each); valid [B, L] bool; returns ctx [B, L, H].
+    pool_valid (config.ponet_special_tokens_mixing = False): the tokens that take part in the pooling branches -- [CLS] / [SEP] then enter
+    no local or segment window and get no mixing output (ctx = 0, residual path only), while still being keys of the global aggregation.
+    One of the two readings of the unavailable original; a user holding the checkpoint picks the one that reproduces it."""
     B, L, H = hq.shape
     d = H // nh
     vf = valid.to(hq.dtype)
@@ -70,6 +85,8 @@ def pooling(hq, hk, ho, hl, hs, valid, segment_ids, nh, runs=False):
     a = a.masked_fill(~valid[:, None, :], float("-inf"))
     p = torch.softmax(a.float(), dim=-1).to(hq.dtype)
     g = torch.einsum("bhj,bjhe->bhe", p, hk.view(B, L, nh, d)).reshape(B, 1, H)
+    if pool_valid is not None:
+        valid = pool_valid
     ninf = torch.finfo(hq.dtype).min
     # segment max over valid tokens with the same id
     if runs:
@@ -92,7 +109,8 @@ def encoder_layer(sd, cfg, x, valid, segment_ids, i, prefix=PFX, runs=False):
         return t @ sd[p + name + ".weight"].t() + sd[p + name + ".bias"]
 
     hq, hk, ho, hl, hs = [lin(x, "attention.self." + n) for n in PROJ]
-    ctx = pooling(hq, hk, ho, hl, hs, valid, segment_ids, cfg.num_attention_heads, runs=runs)
+    pv = None if cfg.get("ponet_special_tokens_mixing", True) else (valid & ~special_positions(valid))
+    ctx = pooling(hq, hk, ho, hl, hs, valid, segment_ids, cfg.num_attention_heads, runs=runs, pool_valid=pv)
     x1 = layer_norm(lin(ctx, "attention.output.dense") + x, sd[p + "attention.output.LayerNorm.weight"],
                     sd[p + "attention.output.LayerNorm.bias"], cfg.layer_norm_eps)
     h = gelu_erf(lin(x1, "intermediate.dense"))

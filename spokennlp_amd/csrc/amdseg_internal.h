@@ -54,7 +54,8 @@ int amdseg_attn_list_bwd_impl(const void* qkv, const float* mask_bias, const voi
                               float* delta, void* dqkv, int B, int L, int heads, float scale, const int* klist, const int* kcnt,
                               const int* qlist, const int* qcnt, int list_stride, const int* korder, const int* qorder, hipStream_t s);
 int amdseg_cast_transpose_batched_impl(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
-                                       hipStream_t s);
+                                       hipStream_t s, const int* only_if = nullptr);
+int amdseg_weights_changed_impl(const void* x, size_t nbytes, void* state, int* changed, hipStream_t s);
 int amdseg_pad_plan_impl(const int64_t* mask, int B, int L, int* kend, int* seq_order, int* runs, int* counts, float* mask_bias, float bias,
                          hipStream_t s);
 int amdseg_pad_rows_guard_impl(const float* x, const int* kend, int B, int L, int H, int* guard, hipStream_t s);

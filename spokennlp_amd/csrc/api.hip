@@ -188,6 +188,13 @@ int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb,
                                   amdseg_stream_t stream) {
     return amdseg_cast_transpose_batched_impl(n, W, Wb, Wt, N, K, S(stream));
 }
+int amdseg_cast_transpose_batched_if(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
+                                     const int32_t* only_if, amdseg_stream_t stream) {
+    return amdseg_cast_transpose_batched_impl(n, W, Wb, Wt, N, K, S(stream), only_if);
+}
+int amdseg_weights_changed(const void* x, size_t nbytes, void* state, int32_t* changed, amdseg_stream_t stream) {
+    return amdseg_weights_changed_impl(x, nbytes, state, changed, S(stream));
+}
 int amdseg_attn_list_fwd(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                          const int* klist, const int* kcnt, int list_stride, const int* korder, amdseg_stream_t stream) {
     return amdseg_attn_list_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, klist, kcnt, list_stride, korder, S(stream));

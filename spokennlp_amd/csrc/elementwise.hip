@@ -531,9 +531,11 @@ struct CastTransposeBatch {
     const float* W[CT_MAXB]; bf16_t* Wb[CT_MAXB]; bf16_t* Wt[CT_MAXB];
     int N[CT_MAXB], K[CT_MAXB], tile0[CT_MAXB + 1];      // tile0: prefix sum of (N/64)*(K/64)
     int n;
+    const int* only_if;                                  // optional device flag: the launch does nothing when *only_if == 0
 };
 __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(CastTransposeBatch b) {
     __shared__ bf16_t tile[64][66];
+    if (b.only_if && *b.only_if == 0) return;
     int m = 0;
     while (m + 1 < b.n && (int)blockIdx.x >= b.tile0[m + 1]) ++m;
     const float* W = b.W[m]; bf16_t* Wb = b.Wb[m]; bf16_t* Wt = b.Wt[m];
@@ -895,8 +897,36 @@ int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K,
     return amdseg_launch_status();
 }
 
+// 64-bit content checksum of a buffer (sum over 32-bit words of word * odd position weight; integer atomics: exact, order independent) and the
+// comparison with the one taken last time -- "were these weights written since the bf16 copies were made?" answered on the device, no host read
+__global__ __launch_bounds__(256) void checksum_u64_kernel(const uint4* __restrict__ x, size_t n16, unsigned long long* state) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = x[i];
+        const unsigned long long w = (unsigned long long)(((uint32_t)i * 2654435761u) | 1u);
+        acc += (unsigned long long)v.x * w + (unsigned long long)v.y * (w + 2) + (unsigned long long)v.z * (w + 4) + (unsigned long long)v.w * (w + 6);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(state, acc);
+}
+__global__ void checksum_compare_kernel(unsigned long long* state, int* changed) {
+    *changed = state[0] != state[1] ? 1 : 0;
+    state[1] = state[0];
+    state[0] = 0ull;
+}
+int amdseg_weights_changed_impl(const void* x, size_t nbytes, void* state, int* changed, hipStream_t s) {
+    if (!x || !state || !changed) return AMDSEG_ERR_ARG;
+    if (nbytes == 0 || (nbytes % 16) || ((uintptr_t)x % 16)) return AMDSEG_ERR_SHAPE;
+    const size_t n16 = nbytes / 16;
+    const unsigned grid = (unsigned)((n16 + 255) / 256 > 2048 ? 2048 : (n16 + 255) / 256);
+    hipLaunchKernelGGL(checksum_u64_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)x, n16, (unsigned long long*)state);
+    hipLaunchKernelGGL(checksum_compare_kernel, dim3(1), dim3(1), 0, s, (unsigned long long*)state, changed);
+    return amdseg_launch_status();
+}
+
 int amdseg_cast_transpose_batched_impl(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
-                                       hipStream_t s) {
+                                       hipStream_t s, const int* only_if) {
     if (n <= 0 || !N || !K || (!Wb && !Wt) || (!W && !(Wb && Wt))) return AMDSEG_ERR_ARG;      // W == NULL: Wb is the input, Wt the output
     for (int base = 0; base < n; base += CT_MAXB) {
         CastTransposeBatch b = {};
@@ -910,6 +940,7 @@ int amdseg_cast_transpose_batched_impl(int n, const float* const* W, void* const
             tiles += (N[j] / 64) * (K[j] / 64);
         }
         b.tile0[b.n] = tiles;
+        b.only_if = only_if;
         hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3(tiles), dim3(256), 0, s, b);
     }
     return amdseg_launch_status();

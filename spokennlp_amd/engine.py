@@ -174,6 +174,8 @@ class BertEncoderEngine:
         # incoming gradient (amdseg_bert_cfg.pad_guard).  Every encoder family (the argument per mixer: DESIGN.md section 8); AMDSEG_PAD_ROWS_DENSE=1 = off
         self.skip_padded_rows_bwd = self.skip_padded_chunks and _os.environ.get("AMDSEG_PAD_ROWS_DENSE", "0") != "1"
         self._pad_guard = None
+        self.eval_weight_check = _os.environ.get("AMDSEG_EVAL_WEIGHT_CHECK", "1") != "0"
+        self._ck_state = None
         # attention-probability dropout decided once per layer (amdseg_attn_keepmask, acts.keep) instead of hashed per element in three kernels;
         # full softmax attention only (the band / list / pooling engines switch it off); AMDSEG_ATTN_HASH=1 keeps the hash path
         self.attn_keepmask = _os.environ.get("AMDSEG_ATTN_HASH", "0") != "1"
@@ -376,7 +378,7 @@ class BertEncoderEngine:
         The engine's fused AdamW refreshes explicitly (force) right after its pass."""
         ver = self._weights_version()
         if not force and not self._dirty and ver == self._shadow_version:
-            return
+            return False
         self._dirty = False
         if self._ct_table is None:
             Ws, Wbs, Wts, Ns, Ks = [], [], [], [], []
@@ -400,6 +402,33 @@ class BertEncoderEngine:
         if getattr(self, "_parity", None) is not None:
             self._split_parity_weights()
         self._shadow_version = self._weights_version()
+        return True
+
+    def _check_unseen_writes(self, parity):
+        """inference forwards: writes to the fp32 masters that none of refresh_shadows' detectors can see (`p.data.copy_(...)` between two
+        eval forwards, raw pointers) are found by a 64-bit content checksum of the encoder's parameter region taken ON THE DEVICE
+        (amdseg_weights_changed, ~80 us for bert-base) and the bf16 copies / transposes are re-derived by a refresh that is a no-op when
+        nothing changed (amdseg_cast_transpose_batched_if) -- no host read, no `mark_weights_dirty()` needed.  "parity" precision re-splits its
+        weight images on the host's say-so, so there the flag is read back (one sync per inference forward of that slower mode).
+        AMDSEG_EVAL_WEIGHT_CHECK=0 switches the check off."""
+        if not self.eval_weight_check or self._ct_table is None:
+            return
+        fp = self.fp
+        if self._ck_state is None:
+            self._ck_state = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self._ck_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+            first = min(fp.offsets[n] for n in fp.offsets if n.startswith(fp.encoder_prefix))
+            self._ck_region = (fp.flat_p.data_ptr() + 4 * first, 4 * (fp.numel - first))
+        s = torch.cuda.current_stream().cuda_stream
+        lib = L.load()
+        L.check(lib.amdseg_weights_changed(self._ck_region[0], self._ck_region[1], self._ck_state.data_ptr(), self._ck_flag.data_ptr(), s),
+                "amdseg_weights_changed")
+        if parity:
+            if int(self._ck_flag.item()):
+                self.refresh_shadows(force=True)
+            return
+        n, pw, pb, pt, pn, pk = self._ct_table
+        L.check(lib.amdseg_cast_transpose_batched_if(n, pw, pb, pt, pn, pk, self._ck_flag.data_ptr(), s), "amdseg_cast_transpose_batched_if")
 
     # ------------------------------------------------------------------------------------------------ arenas
     def _acquire_arena(self, B, Lseq, train, fp32=False):
@@ -525,7 +554,9 @@ class BertEncoderEngine:
         if fp32 == "parity":
             self._parity_weights()
         if fp32 is not True:
-            self.refresh_shadows()
+            refreshed = self.refresh_shadows()
+            if not train and not refreshed:
+                self._check_unseen_writes(fp32 == "parity")
             if train and not self._fused_owner:
                 self._dirty = True                          # an unknown optimiser is expected to write the weights after this step
         A = self._acquire_arena(B, Lseq, train, fp32)

@@ -88,6 +88,8 @@ _PROTOS = {
     "amdseg_cast": [vp, vp, sz, i32, i32, vp],
     "amdseg_cast_transpose": [vp, vp, vp, i32, i32, vp],
     "amdseg_cast_transpose_batched": [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp],
+    "amdseg_cast_transpose_batched_if": [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp, vp],
+    "amdseg_weights_changed": [vp, sz, vp, vp, vp],
     "amdseg_attn_list_f32": [vp, vp, vp, i32, i32, i32, f32, vp, vp, i32, vp],
     "amdseg_attn_list_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, i32, vp, vp],
     "amdseg_attn_list_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp, vp, vp],

@@ -133,12 +133,22 @@ class PoNetEncoderEngine(BertEncoderEngine):
             valid = (attention_mask == 1).to(torch.float32)
             self._run = (rs.to(torch.int32).reshape(-1).contiguous(), re.to(torch.int32).reshape(-1).contiguous())
             from .engine import MASK_BIAS
-            mb = ((1.0 - valid) * MASK_BIAS).reshape(-1).contiguous()
+            pool_valid = valid
+            if not getattr(self.cfg, "ponet_special_tokens_mixing", True):
+                # the other reading of the unavailable original (oracle/ponet_oracle.py `pool_valid`): [CLS] (position 0) and [SEP] (the last
+                # valid token) enter no local / segment pooling window and get no mixing output; they stay keys of the global aggregation
+                pool_valid = valid.clone()
+                pool_valid[:, 0] = 0.0
+                last = ((valid > 0).long() * torch.arange(1, Lseq + 1, device=valid.device)[None, :]).amax(1) - 1
+                rows = torch.arange(B, device=valid.device)[last >= 0]
+                pool_valid[rows, last[last >= 0]] = 0.0
+            mb = ((1.0 - pool_valid) * MASK_BIAS).reshape(-1).contiguous()
+            self._pool_mb = mb.view(B, Lseq)
             self._work = ops.ponet_plan(mb, self._run[0], B, Lseq)           # work lists of the pooling kernels, once per batch
             self._valid = valid.view(B, 1, Lseq).contiguous()
             self._coef_mean = (valid / valid.sum(1, keepdim=True).clamp(min=1.0)).view(B, 1, Lseq).contiguous()
         out, ctx = super().forward(input_ids, attention_mask, token_type_ids, train, seed, p_out)
-        ctx["pn"] = dict(run=self._run, valid=self._valid, coef_mean=self._coef_mean, work=self._work)
+        ctx["pn"] = dict(run=self._run, valid=self._valid, coef_mean=self._coef_mean, work=self._work, pool_mb=self._pool_mb)
         return out, ctx
 
     def _views(self, proj, H):
@@ -162,7 +172,7 @@ class PoNetEncoderEngine(BertEncoderEngine):
             p, pd, _sp = ops.lf_softmax_fwd(scores, cfg.p_attn, seed)
             y = ops.lf_wsum(hk, pd, H, pn["lf_partials"])                                      # [B, heads, H]
             g = (y * self.headmask.unsqueeze(0)).sum(1).contiguous()                           # [B, H]
-            ops.ponet_pool_fwd(la["qkv"], A["mask_bias"], rs, re, self._work, g, pn["part"][li], pn["parg"][li], la["ctx"], B, Lseq, H)
+            ops.ponet_pool_fwd(la["qkv"], self._pool_mb, rs, re, self._work, g, pn["part"][li], pn["parg"][li], la["ctx"], B, Lseq, H)
         cfg.phase = 2
         L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].2")
         cfg.phase = 0
@@ -182,7 +192,7 @@ class PoNetEncoderEngine(BertEncoderEngine):
         rs, re = self._run
         vecq, p, g = saved["vecq"], saved["p"], saved["g"]
         with torch.no_grad():
-            dg = ops.ponet_pool_bwd(proj, A["mask_bias"], rs, re, self._work, g, pn["part"][i], pn["parg"][i], ws["dctx"], dproj, pn["psum"],
+            dg = ops.ponet_pool_bwd(proj, self._pool_mb, rs, re, self._work, g, pn["part"][i], pn["parg"][i], ws["dctx"], dproj, pn["psum"],
                                     B, Lseq, H).view(B, 1, H)                                  # sum of dctx * Ho over the valid tokens
             dgh = (dg * self.headmask.unsqueeze(0)).contiguous()                              # [B, heads, H]
             dpd = ops.lf_rowvec_dot(hk, dgh, B, Lseq)
@@ -235,7 +245,7 @@ class _PoNetEncoderFn(torch.autograd.Function):
             full[:B, :Lq] = dseq
             dseq = full
         eng, pn = ctx.engine, ctx.ectx["pn"]
-        eng._run, eng._valid, eng._coef_mean, eng._work = pn["run"], pn["valid"], pn["coef_mean"], pn["work"]
+        eng._run, eng._valid, eng._coef_mean, eng._work, eng._pool_mb = pn["run"], pn["valid"], pn["coef_mean"], pn["work"], pn["pool_mb"]
         if ctx.nparams:
             grads = eng.compat_backward(lambda: eng.backward(ctx.ectx, dseq, accumulate=True))
             return (torch.zeros(1, device=dseq.device),) + (None,) * 8 + grads

@@ -195,6 +195,48 @@ def test_model_vs_oracle(dev, L, long_run):
     assert (lg - logits.detach()).abs().max().item() < 1e-3
 
 
+def test_special_tokens_mixing_switch_vs_oracle(dev):
+    """config.ponet_special_tokens_mixing = False (the other reading of the unavailable original: [CLS] / [SEP] enter no pooling window and
+    get no mixing output): the HIP path follows the oracle's statement of that variant, and it is a different function from the default"""
+    from oracle import ponet_oracle as PO
+    from oracle import bert_ts_oracle as O
+    m, cfg = build(dev)
+    sd = {k: v.detach().clone().float() for k, v in m.state_dict().items()}
+    ids, am, seg, lab = make_inputs(2, 128, 13, True)
+    outs = {}
+    for flag in (True, False):
+        ocfg = O.make_cfg(num_labels=2, ponet_special_tokens_mixing=flag, **ARCH)
+        with torch.no_grad():
+            _, logits_o = PO.token_classification_forward(sd, ocfg, ids, am, torch.zeros_like(ids), seg, lab)
+        m.config.ponet_special_tokens_mixing = flag
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            lg = m(input_ids=ids.to(dev), attention_mask=am.to(dev), segment_ids=seg.to(dev), return_dict=True).logits.float().cpu()
+        valid = am == 1
+        d = (lg - logits_o).abs()[valid].max().item()
+        assert d < 0.02 * logits_o.abs().max().item() + 0.05, (flag, d)
+        outs[flag] = logits_o
+    assert (outs[True] - outs[False]).abs().max().item() > 0.1          # the switch changes the function
+    # ... and a training step in the variant: gradients against the oracle's autograd
+    m.config.ponet_special_tokens_mixing = False
+    sdg = {k: v.detach().cpu().clone().float().requires_grad_(True) for k, v in m.state_dict().items()}
+    ocfg = O.make_cfg(num_labels=2, ponet_special_tokens_mixing=False, **ARCH)
+    loss_o, _ = PO.token_classification_forward(sdg, ocfg, ids, am, torch.zeros_like(ids), seg, lab)
+    loss_o.backward()
+    m.train()
+    loss = m(input_ids=ids.to(dev), attention_mask=am.to(dev), token_type_ids=torch.zeros_like(ids).to(dev), segment_ids=seg.to(dev),
+             labels=lab.to(dev), return_dict=False)[0]
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) < 0.03
+    for n, p in m.named_parameters():
+        go = sdg[n].grad
+        if go is None or float(go.norm()) < 1e-6:
+            continue
+        c = torch.nn.functional.cosine_similarity(p.grad.float().cpu().flatten(), go.flatten(), dim=0).item()
+        assert c > 0.98, (n, c)
+    m.config.ponet_special_tokens_mixing = True
+
+
 def test_dropout_step_deterministic(dev):
     vals = []
     ids, am, seg, lab = make_inputs(2, 64, 5)
