@@ -374,18 +374,34 @@ __global__ __launch_bounds__(256) void lf_dx_update_mfma_kernel(bf16_t* __restri
         fc[t] = pk.q;
     }
     const bf16_t* vp = vt + ((size_t)b * H + i16) * 32 + g * 8;
-    for (int ct = 0; ct < H / 16; ++ct) {
-        const bf16x8 fv = *reinterpret_cast<const bf16x8*>(vp + (size_t)ct * 16 * 32);
+    // the 16-column tiles of a row are dealt over gridDim.z workgroups and walked four at a time with their loads issued together: one wave
+    // walking all H / 16 = 48 tiles as dependent load -> MFMA -> store trips took 44 us whatever M was (64 workgroups at M = 8192)
+    const int nct = H / 16, per = (nct + gridDim.z - 1) / gridDim.z;
+    const int ct0 = blockIdx.z * per, ct1 = min(nct, ct0 + per);
+    for (int cb = ct0; cb < ct1; cb += 4) {
+        bf16x8 fv[4];
+        uint2 old[4][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fc[t], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            bf16_t* xp = dx + ((size_t)b * L + j0 + t * 16 + i16) * ldx + ct * 16 + g * 4;
-            uint2 old = make_uint2(0u, 0u);
-            if (!assign) old = *reinterpret_cast<const uint2*>(xp);
-            uint2 nw;
-            nw.x = pack2bf(__uint_as_float(old.x << 16) + d[0], __uint_as_float(old.x & 0xffff0000u) + d[1]);
-            nw.y = pack2bf(__uint_as_float(old.y << 16) + d[2], __uint_as_float(old.y & 0xffff0000u) + d[3]);
-            *reinterpret_cast<uint2*>(xp) = nw;
+        for (int u = 0; u < 4; ++u) {
+            const int ct = min(cb + u, ct1 - 1);
+            fv[u] = *reinterpret_cast<const bf16x8*>(vp + (size_t)ct * 16 * 32);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                old[u][t] = make_uint2(0u, 0u);
+                if (!assign) old[u][t] = *reinterpret_cast<const uint2*>(dx + ((size_t)b * L + j0 + t * 16 + i16) * ldx + ct * 16 + g * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (cb + u >= ct1) break;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[u], fc[t], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                uint2 nw;
+                nw.x = pack2bf(__uint_as_float(old[u][t].x << 16) + d[0], __uint_as_float(old[u][t].x & 0xffff0000u) + d[1]);
+                nw.y = pack2bf(__uint_as_float(old[u][t].y << 16) + d[2], __uint_as_float(old[u][t].y & 0xffff0000u) + d[3]);
+                *reinterpret_cast<uint2*>(dx + ((size_t)b * L + j0 + t * 16 + i16) * ldx + (cb + u) * 16 + g * 4) = nw;
+            }
         }
     }
 }
@@ -468,7 +484,8 @@ int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, co
     if (dtype == AMDSEG_BF16 && vt_ws && (H % 16) == 0) {
         const int total = B * H * 32;
         hipLaunchKernelGGL(lf_vt_prep_kernel, dim3((total + 255) / 256), dim3(256), 0, s, vecA, vecB, (bf16_t*)vt_ws, H, heads, total);
-        hipLaunchKernelGGL(lf_dx_update_mfma_kernel, dim3((L + 127) / 128, B), dim3(256), 0, s, (bf16_t*)dx, coefA, coefB, (const bf16_t*)vt_ws, L, H, heads, ldx, assign);
+        const int wgs = ((L + 127) / 128) * B, nz = wgs >= 1024 ? 2 : wgs >= 256 ? 4 : 8;      // column groups: enough workgroups to hide the row loads
+        hipLaunchKernelGGL(lf_dx_update_mfma_kernel, dim3((L + 127) / 128, B, nz), dim3(256), 0, s, (bf16_t*)dx, coefA, coefB, (const bf16_t*)vt_ws, L, H, heads, ldx, assign);
         return amdseg_launch_status();
     }
     const size_t lds = (size_t)heads * H * 4 * 2;
