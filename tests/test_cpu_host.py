@@ -139,3 +139,31 @@ def test_encoder_shape_alignment_rule():
         assert Lp % 64 == 0 and Lp >= L and Lp - L < 64
         assert Bp >= B and (Bp * Lp) % 128 == 0 and Bp - B <= 1
     assert EncoderFn.aligned_shape(32, 512) == (32, 512)
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """the five structs of the composite entry points are declared twice (include/amdseg.h for C callers, spokennlp_amd/lib.py for ctypes);
+    a field added on one side only would shift every pointer behind it.  gcc compiles a probe over the header that prints sizeof / offsetof
+    of every field ctypes knows, and the numbers must agree."""
+    import ctypes as C
+    import subprocess
+    from spokennlp_amd import lib
+    structs = {"amdseg_bert_cfg": lib.BertCfg, "amdseg_bert_layer_params": lib.LayerParams, "amdseg_bert_layer_grads": lib.LayerGrads,
+               "amdseg_bert_layer_acts": lib.LayerActs, "amdseg_bert_layer_ws": lib.LayerWs}
+    hdr = open(os.path.join(ROOT, "include", "amdseg.h")).read()
+    assert set(re.findall(r"typedef struct (amdseg_[a-z_]+)", hdr)) == set(structs), "a struct of the header has no ctypes mirror"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "amdseg.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
