@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 6   /* 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 7   /* 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -300,6 +300,20 @@ int amdseg_lf_global_bwd_a(void* dctx, int dtype, const float* Wv, const float* 
 int amdseg_lf_global_bwd_rest(const void* x, int x_dtype, void* dx, int dx_dtype, const float* Wq, const float* Wk, const float* qg,
                               const float* dout, const float* y, const float* sp, const float* dr, float* dqg, float* dWq, float* dbq,
                               float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads, float scale, amdseg_stream_t stream);
+/* amdseg_lf_global_bwd_rest in two calls, for a caller whose critical path waits for dx only: _dx computes dqg [B, H] and WRITES
+ * trow[b, :] = Wq^T dqg[b] [B, H] fp32 (the global row's contribution to dx[b, 0, :]; added by amdseg_lf_dx_apply) -- it needs neither dx nor x;
+ * _w adds every weight / bias gradient of the three global projections (reads the dqg of _dx) and may run any time before the optimiser. */
+int amdseg_lf_global_bwd_dx(const float* Wq, const float* Wk, const float* dr, float* dqg, float* trow, int B, int L, int H, int heads,
+                            float scale, amdseg_stream_t stream);
+int amdseg_lf_global_bwd_w(const void* x, int x_dtype, const float* qg, const float* dout, const float* y, const float* sp, const float* dr,
+                           const float* dqg, float* dWq, float* dbq, float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads,
+                           amdseg_stream_t stream);
+/* amdseg_lf_dx_update (bf16 dx) in two calls: _prep packs vecA / vecB [B, heads, H] into the MFMA operand image vt_ws [B, H, 32] bf16 (does not
+ * touch dx: may run early, on another stream); _apply is the read-modify-write pass  dx[b, j, :] += sum_h coefA[b, h, j] vecA[b, h, :] +
+ * coefB[b, h, j] vecB[b, h, :]  and, with trow != NULL, dx[b, 0, :] += trow[b, :]. */
+int amdseg_lf_dx_prep(const float* vecA, const float* vecB, void* vt_ws, int B, int L, int H, int heads, amdseg_stream_t stream);
+int amdseg_lf_dx_apply(void* dx, int ldx, const float* coefA, const float* coefB, const void* vt_ws, const float* trow, int B, int L, int H,
+                       int heads, amdseg_stream_t stream);
 
 /* ---- fused loss heads of the training step (csrc/heads.hip): token cross-entropy over the classifier logits (loss_calculator.py:25-57,
  * utils.py:141-182 weighted CE, ignore_index -100; `nseg` equal row segments = anchor half | augmented half, one mean each), CSSL InfoNCE in
@@ -358,8 +372,12 @@ typedef struct amdseg_bert_cfg {
     int32_t phase;                  /* 0 or 3 = whole layer.  1 / 2 = the part before / after the attention context:
                                        forward 1 = QKV projection + attention (writes acts.ctx), 2 = the rest;
                                        backward 1 = from dy down to ws.dctx, 2 = attention backward, dx_in, all weight
-                                       gradients.  A Longformer caller overwrites the global token's ctx row between
-                                       forward phases and consumes + zeroes its dctx row between backward phases.
+                                       gradients.  A Longformer caller writes the global token's ctx row between the
+                                       forward phases (AMDSEG_BF16, window > 0, nglobal > 0: forward phase 1 does NOT store
+                                       the ctx rows of the first nglobal tokens of a sequence, so the caller may write them
+                                       from another stream while phase 1 runs; the fp32 dtypes store a band row there that
+                                       the caller overwrites AFTER phase 1) and consumes + zeroes its dctx row between
+                                       backward phases.
                                        Backward only: 6 = phase 2 without the grouped weight-gradient GEMM, 4 = that GEMM
                                        alone (e.g. on a second stream, under the next layer's backward; the caller orders
                                        the streams and must not reuse ws before it has run). */

@@ -63,7 +63,7 @@ int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_o
 
 int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,
                          float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,
-                         const void* keep = nullptr);
+                         const void* keep = nullptr, int skip_q = 0);
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
                          int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,
@@ -93,6 +93,15 @@ int amdseg_lf_wsum_impl(const void* x, const float* coef, float* partials, float
                         int ldx, hipStream_t s);
 int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, const float* coefB, const float* vecB, void* vt_ws,
                              int B, int L, int H, int heads, int dtype, int ldx, int assign, hipStream_t s);
+
+int amdseg_lf_dx_prep_impl(const float* vecA, const float* vecB, void* vt_ws, int B, int L, int H, int heads, hipStream_t s);
+int amdseg_lf_dx_apply_impl(void* dx, int ldx, const float* coefA, const float* coefB, const void* vt_ws, const float* trow, int B, int L, int H,
+                            int heads, hipStream_t s);
+int amdseg_lf_global_bwd_dx_impl(const float* Wq, const float* Wk, const float* dr, float* dqg, float* trow, int B, int L, int H, int heads,
+                                 float scale, hipStream_t s);
+int amdseg_lf_global_bwd_w_impl(const void* x, int x_dtype, const float* qg, const float* dout, const float* y, const float* sp, const float* dr,
+                                const float* dqg, float* dWq, float* dbq, float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads,
+                                hipStream_t s);
 
 int amdseg_ponet_plan_impl(const float* mask_bias, const int* run_start, int* work, int B, int L, hipStream_t s);
 int amdseg_ponet_pool_fwd_impl(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,

@@ -268,6 +268,22 @@ int amdseg_lf_global_bwd_rest(const void* x, int x_dtype, void* dx, int dx_dtype
     return amdseg_lf_global_bwd_rest_impl(x, x_dtype, dx, dx_dtype, Wq, Wk, qg, dout, y, sp, dr, dqg, dWq, dbq, dWk, dWv, dbv, B, L, H, heads,
                                           scale, S(stream));
 }
+int amdseg_lf_global_bwd_dx(const float* Wq, const float* Wk, const float* dr, float* dqg, float* trow, int B, int L, int H, int heads,
+                            float scale, amdseg_stream_t stream) {
+    return amdseg_lf_global_bwd_dx_impl(Wq, Wk, dr, dqg, trow, B, L, H, heads, scale, S(stream));
+}
+int amdseg_lf_global_bwd_w(const void* x, int x_dtype, const float* qg, const float* dout, const float* y, const float* sp, const float* dr,
+                           const float* dqg, float* dWq, float* dbq, float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads,
+                           amdseg_stream_t stream) {
+    return amdseg_lf_global_bwd_w_impl(x, x_dtype, qg, dout, y, sp, dr, dqg, dWq, dbq, dWk, dWv, dbv, B, L, H, heads, S(stream));
+}
+int amdseg_lf_dx_prep(const float* vecA, const float* vecB, void* vt_ws, int B, int L, int H, int heads, amdseg_stream_t stream) {
+    return amdseg_lf_dx_prep_impl(vecA, vecB, vt_ws, B, L, H, heads, S(stream));
+}
+int amdseg_lf_dx_apply(void* dx, int ldx, const float* coefA, const float* coefB, const void* vt_ws, const float* trow, int B, int L, int H,
+                       int heads, amdseg_stream_t stream) {
+    return amdseg_lf_dx_apply_impl(dx, ldx, coefA, coefB, vt_ws, trow, B, L, H, heads, S(stream));
+}
 int amdseg_heads_fwd(const float* x, int M, int H, const float* logits, const int64_t* labels, const float* class_w, int C, int nseg,
                      float* ce_unit, float* out8, float* acc, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
                      int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off, long t_labels_off,
@@ -387,7 +403,9 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
             const void* keep = (a->keep && c->p_attn > 0.f && c->window == 0) ? a->keep : nullptr;
             if (keep) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s));
             RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0),
-                                        c->window, c->nglobal, s, c->kend, c->seq_order, keep));
+                                        c->window, c->nglobal, s, c->kend, c->seq_order, keep,
+                                        // a phase-1 call of a layer with global tokens: the caller writes their ctx rows (amdseg.h, `phase`)
+                                        (c->phase == 1 && c->window > 0) ? c->nglobal : 0));
         }
     }
     if (!PHASE2(c)) return AMDSEG_OK;

@@ -317,12 +317,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
     const bool padq = (BAND || LIST) && a.mask_bias[tok0 + q] < 0.f;   // padded query: zero row (Longformer :579, BigBird context_layer * from_mask), p == 0 in backward
     if (padq) { inv = 0.f; lse_q = INFINITY; }
     bf16_t* op = a.ctx + (tok0 + q) * H + h * HD;
+    if (!(BAND && q < a.skip_q)) {
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        uint2 pk;
-        pk.x = padq ? 0u : pack2bf(o[d][0] * inv, o[d][1] * inv);
-        pk.y = padq ? 0u : pack2bf(o[d][2] * inv, o[d][3] * inv);
-        *reinterpret_cast<uint2*>(op + d * 16 + g * 4) = pk;
+        for (int d = 0; d < 4; ++d) {
+            uint2 pk;
+            pk.x = padq ? 0u : pack2bf(o[d][0] * inv, o[d][1] * inv);
+            pk.y = padq ? 0u : pack2bf(o[d][2] * inv, o[d][3] * inv);
+            *reinterpret_cast<uint2*>(op + d * 16 + g * 4) = pk;
+        }
     }
     if (a.lse && g == 0) a.lse[prow] = lse_q;
 #undef CHUNK_OF
@@ -827,11 +829,12 @@ int amdseg_attn_keepmask_impl(void* keep, int B, int L, int heads, float p, uint
 
 int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,
                          float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order,
-                         const void* keep) {
+                         const void* keep, int skip_q) {
     if (!qkv || !mask_bias || !ctx) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
+    a.skip_q = window > 0 ? skip_q : 0;
     a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order; a.qguard = nullptr;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
     a.keepA = (const uint64_t*)keep; a.keepB = a.keepA ? a.keepA + (size_t)B * heads * L * (size_t)L / 64 : nullptr;

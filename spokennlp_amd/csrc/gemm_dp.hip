@@ -294,7 +294,16 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
     const bool ok256 = (a_in.N % 256) == 0, ok192 = (a_in.N % 192) == 0;
     static int force = -1;
     if (force < 0) { const char* e = getenv("AMDSEG_DP_BN"); force = e ? atoi(e) : 0; }
-    const bool use192 = ok192 && (!ok256 || force == 192);
+    // ... but ROUNDS count (round 3, M = 8192 = the 4 x 2048 launch shape of run_finetune.sh): N = 2304 is 288 tiles of 256 columns = 2 rounds with
+    // the second one 1/8 full, and 384 tiles of 192 = 2 rounds of 3/4 the work each: 45.0 -> 41.0 us; N = 3072 with the dual-output GELU epilogue
+    // 56.6 -> 52.5 (384 -> 512 tiles).  The residual-reading epilogues lose on the narrow tile's staged stores (GELU' 57.8 -> 59.2) and stay wide.
+    constexpr int EB = EPI_BASE(EPIX);
+    bool narrow = false;
+    if (ok256 && ok192 && force == 0 && (EB == EPI_NONE || EB == EPI_BIAS || EB == EPI_BIAS_GELU)) {
+        const int t256 = (a_in.M / DP_BM) * (a_in.N / 256), t192 = (a_in.M / DP_BM) * (a_in.N / 192);
+        narrow = 0.78f * (float)((t192 + 255) / 256) < (float)((t256 + 255) / 256);
+    }
+    const bool use192 = ok192 && (!ok256 || force == 192 || narrow);
     if (use192) return launch_nt_dp_nf<EPIX, OutT, 3>(a_in, s);
     return launch_nt_dp_nf<EPIX, OutT, 4>(a_in, s);
 }

@@ -23,6 +23,8 @@ struct LfGArgs {
     float* dWq; float* dbq; float* dWk; float* dWv; float* dbv;
     void* dx; int dx_dtype;
     float scale;
+    int qpart;                                             // lf_global_bwd_q: 0 = weight rows + dx rows, 1 = weight rows only, 2 = dx rows only
+    float* trow;                                           // dx rows, optional [B, H]: Wq^T dqg[b] is WRITTEN here instead of added to dx[b, 0, :]
 };
 
 template <typename T> __device__ __forceinline__ float ldf(const void* p, size_t i) { return Act<T>::ld(reinterpret_cast<const T*>(p) + i); }
@@ -177,8 +179,9 @@ __global__ __launch_bounds__(256) void lf_global_bwd_w_kernel(LfGArgs a) {
 // (thread = (column, quarter of the rows), the four quarters summed through LDS -- one block per sequence left 8 workgroups walking 768 x 768: 254 us)
 __global__ __launch_bounds__(256) void lf_global_bwd_q_kernel(LfGArgs a) {
     extern __shared__ float sm[];                        // [H] dqg[b]
-    if ((int)blockIdx.x < a.H) {
-        const int i = blockIdx.x;
+    const int blk = a.qpart == 2 ? (int)blockIdx.x + a.H : (int)blockIdx.x;
+    if (blk < a.H) {
+        const int i = blk;
         for (int c = threadIdx.x; c < a.H; c += 256) {
             float s = 0.f;
             for (int b = 0; b < a.B; ++b) s = fmaf(a.dqg[(size_t)b * a.H + i], ld_any(a.x, (size_t)b * a.L * a.H + c, a.x_dtype), s);
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void lf_global_bwd_q_kernel(LfGArgs a) {
         return;
     }
     __shared__ float red[4][64];
-    const int nb = a.H / 64, id = blockIdx.x - a.H, b = id / nb, c = (id % nb) * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int nb = a.H / 64, id = blk - a.H, b = id / nb, c = (id % nb) * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < a.H; k += 256) sm[k] = a.dqg[(size_t)b * a.H + k];
     __syncthreads();
     const int i0 = part * (a.H / 4), i1 = i0 + a.H / 4;
@@ -206,7 +209,8 @@ __global__ __launch_bounds__(256) void lf_global_bwd_q_kernel(LfGArgs a) {
     if (part == 0) {
         const size_t o = (size_t)b * a.L * a.H + c;
         const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        st_any(a.dx, o, ld_any(a.dx, o, a.dx_dtype) + t, a.dx_dtype);
+        if (a.trow) a.trow[(size_t)b * a.H + c] = t;
+        else st_any(a.dx, o, ld_any(a.dx, o, a.dx_dtype) + t, a.dx_dtype);
     }
 }
 
@@ -258,5 +262,33 @@ int amdseg_lf_global_bwd_rest_impl(const void* x, int x_dtype, void* dx, int dx_
     hipLaunchKernelGGL(lf_global_bwd_b_kernel, dim3(heads, B), dim3(256), H * sizeof(float), s, a);
     hipLaunchKernelGGL(lf_global_bwd_w_kernel, dim3(H), dim3(256), 0, s, a);
     hipLaunchKernelGGL(lf_global_bwd_q_kernel, dim3(H + B * (H / 64)), dim3(256), H * sizeof(float), s, a);
+    return amdseg_launch_status();
+}
+
+// the same backward in two calls, for a caller that wants the part its critical path waits for early and the weight gradients whenever:
+// _dx: dqg (lf_global_bwd_b) and trow[b, :] = Wq^T dqg[b], the global row's contribution to dx[b, 0, :] -- WRITTEN to trow [B, H] fp32, to be added
+// by amdseg_lf_dx_apply;  _w: every weight / bias gradient of the three global projections (needs dqg from _dx).
+int amdseg_lf_global_bwd_dx_impl(const float* Wq, const float* Wk, const float* dr, float* dqg, float* trow, int B, int L, int H, int heads,
+                                 float scale, hipStream_t s) {
+    if (!Wq || !Wk || !dr || !dqg || !trow) return AMDSEG_ERR_ARG;
+    int rc = lfg_check(B, L, H, heads);
+    if (rc) return rc;
+    LfGArgs a = {};
+    a.L = L; a.H = H; a.heads = heads; a.B = B; a.Wq = Wq; a.Wk = Wk; a.dr = dr; a.dqg = dqg; a.trow = trow; a.scale = scale; a.qpart = 2;
+    hipLaunchKernelGGL(lf_global_bwd_b_kernel, dim3(heads, B), dim3(256), H * sizeof(float), s, a);
+    hipLaunchKernelGGL(lf_global_bwd_q_kernel, dim3(B * (H / 64)), dim3(256), H * sizeof(float), s, a);
+    return amdseg_launch_status();
+}
+int amdseg_lf_global_bwd_w_impl(const void* x, int x_dtype, const float* qg, const float* dout, const float* y, const float* sp, const float* dr,
+                                const float* dqg, float* dWq, float* dbq, float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads,
+                                hipStream_t s) {
+    if (!x || !qg || !dout || !y || !sp || !dr || !dqg || !dWq || !dbq || !dWk || !dWv || !dbv) return AMDSEG_ERR_ARG;
+    int rc = lfg_check(B, L, H, heads);
+    if (rc) return rc;
+    LfGArgs a = {};
+    a.x = x; a.x_dtype = x_dtype; a.L = L; a.H = H; a.heads = heads; a.B = B; a.qg = (float*)qg; a.dout = (float*)dout; a.y = y; a.sp = sp; a.dr = dr;
+    a.dqg = (float*)dqg; a.dWq = dWq; a.dbq = dbq; a.dWk = dWk; a.dWv = dWv; a.dbv = dbv; a.qpart = 1;
+    hipLaunchKernelGGL(lf_global_bwd_w_kernel, dim3(H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(lf_global_bwd_q_kernel, dim3(H), dim3(256), H * sizeof(float), s, a);
     return amdseg_launch_status();
 }

@@ -354,7 +354,7 @@ __global__ void lf_vt_prep_kernel(const float* __restrict__ vecA, const float* _
 // consecutive columns: 8-byte read-modify-write.  One wave = 32 tokens; grid (L/128, B)
 __global__ __launch_bounds__(256) void lf_dx_update_mfma_kernel(bf16_t* __restrict__ dx, const float* __restrict__ coefA,
                                                                 const float* __restrict__ coefB, const bf16_t* __restrict__ vt,
-                                                                int L, int H, int heads, int ldx, int assign) {
+                                                                int L, int H, int heads, int ldx, int assign, const float* __restrict__ trow) {
     const int b = blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, i16 = l & 15;
     const int j0 = blockIdx.x * 128 + w * 32;
     if (j0 >= L) return;
@@ -397,6 +397,10 @@ __global__ __launch_bounds__(256) void lf_dx_update_mfma_kernel(bf16_t* __restri
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[u], fc[t], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                if (trow && j0 + t * 16 + i16 == 0) {            // token 0 of the sequence also takes the row vector trow[b, :]
+                    const float4 tr = *reinterpret_cast<const float4*>(trow + (size_t)b * H + (cb + u) * 16 + g * 4);
+                    d[0] += tr.x; d[1] += tr.y; d[2] += tr.z; d[3] += tr.w;
+                }
                 uint2 nw;
                 nw.x = pack2bf(__uint_as_float(old[u][t].x << 16) + d[0], __uint_as_float(old[u][t].x & 0xffff0000u) + d[1]);
                 nw.y = pack2bf(__uint_as_float(old[u][t].y << 16) + d[2], __uint_as_float(old[u][t].y & 0xffff0000u) + d[3]);
@@ -485,7 +489,8 @@ int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, co
         const int total = B * H * 32;
         hipLaunchKernelGGL(lf_vt_prep_kernel, dim3((total + 255) / 256), dim3(256), 0, s, vecA, vecB, (bf16_t*)vt_ws, H, heads, total);
         const int wgs = ((L + 127) / 128) * B, nz = wgs >= 1024 ? 2 : wgs >= 256 ? 4 : 8;      // column groups: enough workgroups to hide the row loads
-        hipLaunchKernelGGL(lf_dx_update_mfma_kernel, dim3((L + 127) / 128, B, nz), dim3(256), 0, s, (bf16_t*)dx, coefA, coefB, (const bf16_t*)vt_ws, L, H, heads, ldx, assign);
+        hipLaunchKernelGGL(lf_dx_update_mfma_kernel, dim3((L + 127) / 128, B, nz), dim3(256), 0, s, (bf16_t*)dx, coefA, coefB, (const bf16_t*)vt_ws, L, H, heads, ldx, assign,
+                           (const float*)nullptr);
         return amdseg_launch_status();
     }
     const size_t lds = (size_t)heads * H * 4 * 2;
@@ -496,5 +501,28 @@ int amdseg_lf_dx_update_impl(void* dx, const float* coefA, const float* vecA, co
         (void)hipFuncSetAttribute((const void*)lf_dx_update_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(lf_dx_update_kernel<float>, dim3(L / 64, B), dim3(256), lds, s, (float*)dx, coefA, vecA, coefB, vecB, L, H, heads, ldx, assign);
     }
+    return amdseg_launch_status();
+}
+
+// amdseg_lf_dx_update in two calls (bf16): _prep packs the two vector sets into the MFMA operand image vt_ws [B, H, 32] -- everything that does
+// not touch dx, so it can run early and elsewhere -- and _apply is the read-modify-write pass over dx alone; with trow [B, H] it also adds
+// trow[b, :] to row b*L (the global token's own row: amdseg_lf_global_bwd_dx).
+int amdseg_lf_dx_prep_impl(const float* vecA, const float* vecB, void* vt_ws, int B, int L, int H, int heads, hipStream_t s) {
+    if (!vecA || !vecB || !vt_ws) return AMDSEG_ERR_ARG;
+    int rc = lf_check(B, L, H, heads);
+    if (rc) return rc;
+    if (H % 16) return AMDSEG_ERR_SHAPE;
+    const int total = B * H * 32;
+    hipLaunchKernelGGL(lf_vt_prep_kernel, dim3((total + 255) / 256), dim3(256), 0, s, vecA, vecB, (bf16_t*)vt_ws, H, heads, total);
+    return amdseg_launch_status();
+}
+int amdseg_lf_dx_apply_impl(void* dx, int ldx, const float* coefA, const float* coefB, const void* vt_ws, const float* trow, int B, int L, int H,
+                            int heads, hipStream_t s) {
+    if (!dx || !coefA || !coefB || !vt_ws || ldx < H || (ldx % 8)) return AMDSEG_ERR_ARG;
+    int rc = lf_check(B, L, H, heads);
+    if (rc) return rc;
+    if (H % 16) return AMDSEG_ERR_SHAPE;
+    const int wgs = ((L + 127) / 128) * B, nz = wgs >= 1024 ? 2 : wgs >= 256 ? 4 : 8;
+    hipLaunchKernelGGL(lf_dx_update_mfma_kernel, dim3((L + 127) / 128, B, nz), dim3(256), 0, s, (bf16_t*)dx, coefA, coefB, (const bf16_t*)vt_ws, L, H, heads, ldx, 0, trow);
     return amdseg_launch_status();
 }

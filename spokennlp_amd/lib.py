@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("AMDSEG_LIB") or os.path.join(_HERE, "libamdseg.so")
 BF16, F32, F32S = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
 EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
@@ -102,6 +102,10 @@ _PROTOS = {
     "amdseg_lf_global_out": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "amdseg_lf_global_bwd_a": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "amdseg_lf_global_bwd_rest": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "amdseg_lf_global_bwd_dx": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "amdseg_lf_global_bwd_w": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "amdseg_lf_dx_prep": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "amdseg_lf_dx_apply": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "amdseg_heads_fwd": [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, C.c_long, C.c_long, C.c_long, i32, i32, i32, f32, vp, vp,
                          C.c_long, C.c_long, i32, i32, f32, f32, f32, vp],
     "amdseg_heads_bwd_ce": [vp, i32, i32, i32, vp, vp, f32, vp, vp],

@@ -42,7 +42,7 @@ class LongformerEncoderEngine(BertEncoderEngine):
         # and the weight-gradient GEMM.  AMDSEG_LF_OVERLAP=0 keeps everything on one stream.
         import os
         self.lf_overlap = os.environ.get("AMDSEG_LF_OVERLAP", "1") != "0" and device.type == "cuda"
-        self._lf_side = torch.cuda.Stream(device=device) if self.lf_overlap else None
+        self._lf_side = torch.cuda.Stream(device=device, priority=int(os.environ.get("AMDSEG_LF_SIDE_PRIO", "0"))) if self.lf_overlap else None
 
     def _on_both(self, main, *tensors):
         """tensors created while one stream was current and read on the other: tell the caching allocator"""
@@ -62,6 +62,9 @@ class LongformerEncoderEngine(BertEncoderEngine):
 
     def _embed_backward_fixup(self, dpos, pad):
         dpos[self.pad_id].zero_()          # nn.Embedding(padding_idx=pad) of the position table ([hf]:394-396)
+        if getattr(self, "_side_pending", False):      # end of backward: the global projections' weight gradients (side stream) are part of flat_g
+            torch.cuda.current_stream().wait_stream(self._lf_side)
+            self._side_pending = False
 
     # ---- forward
     def _layer_forward(self, lib, cfg, lp, A, i, mb, s, train):
@@ -78,8 +81,17 @@ class LongformerEncoderEngine(BertEncoderEngine):
         dtx = L.F32 if x_in.dtype == torch.float32 else L.BF16
         main = torch.cuda.current_stream()
         side = self._lf_side if self.lf_overlap else main
+        # bf16 path: forward phase 1 leaves the [CLS] rows of ctx unwritten (include/amdseg.h, amdseg_bert_cfg.phase), so the WHOLE global-row
+        # chain -- it reads only x_in -- runs beside the projection + band attention and main waits once, for work that is long done.  (Waiting
+        # for the attention, writing the row, and handing back cost two cross-queue hops = ~40 us per layer with the GPU idle.)
+        early = side is not main and x_in.dtype == torch.bfloat16
         if side is not main:
-            fork = torch.cuda.Event(); fork.record(main); side.wait_event(fork)          # x_in is complete
+            fork = torch.cuda.Event(); fork.record(main)                                  # x_in is complete
+        if early:                                      # queue main's work first: the host needs ~8 launches for the chain
+            cfg.phase = 1
+            L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].1")
+        if side is not main:
+            side.wait_event(fork)
         with torch.no_grad(), torch.cuda.stream(side):
             ss = side.cuda_stream
             Wq, bq = self._gp(fp, i, "query_global", "weight"), self._gp(fp, i, "query_global", "bias")
@@ -95,11 +107,12 @@ class LongformerEncoderEngine(BertEncoderEngine):
             seed = (int(cfg.seed) * 0x9E3779B1 + 7919 * (i + 1)) & 0x7FFFFFFFFFFFFFFF
             p, pd, sp = ops.lf_softmax_fwd(scores, cfg.p_attn, seed)
             y = ops.lf_wsum(x_in, pd, H, A["lf_partials"])
-        # the band attention writes its own row 0 of ctx; the global row then overwrites it
-        cfg.phase = 1
-        L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].1")
-        if side is not main:
-            attn_done = torch.cuda.Event(); attn_done.record(main); side.wait_event(attn_done)
+        if not early:
+            # fp32 dtypes: the band attention writes its own row 0 of ctx; the global row then overwrites it
+            cfg.phase = 1
+            L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].1")
+            if side is not main:
+                attn_done = torch.cuda.Event(); attn_done.record(main); side.wait_event(attn_done)
         with torch.no_grad(), torch.cuda.stream(side):
             L.check(lib.amdseg_lf_global_out(Wv.data_ptr(), bv.data_ptr(), y.data_ptr(), sp.data_ptr(), la["ctx"].data_ptr(),
                                              L.F32 if la["ctx"].dtype == torch.float32 else L.BF16, B, Lseq, H, heads, side.cuda_stream),
@@ -141,6 +154,44 @@ class LongformerEncoderEngine(BertEncoderEngine):
             # the attention backward below reads dctx
             L.check(lib.amdseg_lf_global_bwd_a(dctx.data_ptr(), adt, Wv.data_ptr(), bv.data_ptr(), dout.data_ptr(), dyv.data_ptr(),
                                                dsp.data_ptr(), B, Lseq, H, heads, s), "amdseg_lf_global_bwd_a")
+        if side is not main and adt == L.BF16:
+            # Two-stream order of the bf16 path.  Everything the global row adds to dx -- the rank-2*heads update and the [CLS] row's own
+            # term -- depends only on dctx[:, 0] and saved tensors, so the side stream prepares it under the band attention backward + dx GEMM
+            # (operand image vt, row vector trow) and main applies it in one read-modify-write pass right behind the dx GEMM; the weight
+            # gradients of the three global projections follow on the side stream and are joined once, at the end of backward
+            # (_embed_backward_fixup).  (The update + the row term + the weight gradients used to run under the weight-gradient GEMM, which
+            # slowed them 3-5 x and left main waiting ~45 us per layer for the hand-back.)
+            e1 = torch.cuda.Event(); e1.record(main)
+            cfg.phase = 6                                      # attention backward + dx GEMM, queued before the host issues the chain
+            L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].2")
+            side.wait_event(e1)
+            with torch.no_grad(), torch.cuda.stream(side):
+                ss = side.cuda_stream
+                dpd = ops.lf_rowvec_dot(x_in, dyv, B, Lseq, add_bh=dsp)
+                ds, pd = ops.lf_softmax_bwd(p, dpd, cfg.p_attn, saved["seed"])
+                dr = ops.lf_wsum(x_in, ds, H, A["lf_partials"])
+                dqg, trow = torch.empty(B, H, **f32), torch.empty(B, H, **f32)
+                L.check(lib.amdseg_lf_global_bwd_dx(Wq.data_ptr(), Wk.data_ptr(), dr.data_ptr(), dqg.data_ptr(), trow.data_ptr(), B, Lseq, H, heads,
+                                                    self.scale, ss), "amdseg_lf_global_bwd_dx")
+                L.check(lib.amdseg_lf_dx_prep(dyv.data_ptr(), r.data_ptr(), A["lf_vt"].data_ptr(), B, Lseq, H, heads, ss), "amdseg_lf_dx_prep")
+                e2 = torch.cuda.Event(); e2.record(side)
+                g = lambda which, kind: self._gp(fg, i, which, kind).data_ptr()          # noqa: E731
+                L.check(lib.amdseg_lf_global_bwd_w(x_in.data_ptr(), adt, qg.data_ptr(), dout.data_ptr(), y.data_ptr(), sp.data_ptr(), dr.data_ptr(),
+                                                   dqg.data_ptr(), g("query_global", "weight"), g("query_global", "bias"),
+                                                   g("key_global", "weight"), g("value_global", "weight"), g("value_global", "bias"),
+                                                   B, Lseq, H, heads, ss), "amdseg_lf_global_bwd_w")
+                ew = torch.cuda.Event(); ew.record(side)
+            main.wait_event(e2)
+            L.check(lib.amdseg_lf_dx_apply(other.data_ptr(), H, pd.data_ptr(), ds.data_ptr(), A["lf_vt"].data_ptr(), trow.data_ptr(), B, Lseq, H,
+                                           heads, s), "amdseg_lf_dx_apply")
+            cfg.phase = 4
+            L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].4")
+            self._on_both(main, dout, dyv, dsp, dpd, ds, pd, dr, dqg, trow)
+            self._side_pending = True
+            if self.buckets is not None and self.grad_sync:   # data parallel: this layer's slice is reduced right after this call
+                main.wait_event(ew)
+            cfg.phase = 0
+            return
         if side is not main:
             e1 = torch.cuda.Event(); e1.record(main); side.wait_event(e1)
         with torch.no_grad(), torch.cuda.stream(side):          # ... under the band attention backward

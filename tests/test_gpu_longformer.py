@@ -113,6 +113,92 @@ def test_global_row_kernels(dev, dt):
         assert err.max().item() < 1e-4
 
 
+def test_global_row_backward_in_two_calls_equals_the_single_call(dev):
+    """amdseg_lf_global_bwd_dx + amdseg_lf_dx_prep / _apply + amdseg_lf_global_bwd_w (the two-stream order of longformer_engine: the part dx waits
+    for early, the weight gradients whenever) against amdseg_lf_dx_update + amdseg_lf_global_bwd_rest on the same inputs"""
+    from spokennlp_amd import lib as Lb, ops
+    torch.manual_seed(11)
+    B, L, H, heads = 3, 256, 256, 4
+    lib = Lb.load()
+    s = torch.cuda.current_stream().cuda_stream
+    f = dict(dtype=torch.float32, device=dev)
+    x = torch.randn(B * L, H, device=dev).bfloat16()
+    Wq, Wk = torch.randn(H, H, **f) * 0.05, torch.randn(H, H, **f) * 0.05
+    qg, dout, sp = torch.randn(B, heads, 64, **f), torch.randn(B, heads, 64, **f), torch.rand(B, heads, **f)
+    y, dr = torch.randn(B, heads, H, **f), torch.randn(B, heads, H, **f)
+    pd, ds = torch.randn(B, heads, L, **f), torch.randn(B, heads, L, **f)
+    dyv, r = torch.randn(B, heads, H, **f), torch.randn(B, heads, H, **f)
+    dx0 = torch.randn(B * L, H, device=dev).bfloat16()
+    grads = lambda: [torch.randn(H, H, **f), torch.randn(H, **f), torch.randn(H, H, **f), torch.randn(H, H, **f), torch.randn(H, **f)]  # noqa: E731
+    torch.manual_seed(5); g_ref = grads()
+    torch.manual_seed(5); g_new = grads()
+    # single call: dx update, then dqg / weight gradients / dx[:, 0] += Wq^T dqg
+    dx_ref = dx0.clone()
+    ops.lf_dx_update(dx_ref, pd, dyv, ds, r)
+    dqg_ref = torch.empty(B, H, **f)
+    Lb.check(lib.amdseg_lf_global_bwd_rest(x.data_ptr(), Lb.BF16, dx_ref.data_ptr(), Lb.BF16, Wq.data_ptr(), Wk.data_ptr(), qg.data_ptr(),
+                                           dout.data_ptr(), y.data_ptr(), sp.data_ptr(), dr.data_ptr(), dqg_ref.data_ptr(),
+                                           *[t.data_ptr() for t in g_ref], B, L, H, heads, 0.125, s), "bwd_rest")
+    # two calls
+    dx_new = dx0.clone()
+    dqg, trow = torch.empty(B, H, **f), torch.empty(B, H, **f)
+    vt = torch.empty(B * H * 32, dtype=torch.bfloat16, device=dev)
+    Lb.check(lib.amdseg_lf_global_bwd_dx(Wq.data_ptr(), Wk.data_ptr(), dr.data_ptr(), dqg.data_ptr(), trow.data_ptr(), B, L, H, heads, 0.125, s), "bwd_dx")
+    Lb.check(lib.amdseg_lf_dx_prep(dyv.data_ptr(), r.data_ptr(), vt.data_ptr(), B, L, H, heads, s), "dx_prep")
+    Lb.check(lib.amdseg_lf_dx_apply(dx_new.data_ptr(), H, pd.data_ptr(), ds.data_ptr(), vt.data_ptr(), trow.data_ptr(), B, L, H, heads, s), "dx_apply")
+    Lb.check(lib.amdseg_lf_global_bwd_w(x.data_ptr(), Lb.BF16, qg.data_ptr(), dout.data_ptr(), y.data_ptr(), sp.data_ptr(), dr.data_ptr(),
+                                        dqg.data_ptr(), *[t.data_ptr() for t in g_new], B, L, H, heads, s), "bwd_w")
+    assert torch.equal(dqg, dqg_ref)
+    for a, b in zip(g_new, g_ref):
+        assert torch.equal(a, b)
+    rows0 = torch.arange(B, device=dev) * L
+    rest = torch.ones(B * L, dtype=torch.bool, device=dev); rest[rows0] = False
+    assert torch.equal(dx_new[rest], dx_ref[rest])
+    # the [CLS] rows: one bf16 rounding (update + row term together) against two -- and against the fp32 sum
+    want = dx0[rows0].float() + torch.einsum("bh,bhk->bk", pd[:, :, 0], dyv.bfloat16().float()) + torch.einsum("bh,bhk->bk", ds[:, :, 0], r.bfloat16().float()) \
+        + dqg_ref @ Wq
+    assert (dx_new[rows0].float() - want).abs().max().item() < 0.02 * want.abs().max().item()
+    assert (dx_new[rows0].float() - dx_ref[rows0].float()).abs().max().item() < 0.02 * want.abs().max().item()
+
+
+def test_layer_forward_phase1_leaves_the_global_rows_of_ctx_unwritten(dev):
+    """include/amdseg.h, amdseg_bert_cfg.phase (ABI 7): bf16, window > 0, nglobal > 0 -- the caller owns those ctx rows, so it can write them
+    from another stream while phase 1 runs.  Checked through the engine: a sentinel in the rows survives the projection + band attention."""
+    z, sd, batch, arch = lf_case("lf_tiny_L128_w16")
+    m = build_lf(arch, flags_of(z, "train_full"), sd, dev).eval()
+    eng = m.engine()
+    seen = {}
+    orig = type(eng)._layer_forward
+
+    def spy(self, lib, cfg, lp, A, i, mb, s, train):
+        la = A["layers"][i if train else 0]
+        if i == 0:
+            la["ctx"].fill_(768.0)
+        out = orig(self, lib, cfg, lp, A, i, mb, s, train)
+        if i == 0:
+            seen["ctx"] = la["ctx"].clone(); seen["L"] = cfg.L; seen["B"] = cfg.B
+        return out
+    eng._layer_forward = spy.__get__(eng)
+    from spokennlp_amd import lib as Lb
+    lib = Lb.load()
+    with torch.no_grad():
+        m(**{k: v.to(dev) for k, v in batch.items()})
+    ctx, Lq, B = seen["ctx"].float(), seen["L"], seen["B"]
+    assert not (ctx == 768.0).any()                     # every row was written by somebody: the global rows by lf_global_out
+    real = lib.amdseg_lf_global_out
+    try:
+        lib.amdseg_lf_global_out = lambda *a: 0         # nobody writes the global rows now
+        with torch.no_grad():
+            m(**{k: v.to(dev) for k, v in batch.items()})
+    finally:
+        lib.amdseg_lf_global_out = real
+    ctx = seen["ctx"].float()
+    rows0 = torch.arange(B, device=dev) * Lq
+    assert (ctx[rows0] == 768.0).all()                  # phase 1 left them alone
+    rest = torch.ones(B * Lq, dtype=torch.bool, device=dev); rest[rows0] = False
+    assert not (ctx[rest] == 768.0).any()
+
+
 # ---------------------------------------------------------------------------------------------------- model level
 def build_lf(arch, flags, sd, dev, dropout=0.0, precision=None):
     from transformers import LongformerConfig

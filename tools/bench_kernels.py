@@ -1,12 +1,13 @@
 #!/usr/bin/env python
-"""Micro-benchmarks of the libamdseg kernels at the bert-base / M=16384 shapes (HIP-event timing on the launch stream)."""
+"""Micro-benchmarks of the libamdseg kernels at the bert-base / M=16384 shapes (HIP-event timing on the launch stream).  BK_M overrides M for
+the GEMM legs."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from spokennlp_amd import ops
 
 dev = torch.device("cuda:0")
-M, H, I, B, L, heads = 16384, 768, 3072, 32, 512, 12
+M, H, I, B, L, heads = int(os.environ.get("BK_M", 16384)), 768, 3072, 32, 512, 12      # BK_M=8192: the 4 x 2048 launch shape of run_finetune.sh
 
 
 def timeit(fn, reps=20, warm=3):

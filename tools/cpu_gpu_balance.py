@@ -12,7 +12,8 @@ import bench  # noqa: E402
 
 
 class A:
-    model = "bert"; seq_len = 512; seqs_per_gpu = 32; workload = "full_da"; mode = "train"
+    model = os.environ.get("CB_MODEL", "bert"); seq_len = int(os.environ.get("CB_L", 512)); seqs_per_gpu = int(os.environ.get("CB_B", 32))
+    workload = "full_da"; mode = "train"
 
 
 def main():
