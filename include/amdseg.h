@@ -179,6 +179,20 @@ int amdseg_ponet_pool_fwd(const void* proj, int ld, const float* mask_bias, cons
 int amdseg_ponet_pool_bwd(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,
                           const float* g, const void* part, const void* parg, const void* dctx, void* dproj, float* dg, float* psum, int B,
                           int L, int H, amdseg_stream_t stream);
+/* The global aggregation branch of the same mixer (csrc/ponet_global.hip), bf16 column blocks Hq / Hk of the projection (row stride ld):
+ *   qbar_b = sum_j coef_mean[b, j] Hq[b, j, :];  s[b, h, j] = qbar_b[head h] . Hk[b, j, head h] / 8 + mask_bias[b, j];  p = softmax_j s;
+ *   g[b, c] = sum_j dropout(p)[b, head(c), j] Hk[b, j, c]     (heads of 64 columns, H = heads * 64 <= 1024, L % 64 == 0)
+ * forward writes vecq = qbar / 8 [B, H], the raw scores [B, heads, L], lse [B, heads] (all three read again by backward) and g [B, H];
+ * backward takes dg [B, H] (amdseg_ponet_pool_bwd) and WRITES the dHq and dHk column blocks (row stride ldd).  scratch:
+ * amdseg_ponet_global_scratch_floats(B, L, H, heads) floats = B (L/64 (H + 2 heads) + H); dpd_ws: [B, heads, L] floats.  Dropout decisions are those of amdseg_lf_softmax_fwd
+ * with the same seed.  Replaces the amdseg_lf_* formulation of rounds 1-2 (10 / 12 launches and 12 x the arithmetic per layer). */
+size_t amdseg_ponet_global_scratch_floats(int B, int L, int H, int heads);
+int amdseg_ponet_global_fwd(const void* hq, const void* hk, int ld, const float* coef_mean, const float* mask_bias, int B, int L, int H,
+                            int heads, float dropout_p, uint64_t seed, float* scratch, float* vecq, float* scores, float* lse, float* g,
+                            amdseg_stream_t stream);
+int amdseg_ponet_global_bwd(const void* hk, int ld, const float* coef_mean, const float* vecq, const float* scores, const float* lse,
+                            const float* dg, int B, int L, int H, int heads, float dropout_p, uint64_t seed, float* scratch, float* dpd_ws,
+                            void* dhq, void* dhk, int ldd, amdseg_stream_t stream);
 
 /* ---- HBM-bound row kernels (csrc/elementwise.hip) ---------------------------------------------------------------
  * embeddings + LayerNorm + dropout ([hf] models/bert/modeling_bert.py:53-108); tables are the fp32 masters.

@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm_dp.hip", "attention.hip", "attention_split.hip", "elementwise.hip", "optim.hip", "gemm_f32.hip", "longformer.hip", "ponet.hip", "prof.hip", "parity.hip", "heads.hip", "lf_global.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm_dp.hip", "attention.hip", "attention_split.hip", "elementwise.hip", "optim.hip", "gemm_f32.hip", "longformer.hip", "ponet.hip", "ponet_global.hip", "prof.hip", "parity.hip", "heads.hip", "lf_global.hip", "api.hip"]
 OUT = os.path.join(HERE, "libamdseg.so")
 
 

@@ -103,6 +103,13 @@ int amdseg_lf_global_bwd_w_impl(const void* x, int x_dtype, const float* qg, con
                                 const float* dqg, float* dWq, float* dbq, float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads,
                                 hipStream_t s);
 
+size_t amdseg_ponet_global_scratch_floats_impl(int B, int L, int H, int heads);
+int amdseg_ponet_global_fwd_impl(const void* hq, const void* hk, int ld, const float* coef_mean, const float* mask_bias, int B, int L, int H,
+                                 int heads, float p, uint64_t seed, float* scratch, float* vecq, float* scores, float* lse, float* g,
+                                 hipStream_t s);
+int amdseg_ponet_global_bwd_impl(const void* hk, int ld, const float* coef_mean, const float* vecq, const float* scores, const float* lse,
+                                 const float* dg, int B, int L, int H, int heads, float p, uint64_t seed, float* scratch, float* dpd_ws,
+                                 void* dhq, void* dhk, int ldd, hipStream_t s);
 int amdseg_ponet_plan_impl(const float* mask_bias, const int* run_start, int* work, int B, int L, hipStream_t s);
 int amdseg_ponet_pool_fwd_impl(const void* proj, int ld, const float* mask_bias, const int* run_start, const int* run_end, const int* work,
                                const float* g, void* part, void* parg, void* ctx, int B, int L, int H, hipStream_t s);

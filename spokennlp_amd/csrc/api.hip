@@ -268,6 +268,18 @@ int amdseg_lf_global_bwd_rest(const void* x, int x_dtype, void* dx, int dx_dtype
     return amdseg_lf_global_bwd_rest_impl(x, x_dtype, dx, dx_dtype, Wq, Wk, qg, dout, y, sp, dr, dqg, dWq, dbq, dWk, dWv, dbv, B, L, H, heads,
                                           scale, S(stream));
 }
+size_t amdseg_ponet_global_scratch_floats(int B, int L, int H, int heads) { return amdseg_ponet_global_scratch_floats_impl(B, L, H, heads); }
+int amdseg_ponet_global_fwd(const void* hq, const void* hk, int ld, const float* coef_mean, const float* mask_bias, int B, int L, int H,
+                            int heads, float dropout_p, uint64_t seed, float* scratch, float* vecq, float* scores, float* lse, float* g,
+                            amdseg_stream_t stream) {
+    return amdseg_ponet_global_fwd_impl(hq, hk, ld, coef_mean, mask_bias, B, L, H, heads, dropout_p, seed, scratch, vecq, scores, lse, g, S(stream));
+}
+int amdseg_ponet_global_bwd(const void* hk, int ld, const float* coef_mean, const float* vecq, const float* scores, const float* lse,
+                            const float* dg, int B, int L, int H, int heads, float dropout_p, uint64_t seed, float* scratch, float* dpd_ws,
+                            void* dhq, void* dhk, int ldd, amdseg_stream_t stream) {
+    return amdseg_ponet_global_bwd_impl(hk, ld, coef_mean, vecq, scores, lse, dg, B, L, H, heads, dropout_p, seed, scratch, dpd_ws, dhq, dhk, ldd,
+                                        S(stream));
+}
 int amdseg_lf_global_bwd_dx(const float* Wq, const float* Wk, const float* dr, float* dqg, float* trow, int B, int L, int H, int heads,
                             float scale, amdseg_stream_t stream) {
     return amdseg_lf_global_bwd_dx_impl(Wq, Wk, dr, dqg, trow, B, L, H, heads, scale, S(stream));

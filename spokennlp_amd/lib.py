@@ -102,6 +102,9 @@ _PROTOS = {
     "amdseg_lf_global_out": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "amdseg_lf_global_bwd_a": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "amdseg_lf_global_bwd_rest": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "amdseg_ponet_global_scratch_floats": [i32, i32, i32, i32],
+    "amdseg_ponet_global_fwd": [vp, vp, i32, vp, vp, i32, i32, i32, i32, f32, u64, vp, vp, vp, vp, vp, vp],
+    "amdseg_ponet_global_bwd": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, vp, vp, vp, i32, vp],
     "amdseg_lf_global_bwd_dx": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "amdseg_lf_global_bwd_w": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "amdseg_lf_dx_prep": [vp, vp, vp, i32, i32, i32, i32, vp],
@@ -124,7 +127,7 @@ _PROTOS = {
     "amdseg_bert_layer_bwd": [C.POINTER(BertCfg), C.POINTER(LayerParams), C.POINTER(LayerGrads), C.POINTER(LayerActs),
                               C.POINTER(LayerWs), vp, vp, vp, i32, vp],
 }
-_RESTYPE = {"amdseg_error_string": C.c_char_p, "amdseg_attn_keepmask_bytes": C.c_size_t}
+_RESTYPE = {"amdseg_error_string": C.c_char_p, "amdseg_attn_keepmask_bytes": C.c_size_t, "amdseg_ponet_global_scratch_floats": C.c_size_t}
 
 EXPORTS = tuple(_PROTOS)
 _lib = None

@@ -223,7 +223,39 @@ def lf_dx_update(dx, coefA, vecA, coefB, vecB, vt_ws=None, assign=False):
     L.check(rc, "amdseg_lf_dx_update_ld")
 
 
-# ---- PoNet token mixing (csrc/ponet.hip)
+# ---- PoNet token mixing (csrc/ponet.hip, csrc/ponet_global.hip)
+def ponet_global_scratch(B, Lseq, H, heads, device):
+    return torch.empty(int(L.load().amdseg_ponet_global_scratch_floats(B, Lseq, H, heads)), dtype=torch.float32, device=device)
+
+
+def ponet_global_fwd(hq, hk, coef_mean, mask_bias, B, Lseq, H, heads, p=0.0, seed=0, scratch=None):
+    """hq, hk: bf16 column blocks [B*L, H] of the projection (same row stride).  Returns (g [B,H], vecq [B,H], scores [B,heads,L], lse [B,heads])."""
+    dev = hk.device
+    if scratch is None:
+        scratch = ponet_global_scratch(B, Lseq, H, heads, dev)
+    f = dict(dtype=torch.float32, device=dev)
+    vecq, g = torch.empty(B, H, **f), torch.empty(B, H, **f)
+    scores, lse = torch.empty(B, heads, Lseq, **f), torch.empty(B, heads, **f)
+    assert hq.stride(0) == hk.stride(0)
+    rc = L.load().amdseg_ponet_global_fwd(_p(hq), _p(hk), hk.stride(0), _p(coef_mean), _p(mask_bias), B, Lseq, H, heads, p, seed, _p(scratch),
+                                          _p(vecq), _p(scores), _p(lse), _p(g), _s())
+    L.check(rc, "amdseg_ponet_global_fwd")
+    return g, vecq, scores, lse
+
+
+def ponet_global_bwd(hk, coef_mean, vecq, scores, lse, dg, dhq, dhk, B, Lseq, H, heads, p=0.0, seed=0, scratch=None, dpd_ws=None):
+    """writes the dHq / dHk column blocks (bf16, same row stride) of the projection gradient"""
+    dev = hk.device
+    if scratch is None:
+        scratch = ponet_global_scratch(B, Lseq, H, heads, dev)
+    if dpd_ws is None:
+        dpd_ws = torch.empty(B, heads, Lseq, dtype=torch.float32, device=dev)
+    assert dhq.stride(0) == dhk.stride(0)
+    rc = L.load().amdseg_ponet_global_bwd(_p(hk), hk.stride(0), _p(coef_mean), _p(vecq), _p(scores), _p(lse), _p(dg), B, Lseq, H, heads, p, seed,
+                                          _p(scratch), _p(dpd_ws), _p(dhq), _p(dhk), dhk.stride(0), _s())
+    L.check(rc, "amdseg_ponet_global_bwd")
+
+
 def ponet_plan(mask_bias, run_start, B, Lseq):
     """work lists of the PoNet pooling kernels for one batch (csrc/ponet.hip): int32 [2 + 2*B*L] on the device, no host sync"""
     work = torch.empty(2 + 2 * B * Lseq, dtype=torch.int32, device=mask_bias.device)

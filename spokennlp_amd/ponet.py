@@ -16,6 +16,7 @@ Engine: the BERT engine with an EXTERNAL token mixer (amdseg_bert_cfg.mixer = 1)
 followed by the shared attention-output / FFN half of the composite layer call.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -93,6 +94,9 @@ class PoNetEncoderEngine(BertEncoderEngine):
             hm[h, h * 64:(h + 1) * 64] = 1.0
         self.headmask = hm
         self.attn_keepmask = False                          # no softmax attention in this encoder
+        # the global aggregation branch as streaming passes of csrc/ponet_global.hip (4 launches forward, 5 backward); AMDSEG_PN_LF_CHAIN=1 keeps
+        # the rounds-1/2 formulation on the Longformer global-row kernels (10 / 12 launches and torch glue; same dropout decisions)
+        self.fused_global = os.environ.get("AMDSEG_PN_LF_CHAIN", "0") != "1" and self.H <= 1024
         self._seg = None
         # amdseg_bert_cfg.pad_guard holds for the pooling mixer too: a padded token n has dctx_n = 0, so dHo_n = 0; it is no valid neighbour /
         # run member, so no local or segment maximum routes a gradient to it; it is a masked key of the global aggregation (p = 0): dproj_n = 0
@@ -113,7 +117,9 @@ class PoNetEncoderEngine(BertEncoderEngine):
             A["pn"] = dict(part=[torch.empty(2 * M, H, dtype=torch.bfloat16, device=dev) for _ in range(nsave)],
                            parg=[dummy for _ in range(nsave)],
                            lf_partials=torch.empty(B * (Lseq // 64) * self.heads * H, dtype=torch.float32, device=dev),
-                           vt=torch.empty(B * H * 32, dtype=torch.bfloat16, device=dev))
+                           vt=torch.empty(B * H * 32, dtype=torch.bfloat16, device=dev),
+                           gscratch=ops.ponet_global_scratch(B, Lseq, H, self.heads, dev) if self.fused_global else None,
+                           dpd=torch.empty(B, self.heads, Lseq, dtype=torch.float32, device=dev) if (train and self.fused_global) else None)
             if train:
                 A["pn"].update(E=torch.empty(M, H, dtype=torch.bfloat16, device=dev), psum=torch.empty(M, H, dtype=torch.float32, device=dev),
                                zeros=torch.zeros(B, 1, Lseq, dtype=torch.float32, device=dev))
@@ -164,11 +170,20 @@ class PoNetEncoderEngine(BertEncoderEngine):
         la, pn = A["layers"][li], A["pn"]
         hq, hk = self._views(la["qkv"], H)[:2]
         rs, re = self._run
+        seed = (int(cfg.seed) * 0x9E3779B1 + 104729 * (i + 1)) & 0x7FFFFFFFFFFFFFFF
+        if self.fused_global and la["qkv"].dtype == torch.bfloat16:
+            with torch.no_grad():
+                g, vecq, scores, lse = ops.ponet_global_fwd(hq, hk, self._coef_mean, A["mask_bias"], B, Lseq, H, heads, cfg.p_attn, seed,
+                                                            pn["gscratch"])
+                ops.ponet_pool_fwd(la["qkv"], self._pool_mb, rs, re, self._work, g, pn["part"][li], pn["parg"][li], la["ctx"], B, Lseq, H)
+            cfg.phase = 2
+            L.check(lib.amdseg_bert_layer_fwd(C.byref(cfg), C.byref(lp), C.byref(acts), mb, i, s), f"amdseg_bert_layer_fwd[{i}].2")
+            cfg.phase = 0
+            return dict(vecq=vecq, scores=scores, lse=lse, g=g, seed=seed) if train else None
         with torch.no_grad():
             qbar = ops.lf_wsum(hq, self._coef_mean, H, pn["lf_partials"])                      # [B, 1, H]
             vecq = (qbar * self.headmask.unsqueeze(0) * 0.125).contiguous()                   # [B, heads, H], head-sliced, / sqrt(d)
             scores = ops.lf_rowvec_dot(hk, vecq, B, Lseq, add_tok=A["mask_bias"])
-            seed = (int(cfg.seed) * 0x9E3779B1 + 104729 * (i + 1)) & 0x7FFFFFFFFFFFFFFF
             p, pd, _sp = ops.lf_softmax_fwd(scores, cfg.p_attn, seed)
             y = ops.lf_wsum(hk, pd, H, pn["lf_partials"])                                      # [B, heads, H]
             g = (y * self.headmask.unsqueeze(0)).sum(1).contiguous()                           # [B, H]
@@ -190,7 +205,18 @@ class PoNetEncoderEngine(BertEncoderEngine):
         hk = self._views(proj, H)[1]
         dhq, dhk = self._views(dproj, H)[:2]
         rs, re = self._run
-        vecq, p, g = saved["vecq"], saved["p"], saved["g"]
+        vecq, g = saved["vecq"], saved["g"]
+        if "lse" in saved:                                     # csrc/ponet_global.hip
+            with torch.no_grad():
+                dg = ops.ponet_pool_bwd(proj, self._pool_mb, rs, re, self._work, g, pn["part"][i], pn["parg"][i], ws["dctx"], dproj, pn["psum"],
+                                        B, Lseq, H)            # [B, H]: sum of dctx * Ho over the valid tokens
+                ops.ponet_global_bwd(hk, self._coef_mean, vecq, saved["scores"], saved["lse"], dg, dhq, dhk, B, Lseq, H, heads, cfg.p_attn,
+                                     saved["seed"], pn["gscratch"], pn["dpd"])
+            cfg.phase = 2
+            L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].2")
+            cfg.phase = 0
+            return
+        p = saved["p"]
         with torch.no_grad():
             dg = ops.ponet_pool_bwd(proj, self._pool_mb, rs, re, self._work, g, pn["part"][i], pn["parg"][i], ws["dctx"], dproj, pn["psum"],
                                     B, Lseq, H).view(B, 1, H)                                  # sum of dctx * Ho over the valid tokens

@@ -252,6 +252,84 @@ def test_dropout_step_deterministic(dev):
     assert abs(vals[0][1] - vals[1][1]) <= 1e-6 * vals[0][1]          # embedding-table grads use fp32 atomics (order may vary)
 
 
+@pytest.mark.parametrize("B,L,H,heads,pdrop", [(2, 64, 128, 2, 0.0), (3, 256, 768, 12, 0.0), (2, 192, 320, 5, 0.0), (2, 256, 768, 12, 0.25)])
+def test_global_aggregation_kernels_vs_torch(dev, B, L, H, heads, pdrop):
+    """csrc/ponet_global.hip (amdseg_ponet_global_fwd / _bwd) against the same arithmetic in torch fp32 with autograd; with dropout, against
+    the rounds-1/2 formulation on the amdseg_lf_* kernels, which drops the same probabilities"""
+    from spokennlp_amd import ops
+    torch.manual_seed(7)
+    ld = 5 * H
+    proj = (torch.randn(B * L, ld, device=dev) * 0.7).bfloat16()
+    hq, hk = proj[:, :H], proj[:, H:2 * H]
+    valid = torch.ones(B, L, device=dev); valid[-1, L - 37:] = 0
+    coef = (valid / valid.sum(1, keepdim=True)).contiguous()
+    mb = ((1 - valid) * -30000.0).contiguous()
+    dg = torch.randn(B, H, device=dev)
+    seed = 12345
+    g, vecq, scores, lse = ops.ponet_global_fwd(hq, hk, coef, mb, B, L, H, heads, pdrop, seed)
+    dproj = torch.zeros(B * L, ld, device=dev).bfloat16()
+    ops.ponet_global_bwd(hk, coef, vecq, scores, lse, dg, dproj[:, :H], dproj[:, H:2 * H], B, L, H, heads, pdrop, seed)
+    assert not dproj[:, 2 * H:].any()                                # only the two column blocks are written
+    if pdrop == 0.0:
+        q32 = hq.float().view(B, L, H).clone().requires_grad_(True)
+        k32 = hk.float().view(B, L, H).clone().requires_grad_(True)
+        qbar = (coef[:, :, None] * q32).sum(1)                        # [B, H]
+        s = torch.einsum("bhd,bjhd->bhj", qbar.view(B, heads, 64), k32.view(B, L, heads, 64)) * 0.125 + mb[:, None, :]
+        p = torch.softmax(s, -1)
+        gref = torch.einsum("bhj,bjhd->bhd", p, k32.view(B, L, heads, 64)).reshape(B, H)
+        assert (g - gref).abs().max().item() < 2e-4 * max(1.0, gref.abs().max().item())
+        assert (scores - s).abs()[s > -1e4].max().item() < 2e-4 and (lse - torch.logsumexp(s, -1)).abs().max().item() < 1e-4
+        gref.backward(dg)
+        for name, got, ref in (("dhq", dproj[:, :H], q32.grad), ("dhk", dproj[:, H:2 * H], k32.grad)):
+            ref = ref.reshape(B * L, H)
+            err = (got.float() - ref).abs().max().item()
+            assert err < 1e-2 * ref.abs().max().item() + 1e-6, (name, err, ref.abs().max().item())     # stored in bf16
+        return
+    # dropout: the lf_* chain with the same seed
+    hm = torch.zeros(heads, H, device=dev)
+    for h in range(heads):
+        hm[h, h * 64:(h + 1) * 64] = 1.0
+    qbar = ops.lf_wsum(hq, coef.view(B, 1, L), H)
+    vq = (qbar * hm.unsqueeze(0) * 0.125).contiguous()
+    sc = ops.lf_rowvec_dot(hk, vq, B, L, add_tok=mb)
+    p, pd, _ = ops.lf_softmax_fwd(sc, pdrop, seed)
+    y = ops.lf_wsum(hk, pd, H)
+    gref = (y * hm.unsqueeze(0)).sum(1)
+    assert (g - gref).abs().max().item() < 5e-4 * max(1.0, gref.abs().max().item())
+    dgh = (dg.view(B, 1, H) * hm.unsqueeze(0)).contiguous()
+    dpd = ops.lf_rowvec_dot(hk, dgh, B, L)
+    ds, pd2 = ops.lf_softmax_bwd(p, dpd, pdrop, seed)
+    ref = torch.zeros(B * L, ld, device=dev).bfloat16()
+    ops.lf_dx_update(ref[:, H:2 * H], pd2, dgh, ds, vq, assign=True)
+    t = ops.lf_wsum(hk, ds, H)
+    dqbar = ((t * hm.unsqueeze(0)).sum(1, keepdim=True) * 0.125).contiguous()
+    ops.lf_dx_update(ref[:, :H], coef.view(B, 1, L).contiguous(), dqbar, torch.zeros(B, 1, L, device=dev), dqbar, assign=True)
+    for c0 in (0, H):
+        a_, b_ = dproj[:, c0:c0 + H].float(), ref[:, c0:c0 + H].float()
+        assert (a_ - b_).abs().max().item() < 2e-2 * b_.abs().max().item() + 1e-6
+
+
+def test_global_aggregation_fused_equals_lf_chain_in_the_model(dev):
+    """the encoder with the fused global branch (default) against AMDSEG_PN_LF_CHAIN-style execution (engine.fused_global = False): same dropout
+    decisions, so the loss agrees to the rounding of g and the gradients to bf16 noise"""
+    ids, am, seg, lab = make_inputs(2, 256, 9, long_run=True)
+    res = {}
+    for fused in (True, False):
+        m, _ = build(dev, dropout=0.1)
+        m = m.to(dev).train(); m.amdseg_seed = 11
+        eng = m.engine()
+        assert eng.fused_global
+        eng.fused_global = fused
+        loss = m(input_ids=ids.to(dev), attention_mask=am.to(dev), segment_ids=seg.to(dev), labels=lab.to(dev), return_dict=False)[0]
+        loss.backward()
+        res[fused] = (loss.item(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert abs(res[True][0] - res[False][0]) < 2e-3 * abs(res[False][0])
+    for n, g0 in res[True][1].items():
+        g1 = res[False][1][n]
+        cos = torch.nn.functional.cosine_similarity(g0.flatten().float(), g1.flatten().float(), dim=0).item()
+        assert cos > 0.995, (n, cos)
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE config 4: PoNet-base, L = 4096
 BASE = dict(vocab_size=21129, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
             max_position_embeddings=4096, type_vocab_size=2)
