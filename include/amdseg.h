@@ -44,6 +44,9 @@ extern "C" {
 #define AMDSEG_EPI_GELU_BWD 4   /* C = (A B^T) * gelu_erf'(R)                                     */
 #define AMDSEG_EPI_BIAS_SPLIT 5 /* C = bf16 hi of (A B^T + bias), C2 = bf16 lo = bf16(value - hi): the result as a split-bf16 image ("parity"
                                    precision, amdseg_sattn_*); M % 256 == 0, N % 256 == 0, K >= 128 (other shapes: AMDSEG_ERR_SHAPE)   */
+#define AMDSEG_EPI_GELU_BWD_SPLIT 6 /* C = bf16 image [M, 3N] (ldc >= 3N) = [hi | hi | lo] of (A B^T) * gelu_erf'(R), R the fp32 pre-activation
+                                   (ldr in floats): the FFN input gradient of "parity" precision straight in the form the next split GEMM and the
+                                   weight gradient read; same shape rule as BIAS_SPLIT; C2 unused                                        */
 #define AMDSEG_EPI_ACT_TANH 0x100 /* OR-ed into BIAS_GELU / GELU_BWD: "gelu_new" (tanh form, BigBird's hidden_act) instead of erf */
 
 typedef void* amdseg_stream_t;  /* hipStream_t */

@@ -643,7 +643,7 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     a.dbg = g_amdseg_dbg;
 #endif
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldc2 = ldc2; a.M = M; a.N = N; a.K = K;
-    a.tiles_m = M / BM; a.tiles_n = N / BN;
+    a.tiles_m = M / BM; a.tiles_n = N / BN; a.dup_off = 0;
     const bool zok = zkend && zguard && zL > 0 && (zL % PP_BM) == 0 && (M % zL) == 0;      // a 256-row tile lies inside one sequence
     a.zkend = zok ? zkend : nullptr; a.zguard = zok ? zguard : nullptr; a.zL = zok ? zL : 0;
     switch (epi) {
@@ -664,6 +664,11 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
             if (!bias || !C2 || out_fp32 || (ldc2 % 8)) return AMDSEG_ERR_ARG;
             if ((M % 256) || (N % 256) || K < 128) return AMDSEG_ERR_SHAPE;
             return amdseg_launch_nt_dp<EPI_BIAS_SPLIT, bf16_t>(a, stream);
+        case 6:                                             // AMDSEG_EPI_GELU_BWD_SPLIT: C = image [M, 3N] = [hi | hi | lo] of (A B^T) * gelu_erf'(R), R fp32
+            if (!R || out_fp32 || (ldr % 4) || ldc < 3 * N || act) return AMDSEG_ERR_ARG;
+            if ((M % 256) || (N % 256) || K < 128) return AMDSEG_ERR_SHAPE;
+            a.C2 = reinterpret_cast<bf16_t*>(C) + 2 * (size_t)N; a.ldc2 = ldc; a.dup_off = N;
+            return amdseg_launch_nt_dp<EPI_GELU_BWD_SPLIT, bf16_t>(a, stream);
     }
     return AMDSEG_ERR_ARG;
 }

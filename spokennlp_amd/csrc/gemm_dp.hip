@@ -163,13 +163,26 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
                 for (int ep = 0; ep < 2; ++ep) rr[ep] = *reinterpret_cast<const uint4*>(a.R + gm * a.ldr + n0 + wc * 64 + ep * 32 + g * 8);
             }
+            float4 ru[2][2];
+            if (EPI == EPI_GELU_BWD_SPLIT) {                   // the fp32 pre-activation
+#pragma unroll
+                for (int ep = 0; ep < 2; ++ep) {
+                    const float* up = reinterpret_cast<const float*>(a.R) + gm * a.ldr + n0 + wc * 64 + ep * 32 + g * 8;
+                    ru[ep][0] = *reinterpret_cast<const float4*>(up); ru[ep][1] = *reinterpret_cast<const float4*>(up + 4);
+                }
+            }
 #pragma unroll
             for (int ep = 0; ep < 2; ++ep) {
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * ep][r]; v[4 + r] = acc[mf][2 * ep + 1][r]; }
                 const size_t col = (size_t)(n0 + wc * 64 + ep * 32 + g * 8);
-                if (EPI == EPI_BIAS_SPLIT) {                   // x = hi + lo, both bf16: C <- hi, C2 <- lo (same row / column)
+                if (EPI == EPI_GELU_BWD_SPLIT) {
+                    const float uu[8] = {ru[ep][0].x, ru[ep][0].y, ru[ep][0].z, ru[ep][0].w, ru[ep][1].x, ru[ep][1].y, ru[ep][1].z, ru[ep][1].w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] *= gelu_erf_grad(uu[q]);
+                }
+                if (EPI == EPI_BIAS_SPLIT || EPI == EPI_GELU_BWD_SPLIT) {   // x = hi + lo, both bf16: C <- hi, C2 <- lo (same row / column)
                     uint4 hi; hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]); hi.z = pack2bf(v[4], v[5]); hi.w = pack2bf(v[6], v[7]);
                     const uint32_t hw[4] = {hi.x, hi.y, hi.z, hi.w};
                     uint4 lo;
@@ -178,6 +191,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                     for (int q = 0; q < 4; ++q) lw[q] = pack2bf(v[2 * q] - __uint_as_float(hw[q] << 16), v[2 * q + 1] - __uint_as_float(hw[q] & 0xffff0000u));
                     lo.x = lw[0]; lo.y = lw[1]; lo.z = lw[2]; lo.w = lw[3];
                     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + gm * a.ldc + col) = hi;
+                    if (EPI == EPI_GELU_BWD_SPLIT) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + gm * a.ldc + col + a.dup_off) = hi;
                     *reinterpret_cast<uint4*>(a.C2 + gm * a.ldc2 + col) = lo;
                     continue;
                 }
@@ -312,7 +326,7 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
 #define DP_INST(E, T) template int amdseg_launch_nt_dp<E, T>(const GemmNTArgs&, hipStream_t);
 DP_INST(EPI_NONE, bf16_t) DP_INST(EPI_NONE, float) DP_INST(EPI_BIAS, bf16_t) DP_INST(EPI_BIAS, float) DP_INST(EPI_BIAS_GELU, bf16_t)
 DP_INST(EPI_ADD_RES, bf16_t) DP_INST(EPI_ADD_RES, float) DP_INST(EPI_GELU_BWD, bf16_t)
-DP_INST(EPI_BIAS_GELU_TANH, bf16_t) DP_INST(EPI_GELU_BWD_TANH, bf16_t) DP_INST(EPI_BIAS_SPLIT, bf16_t)
+DP_INST(EPI_BIAS_GELU_TANH, bf16_t) DP_INST(EPI_GELU_BWD_TANH, bf16_t) DP_INST(EPI_BIAS_SPLIT, bf16_t) DP_INST(EPI_GELU_BWD_SPLIT, bf16_t)
 
 
 // ==================================================================================================== gemm_tn, deep pipeline

@@ -7,8 +7,10 @@
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_BWD = 4,
        EPI_BIAS_GELU_TANH = 5, EPI_GELU_BWD_TANH = 6,       // kernel template values only: the two GELU epilogues with gelu_new
-       EPI_BIAS_SPLIT = 7 };                                // C = bf16 hi of (A B^T + bias), C2 = bf16 lo = bf16(x - hi): the result as a split image
+       EPI_BIAS_SPLIT = 7,                                  // C = bf16 hi of (A B^T + bias), C2 = bf16 lo = bf16(x - hi): the result as a split image
                                                             // ("parity" precision: the consumer is another split-bf16 product), 256-wide dp kernel only
+       EPI_GELU_BWD_SPLIT = 8 };                            // x = (A B^T) * gelu_erf'(R), R fp32: hi -> C and C + dup_off columns, lo -> C2 (the [hi | hi | lo]
+                                                            // image the next split GEMM and the weight gradient read); 256-wide dp kernel only
 // the kernels are instantiated on the extended value EPIX; EPI = what the epilogue does, ACT = which GELU (a compile-time constant:
 // a run-time flag became one scalar branch PER ELEMENT in the epilogue)
 #define EPI_BASE(X) ((X) == EPI_BIAS_GELU_TANH ? EPI_BIAS_GELU : (X) == EPI_GELU_BWD_TANH ? EPI_GELU_BWD : (X))
@@ -19,6 +21,7 @@ struct GemmNTArgs {
     int lda, ldb, ldc, ldr, ldc2;
     int M, N, K;
     int tiles_m, tiles_n;
+    int dup_off;                                            // EPI_GELU_BWD_SPLIT: second copy of the hi block, in columns from C
     // optional (deep-pipeline kernel only): rows >= zkend[row / zL] of A are known to be exact zeros (activation gradients of trailing
     // padding) unless *zguard != 0 -- a 256-row tile made of such rows skips its K loop and runs the epilogue on zero accumulators
     const int* zkend; const int* zguard; int zL;

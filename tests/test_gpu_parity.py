@@ -74,6 +74,30 @@ def test_gemm_bias_split_epilogue_writes_the_split_image(dev):
     assert rc == 1001                                       # AMDSEG_ERR_SHAPE
 
 
+def test_gemm_gelu_bwd_split_epilogue_writes_the_image(dev):
+    """AMDSEG_EPI_GELU_BWD_SPLIT: the image [hi | hi | lo] of (A B^T) * gelu_erf'(u), u fp32 -- what GEMM (fp32 out) + torch's exact GELU derivative
+    + amdseg_split3 produce, in one launch"""
+    from spokennlp_amd import lib as L, ops
+    torch.manual_seed(4)
+    M, N, K = 512, 768, 384
+    A = torch.randn(M, K, device=dev).bfloat16(); B = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    u = torch.randn(M, N, device=dev) * 1.5
+    img = torch.zeros(M, 3 * N, dtype=torch.bfloat16, device=dev)
+    s_ = torch.cuda.current_stream().cuda_stream
+    rc = L.load().amdseg_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, img.data_ptr(), 3 * N, M, N, K, 6, None, u.data_ptr(), N, None, 0, 0, s_)
+    assert rc == 0
+    y = ops.gemm_nt(A, B, ops.EPI_NONE, out_dtype=torch.float32)
+    ud = u.double()
+    grad = 0.5 * (1 + torch.erf(ud / 2 ** 0.5)) + ud * torch.exp(-0.5 * ud * ud) / (2 * torch.pi) ** 0.5
+    want = y.double() * grad
+    assert torch.equal(img[:, :N], img[:, N:2 * N])
+    got = img[:, :N].double() + img[:, 2 * N:].double()
+    assert (got - want).abs().max().item() < 3e-5 * want.abs().max().item()        # hi + lo carries 16 mantissa bits; erff / expf in fp32
+    assert (img[:, 2 * N:].float().abs() <= img[:, :N].float().abs() * 2.0 ** -7 + 1e-30).all()        # lo is the rounding residue of hi
+    rc = L.load().amdseg_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, img.data_ptr(), 3 * N, 384, 128, K, 6, None, u.data_ptr(), N, None, 0, 0, s_)
+    assert rc == 1001
+
+
 def _attn_ref(qkv, mask_bias, B, Lq, heads):
     H = heads * 64
     q, k, v = [t.view(B, Lq, heads, 64).transpose(1, 2) for t in qkv.view(B, Lq, 3 * H).split(H, -1)]
