@@ -43,10 +43,12 @@ extern "C" {
 #define AMDSEG_EPI_ADD_RES 3    /* C = A B^T + R                                                  */
 #define AMDSEG_EPI_GELU_BWD 4   /* C = (A B^T) * gelu_erf'(R)                                     */
 #define AMDSEG_EPI_BIAS_SPLIT 5 /* C = bf16 hi of (A B^T + bias), C2 = bf16 lo = bf16(value - hi): the result as a split-bf16 image ("parity"
-                                   precision, amdseg_sattn_*); M % 256 == 0, N % 256 == 0, K >= 128 (other shapes: AMDSEG_ERR_SHAPE)   */
+                                   precision, amdseg_sattn_*); M % 256 == 0, N % 256 == 0, K >= 128 (other shapes: AMDSEG_ERR_SHAPE); bias may be NULL   */
 #define AMDSEG_EPI_GELU_BWD_SPLIT 6 /* C = bf16 image [M, 3N] (ldc >= 3N) = [hi | hi | lo] of (A B^T) * gelu_erf'(R), R the fp32 pre-activation
                                    (ldr in floats): the FFN input gradient of "parity" precision straight in the form the next split GEMM and the
                                    weight gradient read; same shape rule as BIAS_SPLIT; C2 unused                                        */
+#define AMDSEG_EPI_BIAS_GELU_SPLIT 7 /* out_fp32 = 1: C = A B^T + bias (fp32 pre-activation), C2 = bf16 image [M, 3N] (ldc2 >= 3N) = [hi | hi | lo] of
+                                   gelu_erf(C): the FFN activation of "parity" precision in the form the next split GEMM reads; same shape rule */
 #define AMDSEG_EPI_ACT_TANH 0x100 /* OR-ed into BIAS_GELU / GELU_BWD: "gelu_new" (tanh form, BigBird's hidden_act) instead of erf */
 
 typedef void* amdseg_stream_t;  /* hipStream_t */
@@ -295,6 +297,10 @@ int amdseg_scale(float* x, size_t n, const float* coef, amdseg_stream_t stream);
 int amdseg_split3(const float* x, int ld, void* out_bf16, int M, int K, int order, amdseg_stream_t stream);
 /* W [N,K] fp32 -> [K, 3N] = [Wt_hi | Wt_lo | Wt_hi]: the weight image of the dgrad dX = dY . W written as an NT product */
 int amdseg_split3_transpose(const float* W, void* out_bf16, int N, int K, amdseg_stream_t stream);
+/* both weight images of n matrices in one launch (host arrays of device pointers, as amdseg_cast_transpose_batched): out[i] [N_i, 3K_i] =
+ * amdseg_split3(order 1), out_t[i] [K_i, 3N_i] = amdseg_split3_transpose; N_i, K_i multiples of 64; out or out_t may be NULL */
+int amdseg_split3_weights_batched(int n, const float* const* W, void* const* out, void* const* out_t, const int* N, const int* K,
+                                  amdseg_stream_t stream);
 /* fp32 attention ([hf] models/bert/modeling_bert.py:111-136) with saved log-sum-exp and hash dropout; qkv [M,3H] fp32, head_dim 64 */
 int amdseg_pattn_fwd(const float* qkv, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale,
                      float p_drop, uint64_t seed, amdseg_stream_t stream);

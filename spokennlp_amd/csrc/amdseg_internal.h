@@ -103,6 +103,7 @@ int amdseg_lf_global_bwd_w_impl(const void* x, int x_dtype, const float* qg, con
                                 const float* dqg, float* dWq, float* dbq, float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads,
                                 hipStream_t s);
 
+int amdseg_split3_weights_batched_impl(int n, const float* const* W, void* const* out, void* const* out_t, const int* N, const int* K, hipStream_t s);
 size_t amdseg_ponet_global_scratch_floats_impl(int B, int L, int H, int heads);
 int amdseg_ponet_global_fwd_impl(const void* hq, const void* hk, int ld, const float* coef_mean, const float* mask_bias, int B, int L, int H,
                                  int heads, float p, uint64_t seed, float* scratch, float* vecq, float* scores, float* lse, float* g,

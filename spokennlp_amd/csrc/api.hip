@@ -188,6 +188,10 @@ int amdseg_cast_transpose_batched(int n, const float* const* W, void* const* Wb,
                                   amdseg_stream_t stream) {
     return amdseg_cast_transpose_batched_impl(n, W, Wb, Wt, N, K, S(stream));
 }
+int amdseg_split3_weights_batched(int n, const float* const* W, void* const* out, void* const* out_t, const int* N, const int* K,
+                                  amdseg_stream_t stream) {
+    return amdseg_split3_weights_batched_impl(n, W, out, out_t, N, K, S(stream));
+}
 int amdseg_cast_transpose_batched_if(int n, const float* const* W, void* const* Wb, void* const* Wt, const int* N, const int* K,
                                      const int32_t* only_if, amdseg_stream_t stream) {
     return amdseg_cast_transpose_batched_impl(n, W, Wb, Wt, N, K, S(stream), only_if);
@@ -383,8 +387,12 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
                                       site_seed(c->seed, li, 1), AMDSEG_F32, s));
         RET_IF(amdseg_split3_impl((const float*)a->x1, H, a->x1_s, M, H, 0, s));
-        RET_IF(amdseg_gemm_nt_impl(a->x1_s, 3 * H, p->w1, 3 * H, a->u, I, M, I, 3 * H, AMDSEG_EPI_BIAS, p->b1, nullptr, 0, nullptr, 0, 1, s));
-        RET_IF(amdseg_gelu_fwd_split_impl((const float*)a->u, a->h_s, M, I, c->act, s));
+        if (c->act == 0 && (M % 256) == 0 && (I % 256) == 0)       // u (fp32, read by backward) and the image of gelu(u) from one epilogue
+            RET_IF(amdseg_gemm_nt_impl(a->x1_s, 3 * H, p->w1, 3 * H, a->u, I, M, I, 3 * H, AMDSEG_EPI_BIAS_GELU_SPLIT, p->b1, nullptr, 0, a->h_s, 3 * I, 1, s));
+        else {
+            RET_IF(amdseg_gemm_nt_impl(a->x1_s, 3 * H, p->w1, 3 * H, a->u, I, M, I, 3 * H, AMDSEG_EPI_BIAS, p->b1, nullptr, 0, nullptr, 0, 1, s));
+            RET_IF(amdseg_gelu_fwd_split_impl((const float*)a->u, a->h_s, M, I, c->act, s));
+        }
         RET_IF(amdseg_gemm_nt_impl(a->h_s, 3 * I, p->w2, 3 * I, a->z2, H, M, H, 3 * I, AMDSEG_EPI_BIAS, p->b2, nullptr, 0, nullptr, 0, 1, s));
         RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, c->p_hidden,
                                       site_seed(c->seed, li, 2), AMDSEG_F32, s));
@@ -459,6 +467,8 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     if (c->dtype == AMDSEG_F32S) {
         // "parity" precision: same dataflow in fp32; every GEMM operand goes through its split image (csrc/parity.hip)
         if (!w->d_out_s || !w->du_s || !w->d_ao_s || !w->dqkv_s || !a->xs || !a->ctx_s || !a->x1_s || !a->h_s) return AMDSEG_ERR_ARG;
+        // full attention on the split kernels: nobody reads d(ctx) in fp32 (a Longformer caller does, between the phases: its global row)
+        const bool dctx_image = a->qkv_s && w->dctx_s && (c->p_attn == 0.f || a->keep) && c->window == 0 && (M % 256) == 0 && (H % 256) == 0;
         if (PHASE1(c)) {
             RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, part_ln2, g->ln2_g, g->ln2_b,
                                       g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, AMDSEG_F32, s));
@@ -479,11 +489,15 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
             RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, part_ln1, g->ln1_g,
                                       g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, AMDSEG_F32, s));
             RET_IF(amdseg_split3_impl((const float*)d_ao, H, w->d_ao_s, M, H, 0, s));
+            if (dctx_image)      // d(ctx) straight as the hi / lo blocks the split attention backward reads (no fp32 d(ctx), no split pass)
+                RET_IF(amdseg_gemm_nt_impl(w->d_ao_s, 3 * H, p->wo_t, 3 * H, w->dctx_s, 3 * H, M, H, 3 * H, AMDSEG_EPI_BIAS_SPLIT, nullptr, nullptr, 0,
+                                           (bf16_t*)w->dctx_s + 2 * H, 3 * H, 0, s));
+            else
             RET_IF(amdseg_gemm_nt_impl(w->d_ao_s, 3 * H, p->wo_t, 3 * H, w->dctx, H, M, H, 3 * H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1, s));
         }
         if (PHASE2(c)) {
             if (a->qkv_s && w->dctx_s && (c->p_attn == 0.f || a->keep)) {
-                RET_IF(amdseg_split3_impl((const float*)w->dctx, H, w->dctx_s, M, H, 0, s));
+                if (!dctx_image) RET_IF(amdseg_split3_impl((const float*)w->dctx, H, w->dctx_s, M, H, 0, s));
                 // ... whose backward writes d(q|k|v) as the [hi | hi | lo] image the next GEMMs read; the bias gradient is summed from the image
                 RET_IF(amdseg_sattn_bwd_impl(a->qkv_s, 9 * H, 6 * H, mask_bias, (const float*)a->ctx, w->dctx_s, 3 * H, 2 * H, a->lse, w->delta,
                                              nullptr, c->B, c->L, c->heads, 0.125f, c->p_attn, c->p_attn > 0.f ? a->keep : nullptr, c->window,

@@ -661,7 +661,7 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
             if (!R || out_fp32 || (ldr % 8)) return AMDSEG_ERR_ARG;
             return act ? launch_nt<EPI_GELU_BWD_TANH, bf16_t>(a, stream) : launch_nt<EPI_GELU_BWD, bf16_t>(a, stream);
         case 5:                                             // AMDSEG_EPI_BIAS_SPLIT: the 256 x 256 deep-pipeline kernel only
-            if (!bias || !C2 || out_fp32 || (ldc2 % 8)) return AMDSEG_ERR_ARG;
+            if (!C2 || out_fp32 || (ldc2 % 8)) return AMDSEG_ERR_ARG;                 // bias may be NULL (no bias added)
             if ((M % 256) || (N % 256) || K < 128) return AMDSEG_ERR_SHAPE;
             return amdseg_launch_nt_dp<EPI_BIAS_SPLIT, bf16_t>(a, stream);
         case 6:                                             // AMDSEG_EPI_GELU_BWD_SPLIT: C = image [M, 3N] = [hi | hi | lo] of (A B^T) * gelu_erf'(R), R fp32
@@ -669,6 +669,11 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
             if ((M % 256) || (N % 256) || K < 128) return AMDSEG_ERR_SHAPE;
             a.C2 = reinterpret_cast<bf16_t*>(C) + 2 * (size_t)N; a.ldc2 = ldc; a.dup_off = N;
             return amdseg_launch_nt_dp<EPI_GELU_BWD_SPLIT, bf16_t>(a, stream);
+        case 7:                                             // AMDSEG_EPI_BIAS_GELU_SPLIT: C fp32 pre-activation, C2 = image [M, 3N] of gelu_erf(C)
+            if (!bias || !C2 || !out_fp32 || (ldc2 % 8) || ldc2 < 3 * N || act) return AMDSEG_ERR_ARG;
+            if ((M % 256) || (N % 256) || K < 128) return AMDSEG_ERR_SHAPE;
+            a.dup_off = N;
+            return amdseg_launch_nt_dp<EPI_BIAS_GELU_SPLIT, float>(a, stream);
     }
     return AMDSEG_ERR_ARG;
 }

@@ -139,14 +139,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     // ---- epilogue.  Lane owns row m = mf*16 + i16 and columns nf*16 + g*4 .. +4 of the wave tile.  bf16 results go through a
     // wave-private 16-KiB LDS image (2 x [64 rows][128 B], swizzled) so every global store instruction writes 8 full 128-B lines.
     float4 bv[NF];
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT) {
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT || EPI == EPI_BIAS_GELU_SPLIT) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
-            bv[nf] = *reinterpret_cast<const float4*>(a.bias + n0 + wc * WN + (NF == 4 ? (nf >> 1) * 32 + g * 8 + (nf & 1) * 4 : nf * 16 + g * 4));
+            bv[nf] = (EPI == EPI_BIAS_SPLIT && !a.bias) ? make_float4(0.f, 0.f, 0.f, 0.f)      // BIAS_SPLIT without a bias: the plain product as an image
+                   : *reinterpret_cast<const float4*>(a.bias + n0 + wc * WN + (NF == 4 ? (nf >> 1) * 32 + g * 8 + (nf & 1) * 4 : nf * 16 + g * 4));
     }
     // the bias goes INTO the accumulators once: recomputing acc + bias in both passes of BIAS_GELU made the compiler keep all
     // 128 sums of pass 0 alive for pass 1 (common subexpression) next to the 128 accumulators -> 116 spilled VGPRs
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT) {
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT || EPI == EPI_BIAS_GELU_SPLIT) {
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
@@ -177,6 +178,23 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * ep][r]; v[4 + r] = acc[mf][2 * ep + 1][r]; }
                 const size_t col = (size_t)(n0 + wc * 64 + ep * 32 + g * 8);
+                if (EPI == EPI_BIAS_GELU_SPLIT) {              // the fp32 pre-activation, then the activation as a split image
+                    float* dst = reinterpret_cast<float*>(a.C) + gm * a.ldc + col;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
+                    uint4 hi; hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]); hi.z = pack2bf(v[4], v[5]); hi.w = pack2bf(v[6], v[7]);
+                    const uint32_t hw[4] = {hi.x, hi.y, hi.z, hi.w};
+                    uint4 lo;
+                    uint32_t lw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) lw[q] = pack2bf(v[2 * q] - __uint_as_float(hw[q] << 16), v[2 * q + 1] - __uint_as_float(hw[q] & 0xffff0000u));
+                    lo.x = lw[0]; lo.y = lw[1]; lo.z = lw[2]; lo.w = lw[3];
+                    bf16_t* img = a.C2 + gm * a.ldc2 + col;
+                    *reinterpret_cast<uint4*>(img) = hi; *reinterpret_cast<uint4*>(img + a.dup_off) = hi; *reinterpret_cast<uint4*>(img + 2 * a.dup_off) = lo;
+                    continue;
+                }
                 if (EPI == EPI_GELU_BWD_SPLIT) {
                     const float uu[8] = {ru[ep][0].x, ru[ep][0].y, ru[ep][0].z, ru[ep][0].w, ru[ep][1].x, ru[ep][1].y, ru[ep][1].z, ru[ep][1].w};
 #pragma unroll
@@ -327,6 +345,7 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
 DP_INST(EPI_NONE, bf16_t) DP_INST(EPI_NONE, float) DP_INST(EPI_BIAS, bf16_t) DP_INST(EPI_BIAS, float) DP_INST(EPI_BIAS_GELU, bf16_t)
 DP_INST(EPI_ADD_RES, bf16_t) DP_INST(EPI_ADD_RES, float) DP_INST(EPI_GELU_BWD, bf16_t)
 DP_INST(EPI_BIAS_GELU_TANH, bf16_t) DP_INST(EPI_GELU_BWD_TANH, bf16_t) DP_INST(EPI_BIAS_SPLIT, bf16_t) DP_INST(EPI_GELU_BWD_SPLIT, bf16_t)
+DP_INST(EPI_BIAS_GELU_SPLIT, float)
 
 
 // ==================================================================================================== gemm_tn, deep pipeline

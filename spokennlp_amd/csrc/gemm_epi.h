@@ -9,7 +9,8 @@ enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_
        EPI_BIAS_GELU_TANH = 5, EPI_GELU_BWD_TANH = 6,       // kernel template values only: the two GELU epilogues with gelu_new
        EPI_BIAS_SPLIT = 7,                                  // C = bf16 hi of (A B^T + bias), C2 = bf16 lo = bf16(x - hi): the result as a split image
                                                             // ("parity" precision: the consumer is another split-bf16 product), 256-wide dp kernel only
-       EPI_GELU_BWD_SPLIT = 8 };                            // x = (A B^T) * gelu_erf'(R), R fp32: hi -> C and C + dup_off columns, lo -> C2 (the [hi | hi | lo]
+       EPI_GELU_BWD_SPLIT = 8,
+       EPI_BIAS_GELU_SPLIT = 9 };                           // C (fp32) = A B^T + bias (the pre-activation backward reads); C2 = bf16 image [hi | hi | lo] of gelu_erf(that)                            // x = (A B^T) * gelu_erf'(R), R fp32: hi -> C and C + dup_off columns, lo -> C2 (the [hi | hi | lo]
                                                             // image the next split GEMM and the weight gradient read); 256-wide dp kernel only
 // the kernels are instantiated on the extended value EPIX; EPI = what the epilogue does, ACT = which GELU (a compile-time constant:
 // a run-time flag became one scalar branch PER ELEMENT in the epilogue)

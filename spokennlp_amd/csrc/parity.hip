@@ -57,6 +57,54 @@ __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __re
     }
 }
 
+// every weight matrix of the model in ONE launch: W_i [N, K] fp32 -> out_i [N, 3K] = [hi | lo | hi] (forward B' operand) and
+// out_t_i [K, 3N] = [Wt_hi | Wt_lo | Wt_hi] (dgrad B' operand).  (One split3 + one split3_transpose launch per matrix were ~100 launches of
+// ~6 us behind every optimiser step.)
+#define SW_MAXB 64
+struct SplitWeightsBatch {
+    const float* W[SW_MAXB]; bf16_t* out[SW_MAXB]; bf16_t* out_t[SW_MAXB];
+    int N[SW_MAXB], K[SW_MAXB], tile0[SW_MAXB + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void split3_weights_batched_kernel(SplitWeightsBatch b) {
+    __shared__ bf16_t th[64][66], tl[64][66];
+    int m = 0;
+    while (m + 1 < b.n && (int)blockIdx.x >= b.tile0[m + 1]) ++m;
+    const float* W = b.W[m]; bf16_t* out = b.out[m]; bf16_t* out_t = b.out_t[m];
+    const int N = b.N[m], K = b.K[m], t = blockIdx.x - b.tile0[m], kt = K / 64;
+    const int n0 = (t / kt) * 64, k0 = (t % kt) * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty * 4 + i;
+        const float4 v = *reinterpret_cast<const float4*>(W + (size_t)(n0 + r) * K + k0 + tx * 4);
+        uint2 hi, lo;
+        split4(v, hi, lo);
+        th[r][tx * 4 + 0] = (bf16_t)(hi.x & 0xffffu); th[r][tx * 4 + 1] = (bf16_t)(hi.x >> 16);
+        th[r][tx * 4 + 2] = (bf16_t)(hi.y & 0xffffu); th[r][tx * 4 + 3] = (bf16_t)(hi.y >> 16);
+        tl[r][tx * 4 + 0] = (bf16_t)(lo.x & 0xffffu); tl[r][tx * 4 + 1] = (bf16_t)(lo.x >> 16);
+        tl[r][tx * 4 + 2] = (bf16_t)(lo.y & 0xffffu); tl[r][tx * 4 + 3] = (bf16_t)(lo.y >> 16);
+        if (out) {
+            bf16_t* o = out + (size_t)(n0 + r) * 3 * K + k0 + tx * 4;
+            *reinterpret_cast<uint2*>(o) = hi; *reinterpret_cast<uint2*>(o + K) = lo; *reinterpret_cast<uint2*>(o + 2 * K) = hi;
+        }
+    }
+    __syncthreads();
+    if (out_t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = ty * 4 + i;
+            uint2 hi, lo;
+            hi.x = (uint32_t)th[tx * 4 + 0][kr] | ((uint32_t)th[tx * 4 + 1][kr] << 16);
+            hi.y = (uint32_t)th[tx * 4 + 2][kr] | ((uint32_t)th[tx * 4 + 3][kr] << 16);
+            lo.x = (uint32_t)tl[tx * 4 + 0][kr] | ((uint32_t)tl[tx * 4 + 1][kr] << 16);
+            lo.y = (uint32_t)tl[tx * 4 + 2][kr] | ((uint32_t)tl[tx * 4 + 3][kr] << 16);
+            bf16_t* o = out_t + (size_t)(k0 + kr) * 3 * N + n0 + tx * 4;
+            *reinterpret_cast<uint2*>(o) = hi; *reinterpret_cast<uint2*>(o + N) = lo; *reinterpret_cast<uint2*>(o + 2 * N) = hi;
+        }
+    }
+}
+
 // h = gelu(u) written directly as the split image [M, 3I] (the fp32 h itself is never needed: W2's GEMM and its weight gradient
 // read the image);  backward: du = du * gelu'(u) in place (fp32, for the bias gradient) + its split image
 __device__ __forceinline__ float gelu_exact(float x, int act) {
@@ -116,6 +164,24 @@ int amdseg_split3_transpose_impl(const float* W, void* out, int N, int K, hipStr
     if (!W || !out) return AMDSEG_ERR_ARG;
     if (N <= 0 || K <= 0 || (N % 32) || (K % 32)) return AMDSEG_ERR_SHAPE;
     hipLaunchKernelGGL(split3_transpose_kernel, dim3(K / 32, N / 32), dim3(256), 0, s, W, (bf16_t*)out, N, K);
+    return amdseg_launch_status();
+}
+int amdseg_split3_weights_batched_impl(int n, const float* const* W, void* const* out, void* const* out_t, const int* N, const int* K, hipStream_t s) {
+    if (n <= 0 || !W || !N || !K || (!out && !out_t)) return AMDSEG_ERR_ARG;
+    for (int base = 0; base < n; base += SW_MAXB) {
+        SplitWeightsBatch b = {};
+        b.n = n - base < SW_MAXB ? n - base : SW_MAXB;
+        int tiles = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const int j = base + i;
+            if (!W[j] || N[j] <= 0 || K[j] <= 0 || (N[j] % 64) || (K[j] % 64)) return AMDSEG_ERR_SHAPE;
+            b.W[i] = W[j]; b.out[i] = out ? (bf16_t*)out[j] : nullptr; b.out_t[i] = out_t ? (bf16_t*)out_t[j] : nullptr;
+            b.N[i] = N[j]; b.K[i] = K[j]; b.tile0[i] = tiles;
+            tiles += (N[j] / 64) * (K[j] / 64);
+        }
+        b.tile0[b.n] = tiles;
+        hipLaunchKernelGGL(split3_weights_batched_kernel, dim3(tiles), dim3(256), 0, s, b);
+    }
     return amdseg_launch_status();
 }
 int amdseg_gelu_fwd_split_impl(const float* u, void* hs, int M, int I, int act, hipStream_t s) {

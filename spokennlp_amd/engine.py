@@ -356,6 +356,24 @@ class BertEncoderEngine:
 
     def _split_parity_weights(self):
         H = self.H
+        if (H % 64) == 0 and (self.I % 64) == 0:
+            # one launch for every matrix of the model (amdseg_split3_weights_batched)
+            if getattr(self, "_sw_table", None) is None:
+                Ws, outs, outts, Ns, Ks = [], [], [], [], []
+                for i in range(self.nlayers):
+                    t = self._parity[i]
+                    for W, k in ((self.fp.view(self.fp.flat_p, self.fp.lp(i, self.proj_w0), (3 * H, H)), "wqkv"),
+                                 (self._p(self.fp.flat_p, i, "attention.output.dense.weight"), "wo"),
+                                 (self._p(self.fp.flat_p, i, "intermediate.dense.weight"), "w1"),
+                                 (self._p(self.fp.flat_p, i, "output.dense.weight"), "w2")):
+                        Ws.append(W.data_ptr()); outs.append(t[k].data_ptr()); outts.append(t[k + "_t"].data_ptr())
+                        Ns.append(W.shape[0]); Ks.append(W.shape[1])
+                n = len(Ws)
+                self._sw_table = (n, (C.c_void_p * n)(*Ws), (C.c_void_p * n)(*outs), (C.c_void_p * n)(*outts), (C.c_int * n)(*Ns), (C.c_int * n)(*Ks))
+            n, pw, po, pt, pn, pk = self._sw_table
+            L.check(L.load().amdseg_split3_weights_batched(n, pw, po, pt, pn, pk, torch.cuda.current_stream().cuda_stream),
+                    "amdseg_split3_weights_batched")
+            return
         for i in range(self.nlayers):
             t = self._parity[i]
             mats = ((self.fp.view(self.fp.flat_p, self.fp.lp(i, self.proj_w0), (3 * H, H)), "wqkv"),

@@ -96,6 +96,7 @@ _PROTOS = {
     "amdseg_debug_force_small_tile": [i32],
     "amdseg_split3": [vp, i32, vp, i32, i32, i32, vp],
     "amdseg_split3_transpose": [vp, vp, i32, i32, vp],
+    "amdseg_split3_weights_batched": [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp],
     "amdseg_pattn_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_pattn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_lf_global_q": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],

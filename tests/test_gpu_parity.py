@@ -98,6 +98,49 @@ def test_gemm_gelu_bwd_split_epilogue_writes_the_image(dev):
     assert rc == 1001
 
 
+def test_gemm_bias_gelu_split_epilogue_and_biasless_split(dev):
+    """AMDSEG_EPI_BIAS_GELU_SPLIT: C = fp32 pre-activation, C2 = image of gelu_erf(C);  AMDSEG_EPI_BIAS_SPLIT with bias == NULL: the plain product"""
+    from spokennlp_amd import lib as L, ops
+    torch.manual_seed(6)
+    M, N, K = 512, 768, 384
+    A = torch.randn(M, K, device=dev).bfloat16(); B = (torch.randn(N, K, device=dev) * 0.1).bfloat16(); bias = torch.randn(N, device=dev)
+    u = torch.empty(M, N, device=dev)
+    img = torch.zeros(M, 3 * N, dtype=torch.bfloat16, device=dev)
+    s_ = torch.cuda.current_stream().cuda_stream
+    rc = L.load().amdseg_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, u.data_ptr(), N, M, N, K, 7, bias.data_ptr(), None, 0, img.data_ptr(), 3 * N, 1, s_)
+    assert rc == 0
+    ref = ops.gemm_nt(A, B, ops.EPI_BIAS, bias=bias, out_dtype=torch.float32)
+    assert torch.equal(u, ref)
+    want = torch.nn.functional.gelu(ref.double())
+    assert torch.equal(img[:, :N], img[:, N:2 * N])
+    got = img[:, :N].double() + img[:, 2 * N:].double()
+    assert (got - want).abs().max().item() < 3e-5 * want.abs().max().item()
+    img2 = torch.zeros(M, 3 * N, dtype=torch.bfloat16, device=dev)
+    rc = L.load().amdseg_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, img2.data_ptr(), 3 * N, M, N, K, 5, None, None, 0, img2[:, 2 * N:].data_ptr(), 3 * N, 0, s_)
+    assert rc == 0
+    plain = ops.gemm_nt(A, B, ops.EPI_NONE, out_dtype=torch.float32)
+    w3 = ops.split3(plain, torch.empty(M, 3 * N, dtype=torch.bfloat16, device=dev), order=0)
+    assert torch.equal(img2[:, :N], w3[:, :N]) and torch.equal(img2[:, 2 * N:], w3[:, 2 * N:])
+
+
+def test_split3_weights_batched_equals_the_single_matrix_calls(dev):
+    from spokennlp_amd import lib as L, ops
+    import ctypes as C
+    torch.manual_seed(8)
+    shapes = [(192, 64), (64, 256), (128, 128)]
+    Ws = [torch.randn(n, k, device=dev) for n, k in shapes]
+    outs = [torch.zeros(n, 3 * k, dtype=torch.bfloat16, device=dev) for n, k in shapes]
+    outts = [torch.zeros(k, 3 * n, dtype=torch.bfloat16, device=dev) for n, k in shapes]
+    n = len(Ws)
+    vp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
+    rc = L.load().amdseg_split3_weights_batched(n, vp(Ws), vp(outs), vp(outts), (C.c_int * n)(*[s[0] for s in shapes]), (C.c_int * n)(*[s[1] for s in shapes]),
+                                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    for W, o, ot in zip(Ws, outs, outts):
+        assert torch.equal(o, ops.split3(W, torch.empty_like(o), order=1))
+        assert torch.equal(ot, ops.split3_transpose(W, torch.empty_like(ot)))
+
+
 def _attn_ref(qkv, mask_bias, B, Lq, heads):
     H = heads * 64
     q, k, v = [t.view(B, Lq, heads, 64).transpose(1, 2) for t in qkv.view(B, Lq, 3 * H).split(H, -1)]
