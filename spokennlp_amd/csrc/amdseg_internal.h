@@ -73,7 +73,8 @@ int amdseg_attn_keepmask_impl(void* keep, int B, int L, int heads, float p, uint
                               int nglobal = 0);
 // attention_split.hip: "parity" precision attention on split-bf16 images (hi at column 0, lo at column lo_*) -- full and band
 int amdseg_sattn_fwd_impl(const void* qs, int ldq, int lo_q, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale,
-                          float p, const void* keep, int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr);
+                          float p, const void* keep, int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,
+                          void* ctx_image = nullptr);
 int amdseg_sattn_bwd_impl(const void* qs, int ldq, int lo_q, const float* mask_bias, const float* ctx, const void* dos, int ldo, int lo_o,
                           const float* lse, float* delta, float* dqkv, int B, int L, int heads, float scale, float p, const void* keep, int window,
                           int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr, const int* qguard = nullptr,

@@ -343,6 +343,13 @@ static int check_cfg(const amdseg_bert_cfg* c) {
 // Backward only: 6 = second part WITHOUT the grouped weight-gradient GEMM, 4 = that GEMM alone -- so a caller can run the
 // weight gradients of layer i on a second stream under the backward of layer i-1 (they are off the critical path: nothing
 // reads them before the optimiser step).
+// A/B switch of the "parity" precision fusions (AMDSEG_PARITY_UNFUSED bit mask: 1 ctx image from the attention, 2 d(ctx) image from the dgrad,
+// 4 GELU / GELU' + split in the FFN GEMM epilogues): set bits fall back to the separate passes
+static int parity_unfused() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("AMDSEG_PARITY_UNFUSED"); v = e ? atoi(e) : 0; }
+    return v;
+}
 #define PHASE1(c) ((c)->phase == 0 || (c)->phase == 1 || (c)->phase == 3)
 #define PHASE2(c) ((c)->phase == 0 || (c)->phase == 2 || (c)->phase == 3 || (c)->phase == 6)
 #define PHASE_WGRAD(c) ((c)->phase == 0 || (c)->phase == 2 || (c)->phase == 3 || (c)->phase == 4)
@@ -376,18 +383,20 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
                 if (c->p_attn > 0.f) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s,
                                                                       c->window, c->nglobal));
                 RET_IF(amdseg_sattn_fwd_impl(a->qkv_s, 9 * H, 6 * H, mask_bias, (float*)a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn,
-                                             c->p_attn > 0.f ? a->keep : nullptr, c->window, c->nglobal, s, c->kend, c->seq_order));
+                                             c->p_attn > 0.f ? a->keep : nullptr, c->window, c->nglobal, s, c->kend, c->seq_order,
+                                             (c->window == 0 && !(parity_unfused() & 1)) ? a->ctx_s : nullptr));      // (a Longformer caller still rewrites the global rows of ctx)
             } else
             RET_IF(amdseg_pattn_fwd_impl((const float*)a->qkv, mask_bias, (float*)a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                          site_seed(c->seed, li, 0), s, c->kend, c->seq_order));
         }
         if (!PHASE2(c)) return AMDSEG_OK;
-        RET_IF(amdseg_split3_impl((const float*)a->ctx, H, a->ctx_s, M, H, 0, s));
+        if (!(a->qkv_s && (c->p_attn == 0.f || a->keep) && c->window == 0 && !(parity_unfused() & 1)))      // (else the split attention wrote the image itself)
+            RET_IF(amdseg_split3_impl((const float*)a->ctx, H, a->ctx_s, M, H, 0, s));
         RET_IF(amdseg_gemm_nt_impl(a->ctx_s, 3 * H, p->wo, 3 * H, a->z1, H, M, H, 3 * H, AMDSEG_EPI_BIAS, p->bo, nullptr, 0, nullptr, 0, 1, s));
         RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
                                       site_seed(c->seed, li, 1), AMDSEG_F32, s));
         RET_IF(amdseg_split3_impl((const float*)a->x1, H, a->x1_s, M, H, 0, s));
-        if (c->act == 0 && (M % 256) == 0 && (I % 256) == 0)       // u (fp32, read by backward) and the image of gelu(u) from one epilogue
+        if (c->act == 0 && (M % 256) == 0 && (I % 256) == 0 && !(parity_unfused() & 4))       // u (fp32, read by backward) and the image of gelu(u) from one epilogue
             RET_IF(amdseg_gemm_nt_impl(a->x1_s, 3 * H, p->w1, 3 * H, a->u, I, M, I, 3 * H, AMDSEG_EPI_BIAS_GELU_SPLIT, p->b1, nullptr, 0, a->h_s, 3 * I, 1, s));
         else {
             RET_IF(amdseg_gemm_nt_impl(a->x1_s, 3 * H, p->w1, 3 * H, a->u, I, M, I, 3 * H, AMDSEG_EPI_BIAS, p->b1, nullptr, 0, nullptr, 0, 1, s));
@@ -468,12 +477,13 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         // "parity" precision: same dataflow in fp32; every GEMM operand goes through its split image (csrc/parity.hip)
         if (!w->d_out_s || !w->du_s || !w->d_ao_s || !w->dqkv_s || !a->xs || !a->ctx_s || !a->x1_s || !a->h_s) return AMDSEG_ERR_ARG;
         // full attention on the split kernels: nobody reads d(ctx) in fp32 (a Longformer caller does, between the phases: its global row)
-        const bool dctx_image = a->qkv_s && w->dctx_s && (c->p_attn == 0.f || a->keep) && c->window == 0 && (M % 256) == 0 && (H % 256) == 0;
+        const bool dctx_image = a->qkv_s && w->dctx_s && (c->p_attn == 0.f || a->keep) && c->window == 0 && (M % 256) == 0 && (H % 256) == 0 &&
+                                !(parity_unfused() & 2);
         if (PHASE1(c)) {
             RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, part_ln2, g->ln2_g, g->ln2_b,
                                       g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, AMDSEG_F32, s));
             RET_IF(amdseg_split3_impl((const float*)d_out, H, w->d_out_s, M, H, 0, s));
-            if (c->act == 0 && (M % 256) == 0 && (I % 256) == 0) {
+            if (c->act == 0 && (M % 256) == 0 && (I % 256) == 0 && !(parity_unfused() & 4)) {
                 // du = (d_out . W2) * gelu'(u) leaves the GEMM as the [hi | hi | lo] image (no fp32 du, no separate GELU' / split pass: 160 us per
                 // layer at bert-base); the bias gradient is summed from the image
                 RET_IF(amdseg_gemm_nt_impl(w->d_out_s, 3 * H, p->w2_t, 3 * H, w->du_s, 3 * I, M, I, 3 * H, AMDSEG_EPI_GELU_BWD_SPLIT, nullptr, a->u, I,

@@ -20,6 +20,7 @@ struct SAttnArgs {
     const float* mask_bias; float* ctx; float* lse;
     const bf16_t* dos; int ldo, lo_o;
     float* delta; float* dqkv;
+    bf16_t* ctx_img;                        // optional (forward): ctx ALSO as the split image [B*L][3H] = [hi | hi | lo] the output projection reads
     bf16_t* dqs; int ldd;                   // optional: write d(q|k|v) as the split image [B*L][ldd] = [hi | hi | lo] (blocks 3H wide: the A operand
                                             // of the next split GEMMs) instead of fp32 dqkv
     int B, L, heads;
@@ -234,6 +235,14 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(SAttnArgs a) {
     for (int d = 0; d < 4; ++d)
         *reinterpret_cast<float4*>(op + d * 16 + g * 4) = padq ? make_float4(0.f, 0.f, 0.f, 0.f)
                                                                : make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv);
+    if (a.ctx_img) {
+        const int Hh = a.heads * HD;
+        bf16_t* ip = a.ctx_img + (size_t)(tok0 + q) * 3 * Hh + h * HD;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            sa_store4(nullptr, ip + d * 16 + g * 4, Hh, padq ? 0.f : o[d][0] * inv, padq ? 0.f : o[d][1] * inv, padq ? 0.f : o[d][2] * inv,
+                      padq ? 0.f : o[d][3] * inv);
+    }
     if (a.lse && g == 0) a.lse[prow] = lse_q;
 #undef CHUNK_OF
 }
@@ -606,12 +615,12 @@ static int sattn_lds(K kernel) {
         hipLaunchKernelGGL(kern, grid, dim3(256), SA_LDS, s, a); } while (0)
 
 int amdseg_sattn_fwd_impl(const void* qs, int ldq, int lo_q, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale,
-                          float p, const void* keep, int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order) {
+                          float p, const void* keep, int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order, void* ctx_image) {
     if (!qs || !mask_bias || !ctx) return AMDSEG_ERR_ARG;
     SAttnArgs a = {};
     int rc = sattn_fill(a, B, L, heads, scale, p, window, nglobal, keep);
     if (rc) return rc;
-    a.qs = (const bf16_t*)qs; a.ldq = ldq; a.lo_q = lo_q; a.mask_bias = mask_bias; a.ctx = ctx; a.lse = lse;
+    a.qs = (const bf16_t*)qs; a.ldq = ldq; a.lo_q = lo_q; a.mask_bias = mask_bias; a.ctx = ctx; a.lse = lse; a.ctx_img = (bf16_t*)ctx_image;
     a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order;
     const dim3 grid(L / 64, heads, B);
     if (window > 0 && a.thresh16) SA_LAUNCH((sattn_fwd_kernel<true, true>), grid);
