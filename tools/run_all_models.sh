@@ -20,4 +20,6 @@ run --model ponet --mode infer --steps 20 --warmup 5
 run --model bigbird --mode infer --steps 20 --warmup 5
 run --model longformer --seq-len 2048 --seqs-per-gpu 4 --steps 20 --warmup 5
 run --model bigbird --seq-len 2048 --seqs-per-gpu 4 --steps 20 --warmup 5
+run --model longformer --precision parity --steps 8 --warmup 3
+run --seqs-per-gpu 8 --steps 40 --warmup 10
 cat $OUT
