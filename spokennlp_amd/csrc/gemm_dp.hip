@@ -335,7 +335,9 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
         const int t256 = (a_in.M / DP_BM) * (a_in.N / 256), t192 = (a_in.M / DP_BM) * (a_in.N / 192);
         narrow = 0.78f * (float)((t192 + 255) / 256) < (float)((t256 + 255) / 256);
     }
-    const bool use192 = ok192 && (!ok256 || force == 192 || narrow);
+    constexpr bool direct_only = EB == EPI_BIAS_SPLIT || EB == EPI_GELU_BWD_SPLIT || EB == EPI_BIAS_GELU_SPLIT;    // epilogues of the 256-wide tile only
+    if (direct_only && !ok256) return AMDSEG_ERR_SHAPE;
+    const bool use192 = !direct_only && ok192 && (!ok256 || force == 192 || narrow);
     if (use192) return launch_nt_dp_nf<EPIX, OutT, 3>(a_in, s);
     return launch_nt_dp_nf<EPIX, OutT, 4>(a_in, s);
 }
