@@ -344,7 +344,8 @@ static int check_cfg(const amdseg_bert_cfg* c) {
 // weight gradients of layer i on a second stream under the backward of layer i-1 (they are off the critical path: nothing
 // reads them before the optimiser step).
 // A/B switch of the "parity" precision fusions (AMDSEG_PARITY_UNFUSED bit mask: 1 ctx image from the attention, 2 d(ctx) image from the dgrad,
-// 4 GELU / GELU' + split in the FFN GEMM epilogues): set bits fall back to the separate passes
+// 4 GELU / GELU' + split in the FFN GEMM epilogues, 8 LayerNorm forward / backward writing the images of x1 / the dense-layer gradients): set bits
+// fall back to the separate passes
 static int parity_unfused() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("AMDSEG_PARITY_UNFUSED"); v = e ? atoi(e) : 0; }
@@ -393,9 +394,10 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         if (!(a->qkv_s && (c->p_attn == 0.f || a->keep) && c->window == 0 && !(parity_unfused() & 1)))      // (else the split attention wrote the image itself)
             RET_IF(amdseg_split3_impl((const float*)a->ctx, H, a->ctx_s, M, H, 0, s));
         RET_IF(amdseg_gemm_nt_impl(a->ctx_s, 3 * H, p->wo, 3 * H, a->z1, H, M, H, 3 * H, AMDSEG_EPI_BIAS, p->bo, nullptr, 0, nullptr, 0, 1, s));
+        const bool ln_img = !(parity_unfused() & 8);
         RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
-                                      site_seed(c->seed, li, 1), AMDSEG_F32, s));
-        RET_IF(amdseg_split3_impl((const float*)a->x1, H, a->x1_s, M, H, 0, s));
+                                      site_seed(c->seed, li, 1), AMDSEG_F32, s, ln_img ? a->x1_s : nullptr));
+        if (!ln_img) RET_IF(amdseg_split3_impl((const float*)a->x1, H, a->x1_s, M, H, 0, s));
         if (c->act == 0 && (M % 256) == 0 && (I % 256) == 0 && !(parity_unfused() & 4))       // u (fp32, read by backward) and the image of gelu(u) from one epilogue
             RET_IF(amdseg_gemm_nt_impl(a->x1_s, 3 * H, p->w1, 3 * H, a->u, I, M, I, 3 * H, AMDSEG_EPI_BIAS_GELU_SPLIT, p->b1, nullptr, 0, a->h_s, 3 * I, 1, s));
         else {
@@ -480,9 +482,11 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         const bool dctx_image = a->qkv_s && w->dctx_s && (c->p_attn == 0.f || a->keep) && c->window == 0 && (M % 256) == 0 && (H % 256) == 0 &&
                                 !(parity_unfused() & 2);
         if (PHASE1(c)) {
+            const bool ln_img = !(parity_unfused() & 8);
             RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, part_ln2, g->ln2_g, g->ln2_b,
-                                      g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, AMDSEG_F32, s));
-            RET_IF(amdseg_split3_impl((const float*)d_out, H, w->d_out_s, M, H, 0, s));
+                                      g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, AMDSEG_F32, s, nullptr, nullptr, 0,
+                                      ln_img ? w->d_out_s : nullptr));
+            if (!ln_img) RET_IF(amdseg_split3_impl((const float*)d_out, H, w->d_out_s, M, H, 0, s));
             if (c->act == 0 && (M % 256) == 0 && (I % 256) == 0 && !(parity_unfused() & 4)) {
                 // du = (d_out . W2) * gelu'(u) leaves the GEMM as the [hi | hi | lo] image (no fp32 du, no separate GELU' / split pass: 160 us per
                 // layer at bert-base); the bias gradient is summed from the image
@@ -497,8 +501,9 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
             RET_IF(amdseg_gemm_nt_impl(w->du_s, 3 * I, p->w1_t, 3 * I, w->dx1, H, M, H, 3 * I, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1, s));
             RET_IF(amdseg_add_inplace_impl((float*)w->dx1, (const float*)w->dz2, (size_t)M * H, s));
             RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, part_ln1, g->ln1_g,
-                                      g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, AMDSEG_F32, s));
-            RET_IF(amdseg_split3_impl((const float*)d_ao, H, w->d_ao_s, M, H, 0, s));
+                                      g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, AMDSEG_F32, s, nullptr, nullptr, 0,
+                                      ln_img ? w->d_ao_s : nullptr));
+            if (!ln_img) RET_IF(amdseg_split3_impl((const float*)d_ao, H, w->d_ao_s, M, H, 0, s));
             if (dctx_image)      // d(ctx) straight as the hi / lo blocks the split attention backward reads (no fp32 d(ctx), no split pass)
                 RET_IF(amdseg_gemm_nt_impl(w->d_ao_s, 3 * H, p->wo_t, 3 * H, w->dctx_s, 3 * H, M, H, 3 * H, AMDSEG_EPI_BIAS_SPLIT, nullptr, nullptr, 0,
                                            (bf16_t*)w->dctx_s + 2 * H, 3 * H, 0, s));

@@ -35,6 +35,24 @@ __device__ __forceinline__ void row_store(T* row, int nch, int l, const float (&
         if (ch < nch) st8<T>(row + ch * 8, v[c]);
     }
 }
+// the row as a split-bf16 image [hi | hi | lo] (row stride 3H): what amdseg_split3(order 0) makes of it ("parity" precision: the next GEMM's A operand)
+template <int NCH>
+__device__ __forceinline__ void row_store_image(bf16_t* img_row, int H, int nch, int l, const float (&v)[NCH][8]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = l + c * 64;
+        if (ch < nch) {
+            uint4 hi, lo;
+            hi.x = pack2bf(v[c][0], v[c][1]); hi.y = pack2bf(v[c][2], v[c][3]); hi.z = pack2bf(v[c][4], v[c][5]); hi.w = pack2bf(v[c][6], v[c][7]);
+            lo.x = pack2bf(v[c][0] - __uint_as_float(hi.x << 16), v[c][1] - __uint_as_float(hi.x & 0xffff0000u));
+            lo.y = pack2bf(v[c][2] - __uint_as_float(hi.y << 16), v[c][3] - __uint_as_float(hi.y & 0xffff0000u));
+            lo.z = pack2bf(v[c][4] - __uint_as_float(hi.z << 16), v[c][5] - __uint_as_float(hi.z & 0xffff0000u));
+            lo.w = pack2bf(v[c][6] - __uint_as_float(hi.w << 16), v[c][7] - __uint_as_float(hi.w & 0xffff0000u));
+            *reinterpret_cast<uint4*>(img_row + ch * 8) = hi; *reinterpret_cast<uint4*>(img_row + H + ch * 8) = hi;
+            *reinterpret_cast<uint4*>(img_row + 2 * H + ch * 8) = lo;
+        }
+    }
+}
 template <int NCH>
 __device__ __forceinline__ void row_stats(const float (&v)[NCH][8], int nch, int l, int H, float eps, float& mean, float& rstd) {
     float s = 0.f;
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const T* __restrict_
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid, const float* gamma, const float* beta, T* out,
                                                          float* mean, float* rstd, int M, int H, float eps, uint32_t thresh,
-                                                         float inv_keep, uint64_t seed) {
+                                                         float inv_keep, uint64_t seed, bf16_t* img) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int m = blockIdx.x * ROWS_PER_BLOCK + w;
     if (m >= M) return;
@@ -195,6 +213,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
         }
     }
     row_store<T, NCH>(out + (size_t)m * H, nch, l, v);
+    if (img) row_store_image<NCH>(img + (size_t)m * 3 * H, H, nch, l, v);
 }
 
 // LN backward.  dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  Also emits
@@ -205,7 +224,7 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, const float* mean, const float* rstd,
                                                      const float* gamma, T* dz, T* dbranch, float* partials, int M, int H,
                                                      uint32_t thresh, float inv_keep, uint64_t seed,
-                                                     const int* zkend, const int* zguard, int zL) {
+                                                     const int* zkend, const int* zguard, int zL, bf16_t* img) {
     extern __shared__ float red[];         // [3][4 waves][H]
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nch = H >> 3;
@@ -225,6 +244,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
                 if (m >= M) break;
                 row_store<T, NCH>(dz + (size_t)m * H, nch, l, zero);
                 if (dbranch) row_store<T, NCH>(dbranch + (size_t)m * H, nch, l, zero);
+                if (img) row_store_image<NCH>(img + (size_t)m * 3 * H, H, nch, l, zero);
             }
             if (partials)
                 for (int i = threadIdx.x; i < 3 * H; i += 256) {
@@ -276,6 +296,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
                 for (int e = 0; e < 8; ++e) g[c][e] = rs * (g[c][e] - s1 - x[c][e] * s2);
             }
         row_store<T, NCH>(dz + (size_t)m * H, nch, l, g);
+        if (img && !dbranch) row_store_image<NCH>(img + (size_t)m * 3 * H, H, nch, l, g);      // no dropout: the dense layer's gradient IS dz
         if (dbranch || partials) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -287,6 +308,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
                 }
             }
             if (dbranch) row_store<T, NCH>(dbranch + (size_t)m * H, nch, l, g);
+            if (img && dbranch) row_store_image<NCH>(img + (size_t)m * 3 * H, H, nch, l, g);
         }
     }
     if (!partials) return;
@@ -718,24 +740,24 @@ int amdseg_embed_bwd_impl(const void* dz, const int64_t* ids, const int64_t* typ
 
 int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out,
                            float* mean, float* rstd, int M, int H, float eps, float p, uint64_t seed, int dtype,
-                           hipStream_t s) {
+                           hipStream_t s, void* out_image) {
     if (!y_inout_z || !resid || !gamma || !beta || !out) return AMDSEG_ERR_ARG;
     if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
     uint32_t th; float ik; drop_params(p, th, ik);
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     if (dtype == AMDSEG_BF16)
         ROWK(add_ln_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta,
-                           (bf16_t*)out, mean, rstd, M, H, eps, th, ik, seed);
+                           (bf16_t*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image);
     else
         ROWK(add_ln_fwd_kernel, float, H, grid, dim3(256), 0, s, (float*)y_inout_z, (const float*)resid, gamma, beta,
-                           (float*)out, mean, rstd, M, H, eps, th, ik, seed);
+                           (float*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image);
     return amdseg_launch_status();
 }
 
 int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                        void* dz, void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M,
                        int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s,
-                       const int* zkend, const int* zguard, int zL) {
+                       const int* zkend, const int* zguard, int zL, void* dense_grad_image) {
     if (!dy || !z || !mean || !rstd || !gamma || !dz) return AMDSEG_ERR_ARG;
     if (!zkend || !zguard || zL <= 0 || (M % zL) || (zL % LNB_ROWS)) { zkend = nullptr; zguard = nullptr; zL = 1; }
     if ((dgamma || dbeta || dbias) && !partials) return AMDSEG_ERR_ARG;
@@ -745,10 +767,10 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
     const size_t shm = (size_t)3 * 4 * H * sizeof(float);
     if (dtype == AMDSEG_BF16)
         ROWK(ln_bwd_kernel, bf16_t, H, dim3(nblk), dim3(256), shm, s, (const bf16_t*)dy, (const bf16_t*)z, mean, rstd,
-                           gamma, (bf16_t*)dz, (bf16_t*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL);
+                           gamma, (bf16_t*)dz, (bf16_t*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL, (bf16_t*)dense_grad_image);
     else
         ROWK(ln_bwd_kernel, float, H, dim3(nblk), dim3(256), shm, s, (const float*)dy, (const float*)z, mean, rstd, gamma,
-                           (float*)dz, (float*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL);
+                           (float*)dz, (float*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL, (bf16_t*)dense_grad_image);
     if (partials) {
         Reduce3 r;
         r.part[0] = partials; r.part[1] = partials + (size_t)nblk * H; r.part[2] = partials + (size_t)2 * nblk * H;
