@@ -110,6 +110,12 @@ int amdseg_attn_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, flo
 int amdseg_attn_bwd_keep(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, const void* keep,
                          amdseg_stream_t stream);
+/* the band kernels on keep masks generated by amdseg_attn_keepmask_band (same window / nglobal): dropout decisions of the Longformer layers */
+int amdseg_attn_band_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
+                              float dropout_p, const void* keep, int window, int nglobal, amdseg_stream_t stream);
+int amdseg_attn_band_bwd_keep(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                              float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, const void* keep,
+                              int window, int nglobal, amdseg_stream_t stream);
 
 /* "Parity" precision attention on the bf16 matrix cores (csrc/attention_split.hip): every contraction of amdseg_attn_fwd / _bwd as a
  * split-bf16 product (x = hi + lo; hi.hi + hi.lo + lo.hi), fp32 softmax, accumulators and outputs.  qs = the amdseg_split3 image of the fp32

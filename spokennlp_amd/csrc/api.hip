@@ -90,6 +90,18 @@ int amdseg_attn_band_bwd(const void* qkv, const float* mask_bias, const void* ct
     if (window <= 0) return AMDSEG_ERR_ARG;
     return amdseg_attn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, seed, window, nglobal, S(stream));
 }
+int amdseg_attn_band_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
+                              float dropout_p, const void* keep, int window, int nglobal, amdseg_stream_t stream) {
+    if (window <= 0) return AMDSEG_ERR_ARG;
+    return amdseg_attn_fwd_impl(qkv, mask_bias, ctx, lse, B, L, heads, scale, dropout_p, 0, window, nglobal, S(stream), nullptr, nullptr, keep);
+}
+int amdseg_attn_band_bwd_keep(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
+                              float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, const void* keep,
+                              int window, int nglobal, amdseg_stream_t stream) {
+    if (window <= 0) return AMDSEG_ERR_ARG;
+    return amdseg_attn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, 0, window, nglobal, S(stream),
+                                nullptr, nullptr, nullptr, keep);
+}
 int amdseg_attn_band_f32(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, float scale, int window,
                          int nglobal, amdseg_stream_t stream) {
     if (window <= 0) return AMDSEG_ERR_ARG;
@@ -431,8 +443,9 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         RET_IF(amdseg_gemm_nt_impl(a->x_in, H, p->wqkv, H, a->qkv, NP, M, NP, H, AMDSEG_EPI_BIAS, p->bqkv, nullptr, 0, nullptr, 0, 0, s));
         if (c->mixer == 0) {
             // dropout on the probabilities: decided once per layer here, read by the forward and the two backward kernels (acts.keep)
-            const void* keep = (a->keep && c->p_attn > 0.f && c->window == 0) ? a->keep : nullptr;
-            if (keep) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s));
+            const void* keep = (a->keep && c->p_attn > 0.f) ? a->keep : nullptr;      // full attention, or the band's cells (window > 0)
+            if (keep) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s, c->window,
+                                                       c->nglobal));
             RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0),
                                         c->window, c->nglobal, s, c->kend, c->seq_order, keep,
                                         // a phase-1 call of a layer with global tokens: the caller writes their ctx rows (amdseg.h, `phase`)
@@ -571,7 +584,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     if (c->mixer == 0)
         RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                     site_seed(c->seed, li, 0), c->window, c->nglobal, s, c->kend, c->seq_order, c->pad_guard,
-                                    (c->p_attn > 0.f && c->window == 0) ? a->keep : nullptr));
+                                    c->p_attn > 0.f ? a->keep : nullptr));
     // dx_in = dqkv . Wqkv + dz1   (external mixer: the caller wrote ws.dqkv [M, nproj*H] between the phases)
     RET_IF(amdseg_gemm_nt_impl(w->dqkv, NP, p->wqkv_t, NP, dx_in, H, M, H, NP, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s, ZPAD));
     }

@@ -856,7 +856,8 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
     if (window > 0) {
         // band: 64-query workgroups visit (64 + 2W) / 64 = 9 chunks at W = 256, 128-query ones 10 -- measured 152 vs 172 us per layer at
         // longformer-base (full attention is the other way round: 8 waves share every K / V tile)
-        if (L % 128 == 0 && (nw4 & 2)) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<8, true>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
+        if (keep && a.thresh16) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<4, true, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        else if (L % 128 == 0 && (nw4 & 2)) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<8, true>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
         else AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
     } else {
         if (L % 128 == 0) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<8, false>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
@@ -888,7 +889,10 @@ int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ct
     // algorithmic FLOPs of backward = 2.5 x forward (dV, dP, dQ, dK + the S recomputation counted once): dQ kernel 3 products, dK/dV 4
     const double span = window > 0 ? (double)(2 * window + 1 + a.nglobal) : (double)L;
     const double unit = 2.0 * B * heads * (double)L * span * HD;
-    if (window > 0) {
+    if (window > 0 && keep && a.thresh16) {                 // band, dropout decisions from the keep masks generated for the band's cells
+        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_BWD_DQ, 2.0 * unit, (attn_bwd_dq_kernel<4, true, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
+        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_BWD_DKV, 3.0 * unit, (attn_bwd_dkv_kernel<4, true, false, true>), dim3((L / 64) * heads * B), dim3(256), 0, s, a);
+    } else if (window > 0) {
         AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_BWD_DQ, 2.0 * unit, (attn_bwd_dq_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
         AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_BWD_DKV, 3.0 * unit, (attn_bwd_dkv_kernel<4, true>), dim3((L / 64) * heads * B), dim3(256), 0, s, a);
     } else {

@@ -61,6 +61,8 @@ _PROTOS = {
     "amdseg_attn_keepmask_band": [vp, i32, i32, i32, f32, u64, i32, i32, vp],
     "amdseg_attn_fwd_keep": [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],
     "amdseg_attn_bwd_keep": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],
+    "amdseg_attn_band_fwd_keep": [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
+    "amdseg_attn_band_bwd_keep": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
     "amdseg_sattn_fwd": [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
     "amdseg_sattn_bwd": [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
     "amdseg_attn_band_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, i32, vp],

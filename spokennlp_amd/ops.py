@@ -115,6 +115,30 @@ def attn_bwd_keep(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, p, keep, scale
     return dqkv
 
 
+def attn_keepmask_band(B, Lseq, heads, p, seed, window, nglobal, device):
+    """keep masks of a band (Longformer) layer: same buffer layout as attn_keepmask, only the cells the band kernels visit are written"""
+    lib = L.load()
+    keep = torch.zeros(lib.amdseg_attn_keepmask_bytes(B, Lseq, heads), dtype=torch.uint8, device=device)
+    L.check(lib.amdseg_attn_keepmask_band(_p(keep), B, Lseq, heads, p, seed, window, nglobal, _s()), "amdseg_attn_keepmask_band")
+    return keep
+
+
+def attn_band_fwd_keep(qkv, mask_bias, B, Lseq, heads, window, nglobal, p, keep, scale=0.125):
+    ctx = torch.empty((B * Lseq, heads * 64), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device)
+    L.check(L.load().amdseg_attn_band_fwd_keep(_p(qkv), _p(mask_bias), _p(ctx), _p(lse), B, Lseq, heads, scale, p, _p(keep), window, nglobal, _s()),
+            "amdseg_attn_band_fwd_keep")
+    return ctx, lse
+
+
+def attn_band_bwd_keep(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, window, nglobal, p, keep, scale=0.125):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B * heads * Lseq,), dtype=torch.float32, device=qkv.device)
+    L.check(L.load().amdseg_attn_band_bwd_keep(_p(qkv), _p(mask_bias), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, Lseq, heads, scale, p,
+                                               _p(keep), window, nglobal, _s()), "amdseg_attn_band_bwd_keep")
+    return dqkv
+
+
 def attn_list_fwd(qkv, mask_bias, B, Lseq, heads, klist, kcnt, stride, ctx=None, lse=None, scale=0.125, korder=None):
     """BigBird block-list attention (amdseg_attn_list_fwd); klist/kcnt: int32 device tensors [heads, L/64, stride] / [heads, L/64]"""
     H = heads * 64

@@ -136,3 +136,36 @@ def test_keepmask_with_kend_skips_only_unread_chunks(dev):
         assert torch.equal(ka[b, :, :, :nvis], kb[b, :, :, :nvis])
         assert abs(ka[b, :, :, :nvis].float().mean().item() - 0.9) < 0.01
         assert not ka[b, :, :, nvis:].any() and not kb[b, :, :, nvis:].any()        # untouched (the buffer was zeroed)
+
+
+@pytest.mark.parametrize("B,L,heads,w,G", [(2, 256, 2, 64, 1), (1, 512, 3, 128, 1), (2, 384, 1, 32, 0)])
+def test_band_keepmask_forward_backward_vs_torch(dev, B, L, heads, w, G):
+    """the band (Longformer) kernels on keep masks generated for the band's cells: forward + dq / dk / dv against a torch band attention that
+    applies the unpacked bits; the two layouts agree on every cell inside the band (cells outside it are never written or read)"""
+    ops = _ops()
+    p, seed = 0.1, 777
+    keep = ops.attn_keepmask_band(B, L, heads, p, seed, w, G, dev)
+    ka, kb = unpack_keep(keep, B, L, heads)
+    i = torch.arange(L)
+    inband = ((i[:, None] - i[None, :]).abs() <= w) | (i[None, :] < G)
+    assert torch.equal(ka[:, inband], kb[:, inband])
+    rate = ka[:, inband].float().mean().item()
+    assert abs(rate - 0.9) < 0.01
+    km = ka.view(B, heads, L, L).float().to(dev)
+    inv_keep = 65536.0 / (65536 - round(p * 65536))
+    qkv, mb = make_qkv(dev, B, L, heads, 31, pad=True)
+    g = torch.Generator(device="cpu").manual_seed(32)
+    dctx = torch.randn(B * L, heads * 64, generator=g).to(dev).bfloat16()
+    ctx, lse = ops.attn_band_fwd_keep(qkv, mb, B, L, heads, w, G, p, keep)
+    H = heads * 64
+    q32 = qkv.float().requires_grad_(True)
+    q, k, v = [t.view(B, L, heads, 64).transpose(1, 2) for t in q32.view(B, L, 3 * H).split(H, dim=-1)]
+    s = q @ k.transpose(-1, -2) * 0.125 + mb.view(B, 1, 1, L)
+    s = s.masked_fill(~inband.to(dev), float("-inf"))
+    pr = torch.softmax(s, -1) * (mb.view(B, 1, L, 1) >= 0)
+    ref = ((pr * km * inv_keep) @ v).transpose(1, 2).reshape(B * L, H)
+    assert rel_err(ctx, ref) < 8e-3
+    dqkv = ops.attn_band_bwd_keep(qkv, mb, ctx, dctx, lse, B, L, heads, w, G, p, keep)
+    ref.backward(dctx.float())
+    for j, name in enumerate(["dq", "dk", "dv"]):
+        assert rel_err(dqkv[:, j * H:(j + 1) * H], q32.grad[:, j * H:(j + 1) * H]) < 2e-2, name
