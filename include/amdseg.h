@@ -348,7 +348,7 @@ int amdseg_lf_dx_apply(void* dx, int ldx, const float* coefA, const float* coefB
  * utils.py:141-182 weighted CE, ignore_index -100; `nseg` equal row segments = anchor half | augmented half, one mean each), CSSL InfoNCE in
  * list form (cssl.py:82-116: anchors x (pk positive + negative) lists of row indices) and TSSP Linear(H, Ct) + CE (tssp.py:16-36).
  *   out8:  [0..1] CE per segment, [2] CSSL, [3] TSSP, [4] total = w_ts * (CE_0 + CE_1) + w_cl * CSSL + w_tssp2 * TSSP, [5..6] 1 / sum of CE
- *          weights per segment (read by backward);  ce_unit [M,C] and acc [16 * ceil(M / 256) + n_anchor + nt] are caller-owned scratch
+ *          weights per segment (read by backward);  ce_unit [M,C] and acc [32 * ceil(M / 256) + n_anchor + nt] are caller-owned scratch
  *          (per-wave CE partials and per-row loss terms, summed in a fixed order: the loss is bit-reproducible).
  *   idx:   ONE int64 device buffer holding every index list of the step (built on the host with the reference's `random` call order);
  *          feat_off -> seq row of feature f; anchor_off -> feature index of anchor i (-1: anchor i = feature i); lists_off ->
@@ -361,6 +361,16 @@ int amdseg_heads_fwd(const float* x, int M, int H, const float* logits, const in
                      int nt, int Ct, float w_ts, float w_cl, float w_tssp2, amdseg_stream_t stream);
 int amdseg_heads_bwd_ce(const float* gout, int M, int C, int nseg, const float* ce_unit, const float* out8, float w_ts, float* dlogits,
                         amdseg_stream_t stream);
+/* the same with the reference's focal loss (focal_loss_gamma != 0, modules/utils.py:141-168): FocalLoss overwrites its `reduction` with 'mean'
+ * before the base class's forward runs, so its value is  mean_i (1 - p_i,t_i)^gamma  x  the scalar (weighted) mean CE, t_i = the label (0 on ignored
+ * rows), the first mean over ALL rows of the segment -- reproduced as is.  ce_unit2: [M, 2C] scratch (CE unit | focal-factor unit);
+ * out12: 12 floats ([8..9] mean focal factor, [10..11] mean CE per segment; [0..7] as amdseg_heads_fwd with [0..1] = their product). */
+int amdseg_heads_fwd_focal(const float* x, int M, int H, const float* logits, const int64_t* labels, const float* class_w, int C, int nseg,
+                           float* ce_unit2, float* out12, float* acc, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
+                           int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off, long t_labels_off,
+                           int nt, int Ct, float w_ts, float w_cl, float w_tssp2, float focal_gamma, amdseg_stream_t stream);
+int amdseg_heads_bwd_ce_focal(const float* gout, int M, int C, int nseg, const float* ce_unit2, const float* out12, float w_ts, float focal_gamma,
+                              float* dlogits, amdseg_stream_t stream);
 int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float* dx, const int64_t* idx, long feat_off, long anchor_off,
                           long lists_off, int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
                           long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, amdseg_stream_t stream);

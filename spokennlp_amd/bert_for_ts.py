@@ -349,10 +349,10 @@ class TopicSegHeadsMixin:
     # ------------------------------------------------------------------------------------------------ fused training heads
     def _fused_heads_ok(self, train):
         """the HIP heads (csrc/heads.hip) cover the training configurations of run_finetune.sh: linear token scores, plain or
-        class-weighted CE, CSSL in list form with a non-zero temperature, TSSP.  Focal loss, the cosine score predictor, the eop_matrix
-        CSSL variant and evaluation (which also returns the cos-sim side output) stay on the torch formulation below."""
+        class-weighted CE or the reference's focal loss, CSSL in list form with a non-zero temperature, TSSP.  The cosine score predictor, the
+        eop_matrix CSSL variant and evaluation (which also returns the cos-sim side output) stay on the torch formulation below."""
         cfg = self.config
-        return (train and getattr(cfg, "amdseg_fused_heads", True) and cfg.ts_score_predictor == "lt" and cfg.focal_loss_gamma == 0
+        return (train and getattr(cfg, "amdseg_fused_heads", True) and cfg.ts_score_predictor == "lt"
                 and (cfg.cl_loss_weight == 0 or (cfg.cl_anchor_level in ("eop_list", "eot_list") and cfg.cl_temp != 0
                                                  and cfg.cl_positive_k + cfg.cl_negative_k <= 16))
                 and cfg.num_labels <= 4 and cfg.num_tssp_labels <= 4
@@ -366,6 +366,7 @@ class TopicSegHeadsMixin:
         pos, lab = self._labelled_rows(host["labels"][:, 0])
         P = dict(nseg=2 if two_pass else 1, feat_off=0, anchor_off=-1, lists_off=0, n_anchor=0, n_list=0, pk=1, temp=float(cfg.cl_temp) or 1.0,
                  t_rows_off=0, t_labels_off=0, nt=0, w_ts=float(cfg.ts_loss_weight), w_cl=float(cfg.cl_loss_weight),
+                 gamma=float(cfg.focal_loss_gamma),
                  w_tssp2=float(cfg.tssp_loss_weight) ** 2)
         if cfg.cl_loss_weight != 0:
             cp = self._plan_cssl(up, req, pos, lab, Lq, 0)                  # same `random` call order as the reference (cssl.py:118-228)

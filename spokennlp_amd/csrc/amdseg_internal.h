@@ -148,9 +148,9 @@ int amdseg_pattn_bwd_impl(const float* qkv, const float* mask_bias, const float*
 int amdseg_heads_fwd_impl(const float* x, int M, int H, const float* logits, const int64_t* labels, const float* class_w, int C, int nseg,
                           float* ce_unit, float* out8, float* acc, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
                           int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
-                          long t_labels_off, int nt, int Ct, float w_ts, float w_cl, float w_tssp2, hipStream_t s);
+                          long t_labels_off, int nt, int Ct, float w_ts, float w_cl, float w_tssp2, hipStream_t s, float focal_gamma = 0.f);
 int amdseg_heads_bwd_ce_impl(const float* gout, int M, int C, int nseg, const float* ce_unit, const float* out8, float w_ts, float* dlogits,
-                             hipStream_t s);
+                             hipStream_t s, float focal_gamma = 0.f);
 int amdseg_heads_bwd_rows_impl(const float* gout, const float* x, int M, int H, float* dx, const int64_t* idx, long feat_off, long anchor_off,
                                long lists_off, int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
                                long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, hipStream_t s);

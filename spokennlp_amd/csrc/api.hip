@@ -323,6 +323,17 @@ int amdseg_heads_bwd_ce(const float* gout, int M, int C, int nseg, const float* 
                         amdseg_stream_t stream) {
     return amdseg_heads_bwd_ce_impl(gout, M, C, nseg, ce_unit, out8, w_ts, dlogits, S(stream));
 }
+int amdseg_heads_fwd_focal(const float* x, int M, int H, const float* logits, const int64_t* labels, const float* class_w, int C, int nseg,
+                           float* ce_unit2, float* out12, float* acc, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
+                           int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off, long t_labels_off,
+                           int nt, int Ct, float w_ts, float w_cl, float w_tssp2, float focal_gamma, amdseg_stream_t stream) {
+    return amdseg_heads_fwd_impl(x, M, H, logits, labels, class_w, C, nseg, ce_unit2, out12, acc, idx, feat_off, anchor_off, lists_off, n_anchor,
+                                 n_list, pk, temp, Wt, bt, t_rows_off, t_labels_off, nt, Ct, w_ts, w_cl, w_tssp2, S(stream), focal_gamma);
+}
+int amdseg_heads_bwd_ce_focal(const float* gout, int M, int C, int nseg, const float* ce_unit2, const float* out12, float w_ts, float focal_gamma,
+                              float* dlogits, amdseg_stream_t stream) {
+    return amdseg_heads_bwd_ce_impl(gout, M, C, nseg, ce_unit2, out12, w_ts, dlogits, S(stream), focal_gamma);
+}
 int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float* dx, const int64_t* idx, long feat_off, long anchor_off,
                           long lists_off, int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
                           long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, amdseg_stream_t stream) {

@@ -3,7 +3,9 @@
 //
 // Reference (emnlp2023-topic_segmentation/src/models/modules):
 //   loss_calculator.py:25-73   loss = ts_w * CE(logits, labels; weight, ignore -100) [+ cl_w * cssl (anchor half)] [+ tssp_w * tssp (DA half)]
-//   utils.py:141-182           weighted CE = sum_i w[y_i] nll_i / sum_i w[y_i]
+//   utils.py:141-182           weighted CE = sum_i w[y_i] nll_i / sum_i w[y_i];  focal_loss_gamma != 0: FocalLoss overwrites its own `reduction`
+//                              with 'mean' before super().forward runs, so what it returns is  mean_i (1 - p_i,t_i)^gamma  x  that SCALAR mean CE
+//                              (t_i = the label, 0 on ignored rows; the mean runs over ALL rows) -- reproduced as is
 //   cssl.py:82-116,118-228     per anchor i: -log( sum_{l < pk} e^{cos(a_i, x_l,i)/tau} / sum_l e^{cos(a_i, x_l,i)/tau} ), mean over anchors
 //                              (lists built on the host with the reference's `random` call order: bert_for_ts.py::_plan_cssl)
 //   tssp.py:16-36              rows at sent_token_mask != -100 -> Linear(H, 3) -> CE (mean); weighted tssp_w twice (tssp.py:36 x :71)
@@ -25,6 +27,7 @@ struct HeadsArgs {
     const int64_t* feat_rows; const int64_t* anchor_idx; const int64_t* lists; int n_anchor, n_list, pk; float inv_temp;
     const float* Wt; const float* bt; const int64_t* t_rows; const int64_t* t_labels; int nt, Ct;
     float w_ts, w_cl, w_tssp2;
+    float gamma;           // focal_loss_gamma; != 0: ce_unit is [M, 2C] (CE unit | focal-factor unit), out[8..9] = mean focal factor, out[10..11] = mean CE per segment
     // backward
     const float* gout; float* dx; float* dWt; float* dbt; float* dlogits;
     float* row_loss;       // forward scratch: per-anchor CSSL terms [n_anchor] followed by per-row TSSP terms [nt]
@@ -35,8 +38,9 @@ struct HeadsArgs {
 // is bit-reproducible run to run)
 __global__ __launch_bounds__(256) void heads_ce_fwd_kernel(HeadsArgs a, float* acc) {      // acc[wave][seg*2 + {0: sum w nll, 1: sum w}]
     const int i = blockIdx.x * 256 + threadIdx.x;
-    float num = 0.f, den = 0.f;
+    float num = 0.f, den = 0.f, foc = 0.f;
     int seg = 0;
+    const int us = a.gamma != 0.f ? 2 * a.C : a.C;          // row stride of ce_unit
     if (i < a.M) {
         seg = i / a.rows_per_seg;
         const int64_t y = a.labels[i];
@@ -51,20 +55,32 @@ __global__ __launch_bounds__(256) void heads_ce_fwd_kernel(HeadsArgs a, float* a
         const float w = valid ? (a.class_w ? a.class_w[y] : 1.0f) : 0.f;
 #pragma unroll
         for (int c = 0; c < HEADS_MAXC; ++c)
-            if (c < a.C) a.ce_unit[(size_t)i * a.C + c] = valid ? w * (expf(lg[c] - lse) - (c == y ? 1.0f : 0.0f)) : 0.f;
+            if (c < a.C) a.ce_unit[(size_t)i * us + c] = valid ? w * (expf(lg[c] - lse) - (c == y ? 1.0f : 0.0f)) : 0.f;
         float ly = 0.f;
 #pragma unroll
         for (int c = 0; c < HEADS_MAXC; ++c) if (c < a.C && c == y) ly = lg[c];
         if (valid) { num = w * (lse - ly); den = w; }
+        if (a.gamma != 0.f) {                               // focal factor of the row: (1 - p_t)^gamma, t = label (0 on ignored rows)
+            const int t = valid ? (int)y : 0;
+            float lt = lg[0];
+#pragma unroll
+            for (int c = 1; c < HEADS_MAXC; ++c) if (c < a.C && c == t) lt = lg[c];
+            const float pt = expf(lt - lse), om = fmaxf(1.0f - pt, 0.f);
+            foc = powf(om, a.gamma);
+            const float dfac = om > 0.f ? a.gamma * powf(om, a.gamma - 1.0f) * pt : 0.f;      // d foc / d z_c = dfac * (p_c - [c == t])
+#pragma unroll
+            for (int c = 0; c < HEADS_MAXC; ++c)
+                if (c < a.C) a.ce_unit[(size_t)i * 2 * a.C + a.C + c] = dfac * (expf(lg[c] - lse) - (c == t ? 1.0f : 0.0f));
+        }
     }
     // rows of one wave may straddle a segment boundary only if rows_per_seg is not a multiple of 64: reduce per segment
 #pragma unroll
     for (int sg = 0; sg < HEADS_MAXSEG; ++sg) {
         if (sg >= a.nseg) break;
-        const float n1 = wave_sum(seg == sg ? num : 0.f), d1 = wave_sum(seg == sg ? den : 0.f);
+        const float n1 = wave_sum(seg == sg ? num : 0.f), d1 = wave_sum(seg == sg ? den : 0.f), f1 = wave_sum(seg == sg ? foc : 0.f);
         if ((threadIdx.x & 63) == 0) {
-            float* slot = acc + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sg * 2;
-            slot[0] = n1; slot[1] = d1;
+            float* slot = acc + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + sg * 4;
+            slot[0] = n1; slot[1] = d1; slot[2] = f1;
         }
     }
 }
@@ -190,18 +206,24 @@ __global__ __launch_bounds__(256) void heads_finalize_kernel(HeadsArgs a, const 
     float tot = 0.f;
     const float cssl = a.n_anchor > 0 ? block_sum_fixed(a.row_loss, a.n_anchor, 1, red) / (float)a.n_anchor : 0.f;
     const float tssp = a.nt > 0 ? block_sum_fixed(a.row_loss + a.n_anchor, a.nt, 1, red) / (float)a.nt : 0.f;
-    float num[HEADS_MAXSEG], dens[HEADS_MAXSEG];
+    float num[HEADS_MAXSEG], dens[HEADS_MAXSEG], focs[HEADS_MAXSEG];
     for (int sg = 0; sg < a.nseg; ++sg) {
-        num[sg] = block_sum_fixed(acc + sg * 2, nwaves, 4, red);
-        dens[sg] = block_sum_fixed(acc + sg * 2 + 1, nwaves, 4, red);
+        num[sg] = block_sum_fixed(acc + sg * 4, nwaves, 8, red);
+        dens[sg] = block_sum_fixed(acc + sg * 4 + 1, nwaves, 8, red);
+        focs[sg] = a.gamma != 0.f ? block_sum_fixed(acc + sg * 4 + 2, nwaves, 8, red) : 0.f;
     }
     if (threadIdx.x != 0) return;
     a.out[2] = cssl; a.out[3] = tssp;
     for (int sg = 0; sg < a.nseg; ++sg) {
         const float den = dens[sg];
-        const float ce = den != 0.f ? num[sg] / den : 0.f / 0.f;     // torch: mean over an empty set = nan
-        a.out[sg] = ce;
+        float ce = den != 0.f ? num[sg] / den : 0.f / 0.f;     // torch: mean over an empty set = nan
         a.out[5 + sg] = den != 0.f ? 1.0f / den : 0.f;
+        if (a.gamma != 0.f) {                                   // focal: mean factor x mean CE (see the header)
+            const float fbar = focs[sg] / (float)a.rows_per_seg;
+            a.out[8 + sg] = fbar; a.out[10 + sg] = ce;
+            ce *= fbar;
+        }
+        a.out[sg] = ce;
         tot += a.w_ts * ce;
     }
     tot += a.w_cl * a.out[2] + a.w_tssp2 * a.out[3];
@@ -211,8 +233,12 @@ __global__ __launch_bounds__(256) void heads_ce_bwd_kernel(HeadsArgs a) {
     const size_t n = (size_t)a.M * a.C;
     const float g = a.gout[0] * a.w_ts;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int seg = (int)((i / a.C) / a.rows_per_seg);
-        a.dlogits[i] = a.ce_unit[i] * g * a.out[5 + seg];
+        const size_t row = i / a.C;
+        const int seg = (int)(row / a.rows_per_seg), c = (int)(i - row * a.C);
+        if (a.gamma == 0.f) { a.dlogits[i] = a.ce_unit[i] * g * a.out[5 + seg]; continue; }
+        // d (fbar * ce) = fbar * d ce + ce * d fbar
+        const float* u = a.ce_unit + row * 2 * a.C;
+        a.dlogits[i] = g * (a.out[8 + seg] * u[c] * a.out[5 + seg] + a.out[10 + seg] * u[a.C + c] / (float)a.rows_per_seg);
     }
 }
 
@@ -244,15 +270,16 @@ static HeadsArgs heads_fill(const float* x, int M, int H, const float* logits, c
 int amdseg_heads_fwd_impl(const float* x, int M, int H, const float* logits, const int64_t* labels, const float* class_w, int C, int nseg,
                           float* ce_unit, float* out8, float* acc, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
                           int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
-                          long t_labels_off, int nt, int Ct, float w_ts, float w_cl, float w_tssp2, hipStream_t s) {
+                          long t_labels_off, int nt, int Ct, float w_ts, float w_cl, float w_tssp2, hipStream_t s, float focal_gamma) {
     HeadsArgs a = heads_fill(x, M, H, logits, labels, class_w, C, nseg, ce_unit, out8, idx, feat_off, anchor_off, lists_off, n_anchor, n_list,
                              pk, temp, Wt, bt, t_rows_off, t_labels_off, nt, Ct, w_ts, w_cl, w_tssp2);
     if (!acc) return AMDSEG_ERR_ARG;
+    a.gamma = focal_gamma;
     int rc = heads_check(a);
     if (rc) return rc;
-    // acc: [4 * ceil(M / 256)][4] per-wave CE partials, then n_anchor + nt per-row loss terms (amdseg.h: amdseg_heads_acc_floats)
+    // acc: [4 * ceil(M / 256)][8] per-wave CE partials (per segment: sum w nll, sum w, sum focal factor, -), then n_anchor + nt per-row loss terms (amdseg.h: amdseg_heads_acc_floats)
     const int blocks = (M + 255) / 256, nwaves = blocks * 4;
-    a.row_loss = acc + (size_t)nwaves * 4;
+    a.row_loss = acc + (size_t)nwaves * 8;
     hipLaunchKernelGGL(heads_ce_fwd_kernel, dim3(blocks), dim3(256), 0, s, a, acc);
     if (n_anchor > 0) hipLaunchKernelGGL(heads_cssl_kernel<false>, dim3((n_anchor + 3) / 4), dim3(256), 0, s, a);
     if (nt > 0) hipLaunchKernelGGL(heads_tssp_kernel<false>, dim3((nt + 3) / 4), dim3(256), 0, s, a);
@@ -263,12 +290,12 @@ int amdseg_heads_fwd_impl(const float* x, int M, int H, const float* logits, con
 // backward: writes dlogits [M,C] (the caller runs the classifier's rowdot backward on it, which WRITES dx), then adds the CSSL / TSSP row
 // gradients into dx and ACCUMULATES dWt / dbt (zeroed by the caller)
 int amdseg_heads_bwd_ce_impl(const float* gout, int M, int C, int nseg, const float* ce_unit, const float* out8, float w_ts, float* dlogits,
-                             hipStream_t s) {
+                             hipStream_t s, float focal_gamma) {
     if (!gout || !ce_unit || !out8 || !dlogits) return AMDSEG_ERR_ARG;
     if (M <= 0 || C < 1 || C > HEADS_MAXC || nseg < 1 || nseg > HEADS_MAXSEG || (M % nseg)) return AMDSEG_ERR_SHAPE;
     HeadsArgs a = {};
     a.M = M; a.C = C; a.nseg = nseg; a.rows_per_seg = M / nseg; a.ce_unit = (float*)ce_unit; a.out = (float*)out8; a.w_ts = w_ts;
-    a.gout = gout; a.dlogits = dlogits;
+    a.gout = gout; a.dlogits = dlogits; a.gamma = focal_gamma;
     size_t blocks = ((size_t)M * C + 255) / 256;
     hipLaunchKernelGGL(heads_ce_bwd_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, a);
     return amdseg_launch_status();

@@ -930,17 +930,21 @@ class FusedHeadsFn(torch.autograd.Function):
         C_ = Wc.shape[0]
         logits = ops.rowdot_fwd(x, Wc, bc)
         dev = x.device
-        out8 = torch.empty(8, dtype=torch.float32, device=dev)
-        acc4 = torch.empty(16 * ((M + 255) // 256) + plan["n_anchor"] + plan["nt"] + 8, dtype=torch.float32, device=dev)
-        unit = torch.empty(M, C_, dtype=torch.float32, device=dev)
+        gamma = float(plan.get("gamma", 0.0))
+        out8 = torch.empty(16, dtype=torch.float32, device=dev)
+        acc4 = torch.empty(32 * ((M + 255) // 256) + plan["n_anchor"] + plan["nt"] + 8, dtype=torch.float32, device=dev)
+        unit = torch.empty(M, C_ * (2 if gamma != 0.0 else 1), dtype=torch.float32, device=dev)
         s = torch.cuda.current_stream().cuda_stream
         P = plan
-        rc = L.load().amdseg_heads_fwd(x.data_ptr(), M, H, logits.data_ptr(), labels_all.data_ptr(), None if class_w is None else class_w.data_ptr(),
-                                       C_, P["nseg"], unit.data_ptr(), out8.data_ptr(), acc4.data_ptr(), idx.data_ptr(), P["feat_off"],
-                                       P["anchor_off"], P["lists_off"], P["n_anchor"], P["n_list"], P["pk"], P["temp"],
-                                       None if Wt is None else Wt.data_ptr(), None if bt is None else bt.data_ptr(), P["t_rows_off"],
-                                       P["t_labels_off"], P["nt"], 0 if Wt is None else Wt.shape[0], P["w_ts"], P["w_cl"], P["w_tssp2"], s)
-        L.check(rc, "amdseg_heads_fwd")
+        args = (x.data_ptr(), M, H, logits.data_ptr(), labels_all.data_ptr(), None if class_w is None else class_w.data_ptr(),
+                C_, P["nseg"], unit.data_ptr(), out8.data_ptr(), acc4.data_ptr(), idx.data_ptr(), P["feat_off"],
+                P["anchor_off"], P["lists_off"], P["n_anchor"], P["n_list"], P["pk"], P["temp"],
+                None if Wt is None else Wt.data_ptr(), None if bt is None else bt.data_ptr(), P["t_rows_off"],
+                P["t_labels_off"], P["nt"], 0 if Wt is None else Wt.shape[0], P["w_ts"], P["w_cl"], P["w_tssp2"])
+        if gamma != 0.0:
+            L.check(L.load().amdseg_heads_fwd_focal(*args, gamma, s), "amdseg_heads_fwd_focal")
+        else:
+            L.check(L.load().amdseg_heads_fwd(*args, s), "amdseg_heads_fwd")
         ctx.save_for_backward(x, Wc, Wt if Wt is not None else x.new_empty(0), bt if bt is not None else x.new_empty(0), idx, unit, out8)
         ctx.plan, ctx.has_tssp = P, Wt is not None
         ctx.mark_non_differentiable(logits)
@@ -956,8 +960,13 @@ class FusedHeadsFn(torch.autograd.Function):
         s = torch.cuda.current_stream().cuda_stream
         g = gloss.reshape(1).float().contiguous()
         dlogits = torch.empty(M, C_, dtype=torch.float32, device=x.device)
-        L.check(lib.amdseg_heads_bwd_ce(g.data_ptr(), M, C_, P["nseg"], unit.data_ptr(), out8.data_ptr(), P["w_ts"], dlogits.data_ptr(), s),
-                "amdseg_heads_bwd_ce")
+        gamma = float(P.get("gamma", 0.0))
+        if gamma != 0.0:
+            L.check(lib.amdseg_heads_bwd_ce_focal(g.data_ptr(), M, C_, P["nseg"], unit.data_ptr(), out8.data_ptr(), P["w_ts"], gamma,
+                                                  dlogits.data_ptr(), s), "amdseg_heads_bwd_ce_focal")
+        else:
+            L.check(lib.amdseg_heads_bwd_ce(g.data_ptr(), M, C_, P["nseg"], unit.data_ptr(), out8.data_ptr(), P["w_ts"], dlogits.data_ptr(), s),
+                    "amdseg_heads_bwd_ce")
         dWc = torch.empty_like(Wc); dbc = torch.empty(C_, dtype=torch.float32, device=x.device)
         dx = ops.rowdot_bwd(x, Wc, dlogits, dW=dWc, db=dbc, need_dx=True)
         dWt = dbt = None

@@ -115,6 +115,9 @@ _PROTOS = {
     "amdseg_heads_fwd": [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, C.c_long, C.c_long, C.c_long, i32, i32, i32, f32, vp, vp,
                          C.c_long, C.c_long, i32, i32, f32, f32, f32, vp],
     "amdseg_heads_bwd_ce": [vp, i32, i32, i32, vp, vp, f32, vp, vp],
+    "amdseg_heads_fwd_focal": [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, C.c_long, C.c_long, C.c_long, i32, i32, i32, f32, vp, vp,
+                               C.c_long, C.c_long, i32, i32, f32, f32, f32, f32, vp],
+    "amdseg_heads_bwd_ce_focal": [vp, i32, i32, i32, vp, vp, f32, f32, vp, vp],
     "amdseg_heads_bwd_rows": [vp, vp, i32, i32, vp, vp, C.c_long, C.c_long, C.c_long, i32, i32, i32, f32, vp, vp, C.c_long, C.c_long, i32, i32,
                               vp, vp, f32, f32, vp],
     "amdseg_prof_enable": [i32],

@@ -393,7 +393,7 @@ def test_real_hf_trainer_train_and_predict(dev, tmp_path):
     assert lab.shape == (len(samples), 2, 64)
 
 
-@pytest.mark.parametrize("variant", ["train_full", "train_eot_list", "train_wce"])
+@pytest.mark.parametrize("variant", ["train_full", "train_eot_list", "train_wce", "train_focal"])
 def test_fused_heads_equal_torch_heads(dev, variant):
     """csrc/heads.hip (token CE + CSSL lists + TSSP in a handful of launches) against the torch formulation of the same heads on the same
     encoder output: loss and every gradient (the reference goldens pin both paths separately; this pins them to each other tightly)"""
