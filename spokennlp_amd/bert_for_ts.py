@@ -283,7 +283,14 @@ class TopicSegHeadsMixin:
             seg_t = up.get(plan["seg"])
             same = seg_t[:, None] == seg_t[None, :]
             num_mask = same & ~torch.eye(n, dtype=torch.bool, device=feats.device)
-            e = torch.exp(_cos(feats.unsqueeze(1), feats.unsqueeze(0), cfg.cl_temp))
+            # cos(x_i, x_j) / temp as ONE [n, H] x [H, n] product of the normalised rows: the broadcast form of nn.CosineSimilarity the reference
+            # uses (cssl.py:56) materialises an [n, n, H] tensor -- 1.2 GB at 640 labelled rows -- for the same numbers
+            if cfg.cl_temp == 0:
+                sim = feats @ feats.t()
+            else:
+                xn = F.normalize(feats, dim=-1, eps=1e-8)
+                sim = (xn @ xn.t()) / cfg.cl_temp
+            e = torch.exp(sim)
             num = (num_mask * e).sum(0)
             den = num + ((~same) * e).sum(0)
             prob = num / den
