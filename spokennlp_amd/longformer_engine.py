@@ -45,6 +45,7 @@ class LongformerEncoderEngine(BertEncoderEngine):
         # stream under the layer's big kernels: forward under the QKV GEMM + band attention, backward under the attention backward
         # and the weight-gradient GEMM.  AMDSEG_LF_OVERLAP=0 keeps everything on one stream.
         self.lf_overlap = os.environ.get("AMDSEG_LF_OVERLAP", "1") != "0" and device.type == "cuda"
+        self._side_pending = False                          # weight gradients of the global projections still running on the second stream
         self._lf_side = torch.cuda.Stream(device=device, priority=int(os.environ.get("AMDSEG_LF_SIDE_PRIO", "0"))) if self.lf_overlap else None
 
     def _on_both(self, main, *tensors):
@@ -65,7 +66,7 @@ class LongformerEncoderEngine(BertEncoderEngine):
 
     def _embed_backward_fixup(self, dpos, pad):
         dpos[self.pad_id].zero_()          # nn.Embedding(padding_idx=pad) of the position table ([hf]:394-396)
-        if getattr(self, "_side_pending", False):      # end of backward: the global projections' weight gradients (side stream) are part of flat_g
+        if self._side_pending:                         # end of backward: the global projections' weight gradients (side stream) are part of flat_g
             torch.cuda.current_stream().wait_stream(self._lf_side)
             self._side_pending = False
 
