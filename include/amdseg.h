@@ -326,6 +326,10 @@ int amdseg_lf_global_out(const float* Wv, const float* bv, const float* y, const
                          int heads, amdseg_stream_t stream);
 int amdseg_lf_global_bwd_a(void* dctx, int dtype, const float* Wv, const float* bv, float* dout, float* dyv, float* dsp, int B, int L, int H,
                            int heads, amdseg_stream_t stream);
+/* the same without zeroing dctx[:, 0] (read-only): for a caller that runs backward phase 6 (AMDSEG_BF16, window > 0: the attention backward
+ * treats the dctx rows of the first nglobal tokens as zero whatever they hold) and this kernel on another stream at the same time */
+int amdseg_lf_global_bwd_a_ro(const void* dctx, int dtype, const float* Wv, const float* bv, float* dout, float* dyv, float* dsp, int B, int L,
+                              int H, int heads, amdseg_stream_t stream);
 int amdseg_lf_global_bwd_rest(const void* x, int x_dtype, void* dx, int dx_dtype, const float* Wq, const float* Wk, const float* qg,
                               const float* dout, const float* y, const float* sp, const float* dr, float* dqg, float* dWq, float* dbq,
                               float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads, float scale, amdseg_stream_t stream);
@@ -416,7 +420,8 @@ typedef struct amdseg_bert_cfg {
                                        the ctx rows of the first nglobal tokens of a sequence, so the caller may write them
                                        from another stream while phase 1 runs; the fp32 dtypes store a band row there that
                                        the caller overwrites AFTER phase 1) and consumes + zeroes its dctx row between
-                                       backward phases.
+                                       backward phases (AMDSEG_BF16, window > 0, backward phase 6: the attention backward takes the
+                                       dctx rows of the first nglobal tokens as zero itself -- amdseg_lf_global_bwd_a_ro).
                                        Backward only: 6 = phase 2 without the grouped weight-gradient GEMM, 4 = that GEMM
                                        alone (e.g. on a second stream, under the next layer's backward; the caller orders
                                        the streams and must not reuse ws before it has run). */

@@ -68,7 +68,7 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
                          int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,
-                         const int* qguard = nullptr, const void* keep = nullptr);
+                         const int* qguard = nullptr, const void* keep = nullptr, int skip_q = 0);
 size_t amdseg_attn_keepmask_bytes_impl(int B, int L, int heads);
 int amdseg_attn_keepmask_impl(void* keep, int B, int L, int heads, float p, uint64_t seed, const int* kend, hipStream_t s, int window = 0,
                               int nglobal = 0);
@@ -161,7 +161,7 @@ int amdseg_lf_global_q_impl(const void* x, int x_dtype, const float* Wq, const f
 int amdseg_lf_global_out_impl(const float* Wv, const float* bv, const float* y, const float* sp, void* ctx, int ctx_dtype, int B, int L, int H,
                               int heads, hipStream_t s);
 int amdseg_lf_global_bwd_a_impl(void* dctx, int dtype, const float* Wv, const float* bv, float* dout, float* dyv, float* dsp, int B, int L,
-                                int H, int heads, hipStream_t s);
+                                int H, int heads, hipStream_t s, int keep_dctx = 0);
 int amdseg_lf_global_bwd_rest_impl(const void* x, int x_dtype, void* dx, int dx_dtype, const float* Wq, const float* Wk, const float* qg,
                                    const float* dout, const float* y, const float* sp, const float* dr, float* dqg, float* dWq, float* dbq,
                                    float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads, float scale, hipStream_t s);

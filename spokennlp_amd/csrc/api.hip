@@ -278,6 +278,10 @@ int amdseg_lf_global_bwd_a(void* dctx, int dtype, const float* Wv, const float* 
                            int heads, amdseg_stream_t stream) {
     return amdseg_lf_global_bwd_a_impl(dctx, dtype, Wv, bv, dout, dyv, dsp, B, L, H, heads, S(stream));
 }
+int amdseg_lf_global_bwd_a_ro(const void* dctx, int dtype, const float* Wv, const float* bv, float* dout, float* dyv, float* dsp, int B, int L,
+                              int H, int heads, amdseg_stream_t stream) {
+    return amdseg_lf_global_bwd_a_impl((void*)dctx, dtype, Wv, bv, dout, dyv, dsp, B, L, H, heads, S(stream), 1);
+}
 int amdseg_lf_global_bwd_rest(const void* x, int x_dtype, void* dx, int dx_dtype, const float* Wq, const float* Wk, const float* qg,
                               const float* dout, const float* y, const float* sp, const float* dr, float* dqg, float* dWq, float* dbq,
                               float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads, float scale, amdseg_stream_t stream) {
@@ -595,7 +599,9 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     if (c->mixer == 0)
         RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                     site_seed(c->seed, li, 0), c->window, c->nglobal, s, c->kend, c->seq_order, c->pad_guard,
-                                    c->p_attn > 0.f ? a->keep : nullptr));
+                                    c->p_attn > 0.f ? a->keep : nullptr,
+                                    // phase 6 of a band layer with global tokens: their dctx rows count as zero (amdseg.h, `phase`)
+                                    (c->phase == 6 && c->window > 0) ? c->nglobal : 0));
     // dx_in = dqkv . Wqkv + dz1   (external mixer: the caller wrote ws.dqkv [M, nproj*H] between the phases)
     RET_IF(amdseg_gemm_nt_impl(w->dqkv, NP, p->wqkv_t, NP, dx_in, H, M, H, NP, AMDSEG_EPI_ADD_RES, nullptr, w->dz1, H, nullptr, 0, 0, s, ZPAD));
     }

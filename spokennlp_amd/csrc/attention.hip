@@ -394,6 +394,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         const bf16_t* dp = a.dctx + (tok0 + q) * H + h * HD;
         fdo[0] = *reinterpret_cast<const bf16x8*>(dp + g * 8);
         fdo[1] = *reinterpret_cast<const bf16x8*>(dp + 32 + g * 8);
+        if (BAND && q < a.skip_q) {                         // a global token's row: its dO counts as zero (delta = 0, dP = 0, dQ row = 0)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { fdo[0][e] = 0; fdo[1][e] = 0; }
+        }
     }
     // delta_q = rowsum(dO * O) of this lane's query row: computed here from the fragments already in registers (was a separate
     // launch); written out for the dK/dV kernel, which runs after this one on the same stream
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         bool edge = false;
         if (BAND) {
             const int wk_lo = kb * (NW * 16) + w * 16;
-            edge = !(q0 >= wk_lo + 15 - a.window && q0 + CH - 1 <= wk_lo + a.window);
+            edge = !(q0 >= wk_lo + 15 - a.window && q0 + CH - 1 <= wk_lo + a.window) || q0 < a.skip_q;
         }
         f32x4 pd[4], ds[4];     // P_drop[q][key], dS[q][key] : lane key = i16, q = qf*16 + g*4 + r
         f32x4 sacc4[4], pacc4[4];
@@ -742,8 +746,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                 const f32x2 t = (f32x2){sacc[rp * 2], sacc[rp * 2 + 1]} * sc2v;
                 f32x2 pe = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
                 if (BAND && edge) {
-                    if (band_masked(q0 + qf * 16 + g * 4 + rp * 2, key, a.window, a.nglobal)) pe.x = 0.f;
-                    if (band_masked(q0 + qf * 16 + g * 4 + rp * 2 + 1, key, a.window, a.nglobal)) pe.y = 0.f;
+                    // (a query in front of skip_q: its dO counts as zero -- p = 0 removes its terms from dV and, through dS = p (dP - delta), from dK)
+                    const int qa = q0 + qf * 16 + g * 4 + rp * 2;
+                    if (band_masked(qa, key, a.window, a.nglobal) || qa < a.skip_q) pe.x = 0.f;
+                    if (band_masked(qa + 1, key, a.window, a.nglobal) || qa + 1 < a.skip_q) pe.y = 0.f;
                 }
                 f32x2 pk = pe;                                           // P_drop without the 1 / keep-rate factor (applied to dV at the end)
                 if (KM) {                                                // stored lane masks (layout B: lane = key row)
@@ -868,11 +874,12 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
 
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
-                         int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order, const int* qguard, const void* keep) {
+                         int window, int nglobal, hipStream_t s, const int* kend, const int* seq_order, const int* qguard, const void* keep, int skip_q) {
     if (!qkv || !mask_bias || !ctx || !dctx || !lse || !delta || !dqkv) return AMDSEG_ERR_ARG;
     AttnArgs a = {};
     int rc = attn_fill(a, B, L, heads, scale, p, seed, window, nglobal);
     if (rc) return rc;
+    a.skip_q = window > 0 ? skip_q : 0;
     a.kend = kend; a.seq_order = (window > 0 || !kend) ? nullptr : seq_order; a.qguard = (window > 0 || !kend) ? nullptr : qguard;
     a.qkv = (const bf16_t*)qkv; a.mask_bias = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = (float*)lse;
     a.dctx = (const bf16_t*)dctx; a.delta = delta; a.dqkv = (bf16_t*)dqkv;

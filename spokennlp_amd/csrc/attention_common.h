@@ -63,7 +63,9 @@ struct AttnArgs {
     const int* qguard;                      // optional (backward, with kend): *qguard == 0 <=> the dctx rows at positions >= kend[b] are exact zeros
                                             // (amdseg_bert_cfg.pad_guard): those query rows get dQ = 0 and add nothing to dK / dV, so they are not visited
     int skip_q;                             // forward, band: the ctx rows of the first skip_q queries of every sequence are NOT stored (their LSE is): the
-                                            // caller of a phase-1 layer call writes the global tokens' rows itself, from another stream if it likes
+                                            // caller of a phase-1 layer call writes the global tokens' rows itself, from another stream if it likes.
+                                            // backward, band: the dctx rows of those queries count as ZERO whatever they hold (their gradient belongs to
+                                            // the caller's global-row backward, which may read them while these kernels run)
     const uint64_t* keepA;                  // dropout keep bits written by attn_keepmask_kernel (KM instantiations), lane-mask layouts A (forward,
     const uint64_t* keepB;                  // dQ) and B (dK/dV), see "dropout keep masks" below
 };

@@ -23,6 +23,7 @@ struct LfGArgs {
     float* dWq; float* dbq; float* dWk; float* dWv; float* dbv;
     void* dx; int dx_dtype;
     float scale;
+    int keep_dctx;                                         // lf_global_bwd_a: 1 = read dctx[:, 0] only (do not zero it)
     int qpart;                                             // lf_global_bwd_q: 0 = weight rows + dx rows, 1 = weight rows only, 2 = dx rows only
     float* trow;                                           // dx rows, optional [B, H]: Wq^T dqg[b] is WRITTEN here instead of added to dx[b, 0, :]
 };
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void lf_global_bwd_a_kernel(LfGArgs a) {
         const float v = ld_any(a.dctx, i, a.ctx_dtype);
         d[threadIdx.x] = v;
         a.dout[bh * 64 + threadIdx.x] = v;
-        st_any(a.dctx, i, 0.f, a.ctx_dtype);             // the band attention's own row 0 was overwritten in forward: no gradient
+        if (!a.keep_dctx) st_any(a.dctx, i, 0.f, a.ctx_dtype);    // the band attention's own row 0 was overwritten in forward: no gradient
     }
     __syncthreads();
     for (int c = threadIdx.x; c < a.H; c += 256) {
@@ -240,12 +241,13 @@ int amdseg_lf_global_out_impl(const float* Wv, const float* bv, const float* y, 
     return amdseg_launch_status();
 }
 int amdseg_lf_global_bwd_a_impl(void* dctx, int dtype, const float* Wv, const float* bv, float* dout, float* dyv, float* dsp, int B, int L,
-                                int H, int heads, hipStream_t s) {
+                                int H, int heads, hipStream_t s, int keep_dctx) {
     if (!dctx || !Wv || !bv || !dout || !dyv || !dsp) return AMDSEG_ERR_ARG;
     int rc = lfg_check(B, L, H, heads);
     if (rc) return rc;
     LfGArgs a = {};
     a.L = L; a.H = H; a.heads = heads; a.B = B; a.Wv = Wv; a.bv = bv; a.dctx = dctx; a.ctx_dtype = dtype; a.dout = dout; a.dyv = dyv; a.dsp = dsp;
+    a.keep_dctx = keep_dctx;
     hipLaunchKernelGGL(lf_global_bwd_a_kernel, dim3(heads, B), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }

@@ -104,6 +104,7 @@ _PROTOS = {
     "amdseg_lf_global_q": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "amdseg_lf_global_out": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "amdseg_lf_global_bwd_a": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "amdseg_lf_global_bwd_a_ro": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "amdseg_lf_global_bwd_rest": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "amdseg_ponet_global_scratch_floats": [i32, i32, i32, i32],
     "amdseg_ponet_global_fwd": [vp, vp, i32, vp, vp, i32, i32, i32, i32, f32, u64, vp, vp, vp, vp, vp, vp],

@@ -150,27 +150,33 @@ class LongformerEncoderEngine(BertEncoderEngine):
         f32 = dict(dtype=torch.float32, device=dev)
         main = torch.cuda.current_stream()
         side = self._lf_side if self.lf_overlap else main
+        fast = side is not main and adt == L.BF16
         with torch.no_grad():
             Wq, Wk = self._gp(fp, i, "query_global", "weight"), self._gp(fp, i, "key_global", "weight")
             Wv, bv = self._gp(fp, i, "value_global", "weight"), self._gp(fp, i, "value_global", "bias")
-            dout, dyv, dsp = torch.empty(B, heads, 64, **f32), torch.empty(B, heads, H, **f32), torch.empty(B, heads, **f32)
-            # consumes + zeroes dctx[:, 0] (the band attention's own row 0 was overwritten in forward: no gradient); on the main stream:
-            # the attention backward below reads dctx
-            L.check(lib.amdseg_lf_global_bwd_a(dctx.data_ptr(), adt, Wv.data_ptr(), bv.data_ptr(), dout.data_ptr(), dyv.data_ptr(),
-                                               dsp.data_ptr(), B, Lseq, H, heads, s), "amdseg_lf_global_bwd_a")
-        if side is not main and adt == L.BF16:
+            if not fast:
+                dout, dyv, dsp = torch.empty(B, heads, 64, **f32), torch.empty(B, heads, H, **f32), torch.empty(B, heads, **f32)
+                # consumes + zeroes dctx[:, 0] (the band attention's own row 0 was overwritten in forward: no gradient); on the main stream:
+                # the attention backward below reads dctx
+                L.check(lib.amdseg_lf_global_bwd_a(dctx.data_ptr(), adt, Wv.data_ptr(), bv.data_ptr(), dout.data_ptr(), dyv.data_ptr(),
+                                                   dsp.data_ptr(), B, Lseq, H, heads, s), "amdseg_lf_global_bwd_a")
+        if fast:
             # Two-stream order of the bf16 path.  Everything the global row adds to dx -- the rank-2*heads update and the [CLS] row's own
             # term -- depends only on dctx[:, 0] and saved tensors, so the side stream prepares it under the band attention backward + dx GEMM
             # (operand image vt, row vector trow) and main applies it in one read-modify-write pass right behind the dx GEMM; the weight
             # gradients of the three global projections follow on the side stream and are joined once, at the end of backward
             # (_embed_backward_fixup).  (The update + the row term + the weight gradients used to run under the weight-gradient GEMM, which
-            # slowed them 3-5 x and left main waiting ~45 us per layer for the hand-back.)
+            # slowed them 3-5 x and left main waiting ~45 us per layer for the hand-back.)  Backward phase 6 takes the [CLS] rows of dctx as zero
+            # itself (include/amdseg.h), so even the kernel that consumes them (amdseg_lf_global_bwd_a_ro) runs on the side stream.
             e1 = torch.cuda.Event(); e1.record(main)
             cfg.phase = 6                                      # attention backward + dx GEMM, queued before the host issues the chain
             L.check(lib.amdseg_bert_layer_bwd(*args), f"amdseg_bert_layer_bwd[{i}].2")
             side.wait_event(e1)
             with torch.no_grad(), torch.cuda.stream(side):
                 ss = side.cuda_stream
+                dout, dyv, dsp = torch.empty(B, heads, 64, **f32), torch.empty(B, heads, H, **f32), torch.empty(B, heads, **f32)
+                L.check(lib.amdseg_lf_global_bwd_a_ro(dctx.data_ptr(), adt, Wv.data_ptr(), bv.data_ptr(), dout.data_ptr(), dyv.data_ptr(),
+                                                      dsp.data_ptr(), B, Lseq, H, heads, ss), "amdseg_lf_global_bwd_a_ro")
                 dpd = ops.lf_rowvec_dot(x_in, dyv, B, Lseq, add_bh=dsp)
                 ds, pd = ops.lf_softmax_bwd(p, dpd, cfg.p_attn, saved["seed"])
                 dr = ops.lf_wsum(x_in, ds, H, A["lf_partials"])
