@@ -530,6 +530,15 @@ def main():
                                           + (f"the {prof_n} steps of the timed region" if prof_timed else f"{prof_n} real steps right after the "
                                              f"timed region") + "; HBM traffic needs separate rocprofv3 --pmc passes: see profiles/",
                                    kernels=prof)
+            # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this is the figure of the
+            # committed separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over THIS command and workload, not a live reading
+            if (dom == "gemm_nt_dp_kernel" and args.model == "bert" and args.mode == "train" and args.seq_len == 512 and args.seqs_per_gpu == 32
+                    and args.workload == "full_da" and getattr(args, "precision", "bf16") in (None, "bf16")):
+                out["roofline"]["traffic"] = 1.82e8
+                out["roofline"]["traffic_unit"] = "B per launch (algorithmic: 1.356e8)"
+                out["roofline"]["traffic_source"] = ("profiles/r03_pmc_instep.md: two separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 "
+                                                     "correction of MI355X_MICROARCH.md, + WRITE_SIZE) over `python bench.py --steps 4 --warmup 2`, "
+                                                     "average of the 8 NT launches of a layer; not re-measured by this run")
             if args.standalone_gemm:
                 out["roofline"]["standalone"] = gemm_roofline(model, args, device)
         if not args.no_roofline and args.model == "ponet":
