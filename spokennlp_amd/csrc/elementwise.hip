@@ -923,11 +923,17 @@ int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K,
 // comparison with the one taken last time -- "were these weights written since the bf16 copies were made?" answered on the device, no host read
 __global__ __launch_bounds__(256) void checksum_u64_kernel(const uint4* __restrict__ x, size_t n16, unsigned long long* state) {
     unsigned long long acc = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
-        const uint4 v = x[i];
-        const unsigned long long w = (unsigned long long)(((uint32_t)i * 2654435761u) | 1u);
-        acc += (unsigned long long)v.x * w + (unsigned long long)v.y * (w + 2) + (unsigned long long)v.z * (w + 4) + (unsigned long long)v.w * (w + 6);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#define CK_TERM(v, idx) do { const unsigned long long w = (unsigned long long)(((uint32_t)(idx) * 2654435761u) | 1u); \
+        acc += (unsigned long long)(v).x * w + (unsigned long long)(v).y * (w + 2) + (unsigned long long)(v).z * (w + 4) + (unsigned long long)(v).w * (w + 6); } while (0)
+    // four 16-B loads in flight per lane (one at a time left this pass latency-bound: 154 us for 340 MB)
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 v0 = x[i], v1 = x[i + stride], v2 = x[i + 2 * stride], v3 = x[i + 3 * stride];
+        CK_TERM(v0, i); CK_TERM(v1, i + stride); CK_TERM(v2, i + 2 * stride); CK_TERM(v3, i + 3 * stride);
     }
+    for (; i < n16; i += stride) { const uint4 v = x[i]; CK_TERM(v, i); }
+#undef CK_TERM
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(state, acc);
