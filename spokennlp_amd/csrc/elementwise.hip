@@ -558,10 +558,13 @@ struct CastTransposeBatch {
 __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(CastTransposeBatch b) {
     __shared__ bf16_t tile[64][66];
     if (b.only_if && *b.only_if == 0) return;
+    // (the conditional form is launched with a capped grid and walks the tiles: its usual case is 'nothing changed', and 20736 workgroups that only
+    //  read the flag still cost ~15 us per inference forward)
+    for (int tb = blockIdx.x; tb < b.tile0[b.n]; tb += gridDim.x) {
     int m = 0;
-    while (m + 1 < b.n && (int)blockIdx.x >= b.tile0[m + 1]) ++m;
+    while (m + 1 < b.n && tb >= b.tile0[m + 1]) ++m;
     const float* W = b.W[m]; bf16_t* Wb = b.Wb[m]; bf16_t* Wt = b.Wt[m];
-    const int N = b.N[m], K = b.K[m], t = blockIdx.x - b.tile0[m], kt = K / 64;
+    const int N = b.N[m], K = b.K[m], t = tb - b.tile0[m], kt = K / 64;
     const int n0 = (t / kt) * 64, k0 = (t % kt) * 64;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
@@ -591,6 +594,8 @@ __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(CastTranspo
             pk.y = (uint32_t)tile[tx * 4 + 2][kr] | ((uint32_t)tile[tx * 4 + 3][kr] << 16);
             *reinterpret_cast<uint2*>(Wt + (size_t)(k0 + kr) * N + n0 + tx * 4) = pk;
         }
+    }
+    __syncthreads();                                        // the tile is rewritten by the next iteration
     }
 }
 
@@ -969,7 +974,7 @@ int amdseg_cast_transpose_batched_impl(int n, const float* const* W, void* const
         }
         b.tile0[b.n] = tiles;
         b.only_if = only_if;
-        hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3(tiles), dim3(256), 0, s, b);
+        hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3(only_if && tiles > 1024 ? 1024 : tiles), dim3(256), 0, s, b);
     }
     return amdseg_launch_status();
 }
