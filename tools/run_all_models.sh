@@ -22,4 +22,6 @@ run --model longformer --seq-len 2048 --seqs-per-gpu 4 --steps 20 --warmup 5
 run --model bigbird --seq-len 2048 --seqs-per-gpu 4 --steps 20 --warmup 5
 run --model longformer --precision parity --steps 8 --warmup 3
 run --seqs-per-gpu 8 --steps 40 --warmup 10
+run --mode infer --precision parity --steps 30 --warmup 8
+run --model longformer --mode infer --precision parity --steps 15 --warmup 5
 cat $OUT
