@@ -392,7 +392,9 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     const int M = c->B * c->L, H = c->H, I = c->I;
     if (c->dtype == AMDSEG_F32S) {
         // "parity" precision (csrc/parity.hip): fp32 activations, every product as one bf16 GEMM over K' = 3K on split images
-        if (!a->xs || !a->ctx_s || !a->x1_s || !a->h_s || !a->u) return AMDSEG_ERR_ARG;
+        if (!a->xs || !a->ctx_s || !a->x1_s || !a->h_s) return AMDSEG_ERR_ARG;
+        const bool ffn_fused = c->act == 0 && (M % 256) == 0 && (I % 256) == 0 && !(parity_unfused() & 4);
+        if (!a->u && !ffn_fused) return AMDSEG_ERR_ARG;      // u == NULL (inference): only the fused up-projection epilogue can leave it out
         const float* fx = (const float*)a->x_in;
         if (PHASE1(c)) {
             RET_IF(amdseg_split3_impl(fx, H, a->xs, M, H, 0, s));
@@ -425,7 +427,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
                                       site_seed(c->seed, li, 1), AMDSEG_F32, s, ln_img ? a->x1_s : nullptr));
         if (!ln_img) RET_IF(amdseg_split3_impl((const float*)a->x1, H, a->x1_s, M, H, 0, s));
-        if (c->act == 0 && (M % 256) == 0 && (I % 256) == 0 && !(parity_unfused() & 4))       // u (fp32, read by backward) and the image of gelu(u) from one epilogue
+        if (ffn_fused)       // u (fp32, read by backward; NULL in inference) and the image of gelu(u) from one epilogue
             RET_IF(amdseg_gemm_nt_impl(a->x1_s, 3 * H, p->w1, 3 * H, a->u, I, M, I, 3 * H, AMDSEG_EPI_BIAS_GELU_SPLIT, p->b1, nullptr, 0, a->h_s, 3 * I, 1, s));
         else {
             RET_IF(amdseg_gemm_nt_impl(a->x1_s, 3 * H, p->w1, 3 * H, a->u, I, M, I, 3 * H, AMDSEG_EPI_BIAS, p->b1, nullptr, 0, nullptr, 0, 1, s));

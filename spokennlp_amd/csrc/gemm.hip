@@ -629,7 +629,7 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
 int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                         int epi, const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32,
                         hipStream_t stream, const int* zkend, const int* zguard, int zL) {
-    if (!A || !B || !C) return AMDSEG_ERR_ARG;
+    if (!A || !B || (!C && (epi & 0xff) != 7)) return AMDSEG_ERR_ARG;      // (BIAS_GELU_SPLIT: C == NULL = no pre-activation output)
     const int act = (epi >> 8) & 1;                         // AMDSEG_EPI_ACT_TANH: gelu_new instead of the erf GELU
     epi &= 0xff;
     const bool big = (M % PP_BM) == 0 && (N % PP_BN) == 0, small = (M % BM) == 0 && (N % BN) == 0;

@@ -179,9 +179,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                 for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * ep][r]; v[4 + r] = acc[mf][2 * ep + 1][r]; }
                 const size_t col = (size_t)(n0 + wc * 64 + ep * 32 + g * 8);
                 if (EPI == EPI_BIAS_GELU_SPLIT) {              // the fp32 pre-activation, then the activation as a split image
-                    float* dst = reinterpret_cast<float*>(a.C) + gm * a.ldc + col;
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    if (a.C) {                                     // (inference passes no pre-activation buffer: only backward reads it)
+                        float* dst = reinterpret_cast<float*>(a.C) + gm * a.ldc + col;
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
                     uint4 hi; hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]); hi.z = pack2bf(v[4], v[5]); hi.w = pack2bf(v[6], v[7]);

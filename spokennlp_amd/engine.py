@@ -547,6 +547,9 @@ class BertEncoderEngine:
                 ptrs["qkv_s"] = la["qkv_s"].data_ptr()
             if not train and not fp32:
                 ptrs["u"] = None                  # inference: the FFN GEMM skips the pre-activation output
+            if (not train and parity and M % 256 == 0 and self.I % 256 == 0 and getattr(self.cfg, "hidden_act", "gelu") == "gelu"
+                    and not (int(__import__("os").environ.get("AMDSEG_PARITY_UNFUSED", "0")) & 4)):
+                ptrs["u"] = None                  # "parity" inference: the fused up-projection epilogue writes only the image of gelu(u)
             A["acts_struct"].append(L.LayerActs(x_in=xin.data_ptr(), x_out=xout.data_ptr(), **ptrs))
         A["x_final"] = A["x"][self.nlayers] if train else A["x"][self.nlayers % 2]
         self._arenas[key] = A
