@@ -293,15 +293,15 @@ def host_cpu():
 
 def cpu_baseline(args):
     """the CPU oracle (validated against the reference's golden vectors; it is the restatement that runs here, not the reference's
-    files) timed on the host cores: bert-base shape, B = 8 sequences of 512 tokens, forward + backward + clip + AdamW in fp32 with
-    stock PyTorch CPU ops, one thread per PHYSICAL core -- a reported baseline, not the target.  Bounded: 1 warm-up step, then timed
-    steps until ~30 s are spent (at least 3, at most 10; SURVEY 8d asks for 3 + 10, which would take minutes at ~10 s per step)."""
+    files) timed on the host cores: bert-base shape, B = 8 sequences of 512 tokens, fp32 stock PyTorch CPU ops.  Two legs:
+    forward-only (eval, no_grad) and the training step (forward + backward + clip + AdamW).  The thread count is SWEPT (more threads than
+    ~one NUMA domain make B = 8 x 512 slower, round 3: 128 threads 0.64 seq/s, 8 threads 1.42): forward-only over {8, 16, 32, 64,
+    physical cores} (1 warm-up + 2 timed each), then the training step at the two best counts (1 warm-up + 3 timed each); `value` is the
+    best training figure, `cores` the threads that gave it.  A reported baseline, not the target."""
     from oracle import bert_ts_oracle as O
     from tests.util import tiny_state_dict
     from spokennlp_amd import data
     model, phys, logical = host_cpu()
-    threads = max(1, phys)
-    torch.set_num_threads(threads)
     arch = dict(vocab_size=30523, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
                 max_position_embeddings=512, type_vocab_size=2)
     flags = dict(do_da_ts=True, do_cssl=True, do_tssp=True, cl_loss_weight=0.5, cl_temp=0.1, cl_anchor_level="eop_list",
@@ -315,7 +315,7 @@ def cpu_baseline(args):
     batch = data.batches_from_docs(docs, args.seq_len, pairs, seed=1)[0]
     opt = torch.optim.AdamW(list(params.values()), lr=5e-5)
 
-    def step():
+    def train_step():
         opt.zero_grad(set_to_none=True)
         random.seed(0)
         loss, _, _ = O.model_forward(params, cfg, batch)
@@ -323,17 +323,115 @@ def cpu_baseline(args):
         torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
         opt.step()
 
-    step()
-    times = []
-    t0 = time.time()
-    while len(times) < 3 or (time.time() - t0 < 30 and len(times) < 10):
-        t = time.time(); step(); times.append(time.time() - t)
-    times.sort()
-    med = times[len(times) // 2]
-    return dict(value=round(nseq / med, 3), unit="seq/s", cores=threads, kind="port", cpu=model,
-                sample=f"median of {len(times)} train steps (1 warm-up; fwd+bwd+clip+AdamW, fp32 torch CPU oracle = the restatement, not the "
-                       f"reference's files) of {nseq} x {args.seq_len}-token sequences, bert-base shape; {threads} threads = physical cores "
-                       f"of {model} ({logical} logical CPUs)")
+    def fwd_step():
+        random.seed(0)
+        with torch.no_grad():
+            O.model_forward(params, cfg, batch)
+
+    def timed(fn, n):
+        fn()
+        ts = []
+        for _ in range(n):
+            t = time.time(); fn(); ts.append(time.time() - t)
+        ts.sort()
+        return ts[len(ts) // 2] if n % 2 else ts[0]          # median of an odd count, best of an even one
+
+    t_start = time.time()
+    counts = sorted({c for c in (8, 16, 32, 64, phys) if 1 <= c <= max(phys, 8)})
+    fwd = {}
+    for c in counts:
+        torch.set_num_threads(c)
+        fwd[c] = round(nseq / timed(fwd_step, 2), 3)
+    order = sorted(counts, key=lambda c: -fwd[c])
+    train = {}
+    for c in order[:2]:
+        if time.time() - t_start > 75 and train:
+            break
+        torch.set_num_threads(c)
+        train[c] = round(nseq / timed(train_step, 3), 3)
+    best = max(train, key=lambda c: train[c])
+    best_f = order[0]
+    return dict(value=train[best], unit="seq/s", cores=best, kind="port", cpu=model, physical_cores=phys, logical_cpus=logical,
+                forward_only=dict(value=fwd[best_f], unit="seq/s", cores=best_f),
+                thread_sweep=dict(forward_only_seq_per_s={str(c): fwd[c] for c in counts}, train_seq_per_s={str(c): train[c] for c in train}),
+                seconds=round(time.time() - t_start, 1),
+                sample=f"fp32 torch CPU oracle (= the restatement validated against the reference's golden vectors, not the reference's files), "
+                       f"bert-base shape, {nseq} x {args.seq_len}-token sequences per step, {args.workload}: forward-only (eval, no_grad) swept over "
+                       f"{counts} threads (1 warm-up + best of 2), training step (fwd+bwd+clip+AdamW) at the two best counts (1 warm-up + median "
+                       f"of 3); value = best training figure; {model}, {phys} physical cores / {logical} logical CPUs")
+
+
+def run_leg(args, device, mode, precision, steps, warmup, prof_steps, seed=7):
+    """one secondary leg on rank 0 (world 1): the same workload at another (mode, precision), its own model and batches, wall clock
+    around `steps` steps bracketed by synchronize, then `prof_steps` more with the launch timer armed (in-step roofline)."""
+    import copy
+    a = copy.copy(args)
+    a.mode, a.precision = mode, precision
+    model, cfg = build(a, device)
+    eng = model.engine()
+    batches, pairs = make_batches(a, 8, seed=seed, device=device)
+    if mode == "infer":
+        model.eval()
+    total = steps + warmup + prof_steps
+
+    def step(i):
+        random.seed(i)
+        if mode == "infer":
+            with torch.no_grad():
+                return model(**batches[i % len(batches)])[0]
+        loss = model(**batches[i % len(batches)])[0]
+        loss.backward()
+        eng.finish_grad_sync()
+        eng.adamw_step(5e-5 * max(0.0, (total - i) / total), max_grad_norm=1.0, grad_scale=1.0)
+        return loss
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    value = a.seqs_per_gpu * steps / dt
+    fl = flops_per_seq(a.seq_len, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, mode == "train")
+    out = dict(value=round(value, 1), unit="seq/s", mode=mode, precision=precision, steps=steps, warmup=warmup,
+               ms_per_step=round(dt / steps * 1e3, 3), seqs_per_step=a.seqs_per_gpu, seq_len=a.seq_len,
+               mfma_frac_whole_step=round(value * fl / (MFMA_PEAK_TFLOPS * 1e12), 4), final_loss=round(float(loss.detach()), 4))
+    prof = instep_roofline(step, warmup + steps, prof_steps) if prof_steps else None
+    if prof:
+        dom = "gemm_nt_dp_kernel" if "gemm_nt_dp_kernel" in prof else max(prof, key=lambda k: prof[k]["us_per_step"])
+        d = prof[dom]
+        rl = dict(bound="mfma", kernel=dom, achieved=d["achieved"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=d["frac"],
+                  avg_launch_us=d["avg_launch_us"], launches_per_step=d["launches_per_step"], gflop_per_launch=d["gflop_per_launch"],
+                  kernels=prof)
+        if precision == "parity":
+            rl["note"] = ("flops are the EXECUTED split-bf16 products (K' = 3K: hi*hi + hi*lo + lo*hi); on the reference's fp32 flops the "
+                          "fraction is frac / 3")
+            rl["frac_reference_flops"] = round(d["frac"] / 3.0, 4)
+        out["roofline"] = rl
+    del model, eng, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def pmc_traffic(args):
+    """profiles/pmc_traffic.json if it describes this workload, else None"""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    w = tr.get("workload", {})
+    mine = dict(model=args.model, mode=args.mode, seq_len=args.seq_len, seqs_per_gpu=args.seqs_per_gpu, workload=args.workload,
+                precision=getattr(args, "precision", "bf16"))
+    return tr if all(w.get(k) == v for k, v in mine.items()) else None
+
+
+def parity_report(device):
+    """SURVEY 8(d) "Parity report": the HIP path in the fast (bf16) and in the tolerance-meeting ("parity") precision against the
+    reference's stored outputs; measured here so the driver-run line carries it (tests/parity_values.py; outside every timed region)."""
+    from tests import parity_values as PV
+    return PV.rounded(PV.measure(device))
 
 
 def via_trainer(args, device, nsteps=30, nwarm=8, nan_filter=False):
@@ -397,6 +495,8 @@ def main():
     ap.add_argument("--standalone-gemm", action="store_true", help="also time the gemm_nt shapes back to back on warm operands")
     ap.add_argument("--via-trainer", action="store_true", help="force the transformers.Trainer leg (default: on for bert, 1 GPU, train)")
     ap.add_argument("--no-via-trainer", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip parity_report / parity_leg / infer_leg (default: on for the default workload: bert, 1 GPU, train, bf16)")
     ap.add_argument("--prof-steps", type=int, default=10, help="extra steps with the launch timer armed (roofline) when it is not armed "
                                                                "over the timed region itself")
     ap.add_argument("--prof-in-timed", action="store_true", help="arm the launch timer over the timed region itself instead of over "
@@ -459,7 +559,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     sync_marks.clear()
-    prof_timed = (not args.no_roofline) and args.mode == "train" and args.prof_in_timed and prof_arm()
+    prof_timed = (not args.no_roofline) and args.prof_in_timed and prof_arm()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
@@ -502,7 +602,7 @@ def main():
     prof_n = args.steps
     if prof_timed:                                          # start / stop events of every launch of the timed region itself
         prof = prof_collect(args.steps)
-    elif not args.no_roofline and args.mode == "train":    # every rank runs the extra steps (the exchange is collective); rank 0 reports
+    elif not args.no_roofline:                              # every rank runs the extra steps (the exchange is collective); rank 0 reports
         prof = instep_roofline(step, total_steps, args.prof_steps)
         prof_n = args.prof_steps
     if rank == 0:
@@ -530,15 +630,18 @@ def main():
                                           + (f"the {prof_n} steps of the timed region" if prof_timed else f"{prof_n} real steps right after the "
                                              f"timed region") + "; HBM traffic needs separate rocprofv3 --pmc passes: see profiles/",
                                    kernels=prof)
-            # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this is the figure of the
-            # committed separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over THIS command and workload, not a live reading
-            if (dom == "gemm_nt_dp_kernel" and args.model == "bert" and args.mode == "train" and args.seq_len == 512 and args.seqs_per_gpu == 32
-                    and args.workload == "full_da" and getattr(args, "precision", "bf16") in (None, "bf16")):
-                out["roofline"]["traffic"] = 1.82e8
-                out["roofline"]["traffic_unit"] = "B per launch (algorithmic: 1.356e8)"
-                out["roofline"]["traffic_source"] = ("profiles/r03_pmc_instep.md: two separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 "
-                                                     "correction of MI355X_MICROARCH.md, + WRITE_SIZE) over `python bench.py --steps 4 --warmup 2`, "
-                                                     "average of the 8 NT launches of a layer; not re-measured by this run")
+            # HBM bytes per launch: PMC counters cannot be read from inside the process, so these are the figures of the committed separate
+            # rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by tools/pmc_to_json.py) -- attached only when the file's workload
+            # is THIS workload, with the commit the passes ran on; null otherwise
+            tr = pmc_traffic(args)
+            if tr and dom in tr["kernels"]:
+                out["roofline"]["traffic"] = tr["kernels"][dom]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_unit"] = "B per launch"
+                out["roofline"]["traffic_algorithmic"] = tr["kernels"][dom].get("algorithmic_bytes_per_launch")
+                out["roofline"]["traffic_source"] = (f"{tr['source']} @ {tr['git']}: separate rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 "
+                                                     f"correction of MI355X_MICROARCH.md) over `{tr['command']}`; read from profiles/pmc_traffic.json, "
+                                                     "not re-measured by this run")
+                out["roofline"]["traffic_all_kernels"] = tr["kernels"]
             if args.standalone_gemm:
                 out["roofline"]["standalone"] = gemm_roofline(model, args, device)
         if not args.no_roofline and args.model == "ponet":
@@ -551,6 +654,19 @@ def main():
                                                       if k in ("value", "ms_per_step", "logging_nan_inf_filter")}
             except Exception as e:                         # the contract line must still be printed
                 out["via_trainer"] = dict(error=f"{type(e).__name__}: {e}"[:300])
+        default_workload = (args.model == "bert" and world == 1 and args.mode == "train" and args.precision == "bf16"
+                            and args.seq_len == 512 and args.seqs_per_gpu == 32)
+        if default_workload and not args.no_extra_legs:
+            # the legs the headline does not cover, each bounded to seconds, all outside the timed region above
+            for key, fn in (("parity_report", lambda: parity_report(device)),
+                            ("parity_leg", lambda: run_leg(args, device, "train", "parity", 10, 3, 4)),
+                            ("infer_leg", lambda: dict(bf16=run_leg(args, device, "infer", "bf16", 40, 8, 6),
+                                                       parity=run_leg(args, device, "infer", "parity", 20, 4, 4)))):
+                try:
+                    out[key] = fn()
+                except Exception as e:                     # the contract line must still be printed
+                    out[key] = dict(error=f"{type(e).__name__}: {e}"[:300])
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

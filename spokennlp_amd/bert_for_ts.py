@@ -158,8 +158,12 @@ class TopicSegHeadsMixin:
         if cfg.focal_loss_gamma != 0:
             # the reference's FocalLoss ends up with reduction='mean' inside super().forward (modules/utils.py:145-168):
             # scalar mean CE times the per-row focal factor, averaged over ALL rows (ignored rows use target 0)
-            ce = F.cross_entropy(logits, labels, weight=weight, ignore_index=-100, reduction="mean")
-            tgt = labels * (labels != -100).long()
+            # No labelled row at all: the reference sees a NaN mean and returns a constant 0 (:150-156) -- here the mean is written as
+            # sum / max(denominator, tiny), which gives that 0 (and zero gradients) without reading anything back to the host.
+            valid = labels != -100
+            tgt = labels * valid.long()
+            den = (weight[tgt] * valid).sum() if weight is not None else valid.sum().to(logits.dtype)
+            ce = F.cross_entropy(logits, labels, weight=weight, ignore_index=-100, reduction="sum") / den.clamp(min=1e-30)
             pt = torch.gather(F.softmax(logits, 1), 1, tgt.unsqueeze(1))
             return torch.mean(torch.pow(1 - pt, cfg.focal_loss_gamma) * ce)
         return F.cross_entropy(logits, labels, weight=weight, ignore_index=-100)

@@ -541,6 +541,9 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
             RET_IF(amdseg_gemm_nt_impl(w->d_ao_s, 3 * H, p->wo_t, 3 * H, w->dctx, H, M, H, 3 * H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1, s));
         }
         if (PHASE2(c)) {
+            // the forward took the split-attention path on (qkv_s && (p_attn == 0 || keep)) and then never wrote the fp32 a->qkv the
+            // fallback below reads: a caller that set qkv_s must bring dctx_s too
+            if (a->qkv_s && !w->dctx_s && (c->p_attn == 0.f || a->keep)) return AMDSEG_ERR_ARG;
             if (a->qkv_s && w->dctx_s && (c->p_attn == 0.f || a->keep)) {
                 if (!dctx_image) RET_IF(amdseg_split3_impl((const float*)w->dctx, H, w->dctx_s, M, H, 0, s));
                 // ... whose backward writes d(q|k|v) as the [hi | hi | lo] image the next GEMMs read; the bias gradient is summed from the image

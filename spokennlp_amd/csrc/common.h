@@ -162,7 +162,12 @@ __device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
 // (profiles/r03_gemm_epilogue_overlap.md), so what is left is fewer instructions per element.  gelu(x) = x Phi(x) with
 //     Phi(x) ~ sigmoid(x (a + b x^2 + c x^4)),   (a, b, c) = (1.5950157686, 0.0740112920, -0.0007030336)
 // a minimax fit to the erf form on |x| <= 9 (x^2 clamped at 64, where Phi is 0 / 1 to fp32 precision): max |error| 2.5e-5 in gelu, 1.1e-4
-// in its derivative -- against a bf16 output rounding of 2^-9 relative (the tanh form "gelu_new" with the same cost is off by 4.7e-4).
+// in its derivative (the tanh form "gelu_new" with the same cost is off by 4.7e-4).  These are ABSOLUTE errors: they sit below the bf16
+// rounding of the stored output (2^-9 relative) only where |gelu(x)| >~ 0.013 (resp. |gelu'(x)| >~ 0.056); for outputs nearer zero (x < -3.3,
+// |x| < 0.026) the fit's error is the larger of the two -- still <= 2.5e-5 absolute on values that enter a K = 3072 dot product next to O(1)
+// terms.  The model-level effect is measured against the REFERENCE's erf GELU at full size by the bf16 legs of
+// tests/test_gpu_fullsize.py and reported per round (profiles/rNN_parity_values.json); -DAMDSEG_GELU_ERF_EPILOGUE (compile-checked by
+// tests/test_cpu_host.py, `build.build(extra_flags=[...], out=...)`) restores the erf form in the bf16 epilogues.
 // One exp2 and one rcp per element instead of exp2 + rcp + a 5-term polynomial: ~14 instead of ~22 issue slots per element forward, ~19
 // instead of ~24 for the derivative.  The fp32 / parity paths keep the exact erf (gemm_f32.hip, parity.hip).
 #ifndef AMDSEG_GELU_ERF_EPILOGUE

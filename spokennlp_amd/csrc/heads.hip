@@ -219,7 +219,10 @@ __global__ __launch_bounds__(256) void heads_finalize_kernel(HeadsArgs a, const 
         float ce = den != 0.f ? num[sg] / den : 0.f / 0.f;     // torch: mean over an empty set = nan
         a.out[5 + sg] = den != 0.f ? 1.0f / den : 0.f;
         if (a.gamma != 0.f) {                                   // focal: mean factor x mean CE (see the header)
-            const float fbar = focs[sg] / (float)a.rows_per_seg;
+            // a segment without a labelled row: the reference's FocalLoss returns a constant 0 when its mean CE is NaN
+            // (modules/utils.py:150-156) -- no loss and no gradient from that segment
+            const float fbar = den != 0.f ? focs[sg] / (float)a.rows_per_seg : 0.f;
+            if (den == 0.f) ce = 0.f;
             a.out[8 + sg] = fbar; a.out[10 + sg] = ce;
             ce *= fbar;
         }

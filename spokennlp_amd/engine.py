@@ -420,6 +420,9 @@ class BertEncoderEngine:
         if getattr(self, "_parity", None) is not None:
             self._split_parity_weights()
         self._shadow_version = self._weights_version()
+        # the content checksums of _check_unseen_writes describe what the copies were derived from LAST TIME IT LOOKED; the copies now
+        # come from the masters as they are at this moment, which that check has not seen: both of its states are stale
+        self._ck_stale = {"bf16": True, "parity": True}
         return True
 
     def _check_unseen_writes(self, parity):
@@ -428,25 +431,38 @@ class BertEncoderEngine:
         (amdseg_weights_changed, ~80 us for bert-base) and the bf16 copies / transposes are re-derived by a refresh that is a no-op when
         nothing changed (amdseg_cast_transpose_batched_if) -- no host read, no `mark_weights_dirty()` needed.  "parity" precision re-splits its
         weight images on the host's say-so, so there the flag is read back (one sync per inference forward of that slower mode).
-        AMDSEG_EVAL_WEIGHT_CHECK=0 switches the check off."""
+        The stored checksum must describe the masters THE COPIES WERE DERIVED FROM, so: there is one state per set of copies
+        (the bf16 copies / the split images of "parity" precision -- a bf16 forward that refreshes only its copies leaves the images' state
+        behind, and the next parity forward sees the difference), and a refresh by any other route (version counters, mark_weights_dirty,
+        optimiser hooks: refresh_shadows) marks both stale -- a stale state is zeroed, which the kernel reads as "first call: changed", i.e.
+        one redundant refresh instead of a missed one.  AMDSEG_EVAL_WEIGHT_CHECK=0 switches the check off."""
         if not self.eval_weight_check or self._ct_table is None:
             return
         fp = self.fp
         if self._ck_state is None:
-            self._ck_state = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self._ck_state = {k: torch.zeros(2, dtype=torch.int64, device=self.device) for k in ("bf16", "parity")}
             self._ck_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
             first = min(fp.offsets[n] for n in fp.offsets if n.startswith(fp.encoder_prefix))
             self._ck_region = (fp.flat_p.data_ptr() + 4 * first, 4 * (fp.numel - first))
+        which = "parity" if parity else "bf16"
+        state = self._ck_state[which]
+        stale = getattr(self, "_ck_stale", None)
+        if stale is None:
+            stale = self._ck_stale = {"bf16": True, "parity": True}
+        if stale[which]:
+            state.zero_()
         s = torch.cuda.current_stream().cuda_stream
         lib = L.load()
-        L.check(lib.amdseg_weights_changed(self._ck_region[0], self._ck_region[1], self._ck_state.data_ptr(), self._ck_flag.data_ptr(), s),
+        L.check(lib.amdseg_weights_changed(self._ck_region[0], self._ck_region[1], state.data_ptr(), self._ck_flag.data_ptr(), s),
                 "amdseg_weights_changed")
         if parity:
             if int(self._ck_flag.item()):
-                self.refresh_shadows(force=True)
+                self.refresh_shadows(force=True)            # every copy re-derived from the content `state` now describes (marks both stale)
+            self._ck_stale["parity"] = False
             return
         n, pw, pb, pt, pn, pk = self._ct_table
         L.check(lib.amdseg_cast_transpose_batched_if(n, pw, pb, pt, pn, pk, self._ck_flag.data_ptr(), s), "amdseg_cast_transpose_batched_if")
+        self._ck_stale["bf16"] = False
 
     # ------------------------------------------------------------------------------------------------ arenas
     def _acquire_arena(self, B, Lseq, train, fp32=False):

@@ -29,8 +29,9 @@ class OracleModel:
         return O.model_forward(self.sd, self.cfg, batch)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "parity"])              # exact-fp32 MFMA | split-bf16 products: both must meet 1e-3 + bit-exact boundaries
 @pytest.mark.parametrize("max_len,bs", [(128, 4), (100, 3)])          # (100, 3): neither a 64-token multiple nor a full 128-row tile
-def test_32_documents_end_to_end(dev, tmp_path, max_len, bs):
+def test_32_documents_end_to_end(dev, tmp_path, max_len, bs, precision):
     from oracle import bert_ts_oracle as O
     from spokennlp_amd import data, inference, preprocess as P
     from tests.test_oracle_golden import load_case, flags_of
@@ -41,8 +42,8 @@ def test_32_documents_end_to_end(dev, tmp_path, max_len, bs):
     bos = arch["vocab_size"] - 1
     sent_ids = [[s.tolist() for s in d["sentences"]] for d in docs]
     labels = [[0 if v == 1 else 1 for v in d["labels"]] for d in docs]           # jsonl label 1 (section end) -> "B-EOP" = id 0
-    m = build_model(arch, dict(flags, amdseg_precision="fp32"), sd, dev)
-    m.config.amdseg_precision = "fp32"
+    m = build_model(arch, dict(flags, amdseg_precision=precision), sd, dev)
+    m.config.amdseg_precision = precision
     got_docs, got_metrics = inference.predict_documents(m, sent_ids, labels, max_len, bos, data.CLS_ID, data.PAD_ID, batch_size=bs, device=dev)
     ref = OracleModel(sd, O.make_cfg(num_labels=2, **arch, **flags))
     ref_docs, ref_metrics = inference.predict_documents(ref, sent_ids, labels, max_len, bos, data.CLS_ID, data.PAD_ID, batch_size=bs, device=None)

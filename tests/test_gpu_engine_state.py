@@ -245,3 +245,49 @@ def test_raw_master_write_between_two_eval_forwards_is_seen(dev, precision):
         assert torch.equal(a2, a3)
         random.seed(0); a4 = m(**b)[1]
         assert torch.equal(a4, a2)
+
+
+def test_checksum_state_follows_what_the_copies_were_derived_from(dev):
+    """ the two ways the content checksum could serve stale weights:
+    (a) eval (checksum S0 stored) -> load_state_dict (seen by the version counters; copies refreshed, checksum untouched) -> raw write BACK to
+        the old weights -> eval: the content equals S0 again, yet the copies hold the load_state_dict weights;
+    (b) eval bf16 -> raw write -> eval bf16 (bf16 copies refreshed, checksum updated) -> eval in "parity" precision: checksum unchanged, yet
+        the split weight images are still the old ones.
+    Both must run on the weights as they are."""
+    from tests.test_oracle_golden import load_case, flags_of
+    from tests.test_gpu_model import build_model, to_dev
+    z, sd, batch, arch = load_case("tiny_L64")
+    b = to_dev(batch, dev)
+    name = "bert.encoder.layer.0.attention.output.dense.weight"
+
+    def fresh(sd_, precision):
+        m_ = build_model(arch, flags_of(z, "full_eval"), sd_, dev).eval()
+        m_.config.amdseg_precision = precision
+        return m_
+
+    with torch.no_grad():
+        # (a)
+        m = fresh(sd, "bf16")
+        random.seed(0); a0 = m(**b)[1].clone()
+        sd_new = {k: (v * 1.25 + 0.02 if k == name else v.clone()) for k, v in sd.items()}
+        m.load_state_dict(sd_new, strict=False)
+        random.seed(0); a1 = m(**b)[1].clone()
+        assert (a1 - a0).abs().max().item() > 1e-3
+        w = dict(m.named_parameters())[name]
+        w.data.copy_(sd[name].to(dev))                      # raw write back to the ORIGINAL content
+        random.seed(0); a2 = m(**b)[1].clone()
+        assert torch.equal(a2, a0)
+        # (b)
+        m = fresh(sd, "bf16")
+        m.config.amdseg_precision = "parity"
+        random.seed(0); p0 = m(**b)[1].clone()              # parity images built from the original weights
+        m.config.amdseg_precision = "bf16"
+        random.seed(0); m(**b)
+        w = dict(m.named_parameters())[name]
+        w.data.copy_(w.data * 1.25 + 0.02)
+        random.seed(0); m(**b)                              # bf16 forward sees the write and refreshes ITS copies
+        m.config.amdseg_precision = "parity"
+        random.seed(0); p1 = m(**b)[1].clone()
+        sd2 = {k: v.detach().clone().cpu() for k, v in m.state_dict().items()}
+        random.seed(0); p_ref = fresh(sd2, "parity")(**b)[1]
+        assert (p1 - p0).abs().max().item() > 1e-3 and torch.equal(p1, p_ref)

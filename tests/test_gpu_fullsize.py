@@ -544,3 +544,24 @@ def test_longformer_base_L4096_batch_of_eight_sequences(dev):
         losses.append(float(loss))
     print("longformer-base 8 x 4096 train losses", losses)
     assert losses[2] < losses[0]
+
+
+def test_parity_values_are_measured_and_written(dev):
+    """the measured parity quantities per precision (tests/parity_values.py, the same function bench.py's `parity_report` runs), written
+    to gpurun_out/parity_values.json so every round can commit them as profiles/rNN_parity_values.json: drift INSIDE the loose bf16
+    bounds of the tests above (8 % gradient norms, 5 % of the logit scale) becomes visible round over round.  Asserted here: the
+    tolerance-meeting precision meets the north star on both fixtures; the fast path stays inside its documented band."""
+    import json
+    from tests import parity_values as PV
+    rep = PV.measure(dev)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_values.json"), "w") as f:
+        json.dump(PV.rounded(rep), f, indent=1)
+    print(json.dumps(PV.rounded(rep)))
+    par, fast = rep["parity"], rep["bf16"]
+    assert par["meets_1e-3"] and par["max_dlogit"] < 1e-3 and par["all_boundaries_equal"]
+    t = par["bert_base_L512"]["train_step"]
+    assert t["loss_rel_delta"] < 1e-3 and t["gradnorm_max_rel_err"] < 1e-3 and t["stored_grad_max_rel_err_excl_qk_bias"] < 1e-3
+    assert fast["max_dlogit"] < 0.05 * fast["bert_base_L512"]["eval"]["max_abs_logit"]
+    assert fast["bert_base_L512"]["train_step"]["gradnorm_max_rel_err"] < 0.08

@@ -418,6 +418,32 @@ def test_fused_heads_equal_torch_heads(dev, variant):
     print(variant, "fused vs torch heads: worst relative gradient difference", worst)
 
 
+def test_focal_loss_of_a_half_without_labelled_rows_is_zero_not_nan(dev):
+    """ FocalLoss on a segment whose labels are all -100: the reference's mean CE is NaN and it returns a constant 0
+    (modules/utils.py:150-156) -- the DA half here; loss and every gradient stay finite, that half adds nothing, and the fused heads
+    (csrc/heads.hip) and the torch formulation agree"""
+    z, sd, batch, arch = load_case("tiny_L64")
+    flags = flags_of(z, "train_focal")
+    b = {k: v.clone() for k, v in batch.items()}
+    b["labels"][:, 1, :] = -100                              # the augmented half carries no token label
+    b = to_dev(b, dev)
+    res = {}
+    for fused in (True, False):
+        m = build_model(arch, flags, sd, dev).train()
+        m.config.amdseg_fused_heads = fused
+        m.config.amdseg_precision = "parity"
+        random.seed(int(z["train_focal.random_seed"]))
+        loss, logits, _ = m(**b)
+        loss.backward()
+        assert torch.isfinite(loss)
+        grads = {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
+        assert all(torch.isfinite(g).all() for g in grads.values())
+        res[fused] = (loss.item(), grads)
+    assert abs(res[True][0] - res[False][0]) < 2e-5 * max(1.0, abs(res[False][0]))
+    for n, g in res[False][1].items():
+        assert float((res[True][1][n] - g).norm()) / max(float(g.norm()), 1e-3) < 1e-4, n
+
+
 def test_trailing_padding_chunks_are_skipped_without_changing_a_bit(dev):
     """amdseg_bert_cfg.kend / seq_order: the full-attention kernels do not visit the 64-key chunks past a sequence's last unmasked key and
     walk the sequences longest first.  The skipped chunks contribute exact zeros, so the forward result is bit-identical; the backward is
