@@ -468,7 +468,9 @@ def via_trainer(args, device, nsteps=30, nwarm=8, nan_filter=False):
                                   seed=0, dataloader_drop_last=True, dataloader_num_workers=2, dataloader_pin_memory=True,
                                   disable_tqdm=True, logging_nan_inf_filter=nan_filter)
         tr = Trainer(model=model, args=targs, train_dataset=DS(), data_collator=default_data_collator, callbacks=[Clock()])
-        tr.train()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):       # the Trainer prints its own summary dict: stdout carries the ONE JSON line only
+            tr.train()
     dt = mark["t1"] - mark["t0"]
     return dict(value=round(args.seqs_per_gpu * nsteps / dt, 1), unit="seq/s", ms_per_step=round(dt / nsteps * 1e3, 3), steps=nsteps,
                 logging_nan_inf_filter=nan_filter,

@@ -450,3 +450,80 @@ def test_grad_norm_twice_in_one_step_reduces_the_tail_bucket_once(dev):
     _train_step(m, batch, dev)
     opt.grad_norm()
     assert len([c for c in calls if c == eng.buckets.rest_slice]) == 2      # the next step reduces it again, once
+
+
+# ------------------------------------------------------------------------------------------------ multi-rank prediction (run_inference.sh:35)
+N_PRED_WINDOWS = 7                                            # odd on purpose: the last batch of one rank is a wrapped-around duplicate
+
+
+def _predict_and_write(tr, ds, path):
+    """Trainer.predict -> the reference's decode + per-document merge + prediction file (ts_sentence_seq_labeling.py:1111-1191)"""
+    import numpy as np
+    from spokennlp_amd import preprocess as P
+    out = tr.predict(ds)
+    logits, cos = out.predictions[0], out.predictions[1]
+    labels = out.label_ids[0] if isinstance(out.label_ids, (tuple, list)) else out.label_ids
+    assert logits.shape[0] == len(ds) and cos.shape[0] == len(ds) and labels.shape[0] == len(ds)     # duplicates of the padded tail truncated
+    decoded = P.decode_anchor_predictions(logits, labels)
+    cos_rows = [[float(v) for v in row[:len(d["pred_ids"])]] for row, d in zip(cos, decoded)]
+    ex = [i // 2 for i in range(len(ds))]
+    docs = P.merge_windows_to_documents(decoded, ex, max(ex) + 1, eop_pair_cos_sim=cos_rows)
+    P.write_prediction_file(path, docs)
+    return np.asarray(logits), np.asarray(cos), decoded
+
+
+def _predict_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      ACCELERATE_TORCH_DEVICE="cuda:0")
+    import numpy as np
+    import torch.distributed as dist
+    from transformers import default_data_collator
+    from spokennlp_amd.trainer import Trainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(0)
+        z, sd, batch, arch = load_case("tiny_L64")
+        m = build_model(arch, flags_of(z, "full_eval"), sd, dev)
+        m.config.amdseg_precision = "parity"
+        ds = _DS(_samples(arch, N_PRED_WINDOWS))
+        tr = Trainer(model=m, args=_args(os.path.join(out_dir, f"p{rank}"), per_device_eval_batch_size=2, ddp_backend="gloo", dataloader_drop_last=False),
+                     data_collator=default_data_collator)
+        logits, cos, _ = _predict_and_write(tr, ds, os.path.join(out_dir, f"pred_rank{rank}.txt"))
+        ev = tr.evaluate(ds)
+        np.savez(os.path.join(out_dir, f"pred{rank}.npz"), logits=logits, cos=cos, eval_loss=ev["eval_loss"])
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_predict_and_evaluate_two_ranks_equal_single_rank(dev, tmp_path):
+    """run_inference.sh:35 launches prediction under torch.distributed: the Trainer's evaluation loop gathers (logits (N,2,L,2),
+    cos_sim (N,k)) across ranks -- k (labelled [BOS] per window) differs per batch AND per rank and is padded with -100, and the 7 windows
+    do not divide over 2 ranks x batches of 2, so the sharded loader wraps around and the gather truncates the duplicates.  Gathered
+    predictions and the written prediction file must equal the single-process run bit for bit (each window's result is independent of its
+    batch mates); the loss `evaluate` reports is the mean of per-batch losses, which the two runs batch differently -- finite on both."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    from transformers import default_data_collator
+    from spokennlp_amd.trainer import Trainer
+    z, sd, batch, arch = load_case("tiny_L64")
+    samples = _samples(arch, N_PRED_WINDOWS)
+    ks = [int((s["labels"][0] != -100).sum()) for s in samples]
+    assert len(set(ks)) > 1, ks                                          # the cos_sim width really differs between windows
+    m = build_model(arch, flags_of(z, "full_eval"), sd, dev)
+    m.config.amdseg_precision = "parity"
+    tr = Trainer(model=m, args=_args(tmp_path / "single", per_device_eval_batch_size=2, dataloader_drop_last=False), data_collator=default_data_collator)
+    logits1, cos1, decoded1 = _predict_and_write(tr, _DS(samples), str(tmp_path / "pred_single.txt"))
+    assert cos1.shape[1] == max(ks)
+    for row, k in zip(cos1, ks):
+        assert (row[k:] == -100).all() and (np.abs(row[:k - 1]) <= 1.0 + 1e-5).all()
+    mp.spawn(_predict_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want = open(tmp_path / "pred_single.txt", "rb").read()
+    assert len(want.splitlines()) == (N_PRED_WINDOWS + 1) // 2
+    for rank in range(2):
+        got = np.load(tmp_path / f"pred{rank}.npz")
+        assert got["logits"].shape == logits1.shape and np.array_equal(got["logits"], logits1), rank
+        assert got["cos"].shape == cos1.shape and np.array_equal(got["cos"], cos1), rank
+        assert open(tmp_path / f"pred_rank{rank}.txt", "rb").read() == want, rank
+        assert math.isfinite(float(got["eval_loss"]))
