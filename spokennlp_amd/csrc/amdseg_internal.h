@@ -28,12 +28,14 @@ int amdseg_embed_bwd_impl(const void* dz, const int64_t* ids, const int64_t* typ
                           int npos, int pad_id, int dtype, hipStream_t s);
 int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out,
                            float* mean, float* rstd, int M, int H, float eps, float p, uint64_t seed, int dtype,
-                           hipStream_t s, void* out_image = nullptr);      // out_image: `out` also as the split image [M, 3H] ("parity" precision)
+                           hipStream_t s, void* out_image = nullptr,         // out_image: `out` also as the split image [M, 3H] ("parity" precision)
+                           void* keepbits = nullptr);                        // keepbits: [M * H / 8] bytes, the dropout decisions kept for ln_bwd
 int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                        void* dz, void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M,
                        int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s,
                        const int* zkend = nullptr, const int* zguard = nullptr, int zL = 0,
-                       void* dense_grad_image = nullptr);    // the dense layer's gradient (dbranch, or dz without dropout) also as the split image [M, 3H]
+                       void* dense_grad_image = nullptr,     // the dense layer's gradient (dbranch, or dz without dropout) also as the split image [M, 3H]
+                       const void* keepbits = nullptr);      // the forward's dropout decisions (amdseg_add_ln_fwd_impl keepbits) instead of the hash
 int amdseg_colsum_impl(const void* x, int ld, float* partials, float* out, int M, int N, int accumulate, int dtype,
                        hipStream_t s);
 int amdseg_colsum_split_impl(const void* x, int ld, int lo_off, float* partials, float* out, int M, int N, int accumulate, hipStream_t s);

@@ -351,6 +351,17 @@ static inline uint64_t site_seed(uint64_t seed, int layer, int site) {
 }
 #define RET_IF(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+int amdseg_bert_keepmask_pregen(const amdseg_bert_cfg* c, void* const* keep, int nlayers, amdseg_stream_t stream) {
+    if (!c || !keep || nlayers <= 0) return AMDSEG_ERR_ARG;
+    if (c->p_attn <= 0.f || c->mixer != 0) return AMDSEG_ERR_ARG;
+    for (int li = 0; li < nlayers; ++li) {
+        if (!keep[li]) return AMDSEG_ERR_ARG;
+        RET_IF(amdseg_attn_keepmask_impl(keep[li], c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), nullptr, S(stream), c->window,
+                                         c->nglobal));
+    }
+    return AMDSEG_OK;
+}
+
 static int check_cfg(const amdseg_bert_cfg* c) {
     if (!c) return AMDSEG_ERR_ARG;
     if (c->dtype != AMDSEG_BF16 && c->dtype != AMDSEG_F32 && c->dtype != AMDSEG_F32S) return AMDSEG_ERR_ARG;
@@ -410,7 +421,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
             if (split_attn) {
                 // attention as split-bf16 products on the bf16 matrix cores (attention_split.hip); dropout from this layer's keep masks
                 if (!fused_qkv) RET_IF(amdseg_split3_impl((const float*)a->qkv, 3 * H, a->qkv_s, M, 3 * H, 0, s));
-                if (c->p_attn > 0.f) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s,
+                if (c->p_attn > 0.f && !c->keep_ready) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s,
                                                                       c->window, c->nglobal));
                 RET_IF(amdseg_sattn_fwd_impl(a->qkv_s, 9 * H, 6 * H, mask_bias, (float*)a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                              c->p_attn > 0.f ? a->keep : nullptr, c->window, c->nglobal, s, c->kend, c->seq_order,
@@ -425,7 +436,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         RET_IF(amdseg_gemm_nt_impl(a->ctx_s, 3 * H, p->wo, 3 * H, a->z1, H, M, H, 3 * H, AMDSEG_EPI_BIAS, p->bo, nullptr, 0, nullptr, 0, 1, s));
         const bool ln_img = !(parity_unfused() & 8);
         RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
-                                      site_seed(c->seed, li, 1), AMDSEG_F32, s, ln_img ? a->x1_s : nullptr));
+                                      site_seed(c->seed, li, 1), AMDSEG_F32, s, ln_img ? a->x1_s : nullptr, a->drop1));
         if (!ln_img) RET_IF(amdseg_split3_impl((const float*)a->x1, H, a->x1_s, M, H, 0, s));
         if (ffn_fused)       // u (fp32, read by backward; NULL in inference) and the image of gelu(u) from one epilogue
             RET_IF(amdseg_gemm_nt_impl(a->x1_s, 3 * H, p->w1, 3 * H, a->u, I, M, I, 3 * H, AMDSEG_EPI_BIAS_GELU_SPLIT, p->b1, nullptr, 0, a->h_s, 3 * I, 1, s));
@@ -435,7 +446,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         }
         RET_IF(amdseg_gemm_nt_impl(a->h_s, 3 * I, p->w2, 3 * I, a->z2, H, M, H, 3 * I, AMDSEG_EPI_BIAS, p->b2, nullptr, 0, nullptr, 0, 1, s));
         RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, c->p_hidden,
-                                      site_seed(c->seed, li, 2), AMDSEG_F32, s));
+                                      site_seed(c->seed, li, 2), AMDSEG_F32, s, nullptr, a->drop2));
         return AMDSEG_OK;
     }
     if (c->dtype == AMDSEG_F32) {
@@ -461,7 +472,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         if (c->mixer == 0) {
             // dropout on the probabilities: decided once per layer here, read by the forward and the two backward kernels (acts.keep)
             const void* keep = (a->keep && c->p_attn > 0.f) ? a->keep : nullptr;      // full attention, or the band's cells (window > 0)
-            if (keep) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s, c->window,
+            if (keep && !c->keep_ready) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s, c->window,
                                                        c->nglobal));
             RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0),
                                         c->window, c->nglobal, s, c->kend, c->seq_order, keep,
@@ -473,12 +484,12 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     // attention output dense -> dropout -> +residual -> LN
     RET_IF(amdseg_gemm_nt_impl(a->ctx, H, p->wo, H, a->z1, H, M, H, H, AMDSEG_EPI_BIAS, p->bo, nullptr, 0, nullptr, 0, 0, s));
     RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
-                                  site_seed(c->seed, li, 1), c->dtype, s));
+                                  site_seed(c->seed, li, 1), c->dtype, s, nullptr, a->drop1));
     // FFN
     RET_IF(amdseg_gemm_nt_impl(a->x1, H, p->w1, H, a->h, I, M, I, H, AMDSEG_EPI_BIAS_GELU | (c->act ? AMDSEG_EPI_ACT_TANH : 0), p->b1, nullptr, 0, a->u, I, 0, s));
     RET_IF(amdseg_gemm_nt_impl(a->h, I, p->w2, I, a->z2, H, M, H, I, AMDSEG_EPI_BIAS, p->b2, nullptr, 0, nullptr, 0, 0, s));
     RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, c->p_hidden,
-                                  site_seed(c->seed, li, 2), c->dtype, s));
+                                  site_seed(c->seed, li, 2), c->dtype, s, nullptr, a->drop2));
     return AMDSEG_OK;
 }
 
@@ -515,7 +526,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
             const bool ln_img = !(parity_unfused() & 8);
             RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, part_ln2, g->ln2_g, g->ln2_b,
                                       g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, AMDSEG_F32, s, nullptr, nullptr, 0,
-                                      ln_img ? w->d_out_s : nullptr));
+                                      ln_img ? w->d_out_s : nullptr, a->drop2));
             if (!ln_img) RET_IF(amdseg_split3_impl((const float*)d_out, H, w->d_out_s, M, H, 0, s));
             if (c->act == 0 && (M % 256) == 0 && (I % 256) == 0 && !(parity_unfused() & 4)) {
                 // du = (d_out . W2) * gelu'(u) leaves the GEMM as the [hi | hi | lo] image (no fp32 du, no separate GELU' / split pass: 160 us per
@@ -532,7 +543,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
             RET_IF(amdseg_add_inplace_impl((float*)w->dx1, (const float*)w->dz2, (size_t)M * H, s));
             RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, part_ln1, g->ln1_g,
                                       g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, AMDSEG_F32, s, nullptr, nullptr, 0,
-                                      ln_img ? w->d_ao_s : nullptr));
+                                      ln_img ? w->d_ao_s : nullptr, a->drop1));
             if (!ln_img) RET_IF(amdseg_split3_impl((const float*)d_ao, H, w->d_ao_s, M, H, 0, s));
             if (dctx_image)      // d(ctx) straight as the hi / lo blocks the split attention backward reads (no fp32 d(ctx), no split pass)
                 RET_IF(amdseg_gemm_nt_impl(w->d_ao_s, 3 * H, p->wo_t, 3 * H, w->dctx_s, 3 * H, M, H, 3 * H, AMDSEG_EPI_BIAS_SPLIT, nullptr, nullptr, 0,
@@ -587,7 +598,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     if (PHASE1(c)) {
     // LN2 backward: dz2 (residual grad), d_out = masked dz2 (grad of the FFN output dense), dln2, db2
     RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, part_ln2, g->ln2_g, g->ln2_b,
-                              g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, c->dtype, s, ZPAD));
+                              g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, c->dtype, s, ZPAD, nullptr, a->drop2));
     // du = (d_out . W2) * gelu'(u)
     RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD | (c->act ? AMDSEG_EPI_ACT_TANH : 0), nullptr, a->u, I, nullptr, 0, 0, s, ZPAD));
     // dx1 = du . W1 + dz2
@@ -595,7 +606,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     // (db1 = colsum(du) and dbqkv = colsum(dqkv) come out of the grouped weight-gradient GEMM below)
     // LN1 backward
     RET_IF(amdseg_ln_bwd_impl(w->dx1, a->z1, a->mean1, a->rstd1, p->ln1_g, w->dz1, drop ? w->dbr1 : nullptr, part_ln1, g->ln1_g,
-                              g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, c->dtype, s, ZPAD));
+                              g->ln1_b, g->bo, M, H, c->p_hidden, site_seed(c->seed, li, 1), acc, c->dtype, s, ZPAD, nullptr, a->drop1));
     // dctx = d_ao . Wo
     RET_IF(amdseg_gemm_nt_impl(d_ao, H, p->wo_t, H, w->dctx, H, M, H, H, AMDSEG_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, s, ZPAD));
     }

@@ -254,6 +254,24 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t 
 // then one multiply round per element pair, 16 bits per element -- 8 quarter-rate v_mul_lo_u32 per chunk instead of 32 (the
 // per-element hash was a quarter of ln_bwd's time at p = 0.1).  keep element e iff its field >= thresh16, thresh16 = round(p * 2^16);
 // inv_keep = 2^16 / (2^16 - thresh16), so the scaling is unbiased for the realised rate.
+// the 8 keep decisions of a chunk as a bit mask (bit e = element e is kept): what the forward row kernel stores per chunk (1 byte) so that
+// the backward reads the decisions instead of re-hashing them (round 4: the hash was +6.4 us of ln_bwd's 29)
+__device__ __forceinline__ uint32_t drop8_bits(uint64_t seed, uint64_t chunk, uint32_t thresh16) {
+    const uint32_t h = rng_u32(seed, chunk);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t x = h ^ (0x9e3779b9u * (uint32_t)(i + 1));
+        x *= 0x7feb352du; x ^= x >> 15;
+        bits |= ((x & 0xffffu) >= thresh16 ? 1u : 0u) << (2 * i);
+        bits |= ((x >> 16) >= thresh16 ? 1u : 0u) << (2 * i + 1);
+    }
+    return bits;
+}
+__device__ __forceinline__ void drop8_apply_bits(uint32_t bits, float inv_keep, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bits >> e) & 1u ? v[e] * inv_keep : 0.f;
+}
 __device__ __forceinline__ void drop8_apply(uint64_t seed, uint64_t chunk, uint32_t thresh16, float inv_keep, float (&v)[8]) {
     const uint32_t h = rng_u32(seed, chunk);
 #pragma unroll

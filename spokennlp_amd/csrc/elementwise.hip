@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const T* __restrict_
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid, const float* gamma, const float* beta, T* out,
                                                          float* mean, float* rstd, int M, int H, float eps, uint32_t thresh,
-                                                         float inv_keep, uint64_t seed, bf16_t* img) {
+                                                         float inv_keep, uint64_t seed, bf16_t* img, uint8_t* keepbits) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int m = blockIdx.x * ROWS_PER_BLOCK + w;
     if (m >= M) return;
@@ -193,7 +193,13 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
     for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
         if (ch < nch) {
-            if (thresh) drop8_apply(seed, (uint64_t)m * nch + ch, thresh, inv_keep, v[c]);
+            if (thresh) {
+                if (keepbits) {                            // the decisions of this chunk, kept for ln_bwd (1 byte per 8 elements)
+                    const uint32_t bits = drop8_bits(seed, (uint64_t)m * nch + ch, thresh);
+                    keepbits[(size_t)m * nch + ch] = (uint8_t)bits;
+                    drop8_apply_bits(bits, inv_keep, v[c]);
+                } else drop8_apply(seed, (uint64_t)m * nch + ch, thresh, inv_keep, v[c]);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[c][e] = x[c][e] + v[c][e];
         }
@@ -224,7 +230,8 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, const float* mean, const float* rstd,
                                                      const float* gamma, T* dz, T* dbranch, float* partials, int M, int H,
                                                      uint32_t thresh, float inv_keep, uint64_t seed,
-                                                     const int* zkend, const int* zguard, int zL, bf16_t* img) {
+                                                     const int* zkend, const int* zguard, int zL, bf16_t* img,
+                                                     const uint8_t* keepbits) {
     extern __shared__ float red[];         // [3][4 waves][H]
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nch = H >> 3;
@@ -269,6 +276,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
         float g[NCH][8], x[NCH][8];
         row_load<T, NCH>(dy + (size_t)m * H, nch, l, g);
         row_load<T, NCH>(z + (size_t)m * H, nch, l, x);
+        uint32_t kb[NCH];                                  // the forward's dropout decisions of this lane's chunks (loaded with the row)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) kb[c] = (keepbits && thresh && l + c * 64 < nch) ? keepbits[(size_t)m * nch + l + c * 64] : 0u;
         const float mu = mean[m], rs = rstd[m];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -302,7 +312,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
             for (int c = 0; c < NCH; ++c) {
                 const int ch = l + c * 64;
                 if (ch < nch) {
-                    if (thresh) drop8_apply(seed, (uint64_t)m * nch + ch, thresh, inv_keep, g[c]);
+                    if (thresh) {
+                        if (keepbits) drop8_apply_bits(kb[c], inv_keep, g[c]);
+                        else drop8_apply(seed, (uint64_t)m * nch + ch, thresh, inv_keep, g[c]);
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) abias[c][e] += g[c][e];
                 }
@@ -745,24 +758,24 @@ int amdseg_embed_bwd_impl(const void* dz, const int64_t* ids, const int64_t* typ
 
 int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out,
                            float* mean, float* rstd, int M, int H, float eps, float p, uint64_t seed, int dtype,
-                           hipStream_t s, void* out_image) {
+                           hipStream_t s, void* out_image, void* keepbits) {
     if (!y_inout_z || !resid || !gamma || !beta || !out) return AMDSEG_ERR_ARG;
     if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
     uint32_t th; float ik; drop_params(p, th, ik);
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     if (dtype == AMDSEG_BF16)
         ROWK(add_ln_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta,
-                           (bf16_t*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image);
+                           (bf16_t*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits);
     else
         ROWK(add_ln_fwd_kernel, float, H, grid, dim3(256), 0, s, (float*)y_inout_z, (const float*)resid, gamma, beta,
-                           (float*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image);
+                           (float*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits);
     return amdseg_launch_status();
 }
 
 int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                        void* dz, void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M,
                        int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s,
-                       const int* zkend, const int* zguard, int zL, void* dense_grad_image) {
+                       const int* zkend, const int* zguard, int zL, void* dense_grad_image, const void* keepbits) {
     if (!dy || !z || !mean || !rstd || !gamma || !dz) return AMDSEG_ERR_ARG;
     if (!zkend || !zguard || zL <= 0 || (M % zL) || (zL % LNB_ROWS)) { zkend = nullptr; zguard = nullptr; zL = 1; }
     if ((dgamma || dbeta || dbias) && !partials) return AMDSEG_ERR_ARG;
@@ -772,10 +785,12 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
     const size_t shm = (size_t)3 * 4 * H * sizeof(float);
     if (dtype == AMDSEG_BF16)
         ROWK(ln_bwd_kernel, bf16_t, H, dim3(nblk), dim3(256), shm, s, (const bf16_t*)dy, (const bf16_t*)z, mean, rstd,
-                           gamma, (bf16_t*)dz, (bf16_t*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL, (bf16_t*)dense_grad_image);
+                           gamma, (bf16_t*)dz, (bf16_t*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL, (bf16_t*)dense_grad_image,
+                           (const uint8_t*)keepbits);
     else
         ROWK(ln_bwd_kernel, float, H, dim3(nblk), dim3(256), shm, s, (const float*)dy, (const float*)z, mean, rstd, gamma,
-                           (float*)dz, (float*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL, (bf16_t*)dense_grad_image);
+                           (float*)dz, (float*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL, (bf16_t*)dense_grad_image,
+                           (const uint8_t*)keepbits);
     if (partials) {
         Reduce3 r;
         r.part[0] = partials; r.part[1] = partials + (size_t)nblk * H; r.part[2] = partials + (size_t)2 * nblk * H;

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("AMDSEG_LIB") or os.path.join(_HERE, "libamdseg.so")
 BF16, F32, F32S = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
 EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
@@ -21,7 +21,7 @@ class BertCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("heads", C.c_int32), ("I", C.c_int32),
                 ("ln_eps", f32), ("p_hidden", f32), ("p_attn", f32), ("seed", u64),
                 ("accumulate_grads", C.c_int32), ("dtype", C.c_int32), ("window", C.c_int32), ("nglobal", C.c_int32),
-                ("nproj", C.c_int32), ("mixer", C.c_int32), ("phase", C.c_int32), ("act", C.c_int32), ("kend", vp), ("seq_order", vp), ("pad_guard", vp), ("pad_runs", vp), ("pad_counts", vp)]
+                ("nproj", C.c_int32), ("mixer", C.c_int32), ("phase", C.c_int32), ("act", C.c_int32), ("kend", vp), ("seq_order", vp), ("pad_guard", vp), ("pad_runs", vp), ("pad_counts", vp), ("keep_ready", C.c_int32)]
 
 
 class LayerParams(C.Structure):
@@ -35,7 +35,7 @@ class LayerGrads(C.Structure):
 
 class LayerActs(C.Structure):
     _fields_ = [(n, vp) for n in ("x_in", "qkv", "ctx", "z1", "x1", "u", "h", "z2", "x_out",
-                                  "lse", "mean1", "rstd1", "mean2", "rstd2", "xs", "ctx_s", "x1_s", "h_s", "keep", "qkv_s")]
+                                  "lse", "mean1", "rstd1", "mean2", "rstd2", "xs", "ctx_s", "x1_s", "h_s", "keep", "qkv_s", "drop1", "drop2")]
 
 
 class LayerWs(C.Structure):
@@ -57,6 +57,7 @@ _PROTOS = {
     "amdseg_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_attn_keepmask_bytes": [i32, i32, i32],
+    "amdseg_bert_keepmask_pregen": [vp, C.POINTER(vp), i32, vp],
     "amdseg_attn_keepmask": [vp, i32, i32, i32, f32, u64, vp, vp],
     "amdseg_attn_keepmask_band": [vp, i32, i32, i32, f32, u64, i32, i32, vp],
     "amdseg_attn_fwd_keep": [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],

@@ -194,6 +194,35 @@ def test_dropout_training_step_is_finite_and_deterministic(dev):
     assert abs(losses[0][1] - losses[1][1]) <= 1e-6 * losses[0][1]
 
 
+@pytest.mark.parametrize("precision", ["bf16", "parity"])
+def test_hidden_dropout_decisions_kept_by_forward_equal_the_rehashed_ones(dev, precision):
+    """acts.drop1 / drop2 (ABI 8): the dropout + residual + LayerNorm forward stores its keep decisions (1 byte per 8 elements) and the
+    LayerNorm backward reads them instead of re-hashing.  Same hash, same decisions: the encoder layers' gradients are BIT-IDENTICAL to
+    the path that evaluates the hash in both directions (engine.hidden_keepbits = False), at a realised drop rate of ~p."""
+    z, sd, batch, arch = load_case("tiny_L128")
+    res = {}
+    for keep in (True, False):
+        m = build_model(arch, flags_of(z, "train_full"), sd, dev, dropout=0.1).train()
+        m.config.amdseg_precision = precision
+        m.amdseg_seed = 7
+        eng = m.engine()
+        eng.hidden_keepbits = keep
+        random.seed(3)
+        loss, _, _ = m(**to_dev(batch, dev))
+        loss.backward()
+        torch.cuda.synchronize()
+        res[keep] = (loss.item(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None and ".layer." in n})
+        if keep:
+            A = [a for a in eng._arenas.values() if a.get("layers") and "drop1" in a["layers"][0]]
+            assert A, "no keep-bit buffers were allocated"
+            bits = A[0]["layers"][0]["drop1"]
+            rate = 1.0 - float(torch.tensor([bin(v).count("1") for v in bits.cpu().tolist()]).sum()) / (bits.numel() * 8)
+            assert 0.08 < rate < 0.12, rate
+    assert res[True][0] == res[False][0]
+    for n, g in res[False][1].items():
+        assert torch.equal(res[True][1][n], g), n
+
+
 def test_fused_adamw_step_matches_torch(dev):
     """engine.adamw_step (clip 1.0 + AdamW over the flat buffers) vs clip_grad_norm_ + torch.optim.AdamW on a clone."""
     z, sd, batch, arch = load_case("tiny_L64")
