@@ -92,9 +92,23 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     bool ztile = false;                                       // workgroup-uniform: every row of this tile's A is an exact zero
     if (a.zkend) { const int zb = m0 / a.zL; ztile = (m0 - zb * a.zL) >= a.zkend[zb] && *a.zguard == 0; }
     if (!ztile) {
+    // prologue: both stages; the first MFMA phase waits for K tile 1 as well (vmcnt(0) at kt = 0).  Round 4 tried the early start -- K tile 1
+    // issued in the loop's own steady-state order so that the counted waits hold from kt = 0 and the first MFMAs wait for K tile 0 only
+    // (-DAMDSEG_ABL_EARLY_START) -- and measured it SLOWER, same box back to back (profiles/r04_gemm_prologue_ablation.md: N = 2304 K = 768
+    // 66.0 -> 68.1 us, bias + GELU 96.5 -> 104.6, the K = 3072 shapes unchanged): both stages of a fresh workgroup land together (the fill is
+    // one latency, not two transfers), and what the early start buys is a first K tile whose MFMAs run beside the second stage's arrival.
     DP_DMA_A(0, 0, 0) DP_DMA_A(0, 1, 0) DP_DMA_B(0, 0)
+#ifndef AMDSEG_ABL_EARLY_START
+#define DP_KT0 1
     if (nk > 1) { DP_DMA_A(1, 0, 1) DP_DMA_A(1, 1, 1) DP_DMA_B(1, 1) DP_WAIT_TILE(); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+#define DP_KT0 0
+    if (nk > 1) {
+        DP_DMA_A(1, 0, 1) DP_DMA_B(1, 1)
+        if (vm8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();             // stagger: group 1 runs one barrier behind group 0
     bf16x8 fa[4][2], fb[NF][2];
@@ -117,9 +131,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         // ---- phase 1: rows 0-63 of the wave tile.  DMA: the rows-64..127 image of K tile kt+1 (other stage; last read in phase 2
         //      of K tile kt-1, retired before that phase's barrier)
         DP_LOAD_B(s) DP_LOAD_A(s, 0)
-        if (kt >= 1 && kt + 1 < nk) { DP_DMA_A(s ^ 1, 1, kt + 1) }
+        if (kt >= DP_KT0 && kt + 1 < nk) { DP_DMA_A(s ^ 1, 1, kt + 1) }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kt >= 1 && kt + 1 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt >= DP_KT0 && kt + 1 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DP_MID();
         DP_MFMA(0)
         DP_END();

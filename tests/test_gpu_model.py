@@ -220,7 +220,10 @@ def test_hidden_dropout_decisions_kept_by_forward_equal_the_rehashed_ones(dev, p
             assert 0.08 < rate < 0.12, rate
     assert res[True][0] == res[False][0]
     for n, g in res[False][1].items():
-        assert torch.equal(res[True][1][n], g), n
+        if precision == "bf16":
+            assert torch.equal(res[True][1][n], g), n
+        else:       # "parity" precision's split attention backward is reproducible to fp32 round-off only; another DECISION would move a gradient by ~1e-1 relative
+            assert float((res[True][1][n] - g).norm()) <= 1e-5 * max(float(g.norm()), 1e-6), n
 
 
 def test_fused_adamw_step_matches_torch(dev):
