@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 8   /* 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_bert_cfg.keep_ready + amdseg_bert_keepmask_pregen; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 8   /* 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward); 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -443,8 +443,6 @@ typedef struct amdseg_bert_cfg {
     const int32_t* pad_runs;        /* with pad_guard: device [B][2] = {first, end} runs of 64-token tiles t (rows 64t .. 64t+63) that hold a
                                        position < kend -- per sequence b with kend[b] > 0: {b*L/64, b*L/64 + ceil(kend[b]/64)}; L % 64 == 0 */
     const int32_t* pad_counts;      /* with pad_guard: device int[2] = {tiles in those runs, number of runs} */
-    int32_t keep_ready;             /* ABI 8, forward only: != 0 = acts.keep of every layer already holds the decisions for `seed`
-                                       (amdseg_bert_keepmask_pregen ran for this seed and shape): the layer call does not generate them */
 } amdseg_bert_cfg;
 
 typedef struct amdseg_bert_layer_params {   /* bf16 compute shadows (+ transposes for dgrad), fp32 vectors */
@@ -489,11 +487,6 @@ typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across
     void* dctx_s;                           /* optional, AMDSEG_F32S with acts.qkv_s: split image [M, 3H] of d(ctx) (scratch) */
 } amdseg_bert_layer_ws;
 
-/* The attention-dropout decisions of ALL layers of the forward that will run with cfg->seed (cfg: B, L, heads, p_attn, seed, window, nglobal;
- * keep[li] = that layer's acts.keep), written ahead of time -- typically on a second stream under the optimiser pass of the previous step
- * (HBM-bound; the generator is VALU-bound), since the seed of the next step is known and the masks depend on nothing else.  Every 64-key
- * chunk is written (kend of the next batch is not known yet).  The forward then runs with cfg->keep_ready = 1.  ABI 8. */
-int amdseg_bert_keepmask_pregen(const amdseg_bert_cfg* cfg, void* const* keep, int nlayers, amdseg_stream_t stream);
 int amdseg_bert_layer_fwd(const amdseg_bert_cfg* cfg, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,
                           const float* mask_bias, int layer_idx, amdseg_stream_t stream);
 /* dy: gradient w.r.t. x_out [M,H]; dx_in: gradient w.r.t. x_in [M,H] (output) */

@@ -28,7 +28,6 @@ from .engine import BertEncoderEngine
 
 class BigBirdEncoderEngine(BertEncoderEngine):
     supports_parity = False
-    supports_keepmask_pregen = False
     def __init__(self, module, config, device, bert_attr="bert"):
         super().__init__(module, config, device, bert_attr=bert_attr)
         if getattr(config, "attention_type", "block_sparse") == "block_sparse" and config.block_size != plan.BLOCK:

@@ -351,17 +351,6 @@ static inline uint64_t site_seed(uint64_t seed, int layer, int site) {
 }
 #define RET_IF(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
-int amdseg_bert_keepmask_pregen(const amdseg_bert_cfg* c, void* const* keep, int nlayers, amdseg_stream_t stream) {
-    if (!c || !keep || nlayers <= 0) return AMDSEG_ERR_ARG;
-    if (c->p_attn <= 0.f || c->mixer != 0) return AMDSEG_ERR_ARG;
-    for (int li = 0; li < nlayers; ++li) {
-        if (!keep[li]) return AMDSEG_ERR_ARG;
-        RET_IF(amdseg_attn_keepmask_impl(keep[li], c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), nullptr, S(stream), c->window,
-                                         c->nglobal));
-    }
-    return AMDSEG_OK;
-}
-
 static int check_cfg(const amdseg_bert_cfg* c) {
     if (!c) return AMDSEG_ERR_ARG;
     if (c->dtype != AMDSEG_BF16 && c->dtype != AMDSEG_F32 && c->dtype != AMDSEG_F32S) return AMDSEG_ERR_ARG;
@@ -421,7 +410,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
             if (split_attn) {
                 // attention as split-bf16 products on the bf16 matrix cores (attention_split.hip); dropout from this layer's keep masks
                 if (!fused_qkv) RET_IF(amdseg_split3_impl((const float*)a->qkv, 3 * H, a->qkv_s, M, 3 * H, 0, s));
-                if (c->p_attn > 0.f && !c->keep_ready) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s,
+                if (c->p_attn > 0.f) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s,
                                                                       c->window, c->nglobal));
                 RET_IF(amdseg_sattn_fwd_impl(a->qkv_s, 9 * H, 6 * H, mask_bias, (float*)a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                              c->p_attn > 0.f ? a->keep : nullptr, c->window, c->nglobal, s, c->kend, c->seq_order,
@@ -472,7 +461,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         if (c->mixer == 0) {
             // dropout on the probabilities: decided once per layer here, read by the forward and the two backward kernels (acts.keep)
             const void* keep = (a->keep && c->p_attn > 0.f) ? a->keep : nullptr;      // full attention, or the band's cells (window > 0)
-            if (keep && !c->keep_ready) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s, c->window,
+            if (keep) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s, c->window,
                                                        c->nglobal));
             RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0),
                                         c->window, c->nglobal, s, c->kend, c->seq_order, keep,

@@ -99,14 +99,7 @@ int amdseg_adamw_impl(float* p, const float* g, float* m, float* v, void* shadow
     if (n == 0 || (n % 4) || step < 1) return AMDSEG_ERR_SHAPE;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    // grid: 2048 blocks of 4 waves fill every wave slot of the chip (8 blocks per CU) with grid-stride loops that all end together, so a kernel
-    // on another stream (the next step's keep masks, amdseg_bert_keepmask_pregen) would get no slot until the pass is over; AMDSEG_ADAMW_BLOCKS
-    // (default below) leaves room
-    static int blocks = -1;
-    if (blocks < 0) { const char* e = getenv("AMDSEG_ADAMW_BLOCKS"); blocks = e ? atoi(e) : 2048; if (blocks < 1) blocks = 2048; }
-    unsigned grid = stream_grid(n / 4);
-    if (grid > (unsigned)blocks) grid = (unsigned)blocks;
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, s, p, (float*)g, m, v, (bf16_t*)shadow, n / 4, lr, beta1,
+    hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, s, p, (float*)g, m, v, (bf16_t*)shadow, n / 4, lr, beta1,
                        beta2, eps, wd, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, zero_grad, chunk_flags);
     return amdseg_launch_status();
 }

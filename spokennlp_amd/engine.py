@@ -182,14 +182,6 @@ class BertEncoderEngine:
         # hidden-state dropout: the forward's add + LayerNorm kernels keep their decisions (1 byte per 8 elements, acts.drop1 / drop2) and the
         # LayerNorm backward reads them instead of re-hashing (every encoder family: the row kernels are shared); AMDSEG_HIDDEN_KEEPBITS=0 = hash twice
         self.hidden_keepbits = _os.environ.get("AMDSEG_HIDDEN_KEEPBITS", "1") != "0"
-        # the NEXT step's attention keep masks written on a second stream under this step's optimiser pass (HBM-bound AdamW beside the
-        # VALU-bound generator; amdseg_bert_keepmask_pregen): the seed of the next training forward is this one's + 1 unless something else
-        # ran in between, and the forward checks (seed, arena, shape) before it trusts them.  AMDSEG_KEEPMASK_PREGEN=0: always inline
-        self.pregen_keepmask = _os.environ.get("AMDSEG_KEEPMASK_PREGEN", "1") != "0"
-        self._pregen = None
-        self._pregen_stream = None
-        self._last_train = None
-        self.pregen_hits = 0
         self._arena_slot = 0
         self.max_live_arenas = 2                            # training arenas per shape that may be alive between forward and backward
         self.grad_sync = True                               # False inside no_sync(): accumulate locally, no bucket all-reduce
@@ -340,7 +332,6 @@ class BertEncoderEngine:
 
     # ---- "parity" precision: split-bf16 weight images (csrc/parity.hip), built on first use and refreshed with the bf16 copies
     supports_parity = True
-    supports_keepmask_pregen = True                         # full softmax attention, one cfg for every layer (the band / list / pooling engines: False)
     parity_needs_split_attn = False                         # band attention exists in split-bf16 form only (no fp32-MFMA fallback)
 
     def _parity_weights(self):
@@ -647,14 +638,6 @@ class BertEncoderEngine:
                                          MASK_BIAS, torch.cuda.current_stream().cuda_stream), "amdseg_pad_plan")
         cfg.kend = A["kend"].data_ptr() if self.skip_padded_chunks else None
         cfg.seq_order = A["seq_order"].data_ptr() if self.skip_padded_chunks else None
-        pg, self._pregen = self._pregen, None
-        if pg is not None:
-            torch.cuda.current_stream().wait_event(pg["done"])      # (also when they do not match: nobody may write these buffers behind us)
-            if train and pg["arena"] is A and pg["key"] == (int(seed), B, Lseq, p_a, int(cfg.dtype)) and "keep" in A["layers"][0]:
-                cfg.keep_ready = 1
-                self.pregen_hits += 1
-        if train:
-            self._last_train = (A, int(seed), B, Lseq, p_a, int(cfg.dtype))
         lib = L.load()
         s = torch.cuda.current_stream().cuda_stream
         eps = float(self.cfg.layer_norm_eps)
@@ -846,30 +829,6 @@ class BertEncoderEngine:
             flags[o:o + c] = (1 if (decay_names is None or n in decay_names) else 0) | (0 if p.requires_grad else 2)
         self._chunk_flags = flags.to(self.device)
 
-    def _queue_keepmask_pregen(self):
-        """called where the optimiser pass of a step starts (every backward that read this step's masks is queued on the current stream):
-        the attention-dropout decisions of the next training forward, all layers, on the side stream"""
-        lt = self._last_train
-        if not self.pregen_keepmask or lt is None or self._pregen is not None:
-            return
-        A, seed, B, Lseq, p_a, dtype = lt
-        if p_a <= 0 or A.get("busy") or "keep" not in A["layers"][0] or not self.supports_keepmask_pregen:
-            return
-        nxt = (seed + 1) & 0x7FFFFFFF
-        if self._pregen_stream is None:
-            self._pregen_stream = torch.cuda.Stream(device=self.device)
-        main, side = torch.cuda.current_stream(), self._pregen_stream
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
-        cfg = self._cfg_struct(B, Lseq, 0.0, p_a, nxt, True)
-        n = self.nlayers
-        keeps = (C.c_void_p * n)(*[A["layers"][i]["keep"].data_ptr() for i in range(n)])
-        L.check(L.load().amdseg_bert_keepmask_pregen(C.byref(cfg), keeps, n, side.cuda_stream), "amdseg_bert_keepmask_pregen")
-        done = torch.cuda.Event()
-        done.record(side)
-        self._pregen = dict(arena=A, key=(nxt, B, Lseq, p_a, dtype), done=done)
-
     def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, grad_scale=1.0,
                    zero_grad=True, coef=None):
         """clip_grad_norm_(max_grad_norm) + torch.optim.AdamW step over the flat buffers, fused; refreshes the bf16 shadows.
@@ -878,7 +837,6 @@ class BertEncoderEngine:
             self.adam_m = torch.zeros_like(self.fp.flat_p)
             self.adam_v = torch.zeros_like(self.fp.flat_p)
         self.opt_step += 1
-        self._queue_keepmask_pregen()
         if coef is None:
             _, coef = self.grad_norm_and_clip_coef(max_grad_norm, grad_scale)
         # the bf16 compute copies ride the AdamW pass (its `shadow` output); what is left for the refresh are the transposes, made from them

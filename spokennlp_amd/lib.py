@@ -21,7 +21,7 @@ class BertCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("heads", C.c_int32), ("I", C.c_int32),
                 ("ln_eps", f32), ("p_hidden", f32), ("p_attn", f32), ("seed", u64),
                 ("accumulate_grads", C.c_int32), ("dtype", C.c_int32), ("window", C.c_int32), ("nglobal", C.c_int32),
-                ("nproj", C.c_int32), ("mixer", C.c_int32), ("phase", C.c_int32), ("act", C.c_int32), ("kend", vp), ("seq_order", vp), ("pad_guard", vp), ("pad_runs", vp), ("pad_counts", vp), ("keep_ready", C.c_int32)]
+                ("nproj", C.c_int32), ("mixer", C.c_int32), ("phase", C.c_int32), ("act", C.c_int32), ("kend", vp), ("seq_order", vp), ("pad_guard", vp), ("pad_runs", vp), ("pad_counts", vp)]
 
 
 class LayerParams(C.Structure):
@@ -57,7 +57,6 @@ _PROTOS = {
     "amdseg_attn_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, vp],
     "amdseg_attn_keepmask_bytes": [i32, i32, i32],
-    "amdseg_bert_keepmask_pregen": [vp, C.POINTER(vp), i32, vp],
     "amdseg_attn_keepmask": [vp, i32, i32, i32, f32, u64, vp, vp],
     "amdseg_attn_keepmask_band": [vp, i32, i32, i32, f32, u64, i32, i32, vp],
     "amdseg_attn_fwd_keep": [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],

@@ -25,7 +25,6 @@ class LongformerEncoderEngine(BertEncoderEngine):
     # "parity" precision (fp32 activations, split-bf16 contractions): the projections as in the BERT engine, the band attention on the
     # split-bf16 kernels of csrc/attention_split.hip, the global row in fp32 (its O(L) passes take fp32 rows)
     supports_parity = True
-    supports_keepmask_pregen = False
     parity_needs_split_attn = True
     def __init__(self, module, config, device, bert_attr="longformer"):
         super().__init__(module, config, device, bert_attr=bert_attr)

@@ -86,7 +86,6 @@ class PoNetModel(nn.Module):
 # ------------------------------------------------------------------------------------------------ engine
 class PoNetEncoderEngine(BertEncoderEngine):
     supports_parity = False
-    supports_keepmask_pregen = False
     def __init__(self, module, config, device, bert_attr="ponet"):
         super().__init__(module, config, device, bert_attr=bert_attr, layer_order=PONET_LAYER_ORDER, nproj=5)
         H, heads = self.H, self.heads
