@@ -108,6 +108,34 @@ def make_batches(args, n, seed, device):
 
 
 PROF_CLASSES = (("gemm_nt_dp_kernel", 0), ("gemm_tn_dp_kernel", 1), ("attn_fwd_kernel", 2), ("attn_bwd_dq_kernel", 3), ("attn_bwd_dkv_kernel", 4))
+# HBM-bound classes: the launch timer's `work` is algorithmic BYTES (include/amdseg.h AMDSEG_PROF_ADD_LN_FWD ..)
+PROF_CLASSES_HBM = (("add_ln_fwd_kernel", 5), ("ln_bwd_kernel", 6), ("adamw_kernel", 7), ("attn_keepmask_kernel", 8))
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s (6.3 TB/s measured copy)
+
+
+def prof_read_all(nsteps):
+    """every class of the launch timer after `nsteps` armed steps: MFMA classes in TFLOP/s against the bf16 peak, HBM classes in GB/s against 8 TB/s"""
+    import ctypes as C
+    from spokennlp_amd import lib as L
+    lib = L.load()
+    torch.cuda.synchronize()
+    out = {}
+    for table, hbm in ((PROF_CLASSES, False), (PROF_CLASSES_HBM, True)):
+        for name, cls in table:
+            us, work, n = C.c_double(), C.c_double(), C.c_longlong()
+            L.check(lib.amdseg_prof_read(cls, C.byref(us), C.byref(work), C.byref(n)), "amdseg_prof_read")
+            if not n.value:
+                continue
+            rec = dict(launches_per_step=round(n.value / nsteps, 2), avg_launch_us=round(us.value / n.value, 2), us_per_step=round(us.value / nsteps, 1))
+            if hbm:
+                gbs = work.value / us.value / 1e3
+                rec.update(bound="hbm", mbytes_per_launch=round(work.value / n.value / 1e6, 2), achieved=round(gbs, 1), unit="GB/s",
+                           frac=round(gbs / HBM_PEAK_GBS, 4))
+            else:
+                rec.update(gflop_per_launch=round(work.value / n.value / 1e9, 3), achieved=round(work.value / us.value / 1e6, 1),
+                           frac=round(work.value / us.value / 1e6 / MFMA_PEAK_TFLOPS, 4))
+            out[name] = rec
+    return out
 
 
 def prof_arm():
@@ -120,19 +148,9 @@ def prof_arm():
 
 
 def prof_collect(nsteps):
-    import ctypes as C
     from spokennlp_amd import lib as L
-    lib = L.load()
-    torch.cuda.synchronize()
-    out = {}
-    for name, cls in PROF_CLASSES:
-        us, work, n = C.c_double(), C.c_double(), C.c_longlong()
-        L.check(lib.amdseg_prof_read(cls, C.byref(us), C.byref(work), C.byref(n)), "amdseg_prof_read")
-        if n.value:
-            out[name] = dict(launches_per_step=round(n.value / nsteps, 2), avg_launch_us=round(us.value / n.value, 2),
-                             us_per_step=round(us.value / nsteps, 1), gflop_per_launch=round(work.value / n.value / 1e9, 3),
-                             achieved=round(work.value / us.value / 1e6, 1), frac=round(work.value / us.value / 1e6 / MFMA_PEAK_TFLOPS, 4))
-    lib.amdseg_prof_enable(0)
+    out = prof_read_all(nsteps)
+    L.load().amdseg_prof_enable(0)
     return out
 
 
@@ -150,15 +168,7 @@ def instep_roofline(step, first_step, nsteps):
     lib.amdseg_prof_reset()
     for i in range(first_step, first_step + nsteps):
         step(i)
-    torch.cuda.synchronize()
-    out = {}
-    for name, cls in PROF_CLASSES:
-        us, work, n = C.c_double(), C.c_double(), C.c_longlong()
-        L.check(lib.amdseg_prof_read(cls, C.byref(us), C.byref(work), C.byref(n)), "amdseg_prof_read")
-        if n.value:
-            out[name] = dict(launches_per_step=round(n.value / nsteps, 2), avg_launch_us=round(us.value / n.value, 2),
-                             us_per_step=round(us.value / nsteps, 1), gflop_per_launch=round(work.value / n.value / 1e9, 3),
-                             achieved=round(work.value / us.value / 1e6, 1), frac=round(work.value / us.value / 1e6 / MFMA_PEAK_TFLOPS, 4))
+    out = prof_read_all(nsteps)
     lib.amdseg_prof_enable(0)
     return out
 
@@ -197,6 +207,54 @@ def gemm_roofline(model, args, device):
                 avg_launch_us=round(tot_t / launches * 1e6, 1), per_shape=detail)
 
 
+def vendor_yardstick(args, device, H=768, I=3072):
+    """the SAME eight projection / dgrad shapes of a layer as plain C = A B^T products (no epilogue work) through the vendor library
+    (hipBLASLt behind torch.matmul) and through amdseg_gemm_nt (EPI_NONE), back to back on warm operands, HIP events on the launch
+    stream.  A yardstick for `roofline.frac`, not a product path: what a hand-tuned library kernel reaches on these K = 768 .. 3072 shapes
+    on this board (power / clock limited well below the nominal 2.5 PFLOP/s) -- and the weight-gradient shapes, where torch has no grouped
+    launch (four separate TN products against one grouped amdseg_gemm_tn_grouped launch)."""
+    from spokennlp_amd import ops
+    M = args.seqs_per_gpu * args.seq_len
+
+    def timeit(fn, reps=10, warm=3):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    shapes = [(3 * H, H), (H, H), (I, H), (H, I), (I, H), (H, I), (H, H), (H, 3 * H)]       # forward 4 + dgrad 4 (N, K)
+    rows, tv, to, fl = [], 0.0, 0.0, 0.0
+    seen = {}
+    for N, K in shapes:
+        if (N, K) not in seen:
+            A = torch.randn(M, K, device=device).bfloat16(); B = (torch.randn(N, K, device=device) * 0.05).bfloat16()
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=device)
+            t_v = timeit(lambda: torch.matmul(A, B.t(), out=out))
+            t_o = timeit(lambda: ops.gemm_nt(A, B, ops.EPI_NONE, out=out))
+            seen[(N, K)] = (t_v, t_o)
+            rows.append(dict(N=N, K=K, hipblaslt_us=round(t_v * 1e6, 1), hipblaslt_tflops=round(2.0 * M * N * K / t_v / 1e12, 1),
+                             amdseg_us=round(t_o * 1e6, 1), amdseg_tflops=round(2.0 * M * N * K / t_o / 1e12, 1)))
+        t_v, t_o = seen[(N, K)]
+        tv += t_v; to += t_o; fl += 2.0 * M * N * K
+    wg = [(H, I), (I, H), (H, H), (3 * H, H)]
+    As = [torch.randn(M, n, device=device).bfloat16() for n, _ in wg]
+    Bs = [torch.randn(M, k, device=device).bfloat16() for _, k in wg]
+    Cs = [torch.zeros(n, k, device=device) for n, k in wg]
+    t_tn_o = timeit(lambda: ops.gemm_tn_grouped(As, Bs, Cs, accumulate=True), reps=6)
+    t_tn_v = timeit(lambda: [torch.matmul(a.t(), b) for a, b in zip(As, Bs)], reps=6)
+    fl_tn = sum(2.0 * M * n * k for n, k in wg)
+    return dict(what="plain GEMMs (no epilogue) on the 8 NT shapes of a layer, M = %d, stand-alone back to back; hipblaslt = torch.matmul" % M,
+                nt_layer_avg=dict(hipblaslt_tflops=round(fl / tv / 1e12, 1), hipblaslt_frac=round(fl / tv / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                  amdseg_tflops=round(fl / to / 1e12, 1), amdseg_frac=round(fl / to / 1e12 / MFMA_PEAK_TFLOPS, 4)),
+                nt_shapes=rows,
+                tn_layer=dict(hipblaslt_4_launches_us=round(t_tn_v * 1e6, 1), hipblaslt_tflops=round(fl_tn / t_tn_v / 1e12, 1),
+                              amdseg_grouped_us=round(t_tn_o * 1e6, 1), amdseg_tflops=round(fl_tn / t_tn_o / 1e12, 1)))
+
+
 def pool_roofline(model, args, device):
     """PoNet config 4: the segment/local max-pool + fusion kernel pair (csrc/ponet.hip) against the HBM roofline;
     algorithmic bytes = read Hs, Ho, Hl + write ctx = 4 * M * H * 2 B per launch."""
@@ -232,11 +290,11 @@ def dp_record(eng, world, device, sync_marks, step, first_step, args):
     ones = torch.ones(1, device=device)
     dist.all_reduce(ones)
     b = eng.buckets
-    sizes = [(hi - lo) * 4 for lo, hi in b.layer_slices] + [(b.rest_slice[1] - b.rest_slice[0]) * 4]
+    sizes = [(hi - lo) * 4 for lo, hi in b.layer_slices] + [(b.rest_slice[1] - b.emb_slice[1]) * 4, (b.emb_slice[1] - b.emb_slice[0]) * 4]
     exposed = sorted(e0.elapsed_time(e1) for e0, e1 in sync_marks)
     rec = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), allreduce_of_ones=float(ones.item()),
                buckets_per_step=len(sizes), bytes_per_step=int(sum(sizes)), tail_bucket_bytes=int(sizes[-1]),
-               layer_bucket_bytes=int(sizes[0]), bucket_order="encoder layers last to first from inside backward (side stream), then embeddings + heads",
+               layer_bucket_bytes=int(sizes[0]), bucket_order="encoder layers last to first, then the embedding tables, all from inside backward (side stream); pooler + loss heads from finish_grad_sync",
                exposed_comm_ms_per_step=round(sum(exposed) / max(len(exposed), 1), 3),
                exposed_comm_ms_median=round(exposed[len(exposed) // 2], 3) if exposed else None,
                exposed_comm_method="HIP events on the compute stream around finish_grad_sync() (tail bucket issue + wait for every bucket), "
@@ -265,6 +323,31 @@ def dp_record(eng, world, device, sync_marks, step, first_step, args):
                              tail_bucket_bytes_on_wire=int(sizes[-1] - 2 * word))
     eng.buckets = old
     return rec
+
+
+def exposed_split(sync_split):
+    """the exposed part of the exchange by bucket class: from the end of backward on the compute stream (e0) to the
+    side-stream events behind (a) the last per-layer bucket, (b) the embeddings bucket -- issued by engine.backward right behind the embedding
+    backward --, (c) the rest (pooler + loss heads, issued by finish_grad_sync).  Each figure = how long that class kept running after the
+    previous one (or after e0) was done; per step, averaged over the timed region; this rank."""
+    if not sync_split:
+        return None
+    acc = dict(layer_buckets=0.0, embeddings_bucket=0.0, rest_bucket=0.0)
+    n = 0
+    for e0, m in sync_split:
+        if not all(k in m for k in ("layers_done", "embeddings_done", "rest_done")):
+            continue
+        t_l = max(0.0, e0.elapsed_time(m["layers_done"]))
+        t_e = max(t_l, e0.elapsed_time(m["embeddings_done"]))
+        t_r = max(t_e, e0.elapsed_time(m["rest_done"]))
+        acc["layer_buckets"] += t_l; acc["embeddings_bucket"] += t_e - t_l; acc["rest_bucket"] += t_r - t_e
+        n += 1
+    if not n:
+        return None
+    out = {k: round(v / n, 3) for k, v in acc.items()}
+    out["note"] = ("ms per step after the end of backward: layer buckets still running / then the embeddings bucket (issued from inside backward) / "
+                   "then pooler + heads (issued by finish_grad_sync)")
+    return out
 
 
 def host_cpu():
@@ -402,8 +485,10 @@ def run_leg(args, device, mode, precision, steps, warmup, prof_steps, seed=7):
     if prof:
         dom = "gemm_nt_dp_kernel" if "gemm_nt_dp_kernel" in prof else max(prof, key=lambda k: prof[k]["us_per_step"])
         d = prof[dom]
-        rl = dict(bound="mfma", kernel=dom, achieved=d["achieved"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=d["frac"],
-                  avg_launch_us=d["avg_launch_us"], launches_per_step=d["launches_per_step"], gflop_per_launch=d["gflop_per_launch"],
+        hbm_dom = d.get("bound") == "hbm"
+        rl = dict(bound="hbm" if hbm_dom else "mfma", kernel=dom, achieved=d["achieved"], peak=HBM_PEAK_GBS if hbm_dom else MFMA_PEAK_TFLOPS,
+                  unit="GB/s" if hbm_dom else "TFLOP/s", frac=d["frac"],
+                  avg_launch_us=d["avg_launch_us"], launches_per_step=d["launches_per_step"], gflop_per_launch=d.get("gflop_per_launch"),
                   kernels=prof)
         if precision == "parity":
             rl["note"] = ("flops are the EXECUTED split-bf16 products (K' = 3K: hi*hi + hi*lo + lo*hi); on the reference's fp32 flops the "
@@ -535,6 +620,9 @@ def main():
     # world > 1: the exposed part of the gradient exchange = what the compute stream spends between the end of backward and the start of
     # clip + AdamW (the tail bucket -- embeddings + heads, produced last -- is issued there, then every outstanding bucket is waited for)
     sync_marks = []
+    sync_split = []
+    if world > 1 and eng.buckets is not None:
+        eng.buckets.timing = True               # side-stream events behind the last layer bucket / the embeddings bucket / the rest
 
     def step(i):
         random.seed(i)
@@ -549,6 +637,8 @@ def main():
             eng.finish_grad_sync()
             e1.record()
             sync_marks.append((e0, e1))
+            if eng.buckets is not None and eng.buckets.timing:
+                sync_split.append((e0, dict(eng.buckets.marks)))
         else:
             eng.finish_grad_sync()
         lr = lr0 * max(0.0, (total_steps - i) / total_steps)        # linear decay, no warm-up (run_finetune.sh:73)
@@ -561,6 +651,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     sync_marks.clear()
+    sync_split.clear()
     prof_timed = (not args.no_roofline) and args.prof_in_timed and prof_arm()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -599,7 +690,10 @@ def main():
     per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     out["ms_per_step_median"] = round(per_step[len(per_step) // 2], 3)
     if world > 1 and args.mode == "train":
+        split = exposed_split(sync_split)
         out["dp"] = dp_record(eng, world, device, sync_marks, step, total_steps, args)
+        if split:
+            out["dp"]["exposed_comm_split_ms"] = split
     prof = None
     prof_n = args.steps
     if prof_timed:                                          # start / stop events of every launch of the timed region itself
@@ -625,9 +719,11 @@ def main():
         if prof:
             dom = max(prof, key=lambda k: prof[k]["us_per_step"]) if "gemm_nt_dp_kernel" not in prof else "gemm_nt_dp_kernel"
             d = prof[dom]
-            out["roofline"] = dict(bound="mfma", achieved=d["achieved"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=d["frac"], traffic=None,
+            hbm_dom = d.get("bound") == "hbm"
+            out["roofline"] = dict(bound="hbm" if hbm_dom else "mfma", achieved=d["achieved"], peak=HBM_PEAK_GBS if hbm_dom else MFMA_PEAK_TFLOPS,
+                                   unit="GB/s" if hbm_dom else "TFLOP/s", frac=d["frac"], traffic=None,
                                    kernel=dom, avg_launch_us=d["avg_launch_us"], launches_per_step=d["launches_per_step"],
-                                   gflop_per_launch=d["gflop_per_launch"],
+                                   gflop_per_launch=d.get("gflop_per_launch"),
                                    method=f"in-step: HIP start/stop events of every launch (hipExtLaunchKernelGGL, csrc/prof.h) over "
                                           + (f"the {prof_n} steps of the timed region" if prof_timed else f"{prof_n} real steps right after the "
                                              f"timed region") + "; HBM traffic needs separate rocprofv3 --pmc passes: see profiles/",
@@ -660,7 +756,8 @@ def main():
                             and args.seq_len == 512 and args.seqs_per_gpu == 32)
         if default_workload and not args.no_extra_legs:
             # the legs the headline does not cover, each bounded to seconds, all outside the timed region above
-            for key, fn in (("parity_report", lambda: parity_report(device)),
+            for key, fn in (("vendor_yardstick", lambda: vendor_yardstick(args, device)),
+                            ("parity_report", lambda: parity_report(device)),
                             ("parity_leg", lambda: run_leg(args, device, "train", "parity", 10, 3, 4)),
                             ("infer_leg", lambda: dict(bf16=run_leg(args, device, "infer", "bf16", 40, 8, 6),
                                                        parity=run_leg(args, device, "infer", "parity", 20, 4, 4)))):

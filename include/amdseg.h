@@ -393,6 +393,11 @@ int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float
 #define AMDSEG_PROF_ATTN_FWD 2
 #define AMDSEG_PROF_ATTN_BWD_DQ 3
 #define AMDSEG_PROF_ATTN_BWD_DKV 4
+/* HBM-bound row / stream kernels (ABI 8): `work` of these classes is the launch's ALGORITHMIC BYTES, not FLOPs */
+#define AMDSEG_PROF_ADD_LN_FWD 5   /* add_ln_fwd_kernel: read y, resid; write z, out                      = 4 * M * H * sizeof(act) */
+#define AMDSEG_PROF_LN_BWD 6       /* ln_bwd_kernel: read dy, z; write dz (+ dbranch with dropout)        = (3 or 4) * M * H * sizeof(act) */
+#define AMDSEG_PROF_ADAMW 7        /* adamw_kernel: p, g, m, v in; p, m, v out (+ bf16 shadow, + zeroed g) = 28 (+2) (+4) B per parameter */
+#define AMDSEG_PROF_KEEPMASK 8     /* attn_keepmask_kernel: the mask bytes written */
 int amdseg_prof_enable(int on);
 int amdseg_prof_reset(void);
 int amdseg_prof_read(int cls, double* total_us, double* total_work, long long* launches);

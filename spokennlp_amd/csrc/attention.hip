@@ -105,8 +105,13 @@ __global__ __launch_bounds__(256) void attn_keepmask_kernel(KeepMaskArgs a) {
 // consumer side.  The words sit in the constant address space so that the (wave-uniform) loads are scalar loads; inverse_ballot turns a
 // wave-uniform 64-bit word into the lane predicate of a select, i.e. v_cndmask with that SGPR pair as its mask operand.
 // ------------------------------------------------------------------------------------------------ forward
+#ifdef AMDSEG_ATTN_FWD_WPE          // occupancy probe: force N waves per SIMD (register budget 512 / N) instead of the two workgroups per CU below
+#define ATTN_FWD_BOUNDS __attribute__((amdgpu_waves_per_eu(AMDSEG_ATTN_FWD_WPE, AMDSEG_ATTN_FWD_WPE))) __launch_bounds__(NW * 64)
+#else
+#define ATTN_FWD_BOUNDS __launch_bounds__(NW * 64, 2)
+#endif
 template <int NW, bool BAND, bool LIST = false, bool KM = false>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ ATTN_FWD_BOUNDS void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -829,7 +834,7 @@ int amdseg_attn_keepmask_impl(void* keep, int B, int L, int heads, float p, uint
     for (int i = 0; i < 16; ++i) k.tn[i] = ((a.thresh16 >> i) & 1) ? 0u : 0xffffffffu;
     const int nblk = L / CH, ngrp = (nblk + KM_CG - 1) / KM_CG;
     const long waves = (long)B * heads * nblk * ngrp;
-    hipLaunchKernelGGL(attn_keepmask_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, k);
+    AMDSEG_LAUNCH_PROF(AMDSEG_PROF_KEEPMASK, 2.0 * B * heads * (double)L * L / 8.0, attn_keepmask_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, k);
     return amdseg_launch_status();
 }
 

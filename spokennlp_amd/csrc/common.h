@@ -17,6 +17,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define AMDSEG_PROF_ATTN_FWD 2
 #define AMDSEG_PROF_ATTN_BWD_DQ 3
 #define AMDSEG_PROF_ATTN_BWD_DKV 4
+#define AMDSEG_PROF_ADD_LN_FWD 5
+#define AMDSEG_PROF_LN_BWD 6
+#define AMDSEG_PROF_ADAMW 7
+#define AMDSEG_PROF_KEEPMASK 8
 #define AMDSEG_ERR_SHAPE 1001      // unsupported / misaligned shape
 #define AMDSEG_ERR_ARG 1002        // null pointer / bad enum
 #define AMDSEG_ERR_LAUNCH 1003     // hip launch error (hipGetLastError non-zero)

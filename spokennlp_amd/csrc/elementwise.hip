@@ -11,6 +11,7 @@
 // second-stage reduce (no atomics on the hot path).
 #include "common.h"
 #include "amdseg_internal.h"
+#include "prof.h"
 
 #define MAXCH 4                 // up to 4 chunks of 8 elements per lane -> H <= 2048
 #define ROWS_PER_BLOCK 4        // one wave per row, 4 waves per block
@@ -226,6 +227,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
 //   dbranch = dz * keepmask / (1-p)   (gradient of the dense output; == dz when p == 0 -> pass dbranch = nullptr)
 //   per-block column partials of dgamma (sum dy*xhat), dbeta (sum dy) and dbias (sum dbranch)
 #define LNB_ROWS 16     // rows per block (4 per wave)
+#ifndef AMDSEG_ABL_LNB
+#define AMDSEG_ABL_LNB 0   // timing probes only (tools/run_r04_lnb.sh): 1 = no dbias column sum, 2 = no column sums at all
+#endif
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, const float* mean, const float* rstd,
                                                      const float* gamma, T* dz, T* dbranch, float* partials, int M, int H,
@@ -290,8 +294,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
                 for (int e = 0; e < 8; ++e) {
                     const float xh = (x[c][e] - mu) * rs;
                     x[c][e] = xh;
-                    ab[c][e] += g[c][e];
-                    ag[c][e] += g[c][e] * xh;
+                    if (AMDSEG_ABL_LNB < 2) { ab[c][e] += g[c][e]; ag[c][e] += g[c][e] * xh; }
                     g[c][e] *= gg[e];
                     s1 += g[c][e];
                     s2 += g[c][e] * xh;
@@ -317,14 +320,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
                         else drop8_apply(seed, (uint64_t)m * nch + ch, thresh, inv_keep, g[c]);
                     }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) abias[c][e] += g[c][e];
+                    for (int e = 0; e < 8; ++e) if (AMDSEG_ABL_LNB < 1) abias[c][e] += g[c][e];
                 }
             }
             if (dbranch) row_store<T, NCH>(dbranch + (size_t)m * H, nch, l, g);
             if (img && dbranch) row_store_image<NCH>(img + (size_t)m * 3 * H, H, nch, l, g);
         }
     }
-    if (!partials) return;
+    if (!partials || AMDSEG_ABL_LNB >= 2) return;
     __syncthreads();                       // every wave is done reading gamma from `red`
     // cross-wave reduce through LDS, then one partial row per block
 #pragma unroll
@@ -709,6 +712,8 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* x, const float
 }
 
 #define ROWK(K, T, H, ...) do { if ((H) <= 1024) hipLaunchKernelGGL((K<T, 2>), __VA_ARGS__); else hipLaunchKernelGGL((K<T, 4>), __VA_ARGS__); } while (0)
+// the same through the launch timer (prof.h): class, algorithmic bytes of the launch
+#define ROWK_PROF(cls, work, K, T, H, ...) do { if ((H) <= 1024) AMDSEG_LAUNCH_PROF(cls, work, (K<T, 2>), __VA_ARGS__); else AMDSEG_LAUNCH_PROF(cls, work, (K<T, 4>), __VA_ARGS__); } while (0)
 // ------------------------------------------------------------------------------------------------ launchers
 // 16-bit threshold of drop8_apply (common.h); p >= 1 drops everything (inv_keep 0 instead of inf so that 0 * inv_keep stays 0)
 static inline void drop_params(float p, uint32_t& thresh, float& inv_keep) {
@@ -764,10 +769,10 @@ int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamm
     uint32_t th; float ik; drop_params(p, th, ik);
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     if (dtype == AMDSEG_BF16)
-        ROWK(add_ln_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta,
+        ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, 4.0 * M * H * 2, add_ln_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta,
                            (bf16_t*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits);
     else
-        ROWK(add_ln_fwd_kernel, float, H, grid, dim3(256), 0, s, (float*)y_inout_z, (const float*)resid, gamma, beta,
+        ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, 4.0 * M * H * 4, add_ln_fwd_kernel, float, H, grid, dim3(256), 0, s, (float*)y_inout_z, (const float*)resid, gamma, beta,
                            (float*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits);
     return amdseg_launch_status();
 }
@@ -782,13 +787,13 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
     if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
     uint32_t th; float ik; drop_params(p, th, ik);
     const int nblk = (M + LNB_ROWS - 1) / LNB_ROWS;
-    const size_t shm = (size_t)3 * 4 * H * sizeof(float);
+    const size_t shm = AMDSEG_ABL_LNB >= 2 ? (size_t)H * sizeof(float) : (size_t)3 * 4 * H * sizeof(float);
     if (dtype == AMDSEG_BF16)
-        ROWK(ln_bwd_kernel, bf16_t, H, dim3(nblk), dim3(256), shm, s, (const bf16_t*)dy, (const bf16_t*)z, mean, rstd,
+        ROWK_PROF(AMDSEG_PROF_LN_BWD, (dbranch ? 4.0 : 3.0) * M * H * 2, ln_bwd_kernel, bf16_t, H, dim3(nblk), dim3(256), shm, s, (const bf16_t*)dy, (const bf16_t*)z, mean, rstd,
                            gamma, (bf16_t*)dz, (bf16_t*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL, (bf16_t*)dense_grad_image,
                            (const uint8_t*)keepbits);
     else
-        ROWK(ln_bwd_kernel, float, H, dim3(nblk), dim3(256), shm, s, (const float*)dy, (const float*)z, mean, rstd, gamma,
+        ROWK_PROF(AMDSEG_PROF_LN_BWD, (dbranch ? 4.0 : 3.0) * M * H * 4, ln_bwd_kernel, float, H, dim3(nblk), dim3(256), shm, s, (const float*)dy, (const float*)z, mean, rstd, gamma,
                            (float*)dz, (float*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL, (bf16_t*)dense_grad_image,
                            (const uint8_t*)keepbits);
     if (partials) {

@@ -7,6 +7,7 @@
 // One pass reads p,g,m,v and writes p,m,v (+ the bf16 compute shadow, + optionally zeroes g): 28-34 B/param.
 #include "common.h"
 #include "amdseg_internal.h"
+#include "prof.h"
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n4, float lr,
@@ -99,7 +100,7 @@ int amdseg_adamw_impl(float* p, const float* g, float* m, float* v, void* shadow
     if (n == 0 || (n % 4) || step < 1) return AMDSEG_ERR_SHAPE;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, s, p, (float*)g, m, v, (bf16_t*)shadow, n / 4, lr, beta1,
+    AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ADAMW, (28.0 + (shadow ? 2.0 : 0.0) + (zero_grad ? 4.0 : 0.0)) * (double)n, adamw_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, s, p, (float*)g, m, v, (bf16_t*)shadow, n / 4, lr, beta1,
                        beta2, eps, wd, (float)bc1, (float)(1.0 / sqrt(bc2)), gscale, zero_grad, chunk_flags);
     return amdseg_launch_status();
 }

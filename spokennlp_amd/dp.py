@@ -57,6 +57,16 @@ class GradBuckets:
             b = offs[first_layer + (li + 1) * per_layer]
             self.layer_slices.append((a, b))
         self.rest_slice = (0, offs[first_layer])
+        # the leading part of the rest that ONLY the encoder's backward writes (embedding tables + their LayerNorm: 23.8 M of bert-base's 24.4 M
+        # non-layer parameters, the fully exposed tail of the exchange): reduced as soon as the embedding backward is queued (engine.backward);
+        # what follows (pooler, loss heads -- written by autograd nodes that may run after the encoder's) waits for finish_grad_sync()
+        n_emb = 0
+        while n_emb < first_layer and ".embeddings." in ("." + names[n_emb]):
+            n_emb += 1
+        self.emb_slice = (0, offs[n_emb])
+        self._emb_reduced = False
+        self.timing = False                    # bench: events behind the last layer bucket / the embeddings bucket / the rest (side stream)
+        self.marks = {}
         self.flat_g = fp.flat_g
         self.handles = []
         self.cuda = fp.flat_g.is_cuda
@@ -77,6 +87,7 @@ class GradBuckets:
     def reset_norm(self):
         self.sumsq.zero_()
         self._covered = 0
+        self._emb_reduced = False
 
     def norm_is_complete(self):
         return self.cuda and self._covered == self.flat_g.numel()
@@ -98,13 +109,23 @@ class GradBuckets:
             ops.sumsq(g, self.sumsq, self._partials, accumulate=True)
         self._covered += b - a
 
+    def _mark(self, key):
+        if self.timing and self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(self.side)
+            self.marks[key] = ev
+
     def reduce_layer(self, li, group=None):
         a, b = self.layer_slices[li]
         self._reduce(a, b, group)
+        if li == 0:
+            self._mark("layers_done")
 
-    def reduce_rest(self, group=None):
-        a, b = self.rest_slice
-        if self.word_slice is None:
+    def _reduce_span(self, a, b, group):
+        """[a, b) of the rest; the word-embedding table inside it in bf16 when that option is on"""
+        if b <= a:
+            return
+        if self.word_slice is None or self.word_slice[1] <= a or self.word_slice[0] >= b:
             self._reduce(a, b, group)
             return
         wa, wb = self.word_slice
@@ -113,6 +134,23 @@ class GradBuckets:
             self._reduce(a, wa, group)
         if b > wb:
             self._reduce(wb, b, group)
+
+    def reduce_embeddings(self, group=None):
+        """called by engine.backward right behind the embedding backward: the tail bucket starts without waiting for the host to come back
+        from loss.backward() and call finish_grad_sync()"""
+        if self._emb_reduced:
+            return
+        self._reduce_span(self.emb_slice[0], self.emb_slice[1], group)
+        self._emb_reduced = True
+        self._mark("embeddings_done")
+
+    def reduce_rest(self, group=None):
+        a, b = self.rest_slice
+        if self._emb_reduced:
+            a = self.emb_slice[1]
+        self._reduce_span(a, b, group)
+        self._emb_reduced = False
+        self._mark("rest_done")
 
     def wait(self):
         for h in self.handles:

@@ -790,6 +790,8 @@ class BertEncoderEngine:
                                   -te.shape[0] if type0_sum else te.shape[0], pe.shape[0], pad, adt, s)
         L.check(rc, "amdseg_embed_bwd")
         self._embed_backward_fixup(pe, pad)
+        if self.buckets is not None and self.grad_sync and not self._rest_reduced:
+            self.buckets.reduce_embeddings()        # the tail bucket (the embedding tables: 94 MB of bert-base's exposed exchange) starts here
         if self.overlap_wgrad:                      # every consumer of flat_g (clip, AdamW, torch optimizers) is on the current stream
             main = torch.cuda.current_stream()
             for ev in self._wgrad_done:

@@ -32,6 +32,16 @@ def _worker(rank, world, port, q):
     mine = fp.flat_g.clone()
     for li in reversed(range(fp.nlayers)):
         b.reduce_layer(li)
+    # the embeddings part of the rest goes first (engine.backward issues it right behind the embedding backward), the remainder (pooler, loss
+    # heads) with finish_grad_sync: together they must cover the rest exactly once
+    emb_names = [n for n in fp.offsets if ".embeddings." in "." + n]
+    assert b.emb_slice[0] == 0
+    assert b.emb_slice[1] <= b.rest_slice[1] and b.emb_slice[1] >= fp.offsets[emb_names[-1]] + fp.params[emb_names[-1]].numel()
+    if rank == 0:
+        b.reduce_embeddings()
+        b.reduce_embeddings()              # idempotent within a step
+    else:
+        b.reduce_embeddings()
     b.reduce_rest()
     b.wait()
     expect = sum(torch.randn(fp.numel, generator=torch.Generator().manual_seed(100 + k)) for k in range(world))
