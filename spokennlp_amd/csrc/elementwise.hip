@@ -348,6 +348,198 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
     }
 }
 
+// ---- ln_bwd for H = 768 in bf16 (bert-base / longformer-base / bigbird-base / PoNet-base: the shape every measured step runs) ----------------
+// Round 4: SQ counters of the generic kernel above (profiles/r04_ln_bwd.md): 489 vector instructions per token row and wave, the four waves
+// of a SIMD ISSUE-bound (active-instruction time ~27 % per wave), half the wave time parked -- not HBM (3.4 TB/s), not loads in flight.  Where
+// the instructions went: 768 = 96 chunks of 8 on 64 lanes means a second chunk that only lanes 0-31 own (a full issue slot for half a wave,
+// behind an exec-mask branch), 64-bit per-lane address arithmetic for every load and store, the dropout decode, gamma re-read per row.
+// This kernel: TWO rows per wave iteration, THREE chunks per lane -- (row A, chunk l), (row B, chunk l), and chunk 64 + (l & 31) of row A for
+// lanes 0-31, of row B for lanes 32-63 -- so every lane owns exactly 24 elements and no issue slot runs half empty; row bases are wave-uniform
+// (SGPR base + one 32-bit lane offset per chunk: no vector address arithmetic), mean / rstd are scalar loads, the row sums come back as
+// scalars (DPP + readlane).  Same partials layout ([3][blocks][H]) and the same second stage as the generic kernel; same padding-block rule.
+__device__ __forceinline__ void lnb_unpack8(const uint4& q, float (&v)[8]) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 lnb_pack8(const float (&v)[8]) {
+    uint4 q;
+    q.x = pack2bf(v[0], v[1]); q.y = pack2bf(v[2], v[3]); q.z = pack2bf(v[4], v[5]); q.w = pack2bf(v[6], v[7]);
+    return q;
+}
+#define LNP_H 768
+#define LNP_NCH 96
+#ifdef AMDSEG_LNP_WPE                  // probe: force N waves per SIMD (spills beyond the register budget)
+#define LNP_BOUNDS __attribute__((amdgpu_waves_per_eu(AMDSEG_LNP_WPE, AMDSEG_LNP_WPE))) __launch_bounds__(256)
+#else
+#define LNP_BOUNDS __launch_bounds__(256)
+#endif
+// raw buffer access: SGPR resource + wave-uniform byte offset (SGPR) + one 32-bit lane offset -- no per-lane 64-bit addresses (the plain
+// pointer form cost 2 VGPRs per access stream and a v_lshl_add_u64 per access; the kernel spilled at 4 waves per SIMD)
+typedef int lnb_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lnb_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint4 lnb_ld16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const lnb_v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
+}
+__device__ __forceinline__ void lnb_st16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const uint4& q) {
+    const lnb_v4i v = {(int)q.x, (int)q.y, (int)q.z, (int)q.w};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+}
+__global__ LNP_BOUNDS void ln_bwd_pair768_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, bf16_t* __restrict__ dz,
+                                                             bf16_t* __restrict__ dbranch, float* __restrict__ partials, int M,
+                                                             uint32_t thresh, float inv_keep, const int* __restrict__ zkend,
+                                                             const int* __restrict__ zguard, int zL, const uint8_t* __restrict__ keepbits) {
+    extern __shared__ float red[];         // gamma [768] during the row loop, then [3][4 waves][768]
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+    // persistent over row PAIRS (grid: pair_grid(), 2 workgroups per CU), pair q goes to wave (q mod waves): with one 16-row block per
+    // workgroup, 1024 blocks on 768 resident slots (148 VGPRs) were a full round plus a third of one
+    const bool zpad = zkend != nullptr && *zguard == 0;    // rows of trailing padding hold a known exact-zero dy: zero rows out, nothing summed
+    const int half = l >> 5;                                // the third chunk belongs to row A (lanes 0-31) or row B (lanes 32-63)
+    const int ch2 = 64 + (l & 31);
+    const uint32_t off0 = (uint32_t)l * 16u, off1 = (uint32_t)(LNP_H * 2) + off0, off2 = (uint32_t)half * (LNP_H * 2) + (uint32_t)ch2 * 16u;
+    const uint32_t kof0 = (uint32_t)l, kof1 = LNP_NCH + kof0, kof2 = (uint32_t)half * LNP_NCH + (uint32_t)ch2;
+    float ag0[8], ab0[8], ai0[8], ag2[8], ab2[8], ai2[8];   // column sums: chunk l (both rows) and chunk ch2 (this lane's row)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag0[e] = ab0[e] = ai0[e] = ag2[e] = ab2[e] = ai2[e] = 0.f; }
+    for (int i = threadIdx.x; i < LNP_H; i += 256) red[i] = gamma[i];
+    __syncthreads();
+    const bool drop = thresh != 0;
+    const __amdgpu_buffer_rsrc_t r_dy = lnb_rsrc(dy), r_z = lnb_rsrc(z), r_dz = lnb_rsrc(dz), r_db = lnb_rsrc(dbranch ? dbranch : dz),
+                                 r_kb = lnb_rsrc(keepbits ? (const void*)keepbits : (const void*)dy);
+#pragma unroll 1
+    for (int pair = blockIdx.x * 4 + w; pair < (M >> 1); pair += gridDim.x * 4) {
+        const int mA = 2 * pair;                            // wave-uniform; rows mA (A) and mA + 1 (B)
+        if (zpad) {                                         // (zL is even: both rows sit in the same sequence)
+            const int zb = mA / zL;
+            if (mA - zb * zL >= zkend[zb]) {
+                const uint4 zq = make_uint4(0u, 0u, 0u, 0u);
+                const uint32_t rowz = (uint32_t)mA * (LNP_H * 2);
+                lnb_st16(r_dz, off0, rowz, zq); lnb_st16(r_dz, off1, rowz, zq); lnb_st16(r_dz, off2, rowz, zq);
+                if (dbranch) { lnb_st16(r_db, off0, rowz, zq); lnb_st16(r_db, off1, rowz, zq); lnb_st16(r_db, off2, rowz, zq); }
+                continue;
+            }
+        }
+        const uint32_t rowb = (uint32_t)mA * (LNP_H * 2);   // byte offset of row A (M * 1536 < 2^31: checked by the launcher)
+        const uint4 rd0 = lnb_ld16(r_dy, off0, rowb), rd1 = lnb_ld16(r_dy, off1, rowb), rd2 = lnb_ld16(r_dy, off2, rowb);
+        const uint4 rz0 = lnb_ld16(r_z, off0, rowb), rz1 = lnb_ld16(r_z, off1, rowb), rz2 = lnb_ld16(r_z, off2, rowb);
+        uint32_t kb0 = 0xffu, kb1 = 0xffu, kb2 = 0xffu;
+        if (drop) {
+            const uint32_t kbrow = (uint32_t)mA * LNP_NCH;
+            kb0 = __builtin_amdgcn_raw_buffer_load_b8(r_kb, (int)kof0, (int)kbrow, 0);
+            kb1 = __builtin_amdgcn_raw_buffer_load_b8(r_kb, (int)kof1, (int)kbrow, 0);
+            kb2 = __builtin_amdgcn_raw_buffer_load_b8(r_kb, (int)kof2, (int)kbrow, 0);
+        }
+        const float muA = mean[mA], rsA = rstd[mA], muB = mean[mA + 1], rsB = rstd[mA + 1];
+        const float mu2 = half ? muB : muA, rs2 = half ? rsB : rsA;
+        // pass 1, chunk by chunk: xhat (kept), the column sums of dy and dy * xhat, the row sums of g = dy * gamma and g * xhat.  g itself is
+        // NOT kept: pass 2 rebuilds it from the raw bf16 dy (3 instructions per element against 24 more live registers).  Register budget
+        // (148 VGPRs = 3 waves per SIMD; measured alternatives, all slower or spilling: xhat rebuilt as well -> the scheduler interleaves the
+        // chunks and needs 173-194; forced to 128 -> 28-62 spills, 24 -> 37 us): 48 accumulators + 24 xhat + 12 raw dy + one chunk of temporaries
+        float x0[8], x1[8], x2[8];
+        lnb_unpack8(rz0, x0); lnb_unpack8(rz1, x1); lnb_unpack8(rz2, x2);
+        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f, s1c = 0.f, s2c = 0.f;
+        const float nmA = -muA * rsA, nmB = -muB * rsB, nm2 = -mu2 * rs2;
+        {
+            float gm[8], d[8];
+            ld8<float>(red + l * 8, gm);
+            lnb_unpack8(rd0, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x0[e] = x0[e] * rsA + nmA;
+                ab0[e] += d[e]; ag0[e] += d[e] * x0[e];
+                const float t = d[e] * gm[e];
+                s1a += t; s2a += t * x0[e];
+            }
+            lnb_unpack8(rd1, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x1[e] = x1[e] * rsB + nmB;
+                ab0[e] += d[e]; ag0[e] += d[e] * x1[e];
+                const float t = d[e] * gm[e];
+                s1b += t; s2b += t * x1[e];
+            }
+            ld8<float>(red + ch2 * 8, gm);
+            lnb_unpack8(rd2, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x2[e] = x2[e] * rs2 + nm2;
+                ab2[e] += d[e]; ag2[e] += d[e] * x2[e];
+                const float t = d[e] * gm[e];
+                s1c += t; s2c += t * x2[e];
+            }
+        }
+        s1a += half ? 0.f : s1c; s2a += half ? 0.f : s2c;
+        s1b += half ? s1c : 0.f; s2b += half ? s2c : 0.f;
+        const float S1A = wave_sum_dpp(s1a) * (1.0f / LNP_H), S2A = wave_sum_dpp(s2a) * (1.0f / LNP_H);
+        const float S1B = wave_sum_dpp(s1b) * (1.0f / LNP_H), S2B = wave_sum_dpp(s2b) * (1.0f / LNP_H);
+        const float S12 = half ? S1B : S1A, S22 = half ? S2B : S2A;
+        float g0[8], g1[8], g2[8];
+        // (opaque to the optimiser: otherwise it keeps pass 1's unpacked dy alive across the reductions instead of re-deriving it)
+        uint4 qd0 = rd0, qd1 = rd1, qd2 = rd2;
+        asm volatile("" : "+v"(qd0.x), "+v"(qd0.y), "+v"(qd0.z), "+v"(qd0.w), "+v"(qd1.x), "+v"(qd1.y), "+v"(qd1.z), "+v"(qd1.w),
+                          "+v"(qd2.x), "+v"(qd2.y), "+v"(qd2.z), "+v"(qd2.w));
+        {
+            float gm[8];
+            ld8<float>(red + l * 8, gm);
+            lnb_unpack8(qd0, g0); lnb_unpack8(qd1, g1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                g0[e] = rsA * (g0[e] * gm[e] - S1A - x0[e] * S2A);
+                g1[e] = rsB * (g1[e] * gm[e] - S1B - x1[e] * S2B);
+            }
+            ld8<float>(red + ch2 * 8, gm);
+            lnb_unpack8(qd2, g2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g2[e] = rs2 * (g2[e] * gm[e] - S12 - x2[e] * S22);
+        }
+        lnb_st16(r_dz, off0, rowb, lnb_pack8(g0));
+        lnb_st16(r_dz, off1, rowb, lnb_pack8(g1));
+        lnb_st16(r_dz, off2, rowb, lnb_pack8(g2));
+        if (drop) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                // bit e -> 0 / all ones -> 0.0f / inv_keep
+                const float k0 = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe(kb0, e, 1) & __float_as_uint(inv_keep));
+                const float k1 = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe(kb1, e, 1) & __float_as_uint(inv_keep));
+                const float k2 = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe(kb2, e, 1) & __float_as_uint(inv_keep));
+                g0[e] *= k0; g1[e] *= k1; g2[e] *= k2;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ai0[e] += g0[e]; ai0[e] += g1[e]; ai2[e] += g2[e]; }
+        if (dbranch) {
+            lnb_st16(r_db, off0, rowb, lnb_pack8(g0));
+            lnb_st16(r_db, off1, rowb, lnb_pack8(g1));
+            lnb_st16(r_db, off2, rowb, lnb_pack8(g2));
+        }
+    }
+    __syncthreads();                       // every wave is done reading gamma from `red`
+    // the two lanes l and l ^ 32 hold the sums of the SAME columns of chunk ch2 (one per row of the pair): combine them, lanes 0-31 write
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ag2[e] += __shfl_xor(ag2[e], 32, 64); ab2[e] += __shfl_xor(ab2[e], 32, 64); ai2[e] += __shfl_xor(ai2[e], 32, 64);
+    }
+    st8<float>(red + (0 * 4 + w) * LNP_H + l * 8, ag0);
+    st8<float>(red + (1 * 4 + w) * LNP_H + l * 8, ab0);
+    st8<float>(red + (2 * 4 + w) * LNP_H + l * 8, ai0);
+    if (l < 32) {
+        st8<float>(red + (0 * 4 + w) * LNP_H + ch2 * 8, ag2);
+        st8<float>(red + (1 * 4 + w) * LNP_H + ch2 * 8, ab2);
+        st8<float>(red + (2 * 4 + w) * LNP_H + ch2 * 8, ai2);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * LNP_H; i += 256) {
+        const int k = i / LNP_H, c = i - k * LNP_H;
+        const float sm = red[(k * 4 + 0) * LNP_H + c] + red[(k * 4 + 1) * LNP_H + c] + red[(k * 4 + 2) * LNP_H + c] + red[(k * 4 + 3) * LNP_H + c];
+        partials[((size_t)k * gridDim.x + blockIdx.x) * LNP_H + c] = sm;
+    }
+}
+
 // out[c] (+)= sum_b partials[b*stride + offset + c]   (deterministic second stage)
 // block = RED_CG float4 column groups (RED_COLS = 32 columns = one 128-B line per partial row) x RED_ROWS = 32 row lanes; each lane strides over
 // the partial rows, LDS tree at the end.  (Was 64 columns x 16 lanes: the LayerNorm jobs of a layer -- 6 x 768 columns of 1024 partial rows,
@@ -777,6 +969,19 @@ int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamm
     return amdseg_launch_status();
 }
 
+// workgroups of the persistent pair kernel: 2 per CU (3 fit at 148 VGPRs; measured in the step at 32 x 512 tokens: 2 -> 20.9 us, 3 -> 21.3,
+// one block per 16 rows = 1024 blocks on 768 slots -> 23.9), never more than one per 16 rows
+static int pair_grid(int nblk) {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const char* e = getenv("AMDSEG_LNP_WGS_PER_CU");
+        slots = cus * (e && atoi(e) > 0 ? atoi(e) : 2);
+    }
+    return nblk < slots ? nblk : slots;
+}
+
 int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                        void* dz, void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M,
                        int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s,
@@ -788,7 +993,18 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
     uint32_t th; float ik; drop_params(p, th, ik);
     const int nblk = (M + LNB_ROWS - 1) / LNB_ROWS;
     const size_t shm = AMDSEG_ABL_LNB >= 2 ? (size_t)H * sizeof(float) : (size_t)3 * 4 * H * sizeof(float);
-    if (dtype == AMDSEG_BF16)
+    int nblk_eff = nblk;                                    // partial rows written per column sum (the pair kernel's grid is persistent)
+    static int generic_only = -1;
+    if (generic_only < 0) { const char* e = getenv("AMDSEG_LN_BWD_GENERIC"); generic_only = (e && atoi(e)) ? 1 : 0; }
+    if (dtype == AMDSEG_BF16 && H == LNP_H && (M % LNB_ROWS) == 0 && (size_t)M * H * 2 < (1ull << 31) && partials && !dense_grad_image && (th == 0 || keepbits) && !generic_only &&
+        AMDSEG_ABL_LNB == 0)
+    {
+        nblk_eff = pair_grid(nblk);
+        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_LN_BWD, (dbranch ? 4.0 : 3.0) * M * H * 2, ln_bwd_pair768_kernel, dim3(nblk_eff), dim3(256), shm, s,
+                           (const bf16_t*)dy, (const bf16_t*)z, mean, rstd, gamma, (bf16_t*)dz, (bf16_t*)dbranch, partials, M, th, ik, zkend, zguard, zL,
+                           (const uint8_t*)keepbits);
+    }
+    else if (dtype == AMDSEG_BF16)
         ROWK_PROF(AMDSEG_PROF_LN_BWD, (dbranch ? 4.0 : 3.0) * M * H * 2, ln_bwd_kernel, bf16_t, H, dim3(nblk), dim3(256), shm, s, (const bf16_t*)dy, (const bf16_t*)z, mean, rstd,
                            gamma, (bf16_t*)dz, (bf16_t*)dbranch, partials, M, H, th, ik, seed, zkend, zguard, zL, (bf16_t*)dense_grad_image,
                            (const uint8_t*)keepbits);
@@ -798,14 +1014,14 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
                            (const uint8_t*)keepbits);
     if (partials) {
         Reduce3 r;
-        r.part[0] = partials; r.part[1] = partials + (size_t)nblk * H; r.part[2] = partials + (size_t)2 * nblk * H;
+        r.part[0] = partials; r.part[1] = partials + (size_t)nblk_eff * H; r.part[2] = partials + (size_t)2 * nblk_eff * H;
         r.out[0] = dgamma; r.out[1] = dbeta; r.out[2] = dbias;
         if ((H % 4) == 0 && (dgamma || dbeta || dbias)) {
             bool queued = g_defer != nullptr && g_defer->njobs + 3 <= AMDSEG_MAX_REDUCE_JOBS && g_defer->accumulate == accumulate;
             if (queued)
                 for (int k = 0; k < 3; ++k)
-                    if (r.out[k]) queued = defer_reduce(r.part[k], nblk, H, 0, H, r.out[k], accumulate) && queued;
-            if (!queued) hipLaunchKernelGGL(reduce3_kernel, dim3((H + RED_COLS - 1) / RED_COLS, 3), dim3(256), 0, s, r, nblk, H, accumulate);
+                    if (r.out[k]) queued = defer_reduce(r.part[k], nblk_eff, H, 0, H, r.out[k], accumulate) && queued;
+            if (!queued) hipLaunchKernelGGL(reduce3_kernel, dim3((H + RED_COLS - 1) / RED_COLS, 3), dim3(256), 0, s, r, nblk_eff, H, accumulate);
         }
     }
     return amdseg_launch_status();

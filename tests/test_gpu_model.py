@@ -223,7 +223,41 @@ def test_hidden_dropout_decisions_kept_by_forward_equal_the_rehashed_ones(dev, p
         if precision == "bf16":
             assert torch.equal(res[True][1][n], g), n
         else:       # "parity" precision's split attention backward is reproducible to fp32 round-off only; another DECISION would move a gradient by ~1e-1 relative
-            assert float((res[True][1][n] - g).norm()) <= 1e-5 * max(float(g.norm()), 1e-6), n
+            assert float((res[True][1][n] - g).norm()) <= 1e-5 * float(g.norm()) + 1e-7, n      # (key.bias: a theoretical zero, ~1e-9 of noise)
+
+
+def test_h768_layernorm_backward_pair_kernel_equals_generic_kernel(dev):
+    """csrc/elementwise.hip ln_bwd_pair768_kernel (H = 768, bf16: two rows per wave iteration, three chunks per lane, buffer addressing, the
+    forward's keep bits) against the generic row kernel with the re-evaluated hash (engine.hidden_keepbits = False selects it): same
+    decisions, same formula, another summation order -- one training step with dropout at H = 768 gives the same loss and gradients that
+    agree to the bf16 rounding of the activation gradients"""
+    from tests.util import tiny_state_dict
+    from spokennlp_amd import data
+    arch = dict(vocab_size=300, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=1024,
+                max_position_embeddings=128, type_vocab_size=2)
+    z, _, _, _ = load_case("tiny_L64")
+    flags = flags_of(z, "train_full")
+    sd = tiny_state_dict(arch, seed=3)
+    docs = data.synth_docs(8, seed=5, vocab=300, mean_sents=14, sd_sents=4, mean_boundaries=3, mu_tok=1.6, sigma_tok=0.4)
+    batch = to_dev(data.batches_from_docs(docs, 128, 2, seed=2)[0], dev)
+    res = {}
+    for keep in (True, False):
+        m = build_model(arch, flags, sd, dev, dropout=0.1).train()
+        m.amdseg_seed = 5
+        m.engine().hidden_keepbits = keep
+        random.seed(3)
+        loss = m(**batch)[0]
+        loss.backward()
+        res[keep] = (loss.item(), {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None and ".layer." in n})
+    assert res[True][0] == res[False][0]                     # the forward is the same kernel either way
+    worst = 0.0
+    for n, g in res[False][1].items():
+        if "key.bias" in n:                                  # softmax is invariant to a key bias: its gradient is rounding noise around 0
+            continue
+        d = float((res[True][1][n] - g).norm()) / max(float(g.norm()), 1e-6)
+        worst = max(worst, d)
+        assert d < 2e-2, (n, d)
+    print("pair kernel vs generic ln_bwd: worst relative gradient difference", worst)
 
 
 def test_fused_adamw_step_matches_torch(dev):
