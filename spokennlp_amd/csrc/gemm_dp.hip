@@ -83,6 +83,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #define DP_DMA_B(s, kt) _Pragma("unroll") for (int i = 0; i < 2; ++i) if (i == 0 || b2) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
         amdseg_glds16_saddr(pB + (kt) * 64, offB[i * 2 + q], DP_TILE_B(s, wr * 2 + i) + (wq * 2 + q) * 1024);
 #define DP_WAIT_TILE() do { if (vm8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
+    // piece j (0..3; j >= 2 only for a group with two B images) of this wave's B duty, one at a time: issued BETWEEN the MFMAs of phase 2
+#define DP_DMA_B_PIECE(s, kt, j) do { if ((j) < 2 || b2) amdseg_glds16_saddr(pB + (kt) * 64, offB[j], DP_TILE_B(s, wr * 2 + ((j) >> 1)) + (wq * 2 + ((j) & 1)) * 1024); } while (0)
     f32x4 acc[8][NF];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -124,6 +126,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #define DP_MFMA(ah) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int f = 0; f < 4; ++f) \
         _Pragma("unroll") for (int e = 0; e < NF; ++e) \
         acc[(ah) * 4 + f][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[e][kk], fa[f][kk], acc[(ah) * 4 + f][e], 0, 0, 0);
+    // (-DAMDSEG_ABL_DMA_AMONG_MFMAS) phase-2 MFMAs with the four B pieces of K tile kt + 2 issued after MFMAs 4, 12, 20 and 28: phase 2's load
+    // half carries 6 of the wave's 8 LDS-DMA pieces per K tile next to 8 fragment reads (phase 1: 2 pieces, 16 reads) -- ~100-185 clk of issue
+    // each in a phase that also reads fragments (MI355X_MICROARCH.md), ~60 among bare MFMAs.  Measured: the stalled MFMA issue costs more
+#define DP_MFMA_DMAB(ah, s_, kt_) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int f = 0; f < 4; ++f) { \
+        _Pragma("unroll") for (int e = 0; e < NF; ++e) \
+            acc[(ah) * 4 + f][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[e][kk], fa[f][kk], acc[(ah) * 4 + f][e], 0, 0, 0); \
+        if (f == 0 || f == 2) { __builtin_amdgcn_sched_barrier(0); if ((kt_) < nk) DP_DMA_B_PIECE(s_, kt_, kk * 2 + (f >> 1)); __builtin_amdgcn_sched_barrier(0); } }
 #define DP_MID() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
 #define DP_END() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
     for (int kt = 0; kt < nk; ++kt) {
@@ -140,11 +149,22 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         // ---- phase 2: rows 64-127.  DMA: rows-0..63 image + this group's two B images of K tile kt+2 into THIS stage (their last
         //      readers -- this group's phase 1 and the other group's phase 1, one slot later -- have retired their reads)
         DP_LOAD_A(s, 1)
+#ifndef AMDSEG_ABL_DMA_AMONG_MFMAS                           // default: all 6 pieces in the load half (round 1..3 placement)
         if (kt + 2 < nk) { DP_DMA_A(s, 0, kt + 2) DP_DMA_B(s, kt + 2) }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (kt + 2 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DP_MID();
         DP_MFMA(1)
+#else
+        // round-4 experiment, measured SLOWER (profiles/r04_gemm_dma_placement.md): the B pieces issued among the MFMAs of this phase.
+        // issue order per K tile is then A1(kt+1) | A0(kt+2) | B(kt+2): what must have landed here is A0(kt+1) and B(kt+1) (issued one K tile
+        // ago); younger than those are only A1(kt+1) and the A0(kt+2) just issued = 4 pieces, whatever the group's number of B pieces
+        if (kt + 2 < nk) { DP_DMA_A(s, 0, kt + 2) }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DP_MID();
+        DP_MFMA_DMAB(1, s, kt + 2)                          // (one MFMA sequence, the pieces behind a scalar branch: two copies of it spilled)
+#endif
         DP_END();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();             // group 0 pays back the stagger barrier: every LDS read is retired now
