@@ -83,8 +83,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #define DP_DMA_B(s, kt) _Pragma("unroll") for (int i = 0; i < 2; ++i) if (i == 0 || b2) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
         amdseg_glds16_saddr(pB + (kt) * 64, offB[i * 2 + q], DP_TILE_B(s, wr * 2 + i) + (wq * 2 + q) * 1024);
 #define DP_WAIT_TILE() do { if (vm8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
-    // piece j (0..3; j >= 2 only for a group with two B images) of this wave's B duty, one at a time: issued BETWEEN the MFMAs of phase 2
-#define DP_DMA_B_PIECE(s, kt, j) do { if ((j) < 2 || b2) amdseg_glds16_saddr(pB + (kt) * 64, offB[j], DP_TILE_B(s, wr * 2 + ((j) >> 1)) + (wq * 2 + ((j) & 1)) * 1024); } while (0)
     f32x4 acc[8][NF];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -123,50 +121,62 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #define DP_LOAD_B(s) _Pragma("unroll") for (int e = 0; e < NF; ++e) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
         fb[e][kk] = NF == 4 ? dp_fragB(DP_TILE_B(s, wc), (e >> 1) * 32 + (i16 >> 2) * 8 + (e & 1) * 4 + (i16 & 3), kk * 4 + g) \
                             : dp_frag(DP_TILE_B(s, fbi[e]), fbr[e] + i16, kk * 4 + g);
+    // NF = 4, unrolled K loop: the fragment addresses written out as (stage, k-half)-specific lane bases + compile-time immediates that fit the
+    // 16-bit offset field of ds_read_b128 (the stage-1 images start at 64 KiB, so each stage has its own bases): 8 VGPRs, no address
+    // arithmetic in the loop.  (c ^ swz) << 4 with c = kk*4 + g splits into (kk << 2) ^ (g ^ swz); both swizzles depend on i16 only.
+    const char* la_[2][2];
+    const char* lb_[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            la_[st][kk] = smem + st * STAGE + wr * 2 * 8192 + i16 * 128 + ((((g ^ dp_swz(i16)) ^ (kk << 2))) << 4);
+            const int rb = (i16 >> 2) * 8 + (i16 & 3);
+            lb_[st][kk] = smem + st * STAGE + (4 + wc) * 8192 + rb * 128 + ((((g ^ dp_swzB(rb)) ^ (kk << 2))) << 4);
+        }
+#define DP_LOAD_A_U(S, h) _Pragma("unroll") for (int f = 0; f < 4; ++f) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+        fa[f][kk] = *reinterpret_cast<const bf16x8*>(la_[S][kk] + (h) * 8192 + f * 2048);
+#define DP_LOAD_B_U(S) _Pragma("unroll") for (int e = 0; e < NF; ++e) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+        fb[e][kk] = *reinterpret_cast<const bf16x8*>(lb_[S][kk] + (e >> 1) * 4096 + (e & 1) * 512);
 #define DP_MFMA(ah) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int f = 0; f < 4; ++f) \
         _Pragma("unroll") for (int e = 0; e < NF; ++e) \
         acc[(ah) * 4 + f][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[e][kk], fa[f][kk], acc[(ah) * 4 + f][e], 0, 0, 0);
-    // (-DAMDSEG_ABL_DMA_AMONG_MFMAS) phase-2 MFMAs with the four B pieces of K tile kt + 2 issued after MFMAs 4, 12, 20 and 28: phase 2's load
-    // half carries 6 of the wave's 8 LDS-DMA pieces per K tile next to 8 fragment reads (phase 1: 2 pieces, 16 reads) -- ~100-185 clk of issue
-    // each in a phase that also reads fragments (MI355X_MICROARCH.md), ~60 among bare MFMAs.  Measured: the stalled MFMA issue costs more
-#define DP_MFMA_DMAB(ah, s_, kt_) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int f = 0; f < 4; ++f) { \
-        _Pragma("unroll") for (int e = 0; e < NF; ++e) \
-            acc[(ah) * 4 + f][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[e][kk], fa[f][kk], acc[(ah) * 4 + f][e], 0, 0, 0); \
-        if (f == 0 || f == 2) { __builtin_amdgcn_sched_barrier(0); if ((kt_) < nk) DP_DMA_B_PIECE(s_, kt_, kk * 2 + (f >> 1)); __builtin_amdgcn_sched_barrier(0); } }
 #define DP_MID() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
 #define DP_END() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-    for (int kt = 0; kt < nk; ++kt) {
-        const int s = kt & 1;
-        // ---- phase 1: rows 0-63 of the wave tile.  DMA: the rows-64..127 image of K tile kt+1 (other stage; last read in phase 2
-        //      of K tile kt-1, retired before that phase's barrier)
-        DP_LOAD_B(s) DP_LOAD_A(s, 0)
-        if (kt >= DP_KT0 && kt + 1 < nk) { DP_DMA_A(s ^ 1, 1, kt + 1) }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kt >= DP_KT0 && kt + 1 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        DP_MID();
-        DP_MFMA(0)
-        DP_END();
-        // ---- phase 2: rows 64-127.  DMA: rows-0..63 image + this group's two B images of K tile kt+2 into THIS stage (their last
-        //      readers -- this group's phase 1 and the other group's phase 1, one slot later -- have retired their reads)
-        DP_LOAD_A(s, 1)
-#ifndef AMDSEG_ABL_DMA_AMONG_MFMAS                           // default: all 6 pieces in the load half (round 1..3 placement)
-        if (kt + 2 < nk) { DP_DMA_A(s, 0, kt + 2) DP_DMA_B(s, kt + 2) }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kt + 2 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        DP_MID();
-        DP_MFMA(1)
-#else
-        // round-4 experiment, measured SLOWER (profiles/r04_gemm_dma_placement.md): the B pieces issued among the MFMAs of this phase.
-        // issue order per K tile is then A1(kt+1) | A0(kt+2) | B(kt+2): what must have landed here is A0(kt+1) and B(kt+1) (issued one K tile
-        // ago); younger than those are only A1(kt+1) and the A0(kt+2) just issued = 4 pieces, whatever the group's number of B pieces
-        if (kt + 2 < nk) { DP_DMA_A(s, 0, kt + 2) }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        DP_MID();
-        DP_MFMA_DMAB(1, s, kt + 2)                          // (one MFMA sequence, the pieces behind a scalar branch: two copies of it spilled)
-#endif
-        DP_END();
+    // one K tile on stage S.  phase 1: rows 0-63 of the wave tile; DMA: the rows-64..127 image of K tile kt+1 (other stage; last read in phase 2
+    // of K tile kt-1, retired before that phase's barrier).  phase 2: rows 64-127; DMA: rows-0..63 image + this group's two B images of K tile
+    // kt+2 into THIS stage (their last readers -- this group's phase 1 and the other group's phase 1, one slot later -- have retired their reads).
+    // (All 6 pieces of phase 2 stay in its load half: issuing the B pieces among the MFMAs measured slower, profiles/r04_gemm_dma_placement.md.)
+#define DP_KTILE(kt, S, LDA, LDB) { \
+        LDB(S) LDA(S, 0) \
+        if ((kt) >= DP_KT0 && (kt) + 1 < nk) { DP_DMA_A((S) ^ 1, 1, (kt) + 1) } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if ((kt) >= DP_KT0 && (kt) + 1 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        DP_MID(); \
+        DP_MFMA(0) \
+        DP_END(); \
+        LDA(S, 1) \
+        if ((kt) + 2 < nk) { DP_DMA_A(S, 0, (kt) + 2) DP_DMA_B(S, (kt) + 2) } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if ((kt) + 2 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        DP_MID(); \
+        DP_MFMA(1) \
+        DP_END(); }
+    int kt = 0;
+#ifndef AMDSEG_ABL_NO_UNROLL2
+    // the K loop unrolled by two: the stage is a compile-time constant in each copy, so every fragment address is (a lane term that does
+    // not depend on the stage) + an immediate -- round 4: the rolled loop re-derived them per K tile, ~40 vector instructions in the load
+    // halves (SQ counters, profiles/r04_gemm_dma_placement.md)
+    if (NF == 4) {
+        for (; kt + 1 < nk; kt += 2) { DP_KTILE(kt, 0, DP_LOAD_A_U, DP_LOAD_B_U) DP_KTILE(kt + 1, 1, DP_LOAD_A_U, DP_LOAD_B_U) }
+        if (kt < nk) DP_KTILE(kt, 0, DP_LOAD_A_U, DP_LOAD_B_U)
+    } else {
+        for (; kt + 1 < nk; kt += 2) { DP_KTILE(kt, 0, DP_LOAD_A, DP_LOAD_B) DP_KTILE(kt + 1, 1, DP_LOAD_A, DP_LOAD_B) }
+        if (kt < nk) DP_KTILE(kt, 0, DP_LOAD_A, DP_LOAD_B)
     }
+#else
+    for (; kt < nk; ++kt) { const int s_ = kt & 1; DP_KTILE(kt, s_, DP_LOAD_A, DP_LOAD_B) }
+#endif
     if (wr == 0) __builtin_amdgcn_s_barrier();             // group 0 pays back the stagger barrier: every LDS read is retired now
     }
 
