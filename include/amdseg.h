@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 8   /* 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward); 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 8   /* 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_gemm_nt_bias_drop_res, amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -62,6 +62,15 @@ const char* amdseg_error_string(int code);
  *   ([hf] models/bert/modeling_bert.py:175-177,282-293,325-351) and, with transposed weight shadows, its dgrad. */
 int amdseg_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
                    const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32, amdseg_stream_t stream);
+/* C = R + dropout(A B^T + bias) (bf16 in / out, fp32 accumulate): the output dense, its dropout and the residual add of BertSelfOutput /
+ * BertOutput ([hf] models/bert/modeling_bert.py:282-293, :340-351) in ONE launch -- the epilogue of the 256 x 256 deep-pipeline GEMM; the
+ * LayerNorm that follows is then amdseg_add_ln_fwd with resid == NULL (reads z, writes out: 2 passes over [M, N] instead of 4).  The keep
+ * decisions are those amdseg_add_ln_fwd makes for the same (seed, row, column) -- one stateless hash per 8 consecutive columns -- and go to
+ * keepbits ([M * N / 8] bytes, bit e = column 8k + e kept; may be NULL), where amdseg_bert_layer_bwd's LayerNorm backward reads them
+ * (amdseg_bert_layer_acts.drop1 / drop2).  M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128 (else AMDSEG_ERR_SHAPE: use amdseg_gemm_nt +
+ * amdseg_add_ln_fwd).  ABI 8. */
+int amdseg_gemm_nt_bias_drop_res(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                                 const void* R, int ldr, float dropout_p, uint64_t seed, void* keepbits, amdseg_stream_t stream);
 /* gemm_tn_grouped: for each problem i: C_i[N_i,K_i] (+)= sum_m A_i[m,N_i] . B_i[m,K_i]  (fp32 out), shared M.
  *   the weight gradients dW = dY^T X of one encoder layer in ONE launch (autograd of the Linear layers above). */
 int amdseg_gemm_tn_grouped(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
@@ -218,7 +227,8 @@ int amdseg_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64
 int amdseg_embed_bwd(const void* dz, const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, float* dword,
                      float* dpos, float* dtype_emb, int M, int L, int H, int vocab, int type_vocab, int npos, int pad_id,
                      int dtype, amdseg_stream_t stream);
-/* z = resid + dropout(y) (written over y), out = LayerNorm(z)   ([hf] modeling_bert.py:282-293, 340-351) */
+/* z = resid + dropout(y) (written over y), out = LayerNorm(z)   ([hf] modeling_bert.py:282-293, 340-351).
+ * resid == NULL (ABI 8): y_inout_z already holds z (amdseg_gemm_nt_bias_drop_res) -- LayerNorm only, y_inout_z is not written, dropout_p ignored */
 int amdseg_add_ln_fwd(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out, float* mean,
                       float* rstd, int M, int H, float eps, float dropout_p, uint64_t seed, int dtype,
                       amdseg_stream_t stream);

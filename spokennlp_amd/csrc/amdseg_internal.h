@@ -26,6 +26,8 @@ int amdseg_embed_ln_fwd_impl(const int64_t* ids, const int64_t* type_ids, const 
 int amdseg_embed_bwd_impl(const void* dz, const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
                           float* dword, float* dpos, float* dtype_emb, int M, int L, int H, int vocab, int type_vocab,
                           int npos, int pad_id, int dtype, hipStream_t s);
+int amdseg_gemm_nt_bias_drop_res_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                      const float* bias, const void* R, int ldr, float p, uint64_t seed, void* keepbits, hipStream_t stream);
 int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out,
                            float* mean, float* rstd, int M, int H, float eps, float p, uint64_t seed, int dtype,
                            hipStream_t s, void* out_image = nullptr,         // out_image: `out` also as the split image [M, 3H] ("parity" precision)

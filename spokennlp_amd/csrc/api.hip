@@ -345,11 +345,22 @@ int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float
                                       t_labels_off, nt, Ct, dWt, dbt, w_cl, w_tssp2, S(stream));
 }
 
+int amdseg_gemm_nt_bias_drop_res(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                                 const void* R, int ldr, float dropout_p, uint64_t seed, void* keepbits, amdseg_stream_t stream) {
+    return amdseg_gemm_nt_bias_drop_res_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, R, ldr, dropout_p, seed, keepbits, S(stream));
+}
+
 // ---------------------------------------------------------------------------------------------------- composite layer
 static inline uint64_t site_seed(uint64_t seed, int layer, int site) {
     return seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer * 8 + site + 1) * 0xD1B54A32D192ED03ull;
 }
 #define RET_IF(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+static bool fuse_drop_res() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("AMDSEG_FUSE_DROP_RES"); v = (e && atoi(e) != 0) ? 1 : 0; }      // default OFF: measured slower, see below
+    return v != 0;
+}
 
 static int check_cfg(const amdseg_bert_cfg* c) {
     if (!c) return AMDSEG_ERR_ARG;
@@ -470,15 +481,32 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         }
     }
     if (!PHASE2(c)) return AMDSEG_OK;
-    // attention output dense -> dropout -> +residual -> LN
+    // attention output dense -> dropout -> +residual -> LN.  Optional (AMDSEG_FUSE_DROP_RES=1): dropout and residual in the GEMM's epilogue
+    // (z = x_in + dropout(ctx Wo^T + bo) leaves the GEMM; same keep decisions, one bf16 rounding less), the row kernel LayerNorm only, 2 passes
+    // over [M, H] instead of 4.  Built and measured in round 4, OFF by default: the row kernel drops 20.7 -> 13.8 us but the two GEMMs gain
+    // 14-16 us each (hash + residual read + byte stores in an exposed epilogue, and the 256-wide tile instead of the 192-wide one these N = 768
+    // shapes otherwise take): 13.81 vs 13.70 ms per step (profiles/r04_fused_drop_res.md)
+    const bool fuse_dr = fuse_drop_res() && c->dtype == AMDSEG_BF16 && (M % 256) == 0 && (H % 256) == 0 && H >= 128 && (I % 64) == 0;
+    if (fuse_dr) {
+        RET_IF(amdseg_gemm_nt_bias_drop_res_impl(a->ctx, H, p->wo, H, a->z1, H, M, H, H, p->bo, a->x_in, H, c->p_hidden, site_seed(c->seed, li, 1),
+                                                 a->drop1, s));
+        RET_IF(amdseg_add_ln_fwd_impl(a->z1, nullptr, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, 0.f, 0, c->dtype, s));
+    } else {
     RET_IF(amdseg_gemm_nt_impl(a->ctx, H, p->wo, H, a->z1, H, M, H, H, AMDSEG_EPI_BIAS, p->bo, nullptr, 0, nullptr, 0, 0, s));
     RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
                                   site_seed(c->seed, li, 1), c->dtype, s, nullptr, a->drop1));
+    }
     // FFN
     RET_IF(amdseg_gemm_nt_impl(a->x1, H, p->w1, H, a->h, I, M, I, H, AMDSEG_EPI_BIAS_GELU | (c->act ? AMDSEG_EPI_ACT_TANH : 0), p->b1, nullptr, 0, a->u, I, 0, s));
+    if (fuse_dr) {
+        RET_IF(amdseg_gemm_nt_bias_drop_res_impl(a->h, I, p->w2, I, a->z2, H, M, H, I, p->b2, a->x1, H, c->p_hidden, site_seed(c->seed, li, 2),
+                                                 a->drop2, s));
+        RET_IF(amdseg_add_ln_fwd_impl(a->z2, nullptr, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, 0.f, 0, c->dtype, s));
+    } else {
     RET_IF(amdseg_gemm_nt_impl(a->h, I, p->w2, I, a->z2, H, M, H, I, AMDSEG_EPI_BIAS, p->b2, nullptr, 0, nullptr, 0, 0, s));
     RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, c->p_hidden,
                                   site_seed(c->seed, li, 2), c->dtype, s, nullptr, a->drop2));
+    }
     return AMDSEG_OK;
 }
 

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
     const int nch = H >> 3;
     float v[NCH][8], x[NCH][8];
     row_load<T, NCH>(y_z + (size_t)m * H, nch, l, v);
+    if (resid) {                                           // (resid == NULL: y_z already IS z -- the GEMM's epilogue added the residual: LayerNorm only)
     row_load<T, NCH>(resid + (size_t)m * H, nch, l, x);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
         }
     }
     row_store<T, NCH>(y_z + (size_t)m * H, nch, l, v);
+    }
     float mu, rs;
     row_stats(v, nch, l, H, eps, mu, rs);
     if (l == 0) { if (mean) mean[m] = mu; if (rstd) rstd[m] = rs; }
@@ -956,15 +958,16 @@ int amdseg_embed_bwd_impl(const void* dz, const int64_t* ids, const int64_t* typ
 int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out,
                            float* mean, float* rstd, int M, int H, float eps, float p, uint64_t seed, int dtype,
                            hipStream_t s, void* out_image, void* keepbits) {
-    if (!y_inout_z || !resid || !gamma || !beta || !out) return AMDSEG_ERR_ARG;
+    if (!y_inout_z || !gamma || !beta || !out) return AMDSEG_ERR_ARG;      // resid == NULL: LayerNorm of y_inout_z as it stands (p ignored)
     if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
     uint32_t th; float ik; drop_params(p, th, ik);
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    const double bytes_per_el = resid ? 4.0 : 2.0;
     if (dtype == AMDSEG_BF16)
-        ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, 4.0 * M * H * 2, add_ln_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta,
+        ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, bytes_per_el * M * H * 2, add_ln_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta,
                            (bf16_t*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits);
     else
-        ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, 4.0 * M * H * 4, add_ln_fwd_kernel, float, H, grid, dim3(256), 0, s, (float*)y_inout_z, (const float*)resid, gamma, beta,
+        ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, bytes_per_el * M * H * 4, add_ln_fwd_kernel, float, H, grid, dim3(256), 0, s, (float*)y_inout_z, (const float*)resid, gamma, beta,
                            (float*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits);
     return amdseg_launch_status();
 }

@@ -644,6 +644,7 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
 #endif
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldc2 = ldc2; a.M = M; a.N = N; a.K = K;
     a.tiles_m = M / BM; a.tiles_n = N / BN; a.dup_off = 0;
+    a.drop_thresh = 0; a.drop_inv_keep = 1.f; a.drop_seed = 0; a.keepbits = nullptr;
     const bool zok = zkend && zguard && zL > 0 && (zL % PP_BM) == 0 && (M % zL) == 0;      // a 256-row tile lies inside one sequence
     a.zkend = zok ? zkend : nullptr; a.zguard = zok ? zguard : nullptr; a.zL = zok ? zL : 0;
     switch (epi) {
@@ -676,6 +677,24 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
             return amdseg_launch_nt_dp<EPI_BIAS_GELU_SPLIT, float>(a, stream);
     }
     return AMDSEG_ERR_ARG;
+}
+
+// C = R + dropout(A B^T + bias): the output dense, its dropout and the residual add of BertSelfOutput / BertOutput ([hf] modeling_bert.py
+// :282-293, :340-351) in the epilogue of the 256 x 256 deep-pipeline kernel; the LayerNorm that follows then reads one tensor instead of two
+// and writes one instead of two.  Keep decisions = drop8_bits(seed, row * N / 8 + column / 8): what amdseg_add_ln_fwd would have decided.
+int amdseg_gemm_nt_bias_drop_res_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                      const float* bias, const void* R, int ldr, float p, uint64_t seed, void* keepbits, hipStream_t stream) {
+    if (!A || !B || !C || !bias || !R) return AMDSEG_ERR_ARG;
+    if (M <= 0 || (M % 256) || (N % 256) || (K % BK) || K < 128) return AMDSEG_ERR_SHAPE;
+    if ((lda % 8) || (ldb % 8) || (ldc % 8) || (ldr % 8)) return AMDSEG_ERR_SHAPE;
+    GemmNTArgs a;
+    a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = bias; a.R = (const bf16_t*)R; a.C2 = nullptr; a.dbg = nullptr;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldc2 = 0; a.M = M; a.N = N; a.K = K;
+    a.tiles_m = M / 256; a.tiles_n = N / 256; a.dup_off = 0;
+    a.zkend = nullptr; a.zguard = nullptr; a.zL = 0;
+    amdseg_drop_params(p, a.drop_thresh, a.drop_inv_keep);
+    a.drop_seed = seed; a.keepbits = (unsigned char*)keepbits;
+    return amdseg_launch_nt_dp<EPI_BIAS_DROP_RES, bf16_t>(a, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ gemm_tn

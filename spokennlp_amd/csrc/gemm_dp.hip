@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     // ---- epilogue.  Lane owns row m = mf*16 + i16 and columns nf*16 + g*4 .. +4 of the wave tile.  bf16 results go through a
     // wave-private 16-KiB LDS image (2 x [64 rows][128 B], swizzled) so every global store instruction writes 8 full 128-B lines.
     float4 bv[NF];
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT || EPI == EPI_BIAS_GELU_SPLIT) {
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT || EPI == EPI_BIAS_GELU_SPLIT || EPI == EPI_BIAS_DROP_RES) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
             bv[nf] = (EPI == EPI_BIAS_SPLIT && !a.bias) ? make_float4(0.f, 0.f, 0.f, 0.f)      // BIAS_SPLIT without a bias: the plain product as an image
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     }
     // the bias goes INTO the accumulators once: recomputing acc + bias in both passes of BIAS_GELU made the compiler keep all
     // 128 sums of pass 0 alive for pass 1 (common subexpression) next to the 128 accumulators -> 116 spilled VGPRs
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT || EPI == EPI_BIAS_GELU_SPLIT) {
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT || EPI == EPI_BIAS_GELU_SPLIT || EPI == EPI_BIAS_DROP_RES) {
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         for (int mf = 0; mf < 8; ++mf) {
             const size_t gm = (size_t)(m0 + wr * 128 + mf * 16 + i16);
             uint4 rr[2];
-            if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+            if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_DROP_RES) {
 #pragma unroll
                 for (int ep = 0; ep < 2; ++ep) rr[ep] = *reinterpret_cast<const uint4*>(a.R + gm * a.ldr + n0 + wc * 64 + ep * 32 + g * 8);
             }
@@ -265,11 +265,23 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                         *reinterpret_cast<uint4*>(a.C2 + gm * a.ldc2 + col) = pk;
                     }
                     gelu_act4(v, ACT); gelu_act4(v + 4, ACT);
-                } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+                } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_DROP_RES) {
                     const uint32_t rw[4] = {rr[ep].x, rr[ep].y, rr[ep].z, rr[ep].w};
                     float rf[8];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { rf[2 * q] = __uint_as_float(rw[q] << 16); rf[2 * q + 1] = __uint_as_float(rw[q] & 0xffff0000u); }
+                    if (EPI == EPI_BIAS_DROP_RES) {
+                        // the lane's 8 consecutive columns ARE one 16-B chunk of the row kernels: the same (seed, chunk) hash decides them
+                        // (drop8_bits, common.h), the byte goes where ln_bwd reads it (chunk = row * N / 8 + column / 8)
+                        if (a.drop_thresh) {
+                            const uint64_t chunk = (uint64_t)gm * (uint64_t)(a.N >> 3) + (col >> 3);
+                            const uint32_t bits = drop8_bits(a.drop_seed, chunk, a.drop_thresh);
+                            if (a.keepbits) a.keepbits[chunk] = (unsigned char)bits;
+                            drop8_apply_bits(bits, a.drop_inv_keep, v);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += rf[q];
+                    } else
                     if (EPI == EPI_ADD_RES) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += rf[q];
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         for (int mf = 0; mf < 8; ++mf) {
             const size_t gm = (size_t)(m0 + wr * 128 + mf * 16 + i16);
             uint2 rr[NF];
-            if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+            if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_DROP_RES) {     // (DROP_RES: 256-wide tile only; this path is never launched for it)
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) rr[nf] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + col0 + nf * 16 + g * 4);
             }
@@ -309,10 +321,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                 float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
                 if (EPI == EPI_BIAS_GELU && pass == 1) {
                     gelu_act4(v, ACT);
-                } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD) {
+                } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_DROP_RES) {
                     const float r0 = __uint_as_float(rr[nf].x << 16), r1 = __uint_as_float(rr[nf].x & 0xffff0000u);
                     const float r2 = __uint_as_float(rr[nf].y << 16), r3 = __uint_as_float(rr[nf].y & 0xffff0000u);
-                    if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
+                    if (EPI == EPI_ADD_RES || EPI == EPI_BIAS_DROP_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
                     else gelu_grad_mul4(v, r0, r1, r2, r3, ACT);
                 }
                 if (STAGED) {
@@ -381,7 +393,7 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
         const int t256 = (a_in.M / DP_BM) * (a_in.N / 256), t192 = (a_in.M / DP_BM) * (a_in.N / 192);
         narrow = 0.78f * (float)((t192 + 255) / 256) < (float)((t256 + 255) / 256);
     }
-    constexpr bool direct_only = EB == EPI_BIAS_SPLIT || EB == EPI_GELU_BWD_SPLIT || EB == EPI_BIAS_GELU_SPLIT;    // epilogues of the 256-wide tile only
+    constexpr bool direct_only = EB == EPI_BIAS_SPLIT || EB == EPI_GELU_BWD_SPLIT || EB == EPI_BIAS_GELU_SPLIT || EB == EPI_BIAS_DROP_RES;    // epilogues of the 256-wide tile only
     if (direct_only && !ok256) return AMDSEG_ERR_SHAPE;
     const bool use192 = !direct_only && ok192 && (!ok256 || force == 192 || narrow);
     if (use192) return launch_nt_dp_nf<EPIX, OutT, 3>(a_in, s);
@@ -393,7 +405,7 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
 DP_INST(EPI_NONE, bf16_t) DP_INST(EPI_NONE, float) DP_INST(EPI_BIAS, bf16_t) DP_INST(EPI_BIAS, float) DP_INST(EPI_BIAS_GELU, bf16_t)
 DP_INST(EPI_ADD_RES, bf16_t) DP_INST(EPI_ADD_RES, float) DP_INST(EPI_GELU_BWD, bf16_t)
 DP_INST(EPI_BIAS_GELU_TANH, bf16_t) DP_INST(EPI_GELU_BWD_TANH, bf16_t) DP_INST(EPI_BIAS_SPLIT, bf16_t) DP_INST(EPI_GELU_BWD_SPLIT, bf16_t)
-DP_INST(EPI_BIAS_GELU_SPLIT, float)
+DP_INST(EPI_BIAS_GELU_SPLIT, float) DP_INST(EPI_BIAS_DROP_RES, bf16_t)
 
 
 // ==================================================================================================== gemm_tn, deep pipeline

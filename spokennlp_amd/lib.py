@@ -48,6 +48,7 @@ _PROTOS = {
     "amdseg_abi_version": [],
     "amdseg_error_string": [i32],
     "amdseg_gemm_nt": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp],
+    "amdseg_gemm_nt_bias_drop_res": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, f32, u64, vp, vp],
     "amdseg_gemm_tn_grouped": [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp),
                                C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, i32, vp],
     "amdseg_gemm_tn_grouped_bias": [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp),

@@ -347,6 +347,20 @@ def ln_partials_numel(M, H):
     return 3 * ((M + LNB_ROWS - 1) // LNB_ROWS) * H
 
 
+def gemm_nt_bias_drop_res(A, B, bias, R, p=0.0, seed=0, want_bits=True):
+    """z = R + dropout(A @ B^T + bias) in the epilogue of the 256 x 256 GEMM (csrc/gemm_dp.hip EPI_BIAS_DROP_RES); returns (z, keep bytes
+    [M * N / 8] or None)"""
+    _chk(A, "A"); _chk(B, "B")
+    M, K = A.shape
+    N = B.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    bits = torch.zeros((M * N // 8,), dtype=torch.uint8, device=A.device) if (want_bits and p > 0) else None
+    rc = L.load().amdseg_gemm_nt_bias_drop_res(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), _p(R),
+                                               R.stride(0), p, seed, _p(bits), _s())
+    L.check(rc, "amdseg_gemm_nt_bias_drop_res")
+    return out, bits
+
+
 def ln_bwd(dy, z, mean, rstd, gamma, p=0.0, seed=0, dgamma=None, dbeta=None, dbias=None, accumulate=False, partials=None):
     M, H = dy.shape
     dz = torch.empty_like(dy)

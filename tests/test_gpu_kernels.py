@@ -599,3 +599,42 @@ def test_pad_plan_and_guard(dev, B, L):
             x2[bi, pi, H - 1] = val
             Lb.check(lib.amdseg_pad_rows_guard(x2.data_ptr(), kend.data_ptr(), B, L, H, guard.data_ptr(), s), "amdseg_pad_rows_guard")
             assert int(guard.item()) == (0 if val == 0 else 1), val
+
+
+@pytest.mark.parametrize("K,p", [(768, 0.1), (3072, 0.1), (768, 0.0)])
+def test_gemm_bias_dropout_residual_epilogue(dev, K, p):
+    """amdseg_gemm_nt_bias_drop_res (ABI 8): z = R + dropout(A B^T + bias) out of the 256 x 256 GEMM's epilogue.  The keep decisions are
+    EXACTLY those of the row kernel amdseg_add_ln_fwd for the same seed (same hash per 8 columns); the values equal gemm_nt(BIAS) followed by
+    add_ln_fwd's z up to the one bf16 rounding of the dense output that the fused form skips; LayerNorm-only mode (resid = None) of
+    amdseg_add_ln_fwd on that z equals the separate path's output to the same tolerance."""
+    ops = _ops()
+    M, N, seed = 512, 768, 1234
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16(); B = (torch.randn(N, K, generator=g) * 0.05).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev); R = torch.randn(M, N, generator=g).to(dev).bfloat16()
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).to(dev); beta = (0.1 * torch.randn(N, generator=g)).to(dev)
+    z, bits = ops.gemm_nt_bias_drop_res(A, B, bias, R, p=p, seed=seed)
+    # the separate path: dense + bias (bf16), then z = R + dropout(y) inside add_ln_fwd
+    y = ops.gemm_nt(A, B, ops.EPI_BIAS, bias=bias)
+    ybuf = y.clone()
+    out_sep, mean_sep, rstd_sep = ops.add_ln_fwd(ybuf, R, gamma, beta, 1e-12, p=p, seed=seed)
+    keep_sep = (ybuf.float() - R.float()).abs() > 0            # dropped elements leave z == R exactly
+    if p > 0:
+        b = bits.view(M, N // 8).cpu()
+        keep_fused = torch.stack([((b >> e) & 1) for e in range(8)], dim=-1).reshape(M, N).bool().to(dev)
+        dense = y.float().abs() > 0.1 * R.float().abs() + 0.05   # (a small dense output next to a large residual rounds away in bf16: no decision visible in z)
+        assert torch.equal(keep_fused[dense], keep_sep[dense])
+        assert abs(1.0 - keep_fused.float().mean().item() - p) < 5e-3
+    ref = A.float() @ B.float().t() + bias
+    if p > 0:
+        q = round(p * 65536) / 65536
+        ref = ref * keep_fused.float() / (1 - q)
+    ref = ref + R.float()
+    assert (z.float() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item() / 4)
+    assert (z.float() - ybuf.float()).abs().max().item() < 6e-2       # vs the separate path: one bf16 rounding of y apart
+    zb = z.clone()
+    out_f, mean_f, rstd_f = ops.add_ln_fwd(zb, None, gamma, beta, 1e-12)
+    assert torch.equal(zb, z)                                         # LayerNorm only: z is not rewritten
+    refln = torch.nn.functional.layer_norm(z.float(), (N,), gamma, beta, 1e-12)
+    assert (out_f.float() - refln).abs().max().item() < 3e-2
+    assert (mean_f - z.float().mean(1)).abs().max().item() < 1e-4
