@@ -631,7 +631,8 @@ def test_gemm_bias_dropout_residual_epilogue(dev, K, p):
         ref = ref * keep_fused.float() / (1 - q)
     ref = ref + R.float()
     assert (z.float() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item() / 4)
-    assert (z.float() - ybuf.float()).abs().max().item() < 6e-2       # vs the separate path: one bf16 rounding of y apart
+    # vs the separate path: one bf16 rounding of y (2^-8 relative, scaled by 1 / keep) and one of z apart
+    assert (z.float() - ybuf.float()).abs().max().item() < 2.0 ** -6 * max(1.0, y.float().abs().max().item(), z.float().abs().max().item())
     zb = z.clone()
     out_f, mean_f, rstd_f = ops.add_ln_fwd(zb, None, gamma, beta, 1e-12)
     assert torch.equal(zb, z)                                         # LayerNorm only: z is not rewritten
