@@ -59,6 +59,40 @@ __device__ __forceinline__ void wave_dot4_lds(const float* __restrict__ w0, int 
     for (int j = 0; j < 4; ++j) out[j] = wave_sum(s[j]);
 }
 
+// eight consecutive weight rows at a time (24 row loads of a lane in flight at H = 768): lf_global_q heads the forward chain of every layer
+__device__ __forceinline__ void wave_dot8_lds(const float* __restrict__ w0, int H, const float* vec, int l, float (&out)[8]) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (H <= 768) {                                          // every trip's loads issued before the first use
+        float4 w[3][8];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int k = l * 4 + t * 256;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[t][j] = k < H ? *reinterpret_cast<const float4*>(w0 + (size_t)j * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int k = l * 4 + t * 256;
+            if (k < H) {
+                const float v0 = vec[k], v1 = vec[k + 1], v2 = vec[k + 2], v3 = vec[k + 3];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += w[t][j].x * v0 + w[t][j].y * v1 + w[t][j].z * v2 + w[t][j].w * v3;
+            }
+        }
+    } else {
+        for (int k = l * 4; k < H; k += 256) {
+            float4 w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const float4*>(w0 + (size_t)j * H + k);
+            const float v0 = vec[k], v1 = vec[k + 1], v2 = vec[k + 2], v3 = vec[k + 3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += w[j].x * v0 + w[j].y * v1 + w[j].z * v2 + w[j].w * v3;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = wave_sum(s[j]);
+}
+
 // grid (heads, B, H / 256), 256 threads: every block recomputes its head's qg (64 short dots), block z writes r columns z*256 ..
 __global__ __launch_bounds__(256) void lf_global_q_kernel(LfGArgs a) {
     extern __shared__ float sm[];                        // [H] x0 | [64] qg
@@ -66,13 +100,13 @@ __global__ __launch_bounds__(256) void lf_global_q_kernel(LfGArgs a) {
     const int h = blockIdx.x, b = blockIdx.y, w = threadIdx.x >> 6, l = threadIdx.x & 63;
     for (int k = threadIdx.x; k < a.H; k += 256) x0[k] = ld_any(a.x, (size_t)b * a.L * a.H + k, a.x_dtype);
     __syncthreads();
-    for (int e = w * 16; e < w * 16 + 16; e += 4) {
+    for (int e = w * 16; e < w * 16 + 16; e += 8) {
         const int row = h * 64 + e;
-        float v[4];
-        wave_dot4_lds(a.Wq + (size_t)row * a.H, a.H, x0, l, v);
+        float v[8];
+        wave_dot8_lds(a.Wq + (size_t)row * a.H, a.H, x0, l, v);
         if (l == 0)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 const float t = (v[j] + a.bq[row + j]) * a.scale;
                 q[e + j] = t;
                 if (blockIdx.z == 0) a.qg[((size_t)b * a.heads + h) * 64 + e + j] = t;
@@ -81,12 +115,19 @@ __global__ __launch_bounds__(256) void lf_global_q_kernel(LfGArgs a) {
     __syncthreads();
     const int c = blockIdx.z * 256 + threadIdx.x;
     if (c < a.H) {
+        // the lane's 64 strided Wk elements in four batches of 16 loads in flight (same four partial sums, same order of additions as before)
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         const float* wk = a.Wk + (size_t)(h * 64) * a.H + c;
-#pragma unroll 4
-        for (int e = 0; e < 64; e += 4) {
-            s0 = fmaf(q[e], wk[(size_t)e * a.H], s0); s1 = fmaf(q[e + 1], wk[(size_t)(e + 1) * a.H], s1);
-            s2 = fmaf(q[e + 2], wk[(size_t)(e + 2) * a.H], s2); s3 = fmaf(q[e + 3], wk[(size_t)(e + 3) * a.H], s3);
+#pragma unroll
+        for (int e0 = 0; e0 < 64; e0 += 16) {
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = wk[(size_t)(e0 + u) * a.H];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                s0 = fmaf(q[e0 + u], wv[u], s0); s1 = fmaf(q[e0 + u + 1], wv[u + 1], s1);
+                s2 = fmaf(q[e0 + u + 2], wv[u + 2], s2); s3 = fmaf(q[e0 + u + 3], wv[u + 3], s3);
+            }
         }
         a.r[((size_t)b * a.heads + h) * a.H + c] = (s0 + s1) + (s2 + s3);
     }
@@ -100,13 +141,13 @@ __global__ __launch_bounds__(256) void lf_global_out_kernel(LfGArgs a) {
     for (int k = threadIdx.x; k < a.H; k += 256) sm[k] = a.y[bh * a.H + k];
     __syncthreads();
     const float spv = a.sp[bh];
-    for (int e = w * 16; e < w * 16 + 16; e += 4) {
+    for (int e = w * 16; e < w * 16 + 16; e += 8) {
         const int row = h * 64 + e;
-        float v[4];
-        wave_dot4_lds(a.Wv + (size_t)row * a.H, a.H, sm, l, v);
+        float v[8];
+        wave_dot8_lds(a.Wv + (size_t)row * a.H, a.H, sm, l, v);
         if (l == 0)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) st_any(a.ctx, (size_t)b * a.L * a.H + row + j, v[j] + a.bv[row + j] * spv, a.ctx_dtype);
+            for (int j = 0; j < 8; ++j) st_any(a.ctx, (size_t)b * a.L * a.H + row + j, v[j] + a.bv[row + j] * spv, a.ctx_dtype);
     }
 }
 

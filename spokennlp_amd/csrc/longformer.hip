@@ -88,6 +88,37 @@ __global__ __launch_bounds__(256) void lf_softmax_fwd_kernel(float* __restrict__
     __shared__ float red[4];
     const size_t row = blockIdx.x;
     float* sr = s_p + row * L;
+    if (L <= 256 * 16) {
+        // the row in registers: ONE round of loads (the three passes over global memory were three dependent round trips per 256 elements,
+        // 13-16 us for an 8-KB row in the forward chain of every Longformer layer).  Same per-thread element order, same reductions.
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int j = threadIdx.x + u * 256; v[u] = j < L ? sr[j] : -INFINITY; }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mx = fmaxf(mx, v[u]);
+        mx = block_reduce(mx, red, true);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int j = threadIdx.x + u * 256; if (j < L) { v[u] = __expf(v[u] - mx); sum += v[u]; } }
+        sum = block_reduce(sum, red, false);
+        const float inv = 1.f / sum;
+        float sd = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = threadIdx.x + u * 256;
+            if (j < L) {
+                const float p = v[u] * inv;
+                sr[j] = p;
+                const float q = (!thresh || drop_keep(seed, row * L + j, thresh)) ? p * inv_keep : 0.f;
+                pd[row * L + j] = q;
+                sd += q;
+            }
+        }
+        sd = block_reduce(sd, red, false);
+        if (threadIdx.x == 0) sp[row] = sd;
+        return;
+    }
     float mx = -INFINITY;
     for (int j = threadIdx.x; j < L; j += 256) mx = fmaxf(mx, sr[j]);
     mx = block_reduce(mx, red, true);
@@ -190,7 +221,15 @@ __global__ void lf_wsum_reduce_kernel(const float* __restrict__ part, float* __r
     if (gid >= total) return;
     const int b = gid / n, i = gid % n;
     float s = 0.f;
-    for (int g = 0; g < nseg; ++g) s += part[((size_t)b * nseg + g) * n + i];
+    int g = 0;
+    for (; g + 8 <= nseg; g += 8) {                         // eight partial rows in flight (same order of additions)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[((size_t)b * nseg + g + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; g < nseg; ++g) s += part[((size_t)b * nseg + g) * n + i];
     y[gid] = s;
 }
 
@@ -270,18 +309,29 @@ __global__ __launch_bounds__(256) void lf_rowvec_dot_mfma_kernel(const bf16_t* _
     const float* vp = vec + ((size_t)b * heads + (i16 < heads ? i16 : 0)) * H + g * 8;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int nk = H / 32;
-    for (int kk = 0; kk < nk; ++kk) {
-        const bf16x8 fx = *reinterpret_cast<const bf16x8*>(xp + kk * 32);
-        float v[8];
-        ld8<float>(vp + kk * 32, v);
-        if (i16 >= heads) {
+    // k-steps in batches of 8 with every load of a batch in flight together: the rolled loop paid one memory round trip per k-step
+    // (24 in a row at H = 768: 20-38 us for 12 MB, on the critical path of every Longformer layer; round 4)
+    for (int kb = 0; kb < nk; kb += 8) {
+        bf16x8 fx[8];
+        float v[8][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        }
-        bf16x8 hi, lo;
-        split_bf16(v, hi, lo);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, hi, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, lo, acc, 0, 0, 0);
+        for (int u = 0; u < 8; ++u)
+            if (kb + u < nk) {
+                fx[u] = *reinterpret_cast<const bf16x8*>(xp + (kb + u) * 32);
+                ld8<float>(vp + (kb + u) * 32, v[u]);
+            }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (kb + u < nk) {
+                if (i16 >= heads) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
+                }
+                bf16x8 hi, lo;
+                split_bf16(v[u], hi, lo);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[u], hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[u], lo, acc, 0, 0, 0);
+            }
     }
     if (i16 < heads) {                         // lane: head i16, tokens j0 + g*4 .. +4
         const int j = j0 + g * 4;
