@@ -8,9 +8,9 @@ OUT=gpurun_out/${TAG}_pmc_instep.txt
 : > $OUT
 for CTR in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_${CTR}
-  rocprofv3 --kernel-trace --pmc $CTR -d /tmp/pmc_${CTR} -o run -- python bench.py --no-cpu-baseline --no-via-trainer --no-roofline --steps 4 --warmup 2 > /dev/null 2> gpurun_out/${TAG}_pmc_${CTR}.err
+  rocprofv3 --kernel-trace --pmc $CTR -d /tmp/pmc_${CTR} -o run -- python bench.py --no-cpu-baseline --no-via-trainer --no-roofline --no-extra-legs --steps 4 --warmup 2 > /dev/null 2> gpurun_out/${TAG}_pmc_${CTR}.err
   DB=$(find /tmp/pmc_${CTR} -name "*.db" | head -1)
   echo "## pass: --pmc $CTR (python bench.py --steps 4 --warmup 2: 6 real training steps)" >> $OUT
-  python tools/pmc_summary.py "$DB" | grep -E "gemm_nt_dp|gemm_tn_dp|attn_|^\| kernel|^\|---" >> $OUT
+  python tools/pmc_summary.py "$DB" | grep -E "gemm_nt_dp|gemm_tn_dp|attn_|ln_bwd|add_ln_fwd|adamw|^\| kernel|^\|---" >> $OUT
 done
 cat $OUT
