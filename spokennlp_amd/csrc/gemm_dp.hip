@@ -80,9 +80,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     // SGPR base + 32-bit lane byte offset: no VALU address arithmetic where the pieces are issued
 #define DP_DMA_A(s, i, kt) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
         amdseg_glds16_saddr(pA + (kt) * 64, offA[(i) * 2 + q], DP_TILE_A(s, wr * 2 + (i)) + (wq * 2 + q) * 1024);
+#ifdef AMDSEG_ABL_NO_B     // timing probe (wrong results): the B operand costs nothing -- no LDS-DMA pieces, no fragment reads for it
+#define DP_DMA_B(s, kt)
+#define DP_WAIT_TILE() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+#else
 #define DP_DMA_B(s, kt) _Pragma("unroll") for (int i = 0; i < 2; ++i) if (i == 0 || b2) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
         amdseg_glds16_saddr(pB + (kt) * 64, offB[i * 2 + q], DP_TILE_B(s, wr * 2 + i) + (wq * 2 + q) * 1024);
 #define DP_WAIT_TILE() do { if (vm8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
+#endif
     f32x4 acc[8][NF];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -138,6 +143,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         fa[f][kk] = *reinterpret_cast<const bf16x8*>(la_[S][kk] + (h) * 8192 + f * 2048);
 #define DP_LOAD_B_U(S) _Pragma("unroll") for (int e = 0; e < NF; ++e) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
         fb[e][kk] = *reinterpret_cast<const bf16x8*>(lb_[S][kk] + (e >> 1) * 4096 + (e & 1) * 512);
+#ifdef AMDSEG_ABL_NO_B
+#undef DP_LOAD_B
+#undef DP_LOAD_B_U
+#define DP_LOAD_B(s)
+#define DP_LOAD_B_U(S)
+#endif
 #define DP_MFMA(ah) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int f = 0; f < 4; ++f) \
         _Pragma("unroll") for (int e = 0; e < NF; ++e) \
         acc[(ah) * 4 + f][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[e][kk], fa[f][kk], acc[(ah) * 4 + f][e], 0, 0, 0);
