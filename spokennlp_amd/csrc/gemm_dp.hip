@@ -158,16 +158,21 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     // of K tile kt-1, retired before that phase's barrier).  phase 2: rows 64-127; DMA: rows-0..63 image + this group's two B images of K tile
     // kt+2 into THIS stage (their last readers -- this group's phase 1 and the other group's phase 1, one slot later -- have retired their reads).
     // (All 6 pieces of phase 2 stay in its load half: issuing the B pieces among the MFMAs measured slower, profiles/r04_gemm_dma_placement.md.)
+#ifdef AMDSEG_ABL_NO_DMA   // timing probe (wrong results): no LDS-DMA issue inside the K loop -- what the compute waves would take if OTHER waves did the loading
+#define DP_LOOP_DMA(x)
+#else
+#define DP_LOOP_DMA(x) x
+#endif
 #define DP_KTILE(kt, S, LDA, LDB) { \
         LDB(S) LDA(S, 0) \
-        if ((kt) >= DP_KT0 && (kt) + 1 < nk) { DP_DMA_A((S) ^ 1, 1, (kt) + 1) } \
+        if ((kt) >= DP_KT0 && (kt) + 1 < nk) { DP_LOOP_DMA(DP_DMA_A((S) ^ 1, 1, (kt) + 1)) } \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         if ((kt) >= DP_KT0 && (kt) + 1 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         DP_MID(); \
         DP_MFMA(0) \
         DP_END(); \
         LDA(S, 1) \
-        if ((kt) + 2 < nk) { DP_DMA_A(S, 0, (kt) + 2) DP_DMA_B(S, (kt) + 2) } \
+        if ((kt) + 2 < nk) { DP_LOOP_DMA(DP_DMA_A(S, 0, (kt) + 2) DP_DMA_B(S, (kt) + 2)) } \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         if ((kt) + 2 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         DP_MID(); \
