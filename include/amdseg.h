@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 8   /* 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_gemm_nt_bias_drop_res, amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 9   /* 9: amdseg_heads_bwd_rows takes n_feat / fix / fix_bytes (order-independent scatter sums), amdseg_scatter_rows_sorted; 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_gemm_nt_bias_drop_res, amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -227,6 +227,12 @@ int amdseg_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64
 int amdseg_embed_bwd(const void* dz, const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, float* dword,
                      float* dpos, float* dtype_emb, int M, int L, int H, int vocab, int type_vocab, int npos, int pad_id,
                      int dtype, amdseg_stream_t stream);
+/* the same scatter for ONE table without atomics (ABI 9; the engine's deterministic mode): table[keys[r]] += dz[r] for every row r with
+   0 <= keys[r] < nrows and keys[r] != skip_key (-1: none), where `order` [M] is a STABLE argsort of keys (torch.sort(keys, stable=True)).
+   The rows of one key are summed front to back by one workgroup per 256 columns and added with a plain store: bit-reproducible.
+   amdseg_embed_bwd with vocab == 0 / npos == 0 leaves the word / position table to this call. */
+int amdseg_scatter_rows_sorted(const void* dz, const int64_t* keys, const int64_t* order, float* table, int M, int H, int nrows,
+                               long skip_key, int dtype, amdseg_stream_t stream);
 /* z = resid + dropout(y) (written over y), out = LayerNorm(z)   ([hf] modeling_bert.py:282-293, 340-351).
  * resid == NULL (ABI 8): y_inout_z already holds z (amdseg_gemm_nt_bias_drop_res) -- LayerNorm only, y_inout_z is not written, dropout_p ignored */
 int amdseg_add_ln_fwd(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out, float* mean,
@@ -368,7 +374,10 @@ int amdseg_lf_dx_apply(void* dx, int ldx, const float* coefA, const float* coefB
  *          feat_off -> seq row of feature f; anchor_off -> feature index of anchor i (-1: anchor i = feature i); lists_off ->
  *          [n_list][n_anchor] feature indices (the first pk lists are the positives); t_rows_off / t_labels_off -> TSSP rows / classes.
  * Backward: amdseg_heads_bwd_ce writes dlogits [M,C] = d total / d logits * gout[0]; the caller runs amdseg_rowdot_bwd on it (which WRITES
- * dx [M,H]); amdseg_heads_bwd_rows then ADDS the CSSL / TSSP row gradients into dx and ACCUMULATES dWt [Ct,H], dbt [Ct]. */
+ * dx [M,H]); amdseg_heads_bwd_rows then ADDS the CSSL / TSSP row gradients into dx and ACCUMULATES dWt [Ct,H], dbt [Ct].  These are scatter
+ * sums (a feature row sits in the lists of many anchors); they are taken as 64-bit fixed-point integers (2^-40 units) in `fix` -- caller-owned
+ * scratch of >= 8 * ((n_feat + nt) * H + Ct * H + Ct) bytes, n_feat = number of CSSL feature rows (entries at feat_off); zeroed by the call --
+ * and added to their destinations by one writer each, so the gradients do not depend on the order the atomics land in. */
 int amdseg_heads_fwd(const float* x, int M, int H, const float* logits, const int64_t* labels, const float* class_w, int C, int nseg,
                      float* ce_unit, float* out8, float* acc, const int64_t* idx, long feat_off, long anchor_off, long lists_off,
                      int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off, long t_labels_off,
@@ -387,7 +396,8 @@ int amdseg_heads_bwd_ce_focal(const float* gout, int M, int C, int nseg, const f
                               float* dlogits, amdseg_stream_t stream);
 int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float* dx, const int64_t* idx, long feat_off, long anchor_off,
                           long lists_off, int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
-                          long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, amdseg_stream_t stream);
+                          long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, int n_feat, void* fix,
+                          size_t fix_bytes, amdseg_stream_t stream);
 
 /* NOTE on additive key masks (`mask_bias` of every attention entry point): 0 for visible keys, a MODERATE negative number for masked ones
  * (the host mirror uses -30000; the kernels fold mask and log-sum-exp into the fp32 MFMA accumulator start, so a magnitude like 1e30

@@ -376,14 +376,14 @@ class TopicSegHeadsMixin:
         up, req = _IndexUploader(seq.device), _RowRequests()
         pos, lab = self._labelled_rows(host["labels"][:, 0])
         P = dict(nseg=2 if two_pass else 1, feat_off=0, anchor_off=-1, lists_off=0, n_anchor=0, n_list=0, pk=1, temp=float(cfg.cl_temp) or 1.0,
-                 t_rows_off=0, t_labels_off=0, nt=0, w_ts=float(cfg.ts_loss_weight), w_cl=float(cfg.cl_loss_weight),
+                 n_feat=0, t_rows_off=0, t_labels_off=0, nt=0, w_ts=float(cfg.ts_loss_weight), w_cl=float(cfg.cl_loss_weight),
                  gamma=float(cfg.focal_loss_gamma),
                  w_tssp2=float(cfg.tssp_loss_weight) ** 2)
         if cfg.cl_loss_weight != 0:
             cp = self._plan_cssl(up, req, pos, lab, Lq, 0)                  # same `random` call order as the reference (cssl.py:118-228)
             if cp is not None:
                 s0, n = cp["rows"]
-                P["feat_off"] = up.add(req.rows[s0:s0 + n])[0]
+                P["feat_off"], P["n_feat"] = up.add(req.rows[s0:s0 + n])[0], n
                 P["lists_off"] = cp["lists"][0]
                 P["n_list"], P["pk"] = cp["nlists"], int(cfg.cl_positive_k)
                 if cp["anchors"] is None:

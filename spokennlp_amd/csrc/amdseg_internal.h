@@ -23,6 +23,8 @@ int amdseg_embed_ln_fwd_impl(const int64_t* ids, const int64_t* type_ids, const 
                              const float* type, const float* gamma, const float* beta, void* z, void* out, float* mean,
                              float* rstd, int M, int L, int H, int vocab, int type_vocab, int npos,
                              const int64_t* pos_ids, float eps, float p, uint64_t seed, int dtype, hipStream_t s);
+int amdseg_scatter_rows_sorted_impl(const void* dz, const int64_t* keys, const int64_t* order, float* table, int M, int H, int nrows,
+                                    long skip_key, int dtype, hipStream_t s);
 int amdseg_embed_bwd_impl(const void* dz, const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
                           float* dword, float* dpos, float* dtype_emb, int M, int L, int H, int vocab, int type_vocab,
                           int npos, int pad_id, int dtype, hipStream_t s);
@@ -157,7 +159,8 @@ int amdseg_heads_bwd_ce_impl(const float* gout, int M, int C, int nseg, const fl
                              hipStream_t s, float focal_gamma = 0.f);
 int amdseg_heads_bwd_rows_impl(const float* gout, const float* x, int M, int H, float* dx, const int64_t* idx, long feat_off, long anchor_off,
                                long lists_off, int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
-                               long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, hipStream_t s);
+                               long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, int n_feat, void* fix,
+                               size_t fix_bytes, hipStream_t s);
 
 // lf_global.hip
 int amdseg_lf_global_q_impl(const void* x, int x_dtype, const float* Wq, const float* bq, const float* Wk, float* qg, float* r, int B, int L,

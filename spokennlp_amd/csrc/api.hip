@@ -134,6 +134,10 @@ int amdseg_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64
     return amdseg_embed_ln_fwd_impl(ids, type_ids, word, pos, type, gamma, beta, z, out, mean, rstd, M, L, H, vocab, type_vocab,
                                     npos, pos_ids, eps, dropout_p, seed, dtype, S(stream));
 }
+int amdseg_scatter_rows_sorted(const void* dz, const int64_t* keys, const int64_t* order, float* table, int M, int H, int nrows,
+                               long skip_key, int dtype, amdseg_stream_t stream) {
+    return amdseg_scatter_rows_sorted_impl(dz, keys, order, table, M, H, nrows, skip_key, dtype, S(stream));
+}
 int amdseg_embed_bwd(const void* dz, const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, float* dword,
                      float* dpos, float* dtype_emb, int M, int L, int H, int vocab, int type_vocab, int npos, int pad_id,
                      int dtype, amdseg_stream_t stream) {
@@ -340,9 +344,10 @@ int amdseg_heads_bwd_ce_focal(const float* gout, int M, int C, int nseg, const f
 }
 int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float* dx, const int64_t* idx, long feat_off, long anchor_off,
                           long lists_off, int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
-                          long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, amdseg_stream_t stream) {
+                          long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, int n_feat, void* fix,
+                          size_t fix_bytes, amdseg_stream_t stream) {
     return amdseg_heads_bwd_rows_impl(gout, x, M, H, dx, idx, feat_off, anchor_off, lists_off, n_anchor, n_list, pk, temp, Wt, bt, t_rows_off,
-                                      t_labels_off, nt, Ct, dWt, dbt, w_cl, w_tssp2, S(stream));
+                                      t_labels_off, nt, Ct, dWt, dbt, w_cl, w_tssp2, n_feat, fix, fix_bytes, S(stream));
 }
 
 int amdseg_gemm_nt_bias_drop_res(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,

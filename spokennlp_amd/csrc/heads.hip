@@ -31,7 +31,30 @@ struct HeadsArgs {
     // backward
     const float* gout; float* dx; float* dWt; float* dbt; float* dlogits;
     float* row_loss;       // forward scratch: per-anchor CSSL terms [n_anchor] followed by per-row TSSP terms [nt]
+    // backward scatter target: fixed-point sums, [n_feat][H] CSSL feature rows | [nt][H] TSSP rows | [Ct][H] dWt | [Ct] dbt
+    unsigned long long* fix; int n_feat;
 };
+
+// The row gradients of CSSL / TSSP are scatter sums (a feature row sits in the lists of many anchors; dWt sums over every TSSP row).
+// Float atomics would make their value depend on the arrival order; the contributions are instead rounded to 2^-40 and summed as 64-bit
+// integers -- integer addition commutes, so the sums (and with them the step) are bit-reproducible -- and converted back by the single
+// writer of each destination (heads_fix_apply_kernel).  |contribution| < 2^23 by a wide margin (these are loss gradients of O(1) rows).
+#define HEADS_FIX_SCALE 1099511627776.0f            // 2^40
+__device__ __forceinline__ void fix_add(unsigned long long* p, float v) {
+    atomicAdd(p, (unsigned long long)__float2ll_rn(v * HEADS_FIX_SCALE));
+}
+// dst[(rows ? rows[slot] : slot)][d] += fix[slot][d] * 2^-40; one wave per slot, each destination element has one writer per launch
+__global__ __launch_bounds__(256) void heads_fix_apply_kernel(const unsigned long long* fix, const int64_t* rows, int n, int H, float* dst) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + w;
+    if (i >= n) return;
+    float* o = dst + (size_t)(rows ? rows[i] : i) * H;
+    const unsigned long long* f = fix + (size_t)i * H;
+    for (int d = l; d < H; d += 64) {
+        const long long q = (long long)f[d];
+        if (q) o[d] += (float)((double)q * (1.0 / 1099511627776.0));
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------- token cross-entropy
 // one thread per row; per-wave (num, den) partials per segment, summed in a fixed order by the finalize kernel (no atomics: the loss
@@ -128,19 +151,19 @@ __global__ __launch_bounds__(256) void heads_cssl_kernel(HeadsArgs a) {
     }
     // d loss_i / d cos_k = inv_temp * (e_k / sall - [k < pk] e_k / spos) / n ; chain through the cosine into both rows
     const float g = a.gout[0] * a.w_cl / (float)a.n_anchor * a.inv_temp;
-    float* dxa = a.dx + (size_t)ra * a.H;
+    unsigned long long* dxa = a.fix + (size_t)fa * a.H;
 #pragma unroll
     for (int k = 0; k < HEADS_MAXLIST; ++k) {
         if (k >= a.n_list) break;
         const float dc = g * (e[k] / sall - (k < a.pk ? e[k] / spos : 0.f));
-        const int64_t ro = a.feat_rows[a.lists[(size_t)k * a.n_anchor + i]];
-        const float* xo = a.x + (size_t)ro * a.H;
-        float* dxo = a.dx + (size_t)ro * a.H;
+        const int64_t fo = a.lists[(size_t)k * a.n_anchor + i];
+        const float* xo = a.x + (size_t)a.feat_rows[fo] * a.H;
+        unsigned long long* dxo = a.fix + (size_t)fo * a.H;
         const float ca = dc / (na * no[k]), cva = dc * cs[k] / (na * na), cvo = dc * cs[k] / (no[k] * no[k]);
         for (int d = l; d < a.H; d += 64) {
             const float va = xa[d], vo = xo[d];
-            atomicAdd(dxa + d, ca * vo - cva * va);
-            atomicAdd(dxo + d, ca * va - cvo * vo);
+            fix_add(dxa + d, ca * vo - cva * va);
+            fix_add(dxo + d, ca * va - cvo * vo);
         }
     }
 }
@@ -176,18 +199,19 @@ __global__ __launch_bounds__(256) void heads_tssp_kernel(HeadsArgs a) {
     float dl[HEADS_MAXC];
 #pragma unroll
     for (int c = 0; c < HEADS_MAXC; ++c) if (c < a.Ct) dl[c] = g * (expf(lg[c] - lse) - (c == y ? 1.0f : 0.0f));
-    float* dxr = a.dx + (size_t)r * a.H;
+    unsigned long long* dxr = a.fix + (size_t)(a.n_feat + i) * a.H;       // this row's own slot: a plain store would do, kept uniform
+    unsigned long long* dW = a.fix + (size_t)(a.n_feat + a.nt) * a.H;
     for (int d = l; d < a.H; d += 64) {
         const float xv = xr[d];
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < HEADS_MAXC; ++c)
-            if (c < a.Ct) { acc += dl[c] * a.Wt[(size_t)c * a.H + d]; atomicAdd(a.dWt + (size_t)c * a.H + d, dl[c] * xv); }
-        atomicAdd(dxr + d, acc);          // a [BOS] row is also an anchor / list row of the other heads
+            if (c < a.Ct) { acc += dl[c] * a.Wt[(size_t)c * a.H + d]; fix_add(dW + (size_t)c * a.H + d, dl[c] * xv); }
+        fix_add(dxr + d, acc);
     }
     if (l == 0)
 #pragma unroll
-        for (int c = 0; c < HEADS_MAXC; ++c) if (c < a.Ct) atomicAdd(a.dbt + c, dl[c]);
+        for (int c = 0; c < HEADS_MAXC; ++c) if (c < a.Ct) fix_add(dW + (size_t)a.Ct * a.H + c, dl[c]);
 }
 
 // ---------------------------------------------------------------------------------------------------- combine / CE backward
@@ -305,15 +329,31 @@ int amdseg_heads_bwd_ce_impl(const float* gout, int M, int C, int nseg, const fl
 }
 int amdseg_heads_bwd_rows_impl(const float* gout, const float* x, int M, int H, float* dx, const int64_t* idx, long feat_off, long anchor_off,
                                long lists_off, int n_anchor, int n_list, int pk, float temp, const float* Wt, const float* bt, long t_rows_off,
-                               long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, hipStream_t s) {
-    if (!gout || !x || !dx) return AMDSEG_ERR_ARG;
+                               long t_labels_off, int nt, int Ct, float* dWt, float* dbt, float w_cl, float w_tssp2, int n_feat, void* fix,
+                               size_t fix_bytes, hipStream_t s) {
+    if (!gout || !x || !dx || !fix) return AMDSEG_ERR_ARG;
+    if (n_anchor <= 0) n_feat = 0;
+    if (nt < 0 || n_feat < 0 || (n_anchor > 0 && n_feat < 1)) return AMDSEG_ERR_ARG;
+    const size_t fix_elems = (size_t)(n_feat + nt) * H + (nt > 0 ? (size_t)Ct * H + Ct : 0);
+    if (fix_bytes < fix_elems * sizeof(unsigned long long)) return AMDSEG_ERR_ARG;
     if (M <= 0 || H <= 0 || (H % 4)) return AMDSEG_ERR_SHAPE;
     HeadsArgs a = heads_fill(x, M, H, nullptr, nullptr, nullptr, 1, 1, nullptr, nullptr, idx, feat_off, anchor_off, lists_off, n_anchor, n_list,
                              pk, temp, Wt, bt, t_rows_off, t_labels_off, nt, Ct, 0.f, w_cl, w_tssp2);
     if (n_anchor > 0 && (!a.feat_rows || !a.lists || n_list < 1 || n_list > HEADS_MAXLIST || pk < 1 || pk > n_list)) return AMDSEG_ERR_ARG;
     if (nt > 0 && (!Wt || !bt || !dWt || !dbt || Ct < 1 || Ct > HEADS_MAXC)) return AMDSEG_ERR_ARG;
-    a.gout = gout; a.dx = dx; a.dWt = dWt; a.dbt = dbt;
+    a.gout = gout; a.dx = dx; a.dWt = dWt; a.dbt = dbt; a.fix = (unsigned long long*)fix; a.n_feat = n_feat;
+    if (fix_elems == 0) return AMDSEG_OK;
+    if (hipMemsetAsync(fix, 0, fix_elems * sizeof(unsigned long long), s) != hipSuccess) return AMDSEG_ERR_LAUNCH;
     if (n_anchor > 0) hipLaunchKernelGGL(heads_cssl_kernel<true>, dim3((n_anchor + 3) / 4), dim3(256), 0, s, a);
     if (nt > 0) hipLaunchKernelGGL(heads_tssp_kernel<true>, dim3((nt + 3) / 4), dim3(256), 0, s, a);
+    // the feature rows of one head are distinct, but a row may serve both heads: one launch per head keeps every dx element single-writer
+    if (n_anchor > 0)
+        hipLaunchKernelGGL(heads_fix_apply_kernel, dim3((n_feat + 3) / 4), dim3(256), 0, s, a.fix, a.feat_rows, n_feat, H, dx);
+    if (nt > 0) {
+        const unsigned long long* ft = a.fix + (size_t)n_feat * H;
+        hipLaunchKernelGGL(heads_fix_apply_kernel, dim3((nt + 3) / 4), dim3(256), 0, s, ft, a.t_rows, nt, H, dx);
+        hipLaunchKernelGGL(heads_fix_apply_kernel, dim3((Ct + 3) / 4), dim3(256), 0, s, ft + (size_t)nt * H, (const int64_t*)nullptr, Ct, H, dWt);
+        hipLaunchKernelGGL(heads_fix_apply_kernel, dim3(1), dim3(256), 0, s, ft + (size_t)nt * H + (size_t)Ct * H, (const int64_t*)nullptr, 1, Ct, dbt);
+    }
     return amdseg_launch_status();
 }

@@ -182,6 +182,12 @@ class BertEncoderEngine:
         # hidden-state dropout: the forward's add + LayerNorm kernels keep their decisions (1 byte per 8 elements, acts.drop1 / drop2) and the
         # LayerNorm backward reads them instead of re-hashing (every encoder family: the row kernels are shared); AMDSEG_HIDDEN_KEEPBITS=0 = hash twice
         self.hidden_keepbits = _os.environ.get("AMDSEG_HIDDEN_KEEPBITS", "1") != "0"
+        # bit-reproducible training steps: the word (and explicit position) embedding gradients are summed over a stable sort of the ids
+        # (amdseg_scatter_rows_sorted) instead of scattered with fp32 atomics -- the only order-dependent sums of a BERT / Longformer step (the loss
+        # heads accumulate in fixed point, every column sum goes through partials added in a fixed order).  config.amdseg_deterministic or
+        # AMDSEG_DETERMINISTIC=1; off by default (the sort costs a few launches per step).  Not covered: token-type ids other than 0 mixed in
+        # one batch (their table rows are still atomics) and the PoNet pooling backward (csrc/ponet.hip merges run pieces with atomics).
+        self.deterministic = bool(getattr(self.cfg, "amdseg_deterministic", False)) or _os.environ.get("AMDSEG_DETERMINISTIC", "0") == "1"
         self._arena_slot = 0
         self.max_live_arenas = 2                            # training arenas per shape that may be alive between forward and backward
         self.grad_sync = True                               # False inside no_sync(): accumulate locally, no bucket all-reduce
@@ -785,10 +791,19 @@ class BertEncoderEngine:
             dy, other = other, dy
         pad = self.cfg.pad_token_id if getattr(self.cfg, "pad_token_id", None) is not None else -1
         pos = ctx.get("pos")
+        det = self.deterministic or bool(getattr(self.cfg, "amdseg_deterministic", False))
         rc = lib.amdseg_embed_bwd(other.data_ptr(), ctx["ids"].data_ptr(), ctx["tts"].data_ptr(), None if pos is None else pos.data_ptr(),
-                                  we.data_ptr(), pe.data_ptr(), te.data_ptr(), M, Lseq, self.H, we.shape[0],
-                                  -te.shape[0] if type0_sum else te.shape[0], pe.shape[0], pad, adt, s)
+                                  we.data_ptr(), pe.data_ptr(), te.data_ptr(), M, Lseq, self.H, 0 if det else we.shape[0],
+                                  -te.shape[0] if type0_sum else te.shape[0], 0 if (det and pos is not None) else pe.shape[0], pad, adt, s)
         L.check(rc, "amdseg_embed_bwd")
+        if det:                                     # the word (and explicit position) tables without atomics: sums over a stable sort
+            for keys, table, skip in ((ctx["ids"], we, pad), (pos, pe, -1)):
+                if keys is None:
+                    continue
+                order = torch.sort(keys.reshape(-1), stable=True)[1]
+                rc = lib.amdseg_scatter_rows_sorted(other.data_ptr(), keys.data_ptr(), order.data_ptr(), table.data_ptr(), M, self.H,
+                                                    table.shape[0], skip, adt, s)
+                L.check(rc, "amdseg_scatter_rows_sorted")
         self._embed_backward_fixup(pe, pad)
         if self.buckets is not None and self.grad_sync and not self._rest_reduced:
             self.buckets.reduce_embeddings()        # the tail bucket (the embedding tables: 94 MB of bert-base's exposed exchange) starts here
@@ -1003,10 +1018,14 @@ class FusedHeadsFn(torch.autograd.Function):
         if ctx.has_tssp:
             dWt = torch.zeros_like(Wt); dbt = torch.zeros_like(bt)
         if P["n_anchor"] > 0 or P["nt"] > 0:
+            # scatter sums as 64-bit fixed point (order independent: the step stays bit-reproducible), zeroed by the call
+            Ct = Wt.shape[0] if ctx.has_tssp else 0
+            fix = torch.empty((P["n_feat"] + P["nt"]) * H + Ct * H + Ct, dtype=torch.int64, device=x.device)
             L.check(lib.amdseg_heads_bwd_rows(g.data_ptr(), x.data_ptr(), M, H, dx.data_ptr(), idx.data_ptr(), P["feat_off"], P["anchor_off"],
                                               P["lists_off"], P["n_anchor"], P["n_list"], P["pk"], P["temp"],
                                               Wt.data_ptr() if ctx.has_tssp else None, bt.data_ptr() if ctx.has_tssp else None,
                                               P["t_rows_off"], P["t_labels_off"], P["nt"], Wt.shape[0] if ctx.has_tssp else 0,
                                               None if dWt is None else dWt.data_ptr(), None if dbt is None else dbt.data_ptr(),
-                                              P["w_cl"], P["w_tssp2"], s), "amdseg_heads_bwd_rows")
+                                              P["w_cl"], P["w_tssp2"], P["n_feat"], fix.data_ptr(), fix.numel() * 8, s),
+                    "amdseg_heads_bwd_rows")
         return dx, dWc, dbc, dWt, dbt, None, None, None, None

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("AMDSEG_LIB") or os.path.join(_HERE, "libamdseg.so")
 BF16, F32, F32S = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
 EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
@@ -81,6 +81,7 @@ _PROTOS = {
     "amdseg_ponet_pool_fwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "amdseg_ponet_pool_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "amdseg_embed_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, u64, i32, vp],
+    "amdseg_scatter_rows_sorted": [vp, vp, vp, vp, i32, i32, i32, C.c_long, i32, vp],
     "amdseg_embed_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "amdseg_add_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, i32, vp],
     "amdseg_ln_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u64, i32, i32, vp],
@@ -121,7 +122,7 @@ _PROTOS = {
                                C.c_long, C.c_long, i32, i32, f32, f32, f32, f32, vp],
     "amdseg_heads_bwd_ce_focal": [vp, i32, i32, i32, vp, vp, f32, f32, vp, vp],
     "amdseg_heads_bwd_rows": [vp, vp, i32, i32, vp, vp, C.c_long, C.c_long, C.c_long, i32, i32, i32, f32, vp, vp, C.c_long, C.c_long, i32, i32,
-                              vp, vp, f32, f32, vp],
+                              vp, vp, f32, f32, i32, vp, C.c_size_t, vp],
     "amdseg_prof_enable": [i32],
     "amdseg_prof_reset": [],
     "amdseg_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],

@@ -1,0 +1,120 @@
+"""Bit-reproducibility of the training step (the reference trains under HF `set_seed` + torch's default non-deterministic scatter kernels;
+here the order-dependent sums are removed instead):
+  * the loss heads' scatter sums (CSSL feature rows, TSSP rows / weights) are 64-bit fixed-point integer sums (csrc/heads.hip) -- always;
+  * the word / explicit-position embedding gradients are sums over a stable sort of the ids (amdseg_scatter_rows_sorted) under
+    config.amdseg_deterministic / AMDSEG_DETERMINISTIC=1 (the default scatter uses fp32 atomics, like torch's embedding backward).
+Everything else of a BERT step (column sums through partials, attention backward, AdamW, the gradient norm) has a fixed summation order."""
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+from tests.test_oracle_golden import load_case, flags_of  # noqa: E402
+from tests.test_gpu_model import build_model, to_dev  # noqa: E402
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_scatter_rows_sorted_equals_index_add_and_repeats_bitwise(dev, dtype):
+    from spokennlp_amd import lib as L
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, H, V, pad = 1000, 200, 37, 3                         # H not a multiple of 256, every key ~27 times, one key skipped, some out of range
+    dz = torch.randn(M, H, generator=g).to(dtype).to(dev)
+    keys = torch.randint(0, V, (M,), generator=g)
+    keys[::50] = -1
+    keys[7::91] = V + 2
+    keys = keys.to(dev)
+    order = torch.sort(keys, stable=True)[1]
+    adt = L.BF16 if dtype == torch.bfloat16 else L.F32
+    outs = []
+    for _ in range(2):
+        table = torch.full((V, H), 0.5, dtype=torch.float32, device=dev)
+        rc = L.load().amdseg_scatter_rows_sorted(dz.data_ptr(), keys.data_ptr(), order.data_ptr(), table.data_ptr(), M, H, V, pad, adt,
+                                                 torch.cuda.current_stream().cuda_stream)
+        L.check(rc, "amdseg_scatter_rows_sorted")
+        outs.append(table)
+    assert torch.equal(outs[0], outs[1])
+    ok = (keys >= 0) & (keys < V) & (keys != pad)
+    ref = torch.full((V, H), 0.5, dtype=torch.float64, device=dev).index_add_(0, keys[ok], dz[ok].double())
+    assert float((outs[0].double() - ref).abs().max()) < 2e-5
+    assert torch.equal(outs[0][pad], torch.full((H,), 0.5, device=dev))
+    # the summation order is the batch order of each key's rows: equal to a serial fp32 sum, bit for bit
+    k0 = int(keys[ok][0])
+    serial = torch.full((H,), 0.0, dtype=torch.float32, device=dev)
+    for r in torch.nonzero(keys == k0).flatten().tolist():
+        serial = serial + dz[r].float()
+    assert torch.equal(outs[0][k0], serial + 0.5)
+
+
+def _three_steps(dev, precision, deterministic, case="tiny_L128"):
+    if case == "bert_base_L512":                           # bert-base, 4 x 512 tokens (x 2 with the augmented half): the H = 768 kernels
+        from tests.test_gpu_fullsize import _fullsize_case
+        z, sd, batch, arch, fl = _fullsize_case()
+        flags = fl(z, "train_full")
+    else:
+        z, sd, batch, arch = load_case(case)
+        flags = flags_of(z, "train_full")
+    m = build_model(arch, flags, sd, dev, dropout=0.1)
+    m.config.amdseg_precision = precision
+    m.config.amdseg_deterministic = deterministic
+    m.train()
+    m.amdseg_seed = 11
+    random.seed(3)
+    b = to_dev(batch, dev)
+    losses = []
+    for _ in range(3):
+        loss, _, _ = m(**b)
+        loss.backward()
+        losses.append(loss.item())
+        m.engine().adamw_step(1e-3, max_grad_norm=1.0)
+    torch.cuda.synchronize()
+    eng = m.engine()
+    assert eng.deterministic == deterministic
+    return losses, eng.fp.flat_p.detach().clone(), {n: p.detach().clone() for n, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("precision,case", [("bf16", "tiny_L128"), ("parity", "tiny_L128"), ("bf16", "bert_base_L512")])
+def test_deterministic_mode_three_training_steps_are_bit_identical(dev, precision, case):
+    """two runs from the same weights, seeds and batch: dropout (stateless hash), CSSL sampling (`random`), three optimiser steps with
+    clipping -- the same bits in every parameter.  (lr 1e-3 so that three steps move every weight well above its last bit)"""
+    a = _three_steps(dev, precision, True, case)
+    b = _three_steps(dev, precision, True, case)
+    assert a[0] == b[0]
+    assert torch.equal(a[1], b[1])
+    for n, p in a[2].items():
+        assert torch.equal(p, b[2][n]), n
+    assert a[0][0] != a[0][2]                              # ... and the steps did move the model
+
+
+def test_deterministic_mode_equals_the_default_scatter_to_rounding(dev):
+    """the sorted sums and the atomics add the same numbers in another order"""
+    a = _three_steps(dev, "bf16", True)
+    b = _three_steps(dev, "bf16", False)
+    assert abs(a[0][0] - b[0][0]) == 0.0                   # the first forward does not depend on it
+    d = (a[1] - b[1]).abs().max().item()
+    assert d < 5e-3, d                                     # AdamW at lr 1e-3 amplifies last-bit gradient noise to at most ~lr per step
+
+
+def test_heads_backward_is_bit_identical_run_to_run(dev):
+    """default mode: everything upstream of the embedding tables is reproducible -- the encoder layers' and heads' gradients of two
+    backward passes over the same batch are the same bits (they were not while CSSL / TSSP scattered with fp32 atomics: the sum over the
+    anchors that list one feature row depended on the arrival order, and every layer below inherited it)."""
+    z, sd, batch, arch = load_case("tiny_L128")
+    grads = []
+    for _ in range(2):
+        m = build_model(arch, flags_of(z, "train_full"), sd, dev, dropout=0.1).train()
+        m.config.amdseg_precision = "parity"
+        m.amdseg_seed = 5
+        random.seed(9)
+        loss, _, _ = m(**to_dev(batch, dev))
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters()
+                      if p.grad is not None and "word_embeddings" not in n})
+    for n, g in grads[0].items():
+        assert torch.equal(g, grads[1][n]), n

@@ -220,10 +220,9 @@ def test_hidden_dropout_decisions_kept_by_forward_equal_the_rehashed_ones(dev, p
             assert 0.08 < rate < 0.12, rate
     assert res[True][0] == res[False][0]
     for n, g in res[False][1].items():
-        if precision == "bf16":
-            assert torch.equal(res[True][1][n], g), n
-        else:       # "parity" precision's split attention backward is reproducible to fp32 round-off only; another DECISION would move a gradient by ~1e-1 relative
-            assert float((res[True][1][n] - g).norm()) <= 1e-5 * float(g.norm()) + 1e-7, n      # (key.bias: a theoretical zero, ~1e-9 of noise)
+        # (both precisions since the loss heads stopped scattering with fp32 atomics: their arrival-order noise used to reach every layer
+        # below them, visible in fp32 activations)
+        assert torch.equal(res[True][1][n], g), n
 
 
 def test_h768_layernorm_backward_pair_kernel_equals_generic_kernel(dev):
