@@ -214,3 +214,147 @@ def topic_segment_evaluate_samples(label_samples, pred_samples):
     ws.pop("test_avg_pred_cnt"); ws.pop("test_avg_true_cnt")
     out.update(ws)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- ROUGE (extractive summarisation, 8(f)-4)
+# alimeeting4mug/metrics/extractive_summarization_eval/extractive_summarization_eval.py:167-180 and metrics/rouge/rouge.py:121-135 call
+# `rouge.Rouge().get_scores(hyps, refs, avg=True)` of the PyPI package rouge==1.0.1 (alimeeting4mug/requirements.txt:90; not in the
+# reference tree, not installed here).  What follows restates that package's published algorithm for its three default metrics.  The
+# only known answer the reference holds is the worked example in metrics/rouge/rouge.py:62-93 (the package's README example), and it is
+# not self-consistent: its rouge-l numbers are the package's `exclusive=True` counting (SETS of words -- the 1.0.1 constructor default),
+# its rouge-1 / rouge-2 numbers are `exclusive=False` counting (multisets, clipped overlap).  Both countings are restated, each pinned
+# on the numbers it reproduces to the last digit (tests/test_evaluate.py); `exclusive=True` is the default here as in the package, so
+# rouge-l is pinned and rouge-1 / rouge-2 are pinned only up to that choice.  Conventions of the package, kept as they are:
+#   * a text is cut into sentences at every "." and whitespace-normalised; n-grams run over the words of ALL sentences joined;
+#   * f = 2 p r / (p + r + 1e-8);
+#   * rouge-l is the summary-level union LCS: for every reference sentence the words of its LCS with every hypothesis sentence are
+#     collected in ONE running collection (a set / a list); r = its size / reference words, p = its size / hypothesis words
+#     (distinct words / all words).
+def _rouge_sentences(text):
+    return [" ".join(s.split()) for s in text.split(".") if len(s) > 0]
+
+
+def _rouge_words(sentences):
+    return [w for s in sentences for w in s.split(" ")]
+
+
+def _clipped_overlap(a, b):
+    """the package's list intersection: every element of a that still finds an unused equal element in b"""
+    left = {}
+    for e in b:
+        left[e] = left.get(e, 0) + 1
+    n = 0
+    for e in a:
+        if left.get(e, 0) > 0:
+            left[e] -= 1; n += 1
+    return n
+
+
+def _rouge_n(hyp, ref, n, exclusive=True):
+    if not hyp:
+        raise ValueError("Hypothesis is empty.")
+    if not ref:
+        raise ValueError("Reference is empty.")
+    hw, rw = _rouge_words(hyp), _rouge_words(ref)
+    hg = [tuple(hw[i:i + n]) for i in range(len(hw) - n + 1)]
+    rg = [tuple(rw[i:i + n]) for i in range(len(rw) - n + 1)]
+    if exclusive:
+        hs, rs = set(hg), set(rg)
+        ov, nh, nr = len(hs & rs), len(hs), len(rs)
+    else:
+        ov, nh, nr = _clipped_overlap(hg, rg), len(hg), len(rg)
+    p = ov / nh if nh else 0.0
+    r = ov / nr if nr else 0.0
+    return {"f": 2.0 * ((p * r) / (p + r + 1e-8)), "p": p, "r": r}
+
+
+def _lcs_words(x, y):
+    """the words of one longest common subsequence of x and y (in order), traced back from the corner of the length table: on a match
+    step diagonally; else up when table[i-1][j] > table[i][j-1], left otherwise (the package's tie rule -- it decides WHICH subsequence)"""
+    n, m = len(x), len(y)
+    t = [[0] * (m + 1) for _ in range(n + 1)]
+    for i in range(1, n + 1):
+        xi, ti, tp = x[i - 1], t[i], t[i - 1]
+        for j in range(1, m + 1):
+            ti[j] = tp[j - 1] + 1 if xi == y[j - 1] else (tp[j] if tp[j] > ti[j - 1] else ti[j - 1])
+    out, i, j = [], n, m
+    while i > 0 and j > 0:
+        if x[i - 1] == y[j - 1]:
+            out.append(x[i - 1]); i -= 1; j -= 1
+        elif t[i - 1][j] > t[i][j - 1]:
+            i -= 1
+        else:
+            j -= 1
+    return out[::-1]
+
+
+def _rouge_l(hyp, ref, exclusive=True):
+    if not hyp or not ref:
+        raise ValueError("Collections must contain at least 1 sentence.")
+    rw_all, hw_all = _rouge_words(ref), _rouge_words(hyp)
+    m, n = (len(set(rw_all)), len(set(hw_all))) if exclusive else (len(rw_all), len(hw_all))
+    union_set, union_len = set(), 0
+    for rs in ref:
+        rw = rs.split(" ")
+        for hs in hyp:
+            lcs = _lcs_words(rw, hs.split(" "))
+            union_set.update(lcs); union_len += len(lcs)
+    llcs = len(union_set) if exclusive else union_len
+    r, p = llcs / m, llcs / n
+    return {"f": 2.0 * ((p * r) / (p + r + 1e-8)), "p": p, "r": r}
+
+
+def rouge_get_scores(hyps, refs, avg=False, exclusive=True):
+    """rouge.Rouge(exclusive=...).get_scores: per pair {"rouge-1" | "rouge-2" | "rouge-l": {"f", "p", "r"}}; avg=True: the mean over pairs"""
+    if isinstance(hyps, str):
+        hyps, refs = [hyps], [refs]
+    assert len(hyps) == len(refs)
+    per = []
+    for h, r in zip(hyps, refs):
+        hs, rs = _rouge_sentences(h), _rouge_sentences(r)
+        per.append({"rouge-1": _rouge_n(hs, rs, 1, exclusive), "rouge-2": _rouge_n(hs, rs, 2, exclusive), "rouge-l": _rouge_l(hs, rs, exclusive)})
+    if not avg:
+        return per
+    return {m: {s: sum(x[m][s] for x in per) / len(per) for s in ("r", "p", "f")} for m in ("rouge-1", "rouge-2", "rouge-l")}
+
+
+def rouge_compute(predictions, references, use_avg=True):
+    """`Seqeval.rouge_compute` / `Rouge._compute` of the reference (extractive_summarization_eval.py:167-180): predictions / references
+    are lists of sentence lists; each is joined with blanks, scored, and flattened to {"score": rouge-1 f, "rouge-1_r": ..}"""
+    scores = rouge_get_scores([" ".join(p) for p in predictions], [" ".join(r) for r in references], avg=use_avg)
+    result = {"score": scores["rouge-1"]["f"]}
+    for k1 in scores:
+        for k2 in scores[k1]:
+            result["{}_{}".format(k1, k2)] = scores[k1][k2]
+    return result
+
+
+def es_rouge_metrics(documents, tokenize_func=lambda s: s.split(), key_label="B-EOP"):
+    """the ROUGE part of the extractive-summarisation `compute_metrics`
+    (alimeeting4mug/src/extractive_summarization/ponet_extractive_summarization.py:904-957).
+    documents: [{"sentences": [str], "labels": [str], "predictions": [str], "multi_labels": [[str]] (optional)}] per document, as glued
+    back from the windows (preprocess.es_collect_predictions).  Selected sentences are tokenised and joined; an empty selection is the
+    one-blank summary [" "] as in the reference.  Returns the single-reference scores plus, when multi_labels are given, the
+    `multi-ref-average_*` (mean over a document's references, then over documents) and `multi-ref-max_*` (the reference with the best
+    rouge-l f per document) entries."""
+    preds, refs = [], []
+    for d in documents:
+        ps = [" ".join(tokenize_func(s)) for s, p in zip(d["sentences"], d["predictions"]) if p == key_label] or [" "]
+        ls = [" ".join(tokenize_func(s)) for s, l in zip(d["sentences"], d["labels"]) if l == key_label] or [" "]
+        preds.append(ps); refs.append(ls)
+    out = rouge_compute(preds, refs)
+    if documents and all("multi_labels" in d for d in documents):
+        ave_all, max_all = [], []
+        for d, pred in zip(documents, preds):
+            multi = []
+            for ref in d["multi_labels"]:
+                assert len(ref) == len(d["sentences"])
+                rs = [" ".join(tokenize_func(s)) for s, l in zip(d["sentences"], ref) if l == key_label] or [" "]
+                multi.append(rouge_compute([pred], [rs]))
+            best = max(multi, key=lambda x: x["rouge-l_f"])
+            max_all.append(best)
+            ave_all.append({k: sum(m[k] for m in multi) / len(multi) for k in best})
+        for k in max_all[0]:
+            out["multi-ref-average_{}".format(k)] = sum(a[k] for a in ave_all) / len(ave_all)
+            out["multi-ref-max_{}".format(k)] = sum(a[k] for a in max_all) / len(max_all)
+    return out

@@ -144,3 +144,76 @@ def test_alimeeting_window_metric_is_strict_like_its_reference():
     assert E.compute_window_metric(bad_p, bad_r)["1-pk"] == E.compute_window_metric(good_p, good_r)["1-pk"]   # emnlp2023: dropped silently
     with pytest.raises(ValueError):
         E.compute_window_metric_alimeeting([], [])
+
+
+# ---------------------------------------------------------------------------------------------------- ROUGE (8(f)-4)
+# the worked example the reference holds: alimeeting4mug/metrics/rouge/rouge.py:62-93 (inputs and the nine expected numbers; data)
+_ROUGE_HYP = ("the #### transcript is a written version of each day 's cnn student news program use this transcript to he    lp students with "
+              "reading comprehension and vocabulary use the weekly newsquiz to test your knowledge of storie s you     saw on cnn student news")
+_ROUGE_REF = ("this page includes the show transcript use the transcript to help students with reading comprehension and     vocabulary at the "
+              "bottom of the page , comment for a chance to be mentioned on cnn student news . you must be a teac    her or a student age # # or "
+              "older to request a mention on the cnn student news roll call . the weekly newsquiz tests     students ' knowledge of even ts in the news")
+_ROUGE_EXPECTED = {"rouge-1": {"f": 0.4786324739396596, "p": 0.6363636363636364, "r": 0.3835616438356164},
+                   "rouge-2": {"f": 0.2608695605353498, "p": 0.3488372093023256, "r": 0.20833333333333334},
+                   "rouge-l": {"f": 0.44705881864636676, "p": 0.5277777777777778, "r": 0.3877551020408163}}
+
+
+def test_rouge_reproduces_the_references_worked_example():
+    """rouge-l: the package-default set counting gives the example's numbers to the last digit; rouge-1 / rouge-2: the example's
+    numbers are the multiset counting (the README example the reference copied mixes the two; evaluate.py says so)"""
+    ex = E.rouge_get_scores(_ROUGE_HYP, _ROUGE_REF)[0]
+    ne = E.rouge_get_scores(_ROUGE_HYP, _ROUGE_REF, exclusive=False)[0]
+    for s in "fpr":
+        assert ex["rouge-l"][s] == _ROUGE_EXPECTED["rouge-l"][s]
+        assert ne["rouge-1"][s] == _ROUGE_EXPECTED["rouge-1"][s]
+        assert ne["rouge-2"][s] == _ROUGE_EXPECTED["rouge-2"][s]
+    # the other counting of each differs visibly, so the match above is not an accident of the example
+    assert abs(ne["rouge-l"]["f"] - _ROUGE_EXPECTED["rouge-l"]["f"]) > 0.05
+    assert abs(ex["rouge-1"]["f"] - _ROUGE_EXPECTED["rouge-1"]["f"]) > 0.01
+
+
+def test_rouge_properties_and_the_es_metric_glue():
+    rng = random.Random(5)
+    vocab = ["w%d" % i for i in range(12)]
+    for _ in range(50):
+        h = " ".join(rng.choice(vocab + ["."]) for _ in range(rng.randint(3, 30))).strip(". ") or "w0"
+        r = " ".join(rng.choice(vocab + ["."]) for _ in range(rng.randint(3, 30))).strip(". ") or "w1"
+        for excl in (True, False):
+            a, b = E.rouge_get_scores(h, r, exclusive=excl)[0], E.rouge_get_scores(r, h, exclusive=excl)[0]
+            for m in ("rouge-1", "rouge-2"):                  # swapping the roles swaps precision and recall
+                assert abs(a[m]["p"] - b[m]["r"]) < 1e-12 and abs(a[m]["f"] - b[m]["f"]) < 1e-12
+            for m in a:                                       # (the list-counted rouge-l adds one LCS per sentence PAIR and may pass 1)
+                if excl or m != "rouge-l":
+                    assert 0.0 <= a[m]["p"] <= 1.0 + 1e-12 and 0.0 <= a[m]["r"] <= 1.0 + 1e-12
+            same = E.rouge_get_scores(h, h, exclusive=excl)[0]
+            assert abs(same["rouge-1"]["f"] - 1.0) < 1e-7 and same["rouge-1"]["p"] == 1.0
+            if excl:
+                assert same["rouge-l"]["p"] == 1.0
+    # LCS words against a brute force over subsequences
+    import itertools
+    for _ in range(30):
+        x = [rng.choice("abcd") for _ in range(rng.randint(1, 8))]
+        y = [rng.choice("abcd") for _ in range(rng.randint(1, 8))]
+        best = 0
+        for k in range(len(x), 0, -1):
+            if any(_is_subseq(c, y) for c in set(itertools.combinations(x, k))):
+                best = k
+                break
+        got = E._lcs_words(x, y)
+        assert len(got) == best and _is_subseq(got, x) and _is_subseq(got, y)
+    # the extractive-summarisation glue: selected sentences joined, empty selection = the one-blank summary
+    docs = [dict(sentences=["a b c", "d e", "f g h i"], labels=["B-EOP", "O", "B-EOP"], predictions=["B-EOP", "B-EOP", "O"],
+                 multi_labels=[["B-EOP", "O", "B-EOP"], ["O", "B-EOP", "O"]]),
+            dict(sentences=["x y", "z"], labels=["O", "O"], predictions=["O", "B-EOP"], multi_labels=[["O", "B-EOP"]])]
+    res = E.es_rouge_metrics(docs)
+    one = E.rouge_get_scores(["a b c d e", "z"], ["a b c f g h i", " "], avg=True)
+    assert res["score"] == one["rouge-1"]["f"] and res["rouge-l_r"] == one["rouge-l"]["r"]
+    assert res["multi-ref-max_rouge-1_f"] >= res["multi-ref-average_rouge-1_f"]
+    d0 = [E.rouge_compute([["a b c", "d e"]], [r]) for r in (["a b c", "f g h i"], ["d e"])]
+    d1 = E.rouge_compute([["z"]], [["z"]])
+    assert abs(res["multi-ref-average_rouge-2_p"] - ((d0[0]["rouge-2_p"] + d0[1]["rouge-2_p"]) / 2 + d1["rouge-2_p"]) / 2) < 1e-12
+
+
+def _is_subseq(c, y):
+    it = iter(y)
+    return all(any(a == b for b in it) for a in c)
