@@ -43,6 +43,11 @@ __device__ __forceinline__ void amdseg_glds16_saddr(const void* uniform_base, ui
     const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(char, lds_wave_base));
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_byte_offset), "s"(uniform_base), "s"(m) : "memory", "m0");
 }
+// ... and the LDS destination given as a wave-uniform 32-bit LDS byte address that the compiler places in m0 itself (an "s" operand built from a
+// generic pointer costs a null check -- s_cmp_lg_u64 + s_cselect -- and, when the pointer went through a VGPR, two v_readfirstlane per piece)
+__device__ __forceinline__ void amdseg_glds16_saddr_lds(const void* uniform_base, uint32_t lane_byte_offset, uint32_t lds_wave_addr) {
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_byte_offset), "s"(uniform_base), "{m0}"(lds_wave_addr) : "memory");
+}
 __device__ __forceinline__ void amdseg_glds4(const void* g, void* lds_wave_base) {
     const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(char, lds_wave_base));
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(m) : "memory", "m0");

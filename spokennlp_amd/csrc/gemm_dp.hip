@@ -78,14 +78,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
             offB[i * 2 + q] = ((i * 64 + r) * a.ldb + cb * 8) * 2;
         }
     // SGPR base + 32-bit lane byte offset: no VALU address arithmetic where the pieces are issued
+    // LDS addresses of this wave's DMA pieces as 32-bit scalars (base of the wave's duty + compile-time offsets): m0 is written by one SALU add
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+    const uint32_t ldsAw = __builtin_amdgcn_readfirstlane(lds0 + (wr * 2) * 8192 + (wq * 2) * 1024);
+    const uint32_t ldsBw = __builtin_amdgcn_readfirstlane(lds0 + (4 + wr * 2) * 8192 + (wq * 2) * 1024);
 #define DP_DMA_A(s, i, kt) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
-        amdseg_glds16_saddr(pA + (kt) * 64, offA[(i) * 2 + q], DP_TILE_A(s, wr * 2 + (i)) + (wq * 2 + q) * 1024);
+        amdseg_glds16_saddr_lds(pA + (kt) * 64, offA[(i) * 2 + q], ldsAw + (s) * STAGE + (i) * 8192 + q * 1024);
 #ifdef AMDSEG_ABL_NO_B     // timing probe (wrong results): the B operand costs nothing -- no LDS-DMA pieces, no fragment reads for it
 #define DP_DMA_B(s, kt)
 #define DP_WAIT_TILE() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
 #else
 #define DP_DMA_B(s, kt) _Pragma("unroll") for (int i = 0; i < 2; ++i) if (i == 0 || b2) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
-        amdseg_glds16_saddr(pB + (kt) * 64, offB[i * 2 + q], DP_TILE_B(s, wr * 2 + i) + (wq * 2 + q) * 1024);
+        amdseg_glds16_saddr_lds(pB + (kt) * 64, offB[i * 2 + q], ldsBw + (s) * STAGE + i * 8192 + q * 1024);
 #define DP_WAIT_TILE() do { if (vm8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
 #endif
     f32x4 acc[8][NF];
@@ -163,17 +167,31 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #else
 #define DP_LOOP_DMA(x) x
 #endif
+    // Which fragment reads have to be RETIRED before the barrier that ends a load half (round 4, second session).  A images are private to a row
+    // group and are refilled by that group two barriers after it read them -- in between lies the group's own MFMA half, which cannot issue
+    // before the data is in its registers.  The same holds for the B reads of group 0.  Group 1 reads a B image one barrier AFTER group 0 did,
+    // and group 0 issues the refill of B images 0 and 1 right behind the next barrier: only those reads need the explicit wait.  So the B reads
+    // go first and the wait in front of the first barrier is lgkmcnt(8) (everything but the 8 A reads issued last); the second load half
+    // waits for nothing (the compiler's own counted waits in front of the MFMAs order the data).  -DAMDSEG_ABL_STRICT_LGKM: the old form,
+    // lgkmcnt(0) in front of both barriers.
+#ifndef AMDSEG_ABL_LAZY_LGKM
+#define DP_LGKM_P1() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define DP_LGKM_P2() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define DP_LGKM_P1() asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory")
+#define DP_LGKM_P2() do { } while (0)
+#endif
 #define DP_KTILE(kt, S, LDA, LDB) { \
-        LDB(S) LDA(S, 0) \
+        LDB(S) __builtin_amdgcn_sched_barrier(0); LDA(S, 0) __builtin_amdgcn_sched_barrier(0); \
         if ((kt) >= DP_KT0 && (kt) + 1 < nk) { DP_LOOP_DMA(DP_DMA_A((S) ^ 1, 1, (kt) + 1)) } \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        DP_LGKM_P1(); \
         if ((kt) >= DP_KT0 && (kt) + 1 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         DP_MID(); \
         DP_MFMA(0) \
         DP_END(); \
         LDA(S, 1) \
         if ((kt) + 2 < nk) { DP_LOOP_DMA(DP_DMA_A(S, 0, (kt) + 2) DP_DMA_B(S, (kt) + 2)) } \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        DP_LGKM_P2(); \
         if ((kt) + 2 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         DP_MID(); \
         DP_MFMA(1) \
@@ -492,9 +510,17 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
     const bf16_t* pA = P.A + n0;
     const bf16_t* pB = P.B + k0;
     // piece j of this wave's DMA duty for K tile kt: j < 4 -> A image 2dr + (j >> 1), 8-row piece 2wq + (j & 1); j >= 4 -> B image dr
-#define TN_DMA_PIECE(s, kt, j) do { if ((j) < 4) amdseg_glds16_saddr(tn_uniform(pA + (size_t)(kt) * 64 * P.lda), offA[j], TN_TILE_A(s, dr * 2 + ((j) >> 1)) + (wq * 2 + ((j) & 1)) * 1024); \
-        else amdseg_glds16_saddr(tn_uniform(pB + (size_t)(kt) * 64 * P.ldb), offB[(j) - 4], TN_TILE_B(s, dr) + (wq * 2 + ((j) - 4)) * 1024); } while (0)
-#define TN_DMA(s, kt) do { _Pragma("unroll") for (int j_ = 0; j_ < 6; ++j_) TN_DMA_PIECE(s, kt, j_); } while (0)
+    // (round 4, second session) the wave-uniform parts of a K tile's six pieces are made ONCE per K tile -- the two global row bases (SGPR pairs)
+    // and the LDS address of the stage as a 32-bit scalar that the compiler adds the piece's constant to and writes to m0 -- instead of once per
+    // piece (64-bit multiplies, two v_readfirstlane and a generic-pointer null check per piece: ~60 scalar + 12 vector instructions per K tile)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+    const uint32_t ldsAw = __builtin_amdgcn_readfirstlane(lds0 + (dr * 2) * 8192 + (wq * 2) * 1024);
+    const uint32_t ldsBw = __builtin_amdgcn_readfirstlane(lds0 + 32768 + dr * 8192 + (wq * 2) * 1024);
+#define TN_DMA_SETUP(s, kt) const bf16_t* const gA_ = tn_uniform(pA + (size_t)(kt) * 64 * P.lda); const bf16_t* const gB_ = tn_uniform(pB + (size_t)(kt) * 64 * P.ldb); \
+        const uint32_t lsA_ = ldsAw + (uint32_t)(s) * TN_STG, lsB_ = ldsBw + (uint32_t)(s) * TN_STG
+#define TN_DMA_PIECE(j) do { if ((j) < 4) amdseg_glds16_saddr_lds(gA_, offA[j], lsA_ + ((j) >> 1) * 8192 + ((j) & 1) * 1024); \
+        else amdseg_glds16_saddr_lds(gB_, offB[(j) - 4], lsB_ + ((j) - 4) * 1024); } while (0)
+#define TN_DMA(s, kt) do { TN_DMA_SETUP(s, kt); _Pragma("unroll") for (int j_ = 0; j_ < 6; ++j_) TN_DMA_PIECE(j_); } while (0)
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -571,6 +597,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
     int sc = 0, sn = 1;                                     // stages of K tiles kt (free: refilled with kt+3) and kt+1 (gathered now)
     // K tile kt.  Top: this wave's gathers of tile kt (issued during kt-1) and its DMA pieces of tile kt+1 have landed; after the
     // barrier that holds for every wave, so stage sn may be read and stage sc (tile kt, now in registers everywhere) refilled.
+    // the bias-gradient column sums run in ~1 of tiles_k K tiles: as ONE block in front of the K tile's MFMAs (all eight A fragments of tile kt are
+    // in registers there) behind one branch -- as eight `if (cs_now)` inside the MFMA stream they were eight taken branches per K tile in the
+    // common case; a second copy of the body for the tiles that sum spilled registers (256 VGPRs + 604 B of scratch)
+#define TN_BODY_CORE(FC, FN, CSX) do { \
+        _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) { \
+            TN_MF(nf, 0, FC); TN_SB(); TN_MF(nf, 1, FC); TN_SB(); TN_LDB(nf, FN); TN_SB(); TN_MF(nf, 2, FC); TN_SB(); TN_MF(nf, 3, FC); TN_SB(); \
+            TN_LDA(nf); TN_SB(); \
+            if (nf >= 1) { TN_DMA_PIECE(nf - 1); TN_SB(); } } \
+        _Pragma("unroll") for (int nf = 4; nf < 8; ++nf) { \
+            TN_MF(nf, 0, FC); TN_MF(nf, 1, FC); TN_MF(nf, 2, FC); TN_MF(nf, 3, FC); TN_SB(); \
+            TN_LDA(nf); TN_SB(); \
+            if (nf <= 6) { TN_DMA_PIECE(nf - 1); TN_SB(); } } } while (0)
 #define TN_BODY(FC, FN) do { \
         TN_WAIT_FRAGS(FC); \
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          /* every K tile issues 6 pieces: tile kt+1 has landed */ \
@@ -578,18 +616,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
         const bool cs_now = cs_on && ph0 == tk; \
         ph0 = ph1; ph1 = ph2; \
         int ktd_; TN_NEXT(ktd_, ph2);                  /* tile of iteration kt + 3 */ \
+        TN_DMA_SETUP(sc, ktd_); \
         _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4) { aA[c4] = laA[c4] + sn * TN_STG; aB[c4] = laB[c4] + sn * TN_STG; } \
         __builtin_amdgcn_s_setprio(1); \
-        _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) { \
-            TN_MF(nf, 0, FC); TN_SB(); TN_MF(nf, 1, FC); TN_SB(); TN_LDB(nf, FN); TN_SB(); TN_MF(nf, 2, FC); TN_SB(); TN_MF(nf, 3, FC); TN_SB(); \
-            if (cs_now) { TN_CS(nf); TN_SB(); } \
-            TN_LDA(nf); TN_SB(); \
-            if (nf >= 1) { TN_DMA_PIECE(sc, ktd_, nf - 1); TN_SB(); } } \
-        _Pragma("unroll") for (int nf = 4; nf < 8; ++nf) { \
-            TN_MF(nf, 0, FC); TN_MF(nf, 1, FC); TN_MF(nf, 2, FC); TN_MF(nf, 3, FC); TN_SB(); \
-            if (cs_now) { TN_CS(nf); TN_SB(); } \
-            TN_LDA(nf); TN_SB(); \
-            if (nf <= 6) { TN_DMA_PIECE(sc, ktd_, nf - 1); TN_SB(); } } \
+        if (cs_now) { _Pragma("unroll") for (int nf = 0; nf < 8; ++nf) TN_CS(nf); TN_SB(); } \
+        TN_BODY_CORE(FC, FN, 0); \
         __builtin_amdgcn_s_setprio(0); \
         sc = sc == 2 ? 0 : sc + 1; sn = sn == 2 ? 0 : sn + 1; } while (0)
     int kt = 0;
