@@ -851,7 +851,7 @@ int amdseg_gemm_tn_grouped_bias_impl(int nprob, const void* const* A, const int*
     static int tn_dp = -1;
     if (tn_dp < 0) { const char* e = getenv("AMDSEG_TN_DP"); tn_dp = e ? atoi(e) : 1; }
     bool dp = tn_dp && M >= 128 && !g_force_small_tile;
-    for (int i = 0; i < nprob; ++i) dp = dp && (N[i] % 256) == 0;
+    for (int i = 0; i < nprob; ++i) dp = dp && (N[i] % 256) == 0 && (size_t)M * (size_t)(lda[i] > ldb[i] ? lda[i] : ldb[i]) < ((size_t)1 << 31);
     if (dp) {
         for (int i = 0; i < nprob; ++i)
             if (colsum_out && colsum_out[i]) a.p[i].colsum_part = colsum_scratch[i];

@@ -516,7 +516,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
     const uint32_t ldsAw = __builtin_amdgcn_readfirstlane(lds0 + (dr * 2) * 8192 + (wq * 2) * 1024);
     const uint32_t ldsBw = __builtin_amdgcn_readfirstlane(lds0 + 32768 + dr * 8192 + (wq * 2) * 1024);
-#define TN_DMA_SETUP(s, kt) const bf16_t* const gA_ = tn_uniform(pA + (size_t)(kt) * 64 * P.lda); const bf16_t* const gB_ = tn_uniform(pB + (size_t)(kt) * 64 * P.ldb); \
+    // (element offsets of a K tile's first row fit 32 bits: the launcher sends shapes with M * ld >= 2^31 to the 128 x 128 kernel)
+#define TN_DMA_SETUP(s, kt) const bf16_t* const gA_ = tn_uniform(pA + (uint32_t)((kt) * 64) * (uint32_t)P.lda); const bf16_t* const gB_ = tn_uniform(pB + (uint32_t)((kt) * 64) * (uint32_t)P.ldb); \
         const uint32_t lsA_ = ldsAw + (uint32_t)(s) * TN_STG, lsB_ = ldsBw + (uint32_t)(s) * TN_STG
 #define TN_DMA_PIECE(j) do { if ((j) < 4) amdseg_glds16_saddr_lds(gA_, offA[j], lsA_ + ((j) >> 1) * 8192 + ((j) & 1) * 1024); \
         else amdseg_glds16_saddr_lds(gB_, offB[(j) - 4], lsB_ + ((j) - 4) * 1024); } while (0)

@@ -57,6 +57,11 @@ class FlatParams:
             off = _align(off + named[n].numel())
         self.numel = off
         self.nlayers = nlayers
+        # the encoder layers are one suffix of the flat buffers: [layers_begin, numel).  grad_stale: that slice of flat_g still holds the
+        # PREVIOUS step's gradients (the fused AdamW did not zero it, engine.adamw_step) and counts as zero: the next backward overwrites it
+        self.layers_begin = self.offsets[order[len(rest)]] if nlayers else off
+        self.layers_dense = all(named[n].numel() % 64 == 0 for n in order[len(rest):])     # no alignment gaps inside the slice
+        self.grad_stale = False
         self.encoder_prefix = encoder_prefix
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
@@ -95,14 +100,23 @@ class FlatParams:
             if not self.grad_is_zero:                # the fused AdamW zeroes the buffer in its own pass
                 self.flat_g.zero_()
                 self.grad_is_zero = True
+                self.grad_stale = False
             for p, n in missing:
                 p.grad = self.view(self.flat_g, n)
         else:
             for p, n in missing:
                 v = self.view(self.flat_g, n)
-                v.zero_()
+                if not (self.grad_stale and self.offsets[n] >= self.layers_begin):     # (a stale slot is overwritten by the next backward)
+                    v.zero_()
                 p.grad = v
         return len(missing)
+
+    def flush_stale(self):
+        """make the flat gradient buffer literally what it stands for: the encoder-layer slice that the fused AdamW left un-zeroed is
+        zeroed now (a reader other than the next backward is about to look at it)"""
+        if self.grad_stale:
+            self.flat_g[self.layers_begin:].zero_()
+            self.grad_stale = False
 
     def intact(self):
         """EVERY parameter still aliases its slot of the flat buffer (False after model.to(...), `p.data = new`, a re-initialised head,
@@ -188,6 +202,11 @@ class BertEncoderEngine:
         # AMDSEG_DETERMINISTIC=1; off by default (the sort costs a few launches per step).  Not covered: token-type ids other than 0 mixed in
         # one batch (their table rows are still atomics) and the PoNet pooling backward (csrc/ponet.hip merges run pieces with atomics).
         self.deterministic = bool(getattr(self.cfg, "amdseg_deterministic", False)) or _os.environ.get("AMDSEG_DETERMINISTIC", "0") == "1"
+        # the fused AdamW does not zero the encoder layers' gradients (78 % of bert-base's parameters): the next backward WRITES them
+        # (accumulate_grads = 0 for its first call) instead of adding to zeros -- 4 B per parameter less written by the optimiser pass and 4 B
+        # less read by the weight-gradient epilogues.  Every other reader of flat_g first calls fp.flush_stale().  Base engine only (the
+        # Longformer / PoNet / BigBird engines write extra per-layer parameters on their own); AMDSEG_LAZY_ZERO=0 switches it off.
+        self.lazy_zero = type(self) is BertEncoderEngine and _os.environ.get("AMDSEG_LAZY_ZERO", "1") != "0"
         self._arena_slot = 0
         self.max_live_arenas = 2                            # training arenas per shape that may be alive between forward and backward
         self.grad_sync = True                               # False inside no_sync(): accumulate locally, no bucket all-reduce
@@ -277,6 +296,7 @@ class BertEncoderEngine:
         """the kernels write this call's gradients into the (zeroed) flat buffer; autograd gets a snapshot, so accumulation over
         micro-steps, DDP's reduction hooks and any torch optimiser work on ordinary gradient tensors"""
         self.fp.flat_g.zero_()
+        self.fp.grad_stale = False
         run_backward()
         snap = self.fp.flat_g.clone()
         self.fp.grad_is_zero = False
@@ -738,7 +758,11 @@ class BertEncoderEngine:
         ws = A["ws"]
         lib = L.load()
         s = torch.cuda.current_stream().cuda_stream
-        cfg = self._cfg_struct(B, Lseq, ctx["p_h"], ctx["p_a"], ctx["seed"], accumulate)
+        # the encoder layers' slice of flat_g may hold the previous step's gradients (lazy_zero): this backward overwrites them
+        layer_acc = accumulate and not self.fp.grad_stale
+        if not accumulate:
+            self.fp.grad_stale = False
+        cfg = self._cfg_struct(B, Lseq, ctx["p_h"], ctx["p_a"], ctx["seed"], layer_acc)
         cfg.kend = A["kend"].data_ptr() if (self.skip_padded_chunks and "kend" in A) else None
         cfg.seq_order = A["seq_order"].data_ptr() if (self.skip_padded_chunks and "seq_order" in A) else None
         adt = L.F32 if ctx.get("parity") else L.BF16            # dtype of the activation gradients
@@ -768,6 +792,7 @@ class BertEncoderEngine:
                         self.buckets.reduce_layer(i)
                 else:
                     self.buckets.reduce_layer(i)
+        self.fp.grad_stale = False                  # every layer's gradients have been written
         # embeddings: out = dropout(LN(z)) (BigBird: LN(dropout(z))); grads of LN affine + the three tables
         if ctx["p_h"] > 0 and not self.emb_dropout_pre_ln:
             rc = lib.amdseg_dropout(dy.data_ptr(), other.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, adt, adt, s)
@@ -821,12 +846,14 @@ class BertEncoderEngine:
     def zero_grad(self):
         self.fp.flat_g.zero_()
         self.fp.grad_is_zero = True
+        self.fp.grad_stale = False
         self._rest_reduced = False
         if self.buckets is not None:
             self.buckets.reset_norm()
 
     def grad_norm_and_clip_coef(self, max_norm, extra_scale=1.0):
         sc = self._scratch
+        self.fp.flush_stale()                       # (no backward since the last lazy optimiser step: those gradients are zeros)
         if self.buckets is not None and self.buckets.norm_is_complete():
             ssq = self.buckets.sumsq                   # accumulated bucket by bucket right behind each all-reduce (dp.GradBuckets)
         else:
@@ -858,8 +885,15 @@ class BertEncoderEngine:
             _, coef = self.grad_norm_and_clip_coef(max_grad_norm, grad_scale)
         # the bf16 compute copies ride the AdamW pass (its `shadow` output); what is left for the refresh are the transposes, made from them
         ride = getattr(self, "_parity", None) is None
-        ops.adamw(self.fp.flat_p, self.fp.flat_g, self.adam_m, self.adam_v, self.shadow if ride else None, lr, betas[0], betas[1], eps,
-                  weight_decay, self.opt_step, gscale=coef, zero_grad=zero_grad, chunk_flags=getattr(self, "_chunk_flags", None))
+        self.fp.flush_stale()
+        fp, flags = self.fp, getattr(self, "_chunk_flags", None)
+        lb = fp.layers_begin
+        lazy = bool(zero_grad) and self.lazy_zero and fp.layers_dense and 0 < lb < fp.numel and not self.ddp_compat()
+        for a, b, zg in (((0, lb, True), (lb, fp.numel, False)) if lazy else ((0, fp.numel, zero_grad),)):
+            ops.adamw(fp.flat_p[a:b], fp.flat_g[a:b], self.adam_m[a:b], self.adam_v[a:b], self.shadow[a:b] if ride else None, lr, betas[0],
+                      betas[1], eps, weight_decay, self.opt_step, gscale=coef, zero_grad=zg,
+                      chunk_flags=None if flags is None else flags[a // 64:(b + 63) // 64])
+        fp.grad_stale = lazy
         self.fp.grad_is_zero = bool(zero_grad)
         self._rest_reduced = False
         if self.buckets is not None:

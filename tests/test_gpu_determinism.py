@@ -51,7 +51,7 @@ def test_scatter_rows_sorted_equals_index_add_and_repeats_bitwise(dev, dtype):
     assert torch.equal(outs[0][k0], serial + 0.5)
 
 
-def _three_steps(dev, precision, deterministic, case="tiny_L128"):
+def _three_steps(dev, precision, deterministic, case="tiny_L128", lazy_zero=None, skip_backward_at=None):
     if case == "bert_base_L512":                           # bert-base, 4 x 512 tokens (x 2 with the augmented half): the H = 768 kernels
         from tests.test_gpu_fullsize import _fullsize_case
         z, sd, batch, arch, fl = _fullsize_case()
@@ -67,9 +67,12 @@ def _three_steps(dev, precision, deterministic, case="tiny_L128"):
     random.seed(3)
     b = to_dev(batch, dev)
     losses = []
-    for _ in range(3):
+    for it in range(3):
         loss, _, _ = m(**b)
-        loss.backward()
+        if lazy_zero is not None:
+            m.engine().lazy_zero = lazy_zero
+        if it != skip_backward_at:                         # (a step without a backward: every gradient counts as zero)
+            loss.backward()
         losses.append(loss.item())
         m.engine().adamw_step(1e-3, max_grad_norm=1.0)
     torch.cuda.synchronize()
@@ -118,3 +121,15 @@ def test_heads_backward_is_bit_identical_run_to_run(dev):
                       if p.grad is not None and "word_embeddings" not in n})
     for n, g in grads[0].items():
         assert torch.equal(g, grads[1][n]), n
+
+
+@pytest.mark.parametrize("precision", ["bf16", "parity"])
+def test_lazy_gradient_zeroing_changes_no_bit(dev, precision):
+    """engine.lazy_zero: the fused AdamW leaves the encoder layers' gradients in place and the next backward overwrites them
+    (accumulate_grads = 0) instead of adding to zeros -- the same bits in every parameter after three steps, also when a step runs
+    without a backward in between (the stale slice then counts as zero)."""
+    for skip in (None, 1):
+        a = _three_steps(dev, precision, True, lazy_zero=True, skip_backward_at=skip)
+        b = _three_steps(dev, precision, True, lazy_zero=False, skip_backward_at=skip)
+        assert a[0] == b[0]
+        assert torch.equal(a[1], b[1])
