@@ -26,6 +26,16 @@
 #define DP_BN 256
 #define DP_STAGE (8 * 8192)
 #define DP_LDS (2 * DP_STAGE)
+// timing probes of the 256-wide epilogue (wrong results): -DAMDSEG_ABL_EPI=1 keeps the epilogue's arithmetic and residual loads but issues no
+// global store; =2 ends the kernel after the K loop (accumulators kept alive)
+#ifndef AMDSEG_ABL_EPI
+#define AMDSEG_ABL_EPI 0
+#endif
+#if AMDSEG_ABL_EPI == 1
+#define DP_ST16(ptr, val) asm volatile("" :: "v"((val).x), "v"((val).y), "v"((val).z), "v"((val).w))
+#else
+#define DP_ST16(ptr, val) *reinterpret_cast<uint4*>(ptr) = (val)
+#endif
 
 __device__ __forceinline__ int dp_swz(int r) { const int p = (r >> 1) & 7; return p ^ (((p + 2) >> 2) & 1); }
 __device__ __forceinline__ bf16x8 dp_frag(const char* tile, int r, int c) {
@@ -231,9 +241,21 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) { acc[mf][nf][0] += bv[nf].x; acc[mf][nf][1] += bv[nf].y; acc[mf][nf][2] += bv[nf].z; acc[mf][nf][3] += bv[nf].w; }
     }
+#if AMDSEG_ABL_EPI == 2
+    if (NF == 4) {
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) asm volatile("" :: "v"(acc[mf][nf]));
+        return;
+    }
+#endif
     if (NF == 4) {
         // ---- direct epilogue (256-wide tile): lane owns row m = mf*16 + i16 and the 8 consecutive columns ep*32 + g*8 .. +8 of its wave's 64.
         // BIAS_GELU writes the pre-activation and the activation of a chunk back to back (the stores of one overlap the GELU math of the next)
+        // (round 4, second session: requesting R for the whole tile up front -- 16 loads of 16 B per lane in flight instead of two per row fragment --
+        //  measured neutral, 91.9 / 96.8 vs 98.2 / 94.1 us for GELU' at N = 3072: the epilogue's R traffic is HBM time, not latency;
+        //  profiles/r04_gemm_epilogue_split.md)
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf) {
             const size_t gm = (size_t)(m0 + wr * 128 + mf * 16 + i16);
@@ -296,7 +318,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                 if (EPI == EPI_BIAS_GELU) {
                     if (a.C2) {
                         uint4 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
-                        *reinterpret_cast<uint4*>(a.C2 + gm * a.ldc2 + col) = pk;
+                        DP_ST16(a.C2 + gm * a.ldc2 + col, pk);
                     }
                     gelu_act4(v, ACT); gelu_act4(v + 4, ACT);
                 } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_DROP_RES) {
@@ -323,7 +345,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                 }
                 if (sizeof(OutT) == 2) {
                     uint4 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + gm * a.ldc + col) = pk;
+                    DP_ST16(reinterpret_cast<bf16_t*>(a.C) + gm * a.ldc + col, pk);
                 } else {
                     float* dst = reinterpret_cast<float*>(a.C) + gm * a.ldc + col;
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
