@@ -55,23 +55,35 @@ __device__ __forceinline__ void dp_glds16(const void* g, void* lds_wave_base) {
 
 // NF = 16-column fragments per column wave: 4 -> 256 x 256 tile, 3 -> 256 x 192 tile (wave tile 128 x 48, three B images per stage)
 // for widths that are multiples of 192 but not of 256.
-template <int EPIX, typename OutT, int NF>
+// PERSIST (256-wide tile, multi-round launches of the two GELU epilogues): the grid is one workgroup per CU and a workgroup walks the tiles
+// bid, bid + grid, ...; behind the K loop of a tile -- its epilogue reads no LDS -- the 16 LDS-DMA pieces of the NEXT tile's two stages are issued
+// before the epilogue's arithmetic and stores, so that tile starts on landed data instead of paying its own fill (3-5 us per round at K = 768:
+// the K-loop-only probe takes 65-70 us for 36 K tiles in three rounds where a 48-K-tile single round takes 68-70).  The next tile's first wait is
+// a COUNTED vmcnt that leaves the youngest 16 memory operations (epilogue stores, issued behind the pieces) in flight: gfx950 retires vector
+// loads and stores in issue order (tools/ubench/vmcnt_order.cpp), so everything older -- the pieces -- has landed.
+template <int EPIX, typename OutT, int NF, bool PERSIST = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
     constexpr int BN = NF * 64, WN = NF * 16, STAGE = (4 + NF) * 8192;     // tile width, wave-tile width, bytes per LDS stage
+    static_assert(!PERSIST || NF == 4, "the persistent form needs the LDS-free epilogue of the 256-wide tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 2, wc = w & 3, wq = w & 3;
     const int g = l >> 4, i16 = l & 15;
     const int nwg = a.tiles_m * a.tiles_n;
-    const int t = xcd_remap(blockIdx.x, nwg);
     const int gsz_full = GROUP_M * a.tiles_n;
-    const int grp = t / gsz_full, first_m = grp * GROUP_M;
-    const int gmn = min(a.tiles_m - first_m, GROUP_M);
-    const int rem = t - grp * gsz_full;
-    const int tm = first_m + rem % gmn, tn = rem / gmn;
-    const int m0 = tm * DP_BM, n0 = tn * BN;
+    // tile of launch index tt (each XCD walks a contiguous range, GROUP_M row tiles share their B panel): (m0, n0)
+#define DP_TILE_OF(tt, M0, N0) { const int t_ = xcd_remap(tt, nwg); const int grp_ = t_ / gsz_full, first_m_ = grp_ * GROUP_M; \
+        const int gmn_ = min(a.tiles_m - first_m_, GROUP_M); const int rem_ = t_ - grp_ * gsz_full; \
+        M0 = (first_m_ + rem_ % gmn_) * DP_BM; N0 = (rem_ / gmn_) * BN; }
+#define DP_ZTILE(M0) (a.zkend != nullptr && ((M0) - ((M0) / a.zL) * a.zL) >= a.zkend[(M0) / a.zL] && *a.zguard == 0)
+    bool pf_ = false;                                      // workgroup-uniform: this tile's two stages were requested behind the previous tile's K loop
+    const int tstep = PERSIST ? (int)gridDim.x : nwg;
+    int tt = blockIdx.x;
+    do {                                                   // (one pass unless PERSIST: the condition at the bottom is a compile-time false)
+    int m0, n0;
+    DP_TILE_OF(tt, m0, n0)
 #define DP_TILE_A(s, i) (smem + (s) * STAGE + (i) * 8192)
 #define DP_TILE_B(s, i) (smem + (s) * STAGE + (4 + (i)) * 8192)
     const bf16_t* pA = a.A + (size_t)(m0 + wr * 128) * a.lda;                 // this group's A rows
@@ -92,14 +104,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
     const uint32_t ldsAw = __builtin_amdgcn_readfirstlane(lds0 + (wr * 2) * 8192 + (wq * 2) * 1024);
     const uint32_t ldsBw = __builtin_amdgcn_readfirstlane(lds0 + (4 + wr * 2) * 8192 + (wq * 2) * 1024);
-#define DP_DMA_A(s, i, kt) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
-        amdseg_glds16_saddr_lds(pA + (kt) * 64, offA[(i) * 2 + q], ldsAw + (s) * STAGE + (i) * 8192 + q * 1024);
+#define DP_DMA_A_P(PA, s, i, kt) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
+        amdseg_glds16_saddr_lds((PA) + (kt) * 64, offA[(i) * 2 + q], ldsAw + (s) * STAGE + (i) * 8192 + q * 1024);
+#define DP_DMA_A(s, i, kt) DP_DMA_A_P(pA, s, i, kt)
 #ifdef AMDSEG_ABL_NO_B     // timing probe (wrong results): the B operand costs nothing -- no LDS-DMA pieces, no fragment reads for it
+#define DP_DMA_B_P(PB, s, kt)
 #define DP_DMA_B(s, kt)
 #define DP_WAIT_TILE() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
 #else
-#define DP_DMA_B(s, kt) _Pragma("unroll") for (int i = 0; i < 2; ++i) if (i == 0 || b2) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
-        amdseg_glds16_saddr_lds(pB + (kt) * 64, offB[i * 2 + q], ldsBw + (s) * STAGE + i * 8192 + q * 1024);
+#define DP_DMA_B_P(PB, s, kt) _Pragma("unroll") for (int i = 0; i < 2; ++i) if (i == 0 || b2) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
+        amdseg_glds16_saddr_lds((PB) + (kt) * 64, offB[i * 2 + q], ldsBw + (s) * STAGE + i * 8192 + q * 1024);
+#define DP_DMA_B(s, kt) DP_DMA_B_P(pB, s, kt)
 #define DP_WAIT_TILE() do { if (vm8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
 #endif
     f32x4 acc[8][NF];
@@ -108,9 +123,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = a.K / 64;
-    bool ztile = false;                                       // workgroup-uniform: every row of this tile's A is an exact zero
-    if (a.zkend) { const int zb = m0 / a.zL; ztile = (m0 - zb * a.zL) >= a.zkend[zb] && *a.zguard == 0; }
+    const bool ztile = DP_ZTILE(m0);                          // workgroup-uniform: every row of this tile's A is an exact zero
     if (!ztile) {
+    if (PERSIST && pf_) {
+        // both stages were requested behind the previous tile's K loop; the 16 youngest operations are that tile's epilogue stores
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
     // prologue: both stages; the first MFMA phase waits for K tile 1 as well (vmcnt(0) at kt = 0).  Round 4 tried the early start -- K tile 1
     // issued in the loop's own steady-state order so that the counted waits hold from kt = 0 and the first MFMAs wait for K tile 0 only
     // (-DAMDSEG_ABL_EARLY_START) -- and measured it SLOWER, same box back to back (profiles/r04_gemm_prologue_ablation.md: N = 2304 K = 768
@@ -128,6 +146,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         if (vm8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+    }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();             // stagger: group 1 runs one barrier behind group 0
     bf16x8 fa[4][2], fb[NF][2];
@@ -195,7 +214,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         LDB(S) __builtin_amdgcn_sched_barrier(0); LDA(S, 0) __builtin_amdgcn_sched_barrier(0); \
         if ((kt) >= DP_KT0 && (kt) + 1 < nk) { DP_LOOP_DMA(DP_DMA_A((S) ^ 1, 1, (kt) + 1)) } \
         DP_LGKM_P1(); \
-        if ((kt) >= DP_KT0 && (kt) + 1 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        if ((kt) >= DP_KT0 && (kt) + 1 < nk) DP_WAIT_TILE(); \
+        else if (PERSIST && pf_ && (kt) == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   /* landed at the tile's start; the stores stay in flight */ \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         DP_MID(); \
         DP_MFMA(0) \
         DP_END(); \
@@ -241,13 +262,33 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) { acc[mf][nf][0] += bv[nf].x; acc[mf][nf][1] += bv[nf].y; acc[mf][nf][2] += bv[nf].z; acc[mf][nf][3] += bv[nf].w; }
     }
+    bool pf_next = false;
+    if (PERSIST) {
+        // the next tile's two stages (every LDS read of this tile was retired by the barriers that ended its K loop; the epilogue below does not
+        // touch LDS).  Issued behind this epilogue's bias loads and in front of its residual loads / stores: the compiler's counted waits for its
+        // own loads then cover older pieces too (conservative), and everything younger than the pieces is what the next tile leaves in flight.
+        const int tnx = tt + tstep;
+        if (tnx < nwg) {
+            int m0n, n0n;
+            DP_TILE_OF(tnx, m0n, n0n)
+            if (!DP_ZTILE(m0n)) {
+                const bf16_t* pAn = a.A + (size_t)(m0n + wr * 128) * a.lda;
+                const bf16_t* pBn = a.B + (size_t)(n0n + wr * 128) * a.ldb;
+                DP_DMA_A_P(pAn, 0, 0, 0) DP_DMA_A_P(pAn, 0, 1, 0) DP_DMA_B_P(pBn, 0, 0)
+                if (nk > 1) { DP_DMA_A_P(pAn, 1, 0, 1) DP_DMA_A_P(pAn, 1, 1, 1) DP_DMA_B_P(pBn, 1, 1) }
+                pf_next = true;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    pf_ = pf_next;
 #if AMDSEG_ABL_EPI == 2
     if (NF == 4) {
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) asm volatile("" :: "v"(acc[mf][nf]));
-        return;
+        continue;
     }
 #endif
     if (NF == 4) {
@@ -354,7 +395,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        return;
+        continue;
     }
     constexpr bool STAGED = sizeof(OutT) == 2;
     char* stg = smem + w * 16384;
@@ -412,6 +453,31 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
+    } while (PERSIST && (tt += tstep) < nwg);              // tiles of this workgroup
+}
+
+// one workgroup per CU for the persistent form
+static int dp_num_cus() {
+    static int n = 0;
+    if (!n) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
+    return n;
+}
+
+template <int EPIX, typename OutT>
+static int launch_nt_dp_persist(const GemmNTArgs& a_in, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr int LDS = 8 * 16384;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dp_kernel<EPIX, OutT, 4, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    GemmNTArgs a = a_in;
+    a.tiles_m = a.M / DP_BM; a.tiles_n = a.N / 256;
+    const int nwg = a.tiles_m * a.tiles_n, grid = nwg < dp_num_cus() ? nwg : dp_num_cus();
+    AMDSEG_LAUNCH_PROF(AMDSEG_PROF_GEMM_NT, 2.0 * a.M * a.N * a.K, (gemm_nt_dp_kernel<EPIX, OutT, 4, true>), dim3(grid), dim3(512), LDS, s, a);
+    return amdseg_launch_status();
 }
 
 template <int EPIX, typename OutT, int NF>
@@ -453,6 +519,15 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
     if (direct_only && !ok256) return AMDSEG_ERR_SHAPE;
     const bool use192 = !direct_only && ok192 && (!ok256 || force == 192 || narrow);
     if (use192) return launch_nt_dp_nf<EPIX, OutT, 3>(a_in, s);
+    // multi-round launches of the two GELU epilogues (bert-base: 768 tiles, three per CU): persistent, next tile's fill under this tile's epilogue
+    if constexpr ((EB == EPI_BIAS_GELU || EB == EPI_GELU_BWD) && sizeof(OutT) == 2) {
+        static int persist = -1;
+        // measured NEUTRAL (round 4, profiles/r04_gemm_epilogue_split.md: stand-alone 99-102 vs 102-108 us (bias + GELU), 96-101 vs 98-101 (GELU'), the
+        // training step 12.86-12.89 ms either way): opt-in, AMDSEG_DP_PERSIST=1
+        if (persist < 0) { const char* e = getenv("AMDSEG_DP_PERSIST"); persist = e ? atoi(e) : 0; }
+        const int nwg = (a_in.M / DP_BM) * (a_in.N / 256);
+        if (persist && nwg > dp_num_cus() && a_in.K >= 128) return launch_nt_dp_persist<EPIX, OutT>(a_in, s);
+    }
     return launch_nt_dp_nf<EPIX, OutT, 4>(a_in, s);
 }
 
