@@ -728,6 +728,17 @@ def main():
                                           + (f"the {prof_n} steps of the timed region" if prof_timed else f"{prof_n} real steps right after the "
                                              f"timed region") + "; HBM traffic needs separate rocprofv3 --pmc passes: see profiles/",
                                    kernels=prof)
+            # BASELINE.json's target is stated on "the encoder GEMMs": projection + input-gradient GEMMs (NT) and the grouped weight-gradient GEMM (TN)
+            # together, the reference's flops over the time both kernels take in a step (and the same on the flops actually executed)
+            nt_, tn_ = prof.get("gemm_nt_dp_kernel"), prof.get("gemm_tn_dp_kernel")
+            if nt_ and tn_ and nt_.get("gflop_per_launch") and tn_.get("gflop_per_launch"):
+                gf = nt_["gflop_per_launch"] * nt_["launches_per_step"] + tn_["gflop_per_launch"] * tn_["launches_per_step"]
+                us = nt_["us_per_step"] + tn_["us_per_step"]
+                gfx = nt_["gflop_per_launch"] * nt_["launches_per_step"] + tn_["gflop_per_launch"] * tn_["launches_per_step"] * tn_.get("token_tiles_walked_frac", 1.0)
+                out["roofline"]["encoder_gemms"] = dict(gflop_per_step=round(gf, 1), us_per_step=round(us, 1), achieved=round(gf / us * 1e3, 1),
+                                                        frac=round(gf / us * 1e3 / MFMA_PEAK_TFLOPS, 4),
+                                                        frac_executed=round(gfx / us * 1e3 / MFMA_PEAK_TFLOPS, 4), unit="TFLOP/s",
+                                                        note="gemm_nt_dp_kernel + gemm_tn_dp_kernel of one step together, reference flops / their time")
             # HBM bytes per launch: PMC counters cannot be read from inside the process, so these are the figures of the committed separate
             # rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by tools/pmc_to_json.py) -- attached only when the file's workload
             # is THIS workload, with the commit the passes ran on; null otherwise

@@ -669,7 +669,16 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
         }
     }
     tn_i32x2 fa[8][2], fb0[4][2], fb1[4][2];
+#ifndef AMDSEG_TN_ASM_GATHER
+// the gathers as builtins (this kernel's LDS-DMA is inline asm, so the compiler knows of no vector memory operation it would have to wait for in
+// front of them): it tracks their lgkmcnt itself and may place a fragment's two halves in the adjacent registers the MFMA wants (the asm form pays
+// two v_mov + s_nop for six of the eight A fragments per K tile; 245 -> 220 VGPRs, stand-alone 266-272 -> 261-264 us, in the step 211.8 -> 209.0;
+// -DAMDSEG_TN_ASM_GATHER keeps the asm form)
+typedef short tn_v4s __attribute__((ext_vector_type(4)));
+#define TN_RD(dst, addr, off) dst = __builtin_bit_cast(tn_i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_v4s*)(uintptr_t)((addr) + (off))))
+#else
 #define TN_RD(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#endif
 #define TN_LDA(nf) do { TN_RD(fa[nf][0], aA[(nf) & 3], ((nf) >> 2) * 8192); TN_RD(fa[nf][1], aA[(nf) & 3], ((nf) >> 2) * 8192 + 2048); } while (0)
 #define TN_LDB(e, FB) do { TN_RD(FB[e][0], aB[e], 0); TN_RD(FB[e][1], aB[e], 2048); } while (0)
 #define TN_CAT(x) __builtin_bit_cast(bf16x8, __builtin_shufflevector(x[0], x[1], 0, 1, 2, 3))
@@ -681,10 +690,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
 #define TN_CS(nf) do { const tn_i32x2 c0_ = fa[nf][0], c1_ = fa[nf][1]; const int e0_ = c0_.x, e1_ = c0_.y, e2_ = c1_.x, e3_ = c1_.y; \
                        accb[nf] = TN_DOT2(e0_, accb[nf]); accb[nf] = TN_DOT2(e1_, accb[nf]); \
                        accb[nf] = TN_DOT2(e2_, accb[nf]); accb[nf] = TN_DOT2(e3_, accb[nf]); } while (0)
+#ifndef AMDSEG_TN_ASM_GATHER
+#define TN_WAIT_FRAGS(FB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
 #define TN_WAIT_FRAGS(FB) asm volatile("s_waitcnt lgkmcnt(0)" \
         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), \
           "+v"(fa[4][0]), "+v"(fa[4][1]), "+v"(fa[5][0]), "+v"(fa[5][1]), "+v"(fa[6][0]), "+v"(fa[6][1]), "+v"(fa[7][0]), "+v"(fa[7][1]), \
           "+v"(FB[0][0]), "+v"(FB[0][1]), "+v"(FB[1][0]), "+v"(FB[1][1]), "+v"(FB[2][0]), "+v"(FB[2][1]), "+v"(FB[3][0]), "+v"(FB[3][1]) :: "memory")
+#endif
     uint32_t aA[4], aB[4];
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) { aA[c4] = laA[c4]; aB[c4] = laB[c4]; }
