@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 9   /* 9: amdseg_heads_bwd_rows takes n_feat / fix / fix_bytes (order-independent scatter sums), amdseg_scatter_rows_sorted; 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_gemm_nt_bias_drop_res, amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 10   /* 10: AMDSEG_EPI_KEEP_DERIV (amdseg_bert_layer_acts.u holds gelu' of the FFN pre-activation in bf16 training when the shape allows); 9: amdseg_heads_bwd_rows takes n_feat / fix / fix_bytes (order-independent scatter sums), amdseg_scatter_rows_sorted; 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_gemm_nt_bias_drop_res, amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -49,6 +49,12 @@ extern "C" {
                                    weight gradient read; same shape rule as BIAS_SPLIT; C2 unused                                        */
 #define AMDSEG_EPI_BIAS_GELU_SPLIT 7 /* out_fp32 = 1: C = A B^T + bias (fp32 pre-activation), C2 = bf16 image [M, 3N] (ldc2 >= 3N) = [hi | hi | lo] of
                                    gelu_erf(C): the FFN activation of "parity" precision in the form the next split GEMM reads; same shape rule */
+#define AMDSEG_EPI_KEEP_DERIV 0x200 /* OR-ed into BIAS_GELU: C2 receives gelu'(A B^T + bias) (bf16) instead of the pre-activation; OR-ed into GELU_BWD: R holds
+                                       that derivative, C = (A B^T) * R -- the backward GEMM's epilogue is one multiply instead of a second GELU evaluation.
+                                       erf GELU only, shapes of the deep-pipeline kernel only (M % 256 == 0, N % 192 == 0 or N % 256 == 0, K >= 128):
+                                       AMDSEG_ERR_SHAPE otherwise.  What amdseg_bert_layer_fwd / _bwd use between themselves when the shape allows */
+#define AMDSEG_EPI_DERIV_U8 0x400 /* with AMDSEG_EPI_KEEP_DERIV: the derivative is ONE BYTE per element, q = round((gelu' + 0.135) * 200) (absolute error <= 0.0025);
+                                     C2 / R point to unsigned char [M, ld] (ld in bytes, % 8 == 0); N % 256 == 0 */
 #define AMDSEG_EPI_ACT_TANH 0x100 /* OR-ed into BIAS_GELU / GELU_BWD: "gelu_new" (tanh form, BigBird's hidden_act) instead of erf */
 
 typedef void* amdseg_stream_t;  /* hipStream_t */

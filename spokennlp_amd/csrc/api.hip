@@ -399,6 +399,20 @@ static int parity_unfused() {
 #define PHASE_WGRAD(c) ((c)->phase == 0 || (c)->phase == 2 || (c)->phase == 3 || (c)->phase == 4)
 // width of the fused input projection: 3H (q|k|v) for BERT / Longformer, nproj*H for an external token mixer (PoNet: 5H)
 #define NPROJ(c) (((c)->nproj ? (c)->nproj : 3) * (c)->H)
+// bf16 training: what the FFN up-projection keeps for backward in acts.u.  0: the pre-activation u (bf16; the backward GEMM's epilogue evaluates
+// gelu'(u)).  1: gelu'(u) in bf16 (AMDSEG_EPI_KEEP_DERIV: the backward epilogue is one multiply -- measured neutral, its cost is reading the
+// tensor, not the arithmetic).  2: gelu'(u) as ONE BYTE per element (AMDSEG_EPI_DERIV_U8): 100 MB less HBM traffic per bert-base layer in two
+// epilogues that are HBM time.  Needs the erf GELU and shapes of the 256-wide deep-pipeline tile; forward and backward evaluate the same
+// predicate on the same cfg.  AMDSEG_FFN_KEEP_DERIV = 0 / 1 / 2 picks the form.
+static inline int ffn_keep_deriv(const amdseg_bert_cfg* c) {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("AMDSEG_FFN_KEEP_DERIV"); mode = e ? atoi(e) : 2; }
+    const int M = c->B * c->L;
+    if (!mode || c->act != 0 || c->dtype != AMDSEG_BF16 || (M % 256) || c->H < 128 || (c->H % 64)) return 0;
+    if (mode == 2 && (c->I % 256) == 0) return AMDSEG_EPI_KEEP_DERIV | AMDSEG_EPI_DERIV_U8;
+    if (mode == 1 && ((c->I % 256) == 0 || (c->I % 192) == 0)) return AMDSEG_EPI_KEEP_DERIV;
+    return 0;
+}
 
 int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,
                           const float* mask_bias, int li, amdseg_stream_t stream) {
@@ -502,7 +516,8 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
                                   site_seed(c->seed, li, 1), c->dtype, s, nullptr, a->drop1));
     }
     // FFN
-    RET_IF(amdseg_gemm_nt_impl(a->x1, H, p->w1, H, a->h, I, M, I, H, AMDSEG_EPI_BIAS_GELU | (c->act ? AMDSEG_EPI_ACT_TANH : 0), p->b1, nullptr, 0, a->u, I, 0, s));
+    RET_IF(amdseg_gemm_nt_impl(a->x1, H, p->w1, H, a->h, I, M, I, H, AMDSEG_EPI_BIAS_GELU | (c->act ? AMDSEG_EPI_ACT_TANH : 0) | ffn_keep_deriv(c),
+                               p->b1, nullptr, 0, a->u, I, 0, s));
     if (fuse_dr) {
         RET_IF(amdseg_gemm_nt_bias_drop_res_impl(a->h, I, p->w2, I, a->z2, H, M, H, I, p->b2, a->x1, H, c->p_hidden, site_seed(c->seed, li, 2),
                                                  a->drop2, s));
@@ -622,7 +637,8 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     RET_IF(amdseg_ln_bwd_impl(dy, a->z2, a->mean2, a->rstd2, p->ln2_g, w->dz2, drop ? w->dbr2 : nullptr, part_ln2, g->ln2_g, g->ln2_b,
                               g->b2, M, H, c->p_hidden, site_seed(c->seed, li, 2), acc, c->dtype, s, ZPAD, nullptr, a->drop2));
     // du = (d_out . W2) * gelu'(u)
-    RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD | (c->act ? AMDSEG_EPI_ACT_TANH : 0), nullptr, a->u, I, nullptr, 0, 0, s, ZPAD));
+    RET_IF(amdseg_gemm_nt_impl(d_out, H, p->w2_t, H, w->du, I, M, I, H, AMDSEG_EPI_GELU_BWD | (c->act ? AMDSEG_EPI_ACT_TANH : 0) | ffn_keep_deriv(c),
+                               nullptr, a->u, I, nullptr, 0, 0, s, ZPAD));
     // dx1 = du . W1 + dz2
     RET_IF(amdseg_gemm_nt_impl(w->du, I, p->w1_t, I, w->dx1, H, M, H, I, AMDSEG_EPI_ADD_RES, nullptr, w->dz2, H, nullptr, 0, 0, s, ZPAD));
     // (db1 = colsum(du) and dbqkv = colsum(dqkv) come out of the grouped weight-gradient GEMM below)

@@ -204,6 +204,26 @@ __device__ __forceinline__ f32x2 gelu_sig_grad2(f32x2 x) {           // d/dx [x 
 }
 #endif
 
+// gelu and its derivative from ONE sigmoid evaluation (the forward GEMM epilogue that keeps the derivative for backward, AMDSEG_EPI_KEEP_DERIV)
+__device__ __forceinline__ void gelu_both2(f32x2 x, f32x2& h, f32x2& d) {
+#ifndef AMDSEG_GELU_ERF_EPILOGUE
+    f32x2 r, x2c;
+    gelu_sig_core(x, r, x2c);
+    const f32x2 sp = (x2c * (-5.0f * GELU_SIG_C * 0.6931471805599453f) + (-3.0f * GELU_SIG_B * 0.6931471805599453f)) * x2c
+                     + (-GELU_SIG_A * 0.6931471805599453f);
+    h = x * r;
+    d = (r - r * r) * (x * sp) + r;
+#else
+    h = gelu_fast2(x); d = gelu_grad_fast2(x);
+#endif
+}
+__device__ __forceinline__ void gelu_both4(float* v, float* d) {
+    f32x2 h0, d0, h1, d1;
+    gelu_both2((f32x2){v[0], v[1]}, h0, d0); gelu_both2((f32x2){v[2], v[3]}, h1, d1);
+    v[0] = h0.x; v[1] = h0.y; v[2] = h1.x; v[3] = h1.y;
+    d[0] = d0.x; d[1] = d0.y; d[2] = d1.x; d[3] = d1.y;
+}
+
 // "gelu_new" (tanh approximation; [hf] activations.py NewGELUActivation -- BigBird's default hidden_act) and its derivative
 __device__ __forceinline__ float gelu_tanh_fast(float x) {
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);

@@ -631,7 +631,11 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
                         hipStream_t stream, const int* zkend, const int* zguard, int zL) {
     if (!A || !B || (!C && (epi & 0xff) != 7)) return AMDSEG_ERR_ARG;      // (BIAS_GELU_SPLIT: C == NULL = no pre-activation output)
     const int act = (epi >> 8) & 1;                         // AMDSEG_EPI_ACT_TANH: gelu_new instead of the erf GELU
+    const int keepd = (epi >> 9) & 1;                       // AMDSEG_EPI_KEEP_DERIV: C2 / R is gelu'(pre-activation), not the pre-activation
+    const int d8 = (epi >> 10) & 1;                         // AMDSEG_EPI_DERIV_U8: ... as one byte per element
     epi &= 0xff;
+    if (keepd && (act || (epi != EPI_BIAS_GELU && epi != EPI_GELU_BWD))) return AMDSEG_ERR_ARG;
+    if (d8 && !keepd) return AMDSEG_ERR_ARG;
     const bool big = (M % PP_BM) == 0 && (N % PP_BN) == 0, small = (M % BM) == 0 && (N % BN) == 0;
     if (M <= 0 || N <= 0 || K <= 0 || !(big || small) || (K % BK)) return AMDSEG_ERR_SHAPE;
     if ((lda % 8) || (ldb % 8) || (ldc % 8)) return AMDSEG_ERR_SHAPE;
@@ -654,12 +658,22 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
             return out_fp32 ? launch_nt<EPI_BIAS, float>(a, stream) : launch_nt<EPI_BIAS, bf16_t>(a, stream);
         case EPI_BIAS_GELU:
             if (!bias || out_fp32 || (C2 && (ldc2 % 8))) return AMDSEG_ERR_ARG;       // C2 == NULL: gelu output only (inference)
+            if (keepd) {
+                if ((M % 256) || ((N % 256) && (N % 192)) || K < 128 || (d8 && (N % 256))) return AMDSEG_ERR_SHAPE;
+                if (d8) return amdseg_launch_nt_dp<EPI_BIAS_GELU_DG8, bf16_t>(a, stream);
+                return amdseg_launch_nt_dp<EPI_BIAS_GELU_DG, bf16_t>(a, stream);
+            }
             return act ? launch_nt<EPI_BIAS_GELU_TANH, bf16_t>(a, stream) : launch_nt<EPI_BIAS_GELU, bf16_t>(a, stream);
         case EPI_ADD_RES:
             if (!R || (ldr % 8)) return AMDSEG_ERR_ARG;
             return out_fp32 ? launch_nt<EPI_ADD_RES, float>(a, stream) : launch_nt<EPI_ADD_RES, bf16_t>(a, stream);
         case EPI_GELU_BWD:
             if (!R || out_fp32 || (ldr % 8)) return AMDSEG_ERR_ARG;
+            if (keepd) {
+                if ((M % 256) || ((N % 256) && (N % 192)) || K < 128 || (d8 && (N % 256))) return AMDSEG_ERR_SHAPE;
+                if (d8) return amdseg_launch_nt_dp<EPI_MUL_RES8, bf16_t>(a, stream);
+                return amdseg_launch_nt_dp<EPI_MUL_RES, bf16_t>(a, stream);
+            }
             return act ? launch_nt<EPI_GELU_BWD_TANH, bf16_t>(a, stream) : launch_nt<EPI_GELU_BWD, bf16_t>(a, stream);
         case 5:                                             // AMDSEG_EPI_BIAS_SPLIT: the 256 x 256 deep-pipeline kernel only
             if (!C2 || out_fp32 || (ldc2 % 8)) return AMDSEG_ERR_ARG;                 // bias may be NULL (no bias added)

@@ -65,6 +65,10 @@ template <int EPIX, typename OutT, int NF, bool PERSIST = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
     constexpr int BN = NF * 64, WN = NF * 16, STAGE = (4 + NF) * 8192;     // tile width, wave-tile width, bytes per LDS stage
+    constexpr bool E_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT || EPI == EPI_BIAS_GELU_SPLIT || EPI == EPI_BIAS_DROP_RES ||
+                            EPI == EPI_BIAS_GELU_DG || EPI == EPI_BIAS_GELU_DG8;           // a bias vector goes into the accumulators
+    constexpr bool E_RES = EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_DROP_RES || EPI == EPI_MUL_RES;    // a bf16 operand R is read
+    constexpr bool E_GELU2 = EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_DG;               // two outputs: C2 (pre-activation / derivative) and C
     static_assert(!PERSIST || NF == 4, "the persistent form needs the LDS-free epilogue of the 256-wide tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     // ---- epilogue.  Lane owns row m = mf*16 + i16 and columns nf*16 + g*4 .. +4 of the wave tile.  bf16 results go through a
     // wave-private 16-KiB LDS image (2 x [64 rows][128 B], swizzled) so every global store instruction writes 8 full 128-B lines.
     float4 bv[NF];
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT || EPI == EPI_BIAS_GELU_SPLIT || EPI == EPI_BIAS_DROP_RES) {
+    if (E_BIAS) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
             bv[nf] = (EPI == EPI_BIAS_SPLIT && !a.bias) ? make_float4(0.f, 0.f, 0.f, 0.f)      // BIAS_SPLIT without a bias: the plain product as an image
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     }
     // the bias goes INTO the accumulators once: recomputing acc + bias in both passes of BIAS_GELU made the compiler keep all
     // 128 sums of pass 0 alive for pass 1 (common subexpression) next to the 128 accumulators -> 116 spilled VGPRs
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT || EPI == EPI_BIAS_GELU_SPLIT || EPI == EPI_BIAS_DROP_RES) {
+    if (E_BIAS) {
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
@@ -301,9 +305,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         for (int mf = 0; mf < 8; ++mf) {
             const size_t gm = (size_t)(m0 + wr * 128 + mf * 16 + i16);
             uint4 rr[2];
-            if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_DROP_RES) {
+            if (E_RES) {
 #pragma unroll
                 for (int ep = 0; ep < 2; ++ep) rr[ep] = *reinterpret_cast<const uint4*>(a.R + gm * a.ldr + n0 + wc * 64 + ep * 32 + g * 8);
+            }
+            uint2 r8[2];
+            if (EPI == EPI_MUL_RES8) {                         // the derivative kept by the forward, one byte per element
+#pragma unroll
+                for (int ep = 0; ep < 2; ++ep)
+                    r8[ep] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(a.R) + gm * a.ldr + n0 + wc * 64 + ep * 32 + g * 8);
             }
             float4 ru[2][2];
             if (EPI == EPI_GELU_BWD_SPLIT) {                   // the fp32 pre-activation
@@ -356,13 +366,33 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                     *reinterpret_cast<uint4*>(a.C2 + gm * a.ldc2 + col) = lo;
                     continue;
                 }
-                if (EPI == EPI_BIAS_GELU) {
+                if (EPI == EPI_BIAS_GELU_DG8) {                // ... the derivative as one byte per element
+                    if (a.C2) {
+                        float d[8];
+                        gelu_both4(v, d); gelu_both4(v + 4, d + 4);
+                        uint2 q; q.x = gelu_dq_pack4(d); q.y = gelu_dq_pack4(d + 4);
+#if AMDSEG_ABL_EPI == 1
+                        asm volatile("" :: "v"(q.x), "v"(q.y));
+#else
+                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(a.C2) + gm * a.ldc2 + col) = q;
+#endif
+                    } else { gelu_act4(v, 0); gelu_act4(v + 4, 0); }
+                } else if (EPI == EPI_MUL_RES8) {
+                    gelu_dq_mul4(v, r8[ep].x); gelu_dq_mul4(v + 4, r8[ep].y);
+                } else if (EPI == EPI_BIAS_GELU_DG) {          // gelu and, for backward, its derivative from one sigmoid (AMDSEG_EPI_KEEP_DERIV)
+                    if (a.C2) {
+                        float d[8];
+                        gelu_both4(v, d); gelu_both4(v + 4, d + 4);
+                        uint4 pk; pk.x = pack2bf(d[0], d[1]); pk.y = pack2bf(d[2], d[3]); pk.z = pack2bf(d[4], d[5]); pk.w = pack2bf(d[6], d[7]);
+                        DP_ST16(a.C2 + gm * a.ldc2 + col, pk);
+                    } else { gelu_act4(v, 0); gelu_act4(v + 4, 0); }
+                } else if (EPI == EPI_BIAS_GELU) {
                     if (a.C2) {
                         uint4 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
                         DP_ST16(a.C2 + gm * a.ldc2 + col, pk);
                     }
                     gelu_act4(v, ACT); gelu_act4(v + 4, ACT);
-                } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_DROP_RES) {
+                } else if (E_RES) {
                     const uint32_t rw[4] = {rr[ep].x, rr[ep].y, rr[ep].z, rr[ep].w};
                     float rf[8];
 #pragma unroll
@@ -382,6 +412,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                     if (EPI == EPI_ADD_RES) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += rf[q];
+                    } else if (EPI == EPI_MUL_RES) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] *= rf[q];
                     } else { gelu_grad_mul4(v, rf[0], rf[1], rf[2], rf[3], ACT); gelu_grad_mul4(v + 4, rf[4], rf[5], rf[6], rf[7], ACT); }
                 }
                 if (sizeof(OutT) == 2) {
@@ -402,26 +435,31 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #define DP_STG_OFF(r, c16) (((r) >> 6) * 8192 + ((r) & 63) * 128 + ((((c16) ^ (((r) & 63) ^ (((r) & 63) >> 3))) & 7) << 4))
     const int col0 = n0 + wc * WN;
 #pragma unroll
-    for (int pass = 0; pass < (EPI == EPI_BIAS_GELU ? 2 : 1); ++pass) {
-        // pass 0 of BIAS_GELU writes the pre-activation (C2), pass 1 the activation; other epilogues have one pass
-        if (EPI == EPI_BIAS_GELU && pass == 0 && !a.C2) continue;
+    for (int pass = 0; pass < (E_GELU2 ? 2 : 1); ++pass) {
+        // pass 0 of BIAS_GELU writes the pre-activation (C2; _DG: the derivative), pass 1 the activation; other epilogues have one pass
+        if (E_GELU2 && pass == 0 && !a.C2) continue;
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf) {
             const size_t gm = (size_t)(m0 + wr * 128 + mf * 16 + i16);
             uint2 rr[NF];
-            if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_DROP_RES) {     // (DROP_RES: 256-wide tile only; this path is never launched for it)
+            if (E_RES) {     // (DROP_RES: 256-wide tile only; this path is never launched for it)
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) rr[nf] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + col0 + nf * 16 + g * 4);
             }
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
                 float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
-                if (EPI == EPI_BIAS_GELU && pass == 1) {
-                    gelu_act4(v, ACT);
-                } else if (EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_DROP_RES) {
+                if (E_GELU2 && pass == 1) {
+                    gelu_act4(v, EPI == EPI_BIAS_GELU_DG ? 0 : ACT);
+                } else if (EPI == EPI_BIAS_GELU_DG) {             // pass 0: the derivative
+                    float d[4] = {1.f, 1.f, 1.f, 1.f};
+                    gelu_grad_mul4(d, v[0], v[1], v[2], v[3], 0);
+                    v[0] = d[0]; v[1] = d[1]; v[2] = d[2]; v[3] = d[3];
+                } else if (E_RES) {
                     const float r0 = __uint_as_float(rr[nf].x << 16), r1 = __uint_as_float(rr[nf].x & 0xffff0000u);
                     const float r2 = __uint_as_float(rr[nf].y << 16), r3 = __uint_as_float(rr[nf].y & 0xffff0000u);
                     if (EPI == EPI_ADD_RES || EPI == EPI_BIAS_DROP_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
+                    else if (EPI == EPI_MUL_RES) { v[0] *= r0; v[1] *= r1; v[2] *= r2; v[3] *= r3; }
                     else gelu_grad_mul4(v, r0, r1, r2, r3, ACT);
                 }
                 if (STAGED) {
@@ -440,8 +478,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int rr0 = l >> 3, cc = l & 7;
-            bf16_t* obase = ((EPI == EPI_BIAS_GELU && pass == 0) ? a.C2 : reinterpret_cast<bf16_t*>(a.C));
-            const int old = (EPI == EPI_BIAS_GELU && pass == 0) ? a.ldc2 : a.ldc;
+            bf16_t* obase = ((E_GELU2 && pass == 0) ? a.C2 : reinterpret_cast<bf16_t*>(a.C));
+            const int old = (E_GELU2 && pass == 0) ? a.ldc2 : a.ldc;
             obase += (size_t)(m0 + wr * 128) * old + col0 + cc * 8;
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
@@ -511,16 +549,17 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
     // 56.6 -> 52.5 (384 -> 512 tiles).  The residual-reading epilogues lose on the narrow tile's staged stores (GELU' 57.8 -> 59.2) and stay wide.
     constexpr int EB = EPI_BASE(EPIX);
     bool narrow = false;
-    if (ok256 && ok192 && force == 0 && (EB == EPI_NONE || EB == EPI_BIAS || EB == EPI_BIAS_GELU)) {
+    if (ok256 && ok192 && force == 0 && (EB == EPI_NONE || EB == EPI_BIAS || EB == EPI_BIAS_GELU || EB == EPI_BIAS_GELU_DG)) {
         const int t256 = (a_in.M / DP_BM) * (a_in.N / 256), t192 = (a_in.M / DP_BM) * (a_in.N / 192);
         narrow = 0.78f * (float)((t192 + 255) / 256) < (float)((t256 + 255) / 256);
     }
-    constexpr bool direct_only = EB == EPI_BIAS_SPLIT || EB == EPI_GELU_BWD_SPLIT || EB == EPI_BIAS_GELU_SPLIT || EB == EPI_BIAS_DROP_RES;    // epilogues of the 256-wide tile only
+    constexpr bool direct_only = EB == EPI_BIAS_SPLIT || EB == EPI_GELU_BWD_SPLIT || EB == EPI_BIAS_GELU_SPLIT || EB == EPI_BIAS_DROP_RES ||
+                                 EB == EPI_BIAS_GELU_DG8 || EB == EPI_MUL_RES8;    // epilogues of the 256-wide tile only
     if (direct_only && !ok256) return AMDSEG_ERR_SHAPE;
     const bool use192 = !direct_only && ok192 && (!ok256 || force == 192 || narrow);
     if (use192) return launch_nt_dp_nf<EPIX, OutT, 3>(a_in, s);
     // multi-round launches of the two GELU epilogues (bert-base: 768 tiles, three per CU): persistent, next tile's fill under this tile's epilogue
-    if constexpr ((EB == EPI_BIAS_GELU || EB == EPI_GELU_BWD) && sizeof(OutT) == 2) {
+    if constexpr ((EB == EPI_BIAS_GELU || EB == EPI_GELU_BWD || EB == EPI_BIAS_GELU_DG || EB == EPI_MUL_RES || EB == EPI_BIAS_GELU_DG8 || EB == EPI_MUL_RES8) && sizeof(OutT) == 2) {
         static int persist = -1;
         // measured NEUTRAL (round 4, profiles/r04_gemm_epilogue_split.md: stand-alone 99-102 vs 102-108 us (bias + GELU), 96-101 vs 98-101 (GELU'), the
         // training step 12.86-12.89 ms either way): opt-in, AMDSEG_DP_PERSIST=1
@@ -536,7 +575,7 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
 DP_INST(EPI_NONE, bf16_t) DP_INST(EPI_NONE, float) DP_INST(EPI_BIAS, bf16_t) DP_INST(EPI_BIAS, float) DP_INST(EPI_BIAS_GELU, bf16_t)
 DP_INST(EPI_ADD_RES, bf16_t) DP_INST(EPI_ADD_RES, float) DP_INST(EPI_GELU_BWD, bf16_t)
 DP_INST(EPI_BIAS_GELU_TANH, bf16_t) DP_INST(EPI_GELU_BWD_TANH, bf16_t) DP_INST(EPI_BIAS_SPLIT, bf16_t) DP_INST(EPI_GELU_BWD_SPLIT, bf16_t)
-DP_INST(EPI_BIAS_GELU_SPLIT, float) DP_INST(EPI_BIAS_DROP_RES, bf16_t)
+DP_INST(EPI_BIAS_GELU_SPLIT, float) DP_INST(EPI_BIAS_DROP_RES, bf16_t) DP_INST(EPI_BIAS_GELU_DG, bf16_t) DP_INST(EPI_MUL_RES, bf16_t) DP_INST(EPI_BIAS_GELU_DG8, bf16_t) DP_INST(EPI_MUL_RES8, bf16_t)
 
 
 // ==================================================================================================== gemm_tn, deep pipeline

@@ -11,7 +11,10 @@ enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_
                                                             // ("parity" precision: the consumer is another split-bf16 product), 256-wide dp kernel only
        EPI_GELU_BWD_SPLIT = 8,
        EPI_BIAS_GELU_SPLIT = 9,
-       EPI_BIAS_DROP_RES = 10 };                            // C = R + dropout(A B^T + bias), keep decisions -> keepbits (1 byte per 8 columns): the dense +
+       EPI_BIAS_DROP_RES = 10,
+       EPI_BIAS_GELU_DG = 11,                               // AMDSEG_EPI_BIAS_GELU | AMDSEG_EPI_KEEP_DERIV: C = gelu(A B^T + bias), C2 = gelu'(A B^T + bias) (deep-pipeline kernel only)
+       EPI_MUL_RES = 12,
+       EPI_BIAS_GELU_DG8 = 13, EPI_MUL_RES8 = 14 };        // the same pair with the derivative as ONE BYTE per element (AMDSEG_EPI_DERIV_U8), 256-wide tile only                                  // AMDSEG_EPI_GELU_BWD | AMDSEG_EPI_KEEP_DERIV: C = (A B^T) * R, R = the derivative kept by the forward                            // C = R + dropout(A B^T + bias), keep decisions -> keepbits (1 byte per 8 columns): the dense +
                                                             // dropout + residual of BertSelfOutput / BertOutput in the GEMM's epilogue (256-wide dp kernel only)                           // C (fp32) = A B^T + bias (the pre-activation backward reads); C2 = bf16 image [hi | hi | lo] of gelu_erf(that)                            // x = (A B^T) * gelu_erf'(R), R fp32: hi -> C and C + dup_off columns, lo -> C2 (the [hi | hi | lo]
                                                             // image the next split GEMM and the weight gradient read); 256-wide dp kernel only
 // the kernels are instantiated on the extended value EPIX; EPI = what the epilogue does, ACT = which GELU (a compile-time constant:
@@ -48,6 +51,29 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+
+// gelu'(x) lies in [-0.129, 1.129]: kept as q = round((g' + 0.135) * 200), one byte, absolute error <= 0.0025 -- smaller than the bf16 rounding
+// of the same value wherever g' >= 0.64 (bf16: 2^-8 relative), larger near zero where the products it enters are small; what it buys is HBM bytes
+// in two epilogues that are HBM time (profiles/r04_gemm_epilogue_split.md): 1 B instead of 2 B per element written by the FFN up-projection and
+// read by the GELU backward GEMM
+#define GELU_DQ_SCALE 200.0f
+#define GELU_DQ_OFF 27.0f
+#define GELU_DQ_STEP 0.005f
+#define GELU_DQ_LO (-0.135f)
+__device__ __forceinline__ uint32_t gelu_dq_pack4(const float* d) {
+    uint32_t w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32(d[0] * GELU_DQ_SCALE + GELU_DQ_OFF, 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(d[1] * GELU_DQ_SCALE + GELU_DQ_OFF, 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(d[2] * GELU_DQ_SCALE + GELU_DQ_OFF, 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(d[3] * GELU_DQ_SCALE + GELU_DQ_OFF, 3, w);
+    return w;
+}
+__device__ __forceinline__ void gelu_dq_mul4(float* v, uint32_t w) {
+    v[0] *= (float)(w & 0xffu) * GELU_DQ_STEP + GELU_DQ_LO;
+    v[1] *= (float)((w >> 8) & 0xffu) * GELU_DQ_STEP + GELU_DQ_LO;
+    v[2] *= (float)((w >> 16) & 0xffu) * GELU_DQ_STEP + GELU_DQ_LO;
+    v[3] *= (float)(w >> 24) * GELU_DQ_STEP + GELU_DQ_LO;
+}
 
 // deep-pipeline 256 x 256 kernel (gemm_dp.hip)
 template <int EPIX, typename OutT> int amdseg_launch_nt_dp(const GemmNTArgs& a, hipStream_t s);

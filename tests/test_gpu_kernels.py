@@ -106,6 +106,36 @@ def _check_all_epilogues(dev, M, N, K):
     assert rel_err(U, base + bias) < 4e-3 and rel_err(H, gelu(base + bias)) < 4e-3
     assert rel_err(ops.gemm_nt(A, B, ops.EPI_ADD_RES, R=R, out_dtype=torch.float32), base + R.float()) < 2e-6
     assert rel_err(ops.gemm_nt(A, B, ops.EPI_GELU_BWD, R=R), base * gelu_grad(R.float())) < 4e-3
+    if K >= 128 and M % 256 == 0:
+        # AMDSEG_EPI_KEEP_DERIV (deep-pipeline kernel): the forward keeps gelu'(pre-activation) as its second output, the backward multiplies by it
+        from spokennlp_amd import lib as L
+        Hd, D = ops.gemm_nt(A, B, ops.EPI_BIAS_GELU | L.EPI_KEEP_DERIV, bias=bias)
+        assert rel_err(Hd, gelu(base + bias)) < 4e-3 and rel_err(D, gelu_grad(base + bias)) < 4e-3
+        if K >= 768:
+            assert torch.equal(Hd, H)                        # the same kernel, the same activation bits as the pre-activation form
+        assert rel_err(ops.gemm_nt(A, B, ops.EPI_GELU_BWD | L.EPI_KEEP_DERIV, R=D), base * D.float()) < 4e-3
+        # ... and the pair is the pair it replaces, to bf16 rounding of the kept tensor
+        assert rel_err(ops.gemm_nt(A, B, ops.EPI_GELU_BWD | L.EPI_KEEP_DERIV, R=D).float(), ops.gemm_nt(A, B, ops.EPI_GELU_BWD, R=U).float()) < 8e-3
+    if K >= 128 and M % 256 == 0 and N % 256 == 0:
+        # ... and the derivative as one byte per element (AMDSEG_EPI_DERIV_U8): q = round((g' + 0.135) * 200), |error| <= 0.0025 (+ the bf16-level
+        # noise of the accumulators under it)
+        from spokennlp_amd import lib as L
+        fl = L.EPI_KEEP_DERIV | L.EPI_DERIV_U8
+        Q = torch.zeros(M, N, dtype=torch.uint8, device=dev)
+        H8 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        rc = L.load().amdseg_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, H8.data_ptr(), N, M, N, K, ops.EPI_BIAS_GELU | fl, bias.data_ptr(), None, 0,
+                                     Q.data_ptr(), N, 0, st)
+        assert rc == 0
+        assert rel_err(H8, gelu(base + bias)) < 4e-3
+        want = gelu_grad(base + bias)
+        got = Q.float() * 0.005 - 0.135
+        assert (got - want).abs().max().item() < 0.0025 + 2e-3, (got - want).abs().max().item()
+        dU = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        rc = L.load().amdseg_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, dU.data_ptr(), N, M, N, K, ops.EPI_GELU_BWD | fl, None, Q.data_ptr(), N,
+                                     None, 0, 0, st)
+        assert rc == 0
+        assert rel_err(dU, base * got) < 4e-3
     # asymmetric small-integer operands: exact, catches any row/col or fragment swap
     A2 = torch.zeros(M, K, device=dev); B2 = torch.zeros(N, K, device=dev)
     A2[:, 0] = torch.arange(M, device=dev) % 61; B2[:, 0] = 1.0
