@@ -409,7 +409,13 @@ static inline int ffn_keep_deriv(const amdseg_bert_cfg* c) {
     if (mode < 0) { const char* e = getenv("AMDSEG_FFN_KEEP_DERIV"); mode = e ? atoi(e) : 2; }
     const int M = c->B * c->L;
     if (!mode || c->act != 0 || c->dtype != AMDSEG_BF16 || (M % 256) || c->H < 128 || (c->H % 64)) return 0;
-    if (mode == 2 && (c->I % 256) == 0) return AMDSEG_EPI_KEEP_DERIV | AMDSEG_EPI_DERIV_U8;
+    if (mode == 2 && (c->I % 256) == 0) {
+        // ... unless the up-projection would take the 192-wide tile for its rounds (amdseg_launch_nt_dp: M = 8192, the 4 x 2048 launch shape), which the
+        // one-byte epilogue does not have: there the narrow tile is worth more than the bytes (longformer-base 4 x 2048: 368 vs 364 seq/s)
+        const int t256 = (M / 256) * (c->I / 256), t192 = (c->I % 192) == 0 ? (M / 256) * (c->I / 192) : 0;
+        const bool narrow = t192 > 0 && 0.78f * (float)((t192 + 255) / 256) < (float)((t256 + 255) / 256);
+        return narrow ? 0 : (AMDSEG_EPI_KEEP_DERIV | AMDSEG_EPI_DERIV_U8);
+    }
     if (mode == 1 && ((c->I % 256) == 0 || (c->I % 192) == 0)) return AMDSEG_EPI_KEEP_DERIV;
     return 0;
 }

@@ -204,9 +204,11 @@ class BertEncoderEngine:
         self.deterministic = bool(getattr(self.cfg, "amdseg_deterministic", False)) or _os.environ.get("AMDSEG_DETERMINISTIC", "0") == "1"
         # the fused AdamW does not zero the encoder layers' gradients (78 % of bert-base's parameters): the next backward WRITES them
         # (accumulate_grads = 0 for its first call) instead of adding to zeros -- 4 B per parameter less written by the optimiser pass and 4 B
-        # less read by the weight-gradient epilogues.  Every other reader of flat_g first calls fp.flush_stale().  Base engine only (the
-        # Longformer / PoNet / BigBird engines write extra per-layer parameters on their own); AMDSEG_LAZY_ZERO=0 switches it off.
-        self.lazy_zero = type(self) is BertEncoderEngine and _os.environ.get("AMDSEG_LAZY_ZERO", "1") != "0"
+        # less read by the weight-gradient epilogues.  Every other reader of flat_g first calls fp.flush_stale().  Every engine family: the slice
+        # holds exactly the parameters amdseg_bert_layer_bwd writes under cfg.accumulate_grads (PoNet's 5H projection and BigBird's layers are those
+        # too; Longformer's global projections, accumulated by csrc/lf_global.hip, are not in layer_order and so sit in the eagerly zeroed front
+        # part).  AMDSEG_LAZY_ZERO=0 switches it off.
+        self.lazy_zero = _os.environ.get("AMDSEG_LAZY_ZERO", "1") != "0"
         self._arena_slot = 0
         self.max_live_arenas = 2                            # training arenas per shape that may be alive between forward and backward
         self.grad_sync = True                               # False inside no_sync(): accumulate locally, no bucket all-reduce
