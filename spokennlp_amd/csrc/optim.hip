@@ -9,6 +9,43 @@
 #include "amdseg_internal.h"
 #include "prof.h"
 
+// streaming form (round 4): every buffer is touched exactly once per step, so loads and stores carry the non-temporal hint (no reuse to keep in
+// L2 / MALL), and a thread handles two float4 quads per trip (8 x 16-B loads in flight).  -DAMDSEG_ADAMW_PLAIN: the plain form.
+typedef float aw_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned aw_u2 __attribute__((ext_vector_type(2)));
+#ifndef AMDSEG_ADAMW_PLAIN
+__device__ __forceinline__ float4 aw_ld_nt(const float* p, size_t i) {
+    const aw_f4 v = __builtin_nontemporal_load(reinterpret_cast<const aw_f4*>(p) + i);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void aw_st_nt(float* p, size_t i, const float4& v) {
+    __builtin_nontemporal_store((aw_f4){v.x, v.y, v.z, v.w}, reinterpret_cast<aw_f4*>(p) + i);
+}
+__device__ __forceinline__ void aw_st2_nt(bf16_t* p, size_t i, const uint2& v) {
+    __builtin_nontemporal_store((aw_u2){v.x, v.y}, reinterpret_cast<aw_u2*>(p) + i);
+}
+#define AW_LD(p, i) aw_ld_nt(p, i)
+#define AW_ST(p, i, v) aw_st_nt(p, i, v)
+#define AW_ST2(p, i, v) aw_st2_nt(p, i, v)
+#else
+#define AW_LD(p, i) (reinterpret_cast<const float4*>(p)[i])
+#define AW_ST(p, i, v) (reinterpret_cast<float4*>(p)[i] = (v))
+#define AW_ST2(p, i, v) (reinterpret_cast<uint2*>(p)[i] = (v))
+#endif
+__device__ __forceinline__ void adamw_quad(float4& pp, const float4& gg, float4& mm, float4& vv, float gs, float decay, float beta1, float beta2,
+                                           float eps, float step_size, float rsqrt_bc2) {
+    float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x, gg.y, gg.z, gg.w}, Mm[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float gr = G[e] * gs;
+        P[e] *= decay;
+        Mm[e] = beta1 * Mm[e] + (1.0f - beta1) * gr;
+        V[e] = beta2 * V[e] + (1.0f - beta2) * gr * gr;
+        const float denom = sqrtf(V[e]) * rsqrt_bc2 + eps;
+        P[e] -= step_size * (Mm[e] / denom);
+    }
+    pp = make_float4(P[0], P[1], P[2], P[3]); mm = make_float4(Mm[0], Mm[1], Mm[2], Mm[3]); vv = make_float4(V[0], V[1], V[2], V[3]);
+}
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n4, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1, float rsqrt_bc2,
@@ -16,37 +53,32 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     const unsigned char* __restrict__ chunk_flags) {
     const float gs = gscale ? *gscale : 1.0f;
     const float step_size = lr / bc1;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // two quads per trip: i and i + stride (both coalesced across the wave)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+        const size_t j = i + stride;
+        const bool hj = j < n4;
         // per 64-element chunk (parameters start on 64-element boundaries of the flat buffer): bit 0 = weight decay applies
         // (HF Trainer decays neither biases nor LayerNorm weights), bit 1 = frozen parameter (requires_grad = False): untouched
-        const unsigned fl = chunk_flags ? chunk_flags[i >> 4] : 1u;
-        if (fl & 2u) {
-            if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            continue;
+        const unsigned fi = chunk_flags ? chunk_flags[i >> 4] : 1u;
+        const unsigned fj = hj ? (chunk_flags ? chunk_flags[j >> 4] : 1u) : 2u;
+        const bool ai = !(fi & 2u), aj = hj && !(fj & 2u);
+        float4 pi, gi, mi, vi, pj, gj, mj, vj;
+        if (ai) { pi = AW_LD(p, i); gi = AW_LD(g, i); mi = AW_LD(m, i); vi = AW_LD(v, i); }
+        if (aj) { pj = AW_LD(p, j); gj = AW_LD(g, j); mj = AW_LD(m, j); vj = AW_LD(v, j); }
+        if (ai) {
+            adamw_quad(pi, gi, mi, vi, gs, (fi & 1u) ? (1.0f - lr * wd) : 1.0f, beta1, beta2, eps, step_size, rsqrt_bc2);
+            AW_ST(p, i, pi); AW_ST(m, i, mi); AW_ST(v, i, vi);
+            if (shadow) { uint2 pk; pk.x = pack2bf(pi.x, pi.y); pk.y = pack2bf(pi.z, pi.w); AW_ST2(shadow, i, pk); }
         }
-        const float decay = (fl & 1u) ? (1.0f - lr * wd) : 1.0f;
-        float4 pp = reinterpret_cast<float4*>(p)[i];
-        float4 gg = reinterpret_cast<float4*>(g)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i];
-        float4 vv = reinterpret_cast<float4*>(v)[i];
-        float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x, gg.y, gg.z, gg.w}, Mm[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float gr = G[e] * gs;
-            P[e] *= decay;
-            Mm[e] = beta1 * Mm[e] + (1.0f - beta1) * gr;
-            V[e] = beta2 * V[e] + (1.0f - beta2) * gr * gr;
-            const float denom = sqrtf(V[e]) * rsqrt_bc2 + eps;
-            P[e] -= step_size * (Mm[e] / denom);
+        if (zero_grad) AW_ST(g, i, z4);
+        if (aj) {
+            adamw_quad(pj, gj, mj, vj, gs, (fj & 1u) ? (1.0f - lr * wd) : 1.0f, beta1, beta2, eps, step_size, rsqrt_bc2);
+            AW_ST(p, j, pj); AW_ST(m, j, mj); AW_ST(v, j, vj);
+            if (shadow) { uint2 pk; pk.x = pack2bf(pj.x, pj.y); pk.y = pack2bf(pj.z, pj.w); AW_ST2(shadow, j, pk); }
         }
-        reinterpret_cast<float4*>(p)[i] = make_float4(P[0], P[1], P[2], P[3]);
-        reinterpret_cast<float4*>(m)[i] = make_float4(Mm[0], Mm[1], Mm[2], Mm[3]);
-        reinterpret_cast<float4*>(v)[i] = make_float4(V[0], V[1], V[2], V[3]);
-        if (shadow) {
-            uint2 pk; pk.x = pack2bf(P[0], P[1]); pk.y = pack2bf(P[2], P[3]);
-            reinterpret_cast<uint2*>(shadow)[i] = pk;
-        }
-        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (zero_grad && hj) AW_ST(g, j, z4);
     }
 }
 
@@ -54,7 +86,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     __shared__ float red[4];
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const float4 a = reinterpret_cast<const float4*>(x)[i];
+        const float4 a = AW_LD(x, i);
         s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
     }
     s = wave_sum(s);
