@@ -7,8 +7,11 @@ import json
 import re
 import sys
 
-CLASSES = {"gemm_nt_dp_kernel": 1.356e8, "gemm_tn_dp_kernel": 4.3e8, "attn_fwd_kernel": 1.14e8, "attn_bwd_dq_kernel": 1.64e8,
-           "attn_bwd_dkv_kernel": 1.65e8, "ln_bwd": 1.007e8, "add_ln_fwd_kernel": 1.007e8, "adamw_kernel": 3.72e9, "attn_keepmask_kernel": 2.52e7}
+# algorithmic bytes per launch.  Round 4, second session: the FFN pre-activation tensor became a one-byte derivative (100.7 MB less
+# per layer over the eight NT launches: 1.356e8 -> 1.230e8 on average); AdamW runs as two launches (eagerly zeroed front part + encoder layers:
+# 3.38e9 B per step together)
+CLASSES = {"gemm_nt_dp_kernel": 1.230e8, "gemm_tn_dp_kernel": 4.3e8, "attn_fwd_kernel": 1.14e8, "attn_bwd_dq_kernel": 1.64e8,
+           "attn_bwd_dkv_kernel": 1.65e8, "ln_bwd": 1.007e8, "add_ln_fwd_kernel": 1.007e8, "adamw_kernel": 1.69e9, "attn_keepmask_kernel": 2.52e7}
 
 
 def main():
