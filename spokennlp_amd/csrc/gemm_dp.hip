@@ -633,7 +633,17 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
         if (i < a.nprob && t >= a.p[i].tile_begin) pi = i;
     const TNProblem P = a.p[pi];
     const int lt = t - P.tile_begin;
+    // tile order inside a problem: an XCD walks a contiguous run of ~tiles / 8 tiles whose workgroups move through the tokens together, so an operand
+    // panel that several of them share is fetched once per XCD.  With K' fastest, a problem with few N tiles and many K' tiles (dW of the FFN
+    // down-projection: 3 x 24) has every XCD read ALL K' panels of B (= h, 100 MB) once per N tile it touches: 290 MB for that problem; with N fastest
+    // an XCD's 27 tiles are a 3 x 9 block: all of A (25 MB) + 9 of 24 B panels.  -DAMDSEG_TN_KFAST: K' fastest everywhere (the order until round 4).
+#ifndef AMDSEG_TN_KFAST
+    const int tiles_n_ = P.N / 256;
+    const bool nfast = tiles_n_ < P.tiles_k;
+    const int tn = nfast ? lt % tiles_n_ : lt / P.tiles_k, tk = nfast ? lt / tiles_n_ : lt % P.tiles_k;
+#else
     const int tn = lt / P.tiles_k, tk = lt % P.tiles_k;
+#endif
     const int n0 = tn * 256, k0 = tk * 128;
 #define TN_TILE_A(s, i) (smem + (s) * TN_STG + (i) * 8192)
 #define TN_TILE_B(s, j) (smem + (s) * TN_STG + 32768 + (j) * 8192)

@@ -176,7 +176,10 @@ def test_lazy_gradient_zeroing_changes_no_bit_in_the_other_engines(dev, family):
     if family in ("ponet", "bigbird"):
         # PoNet's pooling backward merges run pieces with fp32 atomics, BigBird's token-type rows / list attention likewise: two EAGER runs already
         # differ in the last bits (and Adam at lr 1e-3 turns a last-bit gradient difference into up to ~lr per step): equal to that noise only
-        assert abs(a[0][2] - b[0][2]) < 1e-4 and float((a[1] - b[1]).abs().max()) < 5e-3
+        # (a weight whose gradient is noise around zero moves by +-lr per Adam step either way, so single weights may differ by several lr between
+        # two runs; gradients added onto stale ones would move nearly EVERY weight by ~lr = 1e-3: the mean difference tells the two apart)
+        assert abs(a[0][2] - b[0][2]) < 1e-2 * abs(b[0][2]), (a[0], b[0])
+        assert float((a[1] - b[1]).abs().mean()) < 1e-4, float((a[1] - b[1]).abs().mean())
         return
     assert a[0] == b[0]
     assert torch.equal(a[1], b[1])
