@@ -489,7 +489,10 @@ typedef struct amdseg_bert_layer_grads {    /* fp32, views into the flat gradien
 typedef struct amdseg_bert_layer_acts {     /* caller-owned activations; all but x_in are written by forward */
     const void* x_in;                       /* [M,H] layer input */
     void *qkv, *ctx, *z1, *x1, *u, *h, *z2, *x_out;   /* [M,3H] [M,H] [M,H] [M,H] [M,I] [M,I] [M,H] [M,H]; u may be NULL in
-                                                         inference (the pre-activation is only read by backward) */
+                                                         inference (only backward reads it); the bf16 forward then also leaves z1 / z2 holding the
+                                                         dense outputs instead of the pre-LayerNorm sums (backward's other input).  In bf16 training
+                                                         u holds what amdseg_bert_layer_bwd of the SAME cfg expects: the pre-activation, or gelu' of
+                                                         it as one byte per element (AMDSEG_EPI_DERIV_U8) where the shape allows */
     float *lse, *mean1, *rstd1, *mean2, *rstd2;       /* [B*heads*L] [M] [M] [M] [M] */
     /* AMDSEG_F32S only: bf16 split images [hi | hi | lo] of x_in, ctx, x1 and gelu(u): [M,3H] [M,3H] [M,3H] [M,3I] (written by
      * forward, read by the GEMMs of forward and by the weight gradients of backward; `h` is unused in that mode) */

@@ -33,7 +33,8 @@ int amdseg_gemm_nt_bias_drop_res_impl(const void* A, int lda, const void* B, int
 int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out,
                            float* mean, float* rstd, int M, int H, float eps, float p, uint64_t seed, int dtype,
                            hipStream_t s, void* out_image = nullptr,         // out_image: `out` also as the split image [M, 3H] ("parity" precision)
-                           void* keepbits = nullptr);                        // keepbits: [M * H / 8] bytes, the dropout decisions kept for ln_bwd
+                           void* keepbits = nullptr,                         // keepbits: [M * H / 8] bytes, the dropout decisions kept for ln_bwd
+                           bool keep_z = true);                              // false (inference): z = resid + dropout(y) is not written back (only backward reads it)
 int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                        void* dz, void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M,
                        int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s,

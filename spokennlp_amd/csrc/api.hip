@@ -519,7 +519,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     } else {
     RET_IF(amdseg_gemm_nt_impl(a->ctx, H, p->wo, H, a->z1, H, M, H, H, AMDSEG_EPI_BIAS, p->bo, nullptr, 0, nullptr, 0, 0, s));
     RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
-                                  site_seed(c->seed, li, 1), c->dtype, s, nullptr, a->drop1));
+                                  site_seed(c->seed, li, 1), c->dtype, s, nullptr, a->drop1, a->u != nullptr));    // u == NULL = inference: z is not kept
     }
     // FFN
     RET_IF(amdseg_gemm_nt_impl(a->x1, H, p->w1, H, a->h, I, M, I, H, AMDSEG_EPI_BIAS_GELU | (c->act ? AMDSEG_EPI_ACT_TANH : 0) | ffn_keep_deriv(c),
@@ -531,7 +531,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     } else {
     RET_IF(amdseg_gemm_nt_impl(a->h, I, p->w2, I, a->z2, H, M, H, I, AMDSEG_EPI_BIAS, p->b2, nullptr, 0, nullptr, 0, 0, s));
     RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, c->p_hidden,
-                                  site_seed(c->seed, li, 2), c->dtype, s, nullptr, a->drop2));
+                                  site_seed(c->seed, li, 2), c->dtype, s, nullptr, a->drop2, a->u != nullptr));
     }
     return AMDSEG_OK;
 }

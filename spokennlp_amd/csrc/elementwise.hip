@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void scatter_rows_sorted_kernel(const T* __res
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid, const float* gamma, const float* beta, T* out,
                                                          float* mean, float* rstd, int M, int H, float eps, uint32_t thresh,
-                                                         float inv_keep, uint64_t seed, bf16_t* img, uint8_t* keepbits) {
+                                                         float inv_keep, uint64_t seed, bf16_t* img, uint8_t* keepbits, bool keep_z) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int m = blockIdx.x * ROWS_PER_BLOCK + w;
     if (m >= M) return;
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
             for (int e = 0; e < 8; ++e) v[c][e] = x[c][e] + v[c][e];
         }
     }
+    if (keep_z) {
 #ifndef AMDSEG_PLAIN_Z_STORE     // z is read next by backward, in full 128-B lines per row piece: non-temporal stores (20.56 -> 19.86 us per launch)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
 #else
     row_store<T, NCH>(y_z + (size_t)m * H, nch, l, v);
 #endif
+    }
     }
     float mu, rs;
     row_stats(v, nch, l, H, eps, mu, rs);
@@ -1013,18 +1015,18 @@ int amdseg_scatter_rows_sorted_impl(const void* dz, const int64_t* keys, const i
 
 int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out,
                            float* mean, float* rstd, int M, int H, float eps, float p, uint64_t seed, int dtype,
-                           hipStream_t s, void* out_image, void* keepbits) {
+                           hipStream_t s, void* out_image, void* keepbits, bool keep_z) {
     if (!y_inout_z || !gamma || !beta || !out) return AMDSEG_ERR_ARG;      // resid == NULL: LayerNorm of y_inout_z as it stands (p ignored)
     if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
     uint32_t th; float ik; drop_params(p, th, ik);
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
-    const double bytes_per_el = resid ? 4.0 : 2.0;
+    const double bytes_per_el = resid ? (keep_z ? 4.0 : 3.0) : 2.0;
     if (dtype == AMDSEG_BF16)
         ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, bytes_per_el * M * H * 2, add_ln_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta,
-                           (bf16_t*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits);
+                           (bf16_t*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits, keep_z);
     else
         ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, bytes_per_el * M * H * 4, add_ln_fwd_kernel, float, H, grid, dim3(256), 0, s, (float*)y_inout_z, (const float*)resid, gamma, beta,
-                           (float*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits);
+                           (float*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits, keep_z);
     return amdseg_launch_status();
 }
 
