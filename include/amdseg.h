@@ -54,7 +54,7 @@ extern "C" {
                                        erf GELU only, shapes of the deep-pipeline kernel only (M % 256 == 0, N % 192 == 0 or N % 256 == 0, K >= 128):
                                        AMDSEG_ERR_SHAPE otherwise.  What amdseg_bert_layer_fwd / _bwd use between themselves when the shape allows */
 #define AMDSEG_EPI_DERIV_U8 0x400 /* with AMDSEG_EPI_KEEP_DERIV: the derivative is ONE BYTE per element, q = round((gelu' + 0.135) * 200) (absolute error <= 0.0025);
-                                     C2 / R point to unsigned char [M, ld] (ld in bytes, % 8 == 0); N % 256 == 0 */
+                                     C2 / R point to unsigned char [M, ld] (ld in bytes, % 8 == 0); N % 256 == 0; also with AMDSEG_EPI_ACT_TANH (gelu_new) */
 #define AMDSEG_EPI_ACT_TANH 0x100 /* OR-ed into BIAS_GELU / GELU_BWD: "gelu_new" (tanh form, BigBird's hidden_act) instead of erf */
 
 typedef void* amdseg_stream_t;  /* hipStream_t */

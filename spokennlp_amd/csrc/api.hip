@@ -402,21 +402,25 @@ static int parity_unfused() {
 // bf16 training: what the FFN up-projection keeps for backward in acts.u.  0: the pre-activation u (bf16; the backward GEMM's epilogue evaluates
 // gelu'(u)).  1: gelu'(u) in bf16 (AMDSEG_EPI_KEEP_DERIV: the backward epilogue is one multiply -- measured neutral, its cost is reading the
 // tensor, not the arithmetic).  2: gelu'(u) as ONE BYTE per element (AMDSEG_EPI_DERIV_U8): 100 MB less HBM traffic per bert-base layer in two
-// epilogues that are HBM time.  Needs the erf GELU and shapes of the 256-wide deep-pipeline tile; forward and backward evaluate the same
+// epilogues that are HBM time.  Needs shapes of the 256-wide deep-pipeline tile (forms 0 / 1: and the erf GELU); forward and backward evaluate the same
 // predicate on the same cfg.  AMDSEG_FFN_KEEP_DERIV = 0 / 1 / 2 picks the form.
 static inline int ffn_keep_deriv(const amdseg_bert_cfg* c) {
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("AMDSEG_FFN_KEEP_DERIV"); mode = e ? atoi(e) : 2; }
     const int M = c->B * c->L;
-    if (!mode || c->act != 0 || c->dtype != AMDSEG_BF16 || (M % 256) || c->H < 128 || (c->H % 64)) return 0;
-    if (mode == 2 && (c->I % 256) == 0) {
+    int mode_eff = mode;
+    // (gelu_new, BigBird: the one-byte form exists -- AMDSEG_EPI_ACT_TANH | _KEEP_DERIV | _DERIV_U8 -- and measured 343.1 vs 344.4 seq/s at bigbird-base
+    //  8 x 4096: value and derivative of the tanh form are two separate evaluations, their arithmetic costs what the bytes save; AMDSEG_FFN_KEEP_DERIV=3 forces it)
+    if (!mode || c->dtype != AMDSEG_BF16 || (M % 256) || c->H < 128 || (c->H % 64) || (c->act != 0 && mode != 3)) return 0;
+    if (mode == 3) mode_eff = 2;
+    if (mode_eff == 2 && (c->I % 256) == 0) {
         // ... unless the up-projection would take the 192-wide tile for its rounds (amdseg_launch_nt_dp: M = 8192, the 4 x 2048 launch shape), which the
         // one-byte epilogue does not have: there the narrow tile is worth more than the bytes (longformer-base 4 x 2048: 368 vs 364 seq/s)
         const int t256 = (M / 256) * (c->I / 256), t192 = (c->I % 192) == 0 ? (M / 256) * (c->I / 192) : 0;
         const bool narrow = t192 > 0 && 0.78f * (float)((t192 + 255) / 256) < (float)((t256 + 255) / 256);
-        return narrow ? 0 : (AMDSEG_EPI_KEEP_DERIV | AMDSEG_EPI_DERIV_U8);
+        return narrow ? 0 : (AMDSEG_EPI_KEEP_DERIV | AMDSEG_EPI_DERIV_U8);       // (the callers OR AMDSEG_EPI_ACT_TANH in for gelu_new)
     }
-    if (mode == 1 && ((c->I % 256) == 0 || (c->I % 192) == 0)) return AMDSEG_EPI_KEEP_DERIV;
+    if (mode_eff == 1 && ((c->I % 256) == 0 || (c->I % 192) == 0)) return AMDSEG_EPI_KEEP_DERIV;
     return 0;
 }
 

@@ -634,7 +634,7 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     const int keepd = (epi >> 9) & 1;                       // AMDSEG_EPI_KEEP_DERIV: C2 / R is gelu'(pre-activation), not the pre-activation
     const int d8 = (epi >> 10) & 1;                         // AMDSEG_EPI_DERIV_U8: ... as one byte per element
     epi &= 0xff;
-    if (keepd && (act || (epi != EPI_BIAS_GELU && epi != EPI_GELU_BWD))) return AMDSEG_ERR_ARG;
+    if (keepd && ((act && !d8) || (epi != EPI_BIAS_GELU && epi != EPI_GELU_BWD))) return AMDSEG_ERR_ARG;   // gelu_new: the one-byte form only
     if (d8 && !keepd) return AMDSEG_ERR_ARG;
     const bool big = (M % PP_BM) == 0 && (N % PP_BN) == 0, small = (M % BM) == 0 && (N % BN) == 0;
     if (M <= 0 || N <= 0 || K <= 0 || !(big || small) || (K % BK)) return AMDSEG_ERR_SHAPE;
@@ -660,7 +660,7 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
             if (!bias || out_fp32 || (C2 && (ldc2 % 8))) return AMDSEG_ERR_ARG;       // C2 == NULL: gelu output only (inference)
             if (keepd) {
                 if ((M % 256) || ((N % 256) && (N % 192)) || K < 128 || (d8 && (N % 256))) return AMDSEG_ERR_SHAPE;
-                if (d8) return amdseg_launch_nt_dp<EPI_BIAS_GELU_DG8, bf16_t>(a, stream);
+                if (d8) return act ? amdseg_launch_nt_dp<EPI_BIAS_GELU_DG8_TANH, bf16_t>(a, stream) : amdseg_launch_nt_dp<EPI_BIAS_GELU_DG8, bf16_t>(a, stream);
                 return amdseg_launch_nt_dp<EPI_BIAS_GELU_DG, bf16_t>(a, stream);
             }
             return act ? launch_nt<EPI_BIAS_GELU_TANH, bf16_t>(a, stream) : launch_nt<EPI_BIAS_GELU, bf16_t>(a, stream);

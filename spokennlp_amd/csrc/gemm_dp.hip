@@ -369,7 +369,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                 if (EPI == EPI_BIAS_GELU_DG8) {                // ... the derivative as one byte per element
                     if (a.C2) {
                         float d[8];
-                        gelu_both4(v, d); gelu_both4(v + 4, d + 4);
+                        if (ACT) {                                 // gelu_new (BigBird): value and derivative evaluated separately
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { d[e] = gelu_tanh_grad_fast(v[e]); v[e] = gelu_tanh_fast(v[e]); }
+                        } else { gelu_both4(v, d); gelu_both4(v + 4, d + 4); }
                         uint2 q; q.x = gelu_dq_pack4(d); q.y = gelu_dq_pack4(d + 4);
 #if AMDSEG_ABL_EPI == 1
                         asm volatile("" :: "v"(q.x), "v"(q.y));
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                         //  went 59.8 -> 63.5 us: partial lines that bypass L2's write combining)
                         *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(a.C2) + gm * a.ldc2 + col) = q;
 #endif
-                    } else { gelu_act4(v, 0); gelu_act4(v + 4, 0); }
+                    } else { gelu_act4(v, ACT); gelu_act4(v + 4, ACT); }
                 } else if (EPI == EPI_MUL_RES8) {
                     gelu_dq_mul4(v, r8[ep].x); gelu_dq_mul4(v + 4, r8[ep].y);
                 } else if (EPI == EPI_BIAS_GELU_DG) {          // gelu and, for backward, its derivative from one sigmoid (AMDSEG_EPI_KEEP_DERIV)
@@ -577,7 +580,7 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
 DP_INST(EPI_NONE, bf16_t) DP_INST(EPI_NONE, float) DP_INST(EPI_BIAS, bf16_t) DP_INST(EPI_BIAS, float) DP_INST(EPI_BIAS_GELU, bf16_t)
 DP_INST(EPI_ADD_RES, bf16_t) DP_INST(EPI_ADD_RES, float) DP_INST(EPI_GELU_BWD, bf16_t)
 DP_INST(EPI_BIAS_GELU_TANH, bf16_t) DP_INST(EPI_GELU_BWD_TANH, bf16_t) DP_INST(EPI_BIAS_SPLIT, bf16_t) DP_INST(EPI_GELU_BWD_SPLIT, bf16_t)
-DP_INST(EPI_BIAS_GELU_SPLIT, float) DP_INST(EPI_BIAS_DROP_RES, bf16_t) DP_INST(EPI_BIAS_GELU_DG, bf16_t) DP_INST(EPI_MUL_RES, bf16_t) DP_INST(EPI_BIAS_GELU_DG8, bf16_t) DP_INST(EPI_MUL_RES8, bf16_t)
+DP_INST(EPI_BIAS_GELU_SPLIT, float) DP_INST(EPI_BIAS_DROP_RES, bf16_t) DP_INST(EPI_BIAS_GELU_DG, bf16_t) DP_INST(EPI_MUL_RES, bf16_t) DP_INST(EPI_BIAS_GELU_DG8, bf16_t) DP_INST(EPI_MUL_RES8, bf16_t) DP_INST(EPI_BIAS_GELU_DG8_TANH, bf16_t)
 
 
 // ==================================================================================================== gemm_tn, deep pipeline

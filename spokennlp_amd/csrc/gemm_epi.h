@@ -14,13 +14,14 @@ enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_
        EPI_BIAS_DROP_RES = 10,
        EPI_BIAS_GELU_DG = 11,                               // AMDSEG_EPI_BIAS_GELU | AMDSEG_EPI_KEEP_DERIV: C = gelu(A B^T + bias), C2 = gelu'(A B^T + bias) (deep-pipeline kernel only)
        EPI_MUL_RES = 12,
-       EPI_BIAS_GELU_DG8 = 13, EPI_MUL_RES8 = 14 };        // the same pair with the derivative as ONE BYTE per element (AMDSEG_EPI_DERIV_U8), 256-wide tile only                                  // AMDSEG_EPI_GELU_BWD | AMDSEG_EPI_KEEP_DERIV: C = (A B^T) * R, R = the derivative kept by the forward                            // C = R + dropout(A B^T + bias), keep decisions -> keepbits (1 byte per 8 columns): the dense +
+       EPI_BIAS_GELU_DG8 = 13, EPI_MUL_RES8 = 14,
+       EPI_BIAS_GELU_DG8_TANH = 15 };        // the same pair with the derivative as ONE BYTE per element (AMDSEG_EPI_DERIV_U8), 256-wide tile only                                  // AMDSEG_EPI_GELU_BWD | AMDSEG_EPI_KEEP_DERIV: C = (A B^T) * R, R = the derivative kept by the forward                            // C = R + dropout(A B^T + bias), keep decisions -> keepbits (1 byte per 8 columns): the dense +
                                                             // dropout + residual of BertSelfOutput / BertOutput in the GEMM's epilogue (256-wide dp kernel only)                           // C (fp32) = A B^T + bias (the pre-activation backward reads); C2 = bf16 image [hi | hi | lo] of gelu_erf(that)                            // x = (A B^T) * gelu_erf'(R), R fp32: hi -> C and C + dup_off columns, lo -> C2 (the [hi | hi | lo]
                                                             // image the next split GEMM and the weight gradient read); 256-wide dp kernel only
 // the kernels are instantiated on the extended value EPIX; EPI = what the epilogue does, ACT = which GELU (a compile-time constant:
 // a run-time flag became one scalar branch PER ELEMENT in the epilogue)
-#define EPI_BASE(X) ((X) == EPI_BIAS_GELU_TANH ? EPI_BIAS_GELU : (X) == EPI_GELU_BWD_TANH ? EPI_GELU_BWD : (X))
-#define EPI_ACT(X) ((X) >= EPI_BIAS_GELU_TANH ? 1 : 0)
+#define EPI_BASE(X) ((X) == EPI_BIAS_GELU_TANH ? EPI_BIAS_GELU : (X) == EPI_GELU_BWD_TANH ? EPI_GELU_BWD : (X) == EPI_BIAS_GELU_DG8_TANH ? EPI_BIAS_GELU_DG8 : (X))
+#define EPI_ACT(X) (((X) == EPI_BIAS_GELU_TANH || (X) == EPI_GELU_BWD_TANH || (X) == EPI_BIAS_GELU_DG8_TANH) ? 1 : 0)
 
 struct GemmNTArgs {
     const bf16_t* A; const bf16_t* B; void* C; const float* bias; const bf16_t* R; bf16_t* C2; unsigned long long* dbg;

@@ -136,6 +136,17 @@ def _check_all_epilogues(dev, M, N, K):
                                      None, 0, 0, st)
         assert rc == 0
         assert rel_err(dU, base * got) < 4e-3
+        # the same for gelu_new (AMDSEG_EPI_ACT_TANH: BigBird's hidden_act)
+        x = (base + bias).double()
+        inner = 0.7978845608028654 * (x + 0.044715 * x ** 3)
+        th = torch.tanh(inner)
+        want_h = (0.5 * x * (1 + th)).float()
+        want_d = (0.5 * (1 + th) + 0.5 * x * (1 - th * th) * 0.7978845608028654 * (1 + 3 * 0.044715 * x * x)).float()
+        rc = L.load().amdseg_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, H8.data_ptr(), N, M, N, K, ops.EPI_BIAS_GELU | fl | L.EPI_ACT_TANH, bias.data_ptr(),
+                                     None, 0, Q.data_ptr(), N, 0, st)
+        assert rc == 0
+        assert rel_err(H8, want_h) < 4e-3
+        assert ((Q.float() * 0.005 - 0.135) - want_d).abs().max().item() < 0.0025 + 2e-3
     # asymmetric small-integer operands: exact, catches any row/col or fragment swap
     A2 = torch.zeros(M, K, device=dev); B2 = torch.zeros(N, K, device=dev)
     A2[:, 0] = torch.arange(M, device=dev) % 61; B2[:, 0] = 1.0
