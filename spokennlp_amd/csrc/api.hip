@@ -408,11 +408,10 @@ static inline int ffn_keep_deriv(const amdseg_bert_cfg* c) {
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("AMDSEG_FFN_KEEP_DERIV"); mode = e ? atoi(e) : 2; }
     const int M = c->B * c->L;
-    int mode_eff = mode;
-    // (gelu_new, BigBird: the one-byte form exists -- AMDSEG_EPI_ACT_TANH | _KEEP_DERIV | _DERIV_U8 -- and measured 343.1 vs 344.4 seq/s at bigbird-base
-    //  8 x 4096: value and derivative of the tanh form are two separate evaluations, their arithmetic costs what the bytes save; AMDSEG_FFN_KEEP_DERIV=3 forces it)
-    if (!mode || c->dtype != AMDSEG_BF16 || (M % 256) || c->H < 128 || (c->H % 64) || (c->act != 0 && mode != 3)) return 0;
-    if (mode == 3) mode_eff = 2;
+    // gelu_new (BigBird): the one-byte form only (value and derivative from ONE tanh: bigbird-base 8 x 4096 332.6 -> 336.8 seq/s; evaluated
+    // separately they cost what the bytes save: 343.1 vs 344.4 on another box)
+    if (!mode || c->dtype != AMDSEG_BF16 || (M % 256) || c->H < 128 || (c->H % 64) || (c->act != 0 && mode != 2)) return 0;
+    const int mode_eff = mode;
     if (mode_eff == 2 && (c->I % 256) == 0) {
         // ... unless the up-projection would take the 192-wide tile for its rounds (amdseg_launch_nt_dp: M = 8192, the 4 x 2048 launch shape), which the
         // one-byte epilogue does not have: there the narrow tile is worth more than the bytes (longformer-base 4 x 2048: 368 vs 364 seq/s)

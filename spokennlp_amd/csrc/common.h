@@ -236,6 +236,15 @@ __device__ __forceinline__ float gelu_tanh_grad_fast(float x) {
     const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u));
     return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 0.134145f * x2);
 }
+// value and derivative of gelu_new from ONE tanh (one exp + one rcp)
+__device__ __forceinline__ void gelu_tanh_both(float x, float& h, float& d) {
+    const float x2 = x * x;
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u));
+    const float hp = 0.5f * (1.0f + t);
+    h = x * hp;
+    d = hp + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 0.134145f * x2);
+}
 // act: 0 = exact (erf) GELU, 1 = gelu_new; wave-uniform
 __device__ __forceinline__ float gelu_act(float x, int act) { return act ? gelu_tanh_fast(x) : gelu_fast(x); }
 __device__ __forceinline__ float gelu_grad_act(float x, int act) { return act ? gelu_tanh_grad_fast(x) : gelu_grad_fast(x); }

@@ -369,9 +369,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                 if (EPI == EPI_BIAS_GELU_DG8) {                // ... the derivative as one byte per element
                     if (a.C2) {
                         float d[8];
-                        if (ACT) {                                 // gelu_new (BigBird): value and derivative evaluated separately
+                        if (ACT) {                                 // gelu_new (BigBird): value and derivative from one tanh
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { d[e] = gelu_tanh_grad_fast(v[e]); v[e] = gelu_tanh_fast(v[e]); }
+                            for (int e = 0; e < 8; ++e) { float h_; gelu_tanh_both(v[e], h_, d[e]); v[e] = h_; }
                         } else { gelu_both4(v, d); gelu_both4(v + 4, d + 4); }
                         uint2 q; q.x = gelu_dq_pack4(d); q.y = gelu_dq_pack4(d + 4);
 #if AMDSEG_ABL_EPI == 1
