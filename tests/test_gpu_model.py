@@ -278,7 +278,7 @@ def test_fused_adamw_step_matches_torch(dev):
     # the optimiser pass zeroed everything but the encoder layers' slice, which the next backward overwrites (engine.lazy_zero); any other
     # reader flushes it first
     fp = m.engine().fp
-    assert fp.grad_stale and fp.flat_g[:fp.layers_begin].abs().max().item() == 0.0
+    assert fp.grad_stale == m.engine().lazy_zero and fp.flat_g[:fp.layers_begin].abs().max().item() == 0.0     # (AMDSEG_LAZY_ZERO=0: everything zeroed)
     fp.flush_stale()
     assert not fp.grad_stale and fp.flat_g.abs().max().item() == 0.0
 
