@@ -424,6 +424,10 @@ int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float
 #define AMDSEG_PROF_LN_BWD 6       /* ln_bwd_kernel: read dy, z; write dz (+ dbranch with dropout)        = (3 or 4) * M * H * sizeof(act) */
 #define AMDSEG_PROF_ADAMW 7        /* adamw_kernel: p, g, m, v in; p, m, v out (+ bf16 shadow, + zeroed g) = 28 (+2) (+4) B per parameter */
 #define AMDSEG_PROF_KEEPMASK 8     /* attn_keepmask_kernel: the mask bytes written */
+/* Compute units the launch-geometry rules may count on (0 = all; returns the previous value).  A process whose backward overlaps an RCCL all-reduce
+ * sets it to (CUs - RCCL channels): the GEMM tile width is chosen by rounds of workgroups against this number (a 256-tile grid on 240 free CUs is two
+ * rounds).  spokennlp_amd/dp.py does so when world > 1.  ABI 10. */
+int amdseg_set_cu_budget(int cus);
 int amdseg_prof_enable(int on);
 int amdseg_prof_reset(void);
 int amdseg_prof_read(int cls, double* total_us, double* total_work, long long* launches);

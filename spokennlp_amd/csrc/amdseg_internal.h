@@ -173,3 +173,8 @@ int amdseg_lf_global_bwd_a_impl(void* dctx, int dtype, const float* Wv, const fl
 int amdseg_lf_global_bwd_rest_impl(const void* x, int x_dtype, void* dx, int dx_dtype, const float* Wq, const float* Wk, const float* qg,
                                    const float* dout, const float* y, const float* sp, const float* dr, float* dqg, float* dWq, float* dbq,
                                    float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads, float scale, hipStream_t s);
+
+// CUs the launch-geometry rules may count on (gemm_dp.hip)
+extern int g_amdseg_cu_budget;
+int amdseg_cu_budget();
+int amdseg_num_cus();

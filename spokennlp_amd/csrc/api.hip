@@ -9,6 +9,7 @@
 extern "C" {
 
 int amdseg_abi_version(void) { return AMDSEG_ABI_VERSION; }
+int amdseg_set_cu_budget(int cus) { const int prev = g_amdseg_cu_budget; g_amdseg_cu_budget = cus > 0 ? cus : 0; return prev; }
 
 const char* amdseg_error_string(int code) {
     switch (code) {
@@ -415,8 +416,9 @@ static inline int ffn_keep_deriv(const amdseg_bert_cfg* c) {
     if (mode_eff == 2 && (c->I % 256) == 0) {
         // ... unless the up-projection would take the 192-wide tile for its rounds (amdseg_launch_nt_dp: M = 8192, the 4 x 2048 launch shape), which the
         // one-byte epilogue does not have: there the narrow tile is worth more than the bytes (longformer-base 4 x 2048: 368 vs 364 seq/s)
-        const int t256 = (M / 256) * (c->I / 256), t192 = (c->I % 192) == 0 ? (M / 256) * (c->I / 192) : 0;
-        const bool narrow = t192 > 0 && 0.78f * (float)((t192 + 255) / 256) < (float)((t256 + 255) / 256);
+        // (counted against ALL the CUs, not the momentary budget of amdseg_set_cu_budget: forward and backward must come to the same answer)
+        const int t256 = (M / 256) * (c->I / 256), t192 = (c->I % 192) == 0 ? (M / 256) * (c->I / 192) : 0, C = amdseg_num_cus();
+        const bool narrow = t192 > 0 && 0.78f * (float)((t192 + C - 1) / C) < (float)((t256 + C - 1) / C);
         return narrow ? 0 : (AMDSEG_EPI_KEEP_DERIV | AMDSEG_EPI_DERIV_U8);       // (the callers OR AMDSEG_EPI_ACT_TANH in for gelu_new)
     }
     if (mode_eff == 1 && ((c->I % 256) == 0 || (c->I % 192) == 0)) return AMDSEG_EPI_KEEP_DERIV;

@@ -540,6 +540,19 @@ static int launch_nt_dp_nf(const GemmNTArgs& a_in, hipStream_t s) {
     return amdseg_launch_status();
 }
 
+// CUs the grids of this process can count on (amdseg_set_cu_budget / AMDSEG_CU_BUDGET; 0 = all of them).  An overlapped RCCL all-reduce keeps one CU per
+// channel for the whole of backward -- a deep-pipeline workgroup needs a CU's entire register file, so those CUs are lost to it -- and a grid of
+// exactly 256 tiles then runs TWO rounds: measured with tools/dbg/cu_hog.sh, 8 / 16 / 32 occupied CUs all cost the training step 10 % (NT launch
+// average 61 -> 72 us), 64 double the weight-gradient GEMM (216 tiles).  The tile-width choice below counts rounds against the budget.
+int g_amdseg_cu_budget = 0;
+int amdseg_num_cus() { return dp_num_cus(); }
+int amdseg_cu_budget() {
+    static int env = -1, cus = 0;
+    if (env < 0) { const char* e = getenv("AMDSEG_CU_BUDGET"); env = e ? atoi(e) : 0; cus = dp_num_cus(); }
+    const int b = g_amdseg_cu_budget > 0 ? g_amdseg_cu_budget : env;
+    return b > 0 && b < cus ? b : cus;
+}
+
 // tile width: 256 whenever N allows it, 192 for the other multiples of 192.  Picking 192 for wave quantisation (N = 768: 256 tiles
 // instead of 192, N = 2304: 3 full rounds instead of 2.25) measured NO gain in the training step (QKV 67.1 vs 68.6 us, N = 768
 // K = 3072 78.3 vs 79.8, N = 768 K = 768 27.0 vs 25.0): the chip is clock/power limited under MFMA load, 192 busy CUs run as fast
@@ -555,8 +568,8 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
     constexpr int EB = EPI_BASE(EPIX);
     bool narrow = false;
     if (ok256 && ok192 && force == 0 && (EB == EPI_NONE || EB == EPI_BIAS || EB == EPI_BIAS_GELU || EB == EPI_BIAS_GELU_DG)) {
-        const int t256 = (a_in.M / DP_BM) * (a_in.N / 256), t192 = (a_in.M / DP_BM) * (a_in.N / 192);
-        narrow = 0.78f * (float)((t192 + 255) / 256) < (float)((t256 + 255) / 256);
+        const int t256 = (a_in.M / DP_BM) * (a_in.N / 256), t192 = (a_in.M / DP_BM) * (a_in.N / 192), C = amdseg_cu_budget();
+        narrow = 0.78f * (float)((t192 + C - 1) / C) < (float)((t256 + C - 1) / C);
     }
     constexpr bool direct_only = EB == EPI_BIAS_SPLIT || EB == EPI_GELU_BWD_SPLIT || EB == EPI_BIAS_GELU_SPLIT || EB == EPI_BIAS_DROP_RES ||
                                  EB == EPI_BIAS_GELU_DG8 || EB == EPI_MUL_RES8;    // epilogues of the 256-wide tile only

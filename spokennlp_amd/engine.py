@@ -245,6 +245,13 @@ class BertEncoderEngine:
                 dist.broadcast(self.fp.flat_p, src=0)         # what torch DDP does at construction: every rank starts from rank 0's weights
                 self.refresh_shadows(force=True)
             self.buckets = GradBuckets(self.fp)
+            if self.device.type == "cuda" and dist.get_backend() == "nccl":
+                # the CUs the RCCL channels hold during the overlapped exchange are not available to the GEMM grids (include/amdseg.h)
+                import os
+                nch = int(os.environ.get("NCCL_MAX_NCHANNELS", "0") or 0)
+                if nch > 0:
+                    cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+                    self._bwd_cu_budget = max(cus - nch, cus // 2)       # applied around backward only: forward has every CU
         return self.buckets is not None
 
     @contextlib.contextmanager
@@ -748,6 +755,18 @@ class BertEncoderEngine:
 
     def backward(self, ctx, dseq, accumulate=True):
         """dseq: fp32 [B, L, H] gradient of the encoder output.  Writes every parameter gradient into flat_g."""
+        budget = getattr(self, "_bwd_cu_budget", 0) if ((self.buckets is not None and self.grad_sync) or getattr(self, "_bwd_cu_budget_always", False)) else 0
+        if not budget:
+            return self._backward(ctx, dseq, accumulate)
+        # data parallel: the bucket all-reduces run beside this backward and their RCCL channels hold CUs (tile widths are chosen at launch time)
+        lib = L.load()
+        prev = lib.amdseg_set_cu_budget(budget)
+        try:
+            return self._backward(ctx, dseq, accumulate)
+        finally:
+            lib.amdseg_set_cu_budget(prev)
+
+    def _backward(self, ctx, dseq, accumulate=True):
         B, Lseq = ctx["B"], ctx["L"]
         M = B * Lseq
         A = ctx["arena"]

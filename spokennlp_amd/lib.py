@@ -125,6 +125,7 @@ _PROTOS = {
     "amdseg_heads_bwd_ce_focal": [vp, i32, i32, i32, vp, vp, f32, f32, vp, vp],
     "amdseg_heads_bwd_rows": [vp, vp, i32, i32, vp, vp, C.c_long, C.c_long, C.c_long, i32, i32, i32, f32, vp, vp, C.c_long, C.c_long, i32, i32,
                               vp, vp, f32, f32, i32, vp, C.c_size_t, vp],
+    "amdseg_set_cu_budget": [i32],
     "amdseg_prof_enable": [i32],
     "amdseg_prof_reset": [],
     "amdseg_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],

@@ -51,7 +51,7 @@ def test_scatter_rows_sorted_equals_index_add_and_repeats_bitwise(dev, dtype):
     assert torch.equal(outs[0][k0], serial + 0.5)
 
 
-def _three_steps(dev, precision, deterministic, case="tiny_L128", lazy_zero=None, skip_backward_at=None):
+def _three_steps(dev, precision, deterministic, case="tiny_L128", lazy_zero=None, skip_backward_at=None, bwd_cu_budget=0):
     if case == "bert_base_L512":                           # bert-base, 4 x 512 tokens (x 2 with the augmented half): the H = 768 kernels
         from tests.test_gpu_fullsize import _fullsize_case
         z, sd, batch, arch, fl = _fullsize_case()
@@ -71,6 +71,8 @@ def _three_steps(dev, precision, deterministic, case="tiny_L128", lazy_zero=None
         loss, _, _ = m(**b)
         if lazy_zero is not None:
             m.engine().lazy_zero = lazy_zero
+        if bwd_cu_budget:
+            m.engine()._bwd_cu_budget, m.engine()._bwd_cu_budget_always = bwd_cu_budget, True
         if it != skip_backward_at:                         # (a step without a backward: every gradient counts as zero)
             loss.backward()
         losses.append(loss.item())
@@ -183,3 +185,15 @@ def test_lazy_gradient_zeroing_changes_no_bit_in_the_other_engines(dev, family):
         return
     assert a[0] == b[0]
     assert torch.equal(a[1], b[1])
+
+
+def test_backward_under_a_cu_budget_changes_no_bit(dev):
+    """data parallel: backward runs beside the RCCL channels of the bucket all-reduces and chooses its GEMM tile widths by rounds of workgroups over
+    the CUs that are left (amdseg_set_cu_budget): another tile width is another launch geometry, not another summation order -- bert-base 4 x 512,
+    three steps, the same bits in every parameter with 240 of 256 CUs budgeted"""
+    a = _three_steps(dev, "bf16", True, "bert_base_L512", bwd_cu_budget=240)
+    b = _three_steps(dev, "bf16", True, "bert_base_L512")
+    assert a[0] == b[0]
+    assert torch.equal(a[1], b[1])
+    from spokennlp_amd import lib as L
+    assert L.load().amdseg_set_cu_budget(0) == 0           # the budget was restored behind every backward
