@@ -299,6 +299,8 @@ def dp_record(eng, world, device, sync_marks, step, first_step, args):
                exposed_comm_ms_median=round(exposed[len(exposed) // 2], 3) if exposed else None,
                exposed_comm_method="HIP events on the compute stream around finish_grad_sync() (tail bucket issue + wait for every bucket), "
                                    "timed region average")
+    rec["nccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
+    rec["backward_cu_budget"] = getattr(eng, "_bwd_cu_budget", 0) or None     # CUs the tile-width rule of backward counts on (amdseg_set_cu_budget)
     try:
         if dist.get_backend() == "nccl":
             rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())

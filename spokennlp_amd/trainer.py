@@ -16,9 +16,16 @@ puts the engine's own pieces behind the same loop, nothing else changes (callbac
     `gradient_accumulation_steps` > 1 runs the non-final micro-steps under `no_sync()` so every bucket is reduced exactly once.
 """
 import contextlib
+import os
 
 import torch
 import transformers
+
+# multi-GPU launches: the ring of the engine's overlapped gradient exchange gets 16 channels unless the launcher chose otherwise (every RCCL
+# channel holds a CU for the length of the exchange and the GEMM grids of backward are sized by rounds over the CUs: dp.init_from_env,
+# profiles/r04_cu_budget_probe.md).  Has to be in the environment before the process group exists, i.e. before TrainingArguments is built.
+if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
 
 from . import lib as L
 
