@@ -22,8 +22,8 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         # RCCL keeps one CU per channel busy for the whole of an overlapped all-reduce, and the GEMM grids of this path are sized by rounds of
         # workgroups over the CUs (csrc/gemm_dp.hip: amdseg_cu_budget): 436 MB per 13-ms step need tens of GB/s, not every link saturated, so
-        # the ring gets 16 channels unless the launcher says otherwise (the weight-gradient GEMM's 216 tiles need 216 free CUs)
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
+        # the ring gets at most 32 channels unless the launcher says otherwise (the weight-gradient GEMM's 216 tiles need 216 free CUs; 224 are left)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         if backend is None:                      # AMDSEG_DIST_BACKEND=gloo: exercise the multi-rank path on a box with fewer GPUs than ranks
             backend = os.environ.get("AMDSEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():

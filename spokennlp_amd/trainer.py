@@ -21,11 +21,11 @@ import os
 import torch
 import transformers
 
-# multi-GPU launches: the ring of the engine's overlapped gradient exchange gets 16 channels unless the launcher chose otherwise (every RCCL
+# multi-GPU launches: the ring of the engine's overlapped gradient exchange gets at most 32 channels unless the launcher chose otherwise (every RCCL
 # channel holds a CU for the length of the exchange and the GEMM grids of backward are sized by rounds over the CUs: dp.init_from_env,
 # profiles/r04_cu_budget_probe.md).  Has to be in the environment before the process group exists, i.e. before TrainingArguments is built.
 if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
-    os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
 
 from . import lib as L
 
