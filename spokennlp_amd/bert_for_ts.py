@@ -401,6 +401,10 @@ class TopicSegHeadsMixin:
         if cfg.weight_label_zero != 0.5:
             class_w = torch.tensor([cfg.weight_label_zero, 1 - cfg.weight_label_zero], dtype=torch.float32, device=seq.device)
         clf, tc = self.loss_calculator.classifier, self.loss_calculator.tssp.classifier
+        eng = self.engine()
+        if not eng.ddp_compat() and all(t.requires_grad for t in (clf.weight, clf.bias)) and (not use_tssp or all(t.requires_grad for t in (tc.weight, tc.bias))):
+            # native mode: the heads' backward writes these gradients into their .grad views itself (torch DDP needs them from autograd instead)
+            P["direct"] = (clf.weight, clf.bias, tc.weight if use_tssp else None, tc.bias if use_tssp else None)
         loss, logits_all = FusedHeadsFn.apply(seq.reshape(-1, seq.shape[-1]), clf.weight, clf.bias, tc.weight if use_tssp else None,
                                               tc.bias if use_tssp else None, labels_all, up.dev, class_w, P)
         C_ = logits_all.shape[-1]

