@@ -971,7 +971,7 @@ class EncoderFn(torch.autograd.Function):
             grads = eng.compat_backward(lambda: eng.backward(ctx.ectx, dseq, accumulate=True))
             return (torch.zeros(1, device=dseq.device),) + (None,) * 7 + grads
         eng.backward(ctx.ectx, dseq, accumulate=True)
-        return (torch.zeros(1, device=dseq.device),) + (None,) * 7
+        return (None,) * 8                              # (the trigger needs no gradient: None = nothing to accumulate, no fill / add kernel per step)
 
 
 class RowDotFn(torch.autograd.Function):

@@ -276,7 +276,7 @@ class _PoNetEncoderFn(torch.autograd.Function):
             grads = eng.compat_backward(lambda: eng.backward(ctx.ectx, dseq, accumulate=True))
             return (torch.zeros(1, device=dseq.device),) + (None,) * 8 + grads
         eng.backward(ctx.ectx, dseq, accumulate=True)
-        return (torch.zeros(1, device=dseq.device),) + (None,) * 8
+        return (None,) * 9                              # (the trigger needs no gradient: None = nothing to accumulate, no fill / add kernel per step)
 
 
 # ------------------------------------------------------------------------------------------------ model
