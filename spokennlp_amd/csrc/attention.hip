@@ -112,7 +112,14 @@ __global__ __launch_bounds__(256) void attn_keepmask_kernel(KeepMaskArgs a) {
 #endif
 template <int NW, bool BAND, bool LIST = false, bool KM = false>
 __global__ ATTN_FWD_BOUNDS void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
+    // K / V chunk buffers.  -DAMDSEG_ATTN_FWD_NBUF=3 keeps the chunk after next in flight (prefetch distance two chunks instead of one, counted vmcnt):
+    // measured SLOWER in the step, 50.3 vs 48.8 us per launch (three interleaved repetitions, round 4) -- the forward kernel does not wait for its
+    // K / V tiles, one chunk of lead covers them; the third buffer only costs LDS.  The list kernels (BigBird) walk their chunk lists one ahead.
+#ifndef AMDSEG_ATTN_FWD_NBUF
+#define AMDSEG_ATTN_FWD_NBUF 2
+#endif
+    constexpr int NB = LIST ? 2 : AMDSEG_ATTN_FWD_NBUF;
+    __shared__ __attribute__((aligned(16))) char smem[NB * 16384 + NB * 256];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     if (LIST) {                                             // 1-D launch: one (b, h) at a time per XCD, its longest lists first
@@ -127,7 +134,7 @@ __global__ ATTN_FWD_BOUNDS void attn_fwd_kernel(AttnArgs a) {
     const int H = a.heads * HD;
     const size_t tok0 = (size_t)b * a.L;
     const int q = qb * (NW * 16) + w * 16 + i16;                       // this lane's query row (shared by the 4 g-groups)
-#define bufM(i) (smem + 32768 + (i) * 256)
+#define bufM(i) (smem + NB * 16384 + (i) * 256)
     const uint64_t prow = ((uint64_t)(b * a.heads + h)) * a.L + q;
 #define bufK(i) (smem + (i) * 16384)
 #define bufV(i) (smem + 8192 + (i) * 16384)
@@ -192,18 +199,28 @@ __global__ ATTN_FWD_BOUNDS void attn_fwd_kernel(AttnArgs a) {
     // the additive key mask of a chunk travels with its K/V tiles (a global load issued where it is consumed costs a full
     // L2 round trip per key fragment: 4 exposed latencies per chunk)
     if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(0) * CH, bufM(0), l);
+    if (NB == 3 && nch > 1) {
+        at_stage<NW>(kbase + (size_t)CHUNK_OF(1) * CH * a.H3, a.H3, bufK(1), w, l);
+        at_stage<NW>(vbase + (size_t)CHUNK_OF(1) * CH * a.H3, a.H3, bufV(1), w, l);
+        if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(1) * CH, bufM(1), l);
+    }
     // a wait the compiler can see: otherwise it places the vmcnt wait for the Q fragments (plain global loads) at their first use
     // INSIDE the loop, where it drains the chunk prefetch that was just issued, every iteration
     __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+    const bool w0 = __builtin_amdgcn_readfirstlane(w) == 0;  // wave 0 carries one more LDS-DMA per chunk (the key mask)
+    int cur = 0;
     for (int ch = 0; ch < nch; ++ch) {
         ch_ = ch;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NB == 3 && ch > 0 && ch + 1 < nch) {            // chunk ch has landed; chunk ch + 1 (the youngest 2 or 3 operations) may still be in flight
+            if (w0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int cur = ch & 1;
-        if (ch + 1 < nch) {
-            at_stage<NW>(kbase + (size_t)CHUNK_OF(ch + 1) * CH * a.H3, a.H3, bufK(cur ^ 1), w, l);
-            at_stage<NW>(vbase + (size_t)CHUNK_OF(ch + 1) * CH * a.H3, a.H3, bufV(cur ^ 1), w, l);
-            if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(ch + 1) * CH, bufM(cur ^ 1), l);
+        if (NB == 2) cur = ch & 1;
+        const int nxt = NB == 2 ? (cur ^ 1) : (cur >= 1 ? cur - 1 : 2);     // NB == 3: the buffer of chunk ch + 2 = the one chunk ch - 1 used
+        if (ch + (NB - 1) < nch) {
+            at_stage<NW>(kbase + (size_t)CHUNK_OF(ch + NB - 1) * CH * a.H3, a.H3, bufK(nxt), w, l);
+            at_stage<NW>(vbase + (size_t)CHUNK_OF(ch + NB - 1) * CH * a.H3, a.H3, bufV(nxt), w, l);
+            if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(ch + NB - 1) * CH, bufM(nxt), l);
         }
         float4 mbc[4];
 #pragma unroll
@@ -309,6 +326,7 @@ __global__ ATTN_FWD_BOUNDS void attn_fwd_kernel(AttnArgs a) {
             }
         }
         if (LIST) { c_cur = c_nxt; c_nxt = lw.next(l); }
+        if (NB == 3) cur = cur == 2 ? 0 : cur + 1;
         if (KM && ch + 1 < nch) {
             // the next chunk's words, issued behind the last LDS wait of this iteration: scalar loads share lgkmcnt with the LDS and return out
             // of order, so an LDS wait with one of them in flight has to be lgkmcnt(0) and would sit out the load's latency
@@ -362,6 +380,7 @@ __global__ void attn_delta_kernel(const bf16_t* ctx, const bf16_t* dctx, float* 
 // ------------------------------------------------------------------------------------------------ backward: dQ
 template <int NW, bool BAND, bool LIST = false, bool KM = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr int NB = 2;                                   // (the K / V buffer count the bufM macro of the forward kernel refers to)
     __shared__ __attribute__((aligned(16))) char smem[32768 + 512];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -582,6 +601,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 template <int NW, bool BAND, bool LIST = false, bool KM = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+    constexpr int NB = 2;
     __shared__ __attribute__((aligned(16))) char smem[32768 + 1024];
 #define bufL(i) (smem + 32768 + (i) * 512)
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
