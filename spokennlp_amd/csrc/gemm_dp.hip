@@ -735,7 +735,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
             laB[c4] = o + 32768 + wc * 8192;
         }
     }
-    tn_i32x2 fa[8][2], fb0[4][2], fb1[4][2];
+    tn_i32x2 fa[8][2], fax[2][2], fb0[4][2], fb1[4][2];
 #ifndef AMDSEG_TN_ASM_GATHER
 // the gathers as builtins (this kernel's LDS-DMA is inline asm, so the compiler knows of no vector memory operation it would have to wait for in
 // front of them): it tracks their lgkmcnt itself and may place a fragment's two halves in the adjacent registers the MFMA wants (the asm form pays
@@ -746,15 +746,25 @@ typedef short tn_v4s __attribute__((ext_vector_type(4)));
 #else
 #define TN_RD(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #endif
-#define TN_LDA(nf) do { TN_RD(fa[nf][0], aA[(nf) & 3], ((nf) >> 2) * 8192); TN_RD(fa[nf][1], aA[(nf) & 3], ((nf) >> 2) * 8192 + 2048); } while (0)
+// -DAMDSEG_TN_A67_DB (probe, round 4): A fragments 6 and 7 double-buffered (fax) so that the gathers of the NEXT tile's fragments 6 / 7 are issued early
+// in the body instead of behind the body's last MFMAs, and the lgkmcnt(0) in front of the K tile's barrier (the LDS refill order needs it) no longer
+// sits out the latency of gathers issued a few instructions earlier (the SQ counters put 35 % of a wave's cycles at that barrier and its waits,
+// profiles/r04b_tn_counters.md).  Measured NEUTRAL: stand-alone 263.7 / 260.3 / 275.5 vs 273.0 / 272.3 / 264.6 us, training step 13.078 / 13.092 / 13.059 vs
+// 13.046 / 13.049 / 13.058 ms -- the barrier waits for the slowest of eight waves, not for this wave's last gathers.  AC = which set is current.
+#if !defined(AMDSEG_TN_A67_DB) || defined(AMDSEG_TN_ASM_GATHER)
+#define AMDSEG_TN_A67_SINGLE
+#endif
+#define TN_FA(nf, AC) ((nf) < 6 ? fa[nf] : ((AC) ? fax[(nf) - 6] : fa[nf]))
+#define TN_LDA_TO(dst, nf) do { TN_RD((dst)[0], aA[(nf) & 3], ((nf) >> 2) * 8192); TN_RD((dst)[1], aA[(nf) & 3], ((nf) >> 2) * 8192 + 2048); } while (0)
+#define TN_LDA(nf) TN_LDA_TO(fa[nf], nf)
 #define TN_LDB(e, FB) do { TN_RD(FB[e][0], aB[e], 0); TN_RD(FB[e][1], aB[e], 2048); } while (0)
 #define TN_CAT(x) __builtin_bit_cast(bf16x8, __builtin_shufflevector(x[0], x[1], 0, 1, 2, 3))
 #define TN_SB() __builtin_amdgcn_sched_barrier(0)
-#define TN_MF(nf, e, FB) acc[nf][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN_CAT(FB[e]), TN_CAT(fa[nf]), acc[nf][e], 0, 0, 0)
+#define TN_MF(nf, e, FB, AC) acc[nf][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN_CAT(FB[e]), TN_CAT(TN_FA(nf, AC)), acc[nf][e], 0, 0, 0)
 #define TN_DOT2(x, c) __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tn_bf2, x), __builtin_bit_cast(tn_bf2, 0x3f803f80), c, false)
 // (the elements are copied to plain ints first: __builtin_bit_cast applied directly to an ext-vector ELEMENT expression reads element 0
 //  whatever the index -- seen with hipcc 7.2: `bit_cast<bf2>(v.y)` compiled to the same register as `bit_cast<bf2>(v.x)`)
-#define TN_CS(nf) do { const tn_i32x2 c0_ = fa[nf][0], c1_ = fa[nf][1]; const int e0_ = c0_.x, e1_ = c0_.y, e2_ = c1_.x, e3_ = c1_.y; \
+#define TN_CS(nf, AC) do { const tn_i32x2 c0_ = TN_FA(nf, AC)[0], c1_ = TN_FA(nf, AC)[1]; const int e0_ = c0_.x, e1_ = c0_.y, e2_ = c1_.x, e3_ = c1_.y; \
                        accb[nf] = TN_DOT2(e0_, accb[nf]); accb[nf] = TN_DOT2(e1_, accb[nf]); \
                        accb[nf] = TN_DOT2(e2_, accb[nf]); accb[nf] = TN_DOT2(e3_, accb[nf]); } while (0)
 #ifndef AMDSEG_TN_ASM_GATHER
@@ -778,16 +788,35 @@ typedef short tn_v4s __attribute__((ext_vector_type(4)));
     // the bias-gradient column sums run in ~1 of tiles_k K tiles: as ONE block in front of the K tile's MFMAs (all eight A fragments of tile kt are
     // in registers there) behind one branch -- as eight `if (cs_now)` inside the MFMA stream they were eight taken branches per K tile in the
     // common case; a second copy of the body for the tiles that sum spilled registers (256 VGPRs + 604 B of scratch)
-#define TN_BODY_CORE(FC, FN, CSX) do { \
+#ifndef AMDSEG_TN_A67_SINGLE
+#define TN_BODY_CORE(FC, FN, AC) do { \
         _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) { \
-            TN_MF(nf, 0, FC); TN_SB(); TN_MF(nf, 1, FC); TN_SB(); TN_LDB(nf, FN); TN_SB(); TN_MF(nf, 2, FC); TN_SB(); TN_MF(nf, 3, FC); TN_SB(); \
+            TN_MF(nf, 0, FC, AC); TN_SB(); TN_MF(nf, 1, FC, AC); TN_SB(); TN_LDB(nf, FN); TN_SB(); TN_MF(nf, 2, FC, AC); TN_SB(); TN_MF(nf, 3, FC, AC); TN_SB(); \
+            TN_LDA(nf); TN_SB(); \
+            if (nf == 0) { TN_LDA_TO(TN_FA(6, !(AC)), 6); TN_SB(); } \
+            if (nf == 1) { TN_LDA_TO(TN_FA(7, !(AC)), 7); TN_SB(); } \
+            if (nf >= 1) { TN_DMA_PIECE(nf - 1); TN_SB(); } } \
+        _Pragma("unroll") for (int nf = 4; nf < 8; ++nf) { \
+            TN_MF(nf, 0, FC, AC); TN_MF(nf, 1, FC, AC); TN_MF(nf, 2, FC, AC); TN_MF(nf, 3, FC, AC); TN_SB(); \
+            if (nf < 6) { TN_LDA(nf); TN_SB(); } \
+            if (nf <= 6) { TN_DMA_PIECE(nf - 1); TN_SB(); } } } while (0)
+#else
+#define TN_BODY_CORE(FC, FN, AC) do { \
+        _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) { \
+            TN_MF(nf, 0, FC, 0); TN_SB(); TN_MF(nf, 1, FC, 0); TN_SB(); TN_LDB(nf, FN); TN_SB(); TN_MF(nf, 2, FC, 0); TN_SB(); TN_MF(nf, 3, FC, 0); TN_SB(); \
             TN_LDA(nf); TN_SB(); \
             if (nf >= 1) { TN_DMA_PIECE(nf - 1); TN_SB(); } } \
         _Pragma("unroll") for (int nf = 4; nf < 8; ++nf) { \
-            TN_MF(nf, 0, FC); TN_MF(nf, 1, FC); TN_MF(nf, 2, FC); TN_MF(nf, 3, FC); TN_SB(); \
+            TN_MF(nf, 0, FC, 0); TN_MF(nf, 1, FC, 0); TN_MF(nf, 2, FC, 0); TN_MF(nf, 3, FC, 0); TN_SB(); \
             TN_LDA(nf); TN_SB(); \
             if (nf <= 6) { TN_DMA_PIECE(nf - 1); TN_SB(); } } } while (0)
-#define TN_BODY(FC, FN) do { \
+#endif
+#ifndef AMDSEG_TN_A67_SINGLE
+#define TN_ACSEL(AC) (AC)
+#else
+#define TN_ACSEL(AC) 0
+#endif
+#define TN_BODY(FC, FN, AC) do { \
         TN_WAIT_FRAGS(FC); \
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          /* every K tile issues 6 pieces: tile kt+1 has landed */ \
         TN_SB(); __builtin_amdgcn_s_barrier(); TN_SB(); \
@@ -797,16 +826,16 @@ typedef short tn_v4s __attribute__((ext_vector_type(4)));
         TN_DMA_SETUP(sc, ktd_); \
         _Pragma("unroll") for (int c4 = 0; c4 < 4; ++c4) { aA[c4] = laA[c4] + sn * TN_STG; aB[c4] = laB[c4] + sn * TN_STG; } \
         __builtin_amdgcn_s_setprio(1); \
-        if (cs_now) { _Pragma("unroll") for (int nf = 0; nf < 8; ++nf) TN_CS(nf); TN_SB(); } \
-        TN_BODY_CORE(FC, FN, 0); \
+        if (cs_now) { _Pragma("unroll") for (int nf = 0; nf < 8; ++nf) TN_CS(nf, TN_ACSEL(AC)); TN_SB(); } \
+        TN_BODY_CORE(FC, FN, TN_ACSEL(AC)); \
         __builtin_amdgcn_s_setprio(0); \
         sc = sc == 2 ? 0 : sc + 1; sn = sn == 2 ? 0 : sn + 1; } while (0)
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        TN_BODY(fb0, fb1);
-        ++kt; TN_BODY(fb1, fb0); --kt;
+        TN_BODY(fb0, fb1, 0);
+        ++kt; TN_BODY(fb1, fb0, 1); --kt;
     }
-    if (kt < nk) TN_BODY(fb0, fb1);
+    if (kt < nk) TN_BODY(fb0, fb1, 0);
     TN_WAIT_FRAGS(fb0);                                     // the last K tile gathered a (never used) tile nk: retire it before
     TN_WAIT_FRAGS(fb1);                                     // these registers and the ring are reused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // ... and the clamped re-fetches of the last tiles
