@@ -911,7 +911,8 @@ class BertEncoderEngine:
         lb = fp.layers_begin
         lazy = bool(zero_grad) and self.lazy_zero and fp.layers_dense and 0 < lb < fp.numel and not self.ddp_compat()
         for a, b, zg in (((0, lb, True), (lb, fp.numel, False)) if lazy else ((0, fp.numel, zero_grad),)):
-            ops.adamw(fp.flat_p[a:b], fp.flat_g[a:b], self.adam_m[a:b], self.adam_v[a:b], self.shadow[a:b] if ride else None, lr, betas[0],
+            # (bf16 compute copies exist for the encoder layers' matrices only: the front part -- embeddings, heads -- is read in fp32)
+            ops.adamw(fp.flat_p[a:b], fp.flat_g[a:b], self.adam_m[a:b], self.adam_v[a:b], self.shadow[a:b] if (ride and (b > lb or not lazy)) else None, lr, betas[0],
                       betas[1], eps, weight_decay, self.opt_step, gscale=coef, zero_grad=zg,
                       chunk_flags=None if flags is None else flags[a // 64:(b + 63) // 64])
         fp.grad_stale = lazy
