@@ -8,6 +8,7 @@ already resident in HBM.  N GPUs = pure data parallel (weak scaling: per-GPU bat
 gradient buffer overlapped with backward.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 --steps 20 --warmup 5        # starts the 8 ranks itself (torch.distributed.run, 127.0.0.1, a free port)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` (dominant kernel = gemm_nt MFMA projections,
@@ -566,6 +567,33 @@ def via_trainer(args, device, nsteps=30, nwarm=8, nan_filter=False):
                         "reads the loss on the host every step)")
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks here -- the reference's own launch shape,
+    `python -m torch.distributed.launch --nproc_per_node N` (run_finetune.sh:1-2,61; run_inference.sh:35) -- one process per GPU over RCCL,
+    rendezvous on 127.0.0.1 and a free port, and pass rank 0's ONE JSON line through.  Fewer visible GPUs than ranks is refused loudly
+    unless AMDSEG_DIST_BACKEND=gloo says the ranks are to share the GPUs that are there (tests, one-GPU boxes)."""
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and os.environ.get("AMDSEG_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible -- one rank per GPU over RCCL needs {n}; set AMDSEG_DIST_BACKEND=gloo "
+                         f"to run the {n} ranks on the GPU(s) present (a functional check, not a scaling measurement)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")                     # run_finetune.sh:7
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -601,6 +629,15 @@ def main():
         args.no_cpu_baseline = True       # the cpu_baseline leg times the BERT oracle (headline metric) only
     if args.precision != "bf16":
         args.no_via_trainer = True
+
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:                    # not under torchrun: become the launcher of the N ranks
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; they must agree "
+                         f"(n_gpus in the JSON line is the number of ranks that ran)")
 
     from spokennlp_amd import dp
     rank, world, local = dp.init_from_env()

@@ -40,6 +40,24 @@ def shard_indices(n_items, rank, world):
     return idx
 
 
+def gather_sharded(local, n_items, group=None):
+    """inverse of `shard_indices` over the world: every rank passes the rows it computed for ITS indices (in that order, `per` rows -- the
+    wrapped tail included) and gets back the rows of items 0 .. n_items-1 in item order, the wrapped duplicates dropped (the reference's
+    multi-GPU predict: DistributedSampler pads the tail, accelerate gathers, the Trainer truncates to len(dataset) -- run_inference.sh:35).
+    `local`: tensor [per, ...]; works on any backend (gloo on CPU, RCCL on device tensors).  world 1 / no process group: `local[:n_items]`."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local[:n_items]
+    world = dist.get_world_size(group)
+    per = (n_items + world - 1) // world
+    if local.shape[0] != per:
+        raise ValueError(f"gather_sharded: this rank holds {local.shape[0]} rows, shard_indices({n_items}, rank, {world}) has {per}")
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local.contiguous(), group=group)
+    # item i*world + r sits in parts[r][i]: interleave, then cut the wrap-around padding
+    out = torch.stack(parts, dim=1).reshape(per * world, *local.shape[1:])
+    return out[:n_items]
+
+
 class GradBuckets:
     """contiguous slices of the flat gradient buffer in the order backward produces them: [layer N-1] ... [layer 0] [embeddings + heads].
 
@@ -53,14 +71,23 @@ class GradBuckets:
     def __init__(self, fp, bf16_embeddings=None):
         names = list(fp.offsets.keys())
         offs = [fp.offsets[n] for n in names] + [fp.numel]
-        first_layer = next(i for i, n in enumerate(names) if n.startswith(fp.encoder_prefix))
-        per_layer = (len(names) - first_layer) // max(fp.nlayers, 1)
+        # FlatParams lays the buffer out as [rest | layer 0 | ... | layer N-1]: `rest` = every parameter that is not one of the per-layer
+        # names of `layer_order` (for Longformer that includes the query/key/value_global matrices, whose names ALSO start with the encoder
+        # prefix -- so the layer slices are derived from the layout's own counts, never from a name prefix)
+        first_layer = fp.n_rest
+        per_layer = fp.per_layer
+        assert len(names) == first_layer + fp.nlayers * per_layer, "FlatParams layout: rest + nlayers x per_layer names"
         self.layer_slices = []
         for li in range(fp.nlayers):
             a = offs[first_layer + li * per_layer]
             b = offs[first_layer + (li + 1) * per_layer]
+            assert names[first_layer + li * per_layer].startswith(f"{fp.encoder_prefix}{li}."), names[first_layer + li * per_layer]
             self.layer_slices.append((a, b))
         self.rest_slice = (0, offs[first_layer])
+        assert self.rest_slice[1] == fp.layers_begin or not fp.nlayers
+        cov = self.rest_slice[1] - self.rest_slice[0] + sum(b - a for a, b in self.layer_slices)
+        assert cov == fp.numel and all(self.layer_slices[i][1] == self.layer_slices[i + 1][0] for i in range(fp.nlayers - 1)), \
+            "gradient buckets must tile the flat buffer exactly"
         # the leading part of the rest that ONLY the encoder's backward writes (embedding tables + their LayerNorm: 23.8 M of bert-base's 24.4 M
         # non-layer parameters, the fully exposed tail of the exchange): reduced as soon as the embedding backward is queued (engine.backward);
         # what follows (pooler, loss heads -- written by autograd nodes that may run after the encoder's) waits for finish_grad_sync()
@@ -167,4 +194,5 @@ class GradBuckets:
 def allreduce_grads(engine, group=None):
     """non-overlapped fallback: one all-reduce over the whole flat gradient buffer."""
     if dist.is_initialized() and dist.get_world_size() > 1:
+        engine.fp.flush_stale()                  # the slice the fused AdamW left un-zeroed counts as zero: make it so before anyone sums it
         dist.all_reduce(engine.fp.flat_g, op=dist.ReduceOp.SUM, group=group)

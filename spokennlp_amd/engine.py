@@ -57,6 +57,8 @@ class FlatParams:
             off = _align(off + named[n].numel())
         self.numel = off
         self.nlayers = nlayers
+        self.n_rest = len(rest)                 # names [0, n_rest) of `offsets` are the non-layer front part; then nlayers x per_layer names
+        self.per_layer = len(layer_order)
         # the encoder layers are one suffix of the flat buffers: [layers_begin, numel).  grad_stale: that slice of flat_g still holds the
         # PREVIOUS step's gradients (the fused AdamW did not zero it, engine.adamw_step) and counts as zero: the next backward overwrites it
         self.layers_begin = self.offsets[order[len(rest)]] if nlayers else off

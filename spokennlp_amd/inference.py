@@ -22,19 +22,33 @@ def predict_documents(model, docs_sentence_ids, docs_labels, max_seq_length, bos
     cols = P.prepare_features(docs_sentence_ids, docs_labels, list(range(len(docs_sentence_ids))), max_seq_length, bos_id, cls_id,
                               pad_id, tssp_ablation=tssp_ablation)
     n = len(cols["input_ids"])
+    # multi-GPU predict (run_inference.sh:35 launches 2 ranks): this rank's windows are r, r+W, ... (dp.shard_indices, the tail wrapped);
+    # the rows come back in window order through dp.gather_sharded.  One process: mine == range(n), the gather is the identity.
+    import torch.distributed as dist
+    from . import dp
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    mine = dp.shard_indices(n, dist.get_rank(), world) if world > 1 else list(range(n))
     logits_all, cos_all = [], []
     model.eval()
     with torch.no_grad():
-        for i in range(0, n, batch_size):
-            idx = list(range(i, min(i + batch_size, n)))
+        for i in range(0, len(mine), batch_size):
+            idx = mine[i:i + batch_size]
             pad_n = batch_size - len(idx)
             idx = idx + [idx[-1]] * pad_n                   # fixed batch shape (tile-aligned); the tail repeats the last sample
             batch = {k: torch.tensor([cols[k][j] for j in idx], dtype=torch.long, device=device) for k in MODEL_COLUMNS}
             _, logits, cos = model(**batch)[:3]
             keep = batch_size - pad_n
-            logits_all.append(logits[:keep].float().cpu().numpy())
-            cos_all.extend(cos[:keep].float().cpu().numpy().tolist())
-    logits_all = np.concatenate(logits_all, 0)
+            logits_all.append(logits[:keep].float())
+            cos_all.append(cos[:keep].float())
+    logits_t = torch.cat(logits_all, 0)
+    kmax = max(c.shape[1] for c in cos_all)
+    if world > 1:                                             # cos_sim is (B, k) with k = the batch's own maximum: one width for the gather
+        kt = torch.tensor([kmax], device=logits_t.device)
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+        kmax = int(kt.item())
+    cos_t = torch.cat([torch.nn.functional.pad(c, (0, kmax - c.shape[1]), value=-100.0) for c in cos_all], 0)
+    logits_all = dp.gather_sharded(logits_t, n).cpu().numpy()
+    cos_all = dp.gather_sharded(cos_t, n).cpu().numpy().tolist()
     labels = np.array(cols["labels"])
     decoded = P.decode_anchor_predictions(logits_all, labels)
     example_ids = [e[0] for e in cols["example_id"]]

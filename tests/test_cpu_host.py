@@ -167,3 +167,45 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         assert int(got[cname]) == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_bench_gpus_argument_launches_the_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` (the driver's command shape, no torchrun around it) must start N ranks itself -- VERDICT r04: args.gpus was
+    parsed and never read, so the line silently measured dp1.  The argument path, on CPU: the launcher command, and the loud refusals."""
+    import importlib
+    import subprocess
+    import sys
+    import types
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setenv("AMDSEG_DIST_BACKEND", "gloo")          # fewer GPUs than ranks here (none): allowed only over gloo
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    rc = bench.self_launch(types.SimpleNamespace(gpus=4), ["--gpus", "4", "--steps", "2", "--warmup", "1"])
+    assert rc == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    tail = cmd[cmd.index("--master-port") + 2:]
+    assert tail[0].endswith("bench.py") and tail[1:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # without the gloo opt-in, more ranks than GPUs is refused, not silently run as dp1
+    monkeypatch.delenv("AMDSEG_DIST_BACKEND")
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(types.SimpleNamespace(gpus=4), ["--gpus", "4"])
+    assert "only 0 GPU(s) visible" in str(e.value)
+    # main(): --gpus N without WORLD_SIZE goes to the launcher; a launcher that started another number of ranks is refused
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"])
+    monkeypatch.setenv("AMDSEG_DIST_BACKEND", "gloo")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and seen["cmd"][seen["cmd"].index("--nproc-per-node") + 1] == "2"
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "must agree" in str(e.value)
