@@ -631,3 +631,71 @@ def test_backward_drops_the_rows_of_trailing_padding_without_changing_a_bit(dev)
     assert guard0 == 0
     for n in layer_names:
         assert torch.equal(on0[n], off0[n]) and float(on0[n].abs().max()) == 0.0, n
+
+
+# ------------------------------------------------------------------------------------------------ ts_score_predictor = "cos"
+# loss_calculator.py:45-48 / utils.py:111-138: the score is sigmoid(cos(eop_i, eop_next) / temp) and the "logits" output is the (B, 2, k) score
+# matrix; goldens from the reference itself (tools/gen_golden.py --cos-only).  VERDICT r04: this branch had never been compared with anything.
+@pytest.mark.parametrize("precision,tol_score,tol_cos", [("bf16", 5e-3, 2e-2), ("parity", 1e-4, 2e-4)])
+@pytest.mark.parametrize("case", ["tiny_L64_cos", "tiny_L128_cos"])
+@pytest.mark.parametrize("variant", ["eval_cos", "eval_cos_t05", "full_eval_cos"])
+def test_cos_score_predictor_eval_vs_reference_golden(dev, case, variant, precision, tol_score, tol_cos):
+    z, sd, batch, arch = load_case(case)
+    fl = flags_of(z, variant)
+    assert fl["ts_score_predictor"] == "cos"
+    fl["amdseg_precision"] = precision
+    m = build_model(arch, fl, sd, dev).eval()
+    random.seed(int(z[f"{variant}.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos = m(**to_dev(batch, dev))
+    ref_logits, ref_cos = torch.from_numpy(z[f"{variant}.logits"]), torch.from_numpy(z[f"{variant}.cos"])
+    assert logits.shape == ref_logits.shape and cos.shape == ref_cos.shape
+    pad = ref_cos == -100
+    assert torch.equal(cos.cpu() == -100, pad)
+    dc = (cos.cpu() - ref_cos).abs().max().item()
+    ds = (logits.cpu() - ref_logits).abs().max().item()
+    rl = abs(loss.item() - float(z[f"{variant}.loss"])) / abs(float(z[f"{variant}.loss"]))
+    print(f"{case}/{variant}/{precision}: max|dcos| {dc:.2e} max|dscore| {ds:.2e} loss rel {rl:.2e}")
+    assert dc < tol_cos * (2.0 if "t05" in variant else 1.0) and ds < tol_score and rl < (2e-4 if precision == "bf16" else 2e-6)
+    # the decision of this predictor: score > 0.5 <=> cos > 0 at every real pair
+    margin = ref_cos[~pad].abs()
+    sure = margin > 2 * tol_cos
+    assert torch.equal((cos.cpu()[~pad] > 0)[sure], (ref_cos[~pad] > 0)[sure])
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16", 0.06), ("parity", 2e-3)])
+@pytest.mark.parametrize("case", ["tiny_L64_cos", "tiny_L128_cos"])
+@pytest.mark.parametrize("variant", ["train_cos", "train_cos_t05"])
+def test_cos_score_predictor_train_grads_vs_reference_golden(dev, case, variant, precision, tol):
+    z, sd, batch, arch = load_case(case)
+    fl = flags_of(z, variant)
+    fl["amdseg_precision"] = precision
+    m = build_model(arch, fl, sd, dev).train()
+    random.seed(int(z[f"{variant}.random_seed"]))
+    loss, logits, cos = m(**to_dev(batch, dev))
+    loss.backward()
+    ref_loss = float(z[f"{variant}.loss"])
+    assert abs(loss.item() - ref_loss) < (2e-4 if precision == "bf16" else 2e-6) * abs(ref_loss)
+    assert logits.shape == z[f"{variant}.logits"].shape
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for n, gv in zip(z[f"{variant}.gradnorm_names"].tolist(), z[f"{variant}.gradnorm_vals"].tolist()):
+        g = params[n].grad
+        mine = 0.0 if g is None else float(g.float().norm())
+        if gv < 0:                                      # pooler and BOTH linear heads: no gradient in the reference either
+            assert mine == 0.0, n
+            continue
+        rel = abs(mine - gv) / max(gv, 1e-3)
+        worst = max(worst, rel)
+        assert rel < tol, (n, mine, gv)
+    wc = 1.0
+    for k in z.files:
+        if k.startswith(f"{variant}.grad."):
+            n = k[len(f"{variant}.grad."):]
+            ref = torch.from_numpy(z[k])
+            if float(ref.norm()) < 1e-5:
+                continue
+            c = torch.nn.functional.cosine_similarity(params[n].grad.float().cpu().flatten(), ref.flatten(), dim=0).item()
+            wc = min(wc, c)
+            assert c > (0.99 if precision == "bf16" else 0.99999), (n, c)
+    print(f"{case}/{variant}/{precision}: worst grad-norm rel err {worst:.2e}, worst cosine {wc:.6f}")

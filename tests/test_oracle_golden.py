@@ -336,3 +336,49 @@ def test_ponet_oracle_run_form_equals_general_form():
     a = PO.pooling(hq, hk, ho, hl, hs, valid, seg, 2)
     b_ = PO.pooling(hq, hk, ho, hl, hs, valid, seg, 2, runs=True)
     assert torch.equal(a, b_)
+
+
+# ---- ts_score_predictor = "cos" (loss_calculator.py:45-48): score = sigmoid(cos(eop_i, eop_next) / temp), BCE over the padded (B, k) matrix
+COS_EVAL = ["eval_cos", "eval_cos_t05", "full_eval_cos"]
+COS_TRAIN = ["train_cos", "train_cos_t05"]
+
+
+@pytest.mark.parametrize("case", ["tiny_L64_cos", "tiny_L128_cos"])
+@pytest.mark.parametrize("variant", COS_EVAL)
+def test_cos_score_predictor_eval_matches_reference(case, variant):
+    z, sd, batch, arch = load_case(case)
+    fl = flags_of(z, variant)
+    assert fl["ts_score_predictor"] == "cos"
+    cfg = cfg_for(arch, fl)
+    random.seed(int(z[f"{variant}.random_seed"]))
+    with torch.no_grad():
+        loss, logits, cos = O.model_forward(sd, cfg, batch)
+    ref_logits, ref_cos = z[f"{variant}.logits"], z[f"{variant}.cos"]
+    assert logits.shape == ref_logits.shape and logits.dim() == 3            # (B, 2, k): the score matrix, not (B, 2, L, 2)
+    # the loss is dominated by BCE against targets of -100 on the padding (the reference's quirk): relative tolerance
+    assert abs(loss.item() - float(z[f"{variant}.loss"])) < 2e-6 * abs(float(z[f"{variant}.loss"]))
+    assert np.abs(logits.numpy() - ref_logits).max() < 2e-6
+    assert np.abs(cos.numpy() - ref_cos).max() < 5e-6
+    assert np.array_equal(cos.numpy() == -100, ref_cos == -100)
+
+
+@pytest.mark.parametrize("case", ["tiny_L64_cos", "tiny_L128_cos"])
+@pytest.mark.parametrize("variant", COS_TRAIN)
+def test_cos_score_predictor_train_matches_reference(case, variant):
+    z, sd, batch, arch = load_case(case)
+    cfg = cfg_for(arch, flags_of(z, variant))
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    random.seed(int(z[f"{variant}.random_seed"]))
+    loss, logits, cos = O.model_forward(sd, cfg, batch)
+    loss.backward()
+    assert abs(loss.item() - float(z[f"{variant}.loss"])) < 2e-6 * abs(float(z[f"{variant}.loss"]))
+    for n, gv in zip(z[f"{variant}.gradnorm_names"].tolist(), z[f"{variant}.gradnorm_vals"].tolist()):
+        g = sd[n].grad
+        if gv < 0:       # no grad in the reference: pooler, and BOTH linear heads (the cos predictor never touches the classifier)
+            assert g is None or float(g.norm()) == 0.0, n
+            continue
+        assert abs(float(g.norm()) - gv) <= 2e-4 * max(1.0, gv), (n, float(g.norm()), gv)
+    for k in z.files:
+        if k.startswith(f"{variant}.grad."):
+            n = k[len(f"{variant}.grad."):]
+            assert np.abs(sd[n].grad.numpy() - z[k]).max() < 5e-5 * max(1.0, float(np.abs(z[k]).max())), n

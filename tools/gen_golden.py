@@ -115,6 +115,18 @@ def run_case(name, arch, L, B, seed, variants, kind="bert"):
                 out["sd." + k] = v.numpy().copy()
             saved_sd = True
         random.seed(rseed)
+        if mode == "eval_raises":       # record that (and how) the reference itself fails on this configuration
+            m.eval()
+            try:
+                with torch.no_grad():
+                    m(**batch)
+                out[f"{vname}.raised"] = np.array("")
+            except Exception as e:      # noqa: BLE001
+                out[f"{vname}.raised"] = np.array(type(e).__name__)
+                out[f"{vname}.message"] = np.array(str(e)[:200])
+            out[f"{vname}.flags_keys"] = np.array(list(fl.keys())); out[f"{vname}.flags_vals"] = np.array([str(v) for v in fl.values()])
+            print(name, vname, "raised", out[f"{vname}.raised"])
+            continue
         if mode == "eval":
             m.eval()
             with torch.no_grad():
@@ -136,7 +148,7 @@ def run_case(name, arch, L, B, seed, variants, kind="bert"):
                     gn[n] = -1.0
                     continue
                 gn[n] = float(p.grad.norm())
-                if vname.endswith("full") and (L < 512 or "embeddings" not in n):
+                if (vname.endswith("full") or "cos" in vname) and (L < 512 or "embeddings" not in n):
                     out[f"{vname}.grad.{n}"] = p.grad.numpy().copy()
             out[f"{vname}.gradnorm_names"] = np.array(list(gn.keys()))
             out[f"{vname}.gradnorm_vals"] = np.array(list(gn.values()), dtype=np.float64)
@@ -170,6 +182,26 @@ def main():
     run_case("lf_tiny_L128_w16", dict(lf, attention_window=[32, 32]), 128, 2, 3, variants[:3], kind="longformer")
     if "--bigbird" in sys.argv or "--all" in sys.argv:
         main_bigbird(variants)
+
+
+def main_cos():
+    """ts_score_predictor="cos" (loss_calculator.py:45-48, utils.py:111-138): the token score is sigmoid(cos(eop_i, eop_{i+1}) / temp), the
+    loss BCE-with-logits over the (B, k) matrix INCLUDING its -100 padding (targets of -100: the reference's quirk, kept).  Same model
+    seed / documents as tiny_L64 / tiny_L128, separate files so the existing fixtures stay byte-identical.  With the DA pass on, the
+    reference concatenates (B, k_anchor) with (B, k_da) scores (bert_for_ts.py:108): recorded as what it does on this batch."""
+    arch = dict(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                max_position_embeddings=128, type_vocab_size=2)
+    cos1 = dict(ts_score_predictor="cos", ts_score_predictor_cos_temp=1)
+    cos05 = dict(ts_score_predictor="cos", ts_score_predictor_cos_temp=0.5)
+    variants = [
+        ("eval_cos", PLAIN, "eval", 0, cos1),
+        ("eval_cos_t05", PLAIN, "eval", 0, cos05),
+        ("train_cos", PLAIN, "train", 3, cos1),
+        ("train_cos_t05", PLAIN, "train", 3, cos05),
+        ("full_eval_cos", FULL, "eval", 5, cos1),      # k_anchor == k_da on these batches (the DA half permutes the same sentences): the cat at bert_for_ts.py:108 works
+    ]
+    run_case("tiny_L64_cos", arch, 64, 2, 0, variants)
+    run_case("tiny_L128_cos", arch, 128, 2, 1, variants)
 
 
 def main_bigbird(variants):
@@ -252,6 +284,18 @@ def main_fullsize():
         missing, unexpected = m.load_state_dict(sd, strict=False)
         assert not unexpected, unexpected
         random.seed(rseed)
+        if mode == "eval_raises":       # record that (and how) the reference itself fails on this configuration
+            m.eval()
+            try:
+                with torch.no_grad():
+                    m(**batch)
+                out[f"{vname}.raised"] = np.array("")
+            except Exception as e:      # noqa: BLE001
+                out[f"{vname}.raised"] = np.array(type(e).__name__)
+                out[f"{vname}.message"] = np.array(str(e)[:200])
+            out[f"{vname}.flags_keys"] = np.array(list(fl.keys())); out[f"{vname}.flags_vals"] = np.array([str(v) for v in fl.values()])
+            print(name, vname, "raised", out[f"{vname}.raised"])
+            continue
         if mode == "eval":
             m.eval()
             with torch.no_grad():
@@ -378,7 +422,9 @@ def main_fullsize_bb():
 
 
 if __name__ == "__main__":
-    if "--fullsize-bb-only" in sys.argv:
+    if "--cos-only" in sys.argv:
+        main_cos()
+    elif "--fullsize-bb-only" in sys.argv:
         main_fullsize_bb()
     elif "--fullsize-lf-train-only" in sys.argv:
         main_fullsize_lf_train()
