@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 10   /* 10: AMDSEG_EPI_KEEP_DERIV (amdseg_bert_layer_acts.u holds gelu' of the FFN pre-activation in bf16 training when the shape allows); 9: amdseg_heads_bwd_rows takes n_feat / fix / fix_bytes (order-independent scatter sums), amdseg_scatter_rows_sorted; 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_gemm_nt_bias_drop_res, amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 11   /* 11: amdseg_allreduce_* (the gradient exchange over RCCL behind an explicit amdseg_comm context, csrc/comm.hip); 10: AMDSEG_EPI_KEEP_DERIV (amdseg_bert_layer_acts.u holds gelu' of the FFN pre-activation in bf16 training when the shape allows); 9: amdseg_heads_bwd_rows takes n_feat / fix / fix_bytes (order-independent scatter sums), amdseg_scatter_rows_sorted; 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_gemm_nt_bias_drop_res, amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -34,6 +34,8 @@ extern "C" {
 #define AMDSEG_ERR_SHAPE 1001
 #define AMDSEG_ERR_ARG 1002
 #define AMDSEG_ERR_LAUNCH 1003
+#define AMDSEG_ERR_COMM_LIB 1004     /* amdseg_allreduce_*: librccl could not be loaded */
+#define AMDSEG_ERR_COMM_BASE 1100    /* amdseg_allreduce_*: 1100 + ncclResult_t of the failed RCCL call */
 #define AMDSEG_MAX_GROUP 8
 
 /* epilogues of amdseg_gemm_nt */
@@ -531,6 +533,32 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* cfg, const amdseg_bert_layer_pa
 int amdseg_bert_layer_bwd(const amdseg_bert_cfg* cfg, const amdseg_bert_layer_params* p, const amdseg_bert_layer_grads* g,
                           const amdseg_bert_layer_acts* a, const amdseg_bert_layer_ws* ws, const float* mask_bias,
                           const void* dy, void* dx_in, int layer_idx, amdseg_stream_t stream);
+
+/* ---- gradient exchange of pure data parallelism (csrc/comm.hip) -- ABI 11 ----------------------------------------------------
+ * replaces torch DDP's bucketed all-reduce, which the reference gets from `python -m torch.distributed.launch --nproc_per_node N`
+ * (emnlp2023-topic_segmentation/run_finetune.sh:61) + transformers.Trainer's model wrapping.  One process per GPU; `amdseg_comm` is the
+ * explicit context SURVEY 8(b) asks for (the RCCL communicator of this rank on the CURRENT device, a side stream, two events) -- no
+ * global state.  The Python host of this repo does the same exchange through torch.distributed (spokennlp_amd/dp.py: the process group,
+ * launcher contract and Trainer integration live there; backend "nccl" IS RCCL); these entry points give a host without PyTorch the
+ * same thing.  RCCL is bound at run time (dlopen; AMDSEG_RCCL_LIB overrides the search), never at link time.
+ *   unique_id: rank 0 obtains the 128-byte rendezvous id (ncclGetUniqueId) and ships it to the other ranks by its own means;
+ *   init:      collective over the `world` ranks (ncclCommInitRank); rank r's communicator lives on the device current at the call;
+ *   bucket:    `buf[0..n)` (fp32 or bf16, in place) becomes the element-wise SUM over the ranks.  Issued relative to `compute_stream`:
+ *              the reduction starts when everything queued on that stream so far has run (the slice is final) and runs on the context's
+ *              side stream, so the kernels queued on compute_stream afterwards overlap it (issue buckets in the order backward finishes
+ *              them: encoder layers last to first, then the embedding tables, then the heads; the mean = 1/world goes into
+ *              amdseg_adamw_step's grad_scale);
+ *   wait:      compute_stream waits for every bucket issued so far (call it once, in front of the gradient norm / AdamW);
+ *   info:      rank / world / elements issued since the last wait;   destroy: drains the side stream, frees the communicator.
+ * Errors: AMDSEG_ERR_COMM_LIB (no librccl), AMDSEG_ERR_COMM_BASE + ncclResult_t, or a hipError_t; amdseg_error_string knows them all. */
+#define AMDSEG_COMM_ID_BYTES 128
+typedef struct amdseg_comm amdseg_comm;
+int amdseg_allreduce_unique_id(void* id128);
+int amdseg_allreduce_init(amdseg_comm** out, const void* id128, int rank, int world);
+int amdseg_allreduce_bucket(amdseg_comm* comm, void* buf, size_t n, int dtype, amdseg_stream_t compute_stream);
+int amdseg_allreduce_wait(amdseg_comm* comm, amdseg_stream_t compute_stream);
+int amdseg_allreduce_info(const amdseg_comm* comm, int* rank, int* world, size_t* pending_elements);
+int amdseg_allreduce_destroy(amdseg_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -4,3 +4,8 @@ Hand-written HIP kernels behind a C ABI (include/amdseg.h, spokennlp_amd/csrc) +
 reference's HuggingFace plug-in surface (emnlp2023-topic_segmentation/src/models/bert_for_ts.py).
 """
 __version__ = "0.1.0"
+
+# the Auto* surface (north_star: "keeping the HuggingFace AutoModelForTokenClassification + Trainer plug-in surface"): config twins with
+# their own model_type + the drop-in classes, registered with AutoConfig / AutoModelForTokenClassification at package import
+from . import auto  # noqa: E402,F401
+from .auto import amdseg_config  # noqa: E402,F401

@@ -435,8 +435,8 @@ class TopicSegHeadsMixin:
     ):
         if head_mask is not None or position_ids is not None or inputs_embeds is not None:
             raise L.AmdsegError("head_mask / position_ids / inputs_embeds are not supported by the HIP encoder path")
-        if output_attentions or output_hidden_states:
-            raise L.AmdsegError("attention maps / hidden states are never materialised by the fused HIP path")
+        if output_attentions:
+            raise L.AmdsegError("attention maps are never materialised by the fused HIP path (softmax lives in registers)")
         cfg = self.config
         B, two, Lq = input_ids.shape
         if attention_mask is None:
@@ -476,14 +476,27 @@ class TopicSegHeadsMixin:
             tt = torch.cat((token_type_ids[:, 0], token_type_ids[:, 1]))
         else:
             ids, am, tt = input_ids[:, 0].contiguous(), attention_mask[:, 0].contiguous(), token_type_ids[:, 0].contiguous()
-        seq = self.encode(ids, am, tt)
+        hidden = None
+        if output_hidden_states:
+            # bert_for_ts.py:57-63,111-112: the flag goes to the ANCHOR encoder pass and its `hidden_states` tuple (embedding output + every
+            # layer output, (B, L, H) each) is appended to the return.  Detached fp32 copies taken between the layer launches (no gradient
+            # flows through them -- the reference's would, but no caller of the reference differentiates them).
+            eng = self.engine()
+            eng._hidden_sink = []
+            try:
+                seq = self.encode(ids, am, tt)
+                hidden = tuple(h[:B] for h in eng._hidden_sink)
+            finally:
+                eng._hidden_sink = None
+        else:
+            seq = self.encode(ids, am, tt)
         if ev is not None:
             ev.synchronize()
         logits, cos = None, None
         loss = None
         if labels is not None and self._fused_heads_ok(self.training and torch.is_grad_enabled()):
             loss, logits = self._fused_heads(seq, labels, host, B, Lq, two_pass)
-            return (loss, logits, torch.full((B, 1), -100.0, device=seq.device))
+            return (loss, logits, torch.full((B, 1), -100.0, device=seq.device)) + ((hidden,) if hidden is not None else ())
         if labels is not None:
             train = self.training and torch.is_grad_enabled()
             need_cos = (not train) or cfg.ts_score_predictor == "cos"
@@ -509,7 +522,7 @@ class TopicSegHeadsMixin:
                 logits = torch.cat((a_logits.unsqueeze(1), d_logits.unsqueeze(1)), dim=1)
             if cos is None:
                 cos = torch.full((B, 1), -100.0, device=seq.device)
-        output = (logits, cos)
+        output = (logits, cos) + ((hidden,) if hidden is not None else ())
         return ((loss,) + output) if loss is not None else output
 
 

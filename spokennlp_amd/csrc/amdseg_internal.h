@@ -10,6 +10,7 @@
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2
 
+const char* amdseg_comm_error_string_impl(int code);     /* csrc/comm.hip: AMDSEG_ERR_COMM_* */
 int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                         int epi, const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32,
                         hipStream_t stream, const int* zkend = nullptr, const int* zguard = nullptr, int zL = 0);

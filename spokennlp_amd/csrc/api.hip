@@ -17,7 +17,13 @@ const char* amdseg_error_string(int code) {
         case AMDSEG_ERR_SHAPE: return "amdseg: unsupported or misaligned shape";
         case AMDSEG_ERR_ARG: return "amdseg: bad argument (null pointer / enum / missing workspace)";
         case AMDSEG_ERR_LAUNCH: return "amdseg: kernel launch failed";
-        default: return hipGetErrorString((hipError_t)code);
+        default: {
+            if (code == AMDSEG_ERR_COMM_LIB || (code > AMDSEG_ERR_COMM_BASE && code < AMDSEG_ERR_COMM_BASE + 100)) {
+                const char* m = amdseg_comm_error_string_impl(code);
+                return m ? m : "amdseg: RCCL call failed";
+            }
+            return hipGetErrorString((hipError_t)code);
+        }
     }
 }
 

@@ -688,8 +688,18 @@ class BertEncoderEngine:
         L.check(rc, "amdseg_embed_ln_fwd")
         mb = A["mask_bias"].data_ptr()
         saved = []
+        sink = getattr(self, "_hidden_sink", None)          # output_hidden_states: fp32 copies of the embedding output and of every layer output
+
+        def keep_hidden(buf):
+            h = torch.empty(M, self.H, dtype=torch.float32, device=self.device)
+            L.check(lib.amdseg_dropout(buf.data_ptr(), h.data_ptr(), M * self.H, 0.0, 0, dt, L.F32, s), "amdseg_dropout(copy)")
+            sink.append(h.view(B, Lseq, self.H))
+        if sink is not None:
+            keep_hidden(A["x"][0])
         for i in range(self.nlayers):
             saved.append(self._layer_forward(lib, cfg, lparams[i], A, i, mb, s, train))
+            if sink is not None:
+                keep_hidden(A["x"][i + 1] if train else A["x"][(i + 1) % 2])
         # the result is a FRESH tensor per call (the caller and autograd keep it; arena buffers are overwritten by the next forward)
         out = torch.empty(M, self.H, dtype=torch.float32, device=self.device)
         rc = lib.amdseg_dropout(A["x_final"].data_ptr(), out.data_ptr(), M * self.H, p_out if train else 0.0,
@@ -955,6 +965,9 @@ class EncoderFn(torch.autograd.Function):
             attention_mask = torch.nn.functional.pad(attention_mask, grow, value=0)
             token_type_ids = torch.nn.functional.pad(token_type_ids, grow, value=0)
         out, ectx = engine.forward(input_ids, attention_mask, token_type_ids, train, seed, p_out)
+        sink = getattr(engine, "_hidden_sink", None)
+        if sink is not None and (Bp, Lp) != (B, Lq):
+            sink[:] = [h[:B, :Lq].contiguous() for h in sink]
         ctx.engine, ctx.ectx = engine, ectx
         if train:                                           # graph dropped without a backward: the arena is free again
             weakref.finalize(ctx, BertEncoderEngine._release_arena, ectx["arena"], ectx["gen"])

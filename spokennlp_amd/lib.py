@@ -14,7 +14,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
 EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
 EPI_DERIV_U8 = 0x400      # with EPI_KEEP_DERIV: the derivative as one byte per element, q = round((g' + 0.135) * 200)
 EPI_KEEP_DERIV = 0x200    # OR-ed into EPI_BIAS_GELU: out2 = gelu'(pre-activation); into EPI_GELU_BWD: R is that derivative (C = (A B^T) * R)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
@@ -126,6 +126,12 @@ _PROTOS = {
     "amdseg_heads_bwd_rows": [vp, vp, i32, i32, vp, vp, C.c_long, C.c_long, C.c_long, i32, i32, i32, f32, vp, vp, C.c_long, C.c_long, i32, i32,
                               vp, vp, f32, f32, i32, vp, C.c_size_t, vp],
     "amdseg_set_cu_budget": [i32],
+    "amdseg_allreduce_unique_id": [vp],
+    "amdseg_allreduce_init": [C.POINTER(vp), vp, i32, i32],
+    "amdseg_allreduce_bucket": [vp, vp, sz, i32, vp],
+    "amdseg_allreduce_wait": [vp, vp],
+    "amdseg_allreduce_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)],
+    "amdseg_allreduce_destroy": [vp],
     "amdseg_prof_enable": [i32],
     "amdseg_prof_reset": [],
     "amdseg_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],

@@ -151,7 +151,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     structs = {"amdseg_bert_cfg": lib.BertCfg, "amdseg_bert_layer_params": lib.LayerParams, "amdseg_bert_layer_grads": lib.LayerGrads,
                "amdseg_bert_layer_acts": lib.LayerActs, "amdseg_bert_layer_ws": lib.LayerWs}
     hdr = open(os.path.join(ROOT, "include", "amdseg.h")).read()
-    assert set(re.findall(r"typedef struct (amdseg_[a-z_]+)", hdr)) == set(structs), "a struct of the header has no ctypes mirror"
+    assert set(re.findall(r"typedef struct (amdseg_[a-z_]+) *\{", hdr)) == set(structs), "a struct of the header has no ctypes mirror"
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "amdseg.h"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
@@ -209,3 +209,34 @@ def test_bench_gpus_argument_launches_the_ranks(monkeypatch, capsys):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "must agree" in str(e.value)
+
+
+def test_auto_registration_resolves_to_the_drop_in_classes(tmp_path):
+    """SURVEY 8(b) row 1: the drop-in classes are registered with AutoModelForTokenClassification (config twins with their own model_type;
+    transformers ignores register() for its native config classes) and the direct-class path is untouched.  Construction / save / load
+    only -- no compute without a GPU."""
+    import spokennlp_amd
+    from spokennlp_amd import auto
+    from transformers import AutoConfig, AutoModelForTokenClassification, BertConfig, ElectraConfig, LongformerConfig, BigBirdConfig
+    small = dict(vocab_size=50, hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, num_labels=2)
+    stock = {"bert": BertConfig(**small), "electra": ElectraConfig(embedding_size=64, **small),
+             "longformer": LongformerConfig(attention_window=[8], max_position_embeddings=70, type_vocab_size=1, pad_token_id=1, **small),
+             "big_bird": BigBirdConfig(block_size=64, num_random_blocks=3, max_position_embeddings=1024, **small)}
+    for fam, cfg in stock.items():
+        ccls, mcls, direct = auto.FAMILIES[fam]
+        twin = spokennlp_amd.amdseg_config(cfg, do_da_ts=True, cl_loss_weight=0.25)
+        assert type(twin) is ccls and twin.model_type == "amdseg-" + fam.replace("_", "") and twin.hidden_size == 64 and twin.do_da_ts is True
+        m = AutoModelForTokenClassification.from_config(twin)
+        assert type(m) is mcls and isinstance(m, direct)
+        assert set(m.state_dict()) == set(direct(cfg).state_dict())              # same HF parameter names on both paths
+        d = tmp_path / fam
+        m.save_pretrained(d)
+        back = AutoConfig.from_pretrained(d)
+        assert type(back) is ccls and back.cl_loss_weight == 0.25
+        m2 = AutoModelForTokenClassification.from_pretrained(d)
+        assert type(m2) is mcls and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+        # a stock config through Auto* stays stock (nothing built in is overridden)
+        assert not isinstance(AutoModelForTokenClassification.from_config(cfg), direct)
+    with pytest.raises(ValueError):
+        from transformers import GPT2Config
+        spokennlp_amd.amdseg_config(GPT2Config())

@@ -180,3 +180,46 @@ def test_rccl_backend_single_rank_bucketed_exchange(dev):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("nccl world=1")][-1]
     ms, loss = float(line.split("buckets:")[1].split("ms/step")[0]), float(line.rsplit("loss", 1)[1])
     assert 5.0 < ms < 60.0 and loss == loss
+
+
+def test_c_abi_allreduce_context_single_rank(dev):
+    """include/amdseg.h amdseg_allreduce_* (the exchange behind an explicit amdseg_comm, for a host without PyTorch): RCCL bound
+    at run time, a world of ONE rank on this box's GPU -- unique id, communicator, three buckets (fp32, bf16, an empty one) issued from the
+    compute stream and reduced on the context's side stream, one wait; the sum over one rank is the input, bit for bit, and the buckets
+    really are ordered behind the producer kernel on the compute stream.  (RCCL refuses two ranks on one device: the N > 1 run is the
+    driver's; the schedule it exercises is dp.GradBuckets', tested over gloo at world 2 and 8.)"""
+    import ctypes as C
+    from spokennlp_amd import lib as L
+    lib = L.load()
+    uid = (C.c_char * 128)()
+    L.check(lib.amdseg_allreduce_unique_id(uid), "amdseg_allreduce_unique_id")
+    assert any(b != b"\x00" for b in uid)
+    comm = C.c_void_p()
+    L.check(lib.amdseg_allreduce_init(C.byref(comm), uid, 0, 1), "amdseg_allreduce_init")
+    assert comm.value
+    r, w, pend = C.c_int(-1), C.c_int(-1), C.c_size_t(99)
+    L.check(lib.amdseg_allreduce_info(comm, C.byref(r), C.byref(w), C.byref(pend)), "info")
+    assert (r.value, w.value, pend.value) == (0, 1, 0)
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(3)
+    a = torch.randn(1 << 22, device=dev, generator=g)
+    want_a = a * 3.0 + 1.0
+    a.mul_(3.0).add_(1.0)                                     # the "producer" on the compute stream: the bucket must see ITS result
+    b = torch.randn(1 << 20, device=dev, generator=g).bfloat16()
+    want_b = b.clone()
+    L.check(lib.amdseg_allreduce_bucket(comm, a.data_ptr(), a.numel(), L.F32, s), "bucket f32")
+    L.check(lib.amdseg_allreduce_bucket(comm, b.data_ptr(), b.numel(), L.BF16, s), "bucket bf16")
+    L.check(lib.amdseg_allreduce_bucket(comm, None, 0, L.F32, s), "empty bucket")
+    L.check(lib.amdseg_allreduce_info(comm, None, None, C.byref(pend)), "info")
+    assert pend.value == a.numel() + b.numel()
+    L.check(lib.amdseg_allreduce_wait(comm, s), "amdseg_allreduce_wait")
+    a2 = a * 1.0                                              # queued on the compute stream behind the wait
+    torch.cuda.synchronize()
+    assert torch.equal(a2, want_a) and torch.equal(b, want_b)
+    L.check(lib.amdseg_allreduce_info(comm, None, None, C.byref(pend)), "info")
+    assert pend.value == 0
+    # argument errors come back as codes with a message, never as a crash
+    assert lib.amdseg_allreduce_bucket(comm, a.data_ptr(), 8, 7, s) == 1002
+    assert lib.amdseg_allreduce_init(C.byref(C.c_void_p()), uid, 3, 2) == 1002
+    assert b"librccl" in lib.amdseg_error_string(1004)
+    L.check(lib.amdseg_allreduce_destroy(comm), "amdseg_allreduce_destroy")

@@ -699,3 +699,80 @@ def test_cos_score_predictor_train_grads_vs_reference_golden(dev, case, variant,
             wc = min(wc, c)
             assert c > (0.99 if precision == "bf16" else 0.99999), (n, c)
     print(f"{case}/{variant}/{precision}: worst grad-norm rel err {worst:.2e}, worst cosine {wc:.6f}")
+
+
+# ------------------------------------------------------------------------------------------------ pass-through: output_hidden_states
+@pytest.mark.parametrize("precision,tol", [("bf16", 0.06), ("parity", 1e-3), ("fp32", 1e-4)])
+@pytest.mark.parametrize("case", ["tiny_L64", "tiny_L128", "tiny_L100_B3"])
+def test_output_hidden_states_per_layer_vs_reference_golden(dev, case, precision, tol):
+    """bert_for_ts.py:57-63,111-112: `output_hidden_states=True` appends the anchor pass's hidden-state tuple (embedding output + one per
+    layer) to the return.  The goldens hold the reference's own `plain_eval.hidden{i}`: a PER-LAYER parity check of the encoder."""
+    z, sd, batch, arch = load_case(case)
+    fl = flags_of(z, "plain_eval")
+    fl["amdseg_precision"] = precision
+    m = build_model(arch, fl, sd, dev).eval()
+    random.seed(int(z["plain_eval.random_seed"]))
+    with torch.no_grad():
+        out = m(**to_dev(batch, dev), output_hidden_states=True)
+        plain = m(**to_dev(batch, dev))
+    assert len(out) == 4 and len(plain) == 3
+    assert torch.equal(out[1], plain[1]) and torch.equal(out[0], plain[0])       # asking for the states changes nothing else
+    hs = out[3]
+    n = arch["num_hidden_layers"]
+    assert isinstance(hs, tuple) and len(hs) == n + 1
+    worst = []
+    for i, h in enumerate(hs):
+        ref = torch.from_numpy(z[f"plain_eval.hidden{i}"])
+        assert h.shape == ref.shape and h.dtype == torch.float32
+        keep = batch["attention_mask"][:, 0].bool()                # rows of padding are not defined by either side's contract
+        d = (h.cpu() - ref)[keep].abs().max().item()
+        worst.append(d)
+        assert d < tol * max(1.0, float(ref[keep].abs().max()) / 4), (i, d)
+    print(f"{case}/{precision}: max|dhidden| per layer {['%.1e' % w for w in worst]}")
+    # training mode too (the training arena keeps every layer input): same values at dropout 0
+    m.train()
+    random.seed(0)
+    out_t = m(**to_dev(batch, dev), output_hidden_states=True)
+    assert len(out_t) == 4 and all((a - b).abs().max().item() < (1e-6 if precision != "bf16" else 2e-2) for a, b in zip(out_t[3], hs))
+
+
+# ------------------------------------------------------------------------------------------------ the Auto* surface
+def test_auto_model_for_token_classification_round_trip(dev, tmp_path):
+    """north_star: the AutoModelForTokenClassification plug-in surface.  A config twin (model_type "amdseg-bert") resolves through
+    AutoConfig / AutoModelForTokenClassification to the drop-in class; save_pretrained -> from_pretrained gives identical logits; the same
+    checkpoint loads through the reference driver's direct-class path (ts_sentence_seq_labeling.py:250-257) with identical logits."""
+    import spokennlp_amd
+    from transformers import AutoConfig, AutoModelForTokenClassification, BertConfig
+    from spokennlp_amd.bert_for_ts import BertWithDAForSentenceLabelingTopicSegmentation as M
+    z, sd, batch, arch = load_case("tiny_L64")
+    fl = flags_of(z, "full_eval")
+    cfg = spokennlp_amd.amdseg_config(BertConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **arch), **fl)
+    assert cfg.model_type == "amdseg-bert"
+    m = AutoModelForTokenClassification.from_config(cfg)
+    assert isinstance(m, M)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    random.seed(5)
+    with torch.no_grad():
+        loss, logits, cos = m(**to_dev(batch, dev))
+    ref = build_model(arch, fl, sd, dev).eval()                     # the direct class on a stock BertConfig
+    random.seed(5)
+    with torch.no_grad():
+        loss_r, logits_r, cos_r = ref(**to_dev(batch, dev))
+    assert torch.equal(logits, logits_r) and torch.equal(loss, loss_r) and torch.equal(cos, cos_r)
+    m.save_pretrained(tmp_path)
+    c2 = AutoConfig.from_pretrained(tmp_path)
+    assert type(c2).__name__ == "AmdsegBertConfig" and c2.cl_loss_weight == fl["cl_loss_weight"] and c2.do_da_ts is True
+    m2 = AutoModelForTokenClassification.from_pretrained(tmp_path).to(dev).eval()
+    assert isinstance(m2, M) and type(m2).__name__ == "AmdsegBertForTokenClassification"
+    random.seed(5)
+    with torch.no_grad():
+        _, logits2, _ = m2(**to_dev(batch, dev))
+    assert torch.equal(logits2, logits)
+    # ... and through the direct-class path of the reference driver, config passed explicitly
+    dcfg = BertConfig.from_pretrained(tmp_path)
+    m3 = M.from_pretrained(tmp_path, config=dcfg, ignore_mismatched_sizes=True).to(dev).eval()
+    random.seed(5)
+    with torch.no_grad():
+        _, logits3, _ = m3(**to_dev(batch, dev))
+    assert torch.equal(logits3, logits)
