@@ -380,10 +380,10 @@ def host_cpu():
 def cpu_baseline(args):
     """the CPU oracle (validated against the reference's golden vectors; it is the restatement that runs here, not the reference's
     files) timed on the host cores: bert-base shape, B = 8 sequences of 512 tokens, fp32 stock PyTorch CPU ops.  Two legs:
-    forward-only (eval, no_grad) and the training step (forward + backward + clip + AdamW).  The thread count is SWEPT (more threads than
+    forward-only (eval, no_grad) and the training step (forward + backward + clip + AdamW).  The thread count is SWEPT first (more threads than
     ~one NUMA domain make B = 8 x 512 slower, round 3: 128 threads 0.64 seq/s, 8 threads 1.42): forward-only over {8, 16, 32, 64,
-    physical cores} (1 warm-up + 2 timed each), then the training step at the two best counts (1 warm-up + 3 timed each); `value` is the
-    best training figure, `cores` the threads that gave it.  A reported baseline, not the target."""
+    physical cores}, the training step at the two best of them (1 warm-up + best of 3 each); then the BASELINE.md section 4 protocol (3 warm-up
+    + 10 timed steps, median) at the best count gives `value`; `cores` = the threads that ran it.  A reported baseline, not the target."""
     from oracle import bert_ts_oracle as O
     from tests.util import tiny_state_dict
     from spokennlp_amd import data
@@ -414,37 +414,50 @@ def cpu_baseline(args):
         with torch.no_grad():
             O.model_forward(params, cfg, batch)
 
-    def timed(fn, n):
+    def sweep(fn):                       # thread sweep: 1 warm-up + best of 3
         fn()
+        ts = []
+        for _ in range(3):
+            t = time.time(); fn(); ts.append(time.time() - t)
+        return min(ts)
+
+    def protocol(fn, warm=3, n=10):      # 3 warm-up + 10 timed steps; median, and the spread so the figure can be trusted
+        for _ in range(warm):
+            fn()
         ts = []
         for _ in range(n):
             t = time.time(); fn(); ts.append(time.time() - t)
         ts.sort()
-        return ts[len(ts) // 2] if n % 2 else ts[0]          # median of an odd count, best of an even one
+        return 0.5 * (ts[n // 2 - 1] + ts[n // 2]) if n % 2 == 0 else ts[n // 2], ts[0], ts[-1]
 
     t_start = time.time()
     counts = sorted({c for c in (8, 16, 32, 64, phys) if 1 <= c <= max(phys, 8)})
     fwd = {}
     for c in counts:
         torch.set_num_threads(c)
-        fwd[c] = round(nseq / timed(fwd_step, 2), 3)
+        fwd[c] = round(nseq / sweep(fwd_step), 3)
     order = sorted(counts, key=lambda c: -fwd[c])
     train = {}
     for c in order[:2]:
-        if time.time() - t_start > 75 and train:
-            break
         torch.set_num_threads(c)
-        train[c] = round(nseq / timed(train_step, 3), 3)
+        train[c] = round(nseq / sweep(train_step), 3)
     best = max(train, key=lambda c: train[c])
     best_f = order[0]
-    return dict(value=train[best], unit="seq/s", cores=best, kind="port", cpu=model, physical_cores=phys, logical_cpus=logical,
-                forward_only=dict(value=fwd[best_f], unit="seq/s", cores=best_f),
+    torch.set_num_threads(best)
+    med, lo, hi = protocol(train_step)
+    torch.set_num_threads(best_f)
+    fmed, flo, fhi = protocol(fwd_step)
+    return dict(value=round(nseq / med, 3), unit="seq/s", cores=best, kind="port", cpu=model, physical_cores=phys, logical_cpus=logical,
+                spread=dict(fastest_step_seq_per_s=round(nseq / lo, 3), slowest_step_seq_per_s=round(nseq / hi, 3)),
+                forward_only=dict(value=round(nseq / fmed, 3), unit="seq/s", cores=best_f,
+                                  spread=dict(fastest_step_seq_per_s=round(nseq / flo, 3), slowest_step_seq_per_s=round(nseq / fhi, 3))),
                 thread_sweep=dict(forward_only_seq_per_s={str(c): fwd[c] for c in counts}, train_seq_per_s={str(c): train[c] for c in train}),
                 seconds=round(time.time() - t_start, 1),
                 sample=f"fp32 torch CPU oracle (= the restatement validated against the reference's golden vectors, not the reference's files), "
-                       f"bert-base shape, {nseq} x {args.seq_len}-token sequences per step, {args.workload}: forward-only (eval, no_grad) swept over "
-                       f"{counts} threads (1 warm-up + best of 2), training step (fwd+bwd+clip+AdamW) at the two best counts (1 warm-up + median "
-                       f"of 3); value = best training figure; {model}, {phys} physical cores / {logical} logical CPUs")
+                       f"bert-base shape, {nseq} x {args.seq_len}-token sequences per step, {args.workload}.  Thread count swept first (forward-only over "
+                       f"{counts} threads, the training step at the two best of them; 1 warm-up + best of 3 each), then the BASELINE.md section 4 protocol "
+                       f"at the best count: 3 warm-up + 10 timed steps, value = {nseq} / median step time (training step = fwd+bwd+clip+AdamW at "
+                       f"{best} threads; forward-only = eval, no_grad at {best_f} threads); {model}, {phys} physical cores / {logical} logical CPUs")
 
 
 def run_leg(args, device, mode, precision, steps, warmup, prof_steps, seed=7):
@@ -504,15 +517,19 @@ def run_leg(args, device, mode, precision, steps, warmup, prof_steps, seed=7):
 
 
 def pmc_traffic(args):
-    """profiles/pmc_traffic.json if it describes this workload, else None"""
+    """(profiles/pmc_traffic.json, stale) -- the file if it describes this workload, else None; stale = the kernel sources it was measured on
+    (csrc_sha, spokennlp_amd.build.sources_sha) are not the sources shipped now: its figures are then NOT attached to the line"""
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except (OSError, ValueError):
-        return None
+        return None, False
     w = tr.get("workload", {})
     mine = dict(model=args.model, mode=args.mode, seq_len=args.seq_len, seqs_per_gpu=args.seqs_per_gpu, workload=args.workload,
                 precision=getattr(args, "precision", "bf16"))
-    return tr if all(w.get(k) == v for k, v in mine.items()) else None
+    if not all(w.get(k) == v for k, v in mine.items()):
+        return None, False
+    from spokennlp_amd.build import sources_sha
+    return tr, tr.get("csrc_sha") != sources_sha()
 
 
 def parity_report(device):
@@ -781,8 +798,12 @@ def main():
             # HBM bytes per launch: PMC counters cannot be read from inside the process, so these are the figures of the committed separate
             # rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by tools/pmc_to_json.py) -- attached only when the file's workload
             # is THIS workload, with the commit the passes ran on; null otherwise
-            tr = pmc_traffic(args)
-            if tr and dom in tr["kernels"]:
+            tr, stale = pmc_traffic(args)
+            if tr and stale:
+                out["roofline"]["traffic_stale"] = True
+                out["roofline"]["traffic_note"] = (f"profiles/pmc_traffic.json was measured on kernel sources {tr.get('csrc_sha')} @ {tr.get('git')}; the shipped "
+                                                   "sources hash differently, so its figures are not attached (re-run tools/run_pmc_instep.sh + tools/pmc_to_json.py)")
+            elif tr and dom in tr["kernels"]:
                 out["roofline"]["traffic"] = tr["kernels"][dom]["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_unit"] = "B per launch"
                 out["roofline"]["traffic_algorithmic"] = tr["kernels"][dom].get("algorithmic_bytes_per_launch")

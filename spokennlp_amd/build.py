@@ -16,6 +16,18 @@ OUT = os.path.join(HERE, "libamdseg.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
+def sources_sha():
+    """sha256 (16 hex digits) over the kernel sources a measurement depends on: every csrc/*.hip, csrc/*.h and include/amdseg.h, by name.
+    profiles/pmc_traffic.json records it (tools/pmc_to_json.py) and bench.py attaches the file's figures only when it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for f in names:
+        h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "amdseg.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 

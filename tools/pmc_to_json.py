@@ -4,8 +4,11 @@ real bench step): HBM bytes per launch of every kernel class the launch timer kn
 MI355X_MICROARCH.md: the counter reports half the bytes of the 16-B/lane loads these kernels issue) + WRITE_SIZE, both in KB per dispatch.
 usage: python tools/pmc_to_json.py gpurun_out/<tag>_pmc_instep.txt <git hash> [source path recorded in the json]"""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 # algorithmic bytes per launch (DESIGN.md section 5).  Round 4, second session: the FFN pre-activation tensor became a one-byte derivative (100.7 MB less
 # per layer over the eight NT launches: 1.356e8 -> 1.230e8 on average); AdamW runs as two launches (eagerly zeroed front part + encoder layers:
@@ -44,8 +47,10 @@ def main():
     out = {"_comment": "HBM bytes per launch of the profiled kernel classes from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 "
                        "correction of MI355X_MICROARCH.md, + WRITE_SIZE; two separate passes, --kernel-trace only).  bench.py reads this file for "
                        "roofline.traffic; written by tools/pmc_to_json.py from tools/run_pmc_instep.sh output.  PMC counters cannot be read from inside "
-                       "the process, so the figure is NOT re-measured by a bench run: `git` names the commit the passes ran on.",
+                       "the process, so the figure is NOT re-measured by a bench run: `git` names the commit the passes ran on and `csrc_sha` (spokennlp_amd.build.sources_sha) the kernel sources -- bench.py reports "
+                       "traffic: null + traffic_stale when the shipped sources hash differently.",
            "source": label, "git": git,
+           "csrc_sha": __import__("spokennlp_amd.build", fromlist=["sources_sha"]).sources_sha(),
            "command": "python bench.py --no-cpu-baseline --no-via-trainer --no-roofline --no-extra-legs --steps 4 --warmup 2",
            "workload": {"model": "bert", "mode": "train", "seq_len": 512, "seqs_per_gpu": 32, "workload": "full_da", "precision": "bf16"},
            "kernels": kernels}
