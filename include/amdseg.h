@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 11   /* 11: amdseg_allreduce_* (the gradient exchange over RCCL behind an explicit amdseg_comm context, csrc/comm.hip); 10: AMDSEG_EPI_KEEP_DERIV (amdseg_bert_layer_acts.u holds gelu' of the FFN pre-activation in bf16 training when the shape allows); 9: amdseg_heads_bwd_rows takes n_feat / fix / fix_bytes (order-independent scatter sums), amdseg_scatter_rows_sorted; 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_gemm_nt_bias_drop_res, amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 12   /* 12: amdseg_attn_bwd_merged (dQ, dK, dV from one kernel), amdseg_bert_layer_ws.dq_part; 11: amdseg_allreduce_* (the gradient exchange over RCCL behind an explicit amdseg_comm context, csrc/comm.hip); 10: AMDSEG_EPI_KEEP_DERIV (amdseg_bert_layer_acts.u holds gelu' of the FFN pre-activation in bf16 training when the shape allows); 9: amdseg_heads_bwd_rows takes n_feat / fix / fix_bytes (order-independent scatter sums), amdseg_scatter_rows_sorted; 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_gemm_nt_bias_drop_res, amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -127,6 +127,15 @@ int amdseg_attn_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, flo
 int amdseg_attn_bwd_keep(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, const void* keep,
                          amdseg_stream_t stream);
+/* attention backward as ONE kernel (csrc/attention_bwd_merged.hip; ABI 12): full attention, L % 256 == 0, dropout decisions from `keep` only
+ * (dropout_p > 0 without keep: AMDSEG_ERR_ARG).  One evaluation of P and dS feeds dQ, dK and dV (the two-kernel form amdseg_attn_bwd evaluates them
+ * twice); delta = rowsum(dO o O) is computed inside.  dq_part: fp32 scratch of amdseg_attn_bwd_merged_scratch_bytes(B, L, heads) bytes (the dQ
+ * contribution of the first 256-key block of a sequence while the second one is computed; deterministic order of addition).  kend / seq_order /
+ * pad_guard: optional, the fields of the same names of amdseg_bert_cfg: key blocks without an unmasked key and query chunks of exact-zero dO rows are not visited. */
+size_t amdseg_attn_bwd_merged_scratch_bytes(int B, int L, int heads);
+int amdseg_attn_bwd_merged(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse, void* dqkv, void* dq_part,
+                           int B, int L, int heads, float scale, float dropout_p, const void* keep, const int32_t* kend, const int32_t* seq_order,
+                           const int32_t* pad_guard, amdseg_stream_t stream);
 /* the band kernels on keep masks generated by amdseg_attn_keepmask_band (same window / nglobal): dropout decisions of the Longformer layers */
 int amdseg_attn_band_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                               float dropout_p, const void* keep, int window, int nglobal, amdseg_stream_t stream);
@@ -525,6 +534,8 @@ typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across
     /* AMDSEG_F32S only: split images of the four gradient operands d(FFN out), du, d(attention out), dqkv: [M,3H] [M,3I] [M,3H] [M,9H] */
     void *d_out_s, *du_s, *d_ao_s, *dqkv_s;
     void* dctx_s;                           /* optional, AMDSEG_F32S with acts.qkv_s: split image [M, 3H] of d(ctx) (scratch) */
+    void* dq_part;                          /* optional (ABI 12), bf16 full attention with L % 256 == 0: amdseg_attn_bwd_merged_scratch_bytes(B, L, heads)
+                                               bytes; non-NULL = the layer's attention backward runs as ONE kernel (amdseg_attn_bwd_merged) */
 } amdseg_bert_layer_ws;
 
 int amdseg_bert_layer_fwd(const amdseg_bert_cfg* cfg, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,

@@ -73,6 +73,12 @@ int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_o
 int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,
                          float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,
                          const void* keep = nullptr, int skip_q = 0);
+/* csrc/attention_bwd_merged.hip: dQ, dK, dV from ONE kernel (full attention, L % 256 == 0; dropout decisions from keep masks only) */
+size_t amdseg_attn_bwd_merged_scratch_bytes_impl(int B, int L, int heads);
+bool amdseg_attn_bwd_merged_ok(int L, float p, const void* keep);
+int amdseg_attn_bwd_merged_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+                                void* dq_part, int B, int L, int heads, float scale, float p, hipStream_t s, const int* kend, const int* seq_order,
+                                const int* qguard, const void* keep);
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
                          int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,

@@ -8,7 +8,12 @@
 
 extern "C" {
 
+// a library built with -DAMDSEG_PROBES carries wrong-result timing probes: its ABI version is NEGATIVE and spokennlp_amd.lib.load() refuses it
+#ifdef AMDSEG_PROBES
+int amdseg_abi_version(void) { return -AMDSEG_ABI_VERSION; }
+#else
 int amdseg_abi_version(void) { return AMDSEG_ABI_VERSION; }
+#endif
 int amdseg_set_cu_budget(int cus) { const int prev = g_amdseg_cu_budget; g_amdseg_cu_budget = cus > 0 ? cus : 0; return prev; }
 
 const char* amdseg_error_string(int code) {
@@ -75,6 +80,12 @@ int amdseg_attn_bwd_keep(const void* qkv, const float* mask_bias, const void* ct
                          amdseg_stream_t stream) {
     return amdseg_attn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, 0, 0, 0, S(stream), nullptr,
                                 nullptr, nullptr, keep);
+}
+size_t amdseg_attn_bwd_merged_scratch_bytes(int B, int L, int heads) { return amdseg_attn_bwd_merged_scratch_bytes_impl(B, L, heads); }
+int amdseg_attn_bwd_merged(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse, void* dqkv, void* dq_part,
+                           int B, int L, int heads, float scale, float dropout_p, const void* keep, const int32_t* kend, const int32_t* seq_order,
+                           const int32_t* pad_guard, amdseg_stream_t stream) {
+    return amdseg_attn_bwd_merged_impl(qkv, mask_bias, ctx, dctx, lse, dqkv, dq_part, B, L, heads, scale, dropout_p, S(stream), kend, seq_order, pad_guard, keep);
 }
 int amdseg_sattn_fwd(const void* qs, int ldq, int lo_q, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale,
                      float dropout_p, const void* keep, int window, int nglobal, amdseg_stream_t stream) {
@@ -667,7 +678,12 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     }
     const int NP = NPROJ(c);
     if (PHASE2(c)) {
-    if (c->mixer == 0)
+    const void* keep_b = c->p_attn > 0.f ? a->keep : nullptr;
+    if (c->mixer == 0 && c->window == 0 && w->dq_part && amdseg_attn_bwd_merged_ok(c->L, c->p_attn, keep_b))
+        // one kernel for dQ, dK, dV (csrc/attention_bwd_merged.hip): the caller opted in by providing the fp32 scratch of dQ's first key block
+        RET_IF(amdseg_attn_bwd_merged_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->dqkv, w->dq_part, c->B, c->L, c->heads, 0.125f, c->p_attn, s,
+                                           c->kend, c->seq_order, c->pad_guard, keep_b));
+    else if (c->mixer == 0)
         RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                     site_seed(c->seed, li, 0), c->window, c->nglobal, s, c->kend, c->seq_order, c->pad_guard,
                                     c->p_attn > 0.f ? a->keep : nullptr,

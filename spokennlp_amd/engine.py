@@ -195,6 +195,10 @@ class BertEncoderEngine:
         # attention-probability dropout decided once per layer (amdseg_attn_keepmask, acts.keep) instead of hashed per element in three kernels;
         # full softmax attention only (the band / list / pooling engines switch it off); AMDSEG_ATTN_HASH=1 keeps the hash path
         self.attn_keepmask = _os.environ.get("AMDSEG_ATTN_HASH", "0") != "1"
+        # attention backward as ONE kernel (csrc/attention_bwd_merged.hip: dQ, dK, dV from one evaluation of P and dS) -- built in round 5, correct,
+        # bit-reproducible, 35 % fewer instructions than the two-kernel form and SLOWER (191 vs 120 us per layer in the step: one fat workgroup per CU
+        # exposes its prologue / epilogue and runs at 48 % issue utilisation against 80 %, profiles/r05_attn_bwd_merged.md): opt-in, AMDSEG_ATTN_BWD_MERGED=1
+        self.attn_bwd_merged = _os.environ.get("AMDSEG_ATTN_BWD_MERGED", "0") == "1"
         # hidden-state dropout: the forward's add + LayerNorm kernels keep their decisions (1 byte per 8 elements, acts.drop1 / drop2) and the
         # LayerNorm backward reads them instead of re-hashing (every encoder family: the row kernels are shared); AMDSEG_HIDDEN_KEEPBITS=0 = hash twice
         self.hidden_keepbits = _os.environ.get("AMDSEG_HIDDEN_KEEPBITS", "1") != "0"
@@ -590,6 +594,15 @@ class BertEncoderEngine:
             A["ws_sets"] = [ws_set(), ws_set()]
             wkeys = ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx", "dqkv", "delta", "partials") + \
                 (("d_out_s", "du_s", "d_ao_s", "dqkv_s") if parity else ()) + (("dctx_s",) if split_attn else ())
+            p_attn = float(self.cfg.attention_probs_dropout_prob)
+            full_attn = not getattr(self, "windows", None) and getattr(self, "attention_type", "original_full") == "original_full"
+            if (self.attn_bwd_merged and not fp32 and self.nproj == 3 and full_attn and Lseq % 256 == 0 and (p_attn == 0 or self.attn_keepmask)):
+                # ONE scratch for both sets (only the main stream's attention backward touches it); zeroed once: its tail holds the kernel's sync words
+                nbytes = L.load().amdseg_attn_bwd_merged_scratch_bytes(B, Lseq, self.heads)
+                A["dq_part"] = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
+                for wset in A["ws_sets"]:
+                    wset["dq_part"] = A["dq_part"]
+                wkeys = wkeys + ("dq_part",)
             A["ws_structs"] = [L.LayerWs(**{k: w[k].data_ptr() for k in wkeys}) for w in A["ws_sets"]]
             A["ws"] = dict(A["ws_sets"][0], dy=[e(M, H), e(M, H)])
             A["ws_struct"] = A["ws_structs"][0]

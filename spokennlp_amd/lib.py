@@ -14,7 +14,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
 EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
 EPI_DERIV_U8 = 0x400      # with EPI_KEEP_DERIV: the derivative as one byte per element, q = round((g' + 0.135) * 200)
 EPI_KEEP_DERIV = 0x200    # OR-ed into EPI_BIAS_GELU: out2 = gelu'(pre-activation); into EPI_GELU_BWD: R is that derivative (C = (A B^T) * R)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
@@ -42,7 +42,7 @@ class LayerActs(C.Structure):
 
 class LayerWs(C.Structure):
     _fields_ = [(n, vp) for n in ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx", "dqkv", "delta", "partials",
-                                  "d_out_s", "du_s", "d_ao_s", "dqkv_s", "dctx_s")]
+                                  "d_out_s", "du_s", "d_ao_s", "dqkv_s", "dctx_s", "dq_part")]
 
 
 # name -> argtypes (restype is always int unless listed in _RESTYPE); mirrors include/amdseg.h one for one
@@ -66,6 +66,8 @@ _PROTOS = {
     "amdseg_attn_bwd_keep": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],
     "amdseg_attn_band_fwd_keep": [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
     "amdseg_attn_band_bwd_keep": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
+    "amdseg_attn_bwd_merged_scratch_bytes": [i32, i32, i32],
+    "amdseg_attn_bwd_merged": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp],
     "amdseg_sattn_fwd": [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
     "amdseg_sattn_bwd": [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
     "amdseg_attn_band_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, i32, vp],
@@ -145,7 +147,7 @@ _PROTOS = {
     "amdseg_bert_layer_bwd": [C.POINTER(BertCfg), C.POINTER(LayerParams), C.POINTER(LayerGrads), C.POINTER(LayerActs),
                               C.POINTER(LayerWs), vp, vp, vp, i32, vp],
 }
-_RESTYPE = {"amdseg_error_string": C.c_char_p, "amdseg_attn_keepmask_bytes": C.c_size_t, "amdseg_ponet_global_scratch_floats": C.c_size_t}
+_RESTYPE = {"amdseg_error_string": C.c_char_p, "amdseg_attn_keepmask_bytes": C.c_size_t, "amdseg_attn_bwd_merged_scratch_bytes": C.c_size_t, "amdseg_ponet_global_scratch_floats": C.c_size_t}
 
 EXPORTS = tuple(_PROTOS)
 _lib = None
@@ -175,7 +177,11 @@ def load(path=None):
             raise AmdsegError(f"libamdseg.so does not export {name}") from e
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.amdseg_abi_version() != ABI_VERSION:
+    v = lib.amdseg_abi_version()
+    if v == -ABI_VERSION and os.environ.get("AMDSEG_ALLOW_PROBES") != "1":
+        raise AmdsegError(f"{p} was built with -DAMDSEG_PROBES (wrong-result timing probes compiled in): not a product library "
+                          f"(AMDSEG_ALLOW_PROBES=1 loads it for tools/ measurements)")
+    if abs(v) != ABI_VERSION:
         raise AmdsegError("libamdseg.so ABI version mismatch")
     if path is None:
         _lib = lib

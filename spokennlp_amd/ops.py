@@ -115,6 +115,17 @@ def attn_bwd_keep(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, p, keep, scale
     return dqkv
 
 
+def attn_bwd_merged(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, p=0.0, keep=None, kend=None, seq_order=None, pad_guard=None, scale=0.125, dq_part=None):
+    """dQ, dK, dV from one kernel (amdseg_attn_bwd_merged): full attention, Lseq % 256 == 0, dropout decisions from `keep`"""
+    lib = L.load()
+    dqkv = torch.empty_like(qkv)
+    if dq_part is None:
+        dq_part = torch.zeros(lib.amdseg_attn_bwd_merged_scratch_bytes(B, Lseq, heads) // 4, dtype=torch.float32, device=qkv.device)      # (zeroed ONCE: its tail holds the kernel's own sync words)
+    L.check(lib.amdseg_attn_bwd_merged(_p(qkv), _p(mask_bias), _p(ctx), _p(dctx), _p(lse), _p(dqkv), _p(dq_part), B, Lseq, heads, scale, p, _p(keep),
+                                       _p(kend), _p(seq_order), _p(pad_guard), _s()), "amdseg_attn_bwd_merged")
+    return dqkv
+
+
 def attn_keepmask_band(B, Lseq, heads, p, seed, window, nglobal, device):
     """keep masks of a band (Longformer) layer: same buffer layout as attn_keepmask, only the cells the band kernels visit are written"""
     lib = L.load()

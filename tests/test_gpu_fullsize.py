@@ -171,8 +171,8 @@ def test_bad_shapes_and_devices_fail_loudly(dev):
     ids = batch["input_ids"][:1, 0, :40].to(dev)                         # 40 tokens: not a multiple of the kernel tiles -- the wrapper
     with pytest.raises(AmdsegError):                                     # pads such shapes (EncoderFn), the engine itself refuses them
         m.engine().forward(ids, torch.ones_like(ids), torch.zeros_like(ids), False)
-    with pytest.raises(AmdsegError):
-        m(**{k: v.to(dev) for k, v in batch.items()}, output_hidden_states=True)
+    with pytest.raises(AmdsegError):                                     # (hidden states are served since round 5; attention maps never exist)
+        m(**{k: v.to(dev) for k, v in batch.items()}, output_attentions=True)
     from tests.test_gpu_model import build_model  # noqa: F401
     m_cpu, _ = _tiny(torch.device("cpu"))
     with pytest.raises(AmdsegError):
