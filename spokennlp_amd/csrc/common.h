@@ -4,6 +4,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Wrong-result timing probes (-DAMDSEG_ABL_EPI=1/2: epilogue without stores / no epilogue, -DAMDSEG_ABL_NO_B / _NO_DMA: operands that cost nothing,
+// -DAMDSEG_ABL_GELU: a cheap stand-in for GELU, -DAMDSEG_ABL_LNB=1/2: LayerNorm backward without its column sums, AMDSEG_MG_DEBUG of the merged
+// attention backward) exist to time parts of a kernel; a library carrying one computes garbage with AMDSEG_OK.  They compile ONLY together with
+// -DAMDSEG_PROBES, which makes amdseg_abi_version() negative so that spokennlp_amd.lib.load() refuses the library (api.hip, lib.py).  Flags that
+// select a CORRECT variant (AMDSEG_ABL_EARLY_START, _LAZY_LGKM, _STRICT_LGKM, _NO_UNROLL2, AMDSEG_TN_*, AMDSEG_ATTN_FWD_NBUF / _WPE) need no gate.
+#if (defined(AMDSEG_ABL_EPI) && AMDSEG_ABL_EPI) || defined(AMDSEG_ABL_NO_B) || defined(AMDSEG_ABL_NO_DMA) || defined(AMDSEG_ABL_GELU) || (defined(AMDSEG_ABL_LNB) && AMDSEG_ABL_LNB)
+#ifndef AMDSEG_PROBES
+#error "AMDSEG_ABL_* wrong-result probes compile only with -DAMDSEG_PROBES (negative ABI version: not loadable as a product library)"
+#endif
+#endif
+
 typedef uint16_t bf16_t;   // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;

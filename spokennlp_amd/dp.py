@@ -23,7 +23,8 @@ def init_from_env(backend=None):
         # RCCL keeps one CU per channel busy for the whole of an overlapped all-reduce, and the GEMM grids of this path are sized by rounds of
         # workgroups over the CUs (csrc/gemm_dp.hip: amdseg_cu_budget): 436 MB per 13-ms step need tens of GB/s, not every link saturated, so
         # the ring gets at most 32 channels unless the launcher says otherwise (the weight-gradient GEMM's 216 tiles need 216 free CUs; 224 are left)
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
+        if os.environ.get("AMDSEG_NCCL_CHANNEL_CAP", "32") not in ("0", ""):          # (AMDSEG_NCCL_CHANNEL_CAP=0: leave RCCL's channel count alone)
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("AMDSEG_NCCL_CHANNEL_CAP", "32"))
         if backend is None:                      # AMDSEG_DIST_BACKEND=gloo: exercise the multi-rank path on a box with fewer GPUs than ranks
             backend = os.environ.get("AMDSEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():

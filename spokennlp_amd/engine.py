@@ -258,6 +258,11 @@ class BertEncoderEngine:
                 if nch > 0:
                     cus = torch.cuda.get_device_properties(self.device).multi_processor_count
                     self._bwd_cu_budget = max(cus - nch, cus // 2)       # applied around backward only: forward has every CU
+                    if dist.get_rank() == 0 and not getattr(BertEncoderEngine, "_budget_logged", False):
+                        BertEncoderEngine._budget_logged = True
+                        import sys as _sys
+                        print(f"spokennlp_amd: NCCL_MAX_NCHANNELS={nch}: backward tile rule counts on {self._bwd_cu_budget} of {cus} CUs "
+                              f"(AMDSEG_NCCL_CHANNEL_CAP=0 leaves the channel count alone)", file=_sys.stderr)
         return self.buckets is not None
 
     @contextlib.contextmanager

@@ -24,8 +24,10 @@ import transformers
 # multi-GPU launches: the ring of the engine's overlapped gradient exchange gets at most 32 channels unless the launcher chose otherwise (every RCCL
 # channel holds a CU for the length of the exchange and the GEMM grids of backward are sized by rounds over the CUs: dp.init_from_env,
 # profiles/r04_cu_budget_probe.md).  Has to be in the environment before the process group exists, i.e. before TrainingArguments is built.
-if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
-    os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
+# (It therefore also applies to a run that later asks for `Trainer(amdseg_native=False)` -- torch DDP, no CU budget --: AMDSEG_NCCL_CHANNEL_CAP=0 in
+# the environment leaves NCCL_MAX_NCHANNELS alone; any other value is used as the cap.  The engine logs the budget it derived from it once.)
+if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 and os.environ.get("AMDSEG_NCCL_CHANNEL_CAP", "32") not in ("0", ""):
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("AMDSEG_NCCL_CHANNEL_CAP", "32"))
 
 from . import lib as L
 
@@ -155,6 +157,10 @@ class AmdsegFusedAdamW(torch.optim.Optimizer):
         eng = self._engine()
         if not eng.fp.grad_is_zero:
             eng.zero_grad()
+        elif not set_to_none:
+            # an explicit "make the gradients literally zero": the slice the fused AdamW left for the next backward to overwrite is zeroed now
+            # (a reader of p.grad between step() and the next backward -- logging callbacks, custom clipping -- saw stale values)
+            eng.fp.flush_stale()
 
     # ---- checkpointing (Trainer saves optimizer.state_dict() next to the model): the state is three flat tensors
     def state_dict(self):

@@ -240,3 +240,23 @@ def test_auto_registration_resolves_to_the_drop_in_classes(tmp_path):
     with pytest.raises(ValueError):
         from transformers import GPT2Config
         spokennlp_amd.amdseg_config(GPT2Config())
+
+
+def test_wrong_result_probes_cannot_reach_a_product_library(tmp_path):
+    """timing probes that compute garbage (-DAMDSEG_ABL_EPI=1 ...) must not be one mistyped flag away from a product build.
+    They compile only with -DAMDSEG_PROBES, and such a library reports a NEGATIVE ABI version that lib.load() refuses."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    csrc = os.path.join(ROOT, "spokennlp_amd", "csrc")
+    base = [hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-c"]
+    r = subprocess.run(base + ["-DAMDSEG_ABL_EPI=1", os.path.join(csrc, "prof.hip"), "-o", str(tmp_path / "a.o")], capture_output=True, text=True)
+    assert r.returncode != 0 and "AMDSEG_PROBES" in r.stderr                     # a probe flag alone: does not compile
+    r = subprocess.run(base + ["-DAMDSEG_ABL_EPI=1", "-DAMDSEG_PROBES", os.path.join(csrc, "prof.hip"), "-o", str(tmp_path / "b.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    src = open(os.path.join(csrc, "api.hip")).read()
+    assert "return -AMDSEG_ABI_VERSION" in src and "#ifdef AMDSEG_PROBES" in src    # ... and the probe build announces itself
+    from spokennlp_amd import lib
+    assert "AMDSEG_PROBES" in open(lib.__file__).read() and lib.load().amdseg_abi_version() == lib.ABI_VERSION > 0
