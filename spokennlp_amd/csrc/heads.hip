@@ -38,10 +38,18 @@ struct HeadsArgs {
 // The row gradients of CSSL / TSSP are scatter sums (a feature row sits in the lists of many anchors; dWt sums over every TSSP row).
 // Float atomics would make their value depend on the arrival order; the contributions are instead rounded to 2^-40 and summed as 64-bit
 // integers -- integer addition commutes, so the sums (and with them the step) are bit-reproducible -- and converted back by the single
-// writer of each destination (heads_fix_apply_kernel).  |contribution| < 2^23 by a wide margin (these are loss gradients of O(1) rows).
+// writer of each destination (heads_fix_apply_kernel).  Supported range: |contribution| < 2^20 (these are loss gradients of O(1) rows; a loss scale
+// of 65536 still fits); a contribution outside it -- or a NaN / Inf of a diverged step, which __float2ll_rn would turn into 0 / saturate -- is
+// reported by fix_add, and the calling wave then writes NaN into the gradient row it was adding to (heads_poison): the apply pass adds on top
+// of it, so a diverged step reaches the gradient norm as NaN exactly as it did with float atomics.
 #define HEADS_FIX_SCALE 1099511627776.0f            // 2^40
-__device__ __forceinline__ void fix_add(unsigned long long* p, float v) {
-    atomicAdd(p, (unsigned long long)__float2ll_rn(v * HEADS_FIX_SCALE));
+__device__ __forceinline__ bool fix_add(unsigned long long* p, float v) {
+    const bool bad = !(fabsf(v) < 1048576.0f);                                   // also true for NaN
+    atomicAdd(p, (unsigned long long)__float2ll_rn(bad ? 0.f : v * HEADS_FIX_SCALE));
+    return bad;
+}
+__device__ __forceinline__ void heads_poison(bool bad, float* row, int l) {     // wave-wide: any lane's bad contribution poisons the row
+    if (__any(bad)) row[l] = __builtin_nanf("");
 }
 // dst[(rows ? rows[slot] : slot)][d] += fix[slot][d] * 2^-40; one wave per slot, each destination element has one writer per launch
 __global__ __launch_bounds__(256) void heads_fix_apply_kernel(const unsigned long long* fix, const int64_t* rows, int n, int H, float* dst) {
@@ -160,11 +168,13 @@ __global__ __launch_bounds__(256) void heads_cssl_kernel(HeadsArgs a) {
         const float* xo = a.x + (size_t)a.feat_rows[fo] * a.H;
         unsigned long long* dxo = a.fix + (size_t)fo * a.H;
         const float ca = dc / (na * no[k]), cva = dc * cs[k] / (na * na), cvo = dc * cs[k] / (no[k] * no[k]);
+        bool bad = false;
         for (int d = l; d < a.H; d += 64) {
             const float va = xa[d], vo = xo[d];
-            fix_add(dxa + d, ca * vo - cva * va);
-            fix_add(dxo + d, ca * va - cvo * vo);
+            bad |= fix_add(dxa + d, ca * vo - cva * va);
+            bad |= fix_add(dxo + d, ca * va - cvo * vo);
         }
+        heads_poison(bad, a.dx + (size_t)ra * a.H, l);
     }
 }
 
@@ -201,17 +211,19 @@ __global__ __launch_bounds__(256) void heads_tssp_kernel(HeadsArgs a) {
     for (int c = 0; c < HEADS_MAXC; ++c) if (c < a.Ct) dl[c] = g * (expf(lg[c] - lse) - (c == y ? 1.0f : 0.0f));
     unsigned long long* dxr = a.fix + (size_t)(a.n_feat + i) * a.H;       // this row's own slot: a plain store would do, kept uniform
     unsigned long long* dW = a.fix + (size_t)(a.n_feat + a.nt) * a.H;
+    bool bad = false;
     for (int d = l; d < a.H; d += 64) {
         const float xv = xr[d];
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < HEADS_MAXC; ++c)
-            if (c < a.Ct) { acc += dl[c] * a.Wt[(size_t)c * a.H + d]; fix_add(dW + (size_t)c * a.H + d, dl[c] * xv); }
-        fix_add(dxr + d, acc);
+            if (c < a.Ct) { acc += dl[c] * a.Wt[(size_t)c * a.H + d]; bad |= fix_add(dW + (size_t)c * a.H + d, dl[c] * xv); }
+        bad |= fix_add(dxr + d, acc);
     }
     if (l == 0)
 #pragma unroll
-        for (int c = 0; c < HEADS_MAXC; ++c) if (c < a.Ct) fix_add(dW + (size_t)a.Ct * a.H + c, dl[c]);
+        for (int c = 0; c < HEADS_MAXC; ++c) if (c < a.Ct) bad |= fix_add(dW + (size_t)a.Ct * a.H + c, dl[c]);
+    heads_poison(bad, a.dx + (size_t)r * a.H, l);
 }
 
 // ---------------------------------------------------------------------------------------------------- combine / CE backward

@@ -777,3 +777,50 @@ def test_auto_model_for_token_classification_round_trip(dev, tmp_path):
     with torch.no_grad():
         _, logits3, _ = m3(**to_dev(batch, dev))
     assert torch.equal(logits3, logits)
+
+
+def test_fused_heads_propagate_a_diverged_step_as_nan(dev):
+    """the heads' scatter sums are 64-bit fixed-point integers (bit-reproducible) -- a NaN / Inf contribution converts to 0 / saturates there.
+    A diverged step must still reach the gradient norm as NaN (as the float atomics did): the contributing wave poisons the gradient row."""
+    z, sd, batch, arch = load_case("tiny_L64")
+    m = build_model(arch, flags_of(z, "train_full"), sd, dev).train()
+    random.seed(7)
+    loss, _, _ = m(**to_dev(batch, dev))
+    loss.backward()
+    gn_ok = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+    assert math.isfinite(gn_ok) and gn_ok > 0
+    m.zero_grad(set_to_none=False)
+    random.seed(7)
+    loss, _, _ = m(**to_dev(batch, dev))
+    (loss * float("inf")).backward()                       # an overflowed loss scale: every head gradient contribution is Inf / NaN
+    gn = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+    assert not math.isfinite(gn)
+    emb = m.bert.embeddings.word_embeddings.weight.grad
+    assert not bool(torch.isfinite(emb).all())             # ... all the way down the encoder
+
+
+def test_direct_head_gradients_equal_autograd_ones_over_accumulation(dev):
+    """in native mode the fused heads write the classifier / TSSP-classifier gradients straight into their .grad views (accumulate) and hand
+    autograd None.  Over two accumulation micro-steps, and after zero_grad(set_to_none=True), they must equal what autograd computes for the same heads
+    (amdseg_fused_heads=False: torch formulation)."""
+    z, sd, batch, arch = load_case("tiny_L64")
+    names = ["loss_calculator.classifier.weight", "loss_calculator.classifier.bias", "loss_calculator.tssp.classifier.weight", "loss_calculator.tssp.classifier.bias"]
+    got = {}
+    for fused in (True, False):
+        m = build_model(arch, flags_of(z, "train_full"), sd, dev).train()
+        m.config.amdseg_fused_heads = fused
+        m.config.amdseg_precision = "parity"
+        for rnd in range(2):                               # second round: after zero_grad(set_to_none=True) the views must be re-attached and zeroed
+            for micro in range(2):
+                random.seed(11 + micro)
+                loss, _, _ = m(**to_dev(batch, dev))
+                (loss * (0.5 + micro)).backward()
+            params = dict(m.named_parameters())
+            got[(fused, rnd)] = {n: params[n].grad.detach().float().cpu().clone() for n in names}
+            m.zero_grad(set_to_none=True)
+    for rnd in range(2):
+        for n in names:
+            a, b = got[(True, rnd)][n], got[(False, rnd)][n]
+            assert float((a - b).norm()) <= 1e-4 * max(float(b.norm()), 1e-3), (rnd, n)
+        for n in names:                                    # and the second round equals the first: nothing was carried over a zero_grad
+            assert torch.allclose(got[(True, 0)][n], got[(True, 1)][n], rtol=1e-5, atol=1e-7), n
