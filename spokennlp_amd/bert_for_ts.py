@@ -433,8 +433,8 @@ class TopicSegHeadsMixin:
         sent_pair_orders=None,
         sent_token_mask=None,
     ):
-        if head_mask is not None or position_ids is not None or inputs_embeds is not None:
-            raise L.AmdsegError("head_mask / position_ids / inputs_embeds are not supported by the HIP encoder path")
+        if head_mask is not None or inputs_embeds is not None:
+            raise L.AmdsegError("head_mask / inputs_embeds are not supported by the HIP encoder path")
         if output_attentions:
             raise L.AmdsegError("attention maps are never materialised by the fused HIP path (softmax lives in registers)")
         cfg = self.config
@@ -476,6 +476,18 @@ class TopicSegHeadsMixin:
             tt = torch.cat((token_type_ids[:, 0], token_type_ids[:, 1]))
         else:
             ids, am, tt = input_ids[:, 0].contiguous(), attention_mask[:, 0].contiguous(), token_type_ids[:, 0].contiguous()
+        if position_ids is not None:                 # bert_for_ts.py:60,74: (B, 2, L) like the other columns, one slice per encoder pass
+            if position_ids.shape != input_ids.shape:
+                raise L.AmdsegError(f"position_ids must have the shape of input_ids {tuple(input_ids.shape)}, got {tuple(position_ids.shape)}")
+            self.engine()._explicit_pos = (torch.cat((position_ids[:, 0], position_ids[:, 1])) if two_pass else position_ids[:, 0]).contiguous()
+        try:
+            return self._forward_encoded(ids, am, tt, labels, host, ev, B, Lq, two_pass, output_hidden_states)
+        finally:
+            if position_ids is not None:
+                self.engine()._explicit_pos = None
+
+    def _forward_encoded(self, ids, am, tt, labels, host, ev, B, Lq, two_pass, output_hidden_states):
+        cfg = self.config
         hidden = None
         if output_hidden_states:
             # bert_for_ts.py:57-63,111-112: the flag goes to the ANCHOR encoder pass and its `hidden_states` tuple (embedding output + every

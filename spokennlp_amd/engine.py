@@ -697,7 +697,15 @@ class BertEncoderEngine:
         s = torch.cuda.current_stream().cuda_stream
         eps = float(self.cfg.layer_norm_eps)
         we, pe, te = self._emb("word_embeddings.weight"), self._emb("position_embeddings.weight"), self._emb("token_type_embeddings.weight")
-        pos = self._position_ids(input_ids)
+        # caller-given position ids (the wrapper's `position_ids` argument, bert_for_ts.py:60) take the explicit-position path of the embedding
+        # kernels (the one Longformer's pad-aware positions use); otherwise the family's own rule (BERT: 0 .. L-1 inside the kernel)
+        pos = getattr(self, "_explicit_pos", None)
+        if pos is not None:
+            if pos.numel() != M:
+                raise L.AmdsegError(f"position_ids: expected {M} ids for {B} x {Lseq} tokens, got {pos.numel()}")
+            pos = pos.reshape(-1).to(torch.int64).contiguous()
+        else:
+            pos = self._position_ids(input_ids)
         rc = lib.amdseg_embed_ln_fwd(ids.data_ptr(), tts.data_ptr(), None if pos is None else pos.data_ptr(), we.data_ptr(), pe.data_ptr(), te.data_ptr(),
                                      self._emb("LayerNorm.weight").data_ptr(), self._emb("LayerNorm.bias").data_ptr(),
                                      A["emb_z"].data_ptr(), A["x"][0].data_ptr(), A["emb_mean"].data_ptr(), A["emb_rstd"].data_ptr(),
@@ -982,6 +990,9 @@ class EncoderFn(torch.autograd.Function):
             input_ids = torch.nn.functional.pad(input_ids, grow, value=pad_id)
             attention_mask = torch.nn.functional.pad(attention_mask, grow, value=0)
             token_type_ids = torch.nn.functional.pad(token_type_ids, grow, value=0)
+        xp = getattr(engine, "_explicit_pos", None)
+        if xp is not None and (Bp, Lp) != (B, Lq):
+            engine._explicit_pos = torch.nn.functional.pad(xp.reshape(B, Lq), (0, Lp - Lq, 0, Bp - B), value=0)
         out, ectx = engine.forward(input_ids, attention_mask, token_type_ids, train, seed, p_out)
         sink = getattr(engine, "_hidden_sink", None)
         if sink is not None and (Bp, Lp) != (B, Lq):

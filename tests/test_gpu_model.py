@@ -824,3 +824,42 @@ def test_direct_head_gradients_equal_autograd_ones_over_accumulation(dev):
             assert float((a - b).norm()) <= 1e-4 * max(float(b.norm()), 1e-3), (rnd, n)
         for n in names:                                    # and the second round equals the first: nothing was carried over a zero_grad
             assert torch.allclose(got[(True, 0)][n], got[(True, 1)][n], rtol=1e-5, atol=1e-7), n
+
+
+# ------------------------------------------------------------------------------------------------ pass-through: position_ids
+@pytest.mark.parametrize("case", ["tiny_L64", "tiny_L100_B3"])
+def test_position_ids_pass_through(dev, case):
+    """bert_for_ts.py:60,74 forwards `position_ids[:, 0]` / `[:, 1]` to the encoder passes.  Served by the explicit-position path of the embedding kernels:
+    arange ids give exactly the default, and permuted ids give exactly what a model whose position table is permuted the same way computes at the default
+    positions -- forward and the position-table gradient (scattered through the permutation)."""
+    z, sd, batch, arch = load_case(case)
+    fl = flags_of(z, "train_full")
+    B, _, Lq = batch["input_ids"].shape
+    g = torch.Generator().manual_seed(3)
+    perm = torch.randperm(Lq, generator=g)
+    pos_default = torch.arange(Lq)[None, None, :].expand(B, 2, Lq).contiguous()
+    pos_perm = perm[None, None, :].expand(B, 2, Lq).contiguous()
+
+    def run(state, position_ids):
+        m = build_model(arch, fl, state, dev).train()
+        random.seed(5)
+        kw = {} if position_ids is None else {"position_ids": position_ids.to(dev)}
+        loss, logits, _ = m(**to_dev(batch, dev), **kw)
+        loss.backward()
+        return loss.item(), logits.detach().float().cpu(), m.bert.embeddings.position_embeddings.weight.grad.detach().float().cpu().clone()
+
+    l0, lg0, gp0 = run(sd, None)
+    l1, lg1, gp1 = run(sd, pos_default)
+    assert l0 == l1 and torch.equal(lg0, lg1) and torch.allclose(gp0, gp1, rtol=1e-6, atol=1e-7)
+    sd_b = dict(sd)
+    tab = sd["bert.embeddings.position_embeddings.weight"].clone()
+    tab[:Lq] = sd["bert.embeddings.position_embeddings.weight"][perm]
+    sd_b["bert.embeddings.position_embeddings.weight"] = tab
+    l2, lg2, gp2 = run(sd, pos_perm)                          # original table, permuted ids
+    l3, lg3, gp3 = run(sd_b, None)                            # permuted table, default ids
+    assert l2 == l3 and torch.equal(lg2, lg3)
+    assert l2 != l0                                           # (the permutation does change the model)
+    assert torch.allclose(gp2[perm], gp3[:Lq], rtol=1e-5, atol=1e-6)
+    with pytest.raises(Exception):
+        m = build_model(arch, fl, sd, dev).eval()
+        m(**to_dev(batch, dev), position_ids=pos_perm[:, :, :-1].to(dev))
