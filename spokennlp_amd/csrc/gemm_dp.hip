@@ -565,11 +565,17 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
     // ... but ROUNDS count (round 3, M = 8192 = the 4 x 2048 launch shape of run_finetune.sh): N = 2304 is 288 tiles of 256 columns = 2 rounds with
     // the second one 1/8 full, and 384 tiles of 192 = 2 rounds of 3/4 the work each: 45.0 -> 41.0 us; N = 3072 with the dual-output GELU epilogue
     // 56.6 -> 52.5 (384 -> 512 tiles).  The residual-reading epilogues lose on the narrow tile's staged stores (GELU' 57.8 -> 59.2) and stay wide.
+    // Round 5: the residual-adding input-gradient GEMMs (N = 768 at M = 16384: 192 tiles of 256 columns = three quarters of ONE round) take the narrow
+    // tile when that makes the single round (nearly) full: 256 tiles on 256 CUs, 64.4 -> 62 us per launch, 12.91 -> 12.78 ms per step (three
+    // interleaved repetitions on one box, profiles/r05_default_switches.md); at M = 8192 (128 narrow tiles: half a round either way) they stay wide.
     constexpr int EB = EPI_BASE(EPIX);
     bool narrow = false;
-    if (ok256 && ok192 && force == 0 && (EB == EPI_NONE || EB == EPI_BIAS || EB == EPI_BIAS_GELU || EB == EPI_BIAS_GELU_DG)) {
+    if (ok256 && ok192 && force == 0) {
         const int t256 = (a_in.M / DP_BM) * (a_in.N / 256), t192 = (a_in.M / DP_BM) * (a_in.N / 192), C = amdseg_cu_budget();
-        narrow = 0.78f * (float)((t192 + C - 1) / C) < (float)((t256 + C - 1) / C);
+        if (EB == EPI_NONE || EB == EPI_BIAS || EB == EPI_BIAS_GELU || EB == EPI_BIAS_GELU_DG)
+            narrow = 0.78f * (float)((t192 + C - 1) / C) < (float)((t256 + C - 1) / C);
+        else if (EB == EPI_ADD_RES)
+            narrow = t256 < C && t192 <= C && t192 * 8 >= C * 7;
     }
     constexpr bool direct_only = EB == EPI_BIAS_SPLIT || EB == EPI_GELU_BWD_SPLIT || EB == EPI_BIAS_GELU_SPLIT || EB == EPI_BIAS_DROP_RES ||
                                  EB == EPI_BIAS_GELU_DG8 || EB == EPI_MUL_RES8;    // epilogues of the 256-wide tile only

@@ -235,9 +235,11 @@ class BertEncoderEngine:
         self._matrix_params = [self.fp.params[n] for n in self.fp.params if n in mats]
         self.buckets = None
         import os
-        # opt-in: measured SLOWER on 1 x MI355X (19.7 vs 18.3 ms/step) -- the co-running weight-gradient GEMM and the next
-        # layer's GEMMs evict each other's panels from the XCD L2s; kept for multi-stream experiments
-        self.overlap_wgrad = os.environ.get("AMDSEG_OVERLAP_WGRAD", "0") == "1" and device.type == "cuda"
+        # the grouped weight-gradient GEMM of layer i on a second stream under layer i - 1's backward: its 216 tiles leave 40 CUs idle and the
+        # input-gradient GEMMs of the next layer fill them.  Round 1 measured this SLOWER (19.7 vs 18.3 ms: the two GEMMs evicted each other's
+        # panels from the XCD L2s); with the N-fastest tile order and the padding plan it is a gain: 12.91 -> 12.78 ms per step, three
+        # interleaved repetitions on one box (round 5, tools/dbg/ab_env_r05.sh, profiles/r05_default_switches.md).  AMDSEG_OVERLAP_WGRAD=0: one stream
+        self.overlap_wgrad = os.environ.get("AMDSEG_OVERLAP_WGRAD", "1") == "1" and device.type == "cuda"
         self._wgrad_stream = torch.cuda.Stream(device=device, priority=0) if self.overlap_wgrad else None
         self._wgrad_done = [None, None]
         self._wgrad_last = None
