@@ -235,11 +235,12 @@ class BertEncoderEngine:
         self._matrix_params = [self.fp.params[n] for n in self.fp.params if n in mats]
         self.buckets = None
         import os
-        # the grouped weight-gradient GEMM of layer i on a second stream under layer i - 1's backward: its 216 tiles leave 40 CUs idle and the
-        # input-gradient GEMMs of the next layer fill them.  Round 1 measured this SLOWER (19.7 vs 18.3 ms: the two GEMMs evicted each other's
-        # panels from the XCD L2s); with the N-fastest tile order and the padding plan it is a gain: 12.91 -> 12.78 ms per step, three
-        # interleaved repetitions on one box (round 5, tools/dbg/ab_env_r05.sh, profiles/r05_default_switches.md).  AMDSEG_OVERLAP_WGRAD=0: one stream
-        self.overlap_wgrad = os.environ.get("AMDSEG_OVERLAP_WGRAD", "1") == "1" and device.type == "cuda"
+        # opt-in (AMDSEG_OVERLAP_WGRAD=1): the grouped weight-gradient GEMM of layer i on a second stream under layer i - 1's backward -- its 216 tiles
+        # leave 40 CUs idle and the next layer's input-gradient GEMMs fill them.  Round 1 measured it slower (19.7 vs 18.3 ms); round 5, same box,
+        # interleaved: 12.54-12.61 -> 12.44-12.49 ms per step (+1 %, profiles/r05_default_switches.md).  Off by default all the same: the co-running
+        # kernels' spans stretch (NT 58 -> 74 us, TN 200 -> 230 us) and every per-kernel roofline figure -- bench.py's in-step timer as much as a
+        # rocprofv3 table of the same command -- would then describe two kernels sharing the chip instead of the kernel
+        self.overlap_wgrad = os.environ.get("AMDSEG_OVERLAP_WGRAD", "0") == "1" and device.type == "cuda"
         self._wgrad_stream = torch.cuda.Stream(device=device, priority=0) if self.overlap_wgrad else None
         self._wgrad_done = [None, None]
         self._wgrad_last = None
