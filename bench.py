@@ -381,8 +381,8 @@ def cpu_baseline(args):
     """the CPU oracle (validated against the reference's golden vectors; it is the restatement that runs here, not the reference's
     files) timed on the host cores: bert-base shape, B = 8 sequences of 512 tokens, fp32 stock PyTorch CPU ops.  Two legs:
     forward-only (eval, no_grad) and the training step (forward + backward + clip + AdamW).  The thread count is SWEPT first (more threads than
-    ~one NUMA domain make B = 8 x 512 slower, round 3: 128 threads 0.64 seq/s, 8 threads 1.42): forward-only over {8, 16, 32, 64,
-    physical cores}, the training step at the two best of them (1 warm-up + best of 3 each); then the BASELINE.md section 4 protocol (3 warm-up
+    ~one NUMA domain make B = 8 x 512 slower, round 3: 128 threads 0.64 seq/s, 8 threads 1.42): forward-only over {8, 16, 32}
+    (or up to the physical cores of a smaller box), the training step at the two best of them (1 warm-up + best of 3 each); then the BASELINE.md section 4 protocol (3 warm-up
     + 10 timed steps, median) at the best count gives `value`; `cores` = the threads that ran it.  A reported baseline, not the target."""
     from oracle import bert_ts_oracle as O
     from tests.util import tiny_state_dict
@@ -431,7 +431,9 @@ def cpu_baseline(args):
         return 0.5 * (ts[n // 2 - 1] + ts[n // 2]) if n % 2 == 0 else ts[n // 2], ts[0], ts[-1]
 
     t_start = time.time()
-    counts = sorted({c for c in (8, 16, 32, 64, phys) if 1 <= c <= max(phys, 8)})
+    # (rounds 3-5 on the 128-core EPYC 9575F pair: 8 / 16 / 32 threads give 4.8 / 8.7-13.4 / 4.8 seq/s forward, 64 and 128 threads 1-2 seq/s at
+    #  ~10 s per step -- the sweep stops at 32 so that the default run stays within a few minutes; a box with fewer cores sweeps up to what it has)
+    counts = sorted({c for c in (8, 16, 32) if c <= max(phys, 8)} | ({phys} if phys < 32 else set()))
     fwd = {}
     for c in counts:
         torch.set_num_threads(c)
