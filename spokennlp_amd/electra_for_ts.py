@@ -2,7 +2,8 @@
 (ElectraWithDAForSentenceLabelingTopicSegmentation).  ELECTRA-base's encoder is layer-for-layer the BERT block
 ([hf] models/electra/modeling_electra.py: ElectraEmbeddings == BertEmbeddings with embedding_size, ElectraLayer ==
 BertLayer), so the BERT engine runs it unchanged on the parameters found under `electra.*`.  Checkpoints whose
-embedding_size differs from hidden_size (electra-small's `embeddings_project`) are rejected loudly.
+embedding_size differs from hidden_size (electra-small: 128 -> 256) carry `electra.embeddings_project`: the engine then runs the
+embedding kernels at the embedding width and the projection as one NT GEMM (+ its weight / bias / input gradients), bf16 precision only.
 """
 from transformers.models.electra.modeling_electra import ElectraModel, ElectraPreTrainedModel
 
@@ -16,9 +17,6 @@ class ElectraWithDAForSentenceLabelingTopicSegmentation(TopicSegHeadsMixin, Elec
         self._fill_head_defaults(config)
         super().__init__(config)
         self.config = config
-        if config.embedding_size != config.hidden_size:
-            raise L.AmdsegError("the HIP ELECTRA path needs embedding_size == hidden_size (electra-base); "
-                                "embeddings_project is not implemented")
         self.electra = ElectraModel(config)        # parameter container only
         self._init_heads(config, config.hidden_dropout_prob)      # electra_for_ts.py:26
         self.post_init()

@@ -244,6 +244,13 @@ class BertEncoderEngine:
         self._wgrad_stream = torch.cuda.Stream(device=device, priority=0) if self.overlap_wgrad else None
         self._wgrad_done = [None, None]
         self._wgrad_last = None
+        # per-call pass-through state set by the wrappers around ONE encode() (bert_for_ts.TopicSegHeadsMixin.forward) and cleared right after it
+        # ELECTRA with embedding_size != hidden_size (electra-small: 128 -> 256): the embedding tables and their LayerNorm are E wide and a Linear
+        # `embeddings_project` ([hf] models/electra/modeling_electra.py, ElectraModel.forward) maps them to H in front of the first layer
+        self.E = int(getattr(config, "embedding_size", self.H) or self.H) if (self.prefix + "embeddings_project.weight") in self.fp.params else self.H
+        self.emb_project = self.E != self.H
+        self._hidden_sink = None            # list: output_hidden_states -> fp32 copies of the embedding output and every layer output
+        self._explicit_pos = None           # int64 [B * L]: caller-given position ids
 
     def enable_data_parallel(self):
         """overlap per-layer RCCL all-reduce of the flat gradient slices with backward (dp.GradBuckets)."""
@@ -563,7 +570,7 @@ class BertEncoderEngine:
                               lse=e(B * self.heads * Lseq, dt=torch.float32), mean1=e(M, dt=torch.float32),
                               rstd1=e(M, dt=torch.float32), mean2=e(M, dt=torch.float32), rstd2=e(M, dt=torch.float32))
                          for _ in range(nsave)],
-                 emb_z=e(M, H), emb_mean=e(M, dt=torch.float32), emb_rstd=e(M, dt=torch.float32),
+                 emb_z=e(M, self.E), emb_mean=e(M, dt=torch.float32), emb_rstd=e(M, dt=torch.float32),
                  mask_bias=e(B, Lseq, dt=torch.float32), gen=0, busy=False, stamp=0)
         # "parity" precision: attention as split-bf16 products (csrc/attention_split.hip) needs the split image of q|k|v per layer;
         # AMDSEG_PATTN_F32=1 keeps the fp32-MFMA attention of csrc/parity.hip
@@ -614,6 +621,10 @@ class BertEncoderEngine:
             A["ws_structs"] = [L.LayerWs(**{k: w[k].data_ptr() for k in wkeys}) for w in A["ws_sets"]]
             A["ws"] = dict(A["ws_sets"][0], dy=[e(M, H), e(M, H)])
             A["ws_struct"] = A["ws_structs"][0]
+        if self.emb_project:                # the E-wide embedding output (input of the projection; kept for its weight gradient) + backward scratch
+            A["emb_x"] = e(M, self.E)
+            if train:
+                A["demb"] = [e(M, self.E), e(M, self.E)]
         A["acts_struct"] = []
         for i in range(self.nlayers):
             la = A["layers"][i if train else 0]
@@ -709,12 +720,19 @@ class BertEncoderEngine:
             pos = pos.reshape(-1).to(torch.int64).contiguous()
         else:
             pos = self._position_ids(input_ids)
+        if self.emb_project and fp32:
+            raise L.AmdsegError("embeddings_project (ELECTRA with embedding_size != hidden_size) runs in bf16 precision only")
+        emb_out = A["emb_x"] if self.emb_project else A["x"][0]
         rc = lib.amdseg_embed_ln_fwd(ids.data_ptr(), tts.data_ptr(), None if pos is None else pos.data_ptr(), we.data_ptr(), pe.data_ptr(), te.data_ptr(),
                                      self._emb("LayerNorm.weight").data_ptr(), self._emb("LayerNorm.bias").data_ptr(),
-                                     A["emb_z"].data_ptr(), A["x"][0].data_ptr(), A["emb_mean"].data_ptr(), A["emb_rstd"].data_ptr(),
-                                     M, Lseq, self.H, we.shape[0], te.shape[0], pe.shape[0], eps,
+                                     A["emb_z"].data_ptr(), emb_out.data_ptr(), A["emb_mean"].data_ptr(), A["emb_rstd"].data_ptr(),
+                                     M, Lseq, self.E, we.shape[0], te.shape[0], pe.shape[0], eps,
                                      -p_h if self.emb_dropout_pre_ln else p_h, seed * 1000003 + 17, dt, s)
         L.check(rc, "amdseg_embed_ln_fwd")
+        if self.emb_project:                # x0 = emb_x Wp^T + bp (MFMA operand copy of the 2 x E x H matrix made per call: 64 KB)
+            wp = self.fp.params[self.prefix + "embeddings_project.weight"]
+            ops.gemm_nt(emb_out, wp.detach().to(torch.bfloat16), ops.EPI_BIAS, bias=self.fp.params[self.prefix + "embeddings_project.bias"].detach(),
+                        out=A["x"][0])
         mb = A["mask_bias"].data_ptr()
         saved = []
         sink = getattr(self, "_hidden_sink", None)          # output_hidden_states: fp32 copies of the embedding output and of every layer output
@@ -856,8 +874,18 @@ class BertEncoderEngine:
                     self.buckets.reduce_layer(i)
         self.fp.grad_stale = False                  # every layer's gradients have been written
         # embeddings: out = dropout(LN(z)) (BigBird: LN(dropout(z))); grads of LN affine + the three tables
+        Ew = self.E
+        if self.emb_project:
+            # d(Wp) (+)= dx0^T emb_x, d(bp) (+)= colsum(dx0) in one grouped launch; d(emb_x) = dx0 Wp (the NT kernel on the transposed operand copy)
+            wp = self.fp.params[self.prefix + "embeddings_project.weight"]
+            gw = self.fp.view(self.fp.flat_g, self.prefix + "embeddings_project.weight")
+            gb = self.fp.view(self.fp.flat_g, self.prefix + "embeddings_project.bias")
+            dx0 = dy.view(M, self.H) if dy.dim() == 2 else dy.reshape(M, self.H)
+            ops.gemm_tn_grouped([dx0], [A["emb_x"]], [gw], accumulate=bool(accumulate), colsums=[gb])
+            dy, other = A["demb"]
+            ops.gemm_nt(dx0, wp.detach().t().contiguous().to(torch.bfloat16), ops.EPI_NONE, out=dy)
         if ctx["p_h"] > 0 and not self.emb_dropout_pre_ln:
-            rc = lib.amdseg_dropout(dy.data_ptr(), other.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, adt, adt, s)
+            rc = lib.amdseg_dropout(dy.data_ptr(), other.data_ptr(), M * Ew, ctx["p_h"], ctx["seed"] * 1000003 + 17, adt, adt, s)
             L.check(rc, "amdseg_dropout(emb bwd)")
             dy, other = other, dy
         g = lambda n: self.fp.view(self.fp.flat_g, self.prefix + "embeddings." + n)        # noqa: E731
@@ -870,17 +898,17 @@ class BertEncoderEngine:
         rc = lib.amdseg_ln_bwd(dy.data_ptr(), A["emb_z"].data_ptr(), A["emb_mean"].data_ptr(), A["emb_rstd"].data_ptr(),
                                self._emb("LayerNorm.weight").data_ptr(), other.data_ptr(), None, ws["partials"].data_ptr(),
                                g("LayerNorm.weight").data_ptr(), g("LayerNorm.bias").data_ptr(), te.data_ptr() if type0_sum else None,
-                               M, self.H, 0.0, 0, 1 if accumulate else 0, adt, s)
+                               M, Ew, 0.0, 0, 1 if accumulate else 0, adt, s)
         L.check(rc, "amdseg_ln_bwd(emb)")
         if ctx["p_h"] > 0 and self.emb_dropout_pre_ln:
-            rc = lib.amdseg_dropout(other.data_ptr(), dy.data_ptr(), M * self.H, ctx["p_h"], ctx["seed"] * 1000003 + 17, adt, adt, s)
+            rc = lib.amdseg_dropout(other.data_ptr(), dy.data_ptr(), M * Ew, ctx["p_h"], ctx["seed"] * 1000003 + 17, adt, adt, s)
             L.check(rc, "amdseg_dropout(emb bwd, pre-LN)")
             dy, other = other, dy
         pad = self.cfg.pad_token_id if getattr(self.cfg, "pad_token_id", None) is not None else -1
         pos = ctx.get("pos")
         det = self.deterministic or bool(getattr(self.cfg, "amdseg_deterministic", False))
         rc = lib.amdseg_embed_bwd(other.data_ptr(), ctx["ids"].data_ptr(), ctx["tts"].data_ptr(), None if pos is None else pos.data_ptr(),
-                                  we.data_ptr(), pe.data_ptr(), te.data_ptr(), M, Lseq, self.H, 0 if det else we.shape[0],
+                                  we.data_ptr(), pe.data_ptr(), te.data_ptr(), M, Lseq, Ew, 0 if det else we.shape[0],
                                   -te.shape[0] if type0_sum else te.shape[0], 0 if (det and pos is not None) else pe.shape[0], pad, adt, s)
         L.check(rc, "amdseg_embed_bwd")
         if det:                                     # the word (and explicit position) tables without atomics: sums over a stable sort
@@ -888,7 +916,7 @@ class BertEncoderEngine:
                 if keys is None:
                     continue
                 order = torch.sort(keys.reshape(-1), stable=True)[1]
-                rc = lib.amdseg_scatter_rows_sorted(other.data_ptr(), keys.data_ptr(), order.data_ptr(), table.data_ptr(), M, self.H,
+                rc = lib.amdseg_scatter_rows_sorted(other.data_ptr(), keys.data_ptr(), order.data_ptr(), table.data_ptr(), M, Ew,
                                                     table.shape[0], skip, adt, s)
                 L.check(rc, "amdseg_scatter_rows_sorted")
         self._embed_backward_fixup(pe, pad)

@@ -308,11 +308,14 @@ def test_fp32_parity_mode_logits_within_1e3(dev, case, variant):
 
 
 # ------------------------------------------------------------------------------------------------ ELECTRA wrapper (f-3)
-def test_electra_wrapper_vs_reference_golden(dev):
+@pytest.mark.parametrize("case", ["electra_tiny_L64", "electra_small_tiny_L64"])
+def test_electra_wrapper_vs_reference_golden(dev, case):
+    """electra-base's shape family (embedding_size == hidden_size) and electra-small's (128 -> 256 through `embeddings_project`: embedding kernels at the
+    embedding width + one NT GEMM, its weight / bias / input gradients in backward) against the reference's own outputs"""
     from transformers import ElectraConfig
     from spokennlp_amd.electra_for_ts import ElectraWithDAForSentenceLabelingTopicSegmentation as M
     from oracle import bert_ts_oracle as O
-    z, sd, batch, arch = load_case("electra_tiny_L64")
+    z, sd, batch, arch = load_case(case)
     for variant, mode in (("full_eval", "eval"), ("train_full", "train")):
         cfg = ElectraConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **arch)
         for k, v in flags_of(z, variant).items():
@@ -342,7 +345,9 @@ def test_electra_wrapper_vs_reference_golden(dev):
                         continue
                     c = torch.nn.functional.cosine_similarity(params[n].grad.float().cpu().flatten(), ref.flatten(), dim=0).item()
                     assert c > 0.99, (n, c)
-        assert abs(loss.item() - float(z[f"{variant}.loss"])) < 0.05
+            if case == "electra_small_tiny_L64":
+                assert params["electra.embeddings_project.weight"].grad is not None and float(params["electra.embeddings_project.bias"].grad.abs().sum()) > 0
+        assert abs(loss.item() - float(z[f"{variant}.loss"])) < 0.05 * max(1.0, abs(float(z[f"{variant}.loss"])) / 5)
 
 
 def test_stock_torch_optimizer_loop_like_hf_trainer(dev):

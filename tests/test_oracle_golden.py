@@ -196,6 +196,34 @@ def test_electra_train_grads_match_reference():
             assert np.abs(sd[n].grad.numpy() - z[k]).max() < 5e-5, n
 
 
+def test_electra_small_embeddings_project_matches_reference():
+    """electra-small's shape family (embedding_size 128 != hidden_size 256): the `embeddings_project` Linear between the embedding LayerNorm and
+    the first layer ([hf] ElectraModel.forward); eval and train (every stored gradient, the projection's among them)."""
+    z, sd, batch, arch = load_case("electra_small_tiny_L64")
+    arch.pop("embedding_size", None)
+    assert "electra.embeddings_project.weight" in sd and sd["electra.embeddings_project.weight"].shape == (256, 128)
+    for variant in ("plain_eval", "full_eval"):
+        cfg = cfg_for(arch, flags_of(z, variant))
+        random.seed(int(z[f"{variant}.random_seed"]))
+        with torch.no_grad():
+            loss, logits, cos, hs = O.model_forward(sd, cfg, batch, return_hidden=True, encode=electra_encode)
+        assert abs(loss.item() - float(z[f"{variant}.loss"])) < 3e-5 and np.abs(logits.numpy() - z[f"{variant}.logits"]).max() < 3e-5
+        assert hs[0].shape[-1] == 256                        # (the encoder's first "hidden state" is the PROJECTED embedding output)
+    cfg = cfg_for(arch, flags_of(z, "train_full"))
+    sdg = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    random.seed(int(z["train_full.random_seed"]))
+    loss, _, _ = O.model_forward(sdg, cfg, batch, encode=electra_encode)
+    loss.backward()
+    assert abs(loss.item() - float(z["train_full.loss"])) < 5e-5
+    seen = 0
+    for k in z.files:
+        if k.startswith("train_full.grad."):
+            n = k[len("train_full.grad."):]
+            assert np.abs(sdg[n].grad.numpy() - z[k]).max() < 5e-5 * max(1.0, float(np.abs(z[k]).max())), n
+            seen += "embeddings_project" in n
+    assert seen == 2
+
+
 # ------------------------------------------------------------------------------------------------ BigBird (f-3)
 from oracle import bigbird_ts_oracle as BO  # noqa: E402
 from spokennlp_amd import bigbird_plan  # noqa: E402

@@ -422,7 +422,13 @@ def main_fullsize_bb():
 
 
 if __name__ == "__main__":
-    if "--cos-only" in sys.argv:
+    if "--electra-small-only" in sys.argv:
+        # electra-small's shape family: embedding_size != hidden_size -> ElectraModel.embeddings_project (electra_for_ts.py:25 builds the stock ElectraModel)
+        arch_s = dict(vocab_size=200, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, max_position_embeddings=128,
+                      type_vocab_size=2, embedding_size=128)
+        variants = [("plain_eval", PLAIN, "eval", 0, {}), ("full_eval", FULL, "eval", 5, {}), ("train_full", FULL, "train", 7, {})]
+        run_case("electra_small_tiny_L64", arch_s, 64, 2, 6, variants, kind="electra")
+    elif "--cos-only" in sys.argv:
         main_cos()
     elif "--fullsize-bb-only" in sys.argv:
         main_fullsize_bb()
