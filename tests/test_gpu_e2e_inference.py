@@ -109,3 +109,52 @@ def test_prefetcher_feeds_training_steps(dev):
         torch.cuda.Event.synchronize = real_sync
     assert waits["n"] == 0 and losses2[0] == losses[0]
     assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(losses, losses2))
+
+
+def _predict_worker(rank, world, port, out_dir, max_len, bs):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spokennlp_amd import data, inference
+        from tests.test_oracle_golden import load_case, flags_of
+        from tests.test_gpu_model import build_model
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(0)
+        z, sd, _, arch = load_case("tiny_L128")
+        docs = data.synth_docs(11, seed=77, vocab=arch["vocab_size"], mean_sents=30, sd_sents=10, mean_boundaries=4, mu_tok=1.8, sigma_tok=0.5)
+        sent_ids = [[s.tolist() for s in d["sentences"]] for d in docs]
+        labels = [[0 if v == 1 else 1 for v in d["labels"]] for d in docs]
+        m = build_model(arch, flags_of(z, "full_eval"), sd, dev)
+        got, metrics = inference.predict_documents(m, sent_ids, labels, max_len, arch["vocab_size"] - 1, data.CLS_ID, data.PAD_ID, batch_size=bs, device=dev)
+        torch.save(dict(docs=got, metrics=metrics), os.path.join(out_dir, f"pred{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_predict_documents_three_ranks_equal_one_process(dev, tmp_path):
+    """run_inference.sh:35 launches the predict branch on several ranks.  `inference.predict_documents` then shards the windows (rank r takes r, r + W, ...,
+    the tail wrapped), and every rank gathers logits and cos-sim rows back in window order (dp.gather_sharded): documents and metrics on every rank are
+    bit-identical to the single-process run -- 3 ranks (a window count that does not divide), sharing this box's GPU over gloo."""
+    import socket
+    import torch.multiprocessing as mp
+    from spokennlp_amd import data, inference
+    from tests.test_oracle_golden import load_case, flags_of
+    from tests.test_gpu_model import build_model
+    max_len, bs = 128, 2
+    z, sd, _, arch = load_case("tiny_L128")
+    docs = data.synth_docs(11, seed=77, vocab=arch["vocab_size"], mean_sents=30, sd_sents=10, mean_boundaries=4, mu_tok=1.8, sigma_tok=0.5)
+    sent_ids = [[s.tolist() for s in d["sentences"]] for d in docs]
+    labels = [[0 if v == 1 else 1 for v in d["labels"]] for d in docs]
+    m = build_model(arch, flags_of(z, "full_eval"), sd, dev)
+    ref_docs, ref_metrics = inference.predict_documents(m, sent_ids, labels, max_len, arch["vocab_size"] - 1, data.CLS_ID, data.PAD_ID, batch_size=bs, device=dev)
+    so = socket.socket(); so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]; so.close()
+    mp.spawn(_predict_worker, args=(3, port, str(tmp_path), max_len, bs), nprocs=3, join=True)
+    for r in range(3):
+        got = torch.load(tmp_path / f"pred{r}.pt", weights_only=False)
+        assert len(got["docs"]) == len(ref_docs)
+        for g, d in zip(got["docs"], ref_docs):
+            assert g["predictions"] == d["predictions"] and g["int_labels"] == d["int_labels"]
+            assert g["predict_logits"] == d["predict_logits"] and g["eop_pair_cos_sim"] == d["eop_pair_cos_sim"]
+        assert got["metrics"] == ref_metrics
