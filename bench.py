@@ -139,12 +139,19 @@ def prof_read_all(nsteps):
     return out
 
 
+def _graphs_suspended(flag):
+    """launches inside a replayed hipGraph (the engine's small-batch inference path) carry no events: the eager path runs while the launch timer is armed"""
+    from spokennlp_amd import engine
+    engine.GRAPHS_SUSPENDED = bool(flag)
+
+
 def prof_arm():
     from spokennlp_amd import lib as L
     lib = L.load()
     if lib.amdseg_prof_enable(1) < 0:
         return False
     lib.amdseg_prof_reset()
+    _graphs_suspended(True)
     return True
 
 
@@ -152,6 +159,7 @@ def prof_collect(nsteps):
     from spokennlp_amd import lib as L
     out = prof_read_all(nsteps)
     L.load().amdseg_prof_enable(0)
+    _graphs_suspended(False)
     return out
 
 
@@ -167,10 +175,12 @@ def instep_roofline(step, first_step, nsteps):
     if rc < 0:
         return None
     lib.amdseg_prof_reset()
+    _graphs_suspended(True)
     for i in range(first_step, first_step + nsteps):
         step(i)
     out = prof_read_all(nsteps)
     lib.amdseg_prof_enable(0)
+    _graphs_suspended(False)
     return out
 
 

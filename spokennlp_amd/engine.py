@@ -133,6 +133,7 @@ class FlatParams:
         return f"{self.encoder_prefix}{i}.{suffix}"
 
 
+GRAPHS_SUSPENDED = False            # bench.py sets this while the launch timer is armed (launches inside a replayed graph carry no events)
 _LIVE_ENGINES = weakref.WeakSet()
 _HOOKED = []
 
@@ -249,6 +250,8 @@ class BertEncoderEngine:
         # `embeddings_project` ([hf] models/electra/modeling_electra.py, ElectraModel.forward) maps them to H in front of the first layer
         self.E = int(getattr(config, "embedding_size", self.H) or self.H) if (self.prefix + "embeddings_project.weight") in self.fp.params else self.H
         self.emb_project = self.E != self.H
+        self.eval_graphs = os.environ.get("AMDSEG_EVAL_GRAPHS", "0") == "1" and device.type == "cuda"
+        self._eval_graphs = {}              # (B, L) -> captured inference forward
         self._hidden_sink = None            # list: output_hidden_states -> fp32 copies of the embedding output and every layer output
         self._explicit_pos = None           # int64 [B * L]: caller-given position ids
 
@@ -674,6 +677,48 @@ class BertEncoderEngine:
                 self._check_unseen_writes(fp32 == "parity")
             if train and not self._fused_owner:
                 self._dirty = True                          # an unknown optimiser is expected to write the weights after this step
+        if not train and self._eval_graph_ok(fp32, attention_mask):
+            return self._forward_graphed(input_ids, attention_mask, token_type_ids, seed, p_out, fp32)
+        return self._forward_body(input_ids, attention_mask, token_type_ids, train, seed, p_out, fp32)
+
+    # ---- small-batch inference: the encoder's ~100 launches as ONE hipGraph replay (opt-in: AMDSEG_EVAL_GRAPHS=1 / engine.eval_graphs = True)
+    # At 4 x 512 tokens (run_inference.sh ships per_device_eval_batch_size 4) queueing the encoder's launches costs the host 1.21 ms per call
+    # (tools/dbg/infer_small_batch.py).  After two eager calls at a shape the third is captured (torch.cuda.graph over the same `_forward_body`:
+    # static input buffers, the arena's own activations, a static output) and later calls copy their inputs in and replay: 0.1 ms of host time,
+    # bit-identical output (test_eval_forward_as_a_hipgraph_*).  The WALL time does not move -- 1.70 ms per model forward either way: the ~100
+    # kernels of a 2048-token forward are latency-bound on the GPU (1.16 ms + 0.33 ms of weight check + heads) -- so this only frees the host
+    # (tokenisation / gathers of a prediction loop) and stays off by default.  Only the plain engine (BERT / ELECTRA), bf16, hard masks, no
+    # hidden-state / position pass-through; the weight checks stay outside the graph; while the launch timer is armed (bench.py's roofline) the
+    # eager path runs, because launches inside a graph carry no events.
+    def _eval_graph_ok(self, fp32, attention_mask):
+        return (self.eval_graphs and not GRAPHS_SUSPENDED and type(self) is BertEncoderEngine and fp32 is False and not self.emb_project
+                and self._hidden_sink is None and self._explicit_pos is None and not attention_mask.dtype.is_floating_point
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _forward_graphed(self, input_ids, attention_mask, token_type_ids, seed, p_out, fp32):
+        B, Lseq = input_ids.shape
+        key = (B, Lseq)
+        ent = self._eval_graphs.get(key)
+        if ent is None:
+            ent = self._eval_graphs[key] = dict(calls=0, graph=None)
+            if len(self._eval_graphs) > 8:                  # (a prediction loop has one or two shapes; do not hoard graphs for a shape sweep)
+                self._eval_graphs.pop(next(iter(self._eval_graphs)))
+        ent["calls"] += 1
+        if ent["graph"] is None:
+            if ent["calls"] < 3:
+                return self._forward_body(input_ids, attention_mask, token_type_ids, False, seed, p_out, fp32)
+            ent["ids"] = input_ids.clone(); ent["am"] = attention_mask.clone(); ent["tt"] = token_type_ids.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out, _ = self._forward_body(ent["ids"], ent["am"], ent["tt"], False, seed, p_out, fp32)
+            ent["graph"], ent["out"] = g, out
+        ent["ids"].copy_(input_ids); ent["am"].copy_(attention_mask); ent["tt"].copy_(token_type_ids)
+        ent["graph"].replay()
+        return ent["out"].clone(), None                     # (a fresh tensor per call, as the eager path returns)
+
+    def _forward_body(self, input_ids, attention_mask, token_type_ids, train, seed, p_out, fp32):
+        B, Lseq = input_ids.shape
+        M = B * Lseq
         A = self._acquire_arena(B, Lseq, train, fp32)
         dt = L.F32 if fp32 else L.BF16
         p_h = float(self.cfg.hidden_dropout_prob) if train else 0.0

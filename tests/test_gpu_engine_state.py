@@ -291,3 +291,54 @@ def test_checksum_state_follows_what_the_copies_were_derived_from(dev):
         sd2 = {k: v.detach().clone().cpu() for k, v in m.state_dict().items()}
         random.seed(0); p_ref = fresh(sd2, "parity")(**b)[1]
         assert (p1 - p0).abs().max().item() > 1e-3 and torch.equal(p1, p_ref)
+
+
+def test_eval_forward_as_a_hipgraph_is_bit_identical_and_follows_the_weights(dev):
+    """opt-in (AMDSEG_EVAL_GRAPHS=1): small-batch inference replays the encoder as ONE hipGraph from the third call at a shape on
+    (engine._forward_graphed).  The replay must give the eager result bit for bit, see new inputs, see weights changed by an optimiser step or a raw
+    write (the refresh of the bf16 copies stays outside the graph), and step aside for what it does not cover."""
+    from spokennlp_amd import engine as E
+    from tests.test_oracle_golden import load_case, flags_of
+    from tests.test_gpu_model import build_model, to_dev
+    z, sd, batch, arch = load_case("tiny_L128")
+    fl = flags_of(z, "full_eval")
+    m = build_model(arch, fl, sd, dev).eval()
+    ref = build_model(arch, fl, sd, dev).eval()
+    ref.engine().eval_graphs = False
+    eng = m.engine()
+    eng.eval_graphs = True                                   # (opt-in: AMDSEG_EVAL_GRAPHS=1)
+    b1 = to_dev(batch, dev)
+    b2 = {k: v.clone() for k, v in b1.items()}
+    b2["input_ids"] = torch.where(b2["attention_mask"] > 0, (b2["input_ids"] * 7 + 3) % (arch["vocab_size"] - 5) + 4, b2["input_ids"])
+    with torch.no_grad():
+        for it in range(5):
+            for b in (b1, b2):
+                random.seed(5); got = m(**b)
+                random.seed(5); want = ref(**b)
+                assert torch.equal(got[1], want[1]) and torch.equal(got[0], want[0]), it
+        assert any(e["graph"] is not None for e in eng._eval_graphs.values())
+        # weights changed behind the graph's back: raw write to a master + an optimiser-style in-place update
+        for mm in (m, ref):
+            mm.bert.encoder.layer[0].attention.self.query.weight.data.mul_(1.5)
+            mm.bert.embeddings.word_embeddings.weight.data.add_(0.01)
+        random.seed(5); got = m(**b1)
+        random.seed(5); want = ref(**b1)
+        assert torch.equal(got[1], want[1])
+        # pass-throughs and the armed launch timer take the eager path; results stay the same
+        hs = m(**b1, output_hidden_states=True)
+        assert torch.equal(hs[1], want[1]) and len(hs[3]) == arch["num_hidden_layers"] + 1
+        E.GRAPHS_SUSPENDED = True
+        try:
+            assert torch.equal(m(**b1)[1], want[1])
+        finally:
+            E.GRAPHS_SUSPENDED = False
+    # a training step after graphed inference, then inference again
+    m.train()
+    random.seed(1); loss = m(**b1)[0]; loss.backward(); m.engine().adamw_step(1e-3)
+    ref.train()
+    random.seed(1); loss_r = ref(**b1)[0]; loss_r.backward(); ref.engine().adamw_step(1e-3)
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        random.seed(5); got = m(**b1)
+        random.seed(5); want = ref(**b1)
+    assert torch.equal(got[1], want[1])
