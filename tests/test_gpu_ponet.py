@@ -623,3 +623,54 @@ def test_backward_drops_the_rows_of_trailing_padding(dev):
         assert scale > 0
         noise = max(float((on[n] - on2[n]).abs().max()), float((off[n] - off2[n]).abs().max()))
         assert float((on[n] - off[n]).abs().max()) <= max(3 * noise, 3e-3 * scale), (n, noise, scale)   # (a dropped live tile: >= 1/64 of the sum)
+
+
+def test_extractive_summarisation_path_vs_oracle(dev):
+    """PoNet extractive summarisation (ponet_extractive_summarization.py:501 -- the same PoNetForTokenClassification; :611-768 the
+    feature builder with sentence-level segment ids; :853-905 the decode).  End to end on synthetic meetings: ES features (bit-exact builder) -> HIP
+    model -> argmax at the labelled [EOS] -> per-document summary sentences, against the same chain on the PoNet oracle.  (The encoder itself stays
+    parity-UNPINNED: the oracle restates the published algorithm, its source is not in the reference tree.)"""
+    import numpy as np
+    from oracle import ponet_oracle as PO
+    from oracle import bert_ts_oracle as O
+    from spokennlp_amd import preprocess as P
+    L_, eos, cls, pad = 128, 299, 1, 0
+    rng = np.random.default_rng(7)
+    docs = [[rng.integers(10, 290, int(rng.integers(3, 12))).tolist() + [eos] for _ in range(int(rng.integers(25, 60)))] for _ in range(4)]
+    labels = [[0 if rng.random() < 0.25 else 1 for _ in d] for d in docs]           # 0 = "B-EOP" = summary sentence (:907-912)
+    cols = P.ponet_prepare_features(docs, labels, list(range(len(docs))), L_, eos, cls, pad, use_paragraph_segment=False)
+    n = len(cols["input_ids"])
+    assert n >= 8
+    n -= n % 2
+    t = {k: torch.tensor(cols[k][:n], dtype=torch.long) for k in ("input_ids", "attention_mask", "token_type_ids", "segment_ids", "labels")}
+    m, cfg = build(dev)
+    sd = {k: v.detach().clone().float() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        _, logits_o = PO.token_classification_forward(sd, O.make_cfg(num_labels=2, **ARCH), t["input_ids"], t["attention_mask"], t["token_type_ids"],
+                                                      t["segment_ids"], t["labels"])
+        m = m.to(dev).eval()
+        out = m(**{k: v.to(dev) for k, v in t.items()}, return_dict=True)
+    logits = out.logits.float().cpu()
+    lab = t["labels"] != -100
+    d = (logits - logits_o)[lab].abs().max().item()
+    assert d < 0.02 * logits_o.abs().max().item() + 0.05, d
+    margin = (logits_o[..., 0] - logits_o[..., 1]).abs()
+    sure = lab & (margin > 4 * d)                                  # decisions the bf16 noise cannot flip must be equal
+    assert sure.sum() > 0.8 * lab.sum()
+    assert torch.equal(logits.argmax(-1)[sure], logits_o.argmax(-1)[sure])
+    nsent = [b - a for a, b in cols["sentence_range"][:n]]
+    ex = cols["example_id"][:n]
+    # integer decode (es_collect_predictions) on the HIP logits with the unsure positions taken from the oracle: document-level equality
+    pred = torch.where(sure, logits.argmax(-1), logits_o.argmax(-1))
+    got_p, got_g = P.es_collect_predictions(pred.tolist(), t["labels"].tolist(), nsent, ex, len(docs))
+    ref_p, ref_g = P.es_collect_predictions(logits_o.argmax(-1).tolist(), t["labels"].tolist(), nsent, ex, len(docs))
+    assert got_p == ref_p and got_g == ref_g
+    covered = [sum(ns for ns, e in zip(nsent, ex) if e == i) for i in range(len(docs))]
+    for i, (p_, g_) in enumerate(zip(got_p, got_g)):
+        assert len(p_) == len(g_) == covered[i]
+        if covered[i] == len(labels[i]):                           # every window of the document made it into the (even-sized) batch
+            want = [j for j, v in enumerate(labels[i]) if v == 0]
+            got_sel = P.es_selected_sentences(g_)
+            # (a window's cut-off last sentence is scored as "O" by the reference, :897-899: the gold selection is a subset of the true one)
+            assert set(got_sel) <= set(want) and len(want) - len(got_sel) <= n
+    print("ES path: windows", n, "max|dlogit|", d, "sure fraction", float(sure.sum()) / float(lab.sum()))
