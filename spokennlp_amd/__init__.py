@@ -7,5 +7,13 @@ __version__ = "0.1.0"
 
 # the Auto* surface (north_star: "keeping the HuggingFace AutoModelForTokenClassification + Trainer plug-in surface"): config twins with
 # their own model_type + the drop-in classes, registered with AutoConfig / AutoModelForTokenClassification at package import
-from . import auto  # noqa: E402,F401
-from .auto import amdseg_config  # noqa: E402,F401
+# (a ctypes-only user of `spokennlp_amd.lib` / `.build` must not depend on transformers being importable: the registration is best effort here and
+#  `import spokennlp_amd.auto` raises the real error)
+try:
+    from . import auto  # noqa: E402,F401
+    from .auto import amdseg_config  # noqa: E402,F401
+except ImportError as _e:                                    # pragma: no cover -- transformers absent or too old for the model classes
+    _auto_import_error = _e
+
+    def amdseg_config(*_a, **_k):
+        raise ImportError(f"spokennlp_amd.auto could not be imported: {_auto_import_error}")
