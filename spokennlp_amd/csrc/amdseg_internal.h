@@ -182,6 +182,6 @@ int amdseg_lf_global_bwd_rest_impl(const void* x, int x_dtype, void* dx, int dx_
                                    float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads, float scale, hipStream_t s);
 
 // CUs the launch-geometry rules may count on (gemm_dp.hip)
-extern int g_amdseg_cu_budget;
+extern thread_local int g_amdseg_cu_budget;
 int amdseg_cu_budget();
 int amdseg_num_cus();

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
 #endif
 }
 
-static int g_force_small_tile = 0;      // test hook (amdseg_debug_force_small_tile): exercise the 128x128 kernel on big shapes
+static thread_local int g_force_small_tile = 0;      // test hook (amdseg_debug_force_small_tile): exercise the 128x128 kernel on big shapes
 int amdseg_set_force_small_tile(int v) { int o = g_force_small_tile; g_force_small_tile = v; return o; }
 
 // ------------------------------------------------------------------------------------------------ gemm_nt, ping-pong 256x192

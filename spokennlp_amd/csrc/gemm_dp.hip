@@ -544,7 +544,7 @@ static int launch_nt_dp_nf(const GemmNTArgs& a_in, hipStream_t s) {
 // channel for the whole of backward -- a deep-pipeline workgroup needs a CU's entire register file, so those CUs are lost to it -- and a grid of
 // exactly 256 tiles then runs TWO rounds: measured with tools/dbg/cu_hog.sh, 8 / 16 / 32 occupied CUs all cost the training step 10 % (NT launch
 // average 61 -> 72 us), 64 double the weight-gradient GEMM (216 tiles).  The tile-width choice below counts rounds against the budget.
-int g_amdseg_cu_budget = 0;
+thread_local int g_amdseg_cu_budget = 0;        // per calling THREAD (one host thread drives one GPU's streams): two binders in one process do not see each other's budget
 int amdseg_num_cus() { return dp_num_cus(); }
 int amdseg_cu_budget() {
     static int env = -1, cus = 0;
