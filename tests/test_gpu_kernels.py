@@ -708,3 +708,20 @@ def test_gemm_bias_dropout_residual_epilogue(dev, K, p):
     refln = torch.nn.functional.layer_norm(z.float(), (N,), gamma, beta, 1e-12)
     assert (out_f.float() - refln).abs().max().item() < 3e-2
     assert (mean_f - z.float().mean(1)).abs().max().item() < 1e-4
+
+
+def test_c_abi_binder_without_python_or_torch(dev):
+    """the drop-in boundary is a C ABI -- plain pointers, a stream, int codes, caller-owned buffers, no torch types.  tools/cabi_demo.cpp
+    binds include/amdseg.h from C++ with nothing but the HIP runtime (hipMalloc'ed buffers, its own stream): one projection GEMM with the bias epilogue
+    against a double-precision CPU product, the error path, and amdseg_allreduce_* with a world of one rank.  Built by __graft_entry__.build()."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "cabi_demo.bin")
+    if not os.path.exists(exe):
+        pytest.skip("tools/cabi_demo.bin not built (run __graft_entry__.build() where hipcc is)")
+    env = dict(os.environ)
+    import torch as _t                                       # the process needs A HIP runtime on its path: torch's own copy will do on a box without /opt/rocm/lib
+    env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(os.path.dirname(_t.__file__), "lib"), "/opt/rocm/lib", env.get("LD_LIBRARY_PATH", "")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "CABI_DEMO_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+    assert f"amdseg ABI {_ops().L.ABI_VERSION}" in r.stdout
