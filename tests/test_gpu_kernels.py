@@ -2,6 +2,7 @@
 fp32 torch reference of the same op on the same seeded inputs.  Tolerances are stated per test: bf16 outputs carry a
 2^-9 relative rounding, MFMA accumulates in fp32."""
 import math
+import os
 
 import pytest
 import torch
