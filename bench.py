@@ -843,7 +843,23 @@ def main():
                             and args.seq_len == 512 and args.seqs_per_gpu == 32)
         if default_workload and not args.no_extra_legs:
             # the legs the headline does not cover, each bounded to seconds, all outside the timed region above
+            def overlap_leg():
+                # the same workload with the weight-gradient GEMM of layer i on a second stream under layer i - 1's backward (AMDSEG_OVERLAP_WGRAD=1): opt-in
+                # because per-kernel spans then describe co-running kernels (profiles/r05_default_switches.md) -- its throughput is reported here
+                old = os.environ.get("AMDSEG_OVERLAP_WGRAD")
+                os.environ["AMDSEG_OVERLAP_WGRAD"] = "1"
+                try:
+                    r = run_leg(args, device, "train", "bf16", 40, 10, 0)
+                finally:
+                    if old is None:
+                        os.environ.pop("AMDSEG_OVERLAP_WGRAD", None)
+                    else:
+                        os.environ["AMDSEG_OVERLAP_WGRAD"] = old
+                r["note"] = "AMDSEG_OVERLAP_WGRAD=1 (opt-in); the headline `value` is measured without it"
+                return r
+
             for key, fn in (("vendor_yardstick", lambda: vendor_yardstick(args, device)),
+                            ("overlap_wgrad_leg", overlap_leg),
                             ("parity_report", lambda: parity_report(device)),
                             ("parity_leg", lambda: run_leg(args, device, "train", "parity", 10, 3, 4)),
                             ("infer_leg", lambda: dict(bf16=run_leg(args, device, "infer", "bf16", 40, 8, 6),
