@@ -8,9 +8,16 @@ golden vector exists, and the packages are absent here):
     (Beeferman et al. 1999; Pevzner & Hearst 2002) with segeval's defaults: masses in, window size k =
     max(2, round_half_even(mean reference segment mass / 2)), N - k probes, no Lamprier fix;
   * sklearn precision/recall/f1 on the flattened 0/1 lists (:231-234) -- binary, positive class 1, 0 on zero division;
-  * seqeval==1.2.2 chunk P/R/F1 (:141-171) -- with the label set {"B-EOP", "O"} every "B-EOP" tag is a one-token chunk,
-    so chunk-level scores equal the tag-level scores of "B-EOP".
+  * seqeval==1.2.2 chunk P/R/F1 (:141-171): `seqeval_scores` below restates the package's default-mode `classification_report`
+    (conlleval chunk extraction + per-type / micro precision, recall, F1 + tag accuracy) and is pinned on the worked example the
+    reference file holds in its docstring (seqeval.py:96-105: overall_f1 0.5, PER f1 1.0) and on brute-force chunk counting; with the
+    label set {"B-EOP", "O"} every "B-EOP" tag is a one-token chunk, so chunk-level scores equal the tag-level scores of "B-EOP".
+Also here: the `compute_metrics` closure the Trainer calls during fine-tuning (ts_sentence_seq_labeling.py:1018-1074 ->
+`make_compute_metrics`), the WikiSection sentence-level re-scoring of paragraph-level predictions (postprocess_predictions.py:7-75) and
+the `*_str_metric.txt` writer (utils.py:8-48).
 """
+import json
+import os
 from decimal import ROUND_HALF_EVEN, Decimal
 
 import numpy as np
@@ -166,6 +173,212 @@ def compute_metric_example_level(predictions_logits, labels, label_list=("B-EOP"
             soft.append(pred)
         res.update(compute_window_metric(soft, true_bin, prefix="f1@%d_example_level_" % f1_at_k))
     return res
+
+
+# ---------------------------------------------------------------------------------------------------- seqeval chunk-level scores
+def _tag_and_type(label, suffix=False):
+    """seqeval 1.2.2 `get_entities`: "B-EOP" -> ("B", "EOP"); a bare "O" has the type "_" """
+    if suffix:
+        return label[-1], (label[:-1].rsplit("-", maxsplit=1)[0] or "_")
+    return label[0], (label[1:].split("-", maxsplit=1)[-1] or "_")
+
+
+def _end_of_chunk(prev_tag, tag, prev_type, type_):
+    if prev_tag in ("E", "S"):
+        return True
+    if prev_tag in ("B", "I") and tag in ("B", "S", "O"):
+        return True
+    return prev_tag not in ("O", ".") and prev_type != type_
+
+
+def _start_of_chunk(prev_tag, tag, prev_type, type_):
+    if tag in ("B", "S"):
+        return True
+    if prev_tag in ("E", "S", "O") and tag in ("E", "I"):
+        return True
+    return tag not in ("O", ".") and prev_type != type_
+
+
+def get_entities(seq, suffix=False):
+    """the conlleval chunk extraction seqeval's default mode runs (what `classification_report(scheme=None)` of seqeval.py:141-150 calls):
+    a list of tag lists is joined with an "O" between the sequences; returns [(type, first, last)] in positions of the joined list"""
+    if any(isinstance(s, (list, tuple)) for s in seq):
+        seq = [item for sub in seq for item in list(sub) + ["O"]]
+    prev_tag, prev_type, begin, chunks = "O", "", 0, []
+    for i, label in enumerate(list(seq) + ["O"]):
+        tag, type_ = _tag_and_type(label, suffix)
+        if _end_of_chunk(prev_tag, tag, prev_type, type_):
+            chunks.append((prev_type, begin, i - 1))
+        if _start_of_chunk(prev_tag, tag, prev_type, type_):
+            begin = i
+        prev_tag, prev_type = tag, type_
+    return chunks
+
+
+def _prf(tp, npred, ntrue):
+    p = tp / npred if npred else 0.0                    # zero_division="warn" acts as 0 (seqeval.py:76-77)
+    r = tp / ntrue if ntrue else 0.0
+    return p, r, (2 * p * r / (p + r) if (p + r) else 0.0)
+
+
+def seqeval_scores(predictions, references, suffix=False):
+    """`Seqeval._compute` (seqeval.py:125-170) with its defaults (scheme=None, mode=None, no sample weights): per chunk type
+    {"precision", "recall", "f1", "number"} and "overall_precision" / "overall_recall" / "overall_f1" (micro average over chunks) /
+    "overall_accuracy" (tag accuracy).  A chunk counts when type, first and last position all agree."""
+    if len(predictions) != len(references) or any(len(p) != len(r) for p, r in zip(predictions, references)):
+        raise ValueError("Found input variables with inconsistent numbers of samples")          # seqeval's check_consistent_length
+    true_by, pred_by = {}, {}
+    for t, b, e in get_entities(references, suffix):
+        true_by.setdefault(t, set()).add((b, e))
+    for t, b, e in get_entities(predictions, suffix):
+        pred_by.setdefault(t, set()).add((b, e))
+    scores, tp_all, np_all, nt_all = {}, 0, 0, 0
+    for t in sorted(set(true_by) | set(pred_by)):
+        tr, pr = true_by.get(t, set()), pred_by.get(t, set())
+        tp = len(tr & pr)
+        p, r, f = _prf(tp, len(pr), len(tr))
+        scores[t] = {"precision": p, "recall": r, "f1": f, "number": len(tr)}
+        tp_all += tp; np_all += len(pr); nt_all += len(tr)
+    p, r, f = _prf(tp_all, np_all, nt_all)
+    scores["overall_precision"], scores["overall_recall"], scores["overall_f1"] = p, r, f
+    flat_t = [x for row in references for x in row]
+    flat_p = [x for row in predictions for x in row]
+    scores["overall_accuracy"] = (sum(1 for a, b in zip(flat_t, flat_p) if a == b) / len(flat_t)) if flat_t else 0.0
+    return scores
+
+
+def make_compute_metrics(label_list=("B-EOP", "O"), ts_score_predictor="lt", return_entity_level_metrics=True):
+    """the `compute_metrics` closure of ts_sentence_seq_labeling.py:1018-1074 for `transformers.Trainer(compute_metrics=...)`:
+    p = ((logits (N,2,L,2), cos_sim (N,k)), (labels (N,2,L), sent_level_labels)); anchor half = index 0, DA half = index 1.  Returns the
+    anchor's chunk scores and the DA half's under the `da_` prefix -- flattened (`EOP_f1`, `overall_f1`, `da_overall_f1`, ...: what
+    `--metric_for_best_model overall_f1` of run_finetune.sh:80-82 selects on) when return_entity_level_metrics (arguments.py:219-222,
+    default True), else the four overall numbers."""
+    label_list = list(label_list)
+
+    def compute_metrics(p):
+        all_logits, all_labels = p
+        logits, _cos = all_logits
+        labels = all_labels[0] if isinstance(all_labels, (tuple, list)) else all_labels
+        logits, labels = np.asarray(logits), np.asarray(labels)
+        a_lab, d_lab = labels[:, 0], labels[:, 1]
+        true_a = [[label_list[l] for l in row if l != -100] for row in a_lab]
+        true_d = [[label_list[l] for l in row if l != -100] for row in d_lab]
+        if ts_score_predictor == "lt":
+            pa, pd = np.argmax(logits[:, 0], axis=2), np.argmax(logits[:, 1], axis=2)      # 0 -> "B-EOP" = boundary
+            pred_a = [[label_list[q] for q, l in zip(pr, lr) if l != -100] for pr, lr in zip(pa, a_lab)]
+            pred_d = [[label_list[q] for q, l in zip(pr, lr) if l != -100] for pr, lr in zip(pd, d_lab)]
+        elif ts_score_predictor == "cos":
+            # (:1043-1047) the logits ARE per-EOP scores; the reference builds no DA predictions on this branch and then reads
+            # `da_true_predictions` (NameError at :1051) -- here the DA half is scored the same way as the anchor
+            pa, pd = (logits[:, 0] > 0.5).astype(np.int32), (logits[:, 1] > 0.5).astype(np.int32)
+            pred_a = [[label_list[q] for q in pr[:len(t)]] for pr, t in zip(pa, true_a)]
+            pred_d = [[label_list[q] for q in pr[:len(t)]] for pr, t in zip(pd, true_d)]
+        else:
+            raise ValueError("not supported ts_score_predictor %s" % ts_score_predictor)
+        results = seqeval_scores(pred_a, true_a)
+        results.update({"da_" + k: v for k, v in seqeval_scores(pred_d, true_d).items()})
+        if return_entity_level_metrics:
+            final = {}
+            for k, v in results.items():
+                if isinstance(v, dict):
+                    for n, x in v.items():
+                        final[f"{k}_{n}"] = x
+                else:
+                    final[k] = v
+            return final
+        return {"precision": results["overall_precision"], "recall": results["overall_recall"], "f1": results["overall_f1"],
+                "accuracy": results["overall_accuracy"]}
+
+    return compute_metrics
+
+
+# ---------------------------------------------------------------------------------------------------- WikiSection sentence-level re-scoring
+def read_total_pred_and_labels(data_file, pred_file):
+    """postprocess_predictions.py:7-26: the prediction file (one json line per document, tags "B-EOP" / "O") as 0 / 1 lists (1 = boundary)
+    and the data file's sentence-level labels without each document's last one"""
+    para_pred, para_lab, sent_lab = [], [], []
+    with open(pred_file, "r") as f:
+        for line in f:
+            if not line.strip():
+                continue
+            t = json.loads(line)
+            para_lab.append([0 if v == "O" else 1 for v in t["labels"]])
+            para_pred.append([0 if v == "O" else 1 for v in t["predictions"]])
+    with open(data_file, "r") as f:
+        for line in f:
+            if not line.strip():
+                continue
+            sent_lab.append(json.loads(line)["labels"][:-1])
+    return para_pred, para_lab, sent_lab
+
+
+def sent_level_metric_from_para_level_models(total_para_level_predictions, total_para_level_labels, total_sent_level_labels):
+    """postprocess_predictions.py:50-75: a paragraph-level model predicts only at paragraph ends (the sentences whose label is not -100);
+    its predictions are spread over the sentence positions (non-paragraph-end sentences: label 0, prediction 0) and both granularities are
+    scored with the window metric.  Returns (sentence-level result, paragraph-level result) and leaves the inputs untouched (the
+    reference rewrites its label lists in place)."""
+    sent_pred, sent_lab = [], []
+    for para_lab, slab, para_pred in zip(total_para_level_labels, total_sent_level_labels, total_para_level_predictions):
+        assert len(para_lab) == len([v for v in slab if v != -100])
+        sp, sl, pid = [0] * len(slab), list(slab), 0
+        for i, v in enumerate(slab):
+            if v != -100:
+                assert v == para_lab[pid]
+                sp[i] = para_pred[pid]; pid += 1
+            else:
+                sl[i] = 0
+        sent_pred.append(sp); sent_lab.append(sl)
+    return (compute_window_metric(sent_pred, sent_lab),
+            compute_window_metric([list(x) for x in total_para_level_predictions], [list(x) for x in total_para_level_labels]))
+
+
+def _prfkw_line(res):
+    return " / ".join("%.2f" % (v * 100) for v in (res["precision"], res["recall"], res["f1"], res["pk"], res["wd"]))
+
+
+def wiki_section_sent_level_metric(data_file, pred_file, disease_cnt=718, city_cnt=3893, out=print):
+    """postprocess_predictions.py:29-47 (`get_wiki_section_sent_level_metric`, what run_inference.sh:51-57 runs after predicting on
+    wiki_section): en_disease = the first 718 documents, en_city = the next 3893; prints the reference's lines and returns
+    {name: {"sent_level": ..., "para_level": ...}}"""
+    pp, pl, sl = read_total_pred_and_labels(data_file, pred_file)
+    assert len(pp) == disease_cnt + city_cnt
+    parts = {"wiki_section_disease": slice(0, disease_cnt), "wiki_section_city": slice(disease_cnt, None), "wiki_section": slice(None)}
+    out(" / ".join(["p", "r", "f1", "pk", "wd"]))
+    res = {}
+    for name, sel in parts.items():
+        s, p = sent_level_metric_from_para_level_models(pp[sel], pl[sel], sl[sel])
+        out("data_name:  " + name)
+        out("sent_level: " + _prfkw_line(s))
+        out("para_level: " + _prfkw_line(p))
+        out("\n")
+        res[name] = {"sent_level": s, "para_level": p}
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------- result-file helpers (utils.py)
+def abridge_model_name(model_name_or_path):
+    """utils.py:8-20: the short model tag of the cache / prediction file names"""
+    for key, short in (("longformer", "lf"), ("bigbird", "bb"), ("bert", "bert"), ("electra", "ele")):
+        if key in model_name_or_path:
+            return short
+    raise ValueError("not supported model_name")
+
+
+def convert_res_format(file_path, threshold, out=print):
+    """utils.py:23-48: `<name>_results.json` -> `<name>_results_str_metric.txt`, the last file run_inference.sh leaves
+    (ts_sentence_seq_labeling.py:1222): the thresholded example-level P / R / F / Pk / WD as percentages with two decimals.
+    `threshold` is custom_args.threshold (formatted with %s, as in the key names compute_metric_example_level writes)."""
+    out_path = os.path.join(os.path.dirname(file_path), os.path.basename(file_path).split(".json")[0] + "_str_metric.txt")
+    with open(file_path, "r") as f:
+        res = json.load(f)
+    vals = [res["threshold_%s_example_level_%s" % (threshold, k)] for k in ("precision", "recall", "f1", "pk", "wd")]
+    line = "threshold_%s_example_level_metric\n" % threshold + " / ".join("%.2f" % (float(v) * 100) for v in vals)
+    with open(out_path, "w") as f:
+        f.write("p / r / f / pk / wd\n")
+        f.write(line + "\n\n")
+    out("p / r / f / pk / wd\n")
+    out(line + "\n\n")
+    return out_path
 
 
 # ---------------------------------------------------------------------------------------------------- alimeeting4mug twins

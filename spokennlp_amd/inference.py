@@ -53,5 +53,29 @@ def predict_documents(model, docs_sentence_ids, docs_labels, max_seq_length, bos
     decoded = P.decode_anchor_predictions(logits_all, labels)
     example_ids = [e[0] for e in cols["example_id"]]
     docs = P.merge_windows_to_documents(decoded, example_ids, len(docs_sentence_ids), eop_pair_cos_sim=cos_all)
-    metrics = E.compute_metric_example_level([d["predict_logits"] for d in docs], [d["int_labels"] for d in docs], threshold=threshold)
+    # (:1198-1206) documents with a single sentence have no labelled position: the reference drops them before scoring
+    scored = [d for d in docs if len(d["int_labels"]) != 0]
+    metrics = E.compute_metric_example_level([d["predict_logits"] for d in scored], [d["int_labels"] for d in scored], threshold=threshold)
     return docs, metrics
+
+
+def write_predict_outputs(output_dir, docs, metrics, test_data_name, max_seq_length, ts_score_predictor="lt", threshold=0.5,
+                          metric_key_prefix="predict"):
+    """the three files the predict branch of the reference leaves in `output_dir` (ts_sentence_seq_labeling.py:1166-1222):
+      <prefix>_<data>_max_seq<L>_ts_score_<p>.txt                                  one json line per document (:1173-1191)
+      example_level_<prefix>_<data>_max_seq<L>_ts_score_<p>_results.json           `trainer.save_metrics` layout (:1214-1219)
+      example_level_<...>_results_str_metric.txt                                   `convert_res_format` (utils.py:23-48; :1222)
+    `threshold` is formatted with %s as the reference's key names are (0.5 -> "threshold_0.5_example_level_f1").  Returns the paths."""
+    import json
+    import os
+    os.makedirs(output_dir, exist_ok=True)
+    name = "_".join([metric_key_prefix, test_data_name, "max_seq%d" % max_seq_length, "ts_score_%s" % ts_score_predictor])
+    pred_path = os.path.join(output_dir, name + ".txt")
+    P.write_prediction_file(pred_path, docs)
+    m = dict(metrics)
+    m["%s_examples" % metric_key_prefix] = len(docs)
+    res_path = os.path.join(output_dir, "example_level_" + name + "_results.json")
+    with open(res_path, "w") as f:
+        json.dump(m, f, indent=4, sort_keys=True)
+    str_path = E.convert_res_format(res_path, threshold, out=lambda *_: None)
+    return pred_path, res_path, str_path

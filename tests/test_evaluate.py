@@ -4,6 +4,7 @@ hand-worked cases; the surrounding reference logic (mass conversion, thresholds,
 import random
 
 import numpy as np
+import pytest
 
 from spokennlp_amd import evaluate as E
 
@@ -217,3 +218,166 @@ def test_rouge_properties_and_the_es_metric_glue():
 def _is_subseq(c, y):
     it = iter(y)
     return all(any(a == b for b in it) for a in c)
+
+
+# ---------------------------------------------------------------------------------------------------- seqeval chunk scores, compute_metrics, postprocess
+def test_seqeval_scores_reproduce_the_worked_example_the_reference_file_holds():
+    """emnlp2023-topic_segmentation/src/metrics/seqeval.py:96-105 (docstring of the metric): keys, overall_f1 0.5, PER f1 1.0"""
+    predictions = [['O', 'O', 'B-MISC', 'I-MISC', 'I-MISC', 'I-MISC', 'O'], ['B-PER', 'I-PER', 'O']]
+    references = [['O', 'O', 'O', 'B-MISC', 'I-MISC', 'I-MISC', 'O'], ['B-PER', 'I-PER', 'O']]
+    res = E.seqeval_scores(predictions, references)
+    assert list(res.keys()) == ['MISC', 'PER', 'overall_precision', 'overall_recall', 'overall_f1', 'overall_accuracy']
+    assert res["overall_f1"] == 0.5 and res["PER"]["f1"] == 1.0
+    assert res["MISC"] == {"precision": 0.0, "recall": 0.0, "f1": 0.0, "number": 1} and res["PER"]["number"] == 1
+    assert res["overall_precision"] == 0.5 and res["overall_recall"] == 0.5 and res["overall_accuracy"] == 0.8
+
+
+def _brute_chunks(rows):
+    """independent chunk reader for B- / I- / O tags: a chunk starts at a B, or at an I that does not continue a chunk of its type"""
+    out = set()
+    for ri, row in enumerate(rows):
+        i = 0
+        while i < len(row):
+            if row[i] == "O":
+                i += 1
+                continue
+            typ = row[i][2:]
+            j = i + 1
+            while j < len(row) and row[j] == "I-" + typ:
+                j += 1
+            out.add((ri, typ, i, j - 1))
+            i = j
+    return out
+
+
+def test_seqeval_scores_against_bruteforce_chunk_counting():
+    rng = np.random.RandomState(5)
+    tags = ["O", "B-A", "I-A", "B-B", "I-B"]
+    for trial in range(30):
+        refs = [[tags[i] for i in rng.randint(0, 5, size=rng.randint(1, 14))] for _ in range(rng.randint(1, 6))]
+        preds = [[tags[i] for i in rng.randint(0, 5, size=len(r))] for r in refs]
+        res = E.seqeval_scores(preds, refs)
+        ct, cp = _brute_chunks(refs), _brute_chunks(preds)
+        tp = len(ct & cp)
+        p = tp / len(cp) if cp else 0.0
+        r = tp / len(ct) if ct else 0.0
+        f = 2 * p * r / (p + r) if p + r else 0.0
+        assert abs(res["overall_precision"] - p) < 1e-12 and abs(res["overall_recall"] - r) < 1e-12 and abs(res["overall_f1"] - f) < 1e-12
+        for typ in ("A", "B"):
+            nt = sum(1 for c in ct if c[1] == typ)
+            if typ in res:
+                assert res[typ]["number"] == nt
+            else:
+                assert nt == 0 and not any(c[1] == typ for c in cp)
+        flat = [(a, b) for pr, rr in zip(preds, refs) for a, b in zip(pr, rr)]
+        assert abs(res["overall_accuracy"] - sum(a == b for a, b in flat) / len(flat)) < 1e-12
+    with pytest.raises(ValueError):
+        E.seqeval_scores([["O"]], [["O", "O"]])
+
+
+def test_seqeval_scores_on_the_topic_segmentation_label_set_equal_tag_level_scores():
+    """{"B-EOP", "O"}: every B-EOP is a one-token chunk (B after B closes the chunk), so chunk scores == binary scores of the tag"""
+    rng = np.random.RandomState(1)
+    refs = [["B-EOP" if v else "O" for v in rng.rand(n) < 0.2] for n in (7, 1, 30, 12)]
+    preds = [["B-EOP" if v else "O" for v in rng.rand(len(r)) < 0.25] for r in refs]
+    res = E.seqeval_scores(preds, refs)
+    p, r, f = E.binary_prf([int(x == "B-EOP") for row in refs for x in row], [int(x == "B-EOP") for row in preds for x in row])
+    assert abs(res["overall_precision"] - p) < 1e-12 and abs(res["overall_recall"] - r) < 1e-12 and abs(res["overall_f1"] - f) < 1e-12
+    assert set(res) == {"EOP", "overall_precision", "overall_recall", "overall_f1", "overall_accuracy"}
+    assert res["EOP"]["number"] == sum(x == "B-EOP" for row in refs for x in row)
+    # nothing predicted, nothing true: zero division acts as 0 (seqeval's "warn")
+    z = E.seqeval_scores([["O", "O"]], [["O", "O"]])
+    assert z["overall_f1"] == 0.0 and z["overall_accuracy"] == 1.0
+
+
+def test_compute_metrics_closure_of_the_finetune_script():
+    """ts_sentence_seq_labeling.py:1018-1074: p = ((logits (N,2,L,2), cos_sim), (labels (N,2,L), sent_level_labels)) -> anchor scores + da_ scores"""
+    rng = np.random.RandomState(3)
+    N, L = 5, 16
+    labels = np.full((N, 2, L), -100, dtype=np.int64)
+    for n in range(N):
+        for h in range(2):
+            pos = np.sort(rng.choice(np.arange(1, L), size=rng.randint(2, 6), replace=False))
+            labels[n, h, pos] = rng.randint(0, 2, size=len(pos))
+    logits = rng.randn(N, 2, L, 2).astype(np.float32)
+    cos = rng.rand(N, 4).astype(np.float32)
+    cm = E.make_compute_metrics()
+    res = cm(((logits, cos), (labels, np.zeros((N, 2, L)))))
+    for half, prefix in ((0, ""), (1, "da_")):
+        pred = logits[:, half].argmax(-1)
+        keep = labels[:, half] != -100
+        t = (labels[:, half][keep] == 0).astype(int).tolist()
+        q = (pred[keep] == 0).astype(int).tolist()
+        p, r, f = E.binary_prf(t, q)
+        assert abs(res[prefix + "overall_precision"] - p) < 1e-12 and abs(res[prefix + "overall_recall"] - r) < 1e-12
+        assert abs(res[prefix + "overall_f1"] - f) < 1e-12 and abs(res[prefix + "EOP_f1"] - f) < 1e-12
+        assert res[prefix + "EOP_number"] == sum(t)
+        assert abs(res[prefix + "overall_accuracy"] - float((pred[keep] == labels[:, half][keep]).mean())) < 1e-12
+    # also the (predictions, label_ids) object transformers hands over, and the four-number form
+    class P_:
+        predictions, label_ids = (logits, cos), (labels, None)
+
+        def __iter__(self):
+            return iter((self.predictions, self.label_ids))
+    short = E.make_compute_metrics(return_entity_level_metrics=False)(P_())
+    assert set(short) == {"precision", "recall", "f1", "accuracy"} and short["f1"] == res["overall_f1"]
+    # "cos" predictor: per-EOP sigmoid scores (N,2,k), > 0.5 = "O"
+    sc = rng.rand(N, 2, L).astype(np.float32)
+    rc = E.make_compute_metrics(ts_score_predictor="cos")(((sc, cos), (labels, None)))
+    n0 = int((labels[0, 0] != -100).sum())
+    t = [int(v == 0) for row in labels[:, 0] for v in row if v != -100]
+    q = [int(not (s > 0.5)) for n in range(N) for s in sc[n, 0][:int((labels[n, 0] != -100).sum())]]
+    assert n0 > 0 and abs(rc["overall_f1"] - E.binary_prf(t, q)[2]) < 1e-12
+    with pytest.raises(ValueError):
+        E.make_compute_metrics(ts_score_predictor="nope")(((logits, cos), (labels, None)))
+
+
+def test_wiki_section_sentence_level_rescoring_and_the_str_metric_file(tmp_path):
+    """postprocess_predictions.py:7-75 + utils.py:23-48 on a synthetic paragraph-level run"""
+    import json
+    rng = np.random.RandomState(9)
+    docs, preds = [], []
+    for d in range(7):
+        ns = rng.randint(6, 25)
+        sent = [-100] * ns
+        para_ends = sorted(set(rng.choice(np.arange(ns - 1), size=rng.randint(2, min(6, ns - 1)), replace=False).tolist()))
+        for i in para_ends:
+            sent[i] = int(rng.rand() < 0.4)
+        sent[-1] = 1                                                     # the document's last sentence (dropped by [:-1])
+        plab = [sent[i] for i in para_ends]
+        ppred = [int(rng.rand() < 0.4) for _ in para_ends]
+        docs.append({"sentences": ["s"] * ns, "labels": sent})
+        preds.append({"labels": ["B-EOP" if v else "O" for v in plab], "predictions": ["B-EOP" if v else "O" for v in ppred]})
+    data_file, pred_file = tmp_path / "test.jsonl", tmp_path / "pred.txt"
+    data_file.write_text("".join(json.dumps(d) + "\n" for d in docs))
+    pred_file.write_text("".join(json.dumps(d) + "\n" for d in preds))
+    pp, pl, sl = E.read_total_pred_and_labels(str(data_file), str(pred_file))
+    assert [len(x) for x in sl] == [len(d["labels"]) - 1 for d in docs]
+    sent_res, para_res = E.sent_level_metric_from_para_level_models(pp, pl, sl)
+    assert sl[0].count(-100) > 0                                         # inputs untouched
+    # expected: spread by hand
+    sp, sll = [], []
+    for d, p in zip(docs, preds):
+        lab = d["labels"][:-1]
+        it = iter([0 if v == "O" else 1 for v in p["predictions"]])
+        sp.append([next(it) if v != -100 else 0 for v in lab]); sll.append([0 if v == -100 else v for v in lab])
+    assert sent_res == E.compute_window_metric(sp, sll) and para_res == E.compute_window_metric(pp, pl)
+    # same P / R / F at both granularities (only zeros are added); the window metrics differ
+    assert sent_res["precision"] == para_res["precision"] and sent_res["recall"] == para_res["recall"]
+    lines = []
+    res = E.wiki_section_sent_level_metric(str(data_file), str(pred_file), disease_cnt=3, city_cnt=4, out=lines.append)
+    assert set(res) == {"wiki_section_disease", "wiki_section_city", "wiki_section"} and res["wiki_section"]["sent_level"] == sent_res
+    assert lines[0] == "p / r / f1 / pk / wd" and lines[1] == "data_name:  wiki_section_disease" and lines[2].startswith("sent_level: ")
+    with pytest.raises(AssertionError):
+        E.wiki_section_sent_level_metric(str(data_file), str(pred_file))   # the real split sizes (718 + 3893) do not match 7 documents
+    # the metric file
+    m = {"threshold_0.5_example_level_precision": 0.81337, "threshold_0.5_example_level_recall": 0.5, "threshold_0.5_example_level_f1": 0.61925,
+         "threshold_0.5_example_level_pk": 0.1387, "threshold_0.5_example_level_wd": 0.14970000000000006}
+    rp = tmp_path / "example_level_predict_x_results.json"
+    rp.write_text(json.dumps(m))
+    out = E.convert_res_format(str(rp), 0.5, out=lambda *_: None)
+    assert out.endswith("example_level_predict_x_results_str_metric.txt")
+    assert open(out).read() == "p / r / f / pk / wd\nthreshold_0.5_example_level_metric\n81.34 / 50.00 / 61.92 / 13.87 / 14.97\n\n"
+    assert [E.abridge_model_name(x) for x in ("allenai/longformer-base-4096", "google/bigbird-roberta-base", "bert-base-uncased", "google/electra-base")] == ["lf", "bb", "bert", "ele"]
+    with pytest.raises(ValueError):
+        E.abridge_model_name("gpt2")

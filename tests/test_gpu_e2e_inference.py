@@ -62,6 +62,15 @@ def test_32_documents_end_to_end(dev, tmp_path, max_len, bs, precision):
     P.write_prediction_file(str(path), got_docs)
     lines = open(path).read().splitlines()
     assert len(lines) == 32 and json.loads(lines[5])["predictions"] == got_docs[5]["predictions"]
+    # ... and the files run_inference.sh leaves behind the prediction file (ts_sentence_seq_labeling.py:1214-1222, utils.py:23-48):
+    # documents -> HIP encoder -> decode -> example-level metrics -> *_results.json -> *_str_metric.txt
+    pred_p, res_p, str_p = inference.write_predict_outputs(str(tmp_path / "out"), got_docs, got_metrics, "synth", max_len)
+    assert os.path.basename(pred_p) == "predict_synth_max_seq%d_ts_score_lt.txt" % max_len and open(pred_p).read() == open(path).read()
+    assert os.path.basename(str_p) == "example_level_predict_synth_max_seq%d_ts_score_lt_results_str_metric.txt" % max_len
+    saved = json.load(open(res_p))
+    assert saved["predict_examples"] == 32 and saved["threshold_0.5_example_level_f1"] == got_metrics["threshold_0.5_example_level_f1"]
+    want = " / ".join("%.2f" % (ref_metrics["threshold_0.5_example_level_" + k] * 100) for k in ("precision", "recall", "f1", "pk", "wd"))
+    assert open(str_p).read() == "p / r / f / pk / wd\nthreshold_0.5_example_level_metric\n" + want + "\n\n"
     print("e2e: max|dlogit|", worst, {k: got_metrics[k] for k in ("precision", "recall", "f1")})
 
 

@@ -451,15 +451,28 @@ def test_real_hf_trainer_train_and_predict(dev, tmp_path):
 
     m = build_model(arch, flags, sd, dev)
     w0 = m.state_dict()["bert.encoder.layer.0.output.dense.weight"].clone()
+    # run_finetune.sh:74-82: evaluation by steps, --load_best_model_at_end, --metric_for_best_model overall_f1 -- the key the reference's
+    # compute_metrics closure (ts_sentence_seq_labeling.py:1018-1074 -> evaluate.make_compute_metrics) returns
+    from spokennlp_amd import evaluate as E
     args = TrainingArguments(output_dir=str(tmp_path / "out"), per_device_train_batch_size=4, per_device_eval_batch_size=4, max_steps=4,
                              learning_rate=1e-3, lr_scheduler_type="linear", max_grad_norm=1.0, gradient_accumulation_steps=2,
-                             report_to=[], save_strategy="no", logging_steps=1, seed=7, dataloader_drop_last=True, remove_unused_columns=True)
+                             report_to=[], eval_strategy="steps", eval_steps=2, save_strategy="steps", save_steps=2, save_total_limit=2,
+                             load_best_model_at_end=True, metric_for_best_model="overall_f1", eval_accumulation_steps=1000,
+                             logging_steps=1, seed=7, dataloader_drop_last=True, remove_unused_columns=True)
     random.seed(3)
-    tr = Trainer(model=m, args=args, train_dataset=DS(), eval_dataset=DS(), data_collator=default_data_collator)
+    tr = Trainer(model=m, args=args, train_dataset=DS(), eval_dataset=DS(), data_collator=default_data_collator,
+                 compute_metrics=E.make_compute_metrics())
     assert set(tr.label_names) == {"labels", "sent_level_labels"}
     out = tr.train()
     assert out.global_step == 4 and math.isfinite(out.training_loss)
     assert not torch.equal(m.state_dict()["bert.encoder.layer.0.output.dense.weight"], w0)
+    evals = [h for h in tr.state.log_history if "eval_overall_f1" in h]
+    assert len(evals) == 2 and all(0.0 <= h["eval_overall_f1"] <= 1.0 and "eval_da_overall_f1" in h and "eval_EOP_number" in h for h in evals)
+    best = max(evals, key=lambda h: h["eval_overall_f1"])
+    assert tr.state.best_metric == best["eval_overall_f1"] and tr.state.best_model_checkpoint is not None
+    # the best checkpoint was loaded back INTO the engine's flat buffer: evaluating now reproduces its score
+    again = tr.evaluate()
+    assert abs(again["eval_overall_f1"] - tr.state.best_metric) < 1e-12
     pred = tr.predict(DS())
     logits, cos = pred.predictions
     assert logits.shape == (len(samples), 2, 64, 2) and cos.shape[0] == len(samples)
