@@ -32,12 +32,12 @@ struct RcclApi {
     const char* (*GetErrorString)(nccl_result) = nullptr;
 };
 
-// bound once per process; the only process-wide state of this file is the dlopen handle (a loaded library IS process-wide)
-RcclApi* rccl() {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.handle ? &api : nullptr;
-    tried = true;
+// bound once per process; the only process-wide state of this file is the dlopen handle (a loaded library IS process-wide).  The binding is a
+// function-local static initialised by bind(): C++11 makes that initialisation run exactly once and makes every concurrent first caller wait for
+// it (two binder threads calling amdseg_allreduce_* at the same moment both see the finished table -- ADVICE r05); a partially bound library
+// (a missing symbol) is closed again before the failure is reported.
+RcclApi bind_rccl() {
+    RcclApi api;
     const char* env = getenv("AMDSEG_RCCL_LIB");
     const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* h = nullptr;
@@ -45,15 +45,19 @@ RcclApi* rccl() {
         if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
     for (const char* n : names)
         if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (!h) return nullptr;
+    if (!h) return api;
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) return nullptr;
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) { dlclose(h); return RcclApi(); }
     api.handle = h;
-    return &api;
+    return api;
+}
+RcclApi* rccl() {
+    static RcclApi api = bind_rccl();
+    return api.handle ? &api : nullptr;
 }
 
 inline int comm_rc(nccl_result r) { return r == 0 ? AMDSEG_OK : AMDSEG_ERR_COMM_BASE + (int)r; }

@@ -718,8 +718,8 @@ def test_c_abi_binder_without_python_or_torch(dev):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "tools", "cabi_demo.bin")
-    if not os.path.exists(exe):
-        pytest.skip("tools/cabi_demo.bin not built (run __graft_entry__.build() where hipcc is)")
+    # a boundary test fails, it does not skip: on a GPU box the binder must have travelled with the snapshot
+    assert os.path.exists(exe), "tools/cabi_demo.bin not built: run __graft_entry__.build() where hipcc is before going to the GPU box"
     env = dict(os.environ)
     import torch as _t                                       # the process needs A HIP runtime on its path: torch's own copy will do on a box without /opt/rocm/lib
     env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(os.path.dirname(_t.__file__), "lib"), "/opt/rocm/lib", env.get("LD_LIBRARY_PATH", "")])
