@@ -228,6 +228,28 @@ __device__ __forceinline__ void gelu_both2(f32x2 x, f32x2& h, f32x2& d) {
     h = gelu_fast2(x); d = gelu_grad_fast2(x);
 #endif
 }
+// ... with the derivative already in the units of its one-byte code (gemm_epi.h: q = round(gelu' * 200 + 27)): the scale rides the polynomial's
+// constants and the offset the final sum, one packed fma in place of two scalar multiply-adds per pair (the epilogue that calls this is VALU time)
+__device__ __forceinline__ void gelu_both2q(f32x2 x, f32x2& h, f32x2& dq, float scale, float off) {
+#ifndef AMDSEG_GELU_ERF_EPILOGUE
+    f32x2 r, x2c;
+    gelu_sig_core(x, r, x2c);
+    const f32x2 sp = (x2c * (-5.0f * GELU_SIG_C * 0.6931471805599453f * scale) + (-3.0f * GELU_SIG_B * 0.6931471805599453f * scale)) * x2c
+                     + (-GELU_SIG_A * 0.6931471805599453f * scale);
+    h = x * r;
+    dq = (r - r * r) * (x * sp) + (r * scale + off);
+#else
+    f32x2 d;
+    h = gelu_fast2(x); d = gelu_grad_fast2(x);
+    dq = d * scale + off;
+#endif
+}
+__device__ __forceinline__ void gelu_both4q(float* v, float* dq, float scale, float off) {
+    f32x2 h0, d0, h1, d1;
+    gelu_both2q((f32x2){v[0], v[1]}, h0, d0, scale, off); gelu_both2q((f32x2){v[2], v[3]}, h1, d1, scale, off);
+    v[0] = h0.x; v[1] = h0.y; v[2] = h1.x; v[3] = h1.y;
+    dq[0] = d0.x; dq[1] = d0.y; dq[2] = d1.x; dq[3] = d1.y;
+}
 __device__ __forceinline__ void gelu_both4(float* v, float* d) {
     f32x2 h0, d0, h1, d1;
     gelu_both2((f32x2){v[0], v[1]}, h0, d0); gelu_both2((f32x2){v[2], v[3]}, h1, d1);

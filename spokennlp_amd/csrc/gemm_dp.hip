@@ -121,6 +121,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #define DP_DMA_B(s, kt) DP_DMA_B_P(pB, s, kt)
 #define DP_WAIT_TILE() do { if (vm8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
 #endif
+    // the bias vector is requested HERE, in front of the prologue's DMA, and added at the end (round 6): the epilogue used to open with these four
+    // global loads per lane, whose latency every tile of every biased GEMM paid with the matrix pipe idle.  (It is still ADDED last: starting the
+    // accumulators from it was measured too -- another 0.5-1 us per launch -- but rounds differently from the 128 x 128 and ping-pong kernels of
+    // gemm.hip, and the suite holds this library to bit-identical results across batch compositions, i.e. across kernels.)
+    // (256 x 192 tile only: the 256-wide instantiations have no 16 registers to spare across the K loop -- 6 spilled VGPRs in the GELU epilogues -- and
+    //  request the vector at the top of the epilogue as before)
+    constexpr bool BIAS_EARLY = NF == 3;
+#define DP_LOAD_BIAS() _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) \
+            bv[nf] = (EPI == EPI_BIAS_SPLIT && !a.bias) ? make_float4(0.f, 0.f, 0.f, 0.f)      /* BIAS_SPLIT without a bias: the plain product as an image */ \
+                   : *reinterpret_cast<const float4*>(a.bias + n0 + wc * WN + (NF == 4 ? (nf >> 1) * 32 + g * 8 + (nf & 1) * 4 : nf * 16 + g * 4));
+    float4 bv[NF];
+    if (E_BIAS && BIAS_EARLY) { DP_LOAD_BIAS() }
     f32x4 acc[8][NF];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -128,6 +140,33 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = a.K / 64;
     const bool ztile = DP_ZTILE(m0);                          // workgroup-uniform: every row of this tile's A is an exact zero
+    // EPI_MUL_RES8 (round 6): the tile's 256 x 256 one-byte derivatives (64 KiB = one LDS stage) are fetched by LDS-DMA UNDER the last K tile into
+    // the stage that tile does not use -- every read of it was retired two barriers earlier (both groups: see the hazard notes at the top) --
+    // instead of by 16 global loads per lane at the start of the epilogue, where all CUs of a round waited for them with the matrix pipes idle
+    // (rocprofv3, round 6: 91 us per launch against 65-70 for the K loops alone; the derivative reads were the exposed part).
+    // Piece j of wave w = tile rows w*32 + j*4 .. +4, all 256 columns; the 16-B unit (row r, columns c16*16 .. +16) lands at LDS unit (c16 + r) & 15 of
+    // its row, so the epilogue's ds_read_b64 (16 rows x two neighbouring units per wave instruction) touches every 16-B bank group exactly twice.
+    constexpr bool R8PF = EPI == EPI_MUL_RES8 && NF == 4 && !PERSIST;
+    // EPI_ADD_RES on the 256 x 192 tile (the residual-adding input-gradient GEMMs dx1 = du W1 + dz2, dx_in = dqkv Wqkv + dz1): the bf16 residual tile is
+    // 96 KiB, the free stage 56 KiB -- the FIRST HALF of each row group's rows (mf 0..3: tile rows 0-63 and 128-191, 128 rows x 384 B) comes through
+    // LDS under the last K tile, the second half by global loads requested at the top of the epilogue, in front of the arithmetic of the first.
+    // LDS rows are 416 B apart (26 units of 16 B, the last two padding): 16 consecutive rows then start in 8 distinct 32-B bank slots, two each, and
+    // the epilogue's ds_read_b64 (16 rows x 32 B per wave instruction) is conflict-free.  56 pieces of 1 KiB = the stage exactly, 7 per wave.
+    constexpr bool R16PF = EPI == EPI_ADD_RES && NF == 3 && !PERSIST;
+    constexpr bool RPF = R8PF || R16PF;
+#define DP_RPF_WAIT() do { if (R8PF) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); } while (0)
+#define DP_R16_ISSUE(stage) do { if (R16PF) { \
+        const bf16_t* r16b_ = a.R + (size_t)m0 * a.ldr + n0; \
+        _Pragma("unroll") for (int j_ = 0; j_ < 7; ++j_) { \
+            const int u_ = (w * 7 + j_) * 64 + l, rho_ = min(u_ / 26, 127), un_ = min(u_ - rho_ * 26, 23); \
+            const int tr_ = (rho_ & 63) + ((rho_ >> 6) << 7); \
+            amdseg_glds16_saddr_lds(r16b_, (uint32_t)((tr_ * a.ldr + un_ * 8) * 2), lds0 + (stage) * STAGE + (w * 7 + j_) * 1024); } } } while (0)
+#define DP_RPF_ISSUE(stage) do { DP_R8_ISSUE(stage); DP_R16_ISSUE(stage); } while (0)
+#define DP_R8_ISSUE(stage) do { if (R8PF) { \
+        const unsigned char* r8b_ = reinterpret_cast<const unsigned char*>(a.R) + (size_t)(m0 + w * 32) * a.ldr + n0; \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) { \
+            const int r_ = j_ * 4 + (l >> 4); \
+            amdseg_glds16_saddr_lds(r8b_, (uint32_t)(r_ * a.ldr + ((((l & 15) - r_) & 15) << 4)), lds0 + (stage) * STAGE + (w * 32 + j_ * 4) * 256); } } } while (0)
     if (!ztile) {
     if (PERSIST && pf_) {
         // both stages were requested behind the previous tile's K loop; the 16 youngest operations are that tile's epilogue stores
@@ -217,9 +256,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #define DP_KTILE(kt, S, LDA, LDB) { \
         LDB(S) __builtin_amdgcn_sched_barrier(0); LDA(S, 0) __builtin_amdgcn_sched_barrier(0); \
         if ((kt) >= DP_KT0 && (kt) + 1 < nk) { DP_LOOP_DMA(DP_DMA_A((S) ^ 1, 1, (kt) + 1)) } \
+        else if (RPF && (kt) + 1 == nk) DP_RPF_ISSUE((S) ^ 1); \
         DP_LGKM_P1(); \
         if ((kt) >= DP_KT0 && (kt) + 1 < nk) DP_WAIT_TILE(); \
         else if (PERSIST && pf_ && (kt) == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   /* landed at the tile's start; the stores stay in flight */ \
+        else if (RPF && (kt) + 1 == nk) DP_RPF_WAIT();           /* everything but the epilogue operand's pieces */ \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         DP_MID(); \
         DP_MFMA(0) \
@@ -227,7 +268,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         LDA(S, 1) \
         if ((kt) + 2 < nk) { DP_LOOP_DMA(DP_DMA_A(S, 0, (kt) + 2) DP_DMA_B(S, (kt) + 2)) } \
         DP_LGKM_P2(); \
-        if ((kt) + 2 < nk) DP_WAIT_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        if ((kt) + 2 < nk) DP_WAIT_TILE(); \
+        else if (RPF && (kt) + 1 == nk) DP_RPF_WAIT(); \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         DP_MID(); \
         DP_MFMA(1) \
         DP_END(); }
@@ -247,19 +290,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     for (; kt < nk; ++kt) { const int s_ = kt & 1; DP_KTILE(kt, s_, DP_LOAD_A, DP_LOAD_B) }
 #endif
     if (wr == 0) __builtin_amdgcn_s_barrier();             // group 0 pays back the stagger barrier: every LDS read is retired now
+    } else if (RPF) DP_RPF_ISSUE(nk & 1);                  // a skipped tile multiplies zeros by the same derivatives (the sign of a zero is a bit too) / adds the same residual
+    if (RPF) {                                             // the operand image has landed and every wave sees it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
     // ---- epilogue.  Lane owns row m = mf*16 + i16 and columns nf*16 + g*4 .. +4 of the wave tile.  bf16 results go through a
     // wave-private 16-KiB LDS image (2 x [64 rows][128 B], swizzled) so every global store instruction writes 8 full 128-B lines.
-    float4 bv[NF];
-    if (E_BIAS) {
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-            bv[nf] = (EPI == EPI_BIAS_SPLIT && !a.bias) ? make_float4(0.f, 0.f, 0.f, 0.f)      // BIAS_SPLIT without a bias: the plain product as an image
-                   : *reinterpret_cast<const float4*>(a.bias + n0 + wc * WN + (NF == 4 ? (nf >> 1) * 32 + g * 8 + (nf & 1) * 4 : nf * 16 + g * 4));
-    }
     // the bias goes INTO the accumulators once: recomputing acc + bias in both passes of BIAS_GELU made the compiler keep all
     // 128 sums of pass 0 alive for pass 1 (common subexpression) next to the 128 accumulators -> 116 spilled VGPRs
+    if (E_BIAS && !BIAS_EARLY) { DP_LOAD_BIAS() }
     if (E_BIAS) {
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf)
@@ -312,8 +353,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
             uint2 r8[2];
             if (EPI == EPI_MUL_RES8) {                         // the derivative kept by the forward, one byte per element
 #pragma unroll
-                for (int ep = 0; ep < 2; ++ep)
+                for (int ep = 0; ep < 2; ++ep) {
+                    if (R8PF) {                                // ... from the LDS image fetched under the last K tile (stage nk & 1)
+                        const int tr = wr * 128 + mf * 16 + i16, c16 = wc * 4 + ep * 2 + (g >> 1);
+                        r8[ep] = *reinterpret_cast<const uint2*>(smem + (nk & 1) * STAGE + tr * 256 + (((c16 + tr) & 15) << 4) + (g & 1) * 8);
+                    } else
                     r8[ep] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(a.R) + gm * a.ldr + n0 + wc * 64 + ep * 32 + g * 8);
+                }
             }
             float4 ru[2][2];
             if (EPI == EPI_GELU_BWD_SPLIT) {                   // the fp32 pre-activation
@@ -369,11 +415,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                 if (EPI == EPI_BIAS_GELU_DG8) {                // ... the derivative as one byte per element
                     if (a.C2) {
                         float d[8];
+                        uint2 q;
                         if (ACT) {                                 // gelu_new (BigBird): value and derivative from one tanh
 #pragma unroll
                             for (int e = 0; e < 8; ++e) { float h_; gelu_tanh_both(v[e], h_, d[e]); v[e] = h_; }
-                        } else { gelu_both4(v, d); gelu_both4(v + 4, d + 4); }
-                        uint2 q; q.x = gelu_dq_pack4(d); q.y = gelu_dq_pack4(d + 4);
+                            q.x = gelu_dq_pack4(d); q.y = gelu_dq_pack4(d + 4);
+                        } else {                                   // the derivative comes out in the units of its byte code
+                            gelu_both4q(v, d, GELU_DQ_SCALE, GELU_DQ_OFF); gelu_both4q(v + 4, d + 4, GELU_DQ_SCALE, GELU_DQ_OFF);
+                            q.x = gelu_dq_pack4_scaled(d); q.y = gelu_dq_pack4_scaled(d + 4);
+                        }
 #if AMDSEG_ABL_EPI == 1
                         asm volatile("" :: "v"(q.x), "v"(q.y));
 #else
@@ -437,6 +487,23 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     }
     constexpr bool STAGED = sizeof(OutT) == 2;
     char* stg = smem + w * 16384;
+    uint2 rpf[R16PF ? 8 : 1][NF];
+    if (R16PF) {
+        // every residual value of the wave tile in registers before any wave writes its staging image (the images overlap the residual image):
+        // rows of mf 0..3 from LDS, rows of mf 4..7 from memory (in flight under the arithmetic below)
+#pragma unroll
+        for (int mf = 4; mf < 8; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+                rpf[mf][nf] = *reinterpret_cast<const uint2*>(a.R + (size_t)(m0 + wr * 128 + mf * 16 + i16) * a.ldr + n0 + wc * WN + nf * 16 + g * 4);
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+                rpf[mf][nf] = *reinterpret_cast<const uint2*>(smem + (nk & 1) * STAGE + (wr * 64 + mf * 16 + i16) * 416 + wc * 96 + nf * 32 + g * 8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
 #define DP_STG_OFF(r, c16) (((r) >> 6) * 8192 + ((r) & 63) * 128 + ((((c16) ^ (((r) & 63) ^ (((r) & 63) >> 3))) & 7) << 4))
     const int col0 = n0 + wc * WN;
 #pragma unroll
@@ -447,7 +514,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         for (int mf = 0; mf < 8; ++mf) {
             const size_t gm = (size_t)(m0 + wr * 128 + mf * 16 + i16);
             uint2 rr[NF];
-            if (E_RES) {     // (DROP_RES: 256-wide tile only; this path is never launched for it)
+            if (R16PF) {
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) rr[nf] = rpf[mf][nf];
+            } else if (E_RES) {     // (DROP_RES: 256-wide tile only; this path is never launched for it)
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) rr[nf] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + col0 + nf * 16 + g * 4);
             }

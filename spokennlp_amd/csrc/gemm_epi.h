@@ -69,6 +69,14 @@ __device__ __forceinline__ uint32_t gelu_dq_pack4(const float* d) {
     w = __builtin_amdgcn_cvt_pk_u8_f32(d[3] * GELU_DQ_SCALE + GELU_DQ_OFF, 3, w);
     return w;
 }
+__device__ __forceinline__ uint32_t gelu_dq_pack4_scaled(const float* dq) {      // dq = gelu' * GELU_DQ_SCALE + GELU_DQ_OFF already (gelu_both4q)
+    uint32_t w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32(dq[0], 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(dq[1], 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(dq[2], 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(dq[3], 3, w);
+    return w;
+}
 __device__ __forceinline__ void gelu_dq_mul4(float* v, uint32_t w) {
     v[0] *= (float)(w & 0xffu) * GELU_DQ_STEP + GELU_DQ_LO;
     v[1] *= (float)((w >> 8) & 0xffu) * GELU_DQ_STEP + GELU_DQ_LO;

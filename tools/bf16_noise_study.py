@@ -74,6 +74,8 @@ def main():
     cases = [("fp32 (no rounding)", dict(w=0, a=0, o=0, p=0, z=0, s=0)),
              ("fast path: every bf16 store / operand", allon),
              ("... with the residual stream kept in fp32 (bf16 image feeds the GEMMs)", dict(allon, s=0)),
+             ("... and the weights exact too (what a second product x . W_lo per GEMM would approach: 2x the GEMM flops)", dict(allon, s=0, w=0)),
+             ("fast path with exact weights only (bf16 residual stream)", dict(allon, w=0)),
              ("only the residual stream stored in bf16", dict(w=0, a=0, o=0, p=0, z=0, s=1)),
              ("only GEMM activation operands bf16", dict(w=0, a=1, o=0, p=0, z=0, s=0)),
              ("only weights bf16", dict(w=1, a=0, o=0, p=0, z=0, s=0)),
