@@ -114,17 +114,19 @@ PROF_CLASSES_HBM = (("add_ln_fwd_kernel", 5), ("ln_bwd_kernel", 6), ("adamw_kern
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s (6.3 TB/s measured copy)
 
 
-def prof_read_all(nsteps):
-    """every class of the launch timer after `nsteps` armed steps: MFMA classes in TFLOP/s against the bf16 peak, HBM classes in GB/s against 8 TB/s"""
-    import ctypes as C
-    from spokennlp_amd import lib as L
-    lib = L.load()
+class _V:                                                   # (the three numbers of one launch class, as the ctypes out-parameters used to hand them over)
+    def __init__(self, v):
+        self.value = v
+
+
+def prof_read_all(nsteps, ctx):
+    """every class of the launch timer of the engine's context (amdseg_ctx) after `nsteps` armed steps: MFMA classes in TFLOP/s against the bf16 peak,
+    HBM classes in GB/s against 8 TB/s"""
     torch.cuda.synchronize()
     out = {}
     for table, hbm in ((PROF_CLASSES, False), (PROF_CLASSES_HBM, True)):
         for name, cls in table:
-            us, work, n = C.c_double(), C.c_double(), C.c_longlong()
-            L.check(lib.amdseg_prof_read(cls, C.byref(us), C.byref(work), C.byref(n)), "amdseg_prof_read")
+            us, work, n = (_V(x) for x in ctx.prof_read(cls))
             if not n.value:
                 continue
             rec = dict(launches_per_step=round(n.value / nsteps, 2), avg_launch_us=round(us.value / n.value, 2), us_per_step=round(us.value / nsteps, 1))
@@ -145,41 +147,34 @@ def _graphs_suspended(flag):
     engine.GRAPHS_SUSPENDED = bool(flag)
 
 
-def prof_arm():
-    from spokennlp_amd import lib as L
-    lib = L.load()
-    if lib.amdseg_prof_enable(1) < 0:
+def prof_arm(ctx):
+    if ctx.prof_enable(1) < 0:
         return False
-    lib.amdseg_prof_reset()
+    ctx.prof_reset()
     _graphs_suspended(True)
     return True
 
 
-def prof_collect(nsteps):
-    from spokennlp_amd import lib as L
-    out = prof_read_all(nsteps)
-    L.load().amdseg_prof_enable(0)
+def prof_collect(nsteps, ctx):
+    out = prof_read_all(nsteps, ctx)
+    ctx.prof_enable(0)
     _graphs_suspended(False)
     return out
 
 
-def instep_roofline(step, first_step, nsteps):
+def instep_roofline(step, first_step, nsteps, ctx):
     """per-kernel MFMA roofline measured INSIDE real training steps with HIP events: while armed, libamdseg launches the dominant
     kernels through hipExtLaunchKernelGGL with a start and a stop event, which are filled from the dispatch's own completion-signal
     timestamps (csrc/prof.h -- the span rocprofv3 --kernel-trace reports; a hipEventRecord pair AROUND a launch would add the ~5 us
     marker-to-marker gap).  achieved = sum of algorithmic FLOPs of the launches / sum of their spans, over `nsteps` extra steps."""
-    import ctypes as C
-    from spokennlp_amd import lib as L
-    lib = L.load()
-    rc = lib.amdseg_prof_enable(1)
-    if rc < 0:
+    if ctx.prof_enable(1) < 0:
         return None
-    lib.amdseg_prof_reset()
+    ctx.prof_reset()
     _graphs_suspended(True)
     for i in range(first_step, first_step + nsteps):
         step(i)
-    out = prof_read_all(nsteps)
-    lib.amdseg_prof_enable(0)
+    out = prof_read_all(nsteps, ctx)
+    ctx.prof_enable(0)
     _graphs_suspended(False)
     return out
 
@@ -311,7 +306,7 @@ def dp_record(eng, world, device, sync_marks, step, first_step, args):
                exposed_comm_method="HIP events on the compute stream around finish_grad_sync() (tail bucket issue + wait for every bucket), "
                                    "timed region average")
     rec["nccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
-    rec["backward_cu_budget"] = getattr(eng, "_bwd_cu_budget", 0) or None     # CUs the tile-width rule of backward counts on (amdseg_set_cu_budget)
+    rec["backward_cu_budget"] = getattr(eng, "_bwd_cu_budget", 0) or None     # CUs the tile-width rule of backward counts on (amdseg_ctx_set_cu_budget)
     try:
         if dist.get_backend() == "nccl":
             rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -521,7 +516,7 @@ def run_leg(args, device, mode, precision, steps, warmup, prof_steps, seed=7):
     out = dict(value=round(value, 1), unit="seq/s", mode=mode, precision=precision, steps=steps, warmup=warmup,
                ms_per_step=round(dt / steps * 1e3, 3), seqs_per_step=a.seqs_per_gpu, seq_len=a.seq_len,
                mfma_frac_whole_step=round(value * fl / (MFMA_PEAK_TFLOPS * 1e12), 4), final_loss=round(float(loss.detach()), 4))
-    prof = instep_roofline(step, warmup + steps, prof_steps) if prof_steps else None
+    prof = instep_roofline(step, warmup + steps, prof_steps, eng.ctx) if prof_steps else None
     if prof:
         dom = "gemm_nt_dp_kernel" if "gemm_nt_dp_kernel" in prof else max(prof, key=lambda k: prof[k]["us_per_step"])
         d = prof[dom]
@@ -732,7 +727,7 @@ def main():
     torch.cuda.synchronize()
     sync_marks.clear()
     sync_split.clear()
-    prof_timed = (not args.no_roofline) and args.prof_in_timed and prof_arm()
+    prof_timed = (not args.no_roofline) and args.prof_in_timed and prof_arm(eng.ctx)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
@@ -777,9 +772,9 @@ def main():
     prof = None
     prof_n = args.steps
     if prof_timed:                                          # start / stop events of every launch of the timed region itself
-        prof = prof_collect(args.steps)
+        prof = prof_collect(args.steps, eng.ctx)
     elif not args.no_roofline:                              # every rank runs the extra steps (the exchange is collective); rank 0 reports
-        prof = instep_roofline(step, total_steps, args.prof_steps)
+        prof = instep_roofline(step, total_steps, args.prof_steps, eng.ctx)
         prof_n = args.prof_steps
     if rank == 0:
         if prof and "gemm_tn_dp_kernel" in prof and args.model in ("bert", "longformer") and args.precision == "bf16":

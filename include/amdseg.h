@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 12   /* 12: amdseg_attn_bwd_merged (dQ, dK, dV from one kernel), amdseg_bert_layer_ws.dq_part; 11: amdseg_allreduce_* (the gradient exchange over RCCL behind an explicit amdseg_comm context, csrc/comm.hip); 10: AMDSEG_EPI_KEEP_DERIV (amdseg_bert_layer_acts.u holds gelu' of the FFN pre-activation in bf16 training when the shape allows); 9: amdseg_heads_bwd_rows takes n_feat / fix / fix_bytes (order-independent scatter sums), amdseg_scatter_rows_sorted; 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_gemm_nt_bias_drop_res, amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images), amdseg_prof_*; 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 13   /* 13: the explicit context `amdseg_ctx` -- amdseg_ctx_create / _bind / _set_cu_budget / _prof_*, amdseg_bert_cfg.ctx -- replaces the per-thread CU budget, the small-tile hook and the process-wide launch timer of ABI 10-12; the one-kernel attention backward of ABI 12 (+ ws.dq_part) and the fused bias + dropout + residual GEMM of ABI 8 -- measured losers -- are gone; 11: amdseg_allreduce_* (the gradient exchange over RCCL behind an explicit amdseg_comm context, csrc/comm.hip); 10: AMDSEG_EPI_KEEP_DERIV (amdseg_bert_layer_acts.u holds gelu' of the FFN pre-activation in bf16 training when the shape allows); 9: amdseg_heads_bwd_rows takes n_feat / fix / fix_bytes (order-independent scatter sums), amdseg_scatter_rows_sorted; 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images); 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -70,15 +70,6 @@ const char* amdseg_error_string(int code);
  *   ([hf] models/bert/modeling_bert.py:175-177,282-293,325-351) and, with transposed weight shadows, its dgrad. */
 int amdseg_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
                    const float* bias, const void* R, int ldr, void* C2, int ldc2, int out_fp32, amdseg_stream_t stream);
-/* C = R + dropout(A B^T + bias) (bf16 in / out, fp32 accumulate): the output dense, its dropout and the residual add of BertSelfOutput /
- * BertOutput ([hf] models/bert/modeling_bert.py:282-293, :340-351) in ONE launch -- the epilogue of the 256 x 256 deep-pipeline GEMM; the
- * LayerNorm that follows is then amdseg_add_ln_fwd with resid == NULL (reads z, writes out: 2 passes over [M, N] instead of 4).  The keep
- * decisions are those amdseg_add_ln_fwd makes for the same (seed, row, column) -- one stateless hash per 8 consecutive columns -- and go to
- * keepbits ([M * N / 8] bytes, bit e = column 8k + e kept; may be NULL), where amdseg_bert_layer_bwd's LayerNorm backward reads them
- * (amdseg_bert_layer_acts.drop1 / drop2).  M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128 (else AMDSEG_ERR_SHAPE: use amdseg_gemm_nt +
- * amdseg_add_ln_fwd).  ABI 8. */
-int amdseg_gemm_nt_bias_drop_res(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
-                                 const void* R, int ldr, float dropout_p, uint64_t seed, void* keepbits, amdseg_stream_t stream);
 /* gemm_tn_grouped: for each problem i: C_i[N_i,K_i] (+)= sum_m A_i[m,N_i] . B_i[m,K_i]  (fp32 out), shared M.
  *   the weight gradients dW = dY^T X of one encoder layer in ONE launch (autograd of the Linear layers above). */
 int amdseg_gemm_tn_grouped(int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
@@ -127,15 +118,6 @@ int amdseg_attn_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, flo
 int amdseg_attn_bwd_keep(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta_ws, void* dqkv, int B, int L, int heads, float scale, float dropout_p, const void* keep,
                          amdseg_stream_t stream);
-/* attention backward as ONE kernel (csrc/attention_bwd_merged.hip; ABI 12): full attention, L % 256 == 0, dropout decisions from `keep` only
- * (dropout_p > 0 without keep: AMDSEG_ERR_ARG).  One evaluation of P and dS feeds dQ, dK and dV (the two-kernel form amdseg_attn_bwd evaluates them
- * twice); delta = rowsum(dO o O) is computed inside.  dq_part: fp32 scratch of amdseg_attn_bwd_merged_scratch_bytes(B, L, heads) bytes (the dQ
- * contribution of the first 256-key block of a sequence while the second one is computed; deterministic order of addition).  kend / seq_order /
- * pad_guard: optional, the fields of the same names of amdseg_bert_cfg: key blocks without an unmasked key and query chunks of exact-zero dO rows are not visited. */
-size_t amdseg_attn_bwd_merged_scratch_bytes(int B, int L, int heads);
-int amdseg_attn_bwd_merged(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse, void* dqkv, void* dq_part,
-                           int B, int L, int heads, float scale, float dropout_p, const void* keep, const int32_t* kend, const int32_t* seq_order,
-                           const int32_t* pad_guard, amdseg_stream_t stream);
 /* the band kernels on keep masks generated by amdseg_attn_keepmask_band (same window / nglobal): dropout decisions of the Longformer layers */
 int amdseg_attn_band_fwd_keep(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads, float scale,
                               float dropout_p, const void* keep, int window, int nglobal, amdseg_stream_t stream);
@@ -251,7 +233,7 @@ int amdseg_embed_bwd(const void* dz, const int64_t* ids, const int64_t* type_ids
 int amdseg_scatter_rows_sorted(const void* dz, const int64_t* keys, const int64_t* order, float* table, int M, int H, int nrows,
                                long skip_key, int dtype, amdseg_stream_t stream);
 /* z = resid + dropout(y) (written over y), out = LayerNorm(z)   ([hf] modeling_bert.py:282-293, 340-351).
- * resid == NULL (ABI 8): y_inout_z already holds z (amdseg_gemm_nt_bias_drop_res) -- LayerNorm only, y_inout_z is not written, dropout_p ignored */
+ * resid == NULL (ABI 8): y_inout_z already holds z -- LayerNorm only, y_inout_z is not written, dropout_p ignored */
 int amdseg_add_ln_fwd(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out, float* mean,
                       float* rstd, int M, int H, float eps, float dropout_p, uint64_t seed, int dtype,
                       amdseg_stream_t stream);
@@ -307,9 +289,6 @@ int amdseg_attn_list_bwd(const void* qkv, const float* mask_bias, const void* ct
 /* fp32 parity-mode list attention (inference): qkv / ctx fp32, same lists; L <= 4096 (at most 64 listed key blocks per query block) */
 int amdseg_attn_list_f32(const float* qkv, const float* mask_bias, float* ctx, int B, int L, int heads, float scale,
                          const int* klist, const int* kcnt, int list_stride, amdseg_stream_t stream);
-/* test hook: v != 0 routes GEMMs that would take a 256-wide deep-pipeline kernel to the 128 x 128 kernels instead, so both
- * code paths can be compared on one shape; returns the previous value.  Not part of the reference-facing surface. */
-int amdseg_debug_force_small_tile(int v);
 /* small-C linear heads: logits[M,C] = x[M,H] W[C,H]^T + b, C <= 4
  * (modules/loss_calculator.py:17,42 classifier; modules/tssp.py:14,31) and their backward */
 int amdseg_rowdot_fwd(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
@@ -421,10 +400,27 @@ int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float
  * would cost all fp32 digits of (mask - lse) in rows whose visible keys are all masked).  exp() of a masked score is an exact 0 next to
  * any real score either way, which is what the reference's finfo.min mask yields. */
 
-/* ---- measurement plumbing (csrc/prof.h, prof.hip): in-kernel begin/end stamps of the device wall clock for the dominant kernels,
- * taken INSIDE real training steps.  enable(1) allocates + arms the slots (returns the previous state, < 0 on failure); read() syncs
- * the device and returns, for one launch class, the summed kernel spans (us), the summed algorithmic work (FLOPs) and the number
- * of launches since the last reset.  Not part of the reference-facing surface (bench.py's `roofline`). */
+/* ---- the explicit library context (ABI 13; csrc/prof.hip).  EVERYTHING libamdseg remembers between two calls lives in an amdseg_ctx the
+ * caller creates: (1) the CU budget of the launch-geometry rules -- a process whose backward overlaps an RCCL all-reduce sets it to (CUs - RCCL
+ * channels): the GEMM tile width is chosen by rounds of workgroups against this number (a 256-tile grid on 240 free CUs is two rounds);
+ * spokennlp_amd/engine.py does so around backward when world > 1 --, (2) a test hook that routes GEMMs to the 128 x 128 kernels, (3) the launch
+ * timer (start / stop events of every launch of the dominant kernel classes INSIDE real training steps: bench.py's `roofline`).
+ * Which context a call uses: amdseg_bert_cfg.ctx for the composite layer calls; entry points without a cfg use the context the CALLING THREAD
+ * bound with amdseg_ctx_bind() (NULL unbinds); with neither, the defaults apply: every CU, the tile rules' own choice, no timing.  One context
+ * per engine / GPU; calls on one context are serialised by its owner (the 1-process-per-GPU model).  The RCCL communicator `amdseg_comm` below is the second explicit
+ * context: the RCCL communicator.  Besides the two, the library holds only immutable per-process facts (CU count, kernel attributes, dlopen handle). */
+typedef struct amdseg_ctx amdseg_ctx;
+int amdseg_ctx_create(amdseg_ctx** out);
+int amdseg_ctx_destroy(amdseg_ctx* ctx);
+int amdseg_ctx_bind(amdseg_ctx* ctx);                                 /* the calling thread's context for cfg-less entry points; NULL unbinds */
+int amdseg_ctx_set_cu_budget(amdseg_ctx* ctx, int cus);               /* 0 = all; returns the previous value */
+int amdseg_ctx_cu_budget(const amdseg_ctx* ctx);
+int amdseg_ctx_force_small_tile(amdseg_ctx* ctx, int v);              /* test hook; returns the previous value */
+/* launch timer: enable(1) arms it (returns the previous state, < 0 on failure); read() syncs the device and returns, for one launch class, the
+ * summed kernel spans (us), the summed algorithmic work (FLOPs or bytes) and the number of launches since the last reset */
+int amdseg_ctx_prof_enable(amdseg_ctx* ctx, int on);
+int amdseg_ctx_prof_reset(amdseg_ctx* ctx);
+int amdseg_ctx_prof_read(amdseg_ctx* ctx, int cls, double* total_us, double* total_work, long long* launches);
 #define AMDSEG_PROF_GEMM_NT 0      /* gemm_nt_dp_kernel: forward + dgrad projection GEMMs */
 #define AMDSEG_PROF_GEMM_TN 1      /* gemm_tn_dp_kernel: grouped weight-gradient GEMM */
 #define AMDSEG_PROF_ATTN_FWD 2
@@ -435,13 +431,6 @@ int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float
 #define AMDSEG_PROF_LN_BWD 6       /* ln_bwd_kernel: read dy, z; write dz (+ dbranch with dropout)        = (3 or 4) * M * H * sizeof(act) */
 #define AMDSEG_PROF_ADAMW 7        /* adamw_kernel: p, g, m, v in; p, m, v out (+ bf16 shadow, + zeroed g) = 28 (+2) (+4) B per parameter */
 #define AMDSEG_PROF_KEEPMASK 8     /* attn_keepmask_kernel: the mask bytes written */
-/* Compute units the launch-geometry rules may count on (0 = all; returns the previous value).  A process whose backward overlaps an RCCL all-reduce
- * sets it to (CUs - RCCL channels): the GEMM tile width is chosen by rounds of workgroups against this number (a 256-tile grid on 240 free CUs is two
- * rounds).  spokennlp_amd/dp.py does so when world > 1.  ABI 10. */
-int amdseg_set_cu_budget(int cus);
-int amdseg_prof_enable(int on);
-int amdseg_prof_reset(void);
-int amdseg_prof_read(int cls, double* total_us, double* total_work, long long* launches);
 
 /* ---- composite: one BertLayer forward / backward ([hf] models/bert/modeling_bert.py:374-416) -------------------- */
 typedef struct amdseg_bert_cfg {
@@ -489,6 +478,8 @@ typedef struct amdseg_bert_cfg {
     const int32_t* pad_runs;        /* with pad_guard: device [B][2] = {first, end} runs of 64-token tiles t (rows 64t .. 64t+63) that hold a
                                        position < kend -- per sequence b with kend[b] > 0: {b*L/64, b*L/64 + ceil(kend[b]/64)}; L % 64 == 0 */
     const int32_t* pad_counts;      /* with pad_guard: device int[2] = {tiles in those runs, number of runs} */
+    amdseg_ctx* ctx;                /* (ABI 13) the caller's context: CU budget of the tile rules, launch timer.  NULL: the context bound to the calling
+                                       thread, else the defaults */
 } amdseg_bert_cfg;
 
 typedef struct amdseg_bert_layer_params {   /* bf16 compute shadows (+ transposes for dgrad), fp32 vectors */
@@ -534,8 +525,6 @@ typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across
     /* AMDSEG_F32S only: split images of the four gradient operands d(FFN out), du, d(attention out), dqkv: [M,3H] [M,3I] [M,3H] [M,9H] */
     void *d_out_s, *du_s, *d_ao_s, *dqkv_s;
     void* dctx_s;                           /* optional, AMDSEG_F32S with acts.qkv_s: split image [M, 3H] of d(ctx) (scratch) */
-    void* dq_part;                          /* optional (ABI 12), bf16 full attention with L % 256 == 0: amdseg_attn_bwd_merged_scratch_bytes(B, L, heads)
-                                               bytes; non-NULL = the layer's attention backward runs as ONE kernel (amdseg_attn_bwd_merged) */
 } amdseg_bert_layer_ws;
 
 int amdseg_bert_layer_fwd(const amdseg_bert_cfg* cfg, const amdseg_bert_layer_params* p, const amdseg_bert_layer_acts* a,

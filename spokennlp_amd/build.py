@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
-SOURCES = ["gemm.hip", "gemm_dp.hip", "attention.hip", "attention_bwd_merged.hip", "attention_split.hip", "elementwise.hip", "optim.hip", "gemm_f32.hip", "longformer.hip", "ponet.hip", "ponet_global.hip", "prof.hip", "parity.hip", "heads.hip", "lf_global.hip", "comm.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm_dp.hip", "attention.hip", "attention_split.hip", "elementwise.hip", "optim.hip", "gemm_f32.hip", "longformer.hip", "ponet.hip", "ponet_global.hip", "prof.hip", "parity.hip", "heads.hip", "lf_global.hip", "comm.hip", "api.hip"]
 OUT = os.path.join(HERE, "libamdseg.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 

@@ -1,5 +1,7 @@
 // Internal (C++-side) launcher prototypes shared by the kernel translation units and api.cpp.
 #pragma once
+#include <new>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,8 +31,6 @@ int amdseg_scatter_rows_sorted_impl(const void* dz, const int64_t* keys, const i
 int amdseg_embed_bwd_impl(const void* dz, const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
                           float* dword, float* dpos, float* dtype_emb, int M, int L, int H, int vocab, int type_vocab,
                           int npos, int pad_id, int dtype, hipStream_t s);
-int amdseg_gemm_nt_bias_drop_res_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
-                                      const float* bias, const void* R, int ldr, float p, uint64_t seed, void* keepbits, hipStream_t stream);
 int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out,
                            float* mean, float* rstd, int M, int H, float eps, float p, uint64_t seed, int dtype,
                            hipStream_t s, void* out_image = nullptr,         // out_image: `out` also as the split image [M, 3H] ("parity" precision)
@@ -48,7 +48,6 @@ int amdseg_colsum_split_impl(const void* x, int ld, int lo_off, float* partials,
 int amdseg_dropout_impl(const void* x, void* y, size_t n, float p, uint64_t seed, int dtype_in, int dtype_out,
                         hipStream_t s);
 int amdseg_cast_transpose_impl(const float* W, void* Wb, void* Wt, int N, int K, hipStream_t s);
-int amdseg_set_force_small_tile(int v);
 void amdseg_reduce_defer_begin(int accumulate);
 // out[j] (+)= sum_b partials[b * stride + j], j < n (queued if a deferred batch is open)
 void amdseg_reduce_rows(const float* partials, int nblocks, int stride, int n, float* out, int accumulate, hipStream_t s);
@@ -73,12 +72,6 @@ int amdseg_cast_impl(const void* x, void* y, size_t n, int dtype_in, int dtype_o
 int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, float* lse, int B, int L, int heads,
                          float scale, float p, uint64_t seed, int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,
                          const void* keep = nullptr, int skip_q = 0);
-/* csrc/attention_bwd_merged.hip: dQ, dK, dV from ONE kernel (full attention, L % 256 == 0; dropout decisions from keep masks only) */
-size_t amdseg_attn_bwd_merged_scratch_bytes_impl(int B, int L, int heads);
-bool amdseg_attn_bwd_merged_ok(int L, float p, const void* keep);
-int amdseg_attn_bwd_merged_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse, void* dqkv,
-                                void* dq_part, int B, int L, int heads, float scale, float p, hipStream_t s, const int* kend, const int* seq_order,
-                                const int* qguard, const void* keep);
 int amdseg_attn_bwd_impl(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse,
                          float* delta, void* dqkv, int B, int L, int heads, float scale, float p, uint64_t seed,
                          int window, int nglobal, hipStream_t s, const int* kend = nullptr, const int* seq_order = nullptr,
@@ -182,6 +175,24 @@ int amdseg_lf_global_bwd_rest_impl(const void* x, int x_dtype, void* dx, int dx_
                                    float* dWk, float* dWv, float* dbv, int B, int L, int H, int heads, float scale, hipStream_t s);
 
 // CUs the launch-geometry rules may count on (gemm_dp.hip)
-extern thread_local int g_amdseg_cu_budget;
 int amdseg_cu_budget();
 int amdseg_num_cus();
+
+
+// ---- the explicit library context (csrc/prof.hip; include/amdseg.h amdseg_ctx_*)
+struct AmdsegProfRec { int cls; double work; hipEvent_t e0, e1; };
+struct amdseg_ctx {
+    int cu_budget = 0;                  // CUs the tile rules count on (0 = all): an overlapped RCCL exchange holds one CU per channel
+    int force_small_tile = 0;           // test hook: exercise the 128 x 128 kernels on big shapes
+    bool prof_on = false;               // launch timer
+    std::vector<AmdsegProfRec> recs;    // [0, used) are live, the rest are pooled events of earlier rounds
+    size_t used = 0;
+    bool overflow = false;
+};
+amdseg_ctx* amdseg_current_ctx();       // the context of the call in progress / bound to this thread; may be NULL (defaults)
+struct AmdsegCtxScope {                 // a composite entry point runs under its cfg's context (when it has one)
+    amdseg_ctx* prev; bool active;
+    explicit AmdsegCtxScope(amdseg_ctx* c);
+    ~AmdsegCtxScope();
+};
+static inline int amdseg_force_small_tile() { amdseg_ctx* c = amdseg_current_ctx(); return c ? c->force_small_tile : 0; }

@@ -8,13 +8,7 @@
 
 extern "C" {
 
-// a library built with -DAMDSEG_PROBES carries wrong-result timing probes: its ABI version is NEGATIVE and spokennlp_amd.lib.load() refuses it
-#ifdef AMDSEG_PROBES
-int amdseg_abi_version(void) { return -AMDSEG_ABI_VERSION; }
-#else
 int amdseg_abi_version(void) { return AMDSEG_ABI_VERSION; }
-#endif
-int amdseg_set_cu_budget(int cus) { const int prev = g_amdseg_cu_budget; g_amdseg_cu_budget = cus > 0 ? cus : 0; return prev; }
 
 const char* amdseg_error_string(int code) {
     switch (code) {
@@ -80,12 +74,6 @@ int amdseg_attn_bwd_keep(const void* qkv, const float* mask_bias, const void* ct
                          amdseg_stream_t stream) {
     return amdseg_attn_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, dropout_p, 0, 0, 0, S(stream), nullptr,
                                 nullptr, nullptr, keep);
-}
-size_t amdseg_attn_bwd_merged_scratch_bytes(int B, int L, int heads) { return amdseg_attn_bwd_merged_scratch_bytes_impl(B, L, heads); }
-int amdseg_attn_bwd_merged(const void* qkv, const float* mask_bias, const void* ctx, const void* dctx, const float* lse, void* dqkv, void* dq_part,
-                           int B, int L, int heads, float scale, float dropout_p, const void* keep, const int32_t* kend, const int32_t* seq_order,
-                           const int32_t* pad_guard, amdseg_stream_t stream) {
-    return amdseg_attn_bwd_merged_impl(qkv, mask_bias, ctx, dctx, lse, dqkv, dq_part, B, L, heads, scale, dropout_p, S(stream), kend, seq_order, pad_guard, keep);
 }
 int amdseg_sattn_fwd(const void* qs, int ldq, int lo_q, const float* mask_bias, float* ctx, float* lse, int B, int L, int heads, float scale,
                      float dropout_p, const void* keep, int window, int nglobal, amdseg_stream_t stream) {
@@ -247,7 +235,6 @@ int amdseg_attn_list_bwd(const void* qkv, const float* mask_bias, const void* ct
     return amdseg_attn_list_bwd_impl(qkv, mask_bias, ctx, dctx, lse, delta_ws, dqkv, B, L, heads, scale, klist, kcnt, qlist, qcnt,
                                      list_stride, korder, qorder, S(stream));
 }
-int amdseg_debug_force_small_tile(int v) { return amdseg_set_force_small_tile(v); }
 int amdseg_rowdot_fwd(const void* x, const float* W, const float* b, float* out, int M, int H, int C, int dtype,
                       amdseg_stream_t stream) {
     return amdseg_rowdot_fwd_impl(x, W, b, out, M, H, C, dtype, S(stream));
@@ -368,22 +355,11 @@ int amdseg_heads_bwd_rows(const float* gout, const float* x, int M, int H, float
                                       t_labels_off, nt, Ct, dWt, dbt, w_cl, w_tssp2, n_feat, fix, fix_bytes, S(stream));
 }
 
-int amdseg_gemm_nt_bias_drop_res(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
-                                 const void* R, int ldr, float dropout_p, uint64_t seed, void* keepbits, amdseg_stream_t stream) {
-    return amdseg_gemm_nt_bias_drop_res_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, R, ldr, dropout_p, seed, keepbits, S(stream));
-}
-
 // ---------------------------------------------------------------------------------------------------- composite layer
 static inline uint64_t site_seed(uint64_t seed, int layer, int site) {
     return seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer * 8 + site + 1) * 0xD1B54A32D192ED03ull;
 }
 #define RET_IF(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
-
-static bool fuse_drop_res() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("AMDSEG_FUSE_DROP_RES"); v = (e && atoi(e) != 0) ? 1 : 0; }      // default OFF: measured slower, see below
-    return v != 0;
-}
 
 static int check_cfg(const amdseg_bert_cfg* c) {
     if (!c) return AMDSEG_ERR_ARG;
@@ -404,14 +380,9 @@ static int check_cfg(const amdseg_bert_cfg* c) {
 // Backward only: 6 = second part WITHOUT the grouped weight-gradient GEMM, 4 = that GEMM alone -- so a caller can run the
 // weight gradients of layer i on a second stream under the backward of layer i-1 (they are off the critical path: nothing
 // reads them before the optimiser step).
-// A/B switch of the "parity" precision fusions (AMDSEG_PARITY_UNFUSED bit mask: 1 ctx image from the attention, 2 d(ctx) image from the dgrad,
-// 4 GELU / GELU' + split in the FFN GEMM epilogues, 8 LayerNorm forward / backward writing the images of x1 / the dense-layer gradients): set bits
-// fall back to the separate passes
-static int parity_unfused() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("AMDSEG_PARITY_UNFUSED"); v = e ? atoi(e) : 0; }
-    return v;
-}
+// ("parity" precision: the fused forms -- ctx image from the attention, d(ctx) image from the dgrad, GELU / GELU' + split in the FFN GEMM epilogues,
+//  LayerNorm forward / backward writing the images -- are the only forms since round 6; the separate passes they replaced are in the history)
+static inline int parity_unfused() { return 0; }
 #define PHASE1(c) ((c)->phase == 0 || (c)->phase == 1 || (c)->phase == 3)
 #define PHASE2(c) ((c)->phase == 0 || (c)->phase == 2 || (c)->phase == 3 || (c)->phase == 6)
 #define PHASE_WGRAD(c) ((c)->phase == 0 || (c)->phase == 2 || (c)->phase == 3 || (c)->phase == 4)
@@ -423,8 +394,7 @@ static int parity_unfused() {
 // epilogues that are HBM time.  Needs shapes of the 256-wide deep-pipeline tile (forms 0 / 1: and the erf GELU); forward and backward evaluate the same
 // predicate on the same cfg.  AMDSEG_FFN_KEEP_DERIV = 0 / 1 / 2 picks the form.
 static inline int ffn_keep_deriv(const amdseg_bert_cfg* c) {
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("AMDSEG_FFN_KEEP_DERIV"); mode = e ? atoi(e) : 2; }
+    constexpr int mode = 2;         // (0 = u in bf16, 1 = gelu'(u) in bf16 were the other measured forms, profiles/r04_gemm_epilogue_split.md)
     const int M = c->B * c->L;
     // gelu_new (BigBird): the one-byte form only (value and derivative from ONE tanh: bigbird-base 8 x 4096 332.6 -> 336.8 seq/s; evaluated
     // separately they cost what the bytes save: 343.1 vs 344.4 on another box)
@@ -446,6 +416,7 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
                           const float* mask_bias, int li, amdseg_stream_t stream) {
     RET_IF(check_cfg(c));
     if (!p || !a || !mask_bias) return AMDSEG_ERR_ARG;
+    AmdsegCtxScope ctx_scope(c->ctx);                       // tile rules and launch timer of THIS caller (NULL: the thread's bound context or the defaults)
     hipStream_t s = S(stream);
     const int M = c->B * c->L, H = c->H, I = c->I;
     if (c->dtype == AMDSEG_F32S) {
@@ -528,33 +499,17 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         }
     }
     if (!PHASE2(c)) return AMDSEG_OK;
-    // attention output dense -> dropout -> +residual -> LN.  Optional (AMDSEG_FUSE_DROP_RES=1): dropout and residual in the GEMM's epilogue
-    // (z = x_in + dropout(ctx Wo^T + bo) leaves the GEMM; same keep decisions, one bf16 rounding less), the row kernel LayerNorm only, 2 passes
-    // over [M, H] instead of 4.  Built and measured in round 4, OFF by default: the row kernel drops 20.7 -> 13.8 us but the two GEMMs gain
-    // 14-16 us each (hash + residual read + byte stores in an exposed epilogue, and the 256-wide tile instead of the 192-wide one these N = 768
-    // shapes otherwise take): 13.81 vs 13.70 ms per step (profiles/r04_fused_drop_res.md)
-    const bool fuse_dr = fuse_drop_res() && c->dtype == AMDSEG_BF16 && (M % 256) == 0 && (H % 256) == 0 && H >= 128 && (I % 64) == 0;
-    if (fuse_dr) {
-        RET_IF(amdseg_gemm_nt_bias_drop_res_impl(a->ctx, H, p->wo, H, a->z1, H, M, H, H, p->bo, a->x_in, H, c->p_hidden, site_seed(c->seed, li, 1),
-                                                 a->drop1, s));
-        RET_IF(amdseg_add_ln_fwd_impl(a->z1, nullptr, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, 0.f, 0, c->dtype, s));
-    } else {
+    // attention output dense -> dropout -> +residual -> LN.  (Dropout and residual in the GEMM's epilogue -- 2 passes over [M, H] instead of 4 -- were
+    // built and measured in round 4: the row kernel dropped 20.7 -> 13.8 us but the two GEMMs gained 14-16 us each, profiles/r04_fused_drop_res.md.)
     RET_IF(amdseg_gemm_nt_impl(a->ctx, H, p->wo, H, a->z1, H, M, H, H, AMDSEG_EPI_BIAS, p->bo, nullptr, 0, nullptr, 0, 0, s));
     RET_IF(amdseg_add_ln_fwd_impl(a->z1, a->x_in, p->ln1_g, p->ln1_b, a->x1, a->mean1, a->rstd1, M, H, c->ln_eps, c->p_hidden,
                                   site_seed(c->seed, li, 1), c->dtype, s, nullptr, a->drop1, a->u != nullptr));    // u == NULL = inference: z is not kept
-    }
     // FFN
     RET_IF(amdseg_gemm_nt_impl(a->x1, H, p->w1, H, a->h, I, M, I, H, AMDSEG_EPI_BIAS_GELU | (c->act ? AMDSEG_EPI_ACT_TANH : 0) | ffn_keep_deriv(c),
                                p->b1, nullptr, 0, a->u, I, 0, s));
-    if (fuse_dr) {
-        RET_IF(amdseg_gemm_nt_bias_drop_res_impl(a->h, I, p->w2, I, a->z2, H, M, H, I, p->b2, a->x1, H, c->p_hidden, site_seed(c->seed, li, 2),
-                                                 a->drop2, s));
-        RET_IF(amdseg_add_ln_fwd_impl(a->z2, nullptr, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, 0.f, 0, c->dtype, s));
-    } else {
     RET_IF(amdseg_gemm_nt_impl(a->h, I, p->w2, I, a->z2, H, M, H, I, AMDSEG_EPI_BIAS, p->b2, nullptr, 0, nullptr, 0, 0, s));
     RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, c->p_hidden,
                                   site_seed(c->seed, li, 2), c->dtype, s, nullptr, a->drop2, a->u != nullptr));
-    }
     return AMDSEG_OK;
 }
 
@@ -564,6 +519,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     RET_IF(check_cfg(c));
     if (c->dtype != AMDSEG_BF16 && c->dtype != AMDSEG_F32S) return AMDSEG_ERR_ARG;      // training: bf16 fast path or split-bf16 parity
     if (!p || !g || !a || !w || !mask_bias || !dy || !dx_in) return AMDSEG_ERR_ARG;
+    AmdsegCtxScope ctx_scope(c->ctx);                       // the CU budget of this caller's tile rules, its launch timer
     hipStream_t s = S(stream);
     const int M = c->B * c->L, H = c->H, I = c->I, acc = c->accumulate_grads;
     const bool drop = c->p_hidden > 0.f;
@@ -679,11 +635,7 @@ int amdseg_bert_layer_bwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     const int NP = NPROJ(c);
     if (PHASE2(c)) {
     const void* keep_b = c->p_attn > 0.f ? a->keep : nullptr;
-    if (c->mixer == 0 && c->window == 0 && w->dq_part && amdseg_attn_bwd_merged_ok(c->L, c->p_attn, keep_b))
-        // one kernel for dQ, dK, dV (csrc/attention_bwd_merged.hip): the caller opted in by providing the fp32 scratch of dQ's first key block
-        RET_IF(amdseg_attn_bwd_merged_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->dqkv, w->dq_part, c->B, c->L, c->heads, 0.125f, c->p_attn, s,
-                                           c->kend, c->seq_order, c->pad_guard, keep_b));
-    else if (c->mixer == 0)
+    if (c->mixer == 0)
         RET_IF(amdseg_attn_bwd_impl(a->qkv, mask_bias, a->ctx, w->dctx, a->lse, w->delta, w->dqkv, c->B, c->L, c->heads, 0.125f, c->p_attn,
                                     site_seed(c->seed, li, 0), c->window, c->nglobal, s, c->kend, c->seq_order, c->pad_guard,
                                     c->p_attn > 0.f ? a->keep : nullptr,

@@ -105,20 +105,12 @@ __global__ __launch_bounds__(256) void attn_keepmask_kernel(KeepMaskArgs a) {
 // consumer side.  The words sit in the constant address space so that the (wave-uniform) loads are scalar loads; inverse_ballot turns a
 // wave-uniform 64-bit word into the lane predicate of a select, i.e. v_cndmask with that SGPR pair as its mask operand.
 // ------------------------------------------------------------------------------------------------ forward
-#ifdef AMDSEG_ATTN_FWD_WPE          // occupancy probe: force N waves per SIMD (register budget 512 / N) instead of the two workgroups per CU below
-#define ATTN_FWD_BOUNDS __attribute__((amdgpu_waves_per_eu(AMDSEG_ATTN_FWD_WPE, AMDSEG_ATTN_FWD_WPE))) __launch_bounds__(NW * 64)
-#else
 #define ATTN_FWD_BOUNDS __launch_bounds__(NW * 64, 2)
-#endif
 template <int NW, bool BAND, bool LIST = false, bool KM = false>
 __global__ ATTN_FWD_BOUNDS void attn_fwd_kernel(AttnArgs a) {
-    // K / V chunk buffers.  -DAMDSEG_ATTN_FWD_NBUF=3 keeps the chunk after next in flight (prefetch distance two chunks instead of one, counted vmcnt):
-    // measured SLOWER in the step, 50.3 vs 48.8 us per launch (three interleaved repetitions, round 4) -- the forward kernel does not wait for its
-    // K / V tiles, one chunk of lead covers them; the third buffer only costs LDS.  The list kernels (BigBird) walk their chunk lists one ahead.
-#ifndef AMDSEG_ATTN_FWD_NBUF
-#define AMDSEG_ATTN_FWD_NBUF 2
-#endif
-    constexpr int NB = LIST ? 2 : AMDSEG_ATTN_FWD_NBUF;
+    // two K / V chunk buffers.  (A third one -- the chunk after next in flight, counted vmcnt -- measured SLOWER in the step, 50.3 vs 48.8 us per
+    // launch, round 4: the forward kernel does not wait for its K / V tiles, one chunk of lead covers them; removed in round 6.)
+    constexpr int NB = 2;
     __shared__ __attribute__((aligned(16))) char smem[NB * 16384 + NB * 256];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, i16 = l & 15;
     int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -199,24 +191,16 @@ __global__ ATTN_FWD_BOUNDS void attn_fwd_kernel(AttnArgs a) {
     // the additive key mask of a chunk travels with its K/V tiles (a global load issued where it is consumed costs a full
     // L2 round trip per key fragment: 4 exposed latencies per chunk)
     if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(0) * CH, bufM(0), l);
-    if (NB == 3 && nch > 1) {
-        at_stage<NW>(kbase + (size_t)CHUNK_OF(1) * CH * a.H3, a.H3, bufK(1), w, l);
-        at_stage<NW>(vbase + (size_t)CHUNK_OF(1) * CH * a.H3, a.H3, bufV(1), w, l);
-        if (w == 0) at_stage_f32x64(a.mask_bias + tok0 + CHUNK_OF(1) * CH, bufM(1), l);
-    }
     // a wait the compiler can see: otherwise it places the vmcnt wait for the Q fragments (plain global loads) at their first use
     // INSIDE the loop, where it drains the chunk prefetch that was just issued, every iteration
     __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
-    const bool w0 = __builtin_amdgcn_readfirstlane(w) == 0;  // wave 0 carries one more LDS-DMA per chunk (the key mask)
     int cur = 0;
     for (int ch = 0; ch < nch; ++ch) {
         ch_ = ch;
-        if (NB == 3 && ch > 0 && ch + 1 < nch) {            // chunk ch has landed; chunk ch + 1 (the youngest 2 or 3 operations) may still be in flight
-            if (w0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (NB == 2) cur = ch & 1;
-        const int nxt = NB == 2 ? (cur ^ 1) : (cur >= 1 ? cur - 1 : 2);     // NB == 3: the buffer of chunk ch + 2 = the one chunk ch - 1 used
+        cur = ch & 1;
+        const int nxt = cur ^ 1;
         if (ch + (NB - 1) < nch) {
             at_stage<NW>(kbase + (size_t)CHUNK_OF(ch + NB - 1) * CH * a.H3, a.H3, bufK(nxt), w, l);
             at_stage<NW>(vbase + (size_t)CHUNK_OF(ch + NB - 1) * CH * a.H3, a.H3, bufV(nxt), w, l);
@@ -326,7 +310,6 @@ __global__ ATTN_FWD_BOUNDS void attn_fwd_kernel(AttnArgs a) {
             }
         }
         if (LIST) { c_cur = c_nxt; c_nxt = lw.next(l); }
-        if (NB == 3) cur = cur == 2 ? 0 : cur + 1;
         if (KM && ch + 1 < nch) {
             // the next chunk's words, issued behind the last LDS wait of this iteration: scalar loads share lgkmcnt with the LDS and return out
             // of order, so an LDS wait with one of them in flight has to be lgkmcnt(0) and would sit out the load's latency
@@ -878,17 +861,10 @@ int amdseg_attn_fwd_impl(const void* qkv, const float* mask_bias, void* ctx, flo
     // algorithmic FLOPs: QK^T + PV over the visible keys (full: L, band: 2W + 1 + G)
     const double span = window > 0 ? (double)(2 * window + 1 + a.nglobal) : (double)L;
     const double work = 4.0 * B * heads * (double)L * span * HD;
-    static int nw4 = -1;
-    if (nw4 < 0) { const char* e = getenv("AMDSEG_ATTN_NW4"); nw4 = e ? atoi(e) : 0; }
-    if ((nw4 & 1) && window == 0) {
-        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<4, false>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
-        return amdseg_launch_status();
-    }
     if (window > 0) {
         // band: 64-query workgroups visit (64 + 2W) / 64 = 9 chunks at W = 256, 128-query ones 10 -- measured 152 vs 172 us per layer at
         // longformer-base (full attention is the other way round: 8 waves share every K / V tile)
         if (keep && a.thresh16) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<4, true, false, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
-        else if (L % 128 == 0 && (nw4 & 2)) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<8, true>), dim3(L / 128, heads, B), dim3(512), 0, s, a);
         else AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<4, true>), dim3(L / 64, heads, B), dim3(256), 0, s, a);
     } else {
         if (L % 128 == 0) AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ATTN_FWD, work, (attn_fwd_kernel<8, false>), dim3(L / 128, heads, B), dim3(512), 0, s, a);

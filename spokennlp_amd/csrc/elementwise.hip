@@ -237,7 +237,6 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
         }
     }
     if (keep_z) {
-#ifndef AMDSEG_PLAIN_Z_STORE     // z is read next by backward, in full 128-B lines per row piece: non-temporal stores (20.56 -> 19.86 us per launch)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int ch = l + c * 64;
@@ -249,9 +248,6 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
             } else st8<T>(y_z + (size_t)m * H + ch * 8, v[c]);
         }
     }
-#else
-    row_store<T, NCH>(y_z + (size_t)m * H, nch, l, v);
-#endif
     }
     }
     float mu, rs;
@@ -275,9 +271,6 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
 //   dbranch = dz * keepmask / (1-p)   (gradient of the dense output; == dz when p == 0 -> pass dbranch = nullptr)
 //   per-block column partials of dgamma (sum dy*xhat), dbeta (sum dy) and dbias (sum dbranch)
 #define LNB_ROWS 16     // rows per block (4 per wave)
-#ifndef AMDSEG_ABL_LNB
-#define AMDSEG_ABL_LNB 0   // timing probes only (tools/run_r04_lnb.sh): 1 = no dbias column sum, 2 = no column sums at all
-#endif
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, const float* mean, const float* rstd,
                                                      const float* gamma, T* dz, T* dbranch, float* partials, int M, int H,
@@ -342,7 +335,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
                 for (int e = 0; e < 8; ++e) {
                     const float xh = (x[c][e] - mu) * rs;
                     x[c][e] = xh;
-                    if (AMDSEG_ABL_LNB < 2) { ab[c][e] += g[c][e]; ag[c][e] += g[c][e] * xh; }
+                    { ab[c][e] += g[c][e]; ag[c][e] += g[c][e] * xh; }
                     g[c][e] *= gg[e];
                     s1 += g[c][e];
                     s2 += g[c][e] * xh;
@@ -368,14 +361,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* z, co
                         else drop8_apply(seed, (uint64_t)m * nch + ch, thresh, inv_keep, g[c]);
                     }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (AMDSEG_ABL_LNB < 1) abias[c][e] += g[c][e];
+                    for (int e = 0; e < 8; ++e) abias[c][e] += g[c][e];
                 }
             }
             if (dbranch) row_store<T, NCH>(dbranch + (size_t)m * H, nch, l, g);
             if (img && dbranch) row_store_image<NCH>(img + (size_t)m * 3 * H, H, nch, l, g);
         }
     }
-    if (!partials || AMDSEG_ABL_LNB >= 2) return;
+    if (!partials) return;
     __syncthreads();                       // every wave is done reading gamma from `red`
     // cross-wave reduce through LDS, then one partial row per block
 #pragma unroll
@@ -417,11 +410,7 @@ __device__ __forceinline__ uint4 lnb_pack8(const float (&v)[8]) {
 }
 #define LNP_H 768
 #define LNP_NCH 96
-#ifdef AMDSEG_LNP_WPE                  // probe: force N waves per SIMD (spills beyond the register budget)
-#define LNP_BOUNDS __attribute__((amdgpu_waves_per_eu(AMDSEG_LNP_WPE, AMDSEG_LNP_WPE))) __launch_bounds__(256)
-#else
 #define LNP_BOUNDS __launch_bounds__(256)
-#endif
 // raw buffer access: SGPR resource + wave-uniform byte offset (SGPR) + one 32-bit lane offset -- no per-lane 64-bit addresses (the plain
 // pointer form cost 2 VGPRs per access stream and a v_lshl_add_u64 per access; the kernel spilled at 4 waves per SIMD)
 typedef int lnb_v4i __attribute__((ext_vector_type(4)));
@@ -588,108 +577,8 @@ __global__ LNP_BOUNDS void ln_bwd_pair768_kernel(const bf16_t* __restrict__ dy, 
     }
 }
 
-// dropout + residual + LayerNorm forward for H = 768 in the pair mapping of ln_bwd_pair768_kernel (round 4, second session): a wave takes two token rows
-// per trip, lane l holds chunk l of both rows and chunk 64 + (l & 31) of row A (lanes 0-31) / row B (lanes 32-63) -- no issue slot half empty (the
-// one-row kernel loads its second chunk on 32 of 64 lanes) -- gamma / beta stay in registers across the persistent loop (the one-row kernel re-reads 6 KB
-// of them per row from L1 / L2: as many bytes as the row itself), raw buffer accesses.  The SUMMATION ORDER of the two statistics passes is the one-row
-// kernel's, so mean, rstd and every output bit are identical: row A's lane partials are the one-row kernel's by construction; for row B the chunk
-// 64 + j elements travel from lane 32 + j to lane j (v_permlane32_swap) and are added there one by one behind chunk j's, as the one-row kernel's lane j
-// does; the cross-lane sum is the same wave_sum.
-__global__ LNP_BOUNDS void add_ln_fwd_pair768_kernel(bf16_t* __restrict__ y_z, const bf16_t* __restrict__ resid, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, bf16_t* __restrict__ out, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int M, float eps, uint32_t thresh, float inv_keep, uint64_t seed,
-                                                     uint8_t* __restrict__ keepbits, bool keep_z) {
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
-    const int half = l >> 5, ch2 = 64 + (l & 31);
-    const uint32_t off0 = (uint32_t)l * 16u, off1 = (uint32_t)(LNP_H * 2) + off0, off2 = (uint32_t)half * (LNP_H * 2) + (uint32_t)ch2 * 16u;
-    float g0[8], b0[8], g2[8], b2[8];
-    ld8<float>(gamma + l * 8, g0); ld8<float>(beta + l * 8, b0); ld8<float>(gamma + ch2 * 8, g2); ld8<float>(beta + ch2 * 8, b2);
-    const __amdgpu_buffer_rsrc_t r_y = lnb_rsrc(y_z), r_x = lnb_rsrc(resid), r_o = lnb_rsrc(out);
-#pragma unroll 1
-    for (int pair = blockIdx.x * 4 + w; pair < (M >> 1); pair += gridDim.x * 4) {
-        const int mA = 2 * pair;
-        const uint32_t rowb = (uint32_t)mA * (LNP_H * 2);
-        const uint4 ry0 = lnb_ld16(r_y, off0, rowb), ry1 = lnb_ld16(r_y, off1, rowb), ry2 = lnb_ld16(r_y, off2, rowb);
-        const uint4 rx0 = lnb_ld16(r_x, off0, rowb), rx1 = lnb_ld16(r_x, off1, rowb), rx2 = lnb_ld16(r_x, off2, rowb);
-        float v0[8], v1[8], v2[8];                          // (row A, chunk l), (row B, chunk l), (row A or B, chunk ch2)
-        lnb_unpack8(ry0, v0); lnb_unpack8(ry1, v1); lnb_unpack8(ry2, v2);
-        if (thresh) {
-            const uint64_t cA = (uint64_t)mA * LNP_NCH, cB = cA + LNP_NCH, c2 = (half ? cB : cA) + (uint64_t)ch2;
-            const uint32_t k0 = drop8_bits(seed, cA + l, thresh), k1 = drop8_bits(seed, cB + l, thresh), k2 = drop8_bits(seed, c2, thresh);
-            if (keepbits) { keepbits[cA + l] = (uint8_t)k0; keepbits[cB + l] = (uint8_t)k1; keepbits[c2] = (uint8_t)k2; }
-            drop8_apply_bits(k0, inv_keep, v0); drop8_apply_bits(k1, inv_keep, v1); drop8_apply_bits(k2, inv_keep, v2);
-        }
-        {
-            float x[8];
-            lnb_unpack8(rx0, x);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v0[e] = x[e] + v0[e];
-            lnb_unpack8(rx1, x);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v1[e] = x[e] + v1[e];
-            lnb_unpack8(rx2, x);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v2[e] = x[e] + v2[e];
-        }
-        if (keep_z) {
-#ifndef AMDSEG_PLAIN_Z_STORE
-            typedef unsigned ew_u4 __attribute__((ext_vector_type(4)));
-            bf16_t* zr = y_z + (size_t)mA * LNP_H;
-            const uint4 q0 = lnb_pack8(v0), q1 = lnb_pack8(v1), q2 = lnb_pack8(v2);
-            __builtin_nontemporal_store((ew_u4){q0.x, q0.y, q0.z, q0.w}, reinterpret_cast<ew_u4*>(zr + l * 8));
-            __builtin_nontemporal_store((ew_u4){q1.x, q1.y, q1.z, q1.w}, reinterpret_cast<ew_u4*>(zr + LNP_H + l * 8));
-            __builtin_nontemporal_store((ew_u4){q2.x, q2.y, q2.z, q2.w}, reinterpret_cast<ew_u4*>(zr + half * LNP_H + ch2 * 8));
-#else
-            lnb_st16(r_y, off0, rowb, lnb_pack8(v0)); lnb_st16(r_y, off1, rowb, lnb_pack8(v1)); lnb_st16(r_y, off2, rowb, lnb_pack8(v2));
-#endif
-        }
-        // row B's chunk 64 + j: from lane 32 + j (where it is v2) to lane j
-        float t2[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const unsigned u = __float_as_uint(v2[e]);
-            const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            t2[e] = __uint_as_float(r[1]);                  // lanes 0-31: the upper half's value
-        }
-        // pass 1: the sums, in the one-row kernel's order (chunk l's eight elements, then -- lanes 0-31 -- chunk 64 + l's)
-        float sA = 0.f, sB = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sA += v0[e];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sB += v1[e];
-        if (!half) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sA += v2[e];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sB += t2[e];
-        }
-        const float muA = wave_sum(sA) / (float)LNP_H, muB = wave_sum(sB) / (float)LNP_H;
-        float qA = 0.f, qB = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = v0[e] - muA; qA += d * d; }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = v1[e] - muB; qB += d * d; }
-        if (!half) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v2[e] - muA; qA += d * d; }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = t2[e] - muB; qB += d * d; }
-        }
-        const float rsA = rsqrtf(wave_sum(qA) / (float)LNP_H + eps), rsB = rsqrtf(wave_sum(qB) / (float)LNP_H + eps);
-        if (l == 0) {
-            if (mean) { mean[mA] = muA; mean[mA + 1] = muB; }
-            if (rstd) { rstd[mA] = rsA; rstd[mA + 1] = rsB; }
-        }
-        const float mu2 = half ? muB : muA, rs2 = half ? rsB : rsA;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v0[e] = (v0[e] - muA) * rsA * g0[e] + b0[e];
-            v1[e] = (v1[e] - muB) * rsB * g0[e] + b0[e];
-            v2[e] = (v2[e] - mu2) * rs2 * g2[e] + b2[e];
-        }
-        lnb_st16(r_o, off0, rowb, lnb_pack8(v0)); lnb_st16(r_o, off1, rowb, lnb_pack8(v1)); lnb_st16(r_o, off2, rowb, lnb_pack8(v2));
-    }
-}
+// (a forward twin of this pair mapping -- dropout + residual + LayerNorm, two token rows per wave -- gave the same bits and the same time as the one-row
+//  kernel in round 4 (20.0 vs 19.9 us per launch: its waves wait on memory, not on issue slots) and was removed from the product in round 6)
 
 // out[c] (+)= sum_b partials[b*stride + offset + c]   (deterministic second stage)
 // block = RED_CG float4 column groups (RED_COLS = 32 columns = one 128-B line per partial row) x RED_ROWS = 32 row lanes; each lane strides over
@@ -1125,15 +1014,6 @@ int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamm
     uint32_t th; float ik; drop_params(p, th, ik);
     dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     const double bytes_per_el = resid ? (keep_z ? 4.0 : 3.0) : 2.0;
-    // H = 768, bf16, with a residual, no split image: the pair kernel exists and gives the same bits -- and the same time (round 4: 20.0 vs 19.9 us per
-    // launch, step 12.82 / 12.89 / 12.75 vs 12.90 / 12.81 / 12.76 ms: the one-row kernel's waves wait on memory, not on issue slots).  Opt-in, AMDSEG_LNF_PAIR=1
-    const char* lnf_e = getenv("AMDSEG_LNF_PAIR");          // (read per call: the test toggles it inside one process)
-    const bool lnf_generic = !(lnf_e && atoi(lnf_e) != 0);
-    if (!lnf_generic && dtype == AMDSEG_BF16 && H == LNP_H && resid && !out_image && (M % 2) == 0 && (size_t)M * (LNP_H * 2) < ((size_t)1 << 31)) {
-        AMDSEG_LAUNCH_PROF(AMDSEG_PROF_ADD_LN_FWD, bytes_per_el * M * H * 2, add_ln_fwd_pair768_kernel, dim3(pair_grid((M / 2 + 3) / 4)), dim3(256), 0, s,
-                           (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta, (bf16_t*)out, mean, rstd, M, eps, th, ik, seed, (uint8_t*)keepbits, keep_z);
-        return amdseg_launch_status();
-    }
     if (dtype == AMDSEG_BF16)
         ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, bytes_per_el * M * H * 2, add_ln_fwd_kernel, bf16_t, H, grid, dim3(256), 0, s, (bf16_t*)y_inout_z, (const bf16_t*)resid, gamma, beta,
                            (bf16_t*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits, keep_z);
@@ -1150,8 +1030,7 @@ static int pair_grid(int nblk) {
     if (!slots) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const char* e = getenv("AMDSEG_LNP_WGS_PER_CU");
-        slots = cus * (e && atoi(e) > 0 ? atoi(e) : 2);
+        slots = cus * 2;
     }
     return nblk < slots ? nblk : slots;
 }
@@ -1166,12 +1045,9 @@ int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const f
     if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
     uint32_t th; float ik; drop_params(p, th, ik);
     const int nblk = (M + LNB_ROWS - 1) / LNB_ROWS;
-    const size_t shm = AMDSEG_ABL_LNB >= 2 ? (size_t)H * sizeof(float) : (size_t)3 * 4 * H * sizeof(float);
+    const size_t shm = (size_t)3 * 4 * H * sizeof(float);
     int nblk_eff = nblk;                                    // partial rows written per column sum (the pair kernel's grid is persistent)
-    static int generic_only = -1;
-    if (generic_only < 0) { const char* e = getenv("AMDSEG_LN_BWD_GENERIC"); generic_only = (e && atoi(e)) ? 1 : 0; }
-    if (dtype == AMDSEG_BF16 && H == LNP_H && (M % LNB_ROWS) == 0 && (size_t)M * H * 2 < (1ull << 31) && partials && !dense_grad_image && (th == 0 || keepbits) && !generic_only &&
-        AMDSEG_ABL_LNB == 0)
+    if (dtype == AMDSEG_BF16 && H == LNP_H && (M % LNB_ROWS) == 0 && (size_t)M * H * 2 < (1ull << 31) && partials && !dense_grad_image && (th == 0 || keepbits))
     {
         nblk_eff = pair_grid(nblk);
         AMDSEG_LAUNCH_PROF(AMDSEG_PROF_LN_BWD, (dbranch ? 4.0 : 3.0) * M * H * 2, ln_bwd_pair768_kernel, dim3(nblk_eff), dim3(256), shm, s,

@@ -21,17 +21,10 @@
 #define BK 64
 #include "gemm_epi.h"
 
-#ifdef AMDSEG_PHASE_TIMERS
-#define PT_DECL unsigned long long pt_wait = 0, pt_comp = 0, pt_t0, pt_t1, pt_t2; const unsigned long long pt_start = __builtin_readcyclecounter();
-#define PT_A pt_t0 = __builtin_readcyclecounter();
-#define PT_B pt_t1 = __builtin_readcyclecounter(); pt_wait += pt_t1 - pt_t0;
-#define PT_C pt_t2 = __builtin_readcyclecounter(); pt_comp += pt_t2 - pt_t1;
-#else
 #define PT_DECL
 #define PT_A
 #define PT_B
 #define PT_C
-#endif
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(void, lds_wave_base), 16, 0, 0);
 }
@@ -137,15 +130,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#ifdef AMDSEG_PHASE_TIMERS
-        asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][1][15]));
-        asm volatile("s_nop 0" ::: "memory");
-#endif
         PT_C
     }
-#ifdef AMDSEG_PHASE_TIMERS
-    const unsigned long long pt_loop_end = __builtin_readcyclecounter();
-#endif
     // ---- epilogue.  The accumulator layout gives a lane one row and 4 consecutive columns (8 B of bf16): stored directly,
     // one instruction touches 32 rows x 16 B -- 32 partial cache lines -- and the CU's address path (shared with the
     // other resident workgroup's global->LDS staging) becomes the bottleneck (store ablation: +23 us on the QKV shape,
@@ -244,17 +230,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
             }
         }
     }
-#ifdef AMDSEG_PHASE_TIMERS
-    if (a.dbg && l == 0) {
-        const unsigned long long pt_end = __builtin_readcyclecounter();
-        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + w) * 4;
-        d[0] = pt_wait; d[1] = pt_comp; d[2] = pt_loop_end - pt_start; d[3] = pt_end - pt_loop_end;
-    }
-#endif
 }
 
-static thread_local int g_force_small_tile = 0;      // test hook (amdseg_debug_force_small_tile): exercise the 128x128 kernel on big shapes
-int amdseg_set_force_small_tile(int v) { int o = g_force_small_tile; g_force_small_tile = v; return o; }
+#define g_force_small_tile amdseg_force_small_tile()       // test hook of the call's context (amdseg_ctx_force_small_tile): the 128x128 kernels on big shapes
 
 // ------------------------------------------------------------------------------------------------ gemm_nt, ping-pong 256x192
 // Large-shape kernel (M % 256 == 0, N % 192 == 0): one 512-thread workgroup per CU computes a 256 x 192 tile.
@@ -400,10 +378,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
     int ntl = 0;
     while (pp_tile_of(blockIdx.x, ntl, T) >= 0) ++ntl;
     if (ntl == 0) return;
-#ifdef AMDSEG_CLOCK_PROBE
-    const unsigned long long cp_c0 = __builtin_readcyclecounter();
-    unsigned long long cp_r0; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp_r0));
-#endif
     const int total = ntl * nk;
 
     PpLane off;
@@ -562,13 +536,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
         pp_epi_load<EPIX>(a, er, pm0, pn0, grp, wq, l);
         pp_epi_store<EPIX, OutT>(a, er, acc, pm0, pn0, grp, wq, l);
     }
-#ifdef AMDSEG_CLOCK_PROBE
-    if (a.dbg && tid == 0) {
-        const unsigned long long cp_c1 = __builtin_readcyclecounter();
-        unsigned long long cp_r1; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp_r1));
-        a.dbg[blockIdx.x * 2] = cp_c1 - cp_c0; a.dbg[blockIdx.x * 2 + 1] = cp_r1 - cp_r0;
-    }
-#endif
 }
 
 template <int EPIX, typename OutT>
@@ -578,12 +545,11 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     // workgroup per CU pays an exposed prologue + epilogue per tile), the 128x128 kernel (2 workgroups per CU overlap each
     // other's prologue/epilogue) for K <= 768; shapes the small kernel cannot tile always take the ping-pong kernel
     const bool small_ok = (a_in.M % BM) == 0 && (a_in.N % BN) == 0;
-    static int dp_min_k = -1;
-    if (dp_min_k < 0) { const char* e = getenv("AMDSEG_DP_MIN_K"); dp_min_k = e ? atoi(e) : 768; }
+    constexpr int dp_min_k = 768;
     // M % 256 == 0 and N a multiple of 256 (or of 192), K >= 768: the deep-pipeline kernel (gemm_dp.hip).  Measured at M = 16384 against
     // the kernels below: K = 3072 / 2304: 73 / 56 us vs 90 / 68 (ping-pong); K = 768 (since the LDS-DMA is issued as inline asm and
     // the GELU epilogues were slimmed): QKV 65 vs 67, dual-output FFN 95 vs 131, GELU-bwd 92 vs 127, N = 768: 24 vs 27; train step
-    // 16.4 vs 16.9 ms.  AMDSEG_DP_MIN_K moves the threshold.
+    // 16.4 vs 16.9 ms.
     // (a persistent 128 x 256 variant that runs the GELU epilogue of tile i under the main loop of tile i + 1 was built and measured: the
     // slices cost their full time there too -- the two waves of a SIMD share its VALU issue and matrix pipe -- and the half-height tile's
     // main loop is 40 % slower: tools/ubench/gemm_hp_experiment.hip, profiles/r03_gemm_epilogue_overlap.md)
@@ -595,9 +561,7 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
         const int t_dp = (a_in.M / 256) * ((a_in.N % 256) == 0 ? a_in.N / 256 : a_in.N / 192);
         const int t_sm = (a_in.M / BM) * (a_in.N / BN);
         const float c_dp = (float)((t_dp + 255) / 256), c_sm = 0.715f * (float)((t_sm + 511) / 512);
-        static int adaptive = -1;
-        if (adaptive < 0) { const char* e = getenv("AMDSEG_NT_ADAPTIVE"); adaptive = e ? atoi(e) : 1; }
-        if (!(adaptive && small_ok && c_sm < c_dp))
+        if (!(small_ok && c_sm < c_dp))
             return amdseg_launch_nt_dp<EPIX, OutT>(a_in, s);
         hipLaunchKernelGGL((gemm_nt_kernel<EPIX, OutT>), dim3(a_in.tiles_m * a_in.tiles_n), dim3(256), 0, s, a_in);
         return amdseg_launch_status();
@@ -606,8 +570,7 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     const bool single_gelu = EPI == EPI_BIAS_GELU && !a_in.C2;
     if (single_gelu && !small_ok) return AMDSEG_ERR_SHAPE;
     const bool pp_ok = (a_in.M % PP_BM) == 0 && (a_in.N % PP_BN) == 0 && !single_gelu;
-    static int pp_min_k = -1;
-    if (pp_min_k < 0) { const char* e = getenv("AMDSEG_PP_MIN_K"); pp_min_k = e ? atoi(e) : 1536; }
+    constexpr int pp_min_k = 1536;
     if (pp_ok && !(g_force_small_tile && small_ok) && (a_in.K >= pp_min_k || !small_ok || g_force_small_tile < 0)) {
         static bool attr_set = false;          // > 64 KiB of dynamic LDS is opted into once per kernel instantiation
         if (!attr_set) {
@@ -641,14 +604,8 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     if ((lda % 8) || (ldb % 8) || (ldc % 8)) return AMDSEG_ERR_SHAPE;
     GemmNTArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = bias; a.R = (const bf16_t*)R; a.C2 = (bf16_t*)C2;
-    a.dbg = nullptr;
-#if defined(AMDSEG_PHASE_TIMERS) || defined(AMDSEG_CLOCK_PROBE)
-    extern unsigned long long* g_amdseg_dbg;
-    a.dbg = g_amdseg_dbg;
-#endif
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldc2 = ldc2; a.M = M; a.N = N; a.K = K;
     a.tiles_m = M / BM; a.tiles_n = N / BN; a.dup_off = 0;
-    a.drop_thresh = 0; a.drop_inv_keep = 1.f; a.drop_seed = 0; a.keepbits = nullptr;
     const bool zok = zkend && zguard && zL > 0 && (zL % PP_BM) == 0 && (M % zL) == 0;      // a 256-row tile lies inside one sequence
     a.zkend = zok ? zkend : nullptr; a.zguard = zok ? zguard : nullptr; a.zL = zok ? zL : 0;
     switch (epi) {
@@ -691,24 +648,6 @@ int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
             return amdseg_launch_nt_dp<EPI_BIAS_GELU_SPLIT, float>(a, stream);
     }
     return AMDSEG_ERR_ARG;
-}
-
-// C = R + dropout(A B^T + bias): the output dense, its dropout and the residual add of BertSelfOutput / BertOutput ([hf] modeling_bert.py
-// :282-293, :340-351) in the epilogue of the 256 x 256 deep-pipeline kernel; the LayerNorm that follows then reads one tensor instead of two
-// and writes one instead of two.  Keep decisions = drop8_bits(seed, row * N / 8 + column / 8): what amdseg_add_ln_fwd would have decided.
-int amdseg_gemm_nt_bias_drop_res_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
-                                      const float* bias, const void* R, int ldr, float p, uint64_t seed, void* keepbits, hipStream_t stream) {
-    if (!A || !B || !C || !bias || !R) return AMDSEG_ERR_ARG;
-    if (M <= 0 || (M % 256) || (N % 256) || (K % BK) || K < 128) return AMDSEG_ERR_SHAPE;
-    if ((lda % 8) || (ldb % 8) || (ldc % 8) || (ldr % 8)) return AMDSEG_ERR_SHAPE;
-    GemmNTArgs a;
-    a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = bias; a.R = (const bf16_t*)R; a.C2 = nullptr; a.dbg = nullptr;
-    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldc2 = 0; a.M = M; a.N = N; a.K = K;
-    a.tiles_m = M / 256; a.tiles_n = N / 256; a.dup_off = 0;
-    a.zkend = nullptr; a.zguard = nullptr; a.zL = 0;
-    amdseg_drop_params(p, a.drop_thresh, a.drop_inv_keep);
-    a.drop_seed = seed; a.keepbits = (unsigned char*)keepbits;
-    return amdseg_launch_nt_dp<EPI_BIAS_DROP_RES, bf16_t>(a, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ gemm_tn
@@ -862,9 +801,7 @@ int amdseg_gemm_tn_grouped_bias_impl(int nprob, const void* const* A, const int*
     const bool zok = runs && counts && zguard;
     a.runs = zok ? runs : nullptr; a.counts = zok ? counts : nullptr; a.zguard = zok ? zguard : nullptr;
     // 256 x 128 deep-pipeline kernel (gemm_dp.hip) when every problem tiles by it: ~0.7x the time of the kernel below
-    static int tn_dp = -1;
-    if (tn_dp < 0) { const char* e = getenv("AMDSEG_TN_DP"); tn_dp = e ? atoi(e) : 1; }
-    bool dp = tn_dp && M >= 128 && !g_force_small_tile;
+    bool dp = M >= 128 && !g_force_small_tile;
     for (int i = 0; i < nprob; ++i) dp = dp && (N[i] % 256) == 0 && (size_t)M * (size_t)(lda[i] > ldb[i] ? lda[i] : ldb[i]) < ((size_t)1 << 31);
     if (dp) {
         for (int i = 0; i < nprob; ++i)

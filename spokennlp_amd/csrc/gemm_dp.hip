@@ -26,16 +26,7 @@
 #define DP_BN 256
 #define DP_STAGE (8 * 8192)
 #define DP_LDS (2 * DP_STAGE)
-// timing probes of the 256-wide epilogue (wrong results): -DAMDSEG_ABL_EPI=1 keeps the epilogue's arithmetic and residual loads but issues no
-// global store; =2 ends the kernel after the K loop (accumulators kept alive)
-#ifndef AMDSEG_ABL_EPI
-#define AMDSEG_ABL_EPI 0
-#endif
-#if AMDSEG_ABL_EPI == 1
-#define DP_ST16(ptr, val) asm volatile("" :: "v"((val).x), "v"((val).y), "v"((val).z), "v"((val).w))
-#else
 #define DP_ST16(ptr, val) *reinterpret_cast<uint4*>(ptr) = (val)
-#endif
 
 __device__ __forceinline__ int dp_swz(int r) { const int p = (r >> 1) & 7; return p ^ (((p + 2) >> 2) & 1); }
 __device__ __forceinline__ bf16x8 dp_frag(const char* tile, int r, int c) {
@@ -55,21 +46,18 @@ __device__ __forceinline__ void dp_glds16(const void* g, void* lds_wave_base) {
 
 // NF = 16-column fragments per column wave: 4 -> 256 x 256 tile, 3 -> 256 x 192 tile (wave tile 128 x 48, three B images per stage)
 // for widths that are multiples of 192 but not of 256.
-// PERSIST (256-wide tile, multi-round launches of the two GELU epilogues): the grid is one workgroup per CU and a workgroup walks the tiles
-// bid, bid + grid, ...; behind the K loop of a tile -- its epilogue reads no LDS -- the 16 LDS-DMA pieces of the NEXT tile's two stages are issued
-// before the epilogue's arithmetic and stores, so that tile starts on landed data instead of paying its own fill (3-5 us per round at K = 768:
-// the K-loop-only probe takes 65-70 us for 36 K tiles in three rounds where a 48-K-tile single round takes 68-70).  The next tile's first wait is
-// a COUNTED vmcnt that leaves the youngest 16 memory operations (epilogue stores, issued behind the pieces) in flight: gfx950 retires vector
-// loads and stores in issue order (tools/ubench/vmcnt_order.cpp), so everything older -- the pieces -- has landed.
-template <int EPIX, typename OutT, int NF, bool PERSIST = false>
+// (Rounds 3-5 also carried a persistent form -- one workgroup per CU walking its tiles, the next tile's two stages requested behind the K loop -- the
+// early-start prologue, the relaxed lgkmcnt waits, a fused bias + dropout + residual epilogue and a set of wrong-result timing probes; all measured
+// neutral or slower (profiles/r03_gemm_epilogue_overlap.md, r04_gemm_epilogue_split.md, r04_gemm_prologue_ablation.md, r04_fused_drop_res.md) and
+// were removed from the product in round 6: `git show 17e81c4:spokennlp_amd/csrc/gemm_dp.hip`.)
+template <int EPIX, typename OutT, int NF>
 __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
     constexpr int BN = NF * 64, WN = NF * 16, STAGE = (4 + NF) * 8192;     // tile width, wave-tile width, bytes per LDS stage
-    constexpr bool E_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT || EPI == EPI_BIAS_GELU_SPLIT || EPI == EPI_BIAS_DROP_RES ||
+    constexpr bool E_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SPLIT || EPI == EPI_BIAS_GELU_SPLIT ||
                             EPI == EPI_BIAS_GELU_DG || EPI == EPI_BIAS_GELU_DG8;           // a bias vector goes into the accumulators
-    constexpr bool E_RES = EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_DROP_RES || EPI == EPI_MUL_RES;    // a bf16 operand R is read
+    constexpr bool E_RES = EPI == EPI_ADD_RES || EPI == EPI_GELU_BWD || EPI == EPI_MUL_RES;    // a bf16 operand R is read
     constexpr bool E_GELU2 = EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_DG;               // two outputs: C2 (pre-activation / derivative) and C
-    static_assert(!PERSIST || NF == 4, "the persistent form needs the LDS-free epilogue of the 256-wide tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,12 +70,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         const int gmn_ = min(a.tiles_m - first_m_, GROUP_M); const int rem_ = t_ - grp_ * gsz_full; \
         M0 = (first_m_ + rem_ % gmn_) * DP_BM; N0 = (rem_ / gmn_) * BN; }
 #define DP_ZTILE(M0) (a.zkend != nullptr && ((M0) - ((M0) / a.zL) * a.zL) >= a.zkend[(M0) / a.zL] && *a.zguard == 0)
-    bool pf_ = false;                                      // workgroup-uniform: this tile's two stages were requested behind the previous tile's K loop
-    const int tstep = PERSIST ? (int)gridDim.x : nwg;
-    int tt = blockIdx.x;
-    do {                                                   // (one pass unless PERSIST: the condition at the bottom is a compile-time false)
     int m0, n0;
-    DP_TILE_OF(tt, m0, n0)
+    DP_TILE_OF(blockIdx.x, m0, n0)
 #define DP_TILE_A(s, i) (smem + (s) * STAGE + (i) * 8192)
 #define DP_TILE_B(s, i) (smem + (s) * STAGE + (4 + (i)) * 8192)
     const bf16_t* pA = a.A + (size_t)(m0 + wr * 128) * a.lda;                 // this group's A rows
@@ -111,16 +95,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #define DP_DMA_A_P(PA, s, i, kt) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
         amdseg_glds16_saddr_lds((PA) + (kt) * 64, offA[(i) * 2 + q], ldsAw + (s) * STAGE + (i) * 8192 + q * 1024);
 #define DP_DMA_A(s, i, kt) DP_DMA_A_P(pA, s, i, kt)
-#ifdef AMDSEG_ABL_NO_B     // timing probe (wrong results): the B operand costs nothing -- no LDS-DMA pieces, no fragment reads for it
-#define DP_DMA_B_P(PB, s, kt)
-#define DP_DMA_B(s, kt)
-#define DP_WAIT_TILE() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
-#else
 #define DP_DMA_B_P(PB, s, kt) _Pragma("unroll") for (int i = 0; i < 2; ++i) if (i == 0 || b2) _Pragma("unroll") for (int q = 0; q < 2; ++q) \
         amdseg_glds16_saddr_lds((PB) + (kt) * 64, offB[i * 2 + q], ldsBw + (s) * STAGE + i * 8192 + q * 1024);
 #define DP_DMA_B(s, kt) DP_DMA_B_P(pB, s, kt)
 #define DP_WAIT_TILE() do { if (vm8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
-#endif
     // the bias vector is requested HERE, in front of the prologue's DMA, and added at the end (round 6): the epilogue used to open with these four
     // global loads per lane, whose latency every tile of every biased GEMM paid with the matrix pipe idle.  (It is still ADDED last: starting the
     // accumulators from it was measured too -- another 0.5-1 us per launch -- but rounds differently from the 128 x 128 and ping-pong kernels of
@@ -146,13 +124,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     // (rocprofv3, round 6: 91 us per launch against 65-70 for the K loops alone; the derivative reads were the exposed part).
     // Piece j of wave w = tile rows w*32 + j*4 .. +4, all 256 columns; the 16-B unit (row r, columns c16*16 .. +16) lands at LDS unit (c16 + r) & 15 of
     // its row, so the epilogue's ds_read_b64 (16 rows x two neighbouring units per wave instruction) touches every 16-B bank group exactly twice.
-    constexpr bool R8PF = EPI == EPI_MUL_RES8 && NF == 4 && !PERSIST;
+    constexpr bool R8PF = EPI == EPI_MUL_RES8 && NF == 4;
     // EPI_ADD_RES on the 256 x 192 tile (the residual-adding input-gradient GEMMs dx1 = du W1 + dz2, dx_in = dqkv Wqkv + dz1): the bf16 residual tile is
     // 96 KiB, the free stage 56 KiB -- the FIRST HALF of each row group's rows (mf 0..3: tile rows 0-63 and 128-191, 128 rows x 384 B) comes through
     // LDS under the last K tile, the second half by global loads requested at the top of the epilogue, in front of the arithmetic of the first.
     // LDS rows are 416 B apart (26 units of 16 B, the last two padding): 16 consecutive rows then start in 8 distinct 32-B bank slots, two each, and
     // the epilogue's ds_read_b64 (16 rows x 32 B per wave instruction) is conflict-free.  56 pieces of 1 KiB = the stage exactly, 7 per wave.
-    constexpr bool R16PF = EPI == EPI_ADD_RES && NF == 3 && !PERSIST;
+    constexpr bool R16PF = EPI == EPI_ADD_RES && NF == 3;
     constexpr bool RPF = R8PF || R16PF;
 #define DP_RPF_WAIT() do { if (R8PF) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); } while (0)
 #define DP_R16_ISSUE(stage) do { if (R16PF) { \
@@ -168,28 +146,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
             const int r_ = j_ * 4 + (l >> 4); \
             amdseg_glds16_saddr_lds(r8b_, (uint32_t)(r_ * a.ldr + ((((l & 15) - r_) & 15) << 4)), lds0 + (stage) * STAGE + (w * 32 + j_ * 4) * 256); } } } while (0)
     if (!ztile) {
-    if (PERSIST && pf_) {
-        // both stages were requested behind the previous tile's K loop; the 16 youngest operations are that tile's epilogue stores
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    } else {
-    // prologue: both stages; the first MFMA phase waits for K tile 1 as well (vmcnt(0) at kt = 0).  Round 4 tried the early start -- K tile 1
-    // issued in the loop's own steady-state order so that the counted waits hold from kt = 0 and the first MFMAs wait for K tile 0 only
-    // (-DAMDSEG_ABL_EARLY_START) -- and measured it SLOWER, same box back to back (profiles/r04_gemm_prologue_ablation.md: N = 2304 K = 768
-    // 66.0 -> 68.1 us, bias + GELU 96.5 -> 104.6, the K = 3072 shapes unchanged): both stages of a fresh workgroup land together (the fill is
-    // one latency, not two transfers), and what the early start buys is a first K tile whose MFMAs run beside the second stage's arrival.
+    // prologue: both stages; the first MFMA phase waits for K tile 1 as well (vmcnt(0) at kt = 0).  (Round 4 tried an early start -- K tile 1 issued in
+    // the loop's steady-state order so that the first MFMAs wait for K tile 0 only -- and measured it slower, profiles/r04_gemm_prologue_ablation.md:
+    // both stages of a fresh workgroup land together, the fill is one latency, not two transfers.)
     DP_DMA_A(0, 0, 0) DP_DMA_A(0, 1, 0) DP_DMA_B(0, 0)
-#ifndef AMDSEG_ABL_EARLY_START
 #define DP_KT0 1
     if (nk > 1) { DP_DMA_A(1, 0, 1) DP_DMA_A(1, 1, 1) DP_DMA_B(1, 1) DP_WAIT_TILE(); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-#define DP_KT0 0
-    if (nk > 1) {
-        DP_DMA_A(1, 0, 1) DP_DMA_B(1, 1)
-        if (vm8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();             // stagger: group 1 runs one barrier behind group 0
     bf16x8 fa[4][2], fb[NF][2];
@@ -219,12 +182,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         fa[f][kk] = *reinterpret_cast<const bf16x8*>(la_[S][kk] + (h) * 8192 + f * 2048);
 #define DP_LOAD_B_U(S) _Pragma("unroll") for (int e = 0; e < NF; ++e) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
         fb[e][kk] = *reinterpret_cast<const bf16x8*>(lb_[S][kk] + (e >> 1) * 4096 + (e & 1) * 512);
-#ifdef AMDSEG_ABL_NO_B
-#undef DP_LOAD_B
-#undef DP_LOAD_B_U
-#define DP_LOAD_B(s)
-#define DP_LOAD_B_U(S)
-#endif
 #define DP_MFMA(ah) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int f = 0; f < 4; ++f) \
         _Pragma("unroll") for (int e = 0; e < NF; ++e) \
         acc[(ah) * 4 + f][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[e][kk], fa[f][kk], acc[(ah) * 4 + f][e], 0, 0, 0);
@@ -234,32 +191,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
     // of K tile kt-1, retired before that phase's barrier).  phase 2: rows 64-127; DMA: rows-0..63 image + this group's two B images of K tile
     // kt+2 into THIS stage (their last readers -- this group's phase 1 and the other group's phase 1, one slot later -- have retired their reads).
     // (All 6 pieces of phase 2 stay in its load half: issuing the B pieces among the MFMAs measured slower, profiles/r04_gemm_dma_placement.md.)
-#ifdef AMDSEG_ABL_NO_DMA   // timing probe (wrong results): no LDS-DMA issue inside the K loop -- what the compute waves would take if OTHER waves did the loading
-#define DP_LOOP_DMA(x)
-#else
 #define DP_LOOP_DMA(x) x
-#endif
-    // Which fragment reads have to be RETIRED before the barrier that ends a load half (round 4, second session).  A images are private to a row
-    // group and are refilled by that group two barriers after it read them -- in between lies the group's own MFMA half, which cannot issue
-    // before the data is in its registers.  The same holds for the B reads of group 0.  Group 1 reads a B image one barrier AFTER group 0 did,
-    // and group 0 issues the refill of B images 0 and 1 right behind the next barrier: only those reads need the explicit wait.  So the B reads
-    // go first and the wait in front of the first barrier is lgkmcnt(8) (everything but the 8 A reads issued last); the second load half
-    // waits for nothing (the compiler's own counted waits in front of the MFMAs order the data).  -DAMDSEG_ABL_STRICT_LGKM: the old form,
-    // lgkmcnt(0) in front of both barriers.
-#ifndef AMDSEG_ABL_LAZY_LGKM
+    // every fragment read is retired (lgkmcnt(0)) before the barrier that ends its load half: the refill order would allow lgkmcnt(8) in front of
+    // the first barrier and no wait in front of the second (only group 1's B reads need it), measured neutral on all eight shapes (round 4)
 #define DP_LGKM_P1() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define DP_LGKM_P2() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#else
-#define DP_LGKM_P1() asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory")
-#define DP_LGKM_P2() do { } while (0)
-#endif
 #define DP_KTILE(kt, S, LDA, LDB) { \
         LDB(S) __builtin_amdgcn_sched_barrier(0); LDA(S, 0) __builtin_amdgcn_sched_barrier(0); \
         if ((kt) >= DP_KT0 && (kt) + 1 < nk) { DP_LOOP_DMA(DP_DMA_A((S) ^ 1, 1, (kt) + 1)) } \
         else if (RPF && (kt) + 1 == nk) DP_RPF_ISSUE((S) ^ 1); \
         DP_LGKM_P1(); \
         if ((kt) >= DP_KT0 && (kt) + 1 < nk) DP_WAIT_TILE(); \
-        else if (PERSIST && pf_ && (kt) == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   /* landed at the tile's start; the stores stay in flight */ \
         else if (RPF && (kt) + 1 == nk) DP_RPF_WAIT();           /* everything but the epilogue operand's pieces */ \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         DP_MID(); \
@@ -275,7 +217,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         DP_MFMA(1) \
         DP_END(); }
     int kt = 0;
-#ifndef AMDSEG_ABL_NO_UNROLL2
     // the K loop unrolled by two: the stage is a compile-time constant in each copy, so every fragment address is (a lane term that does
     // not depend on the stage) + an immediate -- round 4: the rolled loop re-derived them per K tile, ~40 vector instructions in the load
     // halves (SQ counters, profiles/r04_gemm_dma_placement.md)
@@ -286,9 +227,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
         for (; kt + 1 < nk; kt += 2) { DP_KTILE(kt, 0, DP_LOAD_A, DP_LOAD_B) DP_KTILE(kt + 1, 1, DP_LOAD_A, DP_LOAD_B) }
         if (kt < nk) DP_KTILE(kt, 0, DP_LOAD_A, DP_LOAD_B)
     }
-#else
-    for (; kt < nk; ++kt) { const int s_ = kt & 1; DP_KTILE(kt, s_, DP_LOAD_A, DP_LOAD_B) }
-#endif
     if (wr == 0) __builtin_amdgcn_s_barrier();             // group 0 pays back the stagger barrier: every LDS read is retired now
     } else if (RPF) DP_RPF_ISSUE(nk & 1);                  // a skipped tile multiplies zeros by the same derivatives (the sign of a zero is a bit too) / adds the same residual
     if (RPF) {                                             // the operand image has landed and every wave sees it
@@ -307,35 +245,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) { acc[mf][nf][0] += bv[nf].x; acc[mf][nf][1] += bv[nf].y; acc[mf][nf][2] += bv[nf].z; acc[mf][nf][3] += bv[nf].w; }
     }
-    bool pf_next = false;
-    if (PERSIST) {
-        // the next tile's two stages (every LDS read of this tile was retired by the barriers that ended its K loop; the epilogue below does not
-        // touch LDS).  Issued behind this epilogue's bias loads and in front of its residual loads / stores: the compiler's counted waits for its
-        // own loads then cover older pieces too (conservative), and everything younger than the pieces is what the next tile leaves in flight.
-        const int tnx = tt + tstep;
-        if (tnx < nwg) {
-            int m0n, n0n;
-            DP_TILE_OF(tnx, m0n, n0n)
-            if (!DP_ZTILE(m0n)) {
-                const bf16_t* pAn = a.A + (size_t)(m0n + wr * 128) * a.lda;
-                const bf16_t* pBn = a.B + (size_t)(n0n + wr * 128) * a.ldb;
-                DP_DMA_A_P(pAn, 0, 0, 0) DP_DMA_A_P(pAn, 0, 1, 0) DP_DMA_B_P(pBn, 0, 0)
-                if (nk > 1) { DP_DMA_A_P(pAn, 1, 0, 1) DP_DMA_A_P(pAn, 1, 1, 1) DP_DMA_B_P(pBn, 1, 1) }
-                pf_next = true;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    pf_ = pf_next;
-#if AMDSEG_ABL_EPI == 2
-    if (NF == 4) {
-#pragma unroll
-        for (int mf = 0; mf < 8; ++mf)
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) asm volatile("" :: "v"(acc[mf][nf]));
-        continue;
-    }
-#endif
     if (NF == 4) {
         // ---- direct epilogue (256-wide tile): lane owns row m = mf*16 + i16 and the 8 consecutive columns ep*32 + g*8 .. +8 of its wave's 64.
         // BIAS_GELU writes the pre-activation and the activation of a chunk back to back (the stores of one overlap the GELU math of the next)
@@ -424,13 +333,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                             gelu_both4q(v, d, GELU_DQ_SCALE, GELU_DQ_OFF); gelu_both4q(v + 4, d + 4, GELU_DQ_SCALE, GELU_DQ_OFF);
                             q.x = gelu_dq_pack4_scaled(d); q.y = gelu_dq_pack4_scaled(d + 4);
                         }
-#if AMDSEG_ABL_EPI == 1
-                        asm volatile("" :: "v"(q.x), "v"(q.y));
-#else
                         // (plain stores: as NON-TEMPORAL 8-byte stores -- the tensor is read next by backward -- the launch average of the NT GEMMs
                         //  went 59.8 -> 63.5 us: partial lines that bypass L2's write combining)
                         *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(a.C2) + gm * a.ldc2 + col) = q;
-#endif
                     } else { gelu_act4(v, ACT); gelu_act4(v + 4, ACT); }
                 } else if (EPI == EPI_MUL_RES8) {
                     gelu_dq_mul4(v, r8[ep].x); gelu_dq_mul4(v + 4, r8[ep].y);
@@ -452,18 +357,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                     float rf[8];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { rf[2 * q] = __uint_as_float(rw[q] << 16); rf[2 * q + 1] = __uint_as_float(rw[q] & 0xffff0000u); }
-                    if (EPI == EPI_BIAS_DROP_RES) {
-                        // the lane's 8 consecutive columns ARE one 16-B chunk of the row kernels: the same (seed, chunk) hash decides them
-                        // (drop8_bits, common.h), the byte goes where ln_bwd reads it (chunk = row * N / 8 + column / 8)
-                        if (a.drop_thresh) {
-                            const uint64_t chunk = (uint64_t)gm * (uint64_t)(a.N >> 3) + (col >> 3);
-                            const uint32_t bits = drop8_bits(a.drop_seed, chunk, a.drop_thresh);
-                            if (a.keepbits) a.keepbits[chunk] = (unsigned char)bits;
-                            drop8_apply_bits(bits, a.drop_inv_keep, v);
-                        }
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] += rf[q];
-                    } else
                     if (EPI == EPI_ADD_RES) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += rf[q];
@@ -483,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        continue;
+        return;
     }
     constexpr bool STAGED = sizeof(OutT) == 2;
     char* stg = smem + w * 16384;
@@ -517,7 +410,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
             if (R16PF) {
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) rr[nf] = rpf[mf][nf];
-            } else if (E_RES) {     // (DROP_RES: 256-wide tile only; this path is never launched for it)
+            } else if (E_RES) {
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) rr[nf] = *reinterpret_cast<const uint2*>(a.R + gm * a.ldr + col0 + nf * 16 + g * 4);
             }
@@ -533,7 +426,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
                 } else if (E_RES) {
                     const float r0 = __uint_as_float(rr[nf].x << 16), r1 = __uint_as_float(rr[nf].x & 0xffff0000u);
                     const float r2 = __uint_as_float(rr[nf].y << 16), r3 = __uint_as_float(rr[nf].y & 0xffff0000u);
-                    if (EPI == EPI_ADD_RES || EPI == EPI_BIAS_DROP_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
+                    if (EPI == EPI_ADD_RES) { v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3; }
                     else if (EPI == EPI_MUL_RES) { v[0] *= r0; v[1] *= r1; v[2] *= r2; v[3] *= r3; }
                     else gelu_grad_mul4(v, r0, r1, r2, r3, ACT);
                 }
@@ -566,7 +459,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_dp_kernel(GemmNTArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
-    } while (PERSIST && (tt += tstep) < nwg);              // tiles of this workgroup
 }
 
 // one workgroup per CU for the persistent form
@@ -574,23 +466,6 @@ static int dp_num_cus() {
     static int n = 0;
     if (!n) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
     return n;
-}
-
-template <int EPIX, typename OutT>
-static int launch_nt_dp_persist(const GemmNTArgs& a_in, hipStream_t s) {
-    static bool attr_set = false;
-    constexpr int LDS = 8 * 16384;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dp_kernel<EPIX, OutT, 4, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    GemmNTArgs a = a_in;
-    a.tiles_m = a.M / DP_BM; a.tiles_n = a.N / 256;
-    const int nwg = a.tiles_m * a.tiles_n, grid = nwg < dp_num_cus() ? nwg : dp_num_cus();
-    AMDSEG_LAUNCH_PROF(AMDSEG_PROF_GEMM_NT, 2.0 * a.M * a.N * a.K, (gemm_nt_dp_kernel<EPIX, OutT, 4, true>), dim3(grid), dim3(512), LDS, s, a);
-    return amdseg_launch_status();
 }
 
 template <int EPIX, typename OutT, int NF>
@@ -610,28 +485,24 @@ static int launch_nt_dp_nf(const GemmNTArgs& a_in, hipStream_t s) {
     return amdseg_launch_status();
 }
 
-// CUs the grids of this process can count on (amdseg_set_cu_budget / AMDSEG_CU_BUDGET; 0 = all of them).  An overlapped RCCL all-reduce keeps one CU per
+// CUs the grids of a call can count on (amdseg_ctx_set_cu_budget; 0 = all of them).  An overlapped RCCL all-reduce keeps one CU per
 // channel for the whole of backward -- a deep-pipeline workgroup needs a CU's entire register file, so those CUs are lost to it -- and a grid of
 // exactly 256 tiles then runs TWO rounds: measured with tools/dbg/cu_hog.sh, 8 / 16 / 32 occupied CUs all cost the training step 10 % (NT launch
 // average 61 -> 72 us), 64 double the weight-gradient GEMM (216 tiles).  The tile-width choice below counts rounds against the budget.
-thread_local int g_amdseg_cu_budget = 0;        // per calling THREAD (one host thread drives one GPU's streams): two binders in one process do not see each other's budget
 int amdseg_num_cus() { return dp_num_cus(); }
-int amdseg_cu_budget() {
-    static int env = -1, cus = 0;
-    if (env < 0) { const char* e = getenv("AMDSEG_CU_BUDGET"); env = e ? atoi(e) : 0; cus = dp_num_cus(); }
-    const int b = g_amdseg_cu_budget > 0 ? g_amdseg_cu_budget : env;
+int amdseg_cu_budget() {                                    // the budget of the call's context (amdseg_ctx_set_cu_budget); none, 0 or >= the chip: every CU
+    const amdseg_ctx* c = amdseg_current_ctx();
+    const int b = c ? c->cu_budget : 0, cus = dp_num_cus();
     return b > 0 && b < cus ? b : cus;
 }
 
 // tile width: 256 whenever N allows it, 192 for the other multiples of 192.  Picking 192 for wave quantisation (N = 768: 256 tiles
 // instead of 192, N = 2304: 3 full rounds instead of 2.25) measured NO gain in the training step (QKV 67.1 vs 68.6 us, N = 768
 // K = 3072 78.3 vs 79.8, N = 768 K = 768 27.0 vs 25.0): the chip is clock/power limited under MFMA load, 192 busy CUs run as fast
-// as 256 at 0.75 of the work each.  AMDSEG_DP_BN=192 forces the narrow tile where both fit.
+// as 256 at 0.75 of the work each.
 template <int EPIX, typename OutT>
 int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
     const bool ok256 = (a_in.N % 256) == 0, ok192 = (a_in.N % 192) == 0;
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("AMDSEG_DP_BN"); force = e ? atoi(e) : 0; }
     // ... but ROUNDS count (round 3, M = 8192 = the 4 x 2048 launch shape of run_finetune.sh): N = 2304 is 288 tiles of 256 columns = 2 rounds with
     // the second one 1/8 full, and 384 tiles of 192 = 2 rounds of 3/4 the work each: 45.0 -> 41.0 us; N = 3072 with the dual-output GELU epilogue
     // 56.6 -> 52.5 (384 -> 512 tiles).  The residual-reading epilogues lose on the narrow tile's staged stores (GELU' 57.8 -> 59.2) and stay wide.
@@ -640,27 +511,18 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
     // interleaved repetitions on one box, profiles/r05_default_switches.md); at M = 8192 (128 narrow tiles: half a round either way) they stay wide.
     constexpr int EB = EPI_BASE(EPIX);
     bool narrow = false;
-    if (ok256 && ok192 && force == 0) {
+    if (ok256 && ok192) {
         const int t256 = (a_in.M / DP_BM) * (a_in.N / 256), t192 = (a_in.M / DP_BM) * (a_in.N / 192), C = amdseg_cu_budget();
         if (EB == EPI_NONE || EB == EPI_BIAS || EB == EPI_BIAS_GELU || EB == EPI_BIAS_GELU_DG)
             narrow = 0.78f * (float)((t192 + C - 1) / C) < (float)((t256 + C - 1) / C);
         else if (EB == EPI_ADD_RES)
             narrow = t256 < C && t192 <= C && t192 * 8 >= C * 7;
     }
-    constexpr bool direct_only = EB == EPI_BIAS_SPLIT || EB == EPI_GELU_BWD_SPLIT || EB == EPI_BIAS_GELU_SPLIT || EB == EPI_BIAS_DROP_RES ||
+    constexpr bool direct_only = EB == EPI_BIAS_SPLIT || EB == EPI_GELU_BWD_SPLIT || EB == EPI_BIAS_GELU_SPLIT ||
                                  EB == EPI_BIAS_GELU_DG8 || EB == EPI_MUL_RES8;    // epilogues of the 256-wide tile only
     if (direct_only && !ok256) return AMDSEG_ERR_SHAPE;
-    const bool use192 = !direct_only && ok192 && (!ok256 || force == 192 || narrow);
+    const bool use192 = !direct_only && ok192 && (!ok256 || narrow);
     if (use192) return launch_nt_dp_nf<EPIX, OutT, 3>(a_in, s);
-    // multi-round launches of the two GELU epilogues (bert-base: 768 tiles, three per CU): persistent, next tile's fill under this tile's epilogue
-    if constexpr ((EB == EPI_BIAS_GELU || EB == EPI_GELU_BWD || EB == EPI_BIAS_GELU_DG || EB == EPI_MUL_RES || EB == EPI_BIAS_GELU_DG8 || EB == EPI_MUL_RES8) && sizeof(OutT) == 2) {
-        static int persist = -1;
-        // measured NEUTRAL (round 4, profiles/r04_gemm_epilogue_split.md: stand-alone 99-102 vs 102-108 us (bias + GELU), 96-101 vs 98-101 (GELU'), the
-        // training step 12.86-12.89 ms either way): opt-in, AMDSEG_DP_PERSIST=1
-        if (persist < 0) { const char* e = getenv("AMDSEG_DP_PERSIST"); persist = e ? atoi(e) : 0; }
-        const int nwg = (a_in.M / DP_BM) * (a_in.N / 256);
-        if (persist && nwg > dp_num_cus() && a_in.K >= 128) return launch_nt_dp_persist<EPIX, OutT>(a_in, s);
-    }
     return launch_nt_dp_nf<EPIX, OutT, 4>(a_in, s);
 }
 
@@ -669,7 +531,7 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
 DP_INST(EPI_NONE, bf16_t) DP_INST(EPI_NONE, float) DP_INST(EPI_BIAS, bf16_t) DP_INST(EPI_BIAS, float) DP_INST(EPI_BIAS_GELU, bf16_t)
 DP_INST(EPI_ADD_RES, bf16_t) DP_INST(EPI_ADD_RES, float) DP_INST(EPI_GELU_BWD, bf16_t)
 DP_INST(EPI_BIAS_GELU_TANH, bf16_t) DP_INST(EPI_GELU_BWD_TANH, bf16_t) DP_INST(EPI_BIAS_SPLIT, bf16_t) DP_INST(EPI_GELU_BWD_SPLIT, bf16_t)
-DP_INST(EPI_BIAS_GELU_SPLIT, float) DP_INST(EPI_BIAS_DROP_RES, bf16_t) DP_INST(EPI_BIAS_GELU_DG, bf16_t) DP_INST(EPI_MUL_RES, bf16_t) DP_INST(EPI_BIAS_GELU_DG8, bf16_t) DP_INST(EPI_MUL_RES8, bf16_t) DP_INST(EPI_BIAS_GELU_DG8_TANH, bf16_t)
+DP_INST(EPI_BIAS_GELU_SPLIT, float) DP_INST(EPI_BIAS_GELU_DG, bf16_t) DP_INST(EPI_MUL_RES, bf16_t) DP_INST(EPI_BIAS_GELU_DG8, bf16_t) DP_INST(EPI_MUL_RES8, bf16_t) DP_INST(EPI_BIAS_GELU_DG8_TANH, bf16_t)
 
 
 // ==================================================================================================== gemm_tn, deep pipeline
@@ -728,14 +590,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
     // tile order inside a problem: an XCD walks a contiguous run of ~tiles / 8 tiles whose workgroups move through the tokens together, so an operand
     // panel that several of them share is fetched once per XCD.  With K' fastest, a problem with few N tiles and many K' tiles (dW of the FFN
     // down-projection: 3 x 24) has every XCD read ALL K' panels of B (= h, 100 MB) once per N tile it touches: 290 MB for that problem; with N fastest
-    // an XCD's 27 tiles are a 3 x 9 block: all of A (25 MB) + 9 of 24 B panels.  -DAMDSEG_TN_KFAST: K' fastest everywhere (the order until round 4).
-#ifndef AMDSEG_TN_KFAST
+    // an XCD's 27 tiles are a 3 x 9 block: all of A (25 MB) + 9 of 24 B panels.
     const int tiles_n_ = P.N / 256;
     const bool nfast = tiles_n_ < P.tiles_k;
     const int tn = nfast ? lt % tiles_n_ : lt / P.tiles_k, tk = nfast ? lt / tiles_n_ : lt % P.tiles_k;
-#else
-    const int tn = lt / P.tiles_k, tk = lt % P.tiles_k;
-#endif
     const int n0 = tn * 256, k0 = tk * 128;
 #define TN_TILE_A(s, i) (smem + (s) * TN_STG + (i) * 8192)
 #define TN_TILE_B(s, j) (smem + (s) * TN_STG + 32768 + (j) * 8192)
@@ -811,26 +669,15 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dp_kernel(GemmTNArgs a) {
             laB[c4] = o + 32768 + wc * 8192;
         }
     }
-    tn_i32x2 fa[8][2], fax[2][2], fb0[4][2], fb1[4][2];
-#ifndef AMDSEG_TN_ASM_GATHER
+    tn_i32x2 fa[8][2], fb0[4][2], fb1[4][2];
 // the gathers as builtins (this kernel's LDS-DMA is inline asm, so the compiler knows of no vector memory operation it would have to wait for in
 // front of them): it tracks their lgkmcnt itself and may place a fragment's two halves in the adjacent registers the MFMA wants (the asm form pays
-// two v_mov + s_nop for six of the eight A fragments per K tile; 245 -> 220 VGPRs, stand-alone 266-272 -> 261-264 us, in the step 211.8 -> 209.0;
-// -DAMDSEG_TN_ASM_GATHER keeps the asm form)
+// two v_mov + s_nop for six of the eight A fragments per K tile; 245 -> 220 VGPRs, stand-alone 266-272 -> 261-264 us, in the step 211.8 -> 209.0)
 typedef short tn_v4s __attribute__((ext_vector_type(4)));
 #define TN_RD(dst, addr, off) dst = __builtin_bit_cast(tn_i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_v4s*)(uintptr_t)((addr) + (off))))
-#else
-#define TN_RD(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#endif
-// -DAMDSEG_TN_A67_DB (probe, round 4): A fragments 6 and 7 double-buffered (fax) so that the gathers of the NEXT tile's fragments 6 / 7 are issued early
-// in the body instead of behind the body's last MFMAs, and the lgkmcnt(0) in front of the K tile's barrier (the LDS refill order needs it) no longer
-// sits out the latency of gathers issued a few instructions earlier (the SQ counters put 35 % of a wave's cycles at that barrier and its waits,
-// profiles/r04b_tn_counters.md).  Measured NEUTRAL: stand-alone 263.7 / 260.3 / 275.5 vs 273.0 / 272.3 / 264.6 us, training step 13.078 / 13.092 / 13.059 vs
-// 13.046 / 13.049 / 13.058 ms -- the barrier waits for the slowest of eight waves, not for this wave's last gathers.  AC = which set is current.
-#if !defined(AMDSEG_TN_A67_DB) || defined(AMDSEG_TN_ASM_GATHER)
-#define AMDSEG_TN_A67_SINGLE
-#endif
-#define TN_FA(nf, AC) ((nf) < 6 ? fa[nf] : ((AC) ? fax[(nf) - 6] : fa[nf]))
+// (a probe with A fragments 6 and 7 double-buffered -- their gathers issued early in the body instead of behind its last MFMAs -- measured neutral in round 4,
+//  profiles/r04b_tn_counters.md: the K tile's barrier waits for the slowest of eight waves, not for this wave's last gathers; removed in round 6)
+#define TN_FA(nf, AC) (fa[nf])
 #define TN_LDA_TO(dst, nf) do { TN_RD((dst)[0], aA[(nf) & 3], ((nf) >> 2) * 8192); TN_RD((dst)[1], aA[(nf) & 3], ((nf) >> 2) * 8192 + 2048); } while (0)
 #define TN_LDA(nf) TN_LDA_TO(fa[nf], nf)
 #define TN_LDB(e, FB) do { TN_RD(FB[e][0], aB[e], 0); TN_RD(FB[e][1], aB[e], 2048); } while (0)
@@ -843,14 +690,7 @@ typedef short tn_v4s __attribute__((ext_vector_type(4)));
 #define TN_CS(nf, AC) do { const tn_i32x2 c0_ = TN_FA(nf, AC)[0], c1_ = TN_FA(nf, AC)[1]; const int e0_ = c0_.x, e1_ = c0_.y, e2_ = c1_.x, e3_ = c1_.y; \
                        accb[nf] = TN_DOT2(e0_, accb[nf]); accb[nf] = TN_DOT2(e1_, accb[nf]); \
                        accb[nf] = TN_DOT2(e2_, accb[nf]); accb[nf] = TN_DOT2(e3_, accb[nf]); } while (0)
-#ifndef AMDSEG_TN_ASM_GATHER
 #define TN_WAIT_FRAGS(FB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#else
-#define TN_WAIT_FRAGS(FB) asm volatile("s_waitcnt lgkmcnt(0)" \
-        : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), \
-          "+v"(fa[4][0]), "+v"(fa[4][1]), "+v"(fa[5][0]), "+v"(fa[5][1]), "+v"(fa[6][0]), "+v"(fa[6][1]), "+v"(fa[7][0]), "+v"(fa[7][1]), \
-          "+v"(FB[0][0]), "+v"(FB[0][1]), "+v"(FB[1][0]), "+v"(FB[1][1]), "+v"(FB[2][0]), "+v"(FB[2][1]), "+v"(FB[3][0]), "+v"(FB[3][1]) :: "memory")
-#endif
     uint32_t aA[4], aB[4];
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) { aA[c4] = laA[c4]; aB[c4] = laB[c4]; }
@@ -864,19 +704,6 @@ typedef short tn_v4s __attribute__((ext_vector_type(4)));
     // the bias-gradient column sums run in ~1 of tiles_k K tiles: as ONE block in front of the K tile's MFMAs (all eight A fragments of tile kt are
     // in registers there) behind one branch -- as eight `if (cs_now)` inside the MFMA stream they were eight taken branches per K tile in the
     // common case; a second copy of the body for the tiles that sum spilled registers (256 VGPRs + 604 B of scratch)
-#ifndef AMDSEG_TN_A67_SINGLE
-#define TN_BODY_CORE(FC, FN, AC) do { \
-        _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) { \
-            TN_MF(nf, 0, FC, AC); TN_SB(); TN_MF(nf, 1, FC, AC); TN_SB(); TN_LDB(nf, FN); TN_SB(); TN_MF(nf, 2, FC, AC); TN_SB(); TN_MF(nf, 3, FC, AC); TN_SB(); \
-            TN_LDA(nf); TN_SB(); \
-            if (nf == 0) { TN_LDA_TO(TN_FA(6, !(AC)), 6); TN_SB(); } \
-            if (nf == 1) { TN_LDA_TO(TN_FA(7, !(AC)), 7); TN_SB(); } \
-            if (nf >= 1) { TN_DMA_PIECE(nf - 1); TN_SB(); } } \
-        _Pragma("unroll") for (int nf = 4; nf < 8; ++nf) { \
-            TN_MF(nf, 0, FC, AC); TN_MF(nf, 1, FC, AC); TN_MF(nf, 2, FC, AC); TN_MF(nf, 3, FC, AC); TN_SB(); \
-            if (nf < 6) { TN_LDA(nf); TN_SB(); } \
-            if (nf <= 6) { TN_DMA_PIECE(nf - 1); TN_SB(); } } } while (0)
-#else
 #define TN_BODY_CORE(FC, FN, AC) do { \
         _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) { \
             TN_MF(nf, 0, FC, 0); TN_SB(); TN_MF(nf, 1, FC, 0); TN_SB(); TN_LDB(nf, FN); TN_SB(); TN_MF(nf, 2, FC, 0); TN_SB(); TN_MF(nf, 3, FC, 0); TN_SB(); \
@@ -886,12 +713,7 @@ typedef short tn_v4s __attribute__((ext_vector_type(4)));
             TN_MF(nf, 0, FC, 0); TN_MF(nf, 1, FC, 0); TN_MF(nf, 2, FC, 0); TN_MF(nf, 3, FC, 0); TN_SB(); \
             TN_LDA(nf); TN_SB(); \
             if (nf <= 6) { TN_DMA_PIECE(nf - 1); TN_SB(); } } } while (0)
-#endif
-#ifndef AMDSEG_TN_A67_SINGLE
-#define TN_ACSEL(AC) (AC)
-#else
 #define TN_ACSEL(AC) 0
-#endif
 #define TN_BODY(FC, FN, AC) do { \
         TN_WAIT_FRAGS(FC); \
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          /* every K tile issues 6 pieces: tile kt+1 has landed */ \

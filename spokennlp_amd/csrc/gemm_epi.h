@@ -9,22 +9,21 @@ enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD_RES = 3, EPI_GELU_
        EPI_BIAS_GELU_TANH = 5, EPI_GELU_BWD_TANH = 6,       // kernel template values only: the two GELU epilogues with gelu_new
        EPI_BIAS_SPLIT = 7,                                  // C = bf16 hi of (A B^T + bias), C2 = bf16 lo = bf16(x - hi): the result as a split image
                                                             // ("parity" precision: the consumer is another split-bf16 product), 256-wide dp kernel only
-       EPI_GELU_BWD_SPLIT = 8,
-       EPI_BIAS_GELU_SPLIT = 9,
-       EPI_BIAS_DROP_RES = 10,
-       EPI_BIAS_GELU_DG = 11,                               // AMDSEG_EPI_BIAS_GELU | AMDSEG_EPI_KEEP_DERIV: C = gelu(A B^T + bias), C2 = gelu'(A B^T + bias) (deep-pipeline kernel only)
-       EPI_MUL_RES = 12,
-       EPI_BIAS_GELU_DG8 = 13, EPI_MUL_RES8 = 14,
-       EPI_BIAS_GELU_DG8_TANH = 15 };        // the same pair with the derivative as ONE BYTE per element (AMDSEG_EPI_DERIV_U8), 256-wide tile only                                  // AMDSEG_EPI_GELU_BWD | AMDSEG_EPI_KEEP_DERIV: C = (A B^T) * R, R = the derivative kept by the forward                            // C = R + dropout(A B^T + bias), keep decisions -> keepbits (1 byte per 8 columns): the dense +
-                                                            // dropout + residual of BertSelfOutput / BertOutput in the GEMM's epilogue (256-wide dp kernel only)                           // C (fp32) = A B^T + bias (the pre-activation backward reads); C2 = bf16 image [hi | hi | lo] of gelu_erf(that)                            // x = (A B^T) * gelu_erf'(R), R fp32: hi -> C and C + dup_off columns, lo -> C2 (the [hi | hi | lo]
+       EPI_GELU_BWD_SPLIT = 8,                              // x = (A B^T) * gelu_erf'(R), R fp32: hi -> C and C + dup_off columns, lo -> C2 (the [hi | hi | lo]
                                                             // image the next split GEMM and the weight gradient read); 256-wide dp kernel only
+       EPI_BIAS_GELU_SPLIT = 9,                             // C (fp32) = A B^T + bias (the pre-activation backward reads); C2 = bf16 image [hi | hi | lo] of gelu_erf(that)
+       // (10 was the fused bias + dropout + residual epilogue of rounds 4-5: measured slower, profiles/r04_fused_drop_res.md, removed in round 6)
+       EPI_BIAS_GELU_DG = 11,                               // AMDSEG_EPI_BIAS_GELU | AMDSEG_EPI_KEEP_DERIV: C = gelu(A B^T + bias), C2 = gelu'(A B^T + bias) (deep-pipeline kernel only)
+       EPI_MUL_RES = 12,                                    // AMDSEG_EPI_GELU_BWD | AMDSEG_EPI_KEEP_DERIV: C = (A B^T) * R, R = the derivative kept by the forward
+       EPI_BIAS_GELU_DG8 = 13, EPI_MUL_RES8 = 14,           // the same pair with the derivative as ONE BYTE per element (AMDSEG_EPI_DERIV_U8), 256-wide tile only
+       EPI_BIAS_GELU_DG8_TANH = 15 };
 // the kernels are instantiated on the extended value EPIX; EPI = what the epilogue does, ACT = which GELU (a compile-time constant:
 // a run-time flag became one scalar branch PER ELEMENT in the epilogue)
 #define EPI_BASE(X) ((X) == EPI_BIAS_GELU_TANH ? EPI_BIAS_GELU : (X) == EPI_GELU_BWD_TANH ? EPI_GELU_BWD : (X) == EPI_BIAS_GELU_DG8_TANH ? EPI_BIAS_GELU_DG8 : (X))
 #define EPI_ACT(X) (((X) == EPI_BIAS_GELU_TANH || (X) == EPI_GELU_BWD_TANH || (X) == EPI_BIAS_GELU_DG8_TANH) ? 1 : 0)
 
 struct GemmNTArgs {
-    const bf16_t* A; const bf16_t* B; void* C; const float* bias; const bf16_t* R; bf16_t* C2; unsigned long long* dbg;
+    const bf16_t* A; const bf16_t* B; void* C; const float* bias; const bf16_t* R; bf16_t* C2;
     int lda, ldb, ldc, ldr, ldc2;
     int M, N, K;
     int tiles_m, tiles_n;
@@ -32,18 +31,7 @@ struct GemmNTArgs {
     // optional (deep-pipeline kernel only): rows >= zkend[row / zL] of A are known to be exact zeros (activation gradients of trailing
     // padding) unless *zguard != 0 -- a 256-row tile made of such rows skips its K loop and runs the epilogue on zero accumulators
     const int* zkend; const int* zguard; int zL;
-    // EPI_BIAS_DROP_RES: 16-bit keep threshold / scale of drop8_bits (common.h; 0 = no dropout), the hash seed of the site, and the
-    // [M * N / 8] byte buffer the keep decisions go to (may be NULL)
-    uint32_t drop_thresh; float drop_inv_keep; unsigned long long drop_seed; unsigned char* keepbits;
 };
-// 16-bit threshold of drop8_apply / drop8_bits (common.h); p >= 1 drops everything (inv_keep 0 instead of inf so that 0 * inv_keep stays 0)
-static inline void amdseg_drop_params(float p, uint32_t& thresh, float& inv_keep) {
-    if (p <= 0.f) { thresh = 0; inv_keep = 1.f; return; }
-    double t = (double)p * 65536.0 + 0.5;
-    thresh = t >= 65536.0 ? 65536u : (uint32_t)t;
-    if (thresh == 0) thresh = 1;
-    inv_keep = thresh >= 65536u ? 0.f : (float)(65536.0 / (65536.0 - (double)thresh));
-}
 
 // bijective XCD-aware remap: hardware places workgroup b on XCD b % 8; give each XCD a contiguous tile range
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -13,7 +13,6 @@
 // L2 / MALL), and a thread handles two float4 quads per trip (8 x 16-B loads in flight).  -DAMDSEG_ADAMW_PLAIN: the plain form.
 typedef float aw_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned aw_u2 __attribute__((ext_vector_type(2)));
-#ifndef AMDSEG_ADAMW_PLAIN
 __device__ __forceinline__ float4 aw_ld_nt(const float* p, size_t i) {
     const aw_f4 v = __builtin_nontemporal_load(reinterpret_cast<const aw_f4*>(p) + i);
     return make_float4(v.x, v.y, v.z, v.w);
@@ -27,11 +26,6 @@ __device__ __forceinline__ void aw_st2_nt(bf16_t* p, size_t i, const uint2& v) {
 #define AW_LD(p, i) aw_ld_nt(p, i)
 #define AW_ST(p, i, v) aw_st_nt(p, i, v)
 #define AW_ST2(p, i, v) aw_st2_nt(p, i, v)
-#else
-#define AW_LD(p, i) (reinterpret_cast<const float4*>(p)[i])
-#define AW_ST(p, i, v) (reinterpret_cast<float4*>(p)[i] = (v))
-#define AW_ST2(p, i, v) (reinterpret_cast<uint2*>(p)[i] = (v))
-#endif
 __device__ __forceinline__ void adamw_quad(float4& pp, const float4& gg, float4& mm, float4& vv, float gs, float decay, float beta1, float beta2,
                                            float eps, float step_size, float rsqrt_bc2) {
     float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x, gg.y, gg.z, gg.w}, Mm[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};

@@ -227,135 +227,9 @@ __device__ __forceinline__ int pa2_visible_chunks(const PAttnArgs& a, int b, int
     return ke > 0 ? min(ns, (ke + 63) >> 6) : ns;
 }
 
-__device__ __forceinline__ void pa_stage(float (*dst)[PA_LD], const float* src, int ld) {       // 64 rows x 64 floats, 256 threads
-    const int t = threadIdx.x, r = t >> 2, c0 = (t & 3) * 16;
-    const float* p = src + (size_t)r * ld + c0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(p + 4 * i);
-        dst[r][c0 + 4 * i] = v.x; dst[r][c0 + 4 * i + 1] = v.y; dst[r][c0 + 4 * i + 2] = v.z; dst[r][c0 + 4 * i + 3] = v.w;
-    }
-}
-// sum_d row_reg[d] * chunk[lane][d]   (row_reg: lane d holds element d of the wave's own row)
-__device__ __forceinline__ float pa_dot(float row_reg, const float (*chunk)[PA_LD], int l) {
-    float acc = 0.f;
-#pragma unroll
-    for (int d = 0; d < 64; ++d)
-        acc = fmaf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(row_reg), d)), chunk[l][d], acc);
-    return acc;
-}
-// sum_j w[j] * chunk[j][lane]   (w: lane j holds the weight of chunk row j)
-__device__ __forceinline__ float pa_wsum(float w, const float (*chunk)[PA_LD], int l, float acc) {
-#pragma unroll
-    for (int j = 0; j < 64; ++j)
-        acc = fmaf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), j)), chunk[j][l], acc);
-    return acc;
-}
 __device__ __forceinline__ float pa_keep(const PAttnArgs& a, size_t row_bhq, int key) {
     if (a.thresh == 0) return 1.0f;
     return drop_keep(a.seed, row_bhq * (size_t)a.L + key, a.thresh) ? a.inv_keep : 0.0f;
-}
-
-template <int NS>
-__global__ __launch_bounds__(256) void pattn_fwd_kernel(PAttnArgs a) {
-    __shared__ float Cs[64][PA_LD];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
-    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
-    const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
-    const float qreg = base[(size_t)q * H3 + l];
-    const size_t row = ((size_t)b * a.heads + h) * a.L + q;
-    float s[NS];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int si = 0; si < NS; ++si) {
-        s[si] = -INFINITY;
-        if (si < ns) {
-            __syncthreads();
-            pa_stage(Cs, base + (size_t)si * 64 * H3 + H, H3);
-            __syncthreads();
-            s[si] = pa_dot(qreg, Cs, l) * a.scale + a.mask_bias[(size_t)b * a.L + si * 64 + l];
-            mx = fmaxf(mx, s[si]);
-        }
-    }
-    mx = wave_max(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int si = 0; si < NS; ++si) { s[si] = si < ns ? expf(s[si] - mx) : 0.f; sum += s[si]; }
-    sum = wave_sum(sum);
-    const float inv = 1.0f / sum;
-    float o = 0.f;
-#pragma unroll
-    for (int si = 0; si < NS; ++si) {
-        if (si < ns) {
-            __syncthreads();
-            pa_stage(Cs, base + (size_t)si * 64 * H3 + 2 * H, H3);
-            __syncthreads();
-            o = pa_wsum(s[si] * inv * pa_keep(a, row, si * 64 + l), Cs, l, o);
-        }
-    }
-    a.ctx[((size_t)b * a.L + q) * H + h * 64 + l] = o;
-    if (a.lse && l == 0) a.lse[row] = mx + logf(sum);
-}
-
-// dQ (and delta = dO . O): one pass over the key chunks with K and V chunks both resident
-template <int NS>
-__global__ __launch_bounds__(256) void pattn_bwd_dq_kernel(PAttnArgs a) {
-    __shared__ float Ks[64][PA_LD];
-    __shared__ float Vs[64][PA_LD];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
-    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
-    const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
-    const size_t tok = (size_t)b * a.L + q, row = ((size_t)b * a.heads + h) * a.L + q;
-    const float qreg = base[(size_t)q * H3 + l];
-    const float doreg = a.dctx[tok * H + h * 64 + l];
-    const float delta = wave_sum(doreg * a.ctx[tok * H + h * 64 + l]);
-    const float lse = a.lse[row];
-    if (l == 0) a.delta[row] = delta;
-    float dq = 0.f;
-    for (int si = 0; si < ns; ++si) {
-        __syncthreads();
-        pa_stage(Ks, base + (size_t)si * 64 * H3 + H, H3);
-        pa_stage(Vs, base + (size_t)si * 64 * H3 + 2 * H, H3);
-        __syncthreads();
-        const float sc = pa_dot(qreg, Ks, l) * a.scale + a.mask_bias[(size_t)b * a.L + si * 64 + l];
-        const float p = expf(sc - lse);
-        const float dpd = pa_dot(doreg, Vs, l);
-        const float ds = p * (dpd * pa_keep(a, row, si * 64 + l) - delta);
-        dq = pa_wsum(ds, Ks, l, dq);
-    }
-    a.dqkv[tok * H3 + h * 64 + l] = dq * a.scale;
-}
-
-// dK, dV: workgroup = 4 consecutive keys, streams the query chunks (Q rows and dO rows)
-__global__ __launch_bounds__(256) void pattn_bwd_dkv_kernel(PAttnArgs a) {
-    __shared__ float Qs[64][PA_LD];
-    __shared__ float Ds[64][PA_LD];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
-    const int H = a.heads * 64, H3 = 3 * H, ns = a.L / 64;
-    const float* base = a.qkv + (size_t)b * a.L * H3 + h * 64;
-    const size_t tok = (size_t)b * a.L + j, bh = (size_t)b * a.heads + h;
-    const float kreg = base[(size_t)j * H3 + H + l], vreg = base[(size_t)j * H3 + 2 * H + l];
-    const float mb = a.mask_bias[(size_t)b * a.L + j];
-    float dk = 0.f, dv = 0.f;
-    for (int ci = 0; ci < ns; ++ci) {
-        __syncthreads();
-        pa_stage(Qs, base + (size_t)ci * 64 * H3, H3);
-        pa_stage(Ds, a.dctx + ((size_t)b * a.L + ci * 64) * H + h * 64, H);
-        __syncthreads();
-        const size_t rowi = bh * a.L + ci * 64 + l;                  // query i = ci * 64 + lane
-        const float sc = pa_dot(kreg, Qs, l) * a.scale + mb;
-        const float p = expf(sc - a.lse[rowi]);
-        const float keep = pa_keep(a, rowi, j);
-        const float dpd = pa_dot(vreg, Ds, l);
-        const float ds = p * (dpd * keep - a.delta[rowi]);
-        dv = pa_wsum(p * keep, Ds, l, dv);
-        dk = pa_wsum(ds, Qs, l, dk);
-    }
-    a.dqkv[tok * H3 + H + h * 64 + l] = dk * a.scale;
-    a.dqkv[tok * H3 + 2 * H + h * 64 + l] = dv;
 }
 
 // ------------------------------------------------------------------------------------------------ fp32 attention on the fp32 MFMA
@@ -367,8 +241,7 @@ __global__ __launch_bounds__(256) void pattn_bwd_dkv_kernel(PAttnArgs a) {
 // are lane-local plus two xor-shuffles, and the probabilities feed the next product straight from the accumulator registers: the
 // contraction step r of O^T += V^T P^T takes, in lane group g, exactly key 4g + r -- register r of the S^T tile.
 // Operand maps (cdna_hip_programming.md): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D[i = 4 (l >> 4) + r][j = l & 15].
-// Measured at 32 x 12 x 512: forward 1208 -> see profiles/r02_parity_v1, the vector-ALU kernels stay as the reference implementation
-// (AMDSEG_PATTN_VALU=1).
+// (the vector-ALU kernels these replaced -- profiles/r02_parity_v1 -- were removed from the product in round 6.)
 #define PA2_LD 68
 __device__ __forceinline__ void pa2_stage(float (*dst)[PA2_LD], const float* src, int ld) {      // 64 rows x 64 floats, 256 threads
     const int t = threadIdx.x, r = t >> 2, c0 = (t & 3) * 16;
@@ -615,12 +488,6 @@ __global__ __launch_bounds__(256) void pattn2_bwd_dkv_kernel(PAttnArgs a) {
     }
 }
 
-static bool pattn_use_valu() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("AMDSEG_PATTN_VALU"); v = e ? atoi(e) : 0; }
-    return v != 0;
-}
-
 static int pattn_fill(PAttnArgs& a, int B, int L, int heads, float scale, float p, uint64_t seed) {
     if (B <= 0 || L <= 0 || heads <= 0 || (L % 64) || L > 4096) return AMDSEG_ERR_SHAPE;
     if (p < 0.f || p >= 1.f) return AMDSEG_ERR_ARG;
@@ -639,16 +506,7 @@ int amdseg_pattn_fwd_impl(const float* qkv, const float* mask_bias, float* ctx, 
     if (rc) return rc;
     a.qkv = qkv; a.mask_bias = mask_bias; a.ctx = ctx; a.lse = lse;
     a.kend = kend; a.seq_order = kend ? seq_order : nullptr;
-    if (!pattn_use_valu()) {
-        hipLaunchKernelGGL(pattn2_fwd_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
-        return amdseg_launch_status();
-    }
-    const dim3 grid(L / 4, heads, B);
-    const int ns = L / 64;
-    if (ns <= 2) hipLaunchKernelGGL(pattn_fwd_kernel<2>, grid, dim3(256), 0, s, a);
-    else if (ns <= 8) hipLaunchKernelGGL(pattn_fwd_kernel<8>, grid, dim3(256), 0, s, a);
-    else if (ns <= 16) hipLaunchKernelGGL(pattn_fwd_kernel<16>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(pattn_fwd_kernel<64>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pattn2_fwd_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }
 
@@ -661,13 +519,7 @@ int amdseg_pattn_bwd_impl(const float* qkv, const float* mask_bias, const float*
     if (rc) return rc;
     a.qkv = qkv; a.mask_bias = mask_bias; a.ctx = (float*)ctx; a.lse = (float*)lse; a.dctx = dctx; a.delta = delta; a.dqkv = dqkv;
     a.kend = kend; a.seq_order = kend ? seq_order : nullptr; a.qguard = kend ? qguard : nullptr;
-    if (!pattn_use_valu()) {
-        hipLaunchKernelGGL(pattn2_bwd_dq_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(pattn2_bwd_dkv_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
-        return amdseg_launch_status();
-    }
-    const dim3 grid(L / 4, heads, B);
-    hipLaunchKernelGGL(pattn_bwd_dq_kernel<1>, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(pattn_bwd_dkv_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pattn2_bwd_dq_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pattn2_bwd_dkv_kernel, dim3(L / 64, heads, B), dim3(256), 0, s, a);
     return amdseg_launch_status();
 }

@@ -186,23 +186,23 @@ class BertEncoderEngine:
             _HOOKED.append(register_optimizer_step_post_hook(_optimizer_stepped))
         self._ct_table = None
         import os as _os
-        self.skip_padded_chunks = _os.environ.get("AMDSEG_ATTN_NOSKIP", "0") != "1"
-        # backward: rows of trailing padding have exact-zero gradients; GEMM tiles made of them are dropped after a run-time check of the
-        # incoming gradient (amdseg_bert_cfg.pad_guard).  Every encoder family (the argument per mixer: DESIGN.md section 8); AMDSEG_PAD_ROWS_DENSE=1 = off
-        self.skip_padded_rows_bwd = self.skip_padded_chunks and _os.environ.get("AMDSEG_PAD_ROWS_DENSE", "0") != "1"
+        # the explicit library context of this engine (include/amdseg.h amdseg_ctx): the CU budget of backward's tile rules, the launch timer
+        self.ctx = L.Ctx()
+        # Engine options that are ATTRIBUTES, not environment switches (a test or a tool sets them on the engine before the first forward of a shape):
+        # the trailing-padding chunks of full attention are not visited (False: every chunk, bit-identical results) ...
+        self.skip_padded_chunks = True
+        # ... and in backward the GEMM tiles made of rows of trailing padding (exact-zero gradients) are dropped after a run-time check of the
+        # incoming gradient (amdseg_bert_cfg.pad_guard).  Every encoder family (the argument per mixer: DESIGN.md section 8)
+        self.skip_padded_rows_bwd = True
         self._pad_guard = None
         self.eval_weight_check = _os.environ.get("AMDSEG_EVAL_WEIGHT_CHECK", "1") != "0"
         self._ck_state = None
         # attention-probability dropout decided once per layer (amdseg_attn_keepmask, acts.keep) instead of hashed per element in three kernels;
         # full softmax attention only (the band / list / pooling engines switch it off); AMDSEG_ATTN_HASH=1 keeps the hash path
         self.attn_keepmask = _os.environ.get("AMDSEG_ATTN_HASH", "0") != "1"
-        # attention backward as ONE kernel (csrc/attention_bwd_merged.hip: dQ, dK, dV from one evaluation of P and dS) -- built in round 5, correct,
-        # bit-reproducible, 35 % fewer instructions than the two-kernel form and SLOWER (191 vs 120 us per layer in the step: one fat workgroup per CU
-        # exposes its prologue / epilogue and runs at 48 % issue utilisation against 80 %, profiles/r05_attn_bwd_merged.md): opt-in, AMDSEG_ATTN_BWD_MERGED=1
-        self.attn_bwd_merged = _os.environ.get("AMDSEG_ATTN_BWD_MERGED", "0") == "1"
         # hidden-state dropout: the forward's add + LayerNorm kernels keep their decisions (1 byte per 8 elements, acts.drop1 / drop2) and the
-        # LayerNorm backward reads them instead of re-hashing (every encoder family: the row kernels are shared); AMDSEG_HIDDEN_KEEPBITS=0 = hash twice
-        self.hidden_keepbits = _os.environ.get("AMDSEG_HIDDEN_KEEPBITS", "1") != "0"
+        # LayerNorm backward reads them instead of re-hashing (every encoder family: the row kernels are shared); False = hash twice
+        self.hidden_keepbits = True
         # bit-reproducible training steps: the word (and explicit position) embedding gradients are summed over a stable sort of the ids
         # (amdseg_scatter_rows_sorted) instead of scattered with fp32 atomics -- the only order-dependent sums of a BERT / Longformer step (the loss
         # heads accumulate in fixed point, every column sum goes through partials added in a fixed order).  config.amdseg_deterministic or
@@ -575,10 +575,9 @@ class BertEncoderEngine:
                          for _ in range(nsave)],
                  emb_z=e(M, self.E), emb_mean=e(M, dt=torch.float32), emb_rstd=e(M, dt=torch.float32),
                  mask_bias=e(B, Lseq, dt=torch.float32), gen=0, busy=False, stamp=0)
-        # "parity" precision: attention as split-bf16 products (csrc/attention_split.hip) needs the split image of q|k|v per layer;
-        # AMDSEG_PATTN_F32=1 keeps the fp32-MFMA attention of csrc/parity.hip
-        import os as _os2
-        split_attn = parity and (self.parity_needs_split_attn or _os2.environ.get("AMDSEG_PATTN_F32", "0") != "1")
+        # "parity" precision: attention as split-bf16 products (csrc/attention_split.hip) needs the split image of q|k|v per layer
+        # (engine.parity_split_attn = False keeps the fp32-MFMA attention of csrc/parity.hip where the family allows it)
+        split_attn = parity and (self.parity_needs_split_attn or getattr(self, "parity_split_attn", True))
         if split_attn:
             for la in A["layers"]:
                 la["qkv_s"] = e(M, 9 * H, dt=torch.bfloat16)
@@ -612,15 +611,6 @@ class BertEncoderEngine:
             A["ws_sets"] = [ws_set(), ws_set()]
             wkeys = ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx", "dqkv", "delta", "partials") + \
                 (("d_out_s", "du_s", "d_ao_s", "dqkv_s") if parity else ()) + (("dctx_s",) if split_attn else ())
-            p_attn = float(self.cfg.attention_probs_dropout_prob)
-            full_attn = not getattr(self, "windows", None) and getattr(self, "attention_type", "original_full") == "original_full"
-            if (self.attn_bwd_merged and not fp32 and self.nproj == 3 and full_attn and Lseq % 256 == 0 and (p_attn == 0 or self.attn_keepmask)):
-                # ONE scratch for both sets (only the main stream's attention backward touches it); zeroed once: its tail holds the kernel's sync words
-                nbytes = L.load().amdseg_attn_bwd_merged_scratch_bytes(B, Lseq, self.heads)
-                A["dq_part"] = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
-                for wset in A["ws_sets"]:
-                    wset["dq_part"] = A["dq_part"]
-                wkeys = wkeys + ("dq_part",)
             A["ws_structs"] = [L.LayerWs(**{k: w[k].data_ptr() for k in wkeys}) for w in A["ws_sets"]]
             A["ws"] = dict(A["ws_sets"][0], dy=[e(M, H), e(M, H)])
             A["ws_struct"] = A["ws_structs"][0]
@@ -644,8 +634,7 @@ class BertEncoderEngine:
                 ptrs["drop1"] = la["drop1"].data_ptr(); ptrs["drop2"] = la["drop2"].data_ptr()
             if not train and not fp32:
                 ptrs["u"] = None                  # inference: the FFN GEMM skips the pre-activation output
-            if (not train and parity and M % 256 == 0 and self.I % 256 == 0 and getattr(self.cfg, "hidden_act", "gelu") == "gelu"
-                    and not (int(__import__("os").environ.get("AMDSEG_PARITY_UNFUSED", "0")) & 4)):
+            if not train and parity and M % 256 == 0 and self.I % 256 == 0 and getattr(self.cfg, "hidden_act", "gelu") == "gelu":
                 ptrs["u"] = None                  # "parity" inference: the fused up-projection epilogue writes only the image of gelu(u)
             A["acts_struct"].append(L.LayerActs(x_in=xin.data_ptr(), x_out=xout.data_ptr(), **ptrs))
         A["x_final"] = A["x"][self.nlayers] if train else A["x"][self.nlayers % 2]
@@ -655,7 +644,7 @@ class BertEncoderEngine:
     def _cfg_struct(self, B, Lseq, p_hidden, p_attn, seed, accumulate):
         return L.BertCfg(B=B, L=Lseq, H=self.H, heads=self.heads, I=self.I, ln_eps=float(self.cfg.layer_norm_eps),
                          p_hidden=p_hidden, p_attn=p_attn, seed=seed, accumulate_grads=1 if accumulate else 0, dtype=L.BF16,
-                         window=0, nglobal=0, nproj=0, mixer=0, phase=0, act=self.act)
+                         window=0, nglobal=0, nproj=0, mixer=0, phase=0, act=self.act, ctx=self.ctx.ptr)
 
     # ------------------------------------------------------------------------------------------------ forward / backward
     def _emb(self, name):
@@ -862,13 +851,15 @@ class BertEncoderEngine:
         budget = getattr(self, "_bwd_cu_budget", 0) if ((self.buckets is not None and self.grad_sync) or getattr(self, "_bwd_cu_budget_always", False)) else 0
         if not budget:
             return self._backward(ctx, dseq, accumulate)
-        # data parallel: the bucket all-reduces run beside this backward and their RCCL channels hold CUs (tile widths are chosen at launch time)
-        lib = L.load()
-        prev = lib.amdseg_set_cu_budget(budget)
+        # data parallel: the bucket all-reduces run beside this backward and their RCCL channels hold CUs (tile widths are chosen at launch time).
+        # The budget lives in this engine's context (amdseg_ctx), which every composite call of this backward names in its cfg; the context is
+        # also bound for the cfg-less GEMM calls of the Longformer / PoNet / embedding-projection backward.
+        prev = self.ctx.set_cu_budget(budget)
         try:
-            return self._backward(ctx, dseq, accumulate)
+            with self.ctx.bound():
+                return self._backward(ctx, dseq, accumulate)
         finally:
-            lib.amdseg_set_cu_budget(prev)
+            self.ctx.set_cu_budget(prev)
 
     def _backward(self, ctx, dseq, accumulate=True):
         B, Lseq = ctx["B"], ctx["L"]
@@ -1024,11 +1015,12 @@ class BertEncoderEngine:
         fp, flags = self.fp, getattr(self, "_chunk_flags", None)
         lb = fp.layers_begin
         lazy = bool(zero_grad) and self.lazy_zero and fp.layers_dense and 0 < lb < fp.numel and not self.ddp_compat()
-        for a, b, zg in (((0, lb, True), (lb, fp.numel, False)) if lazy else ((0, fp.numel, zero_grad),)):
-            # (bf16 compute copies exist for the encoder layers' matrices only: the front part -- embeddings, heads -- is read in fp32)
-            ops.adamw(fp.flat_p[a:b], fp.flat_g[a:b], self.adam_m[a:b], self.adam_v[a:b], self.shadow[a:b] if (ride and (b > lb or not lazy)) else None, lr, betas[0],
-                      betas[1], eps, weight_decay, self.opt_step, gscale=coef, zero_grad=zg,
-                      chunk_flags=None if flags is None else flags[a // 64:(b + 63) // 64])
+        with self.ctx.bound():              # (the launch timer of this engine's context also sees the cfg-less amdseg_adamw)
+            for a, b, zg in (((0, lb, True), (lb, fp.numel, False)) if lazy else ((0, fp.numel, zero_grad),)):
+                # (bf16 compute copies exist for the encoder layers' matrices only: the front part -- embeddings, heads -- is read in fp32)
+                ops.adamw(fp.flat_p[a:b], fp.flat_g[a:b], self.adam_m[a:b], self.adam_v[a:b], self.shadow[a:b] if (ride and (b > lb or not lazy)) else None, lr, betas[0],
+                          betas[1], eps, weight_decay, self.opt_step, gscale=coef, zero_grad=zg,
+                          chunk_flags=None if flags is None else flags[a // 64:(b + 63) // 64])
         fp.grad_stale = lazy
         self.fp.grad_is_zero = bool(zero_grad)
         self._rest_reduced = False

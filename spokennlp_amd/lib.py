@@ -14,7 +14,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
 EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
 EPI_DERIV_U8 = 0x400      # with EPI_KEEP_DERIV: the derivative as one byte per element, q = round((g' + 0.135) * 200)
 EPI_KEEP_DERIV = 0x200    # OR-ed into EPI_BIAS_GELU: out2 = gelu'(pre-activation); into EPI_GELU_BWD: R is that derivative (C = (A B^T) * R)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
@@ -23,7 +23,7 @@ class BertCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("heads", C.c_int32), ("I", C.c_int32),
                 ("ln_eps", f32), ("p_hidden", f32), ("p_attn", f32), ("seed", u64),
                 ("accumulate_grads", C.c_int32), ("dtype", C.c_int32), ("window", C.c_int32), ("nglobal", C.c_int32),
-                ("nproj", C.c_int32), ("mixer", C.c_int32), ("phase", C.c_int32), ("act", C.c_int32), ("kend", vp), ("seq_order", vp), ("pad_guard", vp), ("pad_runs", vp), ("pad_counts", vp)]
+                ("nproj", C.c_int32), ("mixer", C.c_int32), ("phase", C.c_int32), ("act", C.c_int32), ("kend", vp), ("seq_order", vp), ("pad_guard", vp), ("pad_runs", vp), ("pad_counts", vp), ("ctx", vp)]
 
 
 class LayerParams(C.Structure):
@@ -42,7 +42,7 @@ class LayerActs(C.Structure):
 
 class LayerWs(C.Structure):
     _fields_ = [(n, vp) for n in ("dz2", "dbr2", "du", "dx1", "dz1", "dbr1", "dctx", "dqkv", "delta", "partials",
-                                  "d_out_s", "du_s", "d_ao_s", "dqkv_s", "dctx_s", "dq_part")]
+                                  "d_out_s", "du_s", "d_ao_s", "dqkv_s", "dctx_s")]
 
 
 # name -> argtypes (restype is always int unless listed in _RESTYPE); mirrors include/amdseg.h one for one
@@ -50,7 +50,6 @@ _PROTOS = {
     "amdseg_abi_version": [],
     "amdseg_error_string": [i32],
     "amdseg_gemm_nt": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp],
-    "amdseg_gemm_nt_bias_drop_res": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, f32, u64, vp, vp],
     "amdseg_gemm_tn_grouped": [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp),
                                C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, i32, vp],
     "amdseg_gemm_tn_grouped_bias": [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp),
@@ -66,8 +65,6 @@ _PROTOS = {
     "amdseg_attn_bwd_keep": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp],
     "amdseg_attn_band_fwd_keep": [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
     "amdseg_attn_band_bwd_keep": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
-    "amdseg_attn_bwd_merged_scratch_bytes": [i32, i32, i32],
-    "amdseg_attn_bwd_merged": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp],
     "amdseg_sattn_fwd": [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
     "amdseg_sattn_bwd": [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp],
     "amdseg_attn_band_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, i32, vp],
@@ -101,7 +98,6 @@ _PROTOS = {
     "amdseg_attn_list_f32": [vp, vp, vp, i32, i32, i32, f32, vp, vp, i32, vp],
     "amdseg_attn_list_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, i32, vp, vp],
     "amdseg_attn_list_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp, vp, vp],
-    "amdseg_debug_force_small_tile": [i32],
     "amdseg_split3": [vp, i32, vp, i32, i32, i32, vp],
     "amdseg_split3_transpose": [vp, vp, i32, i32, vp],
     "amdseg_split3_weights_batched": [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp],
@@ -127,16 +123,21 @@ _PROTOS = {
     "amdseg_heads_bwd_ce_focal": [vp, i32, i32, i32, vp, vp, f32, f32, vp, vp],
     "amdseg_heads_bwd_rows": [vp, vp, i32, i32, vp, vp, C.c_long, C.c_long, C.c_long, i32, i32, i32, f32, vp, vp, C.c_long, C.c_long, i32, i32,
                               vp, vp, f32, f32, i32, vp, C.c_size_t, vp],
-    "amdseg_set_cu_budget": [i32],
+    "amdseg_ctx_create": [C.POINTER(vp)],
+    "amdseg_ctx_destroy": [vp],
+    "amdseg_ctx_bind": [vp],
+    "amdseg_ctx_set_cu_budget": [vp, i32],
+    "amdseg_ctx_cu_budget": [vp],
+    "amdseg_ctx_force_small_tile": [vp, i32],
+    "amdseg_ctx_prof_enable": [vp, i32],
+    "amdseg_ctx_prof_reset": [vp],
+    "amdseg_ctx_prof_read": [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
     "amdseg_allreduce_unique_id": [vp],
     "amdseg_allreduce_init": [C.POINTER(vp), vp, i32, i32],
     "amdseg_allreduce_bucket": [vp, vp, sz, i32, vp],
     "amdseg_allreduce_wait": [vp, vp],
     "amdseg_allreduce_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)],
     "amdseg_allreduce_destroy": [vp],
-    "amdseg_prof_enable": [i32],
-    "amdseg_prof_reset": [],
-    "amdseg_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)],
     "amdseg_rowdot_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "amdseg_rowdot_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "amdseg_adamw": [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, vp, i32, vp, vp],
@@ -147,7 +148,7 @@ _PROTOS = {
     "amdseg_bert_layer_bwd": [C.POINTER(BertCfg), C.POINTER(LayerParams), C.POINTER(LayerGrads), C.POINTER(LayerActs),
                               C.POINTER(LayerWs), vp, vp, vp, i32, vp],
 }
-_RESTYPE = {"amdseg_error_string": C.c_char_p, "amdseg_attn_keepmask_bytes": C.c_size_t, "amdseg_attn_bwd_merged_scratch_bytes": C.c_size_t, "amdseg_ponet_global_scratch_floats": C.c_size_t}
+_RESTYPE = {"amdseg_error_string": C.c_char_p, "amdseg_attn_keepmask_bytes": C.c_size_t, "amdseg_ponet_global_scratch_floats": C.c_size_t}
 
 EXPORTS = tuple(_PROTOS)
 _lib = None
@@ -178,11 +179,8 @@ def load(path=None):
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, C.c_int)
     v = lib.amdseg_abi_version()
-    if v == -ABI_VERSION and os.environ.get("AMDSEG_ALLOW_PROBES") != "1":
-        raise AmdsegError(f"{p} was built with -DAMDSEG_PROBES (wrong-result timing probes compiled in): not a product library "
-                          f"(AMDSEG_ALLOW_PROBES=1 loads it for tools/ measurements)")
-    if abs(v) != ABI_VERSION:
-        raise AmdsegError("libamdseg.so ABI version mismatch")
+    if v != ABI_VERSION:
+        raise AmdsegError(f"libamdseg.so ABI version mismatch: the library says {v}, this binding is written for {ABI_VERSION}")
     if path is None:
         _lib = lib
     return lib
@@ -192,3 +190,54 @@ def check(rc, what=""):
     if rc != 0:
         msg = load().amdseg_error_string(rc)
         raise AmdsegError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")
+
+
+class Ctx:
+    """the explicit library context (include/amdseg.h, amdseg_ctx_*): CU budget of the tile rules, small-tile test hook, launch timer.  One per engine;
+    `ptr` goes into BertCfg.ctx for the composite calls, `bound()` makes it the calling thread's context for the cfg-less entry points."""
+
+    def __init__(self):
+        h = vp()
+        check(load().amdseg_ctx_create(C.byref(h)), "amdseg_ctx_create")
+        self.ptr = h.value
+
+    def close(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.amdseg_ctx_destroy(self.ptr)
+        self.ptr = None
+
+    __del__ = close
+
+    def set_cu_budget(self, cus):
+        return load().amdseg_ctx_set_cu_budget(self.ptr, int(cus))
+
+    def cu_budget(self):
+        return load().amdseg_ctx_cu_budget(self.ptr)
+
+    def force_small_tile(self, v):
+        return load().amdseg_ctx_force_small_tile(self.ptr, int(v))
+
+    def prof_enable(self, on):
+        return load().amdseg_ctx_prof_enable(self.ptr, 1 if on else 0)
+
+    def prof_reset(self):
+        return load().amdseg_ctx_prof_reset(self.ptr)
+
+    def prof_read(self, cls):
+        us, work, n = C.c_double(), C.c_double(), C.c_longlong()
+        check(load().amdseg_ctx_prof_read(self.ptr, cls, C.byref(us), C.byref(work), C.byref(n)), "amdseg_ctx_prof_read")
+        return us.value, work.value, n.value
+
+    def bound(self):
+        """context manager: this context is the calling thread's for the cfg-less entry points (amdseg_adamw, amdseg_gemm_nt, ...) inside the block"""
+        ctx = self
+
+        class _B:
+            def __enter__(self_):
+                load().amdseg_ctx_bind(ctx.ptr)
+                return ctx
+
+            def __exit__(self_, *exc):
+                load().amdseg_ctx_bind(None)
+                return False
+        return _B()

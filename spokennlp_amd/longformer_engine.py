@@ -34,19 +34,19 @@ class LongformerEncoderEngine(BertEncoderEngine):
             raise L.AmdsegError("attention_window must be >= 2")
         self.pad_id = int(config.pad_token_id)
         # band attention keeps the stateless dropout hash by default.  The keep-mask form exists (amdseg_attn_keepmask_band + the BAND / KM kernel
-        # instantiations, AMDSEG_LF_KEEPMASK=1) and is slower end to end at longformer-base 8 x 4096: the three kernels gain 28 us per layer (109 / 146 /
+        # instantiations, engine.attn_keepmask = True before the first forward) and is slower end to end at longformer-base 8 x 4096: the three kernels gain 28 us per layer (109 / 146 /
         # 179 -> 102 / 144 / 165 us) and the generator costs more (288 vs 295 seq/s)
-        self.attn_keepmask = self.attn_keepmask and os.environ.get("AMDSEG_LF_KEEPMASK", "0") == "1"
+        self.attn_keepmask = False
         self.scale = 1.0 / math.sqrt(64.0)
         # False: no global token at all -- LongformerModel called with global_attention_mask=None (the mmvts text encoder,
         # mmvts/src/models/text_encoder/text_encoder.py:73-85 as driven by multi_modal_for_ts.py:173-176): pure band attention
         self.cls_global = True
         # the global-row chain (a dozen small, latency-bound launches per layer and direction plus three HBM passes) runs on a second
         # stream under the layer's big kernels: forward under the QKV GEMM + band attention, backward under the attention backward
-        # and the weight-gradient GEMM.  AMDSEG_LF_OVERLAP=0 keeps everything on one stream.
-        self.lf_overlap = os.environ.get("AMDSEG_LF_OVERLAP", "1") != "0" and device.type == "cuda"
+        # and the weight-gradient GEMM.  engine.lf_overlap = False keeps everything on one stream.
+        self.lf_overlap = device.type == "cuda"
         self._side_pending = False                          # weight gradients of the global projections still running on the second stream
-        self._lf_side = torch.cuda.Stream(device=device, priority=int(os.environ.get("AMDSEG_LF_SIDE_PRIO", "0"))) if self.lf_overlap else None
+        self._lf_side = torch.cuda.Stream(device=device, priority=0) if self.lf_overlap else None
 
     def _on_both(self, main, *tensors):
         """tensors created while one stream was current and read on the other: tell the caching allocator"""

@@ -115,17 +115,6 @@ def attn_bwd_keep(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, p, keep, scale
     return dqkv
 
 
-def attn_bwd_merged(qkv, mask_bias, ctx, dctx, lse, B, Lseq, heads, p=0.0, keep=None, kend=None, seq_order=None, pad_guard=None, scale=0.125, dq_part=None):
-    """dQ, dK, dV from one kernel (amdseg_attn_bwd_merged): full attention, Lseq % 256 == 0, dropout decisions from `keep`"""
-    lib = L.load()
-    dqkv = torch.empty_like(qkv)
-    if dq_part is None:
-        dq_part = torch.zeros(lib.amdseg_attn_bwd_merged_scratch_bytes(B, Lseq, heads) // 4, dtype=torch.float32, device=qkv.device)      # (zeroed ONCE: its tail holds the kernel's own sync words)
-    L.check(lib.amdseg_attn_bwd_merged(_p(qkv), _p(mask_bias), _p(ctx), _p(dctx), _p(lse), _p(dqkv), _p(dq_part), B, Lseq, heads, scale, p, _p(keep),
-                                       _p(kend), _p(seq_order), _p(pad_guard), _s()), "amdseg_attn_bwd_merged")
-    return dqkv
-
-
 def attn_keepmask_band(B, Lseq, heads, p, seed, window, nglobal, device):
     """keep masks of a band (Longformer) layer: same buffer layout as attn_keepmask, only the cells the band kernels visit are written"""
     lib = L.load()
@@ -356,20 +345,6 @@ LNB_ROWS = 16      # rows per workgroup of ln_bwd / rowdot_bwd (csrc/elementwise
 
 def ln_partials_numel(M, H):
     return 3 * ((M + LNB_ROWS - 1) // LNB_ROWS) * H
-
-
-def gemm_nt_bias_drop_res(A, B, bias, R, p=0.0, seed=0, want_bits=True):
-    """z = R + dropout(A @ B^T + bias) in the epilogue of the 256 x 256 GEMM (csrc/gemm_dp.hip EPI_BIAS_DROP_RES); returns (z, keep bytes
-    [M * N / 8] or None)"""
-    _chk(A, "A"); _chk(B, "B")
-    M, K = A.shape
-    N = B.shape[0]
-    out = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
-    bits = torch.zeros((M * N // 8,), dtype=torch.uint8, device=A.device) if (want_bits and p > 0) else None
-    rc = L.load().amdseg_gemm_nt_bias_drop_res(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), _p(R),
-                                               R.stride(0), p, seed, _p(bits), _s())
-    L.check(rc, "amdseg_gemm_nt_bias_drop_res")
-    return out, bits
 
 
 def ln_bwd(dy, z, mean, rstd, gamma, p=0.0, seed=0, dgamma=None, dbeta=None, dbias=None, accumulate=False, partials=None):

@@ -96,7 +96,7 @@ class PoNetEncoderEngine(BertEncoderEngine):
         self.attn_keepmask = False                          # no softmax attention in this encoder
         # the global aggregation branch as streaming passes of csrc/ponet_global.hip (4 launches forward, 5 backward); AMDSEG_PN_LF_CHAIN=1 keeps
         # the rounds-1/2 formulation on the Longformer global-row kernels (10 / 12 launches and torch glue; same dropout decisions)
-        self.fused_global = os.environ.get("AMDSEG_PN_LF_CHAIN", "0") != "1" and self.H <= 1024
+        self.fused_global = self.H <= 1024                  # (engine.fused_global = False: the Longformer global-row chain instead, tests)
         self._seg = None
         # amdseg_bert_cfg.pad_guard holds for the pooling mixer too: a padded token n has dctx_n = 0, so dHo_n = 0; it is no valid neighbour /
         # run member, so no local or segment maximum routes a gradient to it; it is a masked key of the global aggregation (p = 0): dproj_n = 0

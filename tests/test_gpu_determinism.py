@@ -72,7 +72,15 @@ def _three_steps(dev, precision, deterministic, case="tiny_L128", lazy_zero=None
         if lazy_zero is not None:
             m.engine().lazy_zero = lazy_zero
         if bwd_cu_budget:
-            m.engine()._bwd_cu_budget, m.engine()._bwd_cu_budget_always = bwd_cu_budget, True
+            eng_ = m.engine()
+            eng_._bwd_cu_budget, eng_._bwd_cu_budget_always = bwd_cu_budget, True
+            if not hasattr(eng_, "_seen_budgets"):             # what the engine's context held WHILE backward ran (autograd's thread), per step
+                eng_._seen_budgets, inner = [], eng_._backward
+
+                def spy(*a, _inner=inner, _eng=eng_, **kw):
+                    _eng._seen_budgets.append(_eng.ctx.cu_budget())
+                    return _inner(*a, **kw)
+                eng_._backward = spy
         if it != skip_backward_at:                         # (a step without a backward: every gradient counts as zero)
             loss.backward()
         losses.append(loss.item())
@@ -80,6 +88,8 @@ def _three_steps(dev, precision, deterministic, case="tiny_L128", lazy_zero=None
     torch.cuda.synchronize()
     eng = m.engine()
     assert eng.deterministic == deterministic
+    if bwd_cu_budget:                                      # the budget was in force inside every backward and is gone behind it
+        assert eng._seen_budgets == [bwd_cu_budget] * 3 and eng.ctx.cu_budget() == 0
     return losses, eng.fp.flat_p.detach().clone(), {n: p.detach().clone() for n, p in m.named_parameters()}
 
 
@@ -189,11 +199,9 @@ def test_lazy_gradient_zeroing_changes_no_bit_in_the_other_engines(dev, family):
 
 def test_backward_under_a_cu_budget_changes_no_bit(dev):
     """data parallel: backward runs beside the RCCL channels of the bucket all-reduces and chooses its GEMM tile widths by rounds of workgroups over
-    the CUs that are left (amdseg_set_cu_budget): another tile width is another launch geometry, not another summation order -- bert-base 4 x 512,
+    the CUs that are left (amdseg_ctx_set_cu_budget on the engine's context): another tile width is another launch geometry, not another summation order -- bert-base 4 x 512,
     three steps, the same bits in every parameter with 240 of 256 CUs budgeted"""
     a = _three_steps(dev, "bf16", True, "bert_base_L512", bwd_cu_budget=240)
     b = _three_steps(dev, "bf16", True, "bert_base_L512")
     assert a[0] == b[0]
     assert torch.equal(a[1], b[1])
-    from spokennlp_amd import lib as L
-    assert L.load().amdseg_set_cu_budget(0) == 0           # the budget was restored behind every backward

@@ -171,53 +171,3 @@ def test_band_keepmask_forward_backward_vs_torch(dev, B, L, heads, w, G):
         assert rel_err(dqkv[:, j * H:(j + 1) * H], q32.grad[:, j * H:(j + 1) * H]) < 2e-2, name
 
 
-# ------------------------------------------------------------------------------------------------ attention backward as ONE kernel
-@pytest.mark.parametrize("B,L,heads,pad,p", [(2, 512, 3, True, 0.1), (3, 256, 2, False, 0.1), (2, 768, 2, True, 0.0), (4, 512, 12, True, 0.1)])
-@pytest.mark.parametrize("kt", [2, 1])
-def test_attn_bwd_merged_vs_torch_and_vs_the_two_kernel_form(dev, B, L, heads, pad, p, kt):
-    """amdseg_attn_bwd_merged (csrc/attention_bwd_merged.hip: dQ, dK, dV from one evaluation of P and dS; 1, 2 and 3 key blocks of 256; both wave
-    layouts) against the fp32 torch reference with the SAME keep decisions, against amdseg_attn_bwd_keep, and against itself (bit-reproducible; the
-    scratch carries its own generation word across launches)."""
-    import os
-    ops = _ops()
-    os.environ["AMDSEG_ATTN_MERGED_KT"] = str(kt)                        # (read by the launcher at every call)
-    keep = ops.attn_keepmask(B, L, heads, p, 99, dev) if p > 0 else None
-    km, inv_keep = None, 1.0
-    if p > 0:
-        ka, _ = unpack_keep(keep, B, L, heads)
-        km = ka.view(B, heads, L, L).float().to(dev)
-        inv_keep = 65536.0 / (65536 - round(p * 65536))
-    qkv, mb = make_qkv(dev, B, L, heads, 31, pad=pad)
-    g = torch.Generator(device="cpu").manual_seed(32)
-    dctx = torch.randn(B * L, heads * 64, generator=g).to(dev).bfloat16()
-    am = (mb.view(B, L) == 0)
-    dctx = (dctx.view(B, L, -1) * am[:, :, None]).reshape(B * L, -1).contiguous()      # rows of padding carry exact-zero gradients (pad_guard == 0)
-    kend = (am.long() * torch.arange(1, L + 1, device=dev)[None, :]).amax(dim=1).to(torch.int32)
-    order = torch.argsort(kend, descending=True, stable=True).to(torch.int32)
-    zero = torch.zeros(1, dtype=torch.int32, device=dev)
-    if p > 0:
-        ctx, lse = ops.attn_fwd_keep(qkv, mb, B, L, heads, p, keep)
-        two = ops.attn_bwd_keep(qkv, mb, ctx, dctx, lse, B, L, heads, p, keep)
-    else:
-        ctx, lse = ops.attn_fwd(qkv, mb, B, L, heads)
-        two = ops.attn_bwd(qkv, mb, ctx, dctx, lse, B, L, heads)
-    part = torch.zeros(ops.L.load().amdseg_attn_bwd_merged_scratch_bytes(B, L, heads) // 4, dtype=torch.float32, device=dev)
-    outs = []
-    for guard in (zero, None, zero):                                     # with and without the padding guard, three launches on one scratch
-        outs.append(ops.attn_bwd_merged(qkv, mb, ctx, dctx, lse, B, L, heads, p, keep, kend=kend, seq_order=order, pad_guard=guard, dq_part=part))
-    torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[2])                                 # bit-reproducible
-    q32 = qkv.float().requires_grad_(True)
-    ref, _ = attn_ref(q32, mb, B, L, heads, keep=km, inv_keep=inv_keep)
-    ref.backward(dctx.float())
-    H = heads * 64
-    for got in outs[:2]:
-        assert not torch.isnan(got.float()).any()
-        for i, name in enumerate(["dq", "dk", "dv"]):
-            sec, sec2, r = got[:, i * H:(i + 1) * H], two[:, i * H:(i + 1) * H], q32.grad[:, i * H:(i + 1) * H]
-            assert rel_err(sec, r) < 2e-2, name
-            # against the two-kernel form: the same fp32 sums in another order, then ONE bf16 rounding -> isolated last-bit differences at most
-            assert (sec.float() - sec2.float()).abs().max().item() <= 2.0 ** -7 * sec2.float().abs().max().item(), name
-    bad = (~am).reshape(-1)
-    assert not bad.any() or float(outs[0][bad].float().abs().max()) == 0.0            # rows of padding: exact zeros under the guard
-    os.environ.pop("AMDSEG_ATTN_MERGED_KT", None)

@@ -240,12 +240,16 @@ def test_gemm_tn_grouped_dp(dev, M):
         assert (cs[i] - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item()), i
     for a, b, c in zip(As, Bs, C3):
         assert rel_err(c, 2 * (a.float().t() @ b.float())) < 2e-6
-    old = ops.L.load().amdseg_debug_force_small_tile(1)
-    try:
+    ctx = ops.L.Ctx()                                       # the small-tile hook lives in an explicit context, bound for the cfg-less call
+    assert ctx.force_small_tile(1) == 0
+    with ctx.bound():
         C2 = [torch.empty_like(c) for c in Cs]
         ops.gemm_tn_grouped(As, Bs, C2, accumulate=False)
-    finally:
-        ops.L.load().amdseg_debug_force_small_tile(old)
+    C4 = [torch.empty_like(c) for c in Cs]
+    ops.gemm_tn_grouped(As, Bs, C4, accumulate=False)        # unbound again: the deep-pipeline kernel
+    for c2, c4 in zip(C2, C4):
+        assert rel_err(c2, c4) < 2e-6
+    ctx.close()
     for a, b, c in zip(As, Bs, C2):
         assert rel_err(c, a.float().t() @ b.float()) < 2e-6
 
@@ -432,32 +436,6 @@ def test_add_ln_fwd_bwd(dev, dtype, H):
     assert rel_err(dbias, dz.float().sum(0)) < (1e-5 if dtype == torch.float32 else 5e-3)
 
 
-@pytest.mark.parametrize("p", [0.0, 0.1])
-@pytest.mark.parametrize("M", [256, 1030])
-def test_add_ln_fwd_pair_kernel_equals_the_one_row_kernel_bit_for_bit(dev, p, M):
-    """H = 768, bf16: add_ln_fwd_pair768_kernel (two rows per wave trip, gamma / beta in registers) keeps the one-row kernel's summation order in
-    both statistics passes: z, out, mean and rstd are the same bits (AMDSEG_LNF_PAIR=1 selects it; measured neutral, so the one-row kernel stays the default; the kept dropout decisions are
-    compared at model level, test_hidden_dropout_decisions_kept_by_forward_equal_the_rehashed_ones)."""
-    import os
-    H = 768
-    g = torch.Generator(device="cpu").manual_seed(5 + M)
-    y = (3 * torch.randn(M, H, generator=g)).to(dev).bfloat16(); x = torch.randn(M, H, generator=g).to(dev).bfloat16()
-    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev); beta = (0.1 * torch.randn(H, generator=g)).to(dev)
-    res = []
-    for pair in ("0", "1"):
-        os.environ["AMDSEG_LNF_PAIR"] = pair
-        try:
-            z = y.clone()
-            out, mean, rstd = _ops().add_ln_fwd(z, x, gamma, beta, 1e-12, p=p, seed=77)
-            torch.cuda.synchronize()
-            res.append((z.clone(), out.clone(), mean.clone(), rstd.clone()))
-        finally:
-            os.environ.pop("AMDSEG_LNF_PAIR", None)
-    for a, b in zip(res[0], res[1]):
-        assert torch.equal(a, b)
-    ref = torch.nn.functional.layer_norm(res[1][0].float(), (H,), gamma, beta, 1e-12) if p == 0.0 else None
-    if ref is not None:
-        assert (res[1][1].float() - ref).abs().max().item() < 4e-2
 
 
 def test_hidden_dropout_consistency(dev):
@@ -671,41 +649,16 @@ def test_pad_plan_and_guard(dev, B, L):
             assert int(guard.item()) == (0 if val == 0 else 1), val
 
 
-@pytest.mark.parametrize("K,p", [(768, 0.1), (3072, 0.1), (768, 0.0)])
-def test_gemm_bias_dropout_residual_epilogue(dev, K, p):
-    """amdseg_gemm_nt_bias_drop_res (ABI 8): z = R + dropout(A B^T + bias) out of the 256 x 256 GEMM's epilogue.  The keep decisions are
-    EXACTLY those of the row kernel amdseg_add_ln_fwd for the same seed (same hash per 8 columns); the values equal gemm_nt(BIAS) followed by
-    add_ln_fwd's z up to the one bf16 rounding of the dense output that the fused form skips; LayerNorm-only mode (resid = None) of
-    amdseg_add_ln_fwd on that z equals the separate path's output to the same tolerance."""
+def test_add_ln_fwd_layernorm_only_mode(dev):
+    """amdseg_add_ln_fwd with resid == NULL: LayerNorm of the buffer as it stands, which is not rewritten"""
     ops = _ops()
-    M, N, seed = 512, 768, 1234
+    M, N = 512, 768
     g = torch.Generator(device="cpu").manual_seed(5)
-    A = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16(); B = (torch.randn(N, K, generator=g) * 0.05).to(dev).bfloat16()
-    bias = torch.randn(N, generator=g).to(dev); R = torch.randn(M, N, generator=g).to(dev).bfloat16()
+    z = torch.randn(M, N, generator=g).to(dev).bfloat16()
     gamma = (1 + 0.1 * torch.randn(N, generator=g)).to(dev); beta = (0.1 * torch.randn(N, generator=g)).to(dev)
-    z, bits = ops.gemm_nt_bias_drop_res(A, B, bias, R, p=p, seed=seed)
-    # the separate path: dense + bias (bf16), then z = R + dropout(y) inside add_ln_fwd
-    y = ops.gemm_nt(A, B, ops.EPI_BIAS, bias=bias)
-    ybuf = y.clone()
-    out_sep, mean_sep, rstd_sep = ops.add_ln_fwd(ybuf, R, gamma, beta, 1e-12, p=p, seed=seed)
-    keep_sep = (ybuf.float() - R.float()).abs() > 0            # dropped elements leave z == R exactly
-    if p > 0:
-        b = bits.view(M, N // 8).cpu()
-        keep_fused = torch.stack([((b >> e) & 1) for e in range(8)], dim=-1).reshape(M, N).bool().to(dev)
-        dense = y.float().abs() > 0.1 * R.float().abs() + 0.05   # (a small dense output next to a large residual rounds away in bf16: no decision visible in z)
-        assert torch.equal(keep_fused[dense], keep_sep[dense])
-        assert abs(1.0 - keep_fused.float().mean().item() - p) < 5e-3
-    ref = A.float() @ B.float().t() + bias
-    if p > 0:
-        q = round(p * 65536) / 65536
-        ref = ref * keep_fused.float() / (1 - q)
-    ref = ref + R.float()
-    assert (z.float() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item() / 4)
-    # vs the separate path: one bf16 rounding of y (2^-8 relative, scaled by 1 / keep) and one of z apart
-    assert (z.float() - ybuf.float()).abs().max().item() < 2.0 ** -6 * max(1.0, y.float().abs().max().item(), z.float().abs().max().item())
     zb = z.clone()
     out_f, mean_f, rstd_f = ops.add_ln_fwd(zb, None, gamma, beta, 1e-12)
-    assert torch.equal(zb, z)                                         # LayerNorm only: z is not rewritten
+    assert torch.equal(zb, z)
     refln = torch.nn.functional.layer_norm(z.float(), (N,), gamma, beta, 1e-12)
     assert (out_f.float() - refln).abs().max().item() < 3e-2
     assert (mean_f - z.float().mean(1)).abs().max().item() < 1e-4

@@ -73,6 +73,20 @@ int main() {
     if (memcmp(back.data(), hg.data(), ng * 4) != 0) { printf("FAIL: a one-rank sum must return its input\n"); return 1; }
     rc = amdseg_allreduce_destroy(comm);
     printf("allreduce (world 1): identity, destroy -> %d\n", rc);
+    // the explicit library context (ABI 13): created, set, bound for a cfg-less call, destroyed -- all state the library keeps is in it
+    amdseg_ctx* cx = nullptr;
+    rc = amdseg_ctx_create(&cx);
+    if (rc != AMDSEG_OK || !cx) { printf("FAIL ctx_create: %d\n", rc); return 1; }
+    if (amdseg_ctx_set_cu_budget(cx, 240) != 0 || amdseg_ctx_cu_budget(cx) != 240) { printf("FAIL ctx budget\n"); return 1; }
+    amdseg_ctx_prof_enable(cx, 1); amdseg_ctx_prof_reset(cx);
+    amdseg_ctx_bind(cx);
+    rc = amdseg_gemm_nt(dA, K, dB, K, dC, N, M, N, K, AMDSEG_EPI_BIAS, dbias, nullptr, 0, nullptr, 0, 0, st);     // timed by THIS context's launch timer
+    amdseg_ctx_bind(nullptr);
+    double us = 0, work = 0; long long launches = 0;
+    int rc2 = amdseg_ctx_prof_read(cx, AMDSEG_PROF_GEMM_NT, &us, &work, &launches);
+    printf("ctx: budget 240, bound gemm rc %d, launch timer read rc %d: %lld launch(es), %.1f us\n", rc, rc2, launches, us);
+    if (rc != AMDSEG_OK || rc2 != AMDSEG_OK) return 1;
+    amdseg_ctx_destroy(cx);
     printf("CABI_DEMO_OK\n");
     return 0;
 }
