@@ -19,6 +19,7 @@ import json
 import os
 import random
 import sys
+import socket
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -295,16 +296,34 @@ def dp_record(eng, world, device, sync_marks, step, first_step, args):
     from spokennlp_amd.dp import GradBuckets
     ones = torch.ones(1, device=device)
     dist.all_reduce(ones)
+    # the devices the ranks actually sit on (two ranks on one GPU over gloo are not two GPUs)
+    props = torch.cuda.get_device_properties(device)
+    me = f"{socket.gethostname()}:{getattr(props, 'uuid', None) or torch.cuda.current_device()}"
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    distinct = len(set(everyone))
+    if dist.get_backend() == "nccl" and (float(ones.item()) != float(world) or distinct != world):
+        # the line may say n_gpus = N only when RCCL itself summed N ones from N different devices
+        raise SystemExit(f"bench.py --gpus {world}: the nccl (RCCL) all-reduce of ones returned {ones.item()} over {distinct} distinct GPU(s); "
+                         f"refusing to report n_gpus = {world}")
     b = eng.buckets
     sizes = [(hi - lo) * 4 for lo, hi in b.layer_slices] + [(b.rest_slice[1] - b.emb_slice[1]) * 4, (b.emb_slice[1] - b.emb_slice[0]) * 4]
     exposed = sorted(e0.elapsed_time(e1) for e0, e1 in sync_marks)
-    rec = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), allreduce_of_ones=float(ones.item()),
+    rec = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), allreduce_of_ones=float(ones.item()), distinct_gpus=distinct,
+               transport="amdseg_allreduce_* (C ABI, csrc/comm.hip)" if b.native is not None else "torch.distributed.all_reduce",
+               rccl_comm_ranks=(b.native.world if b.native is not None else None), wire=b.wire,
                buckets_per_step=len(sizes), bytes_per_step=int(sum(sizes)), tail_bucket_bytes=int(sizes[-1]),
                layer_bucket_bytes=int(sizes[0]), bucket_order="encoder layers last to first, then the embedding tables, all from inside backward (side stream); pooler + loss heads from finish_grad_sync",
                exposed_comm_ms_per_step=round(sum(exposed) / max(len(exposed), 1), 3),
                exposed_comm_ms_median=round(exposed[len(exposed) // 2], 3) if exposed else None,
                exposed_comm_method="HIP events on the compute stream around finish_grad_sync() (tail bucket issue + wait for every bucket), "
                                    "timed region average")
+    if dist.get_backend() != "nccl":
+        rec["note"] = (f"AMDSEG_DIST_BACKEND={dist.get_backend()}: {world} ranks on {distinct} GPU(s) -- a functional run of the N > 1 path, not a scaling measurement")
+    # the schedule of one step as the buckets logged it (first element, end, wire dtype) and its bytes on the wire
+    last = b.log or b.last_log
+    rec["schedule"] = dict(buckets=len(last), bytes_on_wire=sum((e - a) * (2 if w == "bf16" else 4) for a, e, w in last),
+                           order=[[a, e, w] for a, e, w in last[:3]] + (["..."] if len(last) > 3 else []))
     rec["nccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
     rec["backward_cu_budget"] = getattr(eng, "_bwd_cu_budget", 0) or None     # CUs the tile-width rule of backward counts on (amdseg_ctx_set_cu_budget)
     try:
@@ -329,6 +348,19 @@ def dp_record(eng, world, device, sync_marks, step, first_step, args):
     word = ws[1] - ws[0]
     rec["bf16_embed"] = dict(steps=nextra, ms_per_step=round(dt.item() / nextra * 1e3, 3), exposed_comm_ms_per_step=round(sum(ex) / len(ex), 3),
                              tail_bucket_bytes_on_wire=int(sizes[-1] - 2 * word))
+    # ... and with EVERY bucket in bf16 on the wire (AMDSEG_DP_WIRE=bf16: 217.8 MB instead of 435.6 MB per bert-base step)
+    eng.buckets = GradBuckets(eng.fp, wire="bf16")
+    torch.cuda.synchronize(); dist.barrier()
+    n0 = len(sync_marks)
+    t0 = time.perf_counter()
+    for i in range(first_step + nextra, first_step + 2 * nextra):
+        step(i)
+    torch.cuda.synchronize(); dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=device)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ex = [e0.elapsed_time(e1) for e0, e1 in sync_marks[n0:]]
+    rec["bf16_wire"] = dict(steps=nextra, ms_per_step=round(dt.item() / nextra * 1e3, 3), exposed_comm_ms_per_step=round(sum(ex) / len(ex), 3),
+                            bytes_per_step=int(sum(sizes) // 2))
     eng.buckets = old
     return rec
 

@@ -30,6 +30,7 @@ struct RcclApi {
     nccl_result (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
     nccl_result (*CommDestroy)(nccl_comm) = nullptr;
     const char* (*GetErrorString)(nccl_result) = nullptr;
+    nccl_result (*CommCount)(const nccl_comm, int*) = nullptr;          // optional: the communicator's own rank count
 };
 
 // bound once per process; the only process-wide state of this file is the dlopen handle (a loaded library IS process-wide).  The binding is a
@@ -51,6 +52,7 @@ RcclApi bind_rccl() {
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(h, "ncclCommCount"));
     if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) { dlclose(h); return RcclApi(); }
     api.handle = h;
     return api;
@@ -134,7 +136,12 @@ int amdseg_allreduce_wait(amdseg_comm* c, amdseg_stream_t compute_stream) {
 int amdseg_allreduce_info(const amdseg_comm* c, int* rank, int* world, size_t* pending_elements) {
     if (!c) return AMDSEG_ERR_ARG;
     if (rank) *rank = c->rank;
-    if (world) *world = c->world;
+    if (world) {                                            // what RCCL's communicator itself reports (ncclCommCount), not what init was told
+        *world = c->world;
+        RcclApi* r = rccl();
+        int n = 0;
+        if (r && r->CommCount && r->CommCount(c->comm, &n) == 0 && n > 0) *world = n;
+    }
     if (pending_elements) *pending_elements = c->elements;
     return AMDSEG_OK;
 }

@@ -59,17 +59,57 @@ def gather_sharded(local, n_items, group=None):
     return out[:n_items]
 
 
+class NativeComm:
+    """the gradient exchange of the C ABI (include/amdseg.h amdseg_allreduce_*: RCCL bound by libamdseg itself, csrc/comm.hip) behind the SAME
+    bucket schedule as the torch.distributed one (GradBuckets._reduce): AMDSEG_DP_NATIVE_COMM=1.  The unique id travels over the existing
+    process group (any backend); every rank then joins the RCCL communicator with its torch rank."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import lib as L
+        self.L, self.lib = L, L.load()
+        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            L.check(self.lib.amdseg_allreduce_unique_id(uid), "amdseg_allreduce_unique_id")
+        box = [bytes(uid.raw)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        uid = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        L.check(self.lib.amdseg_allreduce_init(C.byref(h), uid, rank, world), "amdseg_allreduce_init")
+        self.h = h
+        r, w, pend = C.c_int(), C.c_int(), C.c_size_t()
+        L.check(self.lib.amdseg_allreduce_info(h, C.byref(r), C.byref(w), C.byref(pend)), "amdseg_allreduce_info")
+        self.rank, self.world = r.value, w.value          # the rank count as RCCL's communicator reports it (ncclCommCount)
+
+    def allreduce(self, t, stream):
+        """in place, ordered behind everything queued on `stream` so far; `stream` sees the result when this returns (stream-ordered)"""
+        dt = self.L.F32 if t.dtype == torch.float32 else self.L.BF16
+        self.L.check(self.lib.amdseg_allreduce_bucket(self.h, t.data_ptr(), t.numel(), dt, stream.cuda_stream), "amdseg_allreduce_bucket")
+        self.L.check(self.lib.amdseg_allreduce_wait(self.h, stream.cuda_stream), "amdseg_allreduce_wait")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.amdseg_allreduce_destroy(self.h)
+            self.h = None
+
+
 class GradBuckets:
     """contiguous slices of the flat gradient buffer in the order backward produces them: [layer N-1] ... [layer 0] [embeddings + heads].
 
     On a GPU every exchange is issued from a SIDE stream: side waits for the main stream (the slice is final), RCCL reduces it, and the
     slice's sum of squares is accumulated right behind the reduction -- so after the last bucket the global gradient norm needs no
     extra pass over the 436 MB buffer, and the main stream (the rest of backward) never waits before `wait()`.
-    `bf16_embeddings` (opt-in, AMDSEG_DP_BF16_EMBED=1): the word-embedding gradient -- 94 MB of the fully exposed tail bucket, produced
-    last -- is exchanged in bf16 (cast, all-reduce, cast back: half the bytes on the xGMI links; the sum of W bf16 values carries 8
-    mantissa bits, so this deviates from torch DDP's fp32 exchange and is off by default)."""
+    Wire format (`wire`, AMDSEG_DP_WIRE): "fp32" (default: what torch DDP exchanges, 435.6 MB per bert-base step), "bf16_embed" (the
+    word-embedding gradient -- 94 MB of the fully exposed tail bucket, produced last -- in bf16; AMDSEG_DP_BF16_EMBED=1 is the old spelling) or
+    "bf16" (EVERY bucket cast to bf16, all-reduced, cast back: 217.8 MB on the xGMI links; the sum of W bf16 values carries 8 mantissa bits, so
+    both bf16 forms deviate from the reference's fp32 exchange and are opt-in).
+    Transport (`native`, AMDSEG_DP_NATIVE_COMM=1): the same schedule through the C ABI's amdseg_allreduce_* (NativeComm) instead of
+    torch.distributed.all_reduce -- GPU + RCCL only.  `log` records every exchange of a step as (first, end, wire dtype) in issue order: the schedule
+    is the same list whatever the transport (tests/test_dp_gloo.py, tests/test_gpu_ddp.py)."""
 
-    def __init__(self, fp, bf16_embeddings=None):
+    def __init__(self, fp, bf16_embeddings=None, wire=None, native=None):
         names = list(fp.offsets.keys())
         offs = [fp.offsets[n] for n in names] + [fp.numel]
         # FlatParams lays the buffer out as [rest | layer 0 | ... | layer N-1]: `rest` = every parameter that is not one of the per-layer
@@ -106,10 +146,28 @@ class GradBuckets:
         self.sumsq = torch.zeros(1, device=fp.flat_g.device)
         self._partials = torch.empty(2048, device=fp.flat_g.device) if self.cuda else None
         self._covered = 0                      # elements whose squares are in `sumsq` since the last reset
-        if bf16_embeddings is None:
-            bf16_embeddings = os.environ.get("AMDSEG_DP_BF16_EMBED", "0") == "1"
-        self.word_slice = None
+        if wire is None:
+            wire = os.environ.get("AMDSEG_DP_WIRE") or ("bf16_embed" if os.environ.get("AMDSEG_DP_BF16_EMBED", "0") == "1" else "fp32")
         if bf16_embeddings:
+            wire = "bf16_embed"
+        if wire not in ("fp32", "bf16_embed", "bf16"):
+            raise ValueError(f"AMDSEG_DP_WIRE={wire!r}: expected fp32, bf16_embed or bf16")
+        self.wire = wire
+        self.log = []                          # (first, end, "fp32" | "bf16") per exchange since the last reset_norm(), in issue order
+        self.last_log = []
+        if native is None:
+            native = os.environ.get("AMDSEG_DP_NATIVE_COMM", "0") == "1"
+        self.native = None
+        if native:
+            if not self.cuda:
+                raise RuntimeError("AMDSEG_DP_NATIVE_COMM=1: the C-ABI exchange (amdseg_allreduce_*) is RCCL on device buffers; this buffer is on the CPU")
+            self.native = NativeComm()
+        self._wire_buf = None
+        if wire == "bf16" and self.cuda:       # one staging buffer: every exchange runs on the one side stream, in order
+            biggest = max([b - a for a, b in self.layer_slices] + [self.rest_slice[1] - self.rest_slice[0]])
+            self._wire_buf = torch.empty(biggest, dtype=torch.bfloat16, device=fp.flat_g.device)
+        self.word_slice = None
+        if wire == "bf16_embed":
             wn = next((n for n in names[:first_layer] if n.endswith("word_embeddings.weight")), None)
             if wn is not None:
                 o = fp.offsets[wn]
@@ -120,24 +178,46 @@ class GradBuckets:
         self.sumsq.zero_()
         self._covered = 0
         self._emb_reduced = False
+        if self.log:
+            self.last_log = self.log           # the schedule of the step that just ended (bench.py's dp record reads it)
+        self.log = []
+
+    def bytes_on_wire(self):
+        """of the exchanges logged since the last reset"""
+        return sum((b - a) * (2 if w == "bf16" else 4) for a, b, w in self.log)
 
     def norm_is_complete(self):
         return self.cuda and self._covered == self.flat_g.numel()
 
+    def _exchange(self, t, group):
+        """one all-reduce(sum) of `t` in place on the side stream (current), by the chosen transport"""
+        if self.native is not None:
+            self.native.allreduce(t, self.side)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)              # stream-ordered on `side`
+
     def _reduce(self, a, b, group, bf16=False):
         g = self.flat_g[a:b]
+        bf16 = bf16 or self.wire == "bf16"
+        self.log.append((a, b, "bf16" if bf16 else "fp32"))
         if not self.cuda:
-            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            if bf16:                                                           # (CPU / gloo: the wire format is honoured, synchronously)
+                w = g.to(torch.bfloat16)
+                dist.all_reduce(w, op=dist.ReduceOp.SUM, group=group)
+                g.copy_(w)
+            else:
+                self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
             return
         from . import ops
         self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
             if bf16:
-                self._word_bf16.copy_(g)
-                dist.all_reduce(self._word_bf16, op=dist.ReduceOp.SUM, group=group)
-                g.copy_(self._word_bf16)
+                w = self._word_bf16 if (self.wire == "bf16_embed") else self._wire_buf[:b - a]
+                w.copy_(g)
+                self._exchange(w, group)
+                g.copy_(w)
             else:
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)          # stream-ordered on `side`
+                self._exchange(g, group)
             ops.sumsq(g, self.sumsq, self._partials, accumulate=True)
         self._covered += b - a
 

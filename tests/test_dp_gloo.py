@@ -46,6 +46,32 @@ def _worker(rank, world, port, q):
     b.wait()
     expect = sum(torch.randn(fp.numel, generator=torch.Generator().manual_seed(100 + k)) for k in range(world))
     ok = torch.allclose(fp.flat_g, expect, atol=1e-6) and not torch.equal(fp.flat_g, mine)
+    # the schedule of the step as logged: layers last to first, the embeddings part, the remainder of the rest -- fp32 on the wire, every element once
+    sched = list(b.log)
+    want = [(a, e, "fp32") for a, e in reversed(b.layer_slices)] + [(b.emb_slice[0], b.emb_slice[1], "fp32"), (b.emb_slice[1], b.rest_slice[1], "fp32")]
+    ok = ok and sched == want and b.bytes_on_wire() == 4 * fp.numel
+    # wire = "bf16" (AMDSEG_DP_WIRE=bf16): the SAME schedule, every bucket cast / summed / cast back -- half the bytes; the sums carry bf16 rounding
+    b2 = dp.GradBuckets(fp, wire="bf16")
+    fp.flat_g.copy_(torch.randn(fp.numel, generator=torch.Generator().manual_seed(100 + rank)))
+    for li in reversed(range(fp.nlayers)):
+        b2.reduce_layer(li)
+    b2.reduce_embeddings(); b2.reduce_rest(); b2.wait()
+    ok = ok and [(a, e) for a, e, _ in b2.log] == [(a, e) for a, e, _ in want] and all(w == "bf16" for _, _, w in b2.log)
+    ok = ok and b2.bytes_on_wire() == 2 * fp.numel
+    want_bf = sum(torch.randn(fp.numel, generator=torch.Generator().manual_seed(100 + k)).bfloat16() for k in range(world)).float()
+    ok = ok and torch.allclose(fp.flat_g, want_bf, atol=2e-2) and (fp.flat_g - expect).abs().max().item() < 0.05
+    # ... and the embeddings-only form touches exactly the word-embedding table
+    b3 = dp.GradBuckets(fp, wire="bf16_embed")
+    for li in reversed(range(fp.nlayers)):
+        b3.reduce_layer(li)
+    b3.reduce_embeddings(); b3.reduce_rest(); b3.wait()
+    bf = [(a, e) for a, e, w in b3.log if w == "bf16"]
+    ok = ok and bf == [b3.word_slice] and sum(e - a for a, e, _ in b3.log) == fp.numel
+    try:
+        dp.GradBuckets(fp, native=True)                # the C-ABI transport is RCCL on device buffers: refused loudly on a CPU buffer
+        ok = False
+    except RuntimeError:
+        pass
     # parameter .grad views see the reduced values
     n = "bert.encoder.layer.2.output.dense.weight"
     ok = ok and torch.equal(fp.params[n].grad.flatten(), fp.flat_g[fp.offsets[n]:fp.offsets[n] + fp.params[n].numel()])

@@ -143,6 +143,9 @@ def test_bench_two_ranks_on_one_gpu(dev):
     # (>= 0, not > 0: over gloo with two timed steps the embeddings bucket sometimes finishes under the tail of backward -- a timing, not a contract)
     assert all(sp[k] >= 0 for k in ("layer_buckets", "embeddings_bucket", "rest_bucket"))
     assert d["exposed_comm_ms_per_step"] > 0 and d["bf16_embed"]["ms_per_step"] > 0
+    assert d["distinct_gpus"] == min(2, torch.cuda.device_count()) and d["wire"] == "fp32" and d["transport"].startswith("torch.distributed")
+    assert d["schedule"]["buckets"] == 14 and d["schedule"]["bytes_on_wire"] == d["bytes_per_step"] and "not a scaling measurement" in d.get("note", "not a scaling measurement")
+    assert d["bf16_wire"]["bytes_per_step"] * 2 == d["bytes_per_step"] and d["bf16_wire"]["ms_per_step"] > 0
     assert d["bf16_embed"]["tail_bucket_bytes_on_wire"] == d["tail_bucket_bytes"] - 2 * 30523 * 768
 
 
@@ -173,13 +176,23 @@ def test_rccl_backend_single_rank_bucketed_exchange(dev):
     on -- 13 asynchronous RCCL all-reduces per step on slices of the flat gradient buffer, launched from inside backward, followed by the
     fused clip + AdamW (tools/nccl_single_rank_check.py, the multi-rank code path of bench.py; multi-GPU numbers are the driver's to take)"""
     import subprocess
-    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()),
+               AMDSEG_DETERMINISTIC="1")             # (sorted embedding-gradient sums: the transports are compared bit for bit below)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_single_rank_check.py")], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("nccl world=1")][-1]
     ms, loss = float(line.split("buckets:")[1].split("ms/step")[0]), float(line.rsplit("loss", 1)[1])
     assert 5.0 < ms < 60.0 and loss == loss
+    # ... the SAME bucket schedule through the C ABI's exchange (dp.NativeComm -> amdseg_allreduce_bucket / _wait, AMDSEG_DP_NATIVE_COMM=1): RCCL's own
+    # communicator reports one rank, the schedule is the logged list of the torch transport, and the fp32 gradients are the same bits
+    nat = [ln for ln in r.stdout.splitlines() if ln.startswith("native comm:")][-1]
+    assert "rccl ranks 1," in nat and "schedule equal True" in nat and "gradients bit-identical True" in nat, nat
+    # ... and with every bucket in bf16 on the wire (AMDSEG_DP_WIRE=bf16): the same slices, half the bytes, bf16-level difference
+    bfl = [ln for ln in r.stdout.splitlines() if ln.startswith("bf16 wire:")][-1]
+    assert "schedule slices equal True" in bfl, bfl
+    b_fp32 = int(nat.split("buckets, ")[1].split(" B on the wire")[0]); b_bf16 = int(bfl.split("True, ")[1].split(" B on the wire")[0])
+    assert b_bf16 * 2 == b_fp32 and float(bfl.rsplit("difference", 1)[1]) < 1e-2
 
 
 def test_c_abi_allreduce_context_single_rank(dev):
