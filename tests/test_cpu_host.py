@@ -261,3 +261,16 @@ def test_product_sources_carry_no_probe_flags_and_few_switches():
     assert "attention_bwd_merged.hip" not in open(os.path.join(ROOT, "spokennlp_amd", "build.py")).read()
     assert lib.ABI_VERSION == 13 and "amdseg_ctx_create" in lib.EXPORTS and "amdseg_set_cu_budget" not in lib.EXPORTS
 
+
+def test_erf_epilogue_build_flag_still_compiles(tmp_path):
+    """-DAMDSEG_GELU_ERF_EPILOGUE (csrc/common.h: the exact erf form in the bf16 GELU epilogues instead of the fitted sigmoid form) is the one build
+    flag the product sources keep: the deep-pipeline GEMM -- every GELU epilogue, including the one-byte derivative form -- must compile with it"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    csrc = os.path.join(ROOT, "spokennlp_amd", "csrc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DAMDSEG_GELU_ERF_EPILOGUE", "-c",
+                        os.path.join(csrc, "gemm_dp.hip"), "-o", str(tmp_path / "gemm_dp_erf.o")], capture_output=True, text=True, cwd=csrc)
+    assert r.returncode == 0, r.stderr[-1500:]

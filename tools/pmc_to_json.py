@@ -22,7 +22,12 @@ def main():
     label = sys.argv[3] if len(sys.argv) > 3 else src
     acc = {}
     ctr = None
+    measured_sha = None
     for ln in open(src):
+        m = re.match(r"## csrc_sha: (\S+)", ln)
+        if m:
+            measured_sha = m.group(1)          # stamped by tools/run_pmc_instep.sh WHEN the passes ran (not when this converter runs)
+            continue
         m = re.match(r"## pass: --pmc (\S+)", ln)
         if m:
             ctr = m.group(1)
@@ -35,6 +40,11 @@ def main():
             if cls in name:
                 d = acc.setdefault(cls, {}).setdefault(ctr, [0.0, 0])
                 d[0] += per * n; d[1] += n
+    now = __import__("spokennlp_amd.build", fromlist=["sources_sha"]).sources_sha()
+    if measured_sha is None:
+        sys.exit(f"{src} carries no '## csrc_sha:' line (written by tools/run_pmc_instep.sh at measurement time): refusing to stamp it with today's sources")
+    if measured_sha != now:
+        sys.exit(f"{src} was measured on kernel sources {measured_sha}; the shipped sources hash to {now}: re-run tools/run_pmc_instep.sh")
     kernels = {}
     for cls, d in acc.items():
         if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
@@ -50,7 +60,7 @@ def main():
                        "the process, so the figure is NOT re-measured by a bench run: `git` names the commit the passes ran on and `csrc_sha` (spokennlp_amd.build.sources_sha) the kernel sources -- bench.py reports "
                        "traffic: null + traffic_stale when the shipped sources hash differently.",
            "source": label, "git": git,
-           "csrc_sha": __import__("spokennlp_amd.build", fromlist=["sources_sha"]).sources_sha(),
+           "csrc_sha": measured_sha,
            "command": "python bench.py --no-cpu-baseline --no-via-trainer --no-roofline --no-extra-legs --steps 4 --warmup 2",
            "workload": {"model": "bert", "mode": "train", "seq_len": 512, "seqs_per_gpu": 32, "workload": "full_da", "precision": "bf16"},
            "kernels": kernels}

@@ -5,7 +5,8 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 OUT=gpurun_out/${TAG}_pmc_instep.txt
-: > $OUT
+# the hash of the kernel sources the passes RUN on goes into the output (tools/pmc_to_json.py refuses a file whose hash is not the shipped sources')
+echo "## csrc_sha: $(python -c 'from spokennlp_amd.build import sources_sha; print(sources_sha())')" > $OUT
 for CTR in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_${CTR}
   rocprofv3 --kernel-trace --pmc $CTR -d /tmp/pmc_${CTR} -o run -- python bench.py --no-cpu-baseline --no-via-trainer --no-roofline --no-extra-legs --steps 4 --warmup 2 > /dev/null 2> gpurun_out/${TAG}_pmc_${CTR}.err
