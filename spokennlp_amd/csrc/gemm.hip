@@ -53,10 +53,16 @@ __device__ __forceinline__ bf16x8 nt_frag(const char* lds_tile, int r, int c) {
     return *reinterpret_cast<const bf16x8*>(lds_tile + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
 }
 
-template <int EPIX, typename OutT>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
+// NST = LDS stages of [A 16 KiB | B 16 KiB].  2 (64 KiB): two workgroups per CU hide each other's waits -- the form for grids of more tiles than CUs.
+// 4 (128 KiB, round 6): the SMALL-M form.  A grid of at most one tile per CU (bert-base at 8 x 512 tokens: 192 tiles of the N = 768 GEMMs) left every CU with
+// ONE 4-wave workgroup whose only prefetch was the next K tile, requested 0.8 us before it was needed while its A panel comes from HBM: 1,790 cycles per K
+// tile against 512 of MFMA work (rocprofv3, profiles/r06_smallm_bert8_kernel_stats.md: 38.9 us for N = 768, K = 3072 at M = 4096, 0.2 of the peak).  The ring of
+// four keeps three K tiles in flight (LDS-DMA as inline asm + counted vmcnt, as in gemm_dp.hip: the compiler then knows of no vector memory operation it would
+// have to drain in front of the fragment reads).  Same MFMA sequence per accumulator: the same bits.
+template <int EPIX, typename OutT, int NST>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_nt_kernel(GemmNTArgs a) {
     constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
-    __shared__ __attribute__((aligned(16))) char smem[65536];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id as a scalar: LDS bases / M0 stay in SGPRs
     const int wr = w >> 1, wc = w & 1;
@@ -87,19 +93,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs a) {
     const NtLane offA = nt_lane_offsets(a.lda, w, l), offB = nt_lane_offsets(a.ldb, w, l);
     const bf16_t* pA = a.A + (size_t)m0 * a.lda;
     const bf16_t* pB = a.B + (size_t)n0 * a.ldb;
-    nt_stage(pA, offA, bufA(0), w);
-    nt_stage(pB, offB, bufB(0), w);
+    // NST == 4: the 8 pieces of a K tile (4 A + 4 B per wave) as saddr + lane-offset LDS-DMA with the destination in m0 (common.h)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem) + (uint32_t)(w * 32) * 128;
+#define NT_DMA_TILE(kt_, st_) do { const bf16_t* ga_ = a.A + (size_t)m0 * a.lda + (size_t)(kt_) * BK; const bf16_t* gb_ = a.B + (size_t)n0 * a.ldb + (size_t)(kt_) * BK; \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) amdseg_glds16_saddr_lds(ga_, (uint32_t)offA.off[q] * 2u, lds0 + (st_) * 32768 + q * 1024); \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) amdseg_glds16_saddr_lds(gb_, (uint32_t)offB.off[q] * 2u, lds0 + (st_) * 32768 + 16384 + q * 1024); } while (0)
+    if (NST == 2) {
+        nt_stage(pA, offA, bufA(0), w);
+        nt_stage(pB, offB, bufB(0), w);
+    } else {
+        NT_DMA_TILE(0, 0);
+        if (nk > 1) NT_DMA_TILE(1, 1);
+        if (nk > 2) NT_DMA_TILE(2, 2);
+    }
     for (int kt = 0; kt < nk; ++kt) {
         PT_A
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        PT_B
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            pA += BK; pB += BK;
-            nt_stage(pA, offA, bufA(cur ^ 1), w);
-            nt_stage(pB, offB, bufB(cur ^ 1), w);
+        int cur;
+        if (NST == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur = kt & 1;
+            if (kt + 1 < nk) {
+                pA += BK; pB += BK;
+                nt_stage(pA, offA, bufA(cur ^ 1), w);
+                nt_stage(pB, offB, bufB(cur ^ 1), w);
+            }
+        } else {
+            // K tile kt has landed; the (at most two) younger ones -- 8 pieces per wave each -- stay in flight
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                 // ... for every wave; and every wave is done reading the stage of K tile kt - 1
+            cur = kt & 3;
+            if (kt + 3 < nk) NT_DMA_TILE(kt + 3, (kt + 3) & 3);
         }
+        PT_B
         const char* tA = bufA(cur);
         const char* tB = bufB(cur);
         // all 16 fragment reads of the K-step are issued back to back, the 16 MFMAs then retire behind counted
@@ -538,6 +566,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs a) {
     }
 }
 
+// the 128 x 128 kernel: two LDS stages when the grid gives the CUs more than one tile each (two co-resident workgroups hide each other's waits), the
+// ring of four when it does not (round 6, small M: one workgroup per CU has to cover its own HBM latency)
+template <int EPIX, typename OutT>
+static int launch_nt_small(const GemmNTArgs& a, hipStream_t s) {
+    const int tiles = a.tiles_m * a.tiles_n;
+    if (tiles <= amdseg_num_cus()) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<EPIX, OutT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_nt_kernel<EPIX, OutT, 4>), dim3(tiles), dim3(256), 4 * 32768, s, a);
+    } else
+        hipLaunchKernelGGL((gemm_nt_kernel<EPIX, OutT, 2>), dim3(tiles), dim3(256), 2 * 32768, s, a);
+    return amdseg_launch_status();
+}
+
 template <int EPIX, typename OutT>
 static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
     constexpr int EPI = EPI_BASE(EPIX); constexpr int ACT = EPI_ACT(EPIX); (void)ACT;
@@ -563,8 +609,7 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
         const float c_dp = (float)((t_dp + 255) / 256), c_sm = 0.715f * (float)((t_sm + 511) / 512);
         if (!(small_ok && c_sm < c_dp))
             return amdseg_launch_nt_dp<EPIX, OutT>(a_in, s);
-        hipLaunchKernelGGL((gemm_nt_kernel<EPIX, OutT>), dim3(a_in.tiles_m * a_in.tiles_n), dim3(256), 0, s, a_in);
-        return amdseg_launch_status();
+        return launch_nt_small<EPIX, OutT>(a_in, s);
     }
     // the ping-pong kernel counts its in-flight stores (two outputs for BIAS_GELU): the single-output form runs on the 128x128 kernel
     const bool single_gelu = EPI == EPI_BIAS_GELU && !a_in.C2;
@@ -585,8 +630,7 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
         hipLaunchKernelGGL((gemm_nt_pp_kernel<EPIX, OutT>), dim3(T < 256 ? ((T + 7) / 8) * 8 : 256), dim3(512), PP_LDS, s, a);
         return amdseg_launch_status();
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<EPIX, OutT>), dim3(a_in.tiles_m * a_in.tiles_n), dim3(256), 0, s, a_in);
-    return amdseg_launch_status();
+    return launch_nt_small<EPIX, OutT>(a_in, s);
 }
 
 int amdseg_gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,

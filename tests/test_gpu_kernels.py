@@ -85,6 +85,32 @@ def test_gemm_nt_deep_pipeline_kernel_epilogues(dev, M, N, K):
     _check_all_epilogues(dev, M, N, K)
 
 
+@pytest.mark.parametrize("M,N,K", [(2304, 1920, 192), (4096, 768, 3072), (128, 128, 64), (384, 640, 128)])
+def test_gemm_nt_small_kernel_both_ring_depths(dev, M, N, K):
+    """the 128 x 128 kernel (forced through the small-tile hook of an explicit context where the shape would take a wider tile): 270 tiles = more than
+    one per CU -> two LDS stages, two workgroups per CU; 192 / 1 / 15 tiles -> the ring of four stages (round 6: the small-M form), with 3 (K = 192),
+    48, 1 and 2 K tiles (ring not filled, wrap-around, tail waits).  All epilogues + the bit-identity with the unforced kernels of the same shapes."""
+    ops = _ops()
+    ctx = ops.L.Ctx()
+    ctx.force_small_tile(1)
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16(); B = (torch.randn(N, K, generator=g) * 0.1).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev); R = torch.randn(M, N, generator=g).to(dev).bfloat16()
+    base = A.float() @ B.float().t()
+    with ctx.bound():
+        f0 = ops.gemm_nt(A, B, ops.EPI_NONE, out_dtype=torch.float32)
+        f1 = ops.gemm_nt(A, B, ops.EPI_BIAS, bias=bias)
+        f3 = ops.gemm_nt(A, B, ops.EPI_ADD_RES, R=R)
+        h, u = ops.gemm_nt(A, B, ops.EPI_BIAS_GELU, bias=bias)
+        gb = ops.gemm_nt(A, B, ops.EPI_GELU_BWD, R=R)
+    assert rel_err(f0, base) < 2e-6 and rel_err(f1, base + bias) < 4e-3 and rel_err(f3, base + R.float()) < 4e-3
+    assert rel_err(u, base + bias) < 4e-3 and rel_err(h, gelu(base + bias)) < 4e-3 and rel_err(gb, base * gelu_grad(R.float())) < 4e-3
+    # whatever kernel the unforced call takes for this shape: the same fp32 sums, hence the same bits
+    assert torch.equal(f0, ops.gemm_nt(A, B, ops.EPI_NONE, out_dtype=torch.float32))
+    assert torch.equal(f1, ops.gemm_nt(A, B, ops.EPI_BIAS, bias=bias)) and torch.equal(f3, ops.gemm_nt(A, B, ops.EPI_ADD_RES, R=R))
+    ctx.close()
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 192, 64), (512, 384, 320), (768, 960, 128)])
 def test_gemm_nt_pingpong_kernel_epilogues(dev, M, N, K):
     """shapes with M % 256 == 0 and N % 192 == 0 (K < 768) take the 256x192 ping-pong kernel; all epilogues + fp32 output."""
