@@ -98,58 +98,66 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_nt_kernel(GemmNTAr
 #define NT_DMA_TILE(kt_, st_) do { const bf16_t* ga_ = a.A + (size_t)m0 * a.lda + (size_t)(kt_) * BK; const bf16_t* gb_ = a.B + (size_t)n0 * a.ldb + (size_t)(kt_) * BK; \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) amdseg_glds16_saddr_lds(ga_, (uint32_t)offA.off[q] * 2u, lds0 + (st_) * 32768 + q * 1024); \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) amdseg_glds16_saddr_lds(gb_, (uint32_t)offB.off[q] * 2u, lds0 + (st_) * 32768 + 16384 + q * 1024); } while (0)
-    if (NST == 2) {
-        nt_stage(pA, offA, bufA(0), w);
-        nt_stage(pB, offB, bufB(0), w);
-    } else {
+#define NT_READ(FA, FB, st_) do { const char* tA_ = smem + (st_) * 32768; const char* tB_ = tA_ + 16384; \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { const int c_ = kk * 2 + (l >> 5); \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) FA[kk][i] = nt_frag(tA_, wr * 64 + i * 32 + (l & 31), c_); \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) FB[kk][j] = nt_frag(tB_, wc * 64 + j * 32 + (l & 31), c_); } } while (0)
+    // operands swapped (B fragment first): D[row = n][col = m], so a lane owns ONE output row m = lane&31 and
+    // 4 consecutive n per register quad -> the epilogue stores straight from registers, no LDS round trip
+#define NT_MFMA(FA, FB) do { _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[kk][j], FA[kk][i], acc[i][j], 0, 0, 0); } while (0)
+    if constexpr (NST == 4) {
+        // ---- small-M form: ring of four stages, and the fragments of K tile kt + 1 are READ UNDER the MFMAs of K tile kt (two register sets, the
+        // loop unrolled by two): one workgroup per CU = one wave per SIMD has nobody else to cover its LDS latency or its barrier.
+        // Iteration kt: [tile kt + 1 landed: counted vmcnt | every fragment read of tile kt retired: lgkmcnt(0) | barrier] -> the stage of tile kt is
+        // free (its fragments are in registers in every wave): DMA of tile kt + 4 into it -> 16 reads of tile kt + 1 interleaved with the 16 MFMAs of tile kt.
+        bf16x8 fa0[4][2], fb0[4][2], fa1[4][2], fb1[4][2];
         NT_DMA_TILE(0, 0);
         if (nk > 1) NT_DMA_TILE(1, 1);
         if (nk > 2) NT_DMA_TILE(2, 2);
-    }
+        if (nk > 3) NT_DMA_TILE(3, 3);
+        if (nk > 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (nk > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        NT_READ(fa0, fb0, 0);
+#define NT_ITER(kt_, CA, CB, NA, NB) do { \
+            if ((kt_) + 1 < nk) {                                /* tile kt + 1 has landed; tiles kt + 2, kt + 3 (8 pieces per wave each) stay in flight */ \
+                if ((kt_) + 3 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); \
+                else if ((kt_) + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+            } \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+            __syncthreads(); \
+            if ((kt_) + 4 < nk) NT_DMA_TILE((kt_) + 4, (kt_) & 3); \
+            if ((kt_) + 1 < nk) NT_READ(NA, NB, ((kt_) + 1) & 3); \
+            NT_MFMA(CA, CB); \
+            _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
+            __builtin_amdgcn_sched_barrier(0); \
+        } while (0)
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) { NT_ITER(kt, fa0, fb0, fa1, fb1); NT_ITER(kt + 1, fa1, fb1, fa0, fb0); }
+        if (kt < nk) NT_ITER(kt, fa0, fb0, fa1, fb1);
+    } else {
+    nt_stage(pA, offA, bufA(0), w);
+    nt_stage(pB, offB, bufB(0), w);
     for (int kt = 0; kt < nk; ++kt) {
         PT_A
-        int cur;
-        if (NST == 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            cur = kt & 1;
-            if (kt + 1 < nk) {
-                pA += BK; pB += BK;
-                nt_stage(pA, offA, bufA(cur ^ 1), w);
-                nt_stage(pB, offB, bufB(cur ^ 1), w);
-            }
-        } else {
-            // K tile kt has landed; the (at most two) younger ones -- 8 pieces per wave each -- stay in flight
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                 // ... for every wave; and every wave is done reading the stage of K tile kt - 1
-            cur = kt & 3;
-            if (kt + 3 < nk) NT_DMA_TILE(kt + 3, (kt + 3) & 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            pA += BK; pB += BK;
+            nt_stage(pA, offA, bufA(cur ^ 1), w);
+            nt_stage(pB, offB, bufB(cur ^ 1), w);
         }
         PT_B
-        const char* tA = bufA(cur);
-        const char* tB = bufB(cur);
         // all 16 fragment reads of the K-step are issued back to back, the 16 MFMAs then retire behind counted
         // lgkmcnt waits: one exposed LDS latency per K-step instead of four (phase timers: 1510 -> see profiles/)
         bf16x8 fa[4][2], fb[4][2];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int c = kk * 2 + (l >> 5);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[kk][i] = nt_frag(tA, wr * 64 + i * 32 + (l & 31), c);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[kk][j] = nt_frag(tB, wc * 64 + j * 32 + (l & 31), c);
-        }
-        // operands swapped (B fragment first): D[row = n][col = m], so a lane owns ONE output row m = lane&31 and
-        // 4 consecutive n per register quad -> the epilogue stores straight from registers, no LDS round trip
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+        NT_READ(fa, fb, cur);
+        NT_MFMA(fa, fb);
         // schedule: 8 reads up front, then one read behind each of the first 8 MFMAs, then the last 8 MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
@@ -159,6 +167,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_nt_kernel(GemmNTAr
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         PT_C
+    }
     }
     // ---- epilogue.  The accumulator layout gives a lane one row and 4 consecutive columns (8 B of bf16): stored directly,
     // one instruction touches 32 rows x 16 B -- 32 partial cache lines -- and the CU's address path (shared with the
