@@ -563,5 +563,10 @@ def test_parity_values_are_measured_and_written(dev):
     assert par["meets_1e-3"] and par["max_dlogit"] < 1e-3 and par["all_boundaries_equal"]
     t = par["bert_base_L512"]["train_step"]
     assert t["loss_rel_delta"] < 1e-3 and t["gradnorm_max_rel_err"] < 1e-3 and t["stored_grad_max_rel_err_excl_qk_bias"] < 1e-3
-    assert fast["max_dlogit"] < 0.05 * fast["bert_base_L512"]["eval"]["max_abs_logit"]
-    assert fast["bert_base_L512"]["train_step"]["gradnorm_max_rel_err"] < 0.08
+    # the fast path inside measured + 25 % (round 6: 0.2255 / 0.0614 eval max / mean on a scale of 7.9, config 1 0.1937, gradient norms 0.068, stored
+    # gradients 0.0105 without the q / k biases, loss 1.1e-3): drift shows as a failure, not only in the committed json
+    fb = fast["bert_base_L512"]
+    assert fb["eval"]["max_dlogit"] < 0.282 and fb["eval"]["mean_dlogit"] < 0.077 and fast["config1_bert_base"]["max_dlogit"] < 0.243
+    assert fast["all_boundaries_equal"]
+    assert fb["train_step"]["gradnorm_max_rel_err"] < 0.085 and fb["train_step"]["stored_grad_max_rel_err_excl_qk_bias"] < 0.0132
+    assert fb["train_step"]["loss_rel_delta"] < 1.5e-3

@@ -51,7 +51,9 @@ def test_eval_vs_reference_golden(dev, case, variant):
     lab = batch["labels"] != -100
     print(f"{case}/{variant}: max|dlogit| all={d.max():.4f} labelled={d[lab].max():.4f} mean={d.mean():.5f} "
           f"logit std={ref_logits.std():.3f}")
-    assert d.max().item() < 0.08                        # bf16 fast path (logit std ~3): ~1e-2 typical
+    # bf16 fast path, logit std ~3: measured in round 6 0.041-0.046 (max) / 0.0095-0.011 (mean) over the six cases; bound = measured + 25 % (VERDICT r05 #13:
+    # the 0.08 of rounds 1-5 could hide a doubling)
+    assert d.max().item() < 0.058 and d.mean().item() < 0.014
     assert abs(loss.item() - float(z[f"{variant}.loss"])) < 0.05
     assert (cos.cpu() - torch.from_numpy(z[f"{variant}.cos"])).abs().max().item() < 0.02
     # predicted boundary indices bit-exact
@@ -81,7 +83,7 @@ def test_train_grads_vs_reference_golden(dev, variant):
             continue
         rel = abs(mine - gv) / max(gv, 1e-3)
         worst = max(worst, rel)
-        assert rel < 0.05, (n, mine, gv)
+        assert rel < 0.035, (n, mine, gv)               # measured worst over the five variants: 0.0177-0.0273 (+ 25 %; was 0.05)
     print(variant, "worst grad-norm rel err", worst)
     if variant == "train_full":
         for k in z.files:
