@@ -12,8 +12,9 @@ __version__ = "0.1.0"
 try:
     from . import auto  # noqa: E402,F401
     from .auto import amdseg_config  # noqa: E402,F401
-except ImportError as _e:                                    # pragma: no cover -- transformers absent or too old for the model classes
-    _auto_import_error = _e
+except Exception as _e:                                      # noqa: BLE001 -- ImportError (transformers absent / too old) AND what transformers' lazy modules
+    _auto_import_error = _e                                  # raise for a broken sub-module (RuntimeError "Failed to import ..."): the ctypes-only
+                                                             # surface (`spokennlp_amd.lib`, `.build`) must import regardless
 
     def amdseg_config(*_a, **_k):
-        raise ImportError(f"spokennlp_amd.auto could not be imported: {_auto_import_error}")
+        raise ImportError(f"spokennlp_amd.auto could not be imported: {type(_auto_import_error).__name__}: {_auto_import_error}")
