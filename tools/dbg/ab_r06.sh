@@ -1,2 +1,9 @@
-python -m pytest tests/test_gpu_kernels.py tests/test_gpu_keepmask.py tests/test_gpu_longformer.py tests/test_gpu_bigbird.py -q -x 2>&1 | tail -3
-tools/dbg/ab_step_r06.sh r06_dq /root/repo/_ab/libamdseg_base13.so 2>&1 | grep -E "^base|^new|attn_bwd_dq|attn_bwd_dkv|attn_fwd|== "
+F="--no-cpu-baseline --no-via-trainer --no-extra-legs --steps 60 --warmup 10"
+for i in 1 2 3; do
+  for x in "" "--prof-in-timed"; do
+    python bench.py $F $x 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('[$x]', d['value'], d['ms_per_step'], r['avg_launch_us'], r['frac'], r['method'][:90])"
+  done
+done
