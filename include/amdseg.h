@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AMDSEG_ABI_VERSION 13   /* 13: the explicit context `amdseg_ctx` -- amdseg_ctx_create / _bind / _set_cu_budget / _prof_*, amdseg_bert_cfg.ctx -- replaces the per-thread CU budget, the small-tile hook and the process-wide launch timer of ABI 10-12; the one-kernel attention backward of ABI 12 (+ ws.dq_part) and the fused bias + dropout + residual GEMM of ABI 8 -- measured losers -- are gone; 11: amdseg_allreduce_* (the gradient exchange over RCCL behind an explicit amdseg_comm context, csrc/comm.hip); 10: AMDSEG_EPI_KEEP_DERIV (amdseg_bert_layer_acts.u holds gelu' of the FFN pre-activation in bf16 training when the shape allows); 9: amdseg_heads_bwd_rows takes n_feat / fix / fix_bytes (order-independent scatter sums), amdseg_scatter_rows_sorted; 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images); 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
+#define AMDSEG_ABI_VERSION 14   /* 14: amdseg_add_ln_fwd_keepmask (the LayerNorm rows and the NEXT layer's attention-dropout keep masks as one launch), amdseg_bert_layer_acts.keep_next / .keep_ready; 13: the explicit context `amdseg_ctx` -- amdseg_ctx_create / _bind / _set_cu_budget / _prof_*, amdseg_bert_cfg.ctx -- replaces the per-thread CU budget, the small-tile hook and the process-wide launch timer of ABI 10-12; the one-kernel attention backward of ABI 12 (+ ws.dq_part) and the fused bias + dropout + residual GEMM of ABI 8 -- measured losers -- are gone; 11: amdseg_allreduce_* (the gradient exchange over RCCL behind an explicit amdseg_comm context, csrc/comm.hip); 10: AMDSEG_EPI_KEEP_DERIV (amdseg_bert_layer_acts.u holds gelu' of the FFN pre-activation in bf16 training when the shape allows); 9: amdseg_heads_bwd_rows takes n_feat / fix / fix_bytes (order-independent scatter sums), amdseg_scatter_rows_sorted; 8: amdseg_bert_layer_acts.drop1 / .drop2 (the hidden-dropout decisions of a layer kept by forward for backward), amdseg_add_ln_fwd with resid == NULL, AMDSEG_PROF_ADD_LN_FWD .. _KEEPMASK; 7: forward phase 1 of a bf16 band layer with global tokens leaves their ctx rows unwritten (amdseg_bert_cfg.phase), amdseg_lf_global_bwd_dx / _w, amdseg_lf_dx_prep / _apply; 6: amdseg_attn_keepmask / _fwd_keep / _bwd_keep, amdseg_bert_layer_acts.keep / .qkv_s, amdseg_bert_layer_ws.dctx_s, amdseg_sattn_*, amdseg_weights_changed, amdseg_cast_transpose_batched_if, AMDSEG_EPI_BIAS_SPLIT; 5: amdseg_bert_cfg.pad_guard / pad_runs / pad_counts, amdseg_pad_rows_guard; 4: amdseg_bert_cfg.kend (trailing-padding chunks of full attention are not visited); 3: amdseg_adamw chunk_flags, AMDSEG_F32S parity mode (acts / ws split images); 2: amdseg_bert_cfg.act, ws.partials regions, list attention, grouped TN with bias gradients */
 #define AMDSEG_BF16 0
 #define AMDSEG_F32 1
 #define AMDSEG_F32S 2   /* composite layer only: fp32 activations, split-bf16 contractions ("parity" precision, forward + backward) */
@@ -237,6 +237,15 @@ int amdseg_scatter_rows_sorted(const void* dz, const int64_t* keys, const int64_
 int amdseg_add_ln_fwd(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out, float* mean,
                       float* rstd, int M, int H, float eps, float dropout_p, uint64_t seed, int dtype,
                       amdseg_stream_t stream);
+/* ABI 14: amdseg_add_ln_fwd AND amdseg_attn_keepmask (window == 0) / amdseg_attn_keepmask_band (window > 0) of `keep` as ONE launch: the row
+ * kernel is HBM-bound, the mask generator VALU-bound, and as interleaved workgroups of one grid the generator runs under the rows' memory latency
+ * (bert-base 32 x 512: 20.7 + 18.5 us as two launches).  Every output is bit-identical to the two calls.  amdseg_bert_layer_fwd uses it for the
+ * second LayerNorm of layer li and the masks of layer li + 1 (amdseg_bert_layer_acts.keep_next). */
+int amdseg_add_ln_fwd_keepmask(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out, float* mean,
+                               float* rstd, int M, int H, float eps, float dropout_p, uint64_t seed, int dtype,
+                               void* drop_bits, int keep_z,
+                               void* keep, int B, int L, int heads, float attn_dropout_p, uint64_t attn_seed, const int32_t* kend,
+                               int window, int nglobal, amdseg_stream_t stream);
 /* LayerNorm backward: dz (residual-stream grad), dbranch = dropout-masked dz (NULL when p == 0), and the column
  * reductions dgamma, dbeta, dbias (= colsum(dbranch)); partials = workspace of 3*ceil(M/16)*H floats */
 int amdseg_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz,
@@ -516,6 +525,14 @@ typedef struct amdseg_bert_layer_acts {     /* caller-owned activations; all but
      * 8 consecutive elements (bit e = element e kept; the same stateless hash as before decides them), and the LayerNorm backward reads
      * them instead of re-evaluating the hash per element.  NULL: the hash is evaluated in both directions (same decisions). */
     void *drop1, *drop2;
+    /* optional, ABI 14 (bf16 path, p_attn > 0): keep_next = the `keep` buffer of layer li + 1.  Phase 2 of this layer's forward then writes that
+     * layer's keep masks (seed of layer li + 1, this cfg's B / L / heads / kend / window / nglobal) in the launch of its second LayerNorm
+     * (amdseg_add_ln_fwd_keepmask); the acts of layer li + 1 must carry keep_ready != 0, which tells ITS forward that `keep` already holds this
+     * step's masks and must not be generated again.  Same bits as without the pair.  NULL / 0: every layer generates its own masks.
+     * The library pairs only where the shape makes it pay (generator workgroups at most half the row workgroups: csrc/keepmask.h
+     * km_pairs_with_rows); both layers evaluate that rule on the same cfg, so a pair set up here never goes out of step. */
+    void* keep_next;
+    int keep_ready;
 } amdseg_bert_layer_acts;
 
 typedef struct amdseg_bert_layer_ws {       /* backward scratch, reusable across layers */

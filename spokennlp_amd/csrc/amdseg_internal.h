@@ -36,6 +36,9 @@ int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamm
                            hipStream_t s, void* out_image = nullptr,         // out_image: `out` also as the split image [M, 3H] ("parity" precision)
                            void* keepbits = nullptr,                         // keepbits: [M * H / 8] bytes, the dropout decisions kept for ln_bwd
                            bool keep_z = true);                              // false (inference): z = resid + dropout(y) is not written back (only backward reads it)
+int amdseg_add_ln_fwd_km_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out, float* mean, float* rstd, int M, int H,
+                              float eps, float p, uint64_t seed, int dtype, hipStream_t s, void* keepbits, bool keep_z,
+                              void* keep, int B, int L, int heads, float p_attn, uint64_t seed_attn, const int* kend, int window, int nglobal);
 int amdseg_ln_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                        void* dz, void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M,
                        int H, float p, uint64_t seed, int accumulate, int dtype, hipStream_t s,

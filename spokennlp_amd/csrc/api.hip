@@ -3,6 +3,7 @@
 #include "amdseg_internal.h"
 #include <algorithm>
 #include "common.h"
+#include "keepmask.h"      // km_pairs_with_rows: where layer li + 1's keep masks ride in layer li's LayerNorm launch
 
 #define S(x) ((hipStream_t)(x))
 
@@ -154,6 +155,14 @@ int amdseg_add_ln_fwd(void* y_inout_z, const void* resid, const float* gamma, co
                       float* rstd, int M, int H, float eps, float dropout_p, uint64_t seed, int dtype,
                       amdseg_stream_t stream) {
     return amdseg_add_ln_fwd_impl(y_inout_z, resid, gamma, beta, out, mean, rstd, M, H, eps, dropout_p, seed, dtype, S(stream));
+}
+int amdseg_add_ln_fwd_keepmask(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out, float* mean,
+                               float* rstd, int M, int H, float eps, float dropout_p, uint64_t seed, int dtype,
+                               void* drop_bits, int keep_z,
+                               void* keep, int B, int L, int heads, float attn_dropout_p, uint64_t attn_seed, const int32_t* kend,
+                               int window, int nglobal, amdseg_stream_t stream) {
+    return amdseg_add_ln_fwd_km_impl(y_inout_z, resid, gamma, beta, out, mean, rstd, M, H, eps, dropout_p, seed, dtype, S(stream), drop_bits, keep_z != 0,
+                                     keep, B, L, heads, attn_dropout_p, attn_seed, kend, window, nglobal);
 }
 int amdseg_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz,
                   void* dbranch, float* partials, float* dgamma, float* dbeta, float* dbias, int M, int H,
@@ -490,8 +499,9 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
         if (c->mixer == 0) {
             // dropout on the probabilities: decided once per layer here, read by the forward and the two backward kernels (acts.keep)
             const void* keep = (a->keep && c->p_attn > 0.f) ? a->keep : nullptr;      // full attention, or the band's cells (window > 0)
-            if (keep) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s, c->window,
-                                                       c->nglobal));
+            // (keep_ready: the layer in front wrote them in the launch of its second LayerNorm -- acts.keep_next, below)
+            if (keep && !(a->keep_ready && km_pairs_with_rows(c->B, c->L, c->heads, M))) RET_IF(amdseg_attn_keepmask_impl(a->keep, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li, 0), c->kend, s,
+                                                                         c->window, c->nglobal));
             RET_IF(amdseg_attn_fwd_impl(a->qkv, mask_bias, a->ctx, a->lse, c->B, c->L, c->heads, 0.125f, c->p_attn, site_seed(c->seed, li, 0),
                                         c->window, c->nglobal, s, c->kend, c->seq_order, keep,
                                         // a phase-1 call of a layer with global tokens: the caller writes their ctx rows (amdseg.h, `phase`)
@@ -508,6 +518,12 @@ int amdseg_bert_layer_fwd(const amdseg_bert_cfg* c, const amdseg_bert_layer_para
     RET_IF(amdseg_gemm_nt_impl(a->x1, H, p->w1, H, a->h, I, M, I, H, AMDSEG_EPI_BIAS_GELU | (c->act ? AMDSEG_EPI_ACT_TANH : 0) | ffn_keep_deriv(c),
                                p->b1, nullptr, 0, a->u, I, 0, s));
     RET_IF(amdseg_gemm_nt_impl(a->h, I, p->w2, I, a->z2, H, M, H, I, AMDSEG_EPI_BIAS, p->b2, nullptr, 0, nullptr, 0, 0, s));
+    // the keep masks of layer li + 1 as workgroups of this launch (VALU-bound generator under an HBM-bound row kernel: acts.keep_next, amdseg.h)
+    if (a->keep_next && c->p_attn > 0.f && c->mixer == 0 && km_pairs_with_rows(c->B, c->L, c->heads, M))
+        RET_IF(amdseg_add_ln_fwd_km_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, c->p_hidden,
+                                         site_seed(c->seed, li, 2), c->dtype, s, a->drop2, a->u != nullptr,
+                                         a->keep_next, c->B, c->L, c->heads, c->p_attn, site_seed(c->seed, li + 1, 0), c->kend, c->window, c->nglobal));
+    else
     RET_IF(amdseg_add_ln_fwd_impl(a->z2, a->x1, p->ln2_g, p->ln2_b, a->x_out, a->mean2, a->rstd2, M, H, c->ln_eps, c->p_hidden,
                                   site_seed(c->seed, li, 2), c->dtype, s, nullptr, a->drop2, a->u != nullptr));
     return AMDSEG_OK;

@@ -132,6 +132,8 @@ __device__ __forceinline__ int attn_visible_chunks(const AttnArgs& a, int b, int
     return ke > 0 ? min(nch, (ke + CH - 1) / CH) : nch;
 }
 
+#include "keepmask.h"      // the generator of the dropout keep masks (its own header: elementwise.hip runs it inside a LayerNorm launch)
+
 // ---- consumer side of the dropout keep masks (written by attn_keepmask_kernel, attention.hip: layouts documented there)
 typedef const __attribute__((address_space(4))) uint64_t* km_cptr;
 struct KeepWords { uint64_t m[16]; };

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "amdseg_internal.h"
 #include "prof.h"
+#include "keepmask.h"
 
 #define MAXCH 4                 // up to 4 chunks of 8 elements per lane -> H <= 2048
 #define ROWS_PER_BLOCK 4        // one wave per row, 4 waves per block
@@ -210,11 +211,11 @@ __global__ __launch_bounds__(256) void scatter_rows_sorted_kernel(const T* __res
 // ------------------------------------------------------------------------------------------------ dropout + residual + LN
 // y (dense output incl. bias) is overwritten by z = resid + dropout(y) (kept for backward); out = LN(z)
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid, const float* gamma, const float* beta, T* out,
-                                                         float* mean, float* rstd, int M, int H, float eps, uint32_t thresh,
-                                                         float inv_keep, uint64_t seed, bf16_t* img, uint8_t* keepbits, bool keep_z) {
+__device__ __forceinline__ void add_ln_fwd_body(int block, T* y_z, const T* resid, const float* gamma, const float* beta, T* out,
+                                                float* mean, float* rstd, int M, int H, float eps, uint32_t thresh,
+                                                float inv_keep, uint64_t seed, bf16_t* img, uint8_t* keepbits, bool keep_z) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int m = blockIdx.x * ROWS_PER_BLOCK + w;
+    const int m = block * ROWS_PER_BLOCK + w;
     if (m >= M) return;
     const int nch = H >> 3;
     float v[NCH][8], x[NCH][8];
@@ -265,6 +266,34 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid,
     }
     row_store<T, NCH>(out + (size_t)m * H, nch, l, v);
     if (img) row_store_image<NCH>(img + (size_t)m * 3 * H, H, nch, l, v);
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* y_z, const T* resid, const float* gamma, const float* beta, T* out,
+                                                         float* mean, float* rstd, int M, int H, float eps, uint32_t thresh,
+                                                         float inv_keep, uint64_t seed, bf16_t* img, uint8_t* keepbits, bool keep_z) {
+    add_ln_fwd_body<T, NCH>((int)blockIdx.x, y_z, resid, gamma, beta, out, mean, rstd, M, H, eps, thresh, inv_keep, seed, img, keepbits, keep_z);
+}
+
+// The same rows AND the attention-dropout keep masks of the NEXT layer in one grid (round 6).  The row kernel is HBM-bound (4 passes over [M, H],
+// 20.7 us at 16,384 x 768), the generator VALU-bound (18.5 us for 32 x 12 x 512 x 512 decisions): launched back to back they take the sum, as
+// workgroups of ONE launch the generator's waves issue under the rows' memory latency.  The n_km generator blocks are spread evenly through the n_ln
+// row blocks (block b is a generator block iff k(b + 1) > k(b), k(b) ~ b n_km / (n_ln + n_km), see the kernel), so every CU holds both kinds at any time;
+// each kind computes exactly what it computes alone (add_ln_fwd_body / km_block_body on its own block index): the bits do not depend on the fusion.
+struct AddLnArgs {
+    void* y_z; const void* resid; const float* gamma; const float* beta; void* out; float* mean; float* rstd;
+    int M, H; float eps; uint32_t thresh; float inv_keep; uint64_t seed; uint8_t* keepbits; int keep_z;
+};
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void add_ln_fwd_km_kernel(AddLnArgs a, KeepMaskArgs k, unsigned ratio) {
+    // generator blocks in front of block b: k(b) = (b * ratio) >> 32 with ratio = ceil(2^32 n_km / n) -- ONE scalar multiply-high (a 64-bit division
+    // here cost every row wave ~200 vector instructions).  k is monotone with steps of 0 or 1 (ratio < 2^32), k(0) = 0 and k(n) = n_km exactly (the
+    // ceiling's excess times n stays below 2^32), so the generator indices 0 .. n_km - 1 and the row-block indices 0 .. n_ln - 1 are each hit once
+    const unsigned b = blockIdx.x;
+    const unsigned k0 = __umulhi(b, ratio), k1 = __umulhi(b + 1, ratio);
+    if (k1 > k0) km_block_body(k, (int)k0);
+    else add_ln_fwd_body<T, NCH>((int)(b - k0), (T*)a.y_z, (const T*)a.resid, a.gamma, a.beta, (T*)a.out, a.mean, a.rstd, a.M, a.H, a.eps, a.thresh,
+                                 a.inv_keep, a.seed, nullptr, a.keepbits, a.keep_z != 0);
 }
 
 // LN backward.  dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  Also emits
@@ -1020,6 +1049,30 @@ int amdseg_add_ln_fwd_impl(void* y_inout_z, const void* resid, const float* gamm
     else
         ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, bytes_per_el * M * H * 4, add_ln_fwd_kernel, float, H, grid, dim3(256), 0, s, (float*)y_inout_z, (const float*)resid, gamma, beta,
                            (float*)out, mean, rstd, M, H, eps, th, ik, seed, (bf16_t*)out_image, (uint8_t*)keepbits, keep_z);
+    return amdseg_launch_status();
+}
+
+// amdseg_add_ln_fwd_impl + amdseg_attn_keepmask_impl(keep, ...) as ONE launch (add_ln_fwd_km_kernel); same arguments, same bits as the two calls
+int amdseg_add_ln_fwd_km_impl(void* y_inout_z, const void* resid, const float* gamma, const float* beta, void* out, float* mean, float* rstd, int M, int H,
+                              float eps, float p, uint64_t seed, int dtype, hipStream_t s, void* keepbits, bool keep_z,
+                              void* keep, int B, int L, int heads, float p_attn, uint64_t seed_attn, const int* kend, int window, int nglobal) {
+    if (!y_inout_z || !gamma || !beta || !out) return AMDSEG_ERR_ARG;
+    if (M <= 0 || H <= 0 || (H % 8) || H > 8 * 64 * MAXCH) return AMDSEG_ERR_SHAPE;
+    if (dtype != AMDSEG_BF16 && dtype != AMDSEG_F32) return AMDSEG_ERR_ARG;
+    KeepMaskArgs k;
+    const int rc = km_fill(k, keep, B, L, heads, p_attn, seed_attn, kend, window, nglobal);
+    if (rc) return rc;
+    AddLnArgs a = {};
+    drop_params(p, a.thresh, a.inv_keep);
+    a.y_z = y_inout_z; a.resid = resid; a.gamma = gamma; a.beta = beta; a.out = out; a.mean = mean; a.rstd = rstd; a.M = M; a.H = H; a.eps = eps;
+    a.seed = seed; a.keepbits = (uint8_t*)keepbits; a.keep_z = keep_z ? 1 : 0;
+    const unsigned n_ln = (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), n_km = (unsigned)km_blocks(B, L, heads);
+    const double bytes_per_el = resid ? (keep_z ? 4.0 : 3.0) : 2.0, esz = dtype == AMDSEG_BF16 ? 2.0 : 4.0;
+    const double work = bytes_per_el * M * H * esz + 2.0 * B * heads * (double)L * L / 8.0;       // the rows' passes + the mask bytes written
+    const unsigned n_all = n_ln + n_km;                     // (n_ln >= 1: the ratio is below 2^32)
+    const unsigned ratio = (unsigned)((((uint64_t)n_km << 32) + n_all - 1) / n_all);
+    if (dtype == AMDSEG_BF16) ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, work, add_ln_fwd_km_kernel, bf16_t, H, dim3(n_all), dim3(256), 0, s, a, k, ratio);
+    else ROWK_PROF(AMDSEG_PROF_ADD_LN_FWD, work, add_ln_fwd_km_kernel, float, H, dim3(n_all), dim3(256), 0, s, a, k, ratio);
     return amdseg_launch_status();
 }
 

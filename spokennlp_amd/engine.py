@@ -200,6 +200,7 @@ class BertEncoderEngine:
         # attention-probability dropout decided once per layer (amdseg_attn_keepmask, acts.keep) instead of hashed per element in three kernels;
         # full softmax attention only (the band / list / pooling engines switch it off); AMDSEG_ATTN_HASH=1 keeps the hash path
         self.attn_keepmask = _os.environ.get("AMDSEG_ATTN_HASH", "0") != "1"
+        self.keepmask_in_ln = True          # layer i + 1's masks from layer i's LayerNorm launch (set before the first forward; arenas are built once)
         # hidden-state dropout: the forward's add + LayerNorm kernels keep their decisions (1 byte per 8 elements, acts.drop1 / drop2) and the
         # LayerNorm backward reads them instead of re-hashing (every encoder family: the row kernels are shared); False = hash twice
         self.hidden_keepbits = True
@@ -637,6 +638,12 @@ class BertEncoderEngine:
             if not train and parity and M % 256 == 0 and self.I % 256 == 0 and getattr(self.cfg, "hidden_act", "gelu") == "gelu":
                 ptrs["u"] = None                  # "parity" inference: the fused up-projection epilogue writes only the image of gelu(u)
             A["acts_struct"].append(L.LayerActs(x_in=xin.data_ptr(), x_out=xout.data_ptr(), **ptrs))
+        # the keep masks of layer i + 1 written by the launch of layer i's second LayerNorm (amdseg.h: acts.keep_next / keep_ready): the VALU-bound
+        # generator under an HBM-bound row kernel; layer 0 generates its own.  Same bits either way (self.keepmask_in_ln = False: every layer its own)
+        if train and not fp32 and self.keepmask_in_ln and "keep" in A["layers"][0]:
+            for i in range(self.nlayers - 1):
+                A["acts_struct"][i].keep_next = A["layers"][i + 1]["keep"].data_ptr()
+                A["acts_struct"][i + 1].keep_ready = 1
         A["x_final"] = A["x"][self.nlayers] if train else A["x"][self.nlayers % 2]
         self._arenas[key] = A
         return A

@@ -14,7 +14,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
 EPI_ACT_TANH = 0x100      # OR-ed into EPI_BIAS_GELU / EPI_GELU_BWD: gelu_new
 EPI_DERIV_U8 = 0x400      # with EPI_KEEP_DERIV: the derivative as one byte per element, q = round((g' + 0.135) * 200)
 EPI_KEEP_DERIV = 0x200    # OR-ed into EPI_BIAS_GELU: out2 = gelu'(pre-activation); into EPI_GELU_BWD: R is that derivative (C = (A B^T) * R)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 vp, i32, f32, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
@@ -37,7 +37,8 @@ class LayerGrads(C.Structure):
 
 class LayerActs(C.Structure):
     _fields_ = [(n, vp) for n in ("x_in", "qkv", "ctx", "z1", "x1", "u", "h", "z2", "x_out",
-                                  "lse", "mean1", "rstd1", "mean2", "rstd2", "xs", "ctx_s", "x1_s", "h_s", "keep", "qkv_s", "drop1", "drop2")]
+                                  "lse", "mean1", "rstd1", "mean2", "rstd2", "xs", "ctx_s", "x1_s", "h_s", "keep", "qkv_s", "drop1", "drop2",
+                                  "keep_next")] + [("keep_ready", C.c_int)]      # ABI 14: the next layer's masks from this layer's LayerNorm launch
 
 
 class LayerWs(C.Structure):
@@ -85,6 +86,7 @@ _PROTOS = {
     "amdseg_scatter_rows_sorted": [vp, vp, vp, vp, i32, i32, i32, C.c_long, i32, vp],
     "amdseg_embed_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "amdseg_add_ln_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, i32, vp],
+    "amdseg_add_ln_fwd_keepmask": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, i32, vp, i32, vp, i32, i32, i32, f32, u64, vp, i32, i32, vp],
     "amdseg_ln_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u64, i32, i32, vp],
     "amdseg_colsum": [vp, i32, vp, vp, i32, i32, i32, i32, vp],
     "amdseg_pad_plan": [vp, i32, i32, vp, vp, vp, vp, vp, f32, vp],

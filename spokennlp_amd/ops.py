@@ -340,6 +340,22 @@ def add_ln_fwd(y, resid, gamma, beta, eps, p=0.0, seed=0):
     return out, mean, rstd
 
 
+def add_ln_fwd_keepmask(y, resid, gamma, beta, eps, p, seed, B, Lseq, heads, p_attn, seed_attn, kend=None, window=0, nglobal=0, drop_bits=None,
+                        keep_z=True):
+    """add_ln_fwd AND the keep masks of an attention layer as one launch (amdseg_add_ln_fwd_keepmask); returns (out, mean, rstd, keep)"""
+    M, H = y.shape
+    lib = L.load()
+    out = torch.empty_like(y)
+    mean = torch.empty((M,), dtype=torch.float32, device=y.device)
+    rstd = torch.empty((M,), dtype=torch.float32, device=y.device)
+    mk = torch.zeros if window > 0 else torch.empty
+    keep = mk(lib.amdseg_attn_keepmask_bytes(B, Lseq, heads), dtype=torch.uint8, device=y.device)
+    rc = lib.amdseg_add_ln_fwd_keepmask(_p(y), _p(resid), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), M, H, eps, p, seed, _dt(y),
+                                        _p(drop_bits), 1 if keep_z else 0, _p(keep), B, Lseq, heads, p_attn, seed_attn, _p(kend), window, nglobal, _s())
+    L.check(rc, "amdseg_add_ln_fwd_keepmask")
+    return out, mean, rstd, keep
+
+
 LNB_ROWS = 16      # rows per workgroup of ln_bwd / rowdot_bwd (csrc/elementwise.hip)
 
 

@@ -259,7 +259,7 @@ def test_product_sources_carry_no_probe_flags_and_few_switches():
     from spokennlp_amd import lib
     assert not os.path.exists(os.path.join(csrc, "attention_bwd_merged.hip"))
     assert "attention_bwd_merged.hip" not in open(os.path.join(ROOT, "spokennlp_amd", "build.py")).read()
-    assert lib.ABI_VERSION == 13 and "amdseg_ctx_create" in lib.EXPORTS and "amdseg_set_cu_budget" not in lib.EXPORTS
+    assert lib.ABI_VERSION == 14 and "amdseg_add_ln_fwd_keepmask" in lib.EXPORTS and "amdseg_ctx_create" in lib.EXPORTS and "amdseg_set_cu_budget" not in lib.EXPORTS
 
 
 def test_erf_epilogue_build_flag_still_compiles(tmp_path):

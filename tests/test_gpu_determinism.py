@@ -51,7 +51,7 @@ def test_scatter_rows_sorted_equals_index_add_and_repeats_bitwise(dev, dtype):
     assert torch.equal(outs[0][k0], serial + 0.5)
 
 
-def _three_steps(dev, precision, deterministic, case="tiny_L128", lazy_zero=None, skip_backward_at=None, bwd_cu_budget=0):
+def _three_steps(dev, precision, deterministic, case="tiny_L128", lazy_zero=None, skip_backward_at=None, bwd_cu_budget=0, keepmask_in_ln=None):
     if case == "bert_base_L512":                           # bert-base, 4 x 512 tokens (x 2 with the augmented half): the H = 768 kernels
         from tests.test_gpu_fullsize import _fullsize_case
         z, sd, batch, arch, fl = _fullsize_case()
@@ -66,6 +66,8 @@ def _three_steps(dev, precision, deterministic, case="tiny_L128", lazy_zero=None
     m.amdseg_seed = 11
     random.seed(3)
     b = to_dev(batch, dev)
+    if keepmask_in_ln is not None:                         # (before the first forward: the activation arenas carry the pairing)
+        m.engine().keepmask_in_ln = keepmask_in_ln
     losses = []
     for it in range(3):
         loss, _, _ = m(**b)
@@ -205,3 +207,41 @@ def test_backward_under_a_cu_budget_changes_no_bit(dev):
     b = _three_steps(dev, "bf16", True, "bert_base_L512")
     assert a[0] == b[0]
     assert torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("case", ["tiny_L128", "bert_base_L512"])
+def test_keepmasks_from_the_layer_norm_launch_change_no_bit(dev, case):
+    """ABI 14: layer i + 1's attention-dropout keep masks are written by workgroups of layer i's second LayerNorm launch (acts.keep_next /
+    keep_ready, amdseg_add_ln_fwd_keepmask) instead of a launch of their own: same generator, same seeds, same rows -- three training steps
+    end in the same bits"""
+    a = _three_steps(dev, "bf16", True, case, keepmask_in_ln=True)
+    b = _three_steps(dev, "bf16", True, case, keepmask_in_ln=False)
+    assert a[0] == b[0]
+    assert torch.equal(a[1], b[1])
+
+
+def test_keepmask_pairing_launch_counts(dev):
+    """what the pairing does to a bert-base step at 4 x 512 (x 2 with the augmented half): ONE keep-mask launch (layer 0's) instead of twelve, the same
+    number of LayerNorm launches; unpaired, twelve.  Counted by the launch timer of the engine's context (AMDSEG_PROF_KEEPMASK = 8, _ADD_LN_FWD = 5)."""
+    from tests.test_gpu_fullsize import _fullsize_case
+    z, sd, batch, arch, fl = _fullsize_case()
+    counts = {}
+    for flag in (True, False):
+        m = build_model(arch, fl(z, "train_full"), sd, dev, dropout=0.1)
+        m.train()
+        m.amdseg_seed = 3
+        eng = m.engine()
+        eng.keepmask_in_ln = flag
+        b = to_dev(batch, dev)
+        random.seed(1)
+        m(**b)[0].backward()                               # (arenas built, graphs or not: the second step is the one counted)
+        eng.ctx.prof_reset(); eng.ctx.prof_enable(True)
+        random.seed(1)
+        m(**b)[0].backward()
+        torch.cuda.synchronize()
+        eng.ctx.prof_enable(False)
+        counts[flag] = (eng.ctx.prof_read(8)[2], eng.ctx.prof_read(5)[2])
+    nl = 12
+    nfwd = counts[False][0] // nl                          # encoder passes per step
+    assert nfwd >= 1 and counts[False][0] == nfwd * nl and counts[True][0] == nfwd, counts
+    assert counts[True][1] == counts[False][1] == 2 * nl * nfwd, counts

@@ -171,3 +171,50 @@ def test_band_keepmask_forward_backward_vs_torch(dev, B, L, heads, w, G):
         assert rel_err(dqkv[:, j * H:(j + 1) * H], q32.grad[:, j * H:(j + 1) * H]) < 2e-2, name
 
 
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,L,heads,H,window,G,pad", [(4, 512, 12, 768, 0, 0, False), (2, 256, 2, 128, 0, 0, True), (1, 1024, 2, 1536, 256, 1, False),
+                                                      (3, 64, 1, 64, 0, 0, False)])
+def test_add_ln_fwd_keepmask_is_the_two_calls_bit_for_bit(dev, dtype, B, L, heads, H, window, G, pad):
+    """amdseg_add_ln_fwd_keepmask (ABI 14): the LayerNorm rows and the keep masks of an attention layer as interleaved workgroups of ONE launch;
+    every output -- z, out, mean, rstd, the kept hidden-dropout bits, both mask layouts -- equals what amdseg_add_ln_fwd and
+    amdseg_attn_keepmask / _band write alone"""
+    ops = _ops()
+    from spokennlp_amd import lib as Lb
+    M = B * L
+    g = torch.Generator(device="cpu").manual_seed(5)
+    y0 = torch.randn(M, H, generator=g).to(dev, dtype)
+    res = torch.randn(M, H, generator=g).to(dev, dtype)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(H, generator=g)).to(dev)
+    kend = torch.tensor([L - 70 * (b % 3) for b in range(B)], dtype=torch.int32, device=dev) if pad else None
+    # the two launches
+    y1 = y0.clone()
+    out1, mean1, rstd1 = ops.add_ln_fwd(y1, res, gamma, beta, 1e-12, 0.1, 77)
+    keep1 = ops.attn_keepmask_band(B, L, heads, 0.1, 991, window, G, dev) if window else ops.attn_keepmask(B, L, heads, 0.1, 991, dev, kend=kend)
+    # the one launch
+    y2 = y0.clone()
+    bits = torch.zeros(M * H // 8, dtype=torch.uint8, device=dev)
+    out2, mean2, rstd2, keep2 = ops.add_ln_fwd_keepmask(y2, res, gamma, beta, 1e-12, 0.1, 77, B, L, heads, 0.1, 991, kend=kend, window=window, nglobal=G,
+                                                        drop_bits=bits)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and torch.equal(out1, out2) and torch.equal(mean1, mean2) and torch.equal(rstd1, rstd2)
+    if pad:                                                # chunks past kend are written by neither form: compare what the consumers read
+        ka1, kb1 = unpack_keep(keep1, B, L, heads); ka2, kb2 = unpack_keep(keep2, B, L, heads)
+        for b in range(B):
+            nv, hs = (int(kend[b]) + 63) // 64 * 64, slice(b * heads, (b + 1) * heads)
+            assert torch.equal(ka1[hs, :, :nv], ka2[hs, :, :nv]) and torch.equal(kb1[hs, :, :nv], kb2[hs, :, :nv])
+    else:
+        assert torch.equal(keep1, keep2)
+    assert int(bits.count_nonzero()) > 0                   # the hidden-dropout decisions were kept as well ...
+    y3 = y0.clone()                                        # ... and are the hash's: the row kernel without them gives the same z
+    ops.add_ln_fwd(y3, res, gamma, beta, 1e-12, 0.1, 77)
+    assert torch.equal(y3, y2)
+    # errors: no mask buffer, a sequence length the generator does not tile
+    lib = Lb.load()
+    s = torch.cuda.current_stream().cuda_stream
+    args = lambda keep_ptr, L_: (y2.data_ptr(), res.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(),
+                                 M, H, 1e-12, 0.1, 77, Lb.BF16 if dtype == torch.bfloat16 else Lb.F32, None, 1, keep_ptr, B, L_, heads, 0.1, 991, None, 0, 0, s)
+    assert lib.amdseg_add_ln_fwd_keepmask(*args(None, L)) != 0
+    assert lib.amdseg_add_ln_fwd_keepmask(*args(keep2.data_ptr(), L + 8)) != 0
