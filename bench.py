@@ -298,13 +298,17 @@ def dp_record(eng, world, device, sync_marks, step, first_step, args):
     dist.all_reduce(ones)
     # the devices the ranks actually sit on (two ranks on one GPU over gloo are not two GPUs)
     props = torch.cuda.get_device_properties(device)
-    me = f"{socket.gethostname()}:{getattr(props, 'uuid', None) or torch.cuda.current_device()}"
+    # (identity = host + whatever the runtime offers: uuid, PCI location, device index.  Ranks isolated by HIP_VISIBLE_DEVICES all see index 0 and some
+    #  runtimes report an all-zero uuid, so the identity is a REPORT -- `distinct_gpus` -- and the refusal below rests on RCCL's own sum: RCCL does not
+    #  build a communicator with two ranks on one device)
+    ident = [str(getattr(props, n, "")) for n in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id")] + [str(torch.cuda.current_device())]
+    me = f"{socket.gethostname()}:" + ":".join(ident)
     everyone = [None] * world
     dist.all_gather_object(everyone, me)
     distinct = len(set(everyone))
-    if dist.get_backend() == "nccl" and (float(ones.item()) != float(world) or distinct != world):
-        # the line may say n_gpus = N only when RCCL itself summed N ones from N different devices
-        raise SystemExit(f"bench.py --gpus {world}: the nccl (RCCL) all-reduce of ones returned {ones.item()} over {distinct} distinct GPU(s); "
+    if dist.get_backend() == "nccl" and float(ones.item()) != float(world):
+        # the line may say n_gpus = N only when RCCL itself summed N ones
+        raise SystemExit(f"bench.py --gpus {world}: the nccl (RCCL) all-reduce of ones returned {ones.item()} (ranks on {distinct} distinct GPU identities); "
                          f"refusing to report n_gpus = {world}")
     b = eng.buckets
     sizes = [(hi - lo) * 4 for lo, hi in b.layer_slices] + [(b.rest_slice[1] - b.emb_slice[1]) * 4, (b.emb_slice[1] - b.emb_slice[0]) * 4]
