@@ -508,7 +508,12 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
     // 56.6 -> 52.5 (384 -> 512 tiles).  The residual-reading epilogues lose on the narrow tile's staged stores (GELU' 57.8 -> 59.2) and stay wide.
     // Round 5: the residual-adding input-gradient GEMMs (N = 768 at M = 16384: 192 tiles of 256 columns = three quarters of ONE round) take the narrow
     // tile when that makes the single round (nearly) full: 256 tiles on 256 CUs, 64.4 -> 62 us per launch, 12.91 -> 12.78 ms per step (three
-    // interleaved repetitions on one box, profiles/r05_default_switches.md); at M = 8192 (128 narrow tiles: half a round either way) they stay wide.
+    // interleaved repetitions on one box, profiles/r05_default_switches.md).
+    // Round 6 (tools/dbg/nt_addres_shapes.py, K = 3072 / 2304, us per launch wide -> narrow): the same epilogue over MORE than one round follows rounds x
+    // width like the plain epilogues -- M = 24576: 126.6 / 98.8 -> 111.2 / 85.7, M = 32768 (the 8 x 4096 models: 384 wide tiles = 1.5 rounds, 512 narrow = 2):
+    // 146.2 / 104.7 -> 136.3 / 97.4, M = 49152: 225.8 / 171.5 -> 202.5 / 158.2, M = 65536 (3 wide rounds = 4 narrow): unchanged, stays wide -- and a single
+    // partial round takes the narrow tile whenever the narrow tiles still fit into it (M = 12288: 62.3 / 49.4 -> 58.2 / 45.9; its residual tile now arrives
+    // by LDS-DMA under the last K tile, R16PF above).  longformer / PoNet / bigbird-base 8 x 4096: +0.8 / +1.2 / +1.0 % per step, same box, interleaved.
     constexpr int EB = EPI_BASE(EPIX);
     bool narrow = false;
     if (ok256 && ok192) {
@@ -516,7 +521,7 @@ int amdseg_launch_nt_dp(const GemmNTArgs& a_in, hipStream_t s) {
         if (EB == EPI_NONE || EB == EPI_BIAS || EB == EPI_BIAS_GELU || EB == EPI_BIAS_GELU_DG)
             narrow = 0.78f * (float)((t192 + C - 1) / C) < (float)((t256 + C - 1) / C);
         else if (EB == EPI_ADD_RES)
-            narrow = t256 < C && t192 <= C && t192 * 8 >= C * 7;
+            narrow = t256 < C ? (t192 <= C) : 0.78f * (float)((t192 + C - 1) / C) < (float)((t256 + C - 1) / C);
     }
     constexpr bool direct_only = EB == EPI_BIAS_SPLIT || EB == EPI_GELU_BWD_SPLIT || EB == EPI_BIAS_GELU_SPLIT ||
                                  EB == EPI_BIAS_GELU_DG8 || EB == EPI_MUL_RES8;    // epilogues of the 256-wide tile only
