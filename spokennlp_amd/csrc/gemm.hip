@@ -615,7 +615,12 @@ static int launch_nt(const GemmNTArgs& a_in, hipStream_t s) {
         // 8 sequences per step 1114 -> 1210 seq/s, longformer-base 4 x 2048 323 -> 330; at M = 16384 the deep-pipeline kernel wins everywhere.
         const int t_dp = (a_in.M / 256) * ((a_in.N % 256) == 0 ? a_in.N / 256 : a_in.N / 192);
         const int t_sm = (a_in.M / BM) * (a_in.N / BN);
-        const float c_dp = (float)((t_dp + 255) / 256), c_sm = 0.715f * (float)((t_sm + 511) / 512);
+        // Round 6: the 128 x 128 kernel wins clearly only as the RING form (about one tile per CU: M <= 6826 at N = 768 -- 31 vs 46 us at M = 4096,
+        // K = 3072) or on short K; with two tiles on some CUs and a long K the 256 x 192 deep-pipeline tile (its residual / derivative operands now
+        // prefetched under the last K tile) is ahead again: M = 10240, K = 3072 / 2304: 52.3 / 43.4 -> 47.3 / 39.1 us, M = 8192: 46.2 / 39.0 -> 45.0 / 37.7;
+        // bert-base 16 x 512 +2.6 %, longformer 4 x 2048 +1.5 % per step (tools/dbg/ab_smallm_r06.sh, profiles/r06_smallm_dispatch.md)
+        const bool ring = t_sm * 4 <= amdseg_num_cus() * 5;      // (a few CUs with two tiles still favour it: M = 6144, 288 tiles: 7.38 vs 7.46 ms per step)
+        const float c_dp = (float)((t_dp + 255) / 256), c_sm = ((ring || a_in.K < 1536) ? 0.715f : 1.05f) * (float)((t_sm + 511) / 512);
         if (!(small_ok && c_sm < c_dp))
             return amdseg_launch_nt_dp<EPIX, OutT>(a_in, s);
         return launch_nt_small<EPIX, OutT>(a_in, s);
